@@ -1,0 +1,128 @@
+"""Pin the oracle (oracle/hdf_oracle.py) against fixtures produced by the REAL reference
+(oracle/make_goldens.py, run in the build container).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import detgen
+from oracle import hdf_oracle as orc
+
+from conftest import GOLDEN
+
+
+def _load(name):
+    p = os.path.join(GOLDEN, name + ".npz")
+    if not os.path.exists(p):
+        pytest.skip(f"fixture {name} not generated")
+    return np.load(p, allow_pickle=False)
+
+
+def _sample(t, step):
+    sl = (slice(None), slice(None)) + (slice(None, None, step),) * (t.dim() - 2)
+    return t.detach()[sl].numpy()
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def _run_model_fixture(name, grads=True):
+    g = _load(name)
+    in_ch, n_cls, nf, td = [int(v) for v in g["cfg"][:4]]
+    size = tuple(int(v) for v in g["cfg"][4:])
+    batch = int(g["batch"])
+    seed = int(g["train_seed"])
+    sd = orc.det_model(in_ch, n_cls, nf, size, td)
+    x = torch.from_numpy(detgen.det_input(batch, in_ch, size, tag=name))
+    onehot = torch.from_numpy(detgen.one_hot(detgen.det_labels(batch, n_cls, size, tag=name), n_cls))
+    tr = orc.OracleTrainer(sd)
+    drop_seed = None if seed < 0 else seed
+    outs, inter = orc.forward(x, tr.sd, drop_seed, want_intermediates=True)
+    loss = orc.deep_super_loss(outs, onehot)
+    # forward: fp32 noise floor of the reference itself is ~3e-6
+    for i, o in enumerate(outs):
+        step = int(g["sample_step"]) if i == 0 else 1
+        assert _rel(_sample(o, step), g[f"out{i}"]) < 2e-5, f"out{i}"
+    for k, v in inter.items():
+        step = int(g["inter_step"]) if v.shape[-1] > 8 else 1
+        assert _rel(_sample(v, step), g["inter_" + k]) < 2e-5, k
+    assert abs(loss.item() - float(g["loss"])) < 2e-5 * max(1.0, abs(float(g["loss"])))
+    assert abs(orc.compute_dice(outs[0].detach(), onehot) - float(g["dice_rounded"])) < 1e-6
+    if grads and "grad_norms" in g.files:
+        loss.backward()
+        names = [str(n) for n in g["grad_names"]]
+        assert names == list(tr.sd.keys())          # named_parameters order == state_dict order
+        for j, k in enumerate(names):
+            gr = tr.sd[k].grad
+            ref_n = float(g["grad_norms"][j])
+            tol = 5e-4 * max(ref_n, 1e-6) + 2e-7     # dead UpConv biases have ~1e-8 grads
+            assert abs(gr.double().norm().item() - ref_n) < tol, (k, gr.norm().item(), ref_n)
+        for k in [f[len("gradfull_"):] for f in g.files if f.startswith("gradfull_")]:
+            assert _rel(tr.sd[k].grad.numpy(), g["gradfull_" + k]) < 2e-4, k
+
+
+def test_g1_tiny_eval():
+    _run_model_fixture("g1_tiny_eval")
+
+
+def test_g1_tiny_train_hash_dropout():
+    """Train mode: the oracle's dropout sites/ordering against the reference run with
+    torch.nn.functional.dropout replaced by the same hash masks."""
+    _run_model_fixture("g1_tiny_train")
+
+
+def test_g2_odd_token_grid():
+    _run_model_fixture("g2_odd_eval")
+
+
+def test_g5_full_size_eval():
+    _run_model_fixture("g5_full_eval", grads=False)
+
+
+@pytest.mark.parametrize("tag", ["c3", "c4", "c4_absent"])
+def test_g3_loss(tag):
+    g = _load("g3_loss")
+    outs = [torch.from_numpy(g[f"{tag}_logits{i}"]).requires_grad_(True) for i in range(4)]
+    onehot = torch.from_numpy(g[tag + "_onehot"].astype(np.float32))
+    loss = orc.deep_super_loss(outs, onehot)
+    loss.backward()
+    assert abs(loss.item() - float(g[tag + "_loss"])) < 1e-5
+    for i, o in enumerate(outs):
+        assert _rel(o.grad.numpy(), g[f"{tag}_grad{i}"]) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["c4", "c4_absent", "c3"])
+def test_g7_metric(tag):
+    g = _load("g7_metric")
+    logits = torch.from_numpy(g[tag + "_logits"])
+    onehot = torch.from_numpy(g[tag + "_onehot"].astype(np.float32))
+    assert abs(orc.compute_dice(logits, onehot) - float(g[tag + "_dice"])) < 1e-6
+
+
+def test_g6_2d_plumbing():
+    """BASELINE config #1: HDenseFormer_2D 4-ch 256x256 single forward on the CPU path."""
+    g = _load("g6_2d")
+    sd = orc.det_model(4, 2, 32, (256, 256), 24)
+    x = torch.from_numpy(detgen.det_input(1, 4, (1, 256, 256), tag="g6")[:, :, 0])
+    with torch.no_grad():
+        outs = orc.forward(x, sd)
+    for i, o in enumerate(outs):
+        assert tuple(o.shape) == tuple(int(v) for v in g[f"shape{i}"])
+        assert _rel(_sample(o, 4 if i == 0 else 1), g[f"out{i}"]) < 2e-5
+
+
+def test_param_groups_rule():
+    shapes = orc.state_dict_shapes(2, 3, 16, (32, 32, 32), 8)
+    decay, no_decay = orc.param_groups(list(shapes.items()))
+    assert "attns.0.position_embeddings" in decay           # 3-D, not '.bias' -> decayed
+    assert "block_1_1_left.norm.weight" in no_decay and "conv1x1.bias" in no_decay
+    assert len(decay) + len(no_decay) == len(shapes)
+
+
+def test_state_dict_count_full_config():
+    shapes = orc.state_dict_shapes(4, 4, 32, (128, 128, 128), 24)
+    assert len(shapes) == 1420
+    assert sum(int(np.prod(s)) for s in shapes.values()) == 15_430_000 or \
+        abs(sum(int(np.prod(s)) for s in shapes.values()) - 15.43e6) < 0.01e6
