@@ -1,0 +1,53 @@
+// Argument blocks of the implicit-GEMM 3x3x3 convolution family (see conv_igemm.hip).
+#pragma once
+#include "hdf_common.h"
+
+// Pitched channels-last view: voxel (n,d,h,w) channel c lives at p + ((((n*D+d)*H+h)*W+w)*pitch + c)
+// elements.  `p` already points at the first channel of the view, so a channel slice of a wider
+// buffer (e.g. one half of a concat buffer) is just a different p with the same pitch.
+struct ConvArgs {
+  const void* in;
+  int64_t in_pitch;
+  int Cin;  // multiple of 16
+  int N, Di, Hi, Wi;
+  int Do, Ho, Wo;
+  const void* w;        // packed [27][CoutP][Cin] storage type, CoutP = round_up(Cout,32), zero padded
+  const float* bias;    // [Cout] or null
+  const float* in_scale;  // [N][Cin] or null: x -> x*scale+shift (then relu if in_relu)
+  const float* in_shift;
+  int in_relu;
+  void* out;
+  int64_t out_pitch;
+  int Cout;
+  int CoutP;
+  float* stat_partials;  // [N*tiles][CoutP][2] (sum, sum of squares) or null
+  int accumulate;        // out += result
+};
+
+struct WgradArgs {
+  // D[tap][sc][lc] = sum_{n,i} S[n,i][sc] * L[n, STRIDE*i - 1 + tap][lc]
+  const void* sm;
+  int64_t sm_pitch;
+  int SC;  // channels of the small tensor (multiple of 16)
+  const void* lg;
+  int64_t lg_pitch;
+  int LC;
+  int N, Ds, Hs, Ws, Dl, Hl, Wl;
+  const float* sm_scale;  // [N][SC] or null
+  const float* sm_shift;
+  int sm_relu;
+  const float* lg_scale;  // [N][LC] or null
+  const float* lg_shift;
+  int lg_relu;
+  float* partials;  // [G][27][SCp][LCp]
+  int SCp, LCp;
+  int tiles_per_group, num_tiles;
+};
+
+int hdf_launch_conv(int dtype, int mode /*0 conv s1, 1 conv s2, 2 convT*/, const ConvArgs& a, hipStream_t st);
+int hdf_conv_stat_tiles(int mode, int Do, int Ho, int Wo);  // tiles per sample for the stat partials
+int hdf_launch_wgrad(int dtype, int stride, WgradArgs a, float* dw, int sc_store, int lc_store, int accumulate,
+                     void* workspace, size_t workspace_bytes, hipStream_t st);
+size_t hdf_wgrad_workspace_bytes(int stride, int N, int Ds, int Hs, int Ws, int SC, int LC);
+int hdf_launch_pack_w(int dtype, const float* src, void* dst, int O, int I, int OP, int IP, int64_t so, int64_t si,
+                      int flip, hipStream_t st);

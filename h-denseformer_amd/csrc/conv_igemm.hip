@@ -1,0 +1,504 @@
+// Implicit-GEMM 3x3x3 convolution family on the gfx950 matrix cores.
+//
+// One kernel template covers
+//   mode 0  Conv3d(k3,s1,p1)            -- forward of BasicConv3d / UpConv convs (HDenseFormer.py:151,167)
+//                                          and, with flipped+transposed packed weights, their dgrad
+//   mode 1  Conv3d(k3,s2,p1) gather     -- dgrad of ConvTranspose3d(k3,s2,p1,op1)   (HDenseFormer.py:211,215,219)
+//   mode 2  ConvTranspose3d(k3,s2,p1,op1) forward, one launch z-slice per output parity class
+// plus the weight-gradient kernel (wgrad) for stride 1 and 2.
+//
+// Data layout: activations are channels-last (NDHWC) with an explicit voxel pitch, storage bf16 or
+// f32.  GEMM view: M = output voxels of a 3-D tile, N = output channels, K = taps x input channels.
+// A workgroup (4 waves) stages the input halo box of its tile in LDS, 64 bytes of channels per
+// voxel row (32 bf16 / 16 f32) padded to an 80-byte pitch (conflict-free for ds_read_b128), applies
+// the producer's InstanceNorm+ReLU on the way in (so normalised activations are never written to
+// HBM), then walks taps x channel chunks issuing v_mfma_f32_32x32x16_bf16 (bf16 storage) or
+// v_mfma_f32_32x32x2_f32 (f32 storage: exact fp32 fma chains, the parity path).  The epilogue adds
+// bias, stores the raw conv output once and emits per-tile (sum, sum^2) partials for the following
+// InstanceNorm, reduced deterministically by in_finalize (no float atomics).
+#include "conv_igemm.h"
+
+namespace {
+
+constexpr int PITCH = 80;  // LDS bytes per voxel row: 64 payload + 16 pad
+
+template <typename T>
+struct Mma;
+template <>
+struct Mma<bf16_t> {
+  static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <>
+struct Mma<float> {
+  // lane (r, h) holds channels 4h..4h+3 of an 8-channel group: step s contracts channels {s, 4+s}
+  static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+      c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[s]), __uint_as_float(b[s]), c, 0, 0, 0);
+  }
+};
+
+// Stage a box of voxels (channels [c0, c0 + chunk_elems)) of a pitched NDHWC tensor into LDS with the
+// optional per-(n,channel) affine(+relu) transform.  Voxels outside the tensor and channels >= C
+// become zeros (zero padding applies to the TRANSFORMED activation).
+template <typename T, int BD, int BH, int BW, int ROWB /*payload bytes per row*/, int LPITCH>
+__device__ __forceinline__ void stage_box(char* lds, const T* __restrict__ src, int64_t pitch, int C, int n, int D,
+                                          int H, int W, int oz, int oy, int ox, int c0, int row_bytes,
+                                          const float* __restrict__ scale, const float* __restrict__ shift, int relu) {
+  constexpr int EPC = ST<T>::EPC;
+  const int cpv = row_bytes >> 4;  // 16-B chunks per voxel row (power of two)
+  const int cpv_shift = (cpv == 8) ? 3 : (cpv == 4) ? 2 : (cpv == 2) ? 1 : 0;
+  const int total = (BD * BH * BW) << cpv_shift;
+  const int part = threadIdx.x & (cpv - 1);  // constant per thread (256 % cpv == 0)
+  const int cbase = c0 + part * EPC;
+  float sc[EPC], sh[EPC];
+  const bool xf = (scale != nullptr);
+  if (xf) {
+#pragma unroll
+    for (int e = 0; e < EPC; e++) {
+      bool ok = (cbase + e) < C;
+      sc[e] = ok ? scale[(int64_t)n * C + cbase + e] : 0.f;
+      sh[e] = ok ? shift[(int64_t)n * C + cbase + e] : 0.f;
+    }
+  }
+  const bool chan_ok = cbase < C;  // C is a multiple of EPC
+#pragma unroll 4
+  for (int id = threadIdx.x; id < total; id += 256) {
+    int vox = id >> cpv_shift;
+    int bz = vox / (BH * BW);
+    int rem = vox - bz * (BH * BW);
+    int by = rem / BW;
+    int bx = rem - by * BW;
+    int iz = oz + bz, iy = oy + by, ix = ox + bx;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (chan_ok && (unsigned)iz < (unsigned)D && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+      const T* p = src + ((((int64_t)n * D + iz) * H + iy) * W + ix) * pitch + cbase;
+      v = *reinterpret_cast<const u32x4*>(p);
+      if (xf) {
+        float f[EPC];
+        ST<T>::unpack(v, f);
+#pragma unroll
+        for (int e = 0; e < EPC; e++) {
+          f[e] = f[e] * sc[e] + sh[e];
+          if (relu) f[e] = fmaxf(f[e], 0.f);
+        }
+        v = ST<T>::pack(f);
+      }
+    }
+    *reinterpret_cast<u32x4*>(lds + vox * LPITCH + part * 16) = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward-style kernel (modes 0,1,2)
+template <typename T, int TD, int TH, int TW, int WM, int WN, int MB, int S, bool CONVT>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+  static_assert(WM * WN == 4, "4 waves");
+  static_assert(WM * MB * 32 == TD * TH * TW, "tile/wave decomposition");
+  constexpr int BD = CONVT ? TD + 1 : S * (TD - 1) + 3;
+  constexpr int BH = CONVT ? TH + 1 : S * (TH - 1) + 3;
+  constexpr int BW = CONVT ? TW + 1 : S * (TW - 1) + 3;
+  constexpr int SS = CONVT ? 1 : S;
+  constexpr int ESZ = sizeof(T);
+  __shared__ __attribute__((aligned(16))) char lds[BD * BH * BW * PITCH + 4 * 32 * 2 * 4];
+  float* s_red = reinterpret_cast<float*>(lds + BD * BH * BW * PITCH);  // [WN*32][2]
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+
+  // tile space: output voxels (conv) or input voxels m (convT)
+  const int Td = CONVT ? a.Di : a.Do, Th = CONVT ? a.Hi : a.Ho, Tw = CONVT ? a.Wi : a.Wo;
+  const int ntz = (Td + TD - 1) / TD, nty = (Th + TH - 1) / TH, ntx = (Tw + TW - 1) / TW;
+  int t = blockIdx.x;
+  const int tx = t % ntx;
+  t /= ntx;
+  const int ty = t % nty;
+  t /= nty;
+  const int tz = t % ntz;
+  const int n = t / ntz;
+  const int z0 = tz * TD, y0 = ty * TH, x0 = tx * TW;
+  const int n_base = blockIdx.y * (WN * 32) + wn * 32;
+  const int cls = CONVT ? blockIdx.z : 0;
+  const int pz = (cls >> 2) & 1, py = (cls >> 1) & 1, px = cls & 1;
+  const int ntapz = CONVT ? (pz ? 2 : 1) : 3, ntapy = CONVT ? (py ? 2 : 1) : 3, ntapx = CONVT ? (px ? 2 : 1) : 3;
+
+  const int oz = CONVT ? z0 : S * z0 - 1, oy = CONVT ? y0 : S * y0 - 1, ox = CONVT ? x0 : S * x0 - 1;
+
+  int rowbase[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; mb++) {
+    int lin = (wm * MB + mb) * 32 + r;
+    int lz = lin / (TH * TW), ly = (lin / TW) % TH, lx = lin % TW;
+    rowbase[mb] = ((SS * lz) * BH + SS * ly) * BW + SS * lx;
+  }
+  f32x16 acc[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[mb][i] = 0.f;
+
+  const bool n_active = n_base < a.CoutP;  // wave-uniform
+  const char* wrow = reinterpret_cast<const char*>(a.w) + ((int64_t)(n_base + r) * a.Cin) * ESZ + h * 16;
+  const int64_t wtap_stride = (int64_t)a.CoutP * a.Cin * ESZ;
+  const int chunk_elems_max = 64 / ESZ;
+
+  for (int c0 = 0; c0 < a.Cin; c0 += chunk_elems_max) {
+    const int chunk_elems = min(chunk_elems_max, a.Cin - c0);
+    const int row_bytes = chunk_elems * ESZ;  // 64 or 32
+    if (c0 > 0) __syncthreads();
+    stage_box<T, BD, BH, BW, 64, PITCH>(lds, reinterpret_cast<const T*>(a.in), a.in_pitch, a.Cin, n, a.Di, a.Hi, a.Wi,
+                                        oz, oy, ox, c0, row_bytes, a.in_scale, a.in_shift, a.in_relu);
+    __syncthreads();
+    if (n_active) {
+      const int nfs = row_bytes >> 5;  // fragment steps (32 B each) in this chunk
+      for (int jz = 0; jz < ntapz; jz++) {
+        const int offz = CONVT ? (pz ? 1 - jz : 0) : jz, wz = CONVT ? (pz ? 2 * jz : 1) : jz;
+        for (int jy = 0; jy < ntapy; jy++) {
+          const int offy = CONVT ? (py ? 1 - jy : 0) : jy, wy = CONVT ? (py ? 2 * jy : 1) : jy;
+#pragma unroll
+          for (int jx = 0; jx < 3; jx++) {
+            if (jx < ntapx) {
+              const int offx = CONVT ? (px ? 1 - jx : 0) : jx, wx = CONVT ? (px ? 2 * jx : 1) : jx;
+              const int tapoff = ((offz * BH + offy) * BW + offx) * PITCH + h * 16;
+              const char* wp = wrow + ((wz * 3 + wy) * 3 + wx) * wtap_stride + (int64_t)c0 * ESZ;
+              for (int fs = 0; fs < nfs; fs++) {
+                u32x4 bfrag = *reinterpret_cast<const u32x4*>(wp + fs * 32);
+                u32x4 afrag[MB];
+#pragma unroll
+                for (int mb = 0; mb < MB; mb++)
+                  afrag[mb] = *reinterpret_cast<const u32x4*>(lds + rowbase[mb] * PITCH + tapoff + fs * 32);
+#pragma unroll
+                for (int mb = 0; mb < MB; mb++) Mma<T>::run(afrag[mb], bfrag, acc[mb]);
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // ------------------------------------------------------------------------------- epilogue
+  const int ch = n_base + r;
+  const bool ch_ok = n_active && ch < a.Cout;
+  const float bias = (a.bias && ch_ok) ? a.bias[ch] : 0.f;
+  float s1 = 0.f, s2 = 0.f;
+  T* outp = reinterpret_cast<T*>(a.out);
+#pragma unroll
+  for (int mb = 0; mb < MB; mb++) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+      int lin = (wm * MB + mb) * 32 + row;
+      int lz = lin / (TH * TW), ly = (lin / TW) % TH, lx = lin % TW;
+      int gz = z0 + lz, gy = y0 + ly, gx = x0 + lx;
+      if (ch_ok && gz < Td && gy < Th && gx < Tw) {
+        int qz = CONVT ? 2 * gz + pz : gz, qy = CONVT ? 2 * gy + py : gy, qx = CONVT ? 2 * gx + px : gx;
+        T* p = outp + ((((int64_t)n * a.Do + qz) * a.Ho + qy) * a.Wo + qx) * a.out_pitch + ch;
+        float v = acc[mb][i] + bias;
+        if (a.accumulate) v += ST<T>::ld(p);
+        ST<T>::st(p, v);
+        s1 += v;
+        s2 += v * v;
+      }
+    }
+  }
+  if (a.stat_partials) {
+    // lanes r and r+32 hold the same channel (different rows): fold, then reduce over the WM waves
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    __syncthreads();
+    if (threadIdx.x < WN * 32 * 2) s_red[threadIdx.x] = 0.f;
+    __syncthreads();
+    if (h == 0) {
+      atomicAdd(&s_red[(wn * 32 + r) * 2 + 0], s1);  // LDS float add; WM<=4 adders per word
+      atomicAdd(&s_red[(wn * 32 + r) * 2 + 1], s2);
+    }
+    __syncthreads();
+    if (threadIdx.x < WN * 32) {
+      int c = blockIdx.y * (WN * 32) + threadIdx.x;
+      if (c < a.CoutP) {
+        float* q = a.stat_partials + ((int64_t)blockIdx.x * a.CoutP + c) * 2;
+        q[0] = s_red[threadIdx.x * 2 + 0];
+        q[1] = s_red[threadIdx.x * 2 + 1];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient:  D[tap][sc][lc] = sum_{n,i} S[n,i][sc] * L[n, STRIDE*i-1+tap][lc]
+// bf16: both operands are contracted over VOXELS, which are the slow axis of the channels-last LDS
+// rows -> read with ds_read_b64_tr_b16 (hardware transpose, 4 voxels x 16 channels per 16 lanes).
+// f32: v_mfma_f32_32x32x2_f32 takes one scalar per lane, plain ds_read_b32.
+template <typename T>
+struct WG;
+template <>
+struct WG<bf16_t> {
+  static constexpr int KV = 16;  // voxels contracted per MFMA step
+};
+template <>
+struct WG<float> {
+  static constexpr int KV = 2;
+};
+
+template <typename T, int TD, int TH, int TW, int S>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+  constexpr int MT = TD * TH * TW;
+  constexpr int BD = S * (TD - 1) + 3, BH = S * (TH - 1) + 3, BW = S * (TW - 1) + 3;
+  constexpr int ROWB = 32 * sizeof(T);  // 32 channels per LDS row
+  constexpr int LP = ROWB + 16;
+  constexpr int TAPS_PER_WAVE = 7;
+  __shared__ __attribute__((aligned(16))) char lds[(MT + BD * BH * BW) * LP];
+  char* s_lds = lds;
+  char* l_lds = lds + MT * LP;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int scb = blockIdx.y, lcb = blockIdx.z;
+  const int ntz = (a.Ds + TD - 1) / TD, nty = (a.Hs + TH - 1) / TH, ntx = (a.Ws + TW - 1) / TW;
+
+  f32x16 acc[TAPS_PER_WAVE];
+#pragma unroll
+  for (int j = 0; j < TAPS_PER_WAVE; j++)
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[j][i] = 0.f;
+
+  int tapoff[TAPS_PER_WAVE];
+#pragma unroll
+  for (int j = 0; j < TAPS_PER_WAVE; j++) {
+    int tap = wave * TAPS_PER_WAVE + j;
+    int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+    tapoff[j] = ((kz * BH + ky) * BW + kx) * LP;
+  }
+  const int ntaps_here = min(TAPS_PER_WAVE, 27 - wave * TAPS_PER_WAVE);  // 7,7,7,6
+
+  const int t_begin = blockIdx.x * a.tiles_per_group;
+  const int t_end = min(a.num_tiles, t_begin + a.tiles_per_group);
+  for (int tile = t_begin; tile < t_end; tile++) {
+    int t = tile;
+    const int tx = t % ntx;
+    t /= ntx;
+    const int ty = t % nty;
+    t /= nty;
+    const int tz = t % ntz;
+    const int n = t / ntz;
+    const int z0 = tz * TD, y0 = ty * TH, x0 = tx * TW;
+    if (tile > t_begin) __syncthreads();
+    // S tile: MT voxels stored linearly (z,y,x) -> stage as a TDxTHxTW box at (z0,y0,x0)
+    stage_box<T, TD, TH, TW, ROWB, LP>(s_lds, reinterpret_cast<const T*>(a.sm), a.sm_pitch, a.SC, n, a.Ds, a.Hs, a.Ws,
+                                       z0, y0, x0, scb * 32, ROWB, a.sm_scale, a.sm_shift, a.sm_relu);
+    stage_box<T, BD, BH, BW, ROWB, LP>(l_lds, reinterpret_cast<const T*>(a.lg), a.lg_pitch, a.LC, n, a.Dl, a.Hl, a.Wl,
+                                       S * z0 - 1, S * y0 - 1, S * x0 - 1, lcb * 32, ROWB, a.lg_scale, a.lg_shift,
+                                       a.lg_relu);
+    __syncthreads();
+
+    if constexpr (sizeof(T) == 2) {
+      // lane roles for ds_read_b64_tr_b16: group g4 = lane>>4 ; within group i = lane&15, q = i>>2, p = i&3
+      const int g4 = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+      const int hh = g4 >> 1, cb = (g4 & 1) * 16;
+      const int colb = (cb + 4 * p) * 2;
+      for (int ks = 0; ks < MT / 16; ks++) {
+        // the two 4-voxel groups this lane addresses: k = 8*hh + 4*t + q
+        int sA[2], lB[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; tt++) {
+          int lin = ks * 16 + 8 * hh + 4 * tt + q;
+          int lz = lin / (TH * TW), ly = (lin / TW) % TH, lx = lin % TW;
+          sA[tt] = lin * LP + colb;
+          lB[tt] = (((S * lz) * BH + S * ly) * BW + S * lx) * LP + colb;
+        }
+        s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(s_lds + sA[0]));
+        s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(s_lds + sA[1]));
+        u32x2 a0u = __builtin_bit_cast(u32x2, a0), a1u = __builtin_bit_cast(u32x2, a1);
+        u32x4 af = {a0u[0], a0u[1], a1u[0], a1u[1]};
+#pragma unroll
+        for (int j = 0; j < TAPS_PER_WAVE; j++) {
+          if (j < ntaps_here) {
+            s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (s16x4 __attribute__((address_space(3)))*)(l_lds + lB[0] + tapoff[j]));
+            s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (s16x4 __attribute__((address_space(3)))*)(l_lds + lB[1] + tapoff[j]));
+            u32x2 b0u = __builtin_bit_cast(u32x2, b0), b1u = __builtin_bit_cast(u32x2, b1);
+            u32x4 bf = {b0u[0], b0u[1], b1u[0], b1u[1]};
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af),
+                                                             __builtin_bit_cast(bf16x8, bf), acc[j], 0, 0, 0);
+          }
+        }
+      }
+    } else {
+      const int r = lane & 31, hh = lane >> 5;
+      for (int ks = 0; ks < MT / 2; ks++) {
+        int lin = ks * 2 + hh;
+        int lz = lin / (TH * TW), ly = (lin / TW) % TH, lx = lin % TW;
+        float av = *reinterpret_cast<const float*>(s_lds + lin * LP + r * 4);
+        const char* lb = l_lds + (((S * lz) * BH + S * ly) * BW + S * lx) * LP + r * 4;
+#pragma unroll
+        for (int j = 0; j < TAPS_PER_WAVE; j++) {
+          if (j < ntaps_here) {
+            float bv = *reinterpret_cast<const float*>(lb + tapoff[j]);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // partial[g][tap][SCp][LCp]
+  const int col = lane & 31, hh2 = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < TAPS_PER_WAVE; j++) {
+    if (j < ntaps_here) {
+      int tap = wave * TAPS_PER_WAVE + j;
+      float* base = a.partials + (((int64_t)blockIdx.x * 27 + tap) * a.SCp + scb * 32) * a.LCp + lcb * 32 + col;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        int row = (i & 3) + 8 * (i >> 2) + 4 * hh2;
+        base[(int64_t)row * a.LCp] = acc[j][i];
+      }
+    }
+  }
+}
+
+// out[(sc*LC + lc)*27 + tap] (+)= sum_g partial[g][tap][sc][lc]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw, int G, int SCp, int LCp,
+                                    int SC, int LC, int accumulate) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t per = (int64_t)27 * SCp * LCp;
+  if (idx >= per) return;
+  int lc = idx % LCp;
+  int sc = (idx / LCp) % SCp;
+  int tap = idx / ((int64_t)LCp * SCp);
+  if (lc >= LC || sc >= SC) return;
+  double s = 0.0;
+  for (int g = 0; g < G; g++) s += (double)partials[(int64_t)g * per + idx];
+  float* o = dw + ((int64_t)sc * LC + lc) * 27 + tap;
+  *o = accumulate ? (*o + (float)s) : (float)s;
+}
+
+// dst[t][o][i] = src[o*so + i*si + (flip ? 26-t : t)]  (zero for o>=O or i>=I); dst is [27][OP][IP]
+template <typename T>
+__global__ void pack_w_kernel(const float* __restrict__ src, T* __restrict__ dst, int O, int I, int OP, int IP,
+                              int64_t so, int64_t si, int flip) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t total = (int64_t)27 * OP * IP;
+  if (idx >= total) return;
+  int i = idx % IP;
+  int o = (idx / IP) % OP;
+  int t = idx / ((int64_t)IP * OP);
+  float v = 0.f;
+  if (o < O && i < I) v = src[o * so + i * si + (flip ? 26 - t : t)];
+  ST<T>::st(dst + idx, v);
+}
+
+template <typename T, int TD, int TH, int TW, int WM, int WN, int MB, int S, bool CONVT>
+int launch_cfg(const ConvArgs& a, hipStream_t st) {
+  const int Td = CONVT ? a.Di : a.Do, Th = CONVT ? a.Hi : a.Ho, Tw = CONVT ? a.Wi : a.Wo;
+  dim3 grid(a.N * ceil_div(Td, TD) * ceil_div(Th, TH) * ceil_div(Tw, TW), ceil_div(a.CoutP, WN * 32), CONVT ? 8 : 1);
+  hipLaunchKernelGGL((conv_igemm_kernel<T, TD, TH, TW, WM, WN, MB, S, CONVT>), grid, dim3(256), 0, st, a);
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
+// tile-shape choice: shared by the launcher and by hdf_conv_stat_tiles (partials geometry)
+inline bool small_tile(int Do, int Ho, int Wo) { return (int64_t)Do * Ho * Wo <= 32 * 32 * 32 / 2; }
+
+template <typename T>
+int launch_conv_t(int mode, const ConvArgs& a, hipStream_t st) {
+  if (mode == 0) {
+    if (small_tile(a.Do, a.Ho, a.Wo)) return launch_cfg<T, 4, 4, 8, 2, 2, 2, 1, false>(a, st);  // 128 vox x 64 ch
+    if (a.CoutP <= 32) return launch_cfg<T, 4, 8, 8, 4, 1, 2, 1, false>(a, st);                  // 256 vox x 32 ch
+    return launch_cfg<T, 4, 8, 8, 2, 2, 4, 1, false>(a, st);                                     // 256 vox x 64 ch
+  } else if (mode == 1) {
+    return launch_cfg<T, 4, 4, 4, 1, 4, 2, 2, false>(a, st);  // 64 vox x 128 ch, stride 2
+  } else {
+    if (a.CoutP <= 32) return launch_cfg<T, 4, 8, 8, 4, 1, 2, 1, true>(a, st);
+    return launch_cfg<T, 4, 4, 8, 2, 2, 2, 1, true>(a, st);
+  }
+}
+
+template <typename T, int TD, int TH, int TW, int S>
+int launch_wgrad_t(WgradArgs a, float* dw, int sc_store, int lc_store, int accumulate, void* ws, size_t ws_bytes,
+                   hipStream_t st) {
+  a.SCp = round_up(a.SC, 32);
+  a.LCp = round_up(a.LC, 32);
+  a.num_tiles = a.N * ceil_div(a.Ds, TD) * ceil_div(a.Hs, TH) * ceil_div(a.Ws, TW);
+  const int pairs = (a.SCp / 32) * (a.LCp / 32);
+  const int64_t per = (int64_t)27 * a.SCp * a.LCp * sizeof(float);
+  int G = ceil_div(1024, pairs);
+  G = (int)std::min<int64_t>(G, std::max<int64_t>(1, (int64_t)ws_bytes / per));
+  G = std::min(G, a.num_tiles);
+  a.tiles_per_group = ceil_div(a.num_tiles, G);
+  G = ceil_div(a.num_tiles, a.tiles_per_group);
+  HDF_CHECK_ARG((size_t)(G * per) <= ws_bytes, "wgrad workspace too small: need %lld have %zu", (long long)(G * per),
+                ws_bytes);
+  a.partials = reinterpret_cast<float*>(ws);
+  dim3 grid(G, a.SCp / 32, a.LCp / 32);
+  hipLaunchKernelGGL((conv_wgrad_kernel<T, TD, TH, TW, S>), grid, dim3(256), 0, st, a);
+  HDF_LAUNCH_CHECK();
+  int64_t n = (int64_t)27 * a.SCp * a.LCp;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, st, a.partials, dw, G,
+                     a.SCp, a.LCp, sc_store, lc_store, accumulate);
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
+}  // namespace
+
+int hdf_conv_stat_tiles(int mode, int Do, int Ho, int Wo) {
+  if (mode != 0) return 0;
+  if (small_tile(Do, Ho, Wo)) return ceil_div(Do, 4) * ceil_div(Ho, 4) * ceil_div(Wo, 8);
+  return ceil_div(Do, 4) * ceil_div(Ho, 8) * ceil_div(Wo, 8);
+}
+
+int hdf_launch_conv(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
+  HDF_CHECK_ARG(a.Cin % 16 == 0, "conv: Cin=%d must be a multiple of 16 (pad the first layer)", a.Cin);
+  HDF_CHECK_ARG(a.CoutP % 32 == 0 && a.CoutP >= a.Cout, "conv: bad CoutP=%d for Cout=%d", a.CoutP, a.Cout);
+  HDF_CHECK_ARG(a.in_pitch % 8 == 0 && (((uintptr_t)a.in) & 15) == 0, "conv: input view must be 16-byte aligned");
+  HDF_CHECK_ARG(mode == 0 || a.stat_partials == nullptr, "conv: stats only in mode 0");
+  if (dtype == HDF_BF16) return launch_conv_t<bf16_t>(mode, a, st);
+  if (dtype == HDF_F32) return launch_conv_t<float>(mode, a, st);
+  hdf_set_error("conv: unsupported dtype %d", dtype);
+  return HDF_ERR_UNSUPPORTED;
+}
+
+size_t hdf_wgrad_workspace_bytes(int stride, int N, int Ds, int Hs, int Ws, int SC, int LC) {
+  int SCp = round_up(SC, 32), LCp = round_up(LC, 32);
+  int64_t per = (int64_t)27 * SCp * LCp * sizeof(float);
+  int pairs = (SCp / 32) * (LCp / 32);
+  int tiles = stride == 1 ? N * ceil_div(Ds, 4) * ceil_div(Hs, 8) * ceil_div(Ws, 8)
+                          : N * ceil_div(Ds, 4) * ceil_div(Hs, 4) * ceil_div(Ws, 4);
+  int G = std::min(ceil_div(1024, pairs), tiles);
+  int64_t bytes = std::min<int64_t>((int64_t)G * per, std::max<int64_t>(per, (int64_t)96 << 20));
+  return (size_t)bytes;
+}
+
+int hdf_launch_wgrad(int dtype, int stride, WgradArgs a, float* dw, int sc_store, int lc_store, int accumulate,
+                     void* workspace, size_t workspace_bytes, hipStream_t st) {
+  HDF_CHECK_ARG(a.SC % 16 == 0 && a.LC % 16 == 0, "wgrad: channel counts must be multiples of 16 (SC=%d LC=%d)", a.SC,
+                a.LC);
+  HDF_CHECK_ARG(stride == 1 || stride == 2, "wgrad: stride %d", stride);
+  if (dtype == HDF_BF16) {
+    if (stride == 1) return launch_wgrad_t<bf16_t, 4, 8, 8, 1>(a, dw, sc_store, lc_store, accumulate, workspace, workspace_bytes, st);
+    return launch_wgrad_t<bf16_t, 4, 4, 4, 2>(a, dw, sc_store, lc_store, accumulate, workspace, workspace_bytes, st);
+  }
+  if (dtype == HDF_F32) {
+    if (stride == 1) return launch_wgrad_t<float, 4, 8, 8, 1>(a, dw, sc_store, lc_store, accumulate, workspace, workspace_bytes, st);
+    return launch_wgrad_t<float, 4, 4, 4, 2>(a, dw, sc_store, lc_store, accumulate, workspace, workspace_bytes, st);
+  }
+  hdf_set_error("wgrad: unsupported dtype %d", dtype);
+  return HDF_ERR_UNSUPPORTED;
+}
+
+int hdf_launch_pack_w(int dtype, const float* src, void* dst, int O, int I, int OP, int IP, int64_t so, int64_t si,
+                      int flip, hipStream_t st) {
+  int64_t total = (int64_t)27 * OP * IP;
+  dim3 grid((unsigned)ceil_div64(total, 256));
+  if (dtype == HDF_BF16)
+    hipLaunchKernelGGL(pack_w_kernel<bf16_t>, grid, dim3(256), 0, st, src, (bf16_t*)dst, O, I, OP, IP, so, si, flip);
+  else
+    hipLaunchKernelGGL(pack_w_kernel<float>, grid, dim3(256), 0, st, src, (float*)dst, O, I, OP, IP, so, si, flip);
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}

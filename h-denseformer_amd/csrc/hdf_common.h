@@ -1,0 +1,137 @@
+// Common device/host helpers for the gfx950 (CDNA4) kernels of the H-DenseFormer hot path.
+// Everything here is MI355X-only: wave64, MFMA, 160 KiB LDS.  No portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define HDF_OK 0
+#define HDF_ERR_ARG 1
+#define HDF_ERR_HIP 2
+#define HDF_ERR_UNSUPPORTED 3
+
+enum { HDF_F32 = 0, HDF_BF16 = 1 };
+
+void hdf_set_error(const char* fmt, ...);
+
+#define HDF_CHECK_ARG(cond, ...)              \
+  do {                                        \
+    if (!(cond)) {                            \
+      hdf_set_error(__VA_ARGS__);             \
+      return HDF_ERR_ARG;                     \
+    }                                         \
+  } while (0)
+
+#define HDF_LAUNCH_CHECK()                                                        \
+  do {                                                                            \
+    hipError_t e__ = hipGetLastError();                                           \
+    if (e__ != hipSuccess) {                                                      \
+      hdf_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+      return HDF_ERR_HIP;                                                         \
+    }                                                                             \
+  } while (0)
+
+#define HDF_TRY(expr)            \
+  do {                           \
+    int rc__ = (expr);           \
+    if (rc__ != HDF_OK) return rc__; \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// storage types
+struct bf16_t {
+  uint16_t v;
+};
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+__device__ __forceinline__ float bf2f(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+__device__ __forceinline__ uint16_t f2bf(float f) {
+  __bf16 h = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN preserved
+  return __builtin_bit_cast(uint16_t, h);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+
+template <typename T>
+struct ST;  // storage traits
+template <>
+struct ST<float> {
+  static constexpr int EPC = 4;  // elements per 16-byte chunk
+  static constexpr int DT = HDF_F32;
+  __device__ static __forceinline__ float ld(const float* p) { return *p; }
+  __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+  // unpack a 16-B chunk into EPC floats / pack back
+  __device__ static __forceinline__ void unpack(const u32x4& c, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) f[i] = __uint_as_float(c[i]);
+  }
+  __device__ static __forceinline__ u32x4 pack(const float* f) {
+    u32x4 c;
+#pragma unroll
+    for (int i = 0; i < 4; i++) c[i] = __float_as_uint(f[i]);
+    return c;
+  }
+};
+template <>
+struct ST<bf16_t> {
+  static constexpr int EPC = 8;
+  static constexpr int DT = HDF_BF16;
+  __device__ static __forceinline__ float ld(const bf16_t* p) { return bf2f(p->v); }
+  __device__ static __forceinline__ void st(bf16_t* p, float v) { p->v = f2bf(v); }
+  __device__ static __forceinline__ void unpack(const u32x4& c, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      f[2 * i] = __uint_as_float(c[i] << 16);
+      f[2 * i + 1] = __uint_as_float(c[i] & 0xffff0000u);
+    }
+  }
+  __device__ static __forceinline__ u32x4 pack(const float* f) {
+    u32x4 c;
+#pragma unroll
+    for (int i = 0; i < 4; i++) c[i] = pack_bf2(f[2 * i], f[2 * i + 1]);
+    return c;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// dropout hash (same integer recipe as oracle/detgen.py: mix32 / dropout_keep)
+__host__ __device__ __forceinline__ uint32_t hdf_mix32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7FEB352Du;
+  x ^= x >> 15;
+  x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  return x;
+}
+__host__ __device__ __forceinline__ uint32_t hdf_site_key(uint32_t seed, uint32_t site) {
+  return hdf_mix32(seed ^ (site * 0x9E3779B1u));
+}
+// keep decision for flat element index idx under a site key; thresh24 = round((1-p)*2^24)
+__host__ __device__ __forceinline__ bool hdf_keep(uint32_t key, uint32_t idx, uint32_t thresh24) {
+  return (hdf_mix32(idx + key) >> 8) < thresh24;
+}
+__host__ __device__ __forceinline__ uint32_t hdf_site_id(int m, int b, int l, int kind) {
+  return (uint32_t)(((m * 64 + b) * 8 + l) * 8 + kind);
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave helpers (wave = 64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }

@@ -1,0 +1,18 @@
+#pragma once
+#include "hdf_common.h"
+
+struct LossScales {
+  float V[4];
+  float weight[4];
+};
+
+int hdf_loss_blocks();
+size_t hdf_loss_workspace_floats(int N, int nscale);
+int hdf_launch_loss_fwd(int dtype, const void* const* logits, const float* target, int nscale, int N, int C, int D,
+                        int H, int W, float* ws, float* loss_out, hipStream_t st);
+int hdf_launch_loss_bwd(int dtype, const void* const* logits, const float* target, int nscale, int N, int C, int D,
+                        int H, int W, const float* ws, const float* grad_out, void* const* dlogits, hipStream_t st);
+int hdf_launch_dice_counts(int dtype, const void* logits, const float* target, int N, int C, int64_t V,
+                           unsigned long long* counts, hipStream_t st);
+int hdf_launch_adam(float* p, const float* g, float* m, float* v, const uint8_t* decay, int64_t n, float lr, float b1,
+                    float b2, float eps, float wd, int step, float gscale, hipStream_t st);

@@ -1,0 +1,304 @@
+// Fused DeepSuperloss(CEPlusDice) forward/backward, on-device Dice metric, flat Adam.
+//
+// Reference: loss/combine_loss.py:8-35,68-79 ; loss/dice_loss.py:5-87 ; loss/cross_entropy.py:8-22 ;
+// metric trainer.py:891-945 ; optimizer torch.optim.Adam as built by trainer.py:793-840.
+// One pass per scale reads the logits once (NCDHW, coalesced along voxels) and the fp32 one-hot target
+// at the 2^i-strided positions (nearest down-sampling), producing per-(sample,class) sums
+// sum(p*t), sum(p), sum(t) and the CE sum; backward recomputes the softmax from the logits.
+#include "loss.h"
+
+namespace {
+constexpr int MAXC = 8;
+constexpr int LOSS_BLOCKS = 256;
+constexpr int NSTAT = 3 * MAXC + 1;
+
+template <typename T>
+__global__ __launch_bounds__(256) void loss_fwd_kernel(const T* __restrict__ logits, const float* __restrict__ target,
+                                                       int C, int Ds, int Hs, int Ws, int stride, int D, int H, int W,
+                                                       float* __restrict__ partials /*[N][blocks][NSTAT]*/) {
+  __shared__ float red[4][NSTAT];
+  const int n = blockIdx.y;
+  const int64_t V = (int64_t)Ds * Hs * Ws, Vf = (int64_t)D * H * W;
+  float acc[NSTAT];
+#pragma unroll
+  for (int i = 0; i < NSTAT; i++) acc[i] = 0.f;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < V; v += (int64_t)gridDim.x * 256) {
+    int x = v % Ws, y = (v / Ws) % Hs, z = v / ((int64_t)Ws * Hs);
+    int64_t vf = ((int64_t)z * stride * H + (int64_t)y * stride) * W + (int64_t)x * stride;
+    float lg[MAXC], t[MAXC];
+    float mx = -INFINITY, tbest = -INFINITY;
+    int tc = 0;
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) {
+      if (c < C) {
+        lg[c] = ST<T>::ld(logits + ((int64_t)n * C + c) * V + v);
+        t[c] = target[((int64_t)n * C + c) * Vf + vf];
+        mx = fmaxf(mx, lg[c]);
+        if (t[c] > tbest) {
+          tbest = t[c];
+          tc = c;
+        }
+      }
+    }
+    float se = 0.f, e[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; c++)
+      if (c < C) {
+        e[c] = __expf(lg[c] - mx);
+        se += e[c];
+      }
+    float inv = 1.f / se;
+    float lse = mx + __logf(se);
+#pragma unroll
+    for (int c = 0; c < MAXC; c++)
+      if (c < C) {
+        float p = e[c] * inv;
+        acc[c] += p * t[c];
+        acc[MAXC + c] += p;
+        acc[2 * MAXC + c] += t[c];
+        if (c == tc) acc[3 * MAXC] += lse - lg[c];
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < NSTAT; i++) acc[i] = wave_sum(acc[i]);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0)
+#pragma unroll
+    for (int i = 0; i < NSTAT; i++) red[wave][i] = acc[i];
+  __syncthreads();
+  if (threadIdx.x < NSTAT)
+    partials[((int64_t)n * gridDim.x + blockIdx.x) * NSTAT + threadIdx.x] =
+        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// one block: loss scalar + backward coefficients.  coef[(i*N+n)*MAXC + c] = (A, B) of the Dice gradient
+__global__ void loss_finalize_kernel(const float* __restrict__ partials, int nscale, int N, int C, int blocks,
+                                     LossScales sc, float smooth, float* __restrict__ loss_out,
+                                     float* __restrict__ coefA, float* __restrict__ coefB) {
+  __shared__ double tot[4 * 64];  // per (scale, n) contribution
+  const int tid = threadIdx.x;
+  if (tid < nscale * N) {
+    int i = tid / N, n = tid % N;
+    const float* base = partials + (int64_t)i * N * blocks * NSTAT + (int64_t)n * blocks * NSTAT;
+    double s[NSTAT];
+    for (int k = 0; k < NSTAT; k++) s[k] = 0.0;
+    for (int b = 0; b < blocks; b++)
+      for (int k = 0; k < NSTAT; k++) s[k] += (double)base[(int64_t)b * NSTAT + k];
+    double V = (double)sc.V[i];
+    double ce = s[3 * MAXC] / (V * N);
+    double dice = 0.0;
+    for (int c = 1; c < C; c++) {
+      double I = s[c], U = s[MAXC + c] + s[2 * MAXC + c];
+      dice += (1.0 - (2.0 * I + smooth) / (U + smooth)) / (double)N;
+      coefA[((int64_t)i * N + n) * MAXC + c] = (float)(2.0 / (U + smooth));
+      coefB[((int64_t)i * N + n) * MAXC + c] = (float)((2.0 * I + smooth) / ((U + smooth) * (U + smooth)));
+    }
+    coefA[((int64_t)i * N + n) * MAXC] = 0.f;
+    coefB[((int64_t)i * N + n) * MAXC] = 0.f;
+    dice /= (double)(C - 1);
+    tot[tid] = (ce + dice) * (double)sc.weight[i];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0.0;
+    for (int k = 0; k < nscale * N; k++) t += tot[k];
+    *loss_out = (float)t;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void loss_bwd_kernel(const T* __restrict__ logits, const float* __restrict__ target,
+                                                       int N, int C, int Ds, int Hs, int Ws, int stride, int D, int H,
+                                                       int W, const float* __restrict__ coefA,
+                                                       const float* __restrict__ coefB, float weight,
+                                                       const float* __restrict__ gup, T* __restrict__ dlogits) {
+  const int n = blockIdx.y;
+  const int64_t V = (int64_t)Ds * Hs * Ws, Vf = (int64_t)D * H * W;
+  const float g = (*gup) * weight;
+  const float kce = g / ((float)V * (float)N);
+  const float kd = g / ((float)(C - 1) * (float)N);
+  float cA[MAXC], cB[MAXC];
+#pragma unroll
+  for (int c = 0; c < MAXC; c++) {
+    cA[c] = c < C ? coefA[(int64_t)n * MAXC + c] : 0.f;
+    cB[c] = c < C ? coefB[(int64_t)n * MAXC + c] : 0.f;
+  }
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < V; v += (int64_t)gridDim.x * 256) {
+    int x = v % Ws, y = (v / Ws) % Hs, z = v / ((int64_t)Ws * Hs);
+    int64_t vf = ((int64_t)z * stride * H + (int64_t)y * stride) * W + (int64_t)x * stride;
+    float lg[MAXC], t[MAXC];
+    float mx = -INFINITY, tbest = -INFINITY;
+    int tc = 0;
+#pragma unroll
+    for (int c = 0; c < MAXC; c++)
+      if (c < C) {
+        lg[c] = ST<T>::ld(logits + ((int64_t)n * C + c) * V + v);
+        t[c] = target[((int64_t)n * C + c) * Vf + vf];
+        mx = fmaxf(mx, lg[c]);
+        if (t[c] > tbest) {
+          tbest = t[c];
+          tc = c;
+        }
+      }
+    float se = 0.f, p[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; c++)
+      if (c < C) {
+        p[c] = __expf(lg[c] - mx);
+        se += p[c];
+      }
+    float inv = 1.f / se, dot = 0.f, G[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; c++)
+      if (c < C) {
+        p[c] *= inv;
+        G[c] = (c >= 1) ? -kd * (cA[c] * t[c] - cB[c]) : 0.f;  // dDice/dp_c
+        dot += G[c] * p[c];
+      }
+#pragma unroll
+    for (int c = 0; c < MAXC; c++)
+      if (c < C) {
+        float d = kce * (p[c] - (c == tc ? 1.f : 0.f)) + p[c] * (G[c] - dot);
+        ST<T>::st(dlogits + ((int64_t)n * C + c) * V + v, d);
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------- Dice metric
+// counts[n][c][3] = (|P=c & T=c|, |P=c|, |T=c|) from hard argmax of logits / one-hot (trainer.py:919-945)
+template <typename T>
+__global__ __launch_bounds__(256) void dice_count_kernel(const T* __restrict__ logits, const float* __restrict__ target,
+                                                         int C, int64_t V, unsigned long long* __restrict__ counts) {
+  __shared__ unsigned int red[MAXC * 3];
+  const int n = blockIdx.y;
+  if (threadIdx.x < MAXC * 3) red[threadIdx.x] = 0;
+  __syncthreads();
+  unsigned int loc[MAXC * 3];
+#pragma unroll
+  for (int i = 0; i < MAXC * 3; i++) loc[i] = 0;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < V; v += (int64_t)gridDim.x * 256) {
+    float bl = -INFINITY, bt = -INFINITY;
+    int pc = 0, tc = 0;
+#pragma unroll
+    for (int c = 0; c < MAXC; c++)
+      if (c < C) {
+        float l = ST<T>::ld(logits + ((int64_t)n * C + c) * V + v);
+        float t = target[((int64_t)n * C + c) * V + v];
+        if (l > bl) bl = l, pc = c;
+        if (t > bt) bt = t, tc = c;
+      }
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) {
+      loc[c * 3 + 0] += (pc == c && tc == c);
+      loc[c * 3 + 1] += (pc == c);
+      loc[c * 3 + 2] += (tc == c);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXC * 3; i++) atomicAdd(&red[i], loc[i]);
+  __syncthreads();
+  if (threadIdx.x < C * 3) atomicAdd(counts + (int64_t)n * MAXC * 3 + threadIdx.x, (unsigned long long)red[threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------------- Adam
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, const uint8_t* __restrict__ decay, int64_t n, float lr, float b1,
+                            float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float pi = p[i];
+    float gi = g[i] * gscale + ((decay && decay[i]) ? wd * pi : 0.f);
+    float mi = b1 * m[i] + (1.f - b1) * gi;
+    float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - (lr / bc1) * (mi / denom);
+  }
+}
+}  // namespace
+
+int hdf_loss_blocks() { return LOSS_BLOCKS; }
+size_t hdf_loss_workspace_floats(int N, int nscale) {
+  return (size_t)nscale * N * LOSS_BLOCKS * NSTAT + 2 * (size_t)nscale * N * MAXC + 16;
+}
+
+int hdf_launch_loss_fwd(int dtype, const void* const* logits, const float* target, int nscale, int N, int C, int D,
+                        int H, int W, float* ws, float* loss_out, hipStream_t st) {
+  HDF_CHECK_ARG(C <= MAXC && C >= 2, "loss: n_cls=%d unsupported (2..%d)", C, MAXC);
+  HDF_CHECK_ARG(nscale <= 4 && nscale * N <= 256, "loss: nscale=%d N=%d", nscale, N);
+  float* partials = ws;
+  float* coefA = ws + (size_t)nscale * N * LOSS_BLOCKS * NSTAT;
+  float* coefB = coefA + (size_t)nscale * N * MAXC;
+  LossScales sc;
+  for (int i = 0; i < nscale; i++) {
+    int s = 1 << i;
+    HDF_CHECK_ARG(D % s == 0 && H % s == 0 && W % s == 0, "loss: size not divisible by %d", s);
+    int Ds = D / s, Hs = H / s, Ws = W / s;
+    sc.V[i] = (float)((int64_t)Ds * Hs * Ws);
+    sc.weight[i] = 1.f / (float)s;
+    float* pi = partials + (size_t)i * N * LOSS_BLOCKS * NSTAT;
+    if (dtype == HDF_BF16)
+      hipLaunchKernelGGL(loss_fwd_kernel<bf16_t>, dim3(LOSS_BLOCKS, N), dim3(256), 0, st, (const bf16_t*)logits[i],
+                         target, C, Ds, Hs, Ws, s, D, H, W, pi);
+    else
+      hipLaunchKernelGGL(loss_fwd_kernel<float>, dim3(LOSS_BLOCKS, N), dim3(256), 0, st, (const float*)logits[i],
+                         target, C, Ds, Hs, Ws, s, D, H, W, pi);
+    HDF_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, partials, nscale, N, C, LOSS_BLOCKS, sc, 1e-5f,
+                     loss_out, coefA, coefB);
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
+int hdf_launch_loss_bwd(int dtype, const void* const* logits, const float* target, int nscale, int N, int C, int D,
+                        int H, int W, const float* ws, const float* grad_out, void* const* dlogits, hipStream_t st) {
+  const float* coefA = ws + (size_t)nscale * N * LOSS_BLOCKS * NSTAT;
+  const float* coefB = coefA + (size_t)nscale * N * MAXC;
+  for (int i = 0; i < nscale; i++) {
+    int s = 1 << i;
+    int Ds = D / s, Hs = H / s, Ws = W / s;
+    int64_t V = (int64_t)Ds * Hs * Ws;
+    unsigned gx = (unsigned)std::min<int64_t>(ceil_div64(V, 256), 2048);
+    if (dtype == HDF_BF16)
+      hipLaunchKernelGGL(loss_bwd_kernel<bf16_t>, dim3(gx, N), dim3(256), 0, st, (const bf16_t*)logits[i], target, N, C,
+                         Ds, Hs, Ws, s, D, H, W, coefA + (size_t)i * N * MAXC, coefB + (size_t)i * N * MAXC,
+                         1.f / (float)s, grad_out, (bf16_t*)dlogits[i]);
+    else
+      hipLaunchKernelGGL(loss_bwd_kernel<float>, dim3(gx, N), dim3(256), 0, st, (const float*)logits[i], target, N, C,
+                         Ds, Hs, Ws, s, D, H, W, coefA + (size_t)i * N * MAXC, coefB + (size_t)i * N * MAXC,
+                         1.f / (float)s, grad_out, (float*)dlogits[i]);
+    HDF_LAUNCH_CHECK();
+  }
+  return HDF_OK;
+}
+
+int hdf_launch_dice_counts(int dtype, const void* logits, const float* target, int N, int C, int64_t V,
+                           unsigned long long* counts, hipStream_t st) {
+  HDF_CHECK_ARG(C <= MAXC, "dice: n_cls=%d", C);
+  hipError_t e = hipMemsetAsync(counts, 0, (size_t)N * MAXC * 3 * sizeof(unsigned long long), st);
+  if (e != hipSuccess) {
+    hdf_set_error("dice: memset failed: %s", hipGetErrorString(e));
+    return HDF_ERR_HIP;
+  }
+  unsigned gx = (unsigned)std::min<int64_t>(ceil_div64(V, 256), 1024);
+  if (dtype == HDF_BF16)
+    hipLaunchKernelGGL(dice_count_kernel<bf16_t>, dim3(gx, N), dim3(256), 0, st, (const bf16_t*)logits, target, C, V,
+                       counts);
+  else
+    hipLaunchKernelGGL(dice_count_kernel<float>, dim3(gx, N), dim3(256), 0, st, (const float*)logits, target, C, V,
+                       counts);
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
+int hdf_launch_adam(float* p, const float* g, float* m, float* v, const uint8_t* decay, int64_t n, float lr, float b1,
+                    float b2, float eps, float wd, int step, float gscale, hipStream_t st) {
+  float bc1 = 1.f - powf(b1, (float)step);
+  float bc2s = sqrtf(1.f - powf(b2, (float)step));
+  unsigned gx = (unsigned)std::min<int64_t>(ceil_div64(n, 256), 4096);
+  hipLaunchKernelGGL(adam_kernel, dim3(gx), dim3(256), 0, st, p, g, m, v, decay, n, lr, b1, b2, eps, wd, bc1, bc2s,
+                     gscale);
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}

@@ -1,0 +1,1007 @@
+// Model plan / executor: owns the parameter table (= the reference state_dict, HDenseFormer.py:178-227),
+// the workspace layout and the forward/backward launch sequences of HDenseFormer.forward
+// (HDenseFormer.py:229-255) and its autograd.  Host-side C++; every device buffer is caller-owned.
+#include <algorithm>
+#include <cstdarg>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/hdf.h"
+#include "conv_igemm.h"
+#include "loss.h"
+#include "transformer.h"
+#include "unet_ops.h"
+
+static thread_local char g_err[1024] = "";
+void hdf_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+namespace {
+
+struct ParamInfo {
+  std::string name;
+  std::vector<int64_t> shape;
+  int64_t offset, numel;
+};
+
+struct View {  // channels-last view into the workspace
+  size_t off = 0;
+  int64_t pitch = 0;
+  int C = 0;
+  int lvl = 0;
+};
+
+struct Stats {  // per conv layer InstanceNorm statistics, each [B][C] floats
+  size_t mean = 0, rstd = 0, scale = 0, shift = 0;
+};
+
+struct Conv3 {  // 3x3x3 conv + InstanceNorm (+ReLU)
+  std::string name;
+  int Cin = 0, CinP = 0, Cout = 0, lvl = 0;
+  int64_t w = -1, b = -1, gamma = -1, beta = -1;
+  View y;
+  Stats st;
+  size_t wf = 0, wd = 0;  // packed forward / dgrad weights
+};
+struct ConvT3 {
+  std::string name;
+  int Cin = 0, Cout = 0, lvl_in = 0;
+  int64_t w = -1, b = -1;
+  size_t wf = 0, wd = 0;
+};
+struct Head1 {
+  std::string name;
+  int C = 0, lvl = 0;
+  int64_t w = -1, b = -1;
+};
+
+struct Bump {
+  size_t cur = 0;
+  size_t take(size_t bytes) {
+    size_t o = cur;
+    cur += (bytes + 255) & ~(size_t)255;
+    return o;
+  }
+};
+
+}  // namespace
+
+struct hdf_plan {
+  int M, ncls, nf, D, H, W, td, nb, dtype;
+  int esz;
+  int dims[5][3];
+  int DM, DMF, Ntok;
+  std::vector<ParamInfo> params;
+  std::map<std::string, int64_t> pidx;
+  int64_t total_floats = 0;
+  int64_t mstride = 0;
+  // layers
+  Conv3 deep, up[3], enc[4][2], dec[3][2];  // dec[k]: level k (0..2) right blocks
+  ConvT3 upc[3];                            // upc[k] produces level k from level k+1
+  Head1 head[4];
+  // layout for the current batch
+  int batch = -1;
+  size_t ws_bytes = 0;
+  std::map<std::string, View> bufs;
+  // forward buffers
+  View xin, attnall, attnout, at[3] /*at[k] lives at level k*/, cat[3], pooled[3], x4;
+  size_t pool_idx[3];
+  size_t tf_F, tf_save, tf_scratch, tf_dF;
+  size_t stat_partials, wgrad_ws, inb_partials, inb_k;
+  size_t wgrad_ws_bytes = 0;
+  // backward scratch
+  View gA[4], gY[4], dCat[3], dP[3], dUa[4], dUy[4], dX4, dAttnall;
+  // state carried from forward to backward
+  int training = 0;
+  uint32_t seed = 0;
+
+  int64_t vox(int lvl) const { return (int64_t)dims[lvl][0] * dims[lvl][1] * dims[lvl][2]; }
+  int64_t P(const std::string& n) const {
+    auto it = pidx.find(n);
+    return it == pidx.end() ? -1 : params[it->second].offset;
+  }
+};
+
+namespace {
+
+void add_param(hdf_plan* p, const std::string& name, std::vector<int64_t> shape) {
+  ParamInfo pi;
+  pi.name = name;
+  pi.shape = shape;
+  pi.numel = 1;
+  for (auto s : shape) pi.numel *= s;
+  pi.offset = p->total_floats;
+  p->total_floats += (pi.numel + 15) / 16 * 16;
+  p->pidx[name] = (int64_t)p->params.size();
+  p->params.push_back(pi);
+}
+
+void build_params(hdf_plan* p) {
+  const int nf = p->nf, DM = p->DM;
+  char buf[256];
+  for (int m = 0; m < p->M; m++) {
+    int64_t start = p->total_floats;
+    auto nm = [&](const char* fmt, ...) {
+      va_list ap;
+      va_start(ap, fmt);
+      vsnprintf(buf, sizeof(buf), fmt, ap);
+      va_end(ap);
+      return std::string("attns.") + std::to_string(m) + "." + buf;
+    };
+    add_param(p, nm("position_embeddings"), {1, p->Ntok, DM});
+    add_param(p, nm("patch_embeddings.weight"), {DM, 1, 16, 16, 16});
+    add_param(p, nm("patch_embeddings.bias"), {DM});
+    for (int b = 0; b < p->nb; b++) {
+      for (int l = 0; l < 4; l++) {
+        add_param(p, nm("blocks.%d.0.layers.%d.0.weight", b, l), {32, DM + 32 * l});
+        add_param(p, nm("blocks.%d.0.layers.%d.0.bias", b, l), {32});
+        add_param(p, nm("blocks.%d.0.layers.%d.1.norm.weight", b, l), {32});
+        add_param(p, nm("blocks.%d.0.layers.%d.1.norm.bias", b, l), {32});
+        add_param(p, nm("blocks.%d.0.layers.%d.1.fn.to_qkv.weight", b, l), {96, 32});
+        add_param(p, nm("blocks.%d.0.layers.%d.1.fn.to_out.0.weight", b, l), {32, 32});
+        add_param(p, nm("blocks.%d.0.layers.%d.1.fn.to_out.0.bias", b, l), {32});
+        add_param(p, nm("blocks.%d.0.layers.%d.2.norm.weight", b, l), {32});
+        add_param(p, nm("blocks.%d.0.layers.%d.2.norm.bias", b, l), {32});
+        add_param(p, nm("blocks.%d.0.layers.%d.2.fn.net.0.weight", b, l), {64, 32});
+        add_param(p, nm("blocks.%d.0.layers.%d.2.fn.net.0.bias", b, l), {64});
+        add_param(p, nm("blocks.%d.0.layers.%d.2.fn.net.3.weight", b, l), {32, 64});
+        add_param(p, nm("blocks.%d.0.layers.%d.2.fn.net.3.bias", b, l), {32});
+      }
+      add_param(p, nm("blocks.%d.0.out_layer.net.0.weight", b), {64, DM + 128});
+      add_param(p, nm("blocks.%d.0.out_layer.net.0.bias", b), {64});
+      add_param(p, nm("blocks.%d.0.out_layer.net.3.weight", b), {DM, 64});
+      add_param(p, nm("blocks.%d.0.out_layer.net.3.bias", b), {DM});
+    }
+    if (m == 0) p->mstride = p->total_floats - start;
+  }
+  auto upc = [&](const std::string& n, int ci, int co) {
+    add_param(p, n + ".double_conv.0.weight", {co, ci, 3, 3, 3});
+    add_param(p, n + ".double_conv.0.bias", {co});
+  };
+  auto basic = [&](const std::string& n, int ci, int co) {
+    add_param(p, n + ".conv.weight", {co, ci, 3, 3, 3});
+    add_param(p, n + ".norm.weight", {co});
+    add_param(p, n + ".norm.bias", {co});
+  };
+  auto convt = [&](const std::string& n, int ci, int co) {
+    add_param(p, n + ".weight", {ci, co, 3, 3, 3});
+    add_param(p, n + ".bias", {co});
+  };
+  auto head = [&](const std::string& n, int ci) {
+    add_param(p, n + ".weight", {p->ncls, ci, 1, 1, 1});
+    add_param(p, n + ".bias", {p->ncls});
+  };
+  upc("deep_conv", DM * p->M, 8 * nf);
+  upc("up1", 8 * nf, 4 * nf);
+  upc("up2", 4 * nf, 2 * nf);
+  upc("up3", 2 * nf, nf);
+  basic("block_1_1_left", p->M, nf);
+  basic("block_1_2_left", nf, nf);
+  basic("block_2_1_left", nf, 2 * nf);
+  basic("block_2_2_left", 2 * nf, 2 * nf);
+  basic("block_3_1_left", 2 * nf, 4 * nf);
+  basic("block_3_2_left", 4 * nf, 4 * nf);
+  basic("block_4_1_left", 4 * nf, 8 * nf);
+  basic("block_4_2_left", 8 * nf, 8 * nf);
+  convt("upconv_3", 8 * nf, 4 * nf);
+  basic("block_3_1_right", 8 * nf, 4 * nf);
+  basic("block_3_2_right", 4 * nf, 4 * nf);
+  convt("upconv_2", 4 * nf, 2 * nf);
+  basic("block_2_1_right", 4 * nf, 2 * nf);
+  basic("block_2_2_right", 2 * nf, 2 * nf);
+  convt("upconv_1", 2 * nf, nf);
+  basic("block_1_1_right", 2 * nf, nf);
+  basic("block_1_2_right", nf, nf);
+  head("conv1x1", nf);
+  head("conv1x1_d1", 2 * nf);
+  head("conv1x1_d2", 4 * nf);
+  head("conv1x1_d3", 8 * nf);
+}
+
+void init_conv(hdf_plan* p, Conv3& c, const std::string& name, int cin, int cout, int lvl, bool basic) {
+  c.name = name;
+  c.Cin = cin;
+  c.CinP = round_up(cin, 16);
+  c.Cout = cout;
+  c.lvl = lvl;
+  if (basic) {
+    c.w = p->P(name + ".conv.weight");
+    c.gamma = p->P(name + ".norm.weight");
+    c.beta = p->P(name + ".norm.bias");
+  } else {
+    c.w = p->P(name + ".double_conv.0.weight");
+    c.b = p->P(name + ".double_conv.0.bias");
+  }
+}
+
+void build_layers(hdf_plan* p) {
+  const int nf = p->nf;
+  init_conv(p, p->deep, "deep_conv", p->DM * p->M, 8 * nf, 4, false);
+  init_conv(p, p->up[0], "up1", 8 * nf, 4 * nf, 3, false);
+  init_conv(p, p->up[1], "up2", 4 * nf, 2 * nf, 2, false);
+  init_conv(p, p->up[2], "up3", 2 * nf, nf, 1, false);
+  const int ch[4] = {nf, 2 * nf, 4 * nf, 8 * nf};
+  for (int k = 0; k < 4; k++) {
+    std::string b = "block_" + std::to_string(k + 1);
+    init_conv(p, p->enc[k][0], b + "_1_left", k == 0 ? p->M : ch[k - 1], ch[k], k, true);
+    init_conv(p, p->enc[k][1], b + "_2_left", ch[k], ch[k], k, true);
+    if (k < 3) {
+      init_conv(p, p->dec[k][0], b + "_1_right", 2 * ch[k], ch[k], k, true);
+      init_conv(p, p->dec[k][1], b + "_2_right", ch[k], ch[k], k, true);
+      ConvT3& t = p->upc[k];
+      t.name = "upconv_" + std::to_string(k + 1);
+      t.Cin = ch[k + 1];
+      t.Cout = ch[k];
+      t.lvl_in = k + 1;
+      t.w = p->P(t.name + ".weight");
+      t.b = p->P(t.name + ".bias");
+    }
+  }
+  const char* hn[4] = {"conv1x1", "conv1x1_d1", "conv1x1_d2", "conv1x1_d3"};
+  for (int k = 0; k < 4; k++) {
+    p->head[k].name = hn[k];
+    p->head[k].C = ch[k];
+    p->head[k].lvl = k;
+    p->head[k].w = p->P(std::string(hn[k]) + ".weight");
+    p->head[k].b = p->P(std::string(hn[k]) + ".bias");
+  }
+}
+
+View mkview(hdf_plan* p, Bump& bp, const std::string& name, int lvl, int C, int batch) {
+  View v;
+  v.C = C;
+  v.pitch = C;
+  v.lvl = lvl;
+  v.off = bp.take((size_t)batch * p->vox(lvl) * C * p->esz);
+  if (!name.empty()) p->bufs[name] = v;
+  return v;
+}
+View subview(hdf_plan* p, const View& v, int c0, int C, const std::string& name = "") {
+  View s = v;
+  s.off = v.off + (size_t)c0 * p->esz;
+  s.C = C;
+  if (!name.empty()) p->bufs[name] = s;
+  return s;
+}
+
+void layout(hdf_plan* p, int B) {
+  if (p->batch == B) return;
+  p->batch = B;
+  p->bufs.clear();
+  Bump bp;
+  const int nf = p->nf;
+  const int ch[4] = {nf, 2 * nf, 4 * nf, 8 * nf};
+  auto conv_bufs = [&](Conv3& c) {
+    c.y = mkview(p, bp, "y." + c.name, c.lvl, c.Cout, B);
+    size_t s = (size_t)B * c.Cout * sizeof(float);
+    c.st.mean = bp.take(s);
+    c.st.rstd = bp.take(s);
+    c.st.scale = bp.take(s);
+    c.st.shift = bp.take(s);
+    c.wf = bp.take((size_t)27 * round_up(c.Cout, 32) * c.CinP * p->esz);
+    c.wd = bp.take((size_t)27 * round_up(c.CinP, 32) * round_up(c.Cout, 16) * p->esz);
+  };
+  // ---- forward (persistent until backward)
+  p->xin = mkview(p, bp, "xin", 0, 16, B);
+  const int64_t rows = (int64_t)p->M * B * p->Ntok;
+  p->tf_F = bp.take((size_t)p->nb * rows * p->DMF * sizeof(float));
+  p->tf_save = bp.take((size_t)p->nb * 4 * rows * 232 * sizeof(float));
+  p->attnall = mkview(p, bp, "attnall", 4, p->M * p->DM, B);
+  conv_bufs(p->deep);
+  p->attnout = mkview(p, bp, "attnout", 3, 8 * nf, B);
+  for (int k = 0; k < 3; k++) conv_bufs(p->up[k]);
+  p->at[2] = mkview(p, bp, "at1", 2, 4 * nf, B);
+  p->at[1] = mkview(p, bp, "at2", 1, 2 * nf, B);
+  p->at[0] = mkview(p, bp, "at3", 0, nf, B);
+  for (int k = 0; k < 4; k++) {
+    conv_bufs(p->enc[k][0]);
+    conv_bufs(p->enc[k][1]);
+    if (k < 3) {
+      p->cat[k] = mkview(p, bp, "cat" + std::to_string(k + 1), k, 2 * ch[k], B);
+      subview(p, p->cat[k], ch[k], ch[k], "ds" + std::to_string(k));
+      p->pooled[k] = mkview(p, bp, "pool" + std::to_string(k + 1), k + 1, ch[k], B);
+      p->pool_idx[k] = bp.take((size_t)B * p->vox(k + 1) * ch[k]);
+      conv_bufs(p->dec[k][0]);
+      conv_bufs(p->dec[k][1]);
+      ConvT3& t = p->upc[k];
+      t.wf = bp.take((size_t)27 * round_up(t.Cout, 32) * t.Cin * p->esz);
+      t.wd = bp.take((size_t)27 * round_up(t.Cin, 32) * t.Cout * p->esz);
+    }
+  }
+  p->x4 = mkview(p, bp, "bottleneck", 3, 8 * nf, B);
+  // ---- scratch shared by forward and backward
+  size_t maxtiles = 0;
+  for (int l = 0; l < 5; l++)
+    maxtiles = std::max<size_t>(maxtiles, hdf_conv_stat_tiles(0, p->dims[l][0], p->dims[l][1], p->dims[l][2]));
+  p->stat_partials = bp.take((size_t)B * maxtiles * round_up(8 * nf, 32) * 2 * sizeof(float));
+  // ---- backward scratch
+  p->tf_scratch = bp.take((size_t)rows * std::max(160, p->DM) * sizeof(float));
+  p->tf_dF = bp.take((size_t)rows * p->DMF * sizeof(float));
+  p->wgrad_ws_bytes = (size_t)128 << 20;
+  p->wgrad_ws = bp.take(p->wgrad_ws_bytes);
+  p->inb_partials = bp.take((size_t)B * 256 * 8 * nf * 2 * sizeof(float));
+  p->inb_k = bp.take((size_t)3 * B * 8 * nf * sizeof(float));
+  for (int k = 0; k < 4; k++) {
+    p->gA[k] = mkview(p, bp, "", k, ch[k], B);
+    p->gY[k] = mkview(p, bp, "", k, ch[k], B);
+    if (k < 3) {
+      p->dCat[k] = mkview(p, bp, "", k, 2 * ch[k], B);
+      p->dP[k] = mkview(p, bp, "", k + 1, ch[k], B);
+    }
+  }
+  // UpConv chain: conv outputs live at levels 4,3,2,1 with channels 8nf,4nf,2nf,nf
+  const int uc[4] = {8 * nf, 4 * nf, 2 * nf, nf};
+  for (int k = 0; k < 4; k++) {
+    p->dUa[k] = mkview(p, bp, "", 4 - k, uc[k], B);
+    p->dUy[k] = mkview(p, bp, "", 4 - k, uc[k], B);
+  }
+  p->dX4 = mkview(p, bp, "", 3, 8 * nf, B);
+  p->dAttnall = mkview(p, bp, "", 4, p->M * p->DM, B);
+  p->ws_bytes = bp.cur;
+}
+
+struct Exec {
+  hdf_plan* p;
+  char* ws;
+  const float* params;
+  float* grads;
+  int B;
+  hipStream_t st;
+  void* at(const View& v) const { return ws + v.off; }
+  float* f(size_t off) const { return reinterpret_cast<float*>(ws + off); }
+  const float* P(int64_t off) const { return off < 0 ? nullptr : params + off; }
+  float* G(int64_t off) const { return off < 0 ? nullptr : grads + off; }
+  const int* dm(int lvl) const { return p->dims[lvl]; }
+};
+
+// per-(n,c) input transform of a consumer: the producer's InstanceNorm scale/shift (+ReLU)
+struct Xf {
+  const float* scale = nullptr;
+  const float* shift = nullptr;
+  int relu = 0;
+};
+Xf xf_of(const Exec& e, const Conv3& c) { return Xf{e.f(c.st.scale), e.f(c.st.shift), 1}; }
+
+int conv_forward(Exec& e, Conv3& c, const View& in, Xf xf) {
+  hdf_plan* p = e.p;
+  const int* d = e.dm(c.lvl);
+  const int CoutP = round_up(c.Cout, 32);
+  HDF_TRY(hdf_launch_pack_w(p->dtype, e.P(c.w), e.ws + c.wf, c.Cout, c.Cin, CoutP, c.CinP, (int64_t)c.Cin * 27, 27, 0,
+                            e.st));
+  ConvArgs a{};
+  a.in = e.at(in);
+  a.in_pitch = in.pitch;
+  a.Cin = c.CinP;
+  a.N = e.B;
+  a.Di = a.Do = d[0];
+  a.Hi = a.Ho = d[1];
+  a.Wi = a.Wo = d[2];
+  a.w = e.ws + c.wf;
+  a.bias = e.P(c.b);
+  a.in_scale = xf.scale;
+  a.in_shift = xf.shift;
+  a.in_relu = xf.relu;
+  a.out = e.at(c.y);
+  a.out_pitch = c.y.pitch;
+  a.Cout = c.Cout;
+  a.CoutP = CoutP;
+  a.stat_partials = e.f(p->stat_partials);
+  a.accumulate = 0;
+  HDF_TRY(hdf_launch_conv(p->dtype, 0, a, e.st));
+  int tiles = hdf_conv_stat_tiles(0, d[0], d[1], d[2]);
+  HDF_TRY(hdf_launch_in_finalize(e.f(p->stat_partials), e.B, tiles, c.Cout, CoutP, p->vox(c.lvl), e.P(c.gamma),
+                                 e.P(c.beta), 1e-5f, e.f(c.st.mean), e.f(c.st.rstd), e.f(c.st.scale),
+                                 e.f(c.st.shift), e.st));
+  return HDF_OK;
+}
+
+int convt_forward(Exec& e, ConvT3& t, const View& in, Xf xf, const View& out) {
+  hdf_plan* p = e.p;
+  const int* d = e.dm(t.lvl_in);
+  const int CoutP = round_up(t.Cout, 32);
+  // torch ConvTranspose3d weight [Cin][Cout][27] -> [tap][CoutP][Cin]
+  HDF_TRY(hdf_launch_pack_w(p->dtype, e.P(t.w), e.ws + t.wf, t.Cout, t.Cin, CoutP, t.Cin, 27, (int64_t)t.Cout * 27, 0,
+                            e.st));
+  ConvArgs a{};
+  a.in = e.at(in);
+  a.in_pitch = in.pitch;
+  a.Cin = t.Cin;
+  a.N = e.B;
+  a.Di = d[0], a.Hi = d[1], a.Wi = d[2];
+  a.Do = 2 * d[0], a.Ho = 2 * d[1], a.Wo = 2 * d[2];
+  a.w = e.ws + t.wf;
+  a.bias = e.P(t.b);
+  a.in_scale = xf.scale;
+  a.in_shift = xf.shift;
+  a.in_relu = xf.relu;
+  a.out = e.at(out);
+  a.out_pitch = out.pitch;
+  a.Cout = t.Cout;
+  a.CoutP = CoutP;
+  return hdf_launch_conv(p->dtype, 2, a, e.st);
+}
+
+int head_forward(Exec& e, const Head1& h, const View& in, Xf xf, void* out) {
+  return hdf_launch_head_fwd(e.p->dtype, e.at(in), in.pitch, xf.scale, xf.shift, e.P(h.w), e.P(h.b), out, e.B, h.C,
+                             e.p->ncls, e.p->vox(h.lvl), e.st);
+}
+
+TfDims tf_dims(const hdf_plan* p, int B) {
+  TfDims d;
+  d.M = p->M;
+  d.B = B;
+  d.N = p->Ntok;
+  d.DM = p->DM;
+  d.DMF = p->DMF;
+  d.mstride = p->mstride;
+  d.training = p->training;
+  d.seed = p->seed;
+  d.thresh24 = 1u << 23;  // p = 0.5 (HDenseFormer.py:79,105)
+  d.keep_scale = 2.0f;
+  return d;
+}
+
+void tf_layer_ptrs(const hdf_plan* p, float* base, int b, int l, TfLayerP& q) {
+  std::string pre = "attns.0.blocks." + std::to_string(b) + ".0.layers." + std::to_string(l);
+  q.w0 = base + p->P(pre + ".0.weight");
+  q.b0 = base + p->P(pre + ".0.bias");
+  q.ln1g = base + p->P(pre + ".1.norm.weight");
+  q.ln1b = base + p->P(pre + ".1.norm.bias");
+  q.wqkv = base + p->P(pre + ".1.fn.to_qkv.weight");
+  q.wout = base + p->P(pre + ".1.fn.to_out.0.weight");
+  q.bout = base + p->P(pre + ".1.fn.to_out.0.bias");
+  q.ln2g = base + p->P(pre + ".2.norm.weight");
+  q.ln2b = base + p->P(pre + ".2.norm.bias");
+  q.w1 = base + p->P(pre + ".2.fn.net.0.weight");
+  q.b1 = base + p->P(pre + ".2.fn.net.0.bias");
+  q.w2 = base + p->P(pre + ".2.fn.net.3.weight");
+  q.b2 = base + p->P(pre + ".2.fn.net.3.bias");
+}
+void tf_out_ptrs(const hdf_plan* p, float* base, int b, TfOutP& q) {
+  std::string pre = "attns.0.blocks." + std::to_string(b) + ".0.out_layer.net";
+  q.wa = base + p->P(pre + ".0.weight");
+  q.ba = base + p->P(pre + ".0.bias");
+  q.wb = base + p->P(pre + ".3.weight");
+  q.bb = base + p->P(pre + ".3.bias");
+}
+TfLayerSave tf_save(const hdf_plan* p, const Exec& e, int b, int l) {
+  const int64_t rows = (int64_t)p->M * e.B * p->Ntok;
+  float* base = e.f(p->tf_save) + (int64_t)(b * 4 + l) * rows * 232;
+  TfLayerSave s;
+  s.h0 = base;
+  s.qkv = base + rows * 32;
+  s.ob = base + rows * 128;
+  s.lse = base + rows * 160;
+  s.h1 = base + rows * 168;
+  s.h2 = base + rows * 200;
+  return s;
+}
+
+int transformer_forward(Exec& e, const float* x) {
+  hdf_plan* p = e.p;
+  TfDims d = tf_dims(p, e.B);
+  float* pm = const_cast<float*>(e.params);
+  const int64_t rows = (int64_t)p->M * e.B * p->Ntok;
+  float* F0 = e.f(p->tf_F);
+  HDF_TRY(tf_patch_embed_fwd(d, x, p->D, p->H, p->W, pm + p->P("attns.0.patch_embeddings.weight"),
+                             pm + p->P("attns.0.patch_embeddings.bias"), pm + p->P("attns.0.position_embeddings"), F0,
+                             e.st));
+  for (int b = 0; b < p->nb; b++) {
+    float* F = F0 + (int64_t)b * rows * p->DMF;
+    for (int l = 0; l < 4; l++) {
+      TfLayerP q;
+      tf_layer_ptrs(p, pm, b, l, q);
+      HDF_TRY(tf_layer_fwd(d, b, l, q, F, tf_save(p, e, b, l), e.st));
+    }
+    TfOutP o;
+    tf_out_ptrs(p, pm, b, o);
+    bool last = (b == p->nb - 1);
+    HDF_TRY(tf_block_out_fwd(d, b, o, F, last ? nullptr : F + rows * p->DMF, last ? e.at(p->attnall) : nullptr,
+                             p->dtype, e.st));
+  }
+  return HDF_OK;
+}
+
+int transformer_backward(Exec& e, const float* x) {
+  hdf_plan* p = e.p;
+  TfDims d = tf_dims(p, e.B);
+  float* pm = const_cast<float*>(e.params);
+  const int64_t rows = (int64_t)p->M * e.B * p->Ntok;
+  float* F0 = e.f(p->tf_F);
+  float* dF = e.f(p->tf_dF);
+  float* scratch = e.f(p->tf_scratch);
+  for (int b = p->nb - 1; b >= 0; b--) {
+    float* F = F0 + (int64_t)b * rows * p->DMF;
+    TfOutP o, go;
+    tf_out_ptrs(p, pm, b, o);
+    tf_out_ptrs(p, e.grads, b, go);
+    bool last = (b == p->nb - 1);
+    HDF_TRY(tf_block_out_bwd(d, b, o, go, F, last ? nullptr : dF, last ? e.at(p->dAttnall) : nullptr, p->dtype, dF,
+                             e.st));
+    for (int l = 3; l >= 0; l--) {
+      TfLayerP q, gq;
+      tf_layer_ptrs(p, pm, b, l, q);
+      tf_layer_ptrs(p, e.grads, b, l, gq);
+      HDF_TRY(tf_layer_bwd(d, b, l, q, gq, F, dF, tf_save(p, e, b, l), scratch, e.st));
+    }
+  }
+  HDF_TRY(tf_patch_embed_bwd(d, x, p->D, p->H, p->W, dF, e.grads + p->P("attns.0.patch_embeddings.weight"),
+                             e.grads + p->P("attns.0.patch_embeddings.bias"),
+                             e.grads + p->P("attns.0.position_embeddings"), scratch, e.st));
+  return HDF_OK;
+}
+
+// InstanceNorm(+ReLU) backward of conv layer c: da (grad w.r.t. the activation) -> dy (grad w.r.t. raw conv out)
+int in_backward(Exec& e, const Conv3& c, const View& da, const View& dy) {
+  hdf_plan* p = e.p;
+  const int64_t vox = p->vox(c.lvl);
+  const int blocks = hdf_in_bwd_blocks(vox);
+  float* k = e.f(p->inb_k);
+  float* k1 = k;
+  float* ka = k + (size_t)e.B * c.Cout;
+  float* kb = k + (size_t)2 * e.B * c.Cout;
+  HDF_TRY(hdf_launch_in_bwd_reduce(p->dtype, e.at(da), da.pitch, e.at(c.y), c.y.pitch, e.f(c.st.scale),
+                                   e.f(c.st.shift), e.f(c.st.mean), e.f(c.st.rstd), e.f(p->inb_partials), blocks, e.B,
+                                   c.Cout, vox, e.st));
+  HDF_TRY(hdf_launch_in_bwd_finalize(e.f(p->inb_partials), blocks, e.B, c.Cout, vox, e.P(c.gamma), e.f(c.st.rstd), k1,
+                                     ka, kb, e.G(c.gamma), e.G(c.beta), e.st));
+  HDF_TRY(hdf_launch_in_bwd_apply(p->dtype, e.at(da), da.pitch, e.at(c.y), c.y.pitch, e.f(c.st.scale), e.f(c.st.shift),
+                                  e.f(c.st.mean), e.f(c.st.rstd), k1, ka, kb, e.at(dy), dy.pitch, e.B, c.Cout, vox,
+                                  e.st));
+  return HDF_OK;
+}
+
+// conv backward: weight (and bias) gradient from (dy, input) and optionally the input gradient
+int conv_backward(Exec& e, Conv3& c, const View& dy, const View& in, Xf xf, const View* din, int accumulate) {
+  hdf_plan* p = e.p;
+  const int* d = e.dm(c.lvl);
+  WgradArgs w{};
+  w.sm = e.at(dy);
+  w.sm_pitch = dy.pitch;
+  w.SC = c.Cout;
+  w.lg = e.at(in);
+  w.lg_pitch = in.pitch;
+  w.LC = c.CinP;
+  w.N = e.B;
+  w.Ds = w.Dl = d[0];
+  w.Hs = w.Hl = d[1];
+  w.Ws = w.Wl = d[2];
+  w.lg_scale = xf.scale;
+  w.lg_shift = xf.shift;
+  w.lg_relu = xf.relu;
+  HDF_TRY(hdf_launch_wgrad(p->dtype, 1, w, e.G(c.w), c.Cout, c.Cin, 0, e.ws + p->wgrad_ws, p->wgrad_ws_bytes, e.st));
+  if (c.b >= 0) HDF_TRY(hdf_launch_bias_grad(p->dtype, e.at(dy), dy.pitch, e.G(c.b), c.Cout, (int64_t)e.B * p->vox(c.lvl), e.st));
+  if (din) {
+    // dgrad = the same conv with taps reversed and channel roles swapped: Wd[t][ci][co] = W[co][ci][26-t]
+    const int OP = round_up(c.Cin, 32);
+    HDF_TRY(hdf_launch_pack_w(p->dtype, e.P(c.w), e.ws + c.wd, c.Cin, c.Cout, OP, c.Cout, 27, (int64_t)c.Cin * 27, 1,
+                              e.st));
+    ConvArgs a{};
+    a.in = e.at(dy);
+    a.in_pitch = dy.pitch;
+    a.Cin = c.Cout;
+    a.N = e.B;
+    a.Di = a.Do = d[0];
+    a.Hi = a.Ho = d[1];
+    a.Wi = a.Wo = d[2];
+    a.w = e.ws + c.wd;
+    a.out = e.at(*din);
+    a.out_pitch = din->pitch;
+    a.Cout = c.Cin;
+    a.CoutP = OP;
+    a.accumulate = accumulate;
+    HDF_TRY(hdf_launch_conv(p->dtype, 0, a, e.st));
+  }
+  return HDF_OK;
+}
+
+// ConvTranspose3d backward: dOut (hi-res) -> dIn (lo-res, grad w.r.t. the activation fed to the convT)
+int convt_backward(Exec& e, ConvT3& t, const View& dout, const View& in, Xf xf, const View& din) {
+  hdf_plan* p = e.p;
+  const int* d = e.dm(t.lvl_in);
+  HDF_TRY(hdf_launch_bias_grad(p->dtype, e.at(dout), dout.pitch, e.G(t.b), t.Cout, (int64_t)e.B * p->vox(t.lvl_in - 1),
+                               e.st));
+  WgradArgs w{};
+  w.sm = e.at(in);
+  w.sm_pitch = in.pitch;
+  w.SC = t.Cin;
+  w.lg = e.at(dout);
+  w.lg_pitch = dout.pitch;
+  w.LC = t.Cout;
+  w.N = e.B;
+  w.Ds = d[0], w.Hs = d[1], w.Ws = d[2];
+  w.Dl = 2 * d[0], w.Hl = 2 * d[1], w.Wl = 2 * d[2];
+  w.sm_scale = xf.scale;
+  w.sm_shift = xf.shift;
+  w.sm_relu = xf.relu;
+  HDF_TRY(hdf_launch_wgrad(p->dtype, 2, w, e.G(t.w), t.Cin, t.Cout, 0, e.ws + p->wgrad_ws, p->wgrad_ws_bytes, e.st));
+  // dX[i][ci] = sum_k sum_co dY[2i-1+k][co] * W[ci][co][k]  -> stride-2 gather conv, packed [tap][CinP][Cout]
+  const int OP = round_up(t.Cin, 32);
+  HDF_TRY(hdf_launch_pack_w(p->dtype, e.P(t.w), e.ws + t.wd, t.Cin, t.Cout, OP, t.Cout, (int64_t)t.Cout * 27, 27, 0,
+                            e.st));
+  ConvArgs a{};
+  a.in = e.at(dout);
+  a.in_pitch = dout.pitch;
+  a.Cin = t.Cout;
+  a.N = e.B;
+  a.Di = 2 * d[0], a.Hi = 2 * d[1], a.Wi = 2 * d[2];
+  a.Do = d[0], a.Ho = d[1], a.Wo = d[2];
+  a.w = e.ws + t.wd;
+  a.out = e.at(din);
+  a.out_pitch = din.pitch;
+  a.Cout = t.Cin;
+  a.CoutP = OP;
+  return hdf_launch_conv(p->dtype, 1, a, e.st);
+}
+
+int head_backward(Exec& e, const Head1& h, const void* dlogits, const View& in, Xf xf, const View& dx, int acc) {
+  return hdf_launch_head_bwd(e.p->dtype, dlogits, e.at(in), in.pitch, xf.scale, xf.shift, e.P(h.w), e.at(dx), dx.pitch,
+                             acc, e.G(h.w), e.G(h.b), e.B, h.C, e.p->ncls, e.p->vox(h.lvl), e.st);
+}
+
+}  // namespace
+
+// ================================================================================================ C ABI
+extern "C" {
+
+const char* hdf_version(void) { return "hdf-hip 0.1 (gfx950)"; }
+const char* hdf_last_error(void) { return g_err; }
+
+int hdf_plan_create(int in_channels, int n_cls, int n_filters, int D, int H, int W, int transformer_depth, int dtype,
+                    hdf_plan** out) {
+  HDF_CHECK_ARG(out != nullptr, "plan_create: null out");
+  HDF_CHECK_ARG(in_channels >= 1 && in_channels <= 8, "plan_create: in_channels=%d unsupported (1..8)", in_channels);
+  HDF_CHECK_ARG(n_cls >= 2 && n_cls <= 8, "plan_create: n_cls=%d unsupported (2..8)", n_cls);
+  HDF_CHECK_ARG(n_filters >= 16 && n_filters % 16 == 0 && n_filters <= 64,
+                "plan_create: n_filters=%d unsupported (multiple of 16, 16..64)", n_filters);
+  HDF_CHECK_ARG(D % 16 == 0 && H % 16 == 0 && W % 16 == 0 && D >= 32 && H >= 32 && W >= 32,
+                "plan_create: image_size (%d,%d,%d) must be multiples of 16 and >= 32", D, H, W);
+  HDF_CHECK_ARG(transformer_depth >= 4, "plan_create: transformer_depth=%d < 4", transformer_depth);
+  HDF_CHECK_ARG(dtype == HDF_F32 || dtype == HDF_BF16, "plan_create: dtype %d", dtype);
+  hdf_plan* p = new hdf_plan();
+  p->M = in_channels;
+  p->ncls = n_cls;
+  p->nf = n_filters;
+  p->D = D, p->H = H, p->W = W;
+  p->td = transformer_depth;
+  p->nb = transformer_depth / 4;
+  p->dtype = dtype;
+  p->esz = dtype == HDF_BF16 ? 2 : 4;
+  for (int l = 0; l < 5; l++) p->dims[l][0] = D >> l, p->dims[l][1] = H >> l, p->dims[l][2] = W >> l;
+  p->DM = 4 * n_filters;
+  p->DMF = p->DM + 128;
+  p->Ntok = (D / 16) * (H / 16) * (W / 16);
+  build_params(p);
+  build_layers(p);
+  *out = p;
+  return HDF_OK;
+}
+
+void hdf_plan_destroy(hdf_plan* p) { delete p; }
+int64_t hdf_plan_num_params(const hdf_plan* p) { return (int64_t)p->params.size(); }
+int64_t hdf_plan_param_floats(const hdf_plan* p) { return p->total_floats; }
+
+int hdf_plan_param_info(const hdf_plan* p, int64_t idx, char* name, int name_cap, int64_t* offset, int64_t* numel,
+                        int* ndim, int64_t* shape5) {
+  HDF_CHECK_ARG(idx >= 0 && idx < (int64_t)p->params.size(), "param_info: index %lld", (long long)idx);
+  const ParamInfo& pi = p->params[idx];
+  if (name && name_cap > 0) {
+    strncpy(name, pi.name.c_str(), name_cap - 1);
+    name[name_cap - 1] = 0;
+  }
+  if (offset) *offset = pi.offset;
+  if (numel) *numel = pi.numel;
+  if (ndim) *ndim = (int)pi.shape.size();
+  if (shape5)
+    for (size_t i = 0; i < 5; i++) shape5[i] = i < pi.shape.size() ? pi.shape[i] : 1;
+  return HDF_OK;
+}
+
+int64_t hdf_plan_workspace_bytes(hdf_plan* p, int batch) {
+  layout(p, batch);
+  return (int64_t)p->ws_bytes;
+}
+
+int hdf_plan_buffer_info(hdf_plan* p, int batch, const char* name, int64_t* byte_offset, int64_t* pitch_elems,
+                         int* channels, int* d, int* h, int* w) {
+  layout(p, batch);
+  auto it = p->bufs.find(name);
+  HDF_CHECK_ARG(it != p->bufs.end(), "buffer_info: no buffer named '%s'", name);
+  const View& v = it->second;
+  *byte_offset = (int64_t)v.off;
+  *pitch_elems = v.pitch;
+  *channels = v.C;
+  *d = p->dims[v.lvl][0];
+  *h = p->dims[v.lvl][1];
+  *w = p->dims[v.lvl][2];
+  return HDF_OK;
+}
+
+int hdf_forward(hdf_plan* p, const float* x, const float* params, void* workspace, int64_t workspace_bytes, void* out0,
+                void* out1, void* out2, void* out3, int batch, int training, uint64_t seed, hdf_stream stream) {
+  HDF_CHECK_ARG(p && x && params && workspace, "forward: null argument");
+  layout(p, batch);
+  HDF_CHECK_ARG((size_t)workspace_bytes >= p->ws_bytes, "forward: workspace %lld < %zu bytes", (long long)workspace_bytes,
+                p->ws_bytes);
+  p->training = training ? 1 : 0;
+  p->seed = (uint32_t)(seed & 0xffffffffu);
+  Exec e{p, (char*)workspace, params, nullptr, batch, (hipStream_t)stream};
+  const int nf = p->nf;
+  const int ch[4] = {nf, 2 * nf, 4 * nf, 8 * nf};
+  void* outs[4] = {out0, out1, out2, out3};
+  Xf none;
+
+  // ---- multi-path transformer (HDenseFormer.py:230) -> attnall, then the UpConv chain (:231-235)
+  HDF_TRY(transformer_forward(e, x));
+  HDF_TRY(conv_forward(e, p->deep, p->attnall, none));
+  HDF_TRY(hdf_launch_upsample_fwd(p->dtype, e.at(p->deep.y), p->deep.y.pitch, e.f(p->deep.st.scale),
+                                  e.f(p->deep.st.shift), e.at(p->attnout), p->attnout.pitch, batch, 8 * nf,
+                                  p->dims[4][0], p->dims[4][1], p->dims[4][2], e.st));
+  {
+    const View* src = &p->attnout;
+    for (int k = 0; k < 3; k++) {  // up1 -> at1 (lvl 2), up2 -> at2 (lvl 1), up3 -> at3 (lvl 0)
+      Conv3& c = p->up[k];
+      HDF_TRY(conv_forward(e, c, *src, none));
+      const View& dst = p->at[2 - k];
+      HDF_TRY(hdf_launch_upsample_fwd(p->dtype, e.at(c.y), c.y.pitch, e.f(c.st.scale), e.f(c.st.shift), e.at(dst),
+                                      dst.pitch, batch, c.Cout, p->dims[c.lvl][0], p->dims[c.lvl][1],
+                                      p->dims[c.lvl][2], e.st));
+      src = &dst;
+    }
+  }
+  // ---- encoder (:237-244)
+  HDF_TRY(hdf_launch_nchw_to_ndhwc(p->dtype, x, e.at(p->xin), batch, p->M, 16, p->vox(0), e.st));
+  const View* cur = &p->xin;
+  for (int k = 0; k < 4; k++) {
+    HDF_TRY(conv_forward(e, p->enc[k][0], *cur, none));
+    HDF_TRY(conv_forward(e, p->enc[k][1], p->enc[k][0].y, xf_of(e, p->enc[k][0])));
+    Conv3& c = p->enc[k][1];
+    if (k < 3) {
+      View ds = subview(p, p->cat[k], ch[k], ch[k]);
+      HDF_TRY(hdf_launch_norm_relu_add(p->dtype, e.at(c.y), c.y.pitch, e.f(c.st.scale), e.f(c.st.shift),
+                                       e.at(p->at[k]), p->at[k].pitch, e.at(ds), ds.pitch, batch, ch[k], p->vox(k),
+                                       e.st));
+      HDF_TRY(hdf_launch_maxpool_fwd(p->dtype, e.at(ds), ds.pitch, e.at(p->pooled[k]), p->pooled[k].pitch,
+                                     (uint8_t*)(e.ws + p->pool_idx[k]), batch, ch[k], p->dims[k + 1][0],
+                                     p->dims[k + 1][1], p->dims[k + 1][2], e.st));
+      cur = &p->pooled[k];
+    } else {
+      HDF_TRY(hdf_launch_norm_relu_add(p->dtype, e.at(c.y), c.y.pitch, e.f(c.st.scale), e.f(c.st.shift),
+                                       e.at(p->attnout), p->attnout.pitch, e.at(p->x4), p->x4.pitch, batch, ch[3],
+                                       p->vox(3), e.st));
+    }
+  }
+  // ---- decoder (:246-253)
+  HDF_TRY(head_forward(e, p->head[3], p->x4, none, outs[3]));
+  const View* dec_in = &p->x4;
+  Xf dec_xf = none;
+  for (int k = 2; k >= 0; k--) {
+    View up_out = subview(p, p->cat[k], 0, ch[k]);
+    HDF_TRY(convt_forward(e, p->upc[k], *dec_in, dec_xf, up_out));
+    HDF_TRY(conv_forward(e, p->dec[k][0], p->cat[k], none));
+    HDF_TRY(conv_forward(e, p->dec[k][1], p->dec[k][0].y, xf_of(e, p->dec[k][0])));
+    dec_in = &p->dec[k][1].y;
+    dec_xf = xf_of(e, p->dec[k][1]);
+    HDF_TRY(head_forward(e, p->head[k], *dec_in, dec_xf, outs[k]));
+  }
+  return HDF_OK;
+}
+
+int hdf_backward(hdf_plan* p, const float* x, const float* params, void* workspace, int64_t workspace_bytes,
+                 const void* dout0, const void* dout1, const void* dout2, const void* dout3, float* grads, int batch,
+                 hdf_stream stream) {
+  return hdf_backward_stages(p, x, params, workspace, workspace_bytes, dout0, dout1, dout2, dout3, grads, batch, 3,
+                             stream);
+}
+
+int hdf_backward_stages(hdf_plan* p, const float* x, const float* params, void* workspace, int64_t workspace_bytes,
+                        const void* dout0, const void* dout1, const void* dout2, const void* dout3, float* grads,
+                        int batch, int stages, hdf_stream stream) {
+  HDF_CHECK_ARG(p && x && params && workspace && grads, "backward: null argument");
+  HDF_CHECK_ARG(p->batch == batch, "backward: batch %d differs from the forward's %d", batch, p->batch);
+  HDF_CHECK_ARG((size_t)workspace_bytes >= p->ws_bytes, "backward: workspace too small");
+  Exec e{p, (char*)workspace, params, grads, batch, (hipStream_t)stream};
+  const int nf = p->nf;
+  const int ch[4] = {nf, 2 * nf, 4 * nf, 8 * nf};
+  const void* douts[4] = {dout0, dout1, dout2, dout3};
+  Xf none;
+  if (stages & 1) {
+  hipError_t me = hipMemsetAsync(grads, 0, (size_t)p->total_floats * sizeof(float), e.st);
+  if (me != hipSuccess) {
+    hdf_set_error("backward: memset failed: %s", hipGetErrorString(me));
+    return HDF_ERR_HIP;
+  }
+
+  // ---- decoder, top (level 0) down to level 2
+  for (int k = 0; k <= 2; k++) {
+    Conv3 &c1 = p->dec[k][0], &c2 = p->dec[k][1];
+    // gA[k] holds d/d(activation of c2): head gradient (+ convT input gradient from the level above, k>0)
+    HDF_TRY(head_backward(e, p->head[k], douts[k], c2.y, xf_of(e, c2), p->gA[k], k > 0 ? 1 : 0));
+    HDF_TRY(in_backward(e, c2, p->gA[k], p->gY[k]));
+    HDF_TRY(conv_backward(e, c2, p->gY[k], c1.y, xf_of(e, c1), &p->gA[k], 0));
+    HDF_TRY(in_backward(e, c1, p->gA[k], p->gY[k]));
+    HDF_TRY(conv_backward(e, c1, p->gY[k], p->cat[k], none, &p->dCat[k], 0));
+    // upconv_{k+1}: input is dec[k+1][1] activation (k<2) or the bottleneck x4 (k==2)
+    View dup = subview(p, p->dCat[k], 0, ch[k]);
+    if (k < 2)
+      HDF_TRY(convt_backward(e, p->upc[k], dup, p->dec[k + 1][1].y, xf_of(e, p->dec[k + 1][1]), p->gA[k + 1]));
+    else
+      HDF_TRY(convt_backward(e, p->upc[k], dup, p->x4, none, p->dX4));
+  }
+  HDF_TRY(head_backward(e, p->head[3], douts[3], p->x4, none, p->dX4, 1));
+
+  // ---- encoder, bottom (level 3) up to level 0.  dskip: gradient of ds_k (= of the transformer feature at_k too)
+  for (int k = 3; k >= 0; k--) {
+    Conv3 &c1 = p->enc[k][0], &c2 = p->enc[k][1];
+    View dskip = (k == 3) ? p->dX4 : subview(p, p->dCat[k], ch[k], ch[k]);
+    if (k < 3) {
+      // ds_k also feeds pool_{k+1}
+      HDF_TRY(hdf_launch_maxpool_bwd(p->dtype, e.at(p->dP[k]), p->dP[k].pitch, (const uint8_t*)(e.ws + p->pool_idx[k]),
+                                     e.at(dskip), dskip.pitch, batch, ch[k], p->dims[k + 1][0], p->dims[k + 1][1],
+                                     p->dims[k + 1][2], 1, e.st));
+    }
+    HDF_TRY(in_backward(e, c2, dskip, p->gY[k]));
+    HDF_TRY(conv_backward(e, c2, p->gY[k], c1.y, xf_of(e, c1), &p->gA[k], 0));
+    HDF_TRY(in_backward(e, c1, p->gA[k], p->gY[k]));
+    if (k > 0)
+      HDF_TRY(conv_backward(e, c1, p->gY[k], p->pooled[k - 1], none, &p->dP[k - 1], 0));
+    else
+      HDF_TRY(conv_backward(e, c1, p->gY[k], p->xin, none, nullptr, 0));
+  }
+
+  }  // stage 1: every gradient of the encoder / decoder / head parameters is final here
+  if (!(stages & 2)) return HDF_OK;
+
+  // ---- UpConv chain: at3 <- up3 <- at2 <- up2 <- at1 <- up1 <- attnout <- deep_conv <- attnall
+  for (int k = 2; k >= 0; k--) {
+    Conv3& c = p->up[k];                                   // up[k] output level c.lvl, upsampled to level c.lvl-1
+    View dat = subview(p, p->dCat[c.lvl - 1], ch[c.lvl - 1], ch[c.lvl - 1]);  // gradient of at_{..} == of ds
+    const int* d = p->dims[c.lvl];
+    View& da = p->dUa[4 - c.lvl];
+    View& dy = p->dUy[4 - c.lvl];
+    HDF_TRY(hdf_launch_upsample_bwd(p->dtype, e.at(dat), dat.pitch, e.at(da), da.pitch, batch, c.Cout, d[0], d[1], d[2],
+                                    e.st));
+    HDF_TRY(in_backward(e, c, da, dy));
+    // input of up[k]: attnout (k==0) or at_{lvl} ; its gradient buffer already holds the skip-path gradient
+    const View& cin = (k == 0) ? p->attnout : p->at[c.lvl];
+    View din = (k == 0) ? p->dX4 : subview(p, p->dCat[c.lvl], ch[c.lvl], ch[c.lvl]);
+    HDF_TRY(conv_backward(e, c, dy, cin, none, &din, 1));
+  }
+  {
+    Conv3& c = p->deep;
+    const int* d = p->dims[4];
+    HDF_TRY(hdf_launch_upsample_bwd(p->dtype, e.at(p->dX4), p->dX4.pitch, e.at(p->dUa[0]), p->dUa[0].pitch, batch,
+                                    c.Cout, d[0], d[1], d[2], e.st));
+    HDF_TRY(in_backward(e, c, p->dUa[0], p->dUy[0]));
+    HDF_TRY(conv_backward(e, c, p->dUy[0], p->attnall, none, &p->dAttnall, 0));
+  }
+  HDF_TRY(transformer_backward(e, x));
+  return HDF_OK;
+}
+
+// ---------------------------------------------------------------------------------------- loss / metric / adam
+int64_t hdf_loss_workspace_bytes(int batch) { return (int64_t)hdf_loss_workspace_floats(batch, 4) * sizeof(float); }
+
+int hdf_loss_forward(int dtype, const void* out0, const void* out1, const void* out2, const void* out3, int nscale,
+                     const float* target_onehot, int batch, int n_cls, int D, int H, int W, void* workspace,
+                     float* loss_out, hdf_stream stream) {
+  const void* outs[4] = {out0, out1, out2, out3};
+  return hdf_launch_loss_fwd(dtype, outs, target_onehot, nscale, batch, n_cls, D, H, W, (float*)workspace, loss_out,
+                             (hipStream_t)stream);
+}
+int hdf_loss_backward(int dtype, const void* out0, const void* out1, const void* out2, const void* out3, int nscale,
+                      const float* target_onehot, int batch, int n_cls, int D, int H, int W, const void* workspace,
+                      const float* grad_out, void* dout0, void* dout1, void* dout2, void* dout3, hdf_stream stream) {
+  const void* outs[4] = {out0, out1, out2, out3};
+  void* douts[4] = {dout0, dout1, dout2, dout3};
+  return hdf_launch_loss_bwd(dtype, outs, target_onehot, nscale, batch, n_cls, D, H, W, (const float*)workspace,
+                             grad_out, douts, (hipStream_t)stream);
+}
+int hdf_dice_counts(int dtype, const void* logits, const float* target_onehot, int batch, int n_cls, int64_t voxels,
+                    uint64_t* counts, hdf_stream stream) {
+  return hdf_launch_dice_counts(dtype, logits, target_onehot, batch, n_cls, voxels, (unsigned long long*)counts,
+                                (hipStream_t)stream);
+}
+int hdf_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* decay_mask,
+                  int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                  float grad_scale, hdf_stream stream) {
+  HDF_CHECK_ARG(step >= 1, "adam: step=%d must start at 1", step);
+  return hdf_launch_adam(params, grads, exp_avg, exp_avg_sq, decay_mask, n, lr, beta1, beta2, eps, weight_decay, step,
+                         grad_scale, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------- operator level
+int hdf_op_to_channels_last(int dtype, const float* x, void* out, int N, int C, int CP, int64_t voxels,
+                            hdf_stream stream) {
+  return hdf_launch_nchw_to_ndhwc(dtype, x, out, N, C, CP, voxels, (hipStream_t)stream);
+}
+int hdf_op_pack_weights(int dtype, const float* src, void* dst, int O, int I, int OP, int IP, int64_t so, int64_t si,
+                        int flip, hdf_stream stream) {
+  return hdf_launch_pack_w(dtype, src, dst, O, I, OP, IP, so, si, flip, (hipStream_t)stream);
+}
+int hdf_op_conv3d(int dtype, int mode, const void* in, int64_t in_pitch, int Cin, int N, int Di, int Hi, int Wi,
+                  const void* w_packed, const float* bias, const float* in_scale, const float* in_shift, int in_relu,
+                  void* out, int64_t out_pitch, int Cout, float* stat_partials, int accumulate, hdf_stream stream) {
+  ConvArgs a{};
+  a.in = in;
+  a.in_pitch = in_pitch;
+  a.Cin = Cin;
+  a.N = N;
+  a.Di = Di, a.Hi = Hi, a.Wi = Wi;
+  if (mode == 0)
+    a.Do = Di, a.Ho = Hi, a.Wo = Wi;
+  else if (mode == 1)
+    a.Do = Di / 2, a.Ho = Hi / 2, a.Wo = Wi / 2;
+  else
+    a.Do = 2 * Di, a.Ho = 2 * Hi, a.Wo = 2 * Wi;
+  a.w = w_packed;
+  a.bias = bias;
+  a.in_scale = in_scale;
+  a.in_shift = in_shift;
+  a.in_relu = in_relu;
+  a.out = out;
+  a.out_pitch = out_pitch;
+  a.Cout = Cout;
+  a.CoutP = round_up(Cout, 32);
+  a.stat_partials = stat_partials;
+  a.accumulate = accumulate;
+  return hdf_launch_conv(dtype, mode, a, (hipStream_t)stream);
+}
+int hdf_op_conv3d_stat_tiles(int Do, int Ho, int Wo) { return hdf_conv_stat_tiles(0, Do, Ho, Wo); }
+int64_t hdf_op_wgrad_workspace_bytes(int stride, int N, int Ds, int Hs, int Ws, int SC, int LC) {
+  return (int64_t)hdf_wgrad_workspace_bytes(stride, N, Ds, Hs, Ws, SC, LC);
+}
+int hdf_op_conv3d_wgrad(int dtype, int stride, const void* sm, int64_t sm_pitch, int SC, const void* lg,
+                        int64_t lg_pitch, int LC, int N, int Ds, int Hs, int Ws, const float* sm_scale,
+                        const float* sm_shift, int sm_relu, const float* lg_scale, const float* lg_shift, int lg_relu,
+                        float* dw, int sc_store, int lc_store, int accumulate, void* workspace, int64_t workspace_bytes,
+                        hdf_stream stream) {
+  WgradArgs w{};
+  w.sm = sm, w.sm_pitch = sm_pitch, w.SC = SC;
+  w.lg = lg, w.lg_pitch = lg_pitch, w.LC = LC;
+  w.N = N;
+  w.Ds = Ds, w.Hs = Hs, w.Ws = Ws;
+  w.Dl = stride * Ds, w.Hl = stride * Hs, w.Wl = stride * Ws;
+  w.sm_scale = sm_scale, w.sm_shift = sm_shift, w.sm_relu = sm_relu;
+  w.lg_scale = lg_scale, w.lg_shift = lg_shift, w.lg_relu = lg_relu;
+  return hdf_launch_wgrad(dtype, stride, w, dw, sc_store, lc_store, accumulate, workspace, (size_t)workspace_bytes,
+                          (hipStream_t)stream);
+}
+int hdf_op_in_finalize(const float* partials, int N, int tiles, int C, int CP, int64_t voxels, const float* gamma,
+                       const float* beta, float eps, float* mean, float* rstd, float* scale, float* shift,
+                       hdf_stream stream) {
+  return hdf_launch_in_finalize(partials, N, tiles, C, CP, voxels, gamma, beta, eps, mean, rstd, scale, shift,
+                                (hipStream_t)stream);
+}
+int hdf_op_norm_relu_add(int dtype, const void* y, int64_t y_pitch, const float* scale, const float* shift,
+                         const void* skip, int64_t skip_pitch, void* out, int64_t out_pitch, int N, int C,
+                         int64_t voxels, hdf_stream stream) {
+  return hdf_launch_norm_relu_add(dtype, y, y_pitch, scale, shift, skip, skip_pitch, out, out_pitch, N, C, voxels,
+                                  (hipStream_t)stream);
+}
+int hdf_op_maxpool_fwd(int dtype, const void* in, int64_t in_pitch, void* out, int64_t out_pitch, uint8_t* idx, int N,
+                       int C, int Do, int Ho, int Wo, hdf_stream stream) {
+  return hdf_launch_maxpool_fwd(dtype, in, in_pitch, out, out_pitch, idx, N, C, Do, Ho, Wo, (hipStream_t)stream);
+}
+int hdf_op_maxpool_bwd(int dtype, const void* dout, int64_t dout_pitch, const uint8_t* idx, void* din,
+                       int64_t din_pitch, int N, int C, int Do, int Ho, int Wo, int accumulate, hdf_stream stream) {
+  return hdf_launch_maxpool_bwd(dtype, dout, dout_pitch, idx, din, din_pitch, N, C, Do, Ho, Wo, accumulate,
+                                (hipStream_t)stream);
+}
+int hdf_op_upsample_fwd(int dtype, const void* y, int64_t y_pitch, const float* scale, const float* shift, void* out,
+                        int64_t out_pitch, int N, int C, int Di, int Hi, int Wi, hdf_stream stream) {
+  return hdf_launch_upsample_fwd(dtype, y, y_pitch, scale, shift, out, out_pitch, N, C, Di, Hi, Wi,
+                                 (hipStream_t)stream);
+}
+int hdf_op_upsample_bwd(int dtype, const void* dout, int64_t dout_pitch, void* din, int64_t din_pitch, int N, int C,
+                        int Di, int Hi, int Wi, hdf_stream stream) {
+  return hdf_launch_upsample_bwd(dtype, dout, dout_pitch, din, din_pitch, N, C, Di, Hi, Wi, (hipStream_t)stream);
+}
+
+}  // extern "C"

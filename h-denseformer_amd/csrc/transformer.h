@@ -1,0 +1,56 @@
+// Multi-path densely-connected Transformer branch (HDenseFormer.py:33-145), fp32 arithmetic.
+// Row order of every token buffer: row = (m*B + b)*N + n  (modality outermost, so one workgroup only
+// ever touches one modality's weights).  Per-modality parameters are addressed as base + m*mstride
+// (the branches have identical structure, so their parameter blocks are equally spaced in the flat
+// parameter buffer).
+#pragma once
+#include "hdf_common.h"
+
+struct TfDims {
+  int M;    // modalities (= in_channels)
+  int B;    // batch
+  int N;    // tokens per sample
+  int DM;   // token dim = 4*n_filters
+  int DMF;  // DM + 128: width of the dense feature buffer
+  int64_t mstride;  // floats between the parameter blocks of consecutive modalities
+  // dropout
+  int training;
+  uint32_t seed;
+  uint32_t thresh24;  // round((1-p)*2^24)
+  float keep_scale;   // 1/(1-p)
+};
+
+struct TfLayerP {  // pointers into modality 0's block (parameters or, for backward, gradients)
+  float *w0, *b0, *ln1g, *ln1b, *wqkv, *wout, *bout, *ln2g, *ln2b, *w1, *b1, *w2, *b2;
+};
+struct TfOutP {
+  float *wa, *ba, *wb, *bb;
+};
+
+// saved per layer (forward -> backward): all [rows][..] fp32
+struct TfLayerSave {
+  float* h0;   // [rows][32]
+  float* qkv;  // [rows][96]
+  float* ob;   // [rows][32] attention output before to_out
+  float* lse;  // [rows][8]
+  float* h1;   // [rows][32]
+  float* h2;   // [rows][32]
+};
+
+int tf_patch_embed_fwd(const TfDims& d, const float* x /*[B][M][D][H][W]*/, int D, int H, int W, const float* wpe,
+                       const float* bpe, const float* pos, float* F /*[rows][DMF]*/, hipStream_t st);
+int tf_patch_embed_bwd(const TfDims& d, const float* x, int D, int H, int W, const float* dF /*[rows][DMF]*/,
+                       float* dwpe, float* dbpe, float* dpos, float* scratch /*[rows][DM]*/, hipStream_t st);
+
+int tf_layer_fwd(const TfDims& d, int block, int layer, const TfLayerP& p, float* F, const TfLayerSave& s,
+                 hipStream_t st);
+int tf_layer_bwd(const TfDims& d, int block, int layer, const TfLayerP& p, const TfLayerP& g, const float* F, float* dF,
+                 const TfLayerSave& s, float* scratch /*[rows][32+32+96]*/, hipStream_t st);
+
+// out_layer of a block.  next_F != null: write fp32 into next block's feature buffer columns [0,DM);
+// else write storage-typed rows into the channels-last attnall buffer [B][N][M*DM].
+int tf_block_out_fwd(const TfDims& d, int block, const TfOutP& p, const float* F, float* next_F, void* attnall,
+                     int dtype, hipStream_t st);
+// dout comes from dF_next[rows][0:DM] (fp32, pitch DMF) or from d_attnall (storage type).  Writes dF[rows][0:DMF].
+int tf_block_out_bwd(const TfDims& d, int block, const TfOutP& p, const TfOutP& g, const float* F,
+                     const float* dF_next, const void* d_attnall, int dtype, float* dF, hipStream_t st);

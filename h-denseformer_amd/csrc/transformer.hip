@@ -1,0 +1,773 @@
+// Multi-path densely-connected Transformer branch: forward and backward kernels (fp32).
+//
+// Reference: models/HDenseFormer.py:33-145.  Per dense layer l of block b (DensePreConv_AttentionBlock
+// .forward, :91-101):   h0 = Linear(cat(features));  h1 = attn(LN1(h0)) + h0;  h2 = ff(LN2(h1)) + h1;
+// feature = ff(LN2(h2))  (second evaluation of the same ff, :98).  The feature concat is never
+// materialised: every block owns a dense buffer F[rows][DM+128] whose column ranges ARE the features.
+//
+// Work decomposition: token-parallel kernels give one token to each 32-lane half-wave (the layer
+// width is 32 = growth_rate), 32 tokens per workgroup; attention is a flash-style pass with K,V of
+// one (sample, modality, head) in LDS (N x 4 floats each), 4 lanes per query, no N x N tensor in
+// HBM; backward recomputes the probabilities from the saved log-sum-exp.  Parameter gradients are
+// reduced per workgroup through LDS outer products and then added with fp32 atomics.  The patch
+// embedding (a 4096-deep contraction) and its weight gradient run on v_mfma_f32_32x32x2_f32.
+#include "transformer.h"
+
+namespace {
+
+constexpr int TB = 32;  // tokens per workgroup
+
+__device__ __forceinline__ float hsum32(float v) {  // sum over the 32 lanes of a half-wave
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad(float x) {
+  return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+__device__ __forceinline__ float dot_row(const float* __restrict__ w, const float* sv, int K) {
+  float acc = 0.f;
+  for (int k = 0; k < K; k += 4) {
+    float4 a = *reinterpret_cast<const float4*>(w + k);
+    float4 b = *reinterpret_cast<const float4*>(sv + k);
+    acc += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+  }
+  return acc;
+}
+// sum_o W[o*ld + col] * sv[o]
+__device__ __forceinline__ float dot_col(const float* __restrict__ w, int ld, int col, const float* sv, int O) {
+  float acc = 0.f;
+  for (int o = 0; o < O; o++) acc += w[(int64_t)o * ld + col] * sv[o];
+  return acc;
+}
+struct Drop {
+  int training;
+  uint32_t seed, thresh;
+  float scale;
+  __device__ __forceinline__ float mask(uint32_t site, uint32_t idx) const {
+    if (!training) return 1.f;
+    return hdf_keep(hdf_site_key(seed, site), idx, thresh) ? scale : 0.f;
+  }
+};
+__device__ __forceinline__ Drop make_drop(const TfDims& d) { return Drop{d.training, d.seed, d.thresh24, d.keep_scale}; }
+
+// gW[o*K + k] += sum_t sA[t*lda + o] * sB[t*ldb + k]   (t < TB; padded tokens hold zeros)
+__device__ __forceinline__ void outer_acc(float* __restrict__ gW, int O, int K, const float* sA, int lda,
+                                          const float* sB, int ldb) {
+  for (int idx = threadIdx.x; idx < O * K; idx += 256) {
+    int o = idx / K, k = idx - o * K;
+    float s = 0.f;
+#pragma unroll 8
+    for (int t = 0; t < TB; t++) s += sA[t * lda + o] * sB[t * ldb + k];
+    atomicAdd(gW + idx, s);
+  }
+}
+// gb[o] += sum_t sA[t*lda + o]
+__device__ __forceinline__ void col_acc(float* __restrict__ gb, int O, const float* sA, int lda) {
+  for (int o = threadIdx.x; o < O; o += 256) {
+    float s = 0.f;
+    for (int t = 0; t < TB; t++) s += sA[t * lda + o];
+    atomicAdd(gb + o, s);
+  }
+}
+
+#define TOK_LOOP(j, tl, t, ok, R)                       \
+  _Pragma("unroll") for (int j = 0; j < 4; j++)         \
+    if (int tl = (threadIdx.x >> 5) + 8 * j; true)      \
+      if (int t = blockIdx.x * TB + tl; true)           \
+        if (bool ok = t < BN; true)                     \
+          if (int64_t R = (int64_t)m * BN + (ok ? t : 0); true)
+
+// ------------------------------------------------------------------------------ K1: Linear0 + LN1 + QKV
+__global__ __launch_bounds__(256) void dense_pre_fwd_kernel(TfDims d, int K, TfLayerP p, const float* __restrict__ F,
+                                                            float* __restrict__ h0, float* __restrict__ qkv) {
+  extern __shared__ float sm[];
+  float* s_in = sm;            // [TB][K]
+  float* s_t = sm + TB * K;    // [TB][32]
+  const int m = blockIdx.y, BN = d.B * d.N, o = threadIdx.x & 31;
+  const int64_t mo = (int64_t)m * d.mstride;
+  for (int i = threadIdx.x; i < TB * K; i += 256) {
+    int tl = i / K, k = i - tl * K, t = blockIdx.x * TB + tl;
+    s_in[i] = (t < BN) ? F[((int64_t)m * BN + t) * d.DMF + k] : 0.f;
+  }
+  __syncthreads();
+  TOK_LOOP(j, tl, t, ok, R) {
+    float h = p.b0[mo + o] + dot_row(p.w0 + mo + (int64_t)o * K, s_in + tl * K, K);
+    float mean = hsum32(h) * (1.f / 32.f);
+    float dd = h - mean;
+    float rstd = rsqrtf(hsum32(dd * dd) * (1.f / 32.f) + 1e-5f);
+    s_t[tl * 32 + o] = dd * rstd * p.ln1g[mo + o] + p.ln1b[mo + o];
+    if (ok) h0[R * 32 + o] = h;
+  }
+  __syncthreads();
+  TOK_LOOP(j, tl, t, ok, R) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      int jj = o + 32 * c;
+      float q = dot_row(p.wqkv + mo + jj * 32, s_t + tl * 32, 32);
+      if (ok) qkv[R * 96 + jj] = q;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------ K2: attention
+// grid (ceil(N/64), 8 heads, M*B).  4 lanes per query, keys interleaved over the 4 lanes.
+__global__ __launch_bounds__(256) void attn_fwd_kernel(int N, const float* __restrict__ qkv, float* __restrict__ ob,
+                                                       float* __restrict__ lse) {
+  extern __shared__ float4 skv[];
+  float4* sK = skv;
+  float4* sV = skv + N;
+  const int head = blockIdx.y;
+  const int64_t rowbase = (int64_t)blockIdx.z * N;
+  for (int i = threadIdx.x; i < N; i += 256) {
+    const float* r = qkv + (rowbase + i) * 96;
+    sK[i] = *reinterpret_cast<const float4*>(r + 32 + head * 4);
+    sV[i] = *reinterpret_cast<const float4*>(r + 64 + head * 4);
+  }
+  __syncthreads();
+  const int qi = blockIdx.x * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
+  const bool ok = qi < N;
+  float4 q = ok ? *reinterpret_cast<const float4*>(qkv + (rowbase + qi) * 96 + head * 4) : make_float4(0, 0, 0, 0);
+  q.x *= 0.5f, q.y *= 0.5f, q.z *= 0.5f, q.w *= 0.5f;  // dim_head^-0.5 with dim_head = 4
+  float mx = -INFINITY, l = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  for (int j = sub; j < N; j += 4) {
+    float4 k = sK[j], v = sV[j];
+    float s = q.x * k.x + q.y * k.y + q.z * k.z + q.w * k.w;
+    float mn = fmaxf(mx, s);
+    float c = __expf(mx - mn), pr = __expf(s - mn);
+    l = l * c + pr;
+    a0 = a0 * c + pr * v.x, a1 = a1 * c + pr * v.y, a2 = a2 * c + pr * v.z, a3 = a3 * c + pr * v.w;
+    mx = mn;
+  }
+#pragma unroll
+  for (int off = 1; off <= 2; off <<= 1) {
+    float m2 = __shfl_xor(mx, off, 64), l2 = __shfl_xor(l, off, 64);
+    float b0 = __shfl_xor(a0, off, 64), b1 = __shfl_xor(a1, off, 64), b2 = __shfl_xor(a2, off, 64),
+          b3 = __shfl_xor(a3, off, 64);
+    float mn = fmaxf(mx, m2);
+    float ca = __expf(mx - mn), cb = __expf(m2 - mn);
+    l = l * ca + l2 * cb;
+    a0 = a0 * ca + b0 * cb, a1 = a1 * ca + b1 * cb, a2 = a2 * ca + b2 * cb, a3 = a3 * ca + b3 * cb;
+    mx = mn;
+  }
+  if (ok && sub == 0) {
+    float inv = 1.f / l;
+    *reinterpret_cast<float4*>(ob + (rowbase + qi) * 32 + head * 4) = make_float4(a0 * inv, a1 * inv, a2 * inv, a3 * inv);
+    lse[(rowbase + qi) * 8 + head] = mx + __logf(l);
+  }
+}
+
+// dQ: same decomposition as forward
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(int N, const float* __restrict__ qkv,
+                                                          const float* __restrict__ ob, const float* __restrict__ lse,
+                                                          const float* __restrict__ dO, float* __restrict__ dqkv) {
+  extern __shared__ float4 skv[];
+  float4* sK = skv;
+  float4* sV = skv + N;
+  const int head = blockIdx.y;
+  const int64_t rowbase = (int64_t)blockIdx.z * N;
+  for (int i = threadIdx.x; i < N; i += 256) {
+    const float* r = qkv + (rowbase + i) * 96;
+    sK[i] = *reinterpret_cast<const float4*>(r + 32 + head * 4);
+    sV[i] = *reinterpret_cast<const float4*>(r + 64 + head * 4);
+  }
+  __syncthreads();
+  const int qi = blockIdx.x * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
+  const bool ok = qi < N;
+  const int64_t R = rowbase + (ok ? qi : 0);
+  float4 q = *reinterpret_cast<const float4*>(qkv + R * 96 + head * 4);
+  q.x *= 0.5f, q.y *= 0.5f, q.z *= 0.5f, q.w *= 0.5f;
+  float4 go = *reinterpret_cast<const float4*>(dO + R * 32 + head * 4);
+  float4 oo = *reinterpret_cast<const float4*>(ob + R * 32 + head * 4);
+  const float delta = go.x * oo.x + go.y * oo.y + go.z * oo.z + go.w * oo.w;
+  const float ls = lse[R * 8 + head];
+  float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+  for (int j = sub; j < N; j += 4) {
+    float4 k = sK[j], v = sV[j];
+    float s = q.x * k.x + q.y * k.y + q.z * k.z + q.w * k.w;
+    float pr = __expf(s - ls);
+    float ds = pr * (go.x * v.x + go.y * v.y + go.z * v.z + go.w * v.w - delta);
+    d0 += ds * k.x, d1 += ds * k.y, d2 += ds * k.z, d3 += ds * k.w;
+  }
+#pragma unroll
+  for (int off = 1; off <= 2; off <<= 1) {
+    d0 += __shfl_xor(d0, off, 64), d1 += __shfl_xor(d1, off, 64), d2 += __shfl_xor(d2, off, 64),
+        d3 += __shfl_xor(d3, off, 64);
+  }
+  if (ok && sub == 0)
+    *reinterpret_cast<float4*>(dqkv + R * 96 + head * 4) = make_float4(0.5f * d0, 0.5f * d1, 0.5f * d2, 0.5f * d3);
+}
+
+// dK, dV: 4 lanes per key, queries interleaved over the 4 lanes
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(int N, const float* __restrict__ qkv,
+                                                           const float* __restrict__ ob, const float* __restrict__ lse,
+                                                           const float* __restrict__ dO, float* __restrict__ dqkv) {
+  extern __shared__ float4 skv[];
+  float4* sQ = skv;        // pre-scaled by 0.5
+  float4* sG = skv + N;    // dO
+  float2* sL = reinterpret_cast<float2*>(skv + 2 * N);  // (lse, delta)
+  const int head = blockIdx.y;
+  const int64_t rowbase = (int64_t)blockIdx.z * N;
+  for (int i = threadIdx.x; i < N; i += 256) {
+    float4 q = *reinterpret_cast<const float4*>(qkv + (rowbase + i) * 96 + head * 4);
+    q.x *= 0.5f, q.y *= 0.5f, q.z *= 0.5f, q.w *= 0.5f;
+    float4 go = *reinterpret_cast<const float4*>(dO + (rowbase + i) * 32 + head * 4);
+    float4 oo = *reinterpret_cast<const float4*>(ob + (rowbase + i) * 32 + head * 4);
+    sQ[i] = q;
+    sG[i] = go;
+    sL[i] = make_float2(lse[(rowbase + i) * 8 + head], go.x * oo.x + go.y * oo.y + go.z * oo.z + go.w * oo.w);
+  }
+  __syncthreads();
+  const int kj = blockIdx.x * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
+  const bool ok = kj < N;
+  const int64_t R = rowbase + (ok ? kj : 0);
+  const float4 k = *reinterpret_cast<const float4*>(qkv + R * 96 + 32 + head * 4);
+  const float4 v = *reinterpret_cast<const float4*>(qkv + R * 96 + 64 + head * 4);
+  float k0 = 0.f, k1 = 0.f, k2 = 0.f, k3 = 0.f, v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+  for (int i = sub; i < N; i += 4) {
+    float4 q = sQ[i], go = sG[i];
+    float2 ld = sL[i];
+    float pr = __expf(q.x * k.x + q.y * k.y + q.z * k.z + q.w * k.w - ld.x);
+    v0 += pr * go.x, v1 += pr * go.y, v2 += pr * go.z, v3 += pr * go.w;
+    float ds = pr * (go.x * v.x + go.y * v.y + go.z * v.z + go.w * v.w - ld.y);
+    k0 += ds * q.x, k1 += ds * q.y, k2 += ds * q.z, k3 += ds * q.w;
+  }
+#pragma unroll
+  for (int off = 1; off <= 2; off <<= 1) {
+    k0 += __shfl_xor(k0, off, 64), k1 += __shfl_xor(k1, off, 64), k2 += __shfl_xor(k2, off, 64),
+        k3 += __shfl_xor(k3, off, 64);
+    v0 += __shfl_xor(v0, off, 64), v1 += __shfl_xor(v1, off, 64), v2 += __shfl_xor(v2, off, 64),
+        v3 += __shfl_xor(v3, off, 64);
+  }
+  if (ok && sub == 0) {
+    *reinterpret_cast<float4*>(dqkv + R * 96 + 32 + head * 4) = make_float4(k0, k1, k2, k3);
+    *reinterpret_cast<float4*>(dqkv + R * 96 + 64 + head * 4) = make_float4(v0, v1, v2, v3);
+  }
+}
+
+// ------------------------------------------------------------------------------ K3: to_out + residual + ff + ff
+__global__ __launch_bounds__(256) void dense_post_fwd_kernel(TfDims d, int block, int layer, TfLayerP p,
+                                                             const float* __restrict__ h0, const float* __restrict__ ob,
+                                                             float* __restrict__ h1s, float* __restrict__ h2s,
+                                                             float* __restrict__ F) {
+  __shared__ float s_a[TB][32], s_u[TB][32], s_f[TB][64];
+  const int m = blockIdx.y, BN = d.B * d.N, o = threadIdx.x & 31;
+  const int64_t mo = (int64_t)m * d.mstride;
+  const Drop dr = make_drop(d);
+  const uint32_t site0 = hdf_site_id(m, block, layer, 0);
+  float h1r[4], hcur[4];
+  TOK_LOOP(j, tl, t, ok, R) { s_a[tl][o] = ok ? ob[R * 32 + o] : 0.f; }
+  __syncthreads();
+  TOK_LOOP(j, tl, t, ok, R) {
+    float a = p.bout[mo + o] + dot_row(p.wout + mo + o * 32, s_a[tl], 32);
+    a *= dr.mask(site0 + 0, (uint32_t)t * 32 + o);
+    float h1 = a + (ok ? h0[R * 32 + o] : 0.f);
+    h1r[j] = h1;
+    hcur[j] = h1;
+    if (ok) h1s[R * 32 + o] = h1;
+  }
+  for (int pass = 0; pass < 2; pass++) {  // pass 0: h2 = ff(LN2(h1)) + h1 ; pass 1: feature = ff(LN2(h2))
+    TOK_LOOP(j, tl, t, ok, R) {
+      float mean = hsum32(hcur[j]) * (1.f / 32.f);
+      float dd = hcur[j] - mean;
+      float rstd = rsqrtf(hsum32(dd * dd) * (1.f / 32.f) + 1e-5f);
+      s_u[tl][o] = dd * rstd * p.ln2g[mo + o] + p.ln2b[mo + o];
+    }
+    __syncthreads();
+    TOK_LOOP(j, tl, t, ok, R) {
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        int jj = o + 32 * c;
+        float z = p.b1[mo + jj] + dot_row(p.w1 + mo + jj * 32, s_u[tl], 32);
+        s_f[tl][jj] = gelu_f(z) * dr.mask(site0 + 1 + 2 * pass, (uint32_t)t * 64 + jj);
+      }
+    }
+    __syncthreads();
+    TOK_LOOP(j, tl, t, ok, R) {
+      float g = p.b2[mo + o] + dot_row(p.w2 + mo + o * 64, s_f[tl], 64);
+      g *= dr.mask(site0 + 2 + 2 * pass, (uint32_t)t * 32 + o);
+      if (pass == 0) {
+        hcur[j] = g + h1r[j];
+        if (ok) h2s[R * 32 + o] = hcur[j];
+      } else if (ok) {
+        F[R * d.DMF + d.DM + 32 * layer + o] = g;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// backward of K3.  Inputs: dfeat = dF[:, DM+32l .. +32], saved h1,h2,ob.  Outputs: dO (grad of attention
+// output before to_out), dh0acc (= dh1, the residual path into h0), parameter gradients.
+__global__ __launch_bounds__(256) void dense_post_bwd_kernel(TfDims d, int block, int layer, TfLayerP p, TfLayerP g,
+                                                             const float* __restrict__ h1s,
+                                                             const float* __restrict__ h2s,
+                                                             const float* __restrict__ ob, const float* __restrict__ dF,
+                                                             float* __restrict__ dO, float* __restrict__ dh0acc) {
+  __shared__ float s_u[TB][32], s_f[TB][64], s_dz[TB][64], s_dg[TB][32], s_red[8][32][2];
+  const int m = blockIdx.y, BN = d.B * d.N, o = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int64_t mo = (int64_t)m * d.mstride;
+  const Drop dr = make_drop(d);
+  const uint32_t site0 = hdf_site_id(m, block, layer, 0);
+  float dcur[4];   // gradient flowing into the current ff's output (post-dropout side)
+  float dres[4];   // gradient of the residual input accumulated so far
+  float gam = 0.f, bet = 0.f;  // LN2 gamma/beta gradient partials of this thread's channel
+  TOK_LOOP(j, tl, t, ok, R) {
+    dcur[j] = ok ? dF[R * d.DMF + d.DM + 32 * layer + o] : 0.f;
+    dres[j] = 0.f;
+  }
+  for (int pass = 1; pass >= 0; pass--) {  // pass 1: second ff on h2 ; pass 0: first ff on h1
+    const float* hs = pass ? h2s : h1s;
+    float xh[4], rs[4], zz[4][2], mk[4][2];
+    TOK_LOOP(j, tl, t, ok, R) {
+      float h = ok ? hs[R * 32 + o] : 0.f;
+      float mean = hsum32(h) * (1.f / 32.f);
+      float dd = h - mean;
+      rs[j] = rsqrtf(hsum32(dd * dd) * (1.f / 32.f) + 1e-5f);
+      xh[j] = dd * rs[j];
+      s_u[tl][o] = xh[j] * p.ln2g[mo + o] + p.ln2b[mo + o];
+      s_dg[tl][o] = ok ? dcur[j] * dr.mask(site0 + 2 + 2 * pass, (uint32_t)t * 32 + o) : 0.f;
+    }
+    __syncthreads();
+    TOK_LOOP(j, tl, t, ok, R) {
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        int jj = o + 32 * c;
+        float z = p.b1[mo + jj] + dot_row(p.w1 + mo + jj * 32, s_u[tl], 32);
+        float mkv = dr.mask(site0 + 1 + 2 * pass, (uint32_t)t * 64 + jj);
+        zz[j][c] = z;
+        mk[j][c] = mkv;
+        s_f[tl][jj] = ok ? gelu_f(z) * mkv : 0.f;
+        float df = dot_col(p.w2 + mo, 64, jj, s_dg[tl], 32);
+        s_dz[tl][jj] = ok ? df * mkv * gelu_grad(z) : 0.f;
+      }
+    }
+    __syncthreads();
+    outer_acc(g.w2 + mo, 32, 64, &s_dg[0][0], 32, &s_f[0][0], 64);
+    col_acc(g.b2 + mo, 32, &s_dg[0][0], 32);
+    outer_acc(g.w1 + mo, 64, 32, &s_dz[0][0], 64, &s_u[0][0], 32);
+    col_acc(g.b1 + mo, 64, &s_dz[0][0], 64);
+    TOK_LOOP(j, tl, t, ok, R) {
+      float du = dot_col(p.w1 + mo, 32, o, s_dz[tl], 64);
+      gam += du * xh[j];
+      bet += du;
+      float dxh = du * p.ln2g[mo + o];
+      float m1 = hsum32(dxh) * (1.f / 32.f), m2 = hsum32(dxh * xh[j]) * (1.f / 32.f);
+      float dh = rs[j] * (dxh - m1 - xh[j] * m2);
+      if (pass == 1) {
+        dcur[j] = ok ? dh : 0.f;   // h2 feeds only the second ff; its gradient flows into ff#1's output
+        dres[j] = dcur[j];         // ... and into the residual h1
+      } else {
+        dres[j] += ok ? dh : 0.f;  // dh1 = dh2 + LN2-bwd path of ff#1
+      }
+    }
+    __syncthreads();
+  }
+  // LN2 gamma/beta: reduce over the 8 token groups, one atomic per channel
+  s_red[grp][o][0] = gam;
+  s_red[grp][o][1] = bet;
+  __syncthreads();
+  if (grp == 0) {
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < 8; k++) a += s_red[k][o][0], b += s_red[k][o][1];
+    atomicAdd(g.ln2g + mo + o, a);
+    atomicAdd(g.ln2b + mo + o, b);
+  }
+  // to_out: a = (Wout.ob + bout) * mask ; h1 = a + h0
+  TOK_LOOP(j, tl, t, ok, R) {
+    s_dg[tl][o] = ok ? dres[j] * dr.mask(site0 + 0, (uint32_t)t * 32 + o) : 0.f;
+    s_u[tl][o] = ok ? ob[R * 32 + o] : 0.f;
+    if (ok) dh0acc[R * 32 + o] = dres[j];
+  }
+  __syncthreads();
+  outer_acc(g.wout + mo, 32, 32, &s_dg[0][0], 32, &s_u[0][0], 32);
+  col_acc(g.bout + mo, 32, &s_dg[0][0], 32);
+  TOK_LOOP(j, tl, t, ok, R) {
+    float v = dot_col(p.wout + mo, 32, o, s_dg[tl], 32);
+    if (ok) dO[R * 32 + o] = v;
+  }
+}
+
+// backward of K1.  dF[:, 0:K] += W0^T dh0
+__global__ __launch_bounds__(256) void dense_pre_bwd_kernel(TfDims d, int K, TfLayerP p, TfLayerP g,
+                                                            const float* __restrict__ F, const float* __restrict__ h0,
+                                                            const float* __restrict__ dqkv,
+                                                            const float* __restrict__ dh0acc, float* __restrict__ dF) {
+  extern __shared__ float sm[];
+  float* s_in = sm;                 // [TB][K]
+  float* s_t = s_in + TB * K;       // [TB][32]
+  float* s_dq = s_t + TB * 32;      // [TB][96]
+  float* s_dh = s_dq + TB * 96;     // [TB][32]
+  float* s_red = s_dh + TB * 32;    // [8][32][2]
+  const int m = blockIdx.y, BN = d.B * d.N, o = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int64_t mo = (int64_t)m * d.mstride;
+  float xh[4], rs[4];
+  for (int i = threadIdx.x; i < TB * K; i += 256) {
+    int tl = i / K, k = i - tl * K, t = blockIdx.x * TB + tl;
+    s_in[i] = (t < BN) ? F[((int64_t)m * BN + t) * d.DMF + k] : 0.f;
+  }
+  TOK_LOOP(j, tl, t, ok, R) {
+    float h = ok ? h0[R * 32 + o] : 0.f;
+    float mean = hsum32(h) * (1.f / 32.f);
+    float dd = h - mean;
+    rs[j] = rsqrtf(hsum32(dd * dd) * (1.f / 32.f) + 1e-5f);
+    xh[j] = dd * rs[j];
+    s_t[tl * 32 + o] = ok ? xh[j] * p.ln1g[mo + o] + p.ln1b[mo + o] : 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) s_dq[tl * 96 + o + 32 * c] = ok ? dqkv[R * 96 + o + 32 * c] : 0.f;
+  }
+  __syncthreads();
+  outer_acc(g.wqkv + mo, 96, 32, s_dq, 96, s_t, 32);
+  float gam = 0.f, bet = 0.f;
+  TOK_LOOP(j, tl, t, ok, R) {
+    float dt = dot_col(p.wqkv + mo, 32, o, s_dq + tl * 96, 96);
+    gam += dt * xh[j];
+    bet += dt;
+    float dxh = dt * p.ln1g[mo + o];
+    float m1 = hsum32(dxh) * (1.f / 32.f), m2 = hsum32(dxh * xh[j]) * (1.f / 32.f);
+    float dh = rs[j] * (dxh - m1 - xh[j] * m2) + (ok ? dh0acc[R * 32 + o] : 0.f);
+    s_dh[tl * 32 + o] = ok ? dh : 0.f;
+  }
+  s_red[(grp * 32 + o) * 2 + 0] = gam;
+  s_red[(grp * 32 + o) * 2 + 1] = bet;
+  __syncthreads();
+  if (grp == 0) {
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < 8; k++) a += s_red[(k * 32 + o) * 2], b += s_red[(k * 32 + o) * 2 + 1];
+    atomicAdd(g.ln1g + mo + o, a);
+    atomicAdd(g.ln1b + mo + o, b);
+  }
+  outer_acc(g.w0 + mo, 32, K, s_dh, 32, s_in, K);
+  col_acc(g.b0 + mo, 32, s_dh, 32);
+  for (int i = threadIdx.x; i < TB * K; i += 256) {
+    int tl = i / K, k = i - tl * K, t = blockIdx.x * TB + tl;
+    if (t < BN) {
+      float v = dot_col(p.w0 + mo, K, k, s_dh + tl * 32, 32);
+      dF[((int64_t)m * BN + t) * d.DMF + k] += v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------ K4: block out_layer
+template <typename T>
+__global__ __launch_bounds__(256) void block_out_fwd_kernel(TfDims d, int block, TfOutP p, const float* __restrict__ F,
+                                                            float* __restrict__ next_F, T* __restrict__ attnall) {
+  extern __shared__ float sm[];
+  const int K = d.DMF;
+  float* s_in = sm;           // [TB][K]
+  float* s_f = sm + TB * K;   // [TB][64]
+  const int m = blockIdx.y, BN = d.B * d.N, o = threadIdx.x & 31;
+  const int64_t mo = (int64_t)m * d.mstride;
+  const Drop dr = make_drop(d);
+  const uint32_t site0 = hdf_site_id(m, block, 4, 0);
+  for (int i = threadIdx.x; i < TB * K; i += 256) {
+    int tl = i / K, k = i - tl * K, t = blockIdx.x * TB + tl;
+    s_in[i] = (t < BN) ? F[((int64_t)m * BN + t) * d.DMF + k] : 0.f;
+  }
+  __syncthreads();
+  TOK_LOOP(j, tl, t, ok, R) {
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      int jj = o + 32 * c;
+      float z = p.ba[mo + jj] + dot_row(p.wa + mo + (int64_t)jj * K, s_in + tl * K, K);
+      s_f[tl * 64 + jj] = gelu_f(z) * dr.mask(site0 + 0, (uint32_t)t * 64 + jj);
+    }
+  }
+  __syncthreads();
+  TOK_LOOP(j, tl, t, ok, R) {
+    for (int c = o; c < d.DM; c += 32) {
+      float v = p.bb[mo + c] + dot_row(p.wb + mo + c * 64, s_f + tl * 64, 64);
+      v *= dr.mask(site0 + 1, (uint32_t)t * d.DM + c);
+      if (ok) {
+        if (next_F)
+          next_F[R * d.DMF + c] = v;
+        else {
+          int b = t / d.N, n = t - b * d.N;
+          ST<T>::st(attnall + ((int64_t)b * d.N + n) * ((int64_t)d.M * d.DM) + (int64_t)m * d.DM + c, v);
+        }
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void block_out_bwd_kernel(TfDims d, int block, TfOutP p, TfOutP g,
+                                                            const float* __restrict__ F,
+                                                            const float* __restrict__ dF_next,
+                                                            const T* __restrict__ d_attnall, float* __restrict__ dF) {
+  extern __shared__ float sm[];
+  const int K = d.DMF, DM = d.DM;
+  float* s_in = sm;                // [TB][K]
+  float* s_f = s_in + TB * K;      // [TB][64]
+  float* s_dz = s_f + TB * 64;     // [TB][64]
+  float* s_do = s_dz + TB * 64;    // [TB][DM]
+  const int m = blockIdx.y, BN = d.B * d.N, o = threadIdx.x & 31;
+  const int64_t mo = (int64_t)m * d.mstride;
+  const Drop dr = make_drop(d);
+  const uint32_t site0 = hdf_site_id(m, block, 4, 0);
+  for (int i = threadIdx.x; i < TB * K; i += 256) {
+    int tl = i / K, k = i - tl * K, t = blockIdx.x * TB + tl;
+    s_in[i] = (t < BN) ? F[((int64_t)m * BN + t) * d.DMF + k] : 0.f;
+  }
+  for (int i = threadIdx.x; i < TB * DM; i += 256) {
+    int tl = i / DM, c = i - tl * DM, t = blockIdx.x * TB + tl;
+    float v = 0.f;
+    if (t < BN) {
+      if (dF_next)
+        v = dF_next[((int64_t)m * BN + t) * d.DMF + c];
+      else {
+        int b = t / d.N, n = t - b * d.N;
+        v = ST<T>::ld(d_attnall + ((int64_t)b * d.N + n) * ((int64_t)d.M * DM) + (int64_t)m * DM + c);
+      }
+      v *= dr.mask(site0 + 1, (uint32_t)t * DM + c);
+    }
+    s_do[i] = v;
+  }
+  __syncthreads();
+  float zz[4][2], mk[4][2];
+  TOK_LOOP(j, tl, t, ok, R) {
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      int jj = o + 32 * c;
+      float z = p.ba[mo + jj] + dot_row(p.wa + mo + (int64_t)jj * K, s_in + tl * K, K);
+      zz[j][c] = z;
+      mk[j][c] = dr.mask(site0 + 0, (uint32_t)t * 64 + jj);
+      s_f[tl * 64 + jj] = ok ? gelu_f(z) * mk[j][c] : 0.f;
+      float df = dot_col(p.wb + mo, 64, jj, s_do + tl * DM, DM);
+      s_dz[tl * 64 + jj] = ok ? df * mk[j][c] * gelu_grad(z) : 0.f;
+    }
+  }
+  __syncthreads();
+  outer_acc(g.wb + mo, DM, 64, s_do, DM, s_f, 64);
+  col_acc(g.bb + mo, DM, s_do, DM);
+  outer_acc(g.wa + mo, 64, K, s_dz, 64, s_in, K);
+  col_acc(g.ba + mo, 64, s_dz, 64);
+  for (int i = threadIdx.x; i < TB * K; i += 256) {
+    int tl = i / K, k = i - tl * K, t = blockIdx.x * TB + tl;
+    if (t < BN) dF[((int64_t)m * BN + t) * d.DMF + k] = dot_col(p.wa + mo, K, k, s_dz + tl * 64, 64);
+  }
+}
+
+// ------------------------------------------------------------------------------ patch embedding (MFMA f32)
+// tokens[32] x DM tile per workgroup, K = 4096 in chunks of 64 (4 rows of 16 voxels of the 16^3 brick)
+__global__ __launch_bounds__(256) void patch_embed_fwd_kernel(TfDims d, const float* __restrict__ x, int D, int H,
+                                                              int W, const float* __restrict__ wpe,
+                                                              const float* __restrict__ bpe,
+                                                              const float* __restrict__ pos, float* __restrict__ F) {
+  extern __shared__ float sm[];
+  constexpr int KC = 64, LD = KC + 1;
+  float* sA = sm;             // [32][LD]
+  float* sB = sm + 32 * LD;   // [DM][LD]
+  const int m = blockIdx.y, BN = d.B * d.N, DM = d.DM;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int gh = H / 16, gw = W / 16;
+  const float* wm = wpe + (int64_t)m * d.mstride;
+  f32x16 acc[2];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[a][i] = 0.f;
+  for (int kc = 0; kc < 4096; kc += KC) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * KC; i += 256) {
+      int tl = i >> 6, kk = i & 63, t = blockIdx.x * 32 + tl;
+      float v = 0.f;
+      if (t < BN) {
+        int b = t / d.N, n = t - b * d.N;
+        int gz = n / (gh * gw), gy = (n / gw) % gh, gx = n % gw;
+        int k = kc + kk, dz = k >> 8, dy = (k >> 4) & 15, dx = k & 15;
+        v = x[((((int64_t)b * d.M + m) * D + gz * 16 + dz) * H + gy * 16 + dy) * W + gx * 16 + dx];
+      }
+      sA[tl * LD + kk] = v;
+    }
+    for (int i = threadIdx.x; i < DM * KC; i += 256) {
+      int c = i >> 6, kk = i & 63;
+      sB[c * LD + kk] = wm[(int64_t)c * 4096 + kc + kk];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+      int nb = wave + 4 * a;
+      if (nb * 32 < DM) {
+        for (int k2 = 0; k2 < KC / 2; k2++) {
+          float av = sA[r * LD + 2 * k2 + h];
+          float bv = sB[(nb * 32 + r) * LD + 2 * k2 + h];
+          acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a], 0, 0, 0);
+        }
+      }
+    }
+  }
+  const Drop dr = make_drop(d);
+  const uint32_t site = hdf_site_id(m, 63, 7, 7);
+#pragma unroll
+  for (int a = 0; a < 2; a++) {
+    int nb = wave + 4 * a;
+    if (nb * 32 < DM) {
+      int c = nb * 32 + r;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        int tl = (i & 3) + 8 * (i >> 2) + 4 * h, t = blockIdx.x * 32 + tl;
+        if (t < BN) {
+          int n = t % d.N;
+          float v = acc[a][i] + bpe[(int64_t)m * d.mstride + c] + pos[(int64_t)m * d.mstride + (int64_t)n * DM + c];
+          v *= dr.mask(site, (uint32_t)t * DM + c);
+          F[((int64_t)m * BN + t) * d.DMF + c] = v;
+        }
+      }
+    }
+  }
+}
+
+// masked token gradient + dpos + dbias
+__global__ void patch_embed_bwd_prep_kernel(TfDims d, const float* __restrict__ dF, float* __restrict__ dtok,
+                                            float* __restrict__ dbpe, float* __restrict__ dpos) {
+  const int m = blockIdx.y, DM = d.DM, BN = d.B * d.N;
+  const Drop dr = make_drop(d);
+  const uint32_t site = hdf_site_id(m, 63, 7, 7);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.N * DM; i += gridDim.x * blockDim.x) {
+    int n = i / DM, c = i - n * DM;
+    float s = 0.f;
+    for (int b = 0; b < d.B; b++) {
+      int t = b * d.N + n;
+      float v = dF[((int64_t)m * BN + t) * d.DMF + c] * dr.mask(site, (uint32_t)t * DM + c);
+      dtok[((int64_t)m * BN + t) * DM + c] = v;
+      s += v;
+    }
+    dpos[(int64_t)m * d.mstride + i] += s;
+    atomicAdd(dbpe + (int64_t)m * d.mstride + c, s);
+  }
+}
+
+// dW[c][k] = sum_t dtok[t][c] * patch[t][k].  grid (4096/128, ceil(DM/32), M); wave w owns k columns w*32..+32
+__global__ __launch_bounds__(256) void patch_embed_wgrad_kernel(TfDims d, const float* __restrict__ x, int D, int H,
+                                                                int W, const float* __restrict__ dtok,
+                                                                float* __restrict__ dwpe) {
+  constexpr int TT = 32, LDD = 33, LDP = 129;
+  __shared__ float sD[TT * LDD], sP[TT * LDP];
+  const int m = blockIdx.z, BN = d.B * d.N, DM = d.DM;
+  const int cb = blockIdx.y * 32, kb = blockIdx.x * 128;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int gh = H / 16, gw = W / 16;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; i++) acc[i] = 0.f;
+  for (int t0 = 0; t0 < BN; t0 += TT) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < TT * 32; i += 256) {
+      int tl = i >> 5, c = i & 31, t = t0 + tl;
+      sD[tl * LDD + c] = (t < BN && cb + c < DM) ? dtok[((int64_t)m * BN + t) * DM + cb + c] : 0.f;
+    }
+    for (int i = threadIdx.x; i < TT * 128; i += 256) {
+      int tl = i >> 7, kk = i & 127, t = t0 + tl;
+      float v = 0.f;
+      if (t < BN) {
+        int b = t / d.N, n = t - b * d.N;
+        int gz = n / (gh * gw), gy = (n / gw) % gh, gx = n % gw;
+        int k = kb + kk, dz = k >> 8, dy = (k >> 4) & 15, dx = k & 15;
+        v = x[((((int64_t)b * d.M + m) * D + gz * 16 + dz) * H + gy * 16 + dy) * W + gx * 16 + dx];
+      }
+      sP[tl * LDP + kk] = v;
+    }
+    __syncthreads();
+    for (int t2 = 0; t2 < TT / 2; t2++) {
+      float av = sD[(2 * t2 + h) * LDD + r];
+      float bv = sP[(2 * t2 + h) * LDP + wave * 32 + r];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    int c = cb + (i & 3) + 8 * (i >> 2) + 4 * h;
+    if (c < DM) dwpe[(int64_t)m * d.mstride + (int64_t)c * 4096 + kb + wave * 32 + r] += acc[i];
+  }
+}
+
+inline TfLayerP offset_none(const TfLayerP& p) { return p; }
+
+}  // namespace
+
+int tf_patch_embed_fwd(const TfDims& d, const float* x, int D, int H, int W, const float* wpe, const float* bpe,
+                       const float* pos, float* F, hipStream_t st) {
+  HDF_CHECK_ARG(d.DM <= 256 && d.DM % 32 == 0, "patch_embed: token dim %d unsupported", d.DM);
+  size_t shm = (size_t)(32 + d.DM) * 65 * sizeof(float);
+  hipLaunchKernelGGL(patch_embed_fwd_kernel, dim3(ceil_div(d.B * d.N, 32), d.M), dim3(256), shm, st, d, x, D, H, W, wpe,
+                     bpe, pos, F);
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
+int tf_patch_embed_bwd(const TfDims& d, const float* x, int D, int H, int W, const float* dF, float* dwpe, float* dbpe,
+                       float* dpos, float* scratch, hipStream_t st) {
+  hipLaunchKernelGGL(patch_embed_bwd_prep_kernel, dim3(ceil_div(d.N * d.DM, 256), d.M), dim3(256), 0, st, d, dF,
+                     scratch, dbpe, dpos);
+  HDF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(patch_embed_wgrad_kernel, dim3(4096 / 128, ceil_div(d.DM, 32), d.M), dim3(256), 0, st, d, x, D, H,
+                     W, scratch, dwpe);
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
+int tf_layer_fwd(const TfDims& d, int block, int layer, const TfLayerP& p, float* F, const TfLayerSave& s,
+                 hipStream_t st) {
+  const int K = d.DM + 32 * layer, BN = d.B * d.N;
+  dim3 grid(ceil_div(BN, TB), d.M);
+  size_t shm = (size_t)(TB * K + TB * 32) * sizeof(float);
+  hipLaunchKernelGGL(dense_pre_fwd_kernel, grid, dim3(256), shm, st, d, K, p, F, s.h0, s.qkv);
+  HDF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(ceil_div(d.N, 64), 8, d.M * d.B), dim3(256), (size_t)d.N * 32, st, d.N,
+                     s.qkv, s.ob, s.lse);
+  HDF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(dense_post_fwd_kernel, grid, dim3(256), 0, st, d, block, layer, p, s.h0, s.ob, s.h1, s.h2, F);
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
+int tf_layer_bwd(const TfDims& d, int block, int layer, const TfLayerP& p, const TfLayerP& g, const float* F, float* dF,
+                 const TfLayerSave& s, float* scratch, hipStream_t st) {
+  const int K = d.DM + 32 * layer, BN = d.B * d.N;
+  const int64_t rows = (int64_t)d.M * BN;
+  float* dO = scratch;
+  float* dh0acc = scratch + rows * 32;
+  float* dqkv = scratch + rows * 64;
+  dim3 grid(ceil_div(BN, TB), d.M);
+  hipLaunchKernelGGL(dense_post_bwd_kernel, grid, dim3(256), 0, st, d, block, layer, p, g, s.h1, s.h2, s.ob, dF, dO,
+                     dh0acc);
+  HDF_LAUNCH_CHECK();
+  dim3 ag(ceil_div(d.N, 64), 8, d.M * d.B);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, ag, dim3(256), (size_t)d.N * 32, st, d.N, s.qkv, s.ob, s.lse, dO, dqkv);
+  HDF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, ag, dim3(256), (size_t)d.N * 40, st, d.N, s.qkv, s.ob, s.lse, dO, dqkv);
+  HDF_LAUNCH_CHECK();
+  size_t shm = (size_t)(TB * K + TB * 32 + TB * 96 + TB * 32 + 8 * 32 * 2) * sizeof(float);
+  hipLaunchKernelGGL(dense_pre_bwd_kernel, grid, dim3(256), shm, st, d, K, p, g, F, s.h0, dqkv, dh0acc, dF);
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
+int tf_block_out_fwd(const TfDims& d, int block, const TfOutP& p, const float* F, float* next_F, void* attnall,
+                     int dtype, hipStream_t st) {
+  dim3 grid(ceil_div(d.B * d.N, TB), d.M);
+  size_t shm = (size_t)(TB * d.DMF + TB * 64) * sizeof(float);
+  if (dtype == HDF_BF16)
+    hipLaunchKernelGGL(block_out_fwd_kernel<bf16_t>, grid, dim3(256), shm, st, d, block, p, F, next_F,
+                       (bf16_t*)attnall);
+  else
+    hipLaunchKernelGGL(block_out_fwd_kernel<float>, grid, dim3(256), shm, st, d, block, p, F, next_F, (float*)attnall);
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
+int tf_block_out_bwd(const TfDims& d, int block, const TfOutP& p, const TfOutP& g, const float* F,
+                     const float* dF_next, const void* d_attnall, int dtype, float* dF, hipStream_t st) {
+  dim3 grid(ceil_div(d.B * d.N, TB), d.M);
+  size_t shm = (size_t)(TB * d.DMF + TB * 64 * 2 + TB * d.DM) * sizeof(float);
+  if (dtype == HDF_BF16)
+    hipLaunchKernelGGL(block_out_bwd_kernel<bf16_t>, grid, dim3(256), shm, st, d, block, p, g, F, dF_next,
+                       (const bf16_t*)d_attnall, dF);
+  else
+    hipLaunchKernelGGL(block_out_bwd_kernel<float>, grid, dim3(256), shm, st, d, block, p, g, F, dF_next,
+                       (const float*)d_attnall, dF);
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}

@@ -1,0 +1,760 @@
+// HBM-bound U-Net ops: layout conversion, InstanceNorm statistics/finalise, norm+ReLU(+skip)
+// materialisation, MaxPool3d(2,2) fwd/bwd, trilinear x2 fwd/bwd, the 1x1x1 heads fwd/bwd and the
+// InstanceNorm+ReLU backward (reduce / finalise / apply).  Every thread moves 16-byte channel chunks
+// of channels-last rows (8 bf16 / 4 f32), the coalescing sweet spot on CDNA4.
+//
+// Reference semantics: HDenseFormer.py:148-175 (BasicConv3d / UpConv), :199-207 (MaxPool3d),
+// :223-227 (heads); torch semantics restated in SURVEY.md appendix A items 7-9,18.
+#include "unet_ops.h"
+
+namespace {
+
+constexpr int MAX_BLOCKS = 4096;
+
+template <typename T>
+__device__ __forceinline__ void load_chunk(const T* p, float* f) {
+  u32x4 v = *reinterpret_cast<const u32x4*>(p);
+  ST<T>::unpack(v, f);
+}
+template <typename T>
+__device__ __forceinline__ void store_chunk(T* p, const float* f) {
+  *reinterpret_cast<u32x4*>(p) = ST<T>::pack(f);
+}
+
+// ------------------------------------------------------------------------------ layout conversion
+template <typename T>
+__global__ void nchw_to_ndhwc_kernel(const float* __restrict__ x, T* __restrict__ out, int N, int C, int CP,
+                                     int64_t vox) {
+  int64_t total = (int64_t)N * vox;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t n = i / vox, v = i - n * vox;
+    for (int c0 = 0; c0 < CP; c0 += ST<T>::EPC) {
+      float f[ST<T>::EPC];
+#pragma unroll
+      for (int e = 0; e < ST<T>::EPC; e++) f[e] = (c0 + e < C) ? x[(n * C + c0 + e) * vox + v] : 0.f;
+      store_chunk<T>(out + i * CP + c0, f);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------ IN statistics
+// one workgroup per (n, 32-channel group): 8 tile lanes x 32 channels, double accumulation
+__global__ __launch_bounds__(256) void in_finalize_kernel(const float* __restrict__ partials, int tiles, int C, int CP,
+                                                          int64_t vox, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps,
+                                                          float* __restrict__ mean, float* __restrict__ rstd,
+                                                          float* __restrict__ scale, float* __restrict__ shift) {
+  __shared__ double red[8][32][2];
+  const int n = blockIdx.y, cg = blockIdx.x;
+  const int c = cg * 32 + (threadIdx.x & 31), tl = threadIdx.x >> 5;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < CP) {
+    const float* p = partials + ((int64_t)n * tiles * CP + c) * 2;
+    for (int t = tl; t < tiles; t += 8) {
+      float2 v = *reinterpret_cast<const float2*>(p + (int64_t)t * CP * 2);
+      s1 += (double)v.x;
+      s2 += (double)v.y;
+    }
+  }
+  red[tl][threadIdx.x & 31][0] = s1;
+  red[tl][threadIdx.x & 31][1] = s2;
+  __syncthreads();
+  if (tl == 0 && c < C) {
+    for (int k = 1; k < 8; k++) {
+      s1 += red[k][threadIdx.x][0];
+      s2 += red[k][threadIdx.x][1];
+    }
+    double m = s1 / (double)vox;
+    double var = s2 / (double)vox - m * m;  // biased variance
+    if (var < 0.0) var = 0.0;
+    float r = (float)(1.0 / sqrt(var + (double)eps));
+    float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    int64_t o = (int64_t)n * C + c;
+    mean[o] = (float)m;
+    rstd[o] = r;
+    scale[o] = g * r;
+    shift[o] = b - (float)m * g * r;
+  }
+}
+
+// ------------------------------------------------------------------------------ norm+relu(+skip)
+template <typename T>
+__global__ void norm_relu_add_kernel(const T* __restrict__ y, int64_t y_pitch, const float* __restrict__ scale,
+                                     const float* __restrict__ shift, const T* __restrict__ skip, int64_t skip_pitch,
+                                     T* __restrict__ out, int64_t out_pitch, int N, int C, int64_t vox) {
+  constexpr int EPC = ST<T>::EPC;
+  const int cols = C / EPC;
+  int64_t total = (int64_t)N * vox * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t row = i / cols;
+    int c0 = (int)(i - row * cols) * EPC;
+    int n = (int)(row / vox);
+    float f[EPC], s[EPC];
+    load_chunk<T>(y + row * y_pitch + c0, f);
+    if (skip) load_chunk<T>(skip + row * skip_pitch + c0, s);
+#pragma unroll
+    for (int e = 0; e < EPC; e++) {
+      float v = fmaxf(f[e] * scale[(int64_t)n * C + c0 + e] + shift[(int64_t)n * C + c0 + e], 0.f);
+      f[e] = skip ? v + s[e] : v;
+    }
+    store_chunk<T>(out + row * out_pitch + c0, f);
+  }
+}
+
+// ------------------------------------------------------------------------------ maxpool 2x2x2
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T* __restrict__ in, int64_t in_pitch, T* __restrict__ out, int64_t out_pitch,
+                                   uint8_t* __restrict__ idx, int N, int C, int Do, int Ho, int Wo) {
+  constexpr int EPC = ST<T>::EPC;
+  const int cols = C / EPC;
+  const int Hi = Ho * 2, Wi = Wo * 2, Di = Do * 2;
+  int64_t total = (int64_t)N * Do * Ho * Wo * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t row = i / cols;
+    int c0 = (int)(i - row * cols) * EPC;
+    int64_t t = row;
+    int ow = t % Wo;
+    t /= Wo;
+    int oh = t % Ho;
+    t /= Ho;
+    int od = t % Do;
+    int n = (int)(t / Do);
+    float best[EPC];
+    int bi[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; e++) {
+      best[e] = -INFINITY;
+      bi[e] = 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {  // scan order d,h,w; strict > keeps the FIRST maximum (torch tie rule)
+      int dz = k >> 2, dy = (k >> 1) & 1, dx = k & 1;
+      int64_t irow = (((int64_t)n * Di + 2 * od + dz) * Hi + 2 * oh + dy) * Wi + 2 * ow + dx;
+      float f[EPC];
+      load_chunk<T>(in + irow * in_pitch + c0, f);
+#pragma unroll
+      for (int e = 0; e < EPC; e++) {
+        if (f[e] > best[e] || f[e] != f[e]) {
+          best[e] = f[e];
+          bi[e] = k;
+        }
+      }
+    }
+    store_chunk<T>(out + row * out_pitch + c0, best);
+#pragma unroll
+    for (int e = 0; e < EPC; e++) idx[row * C + c0 + e] = (uint8_t)bi[e];
+  }
+}
+
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T* __restrict__ dout, int64_t dout_pitch, const uint8_t* __restrict__ idx,
+                                   T* __restrict__ din, int64_t din_pitch, int N, int C, int Do, int Ho, int Wo,
+                                   int accumulate) {
+  constexpr int EPC = ST<T>::EPC;
+  const int cols = C / EPC;
+  const int Hi = Ho * 2, Wi = Wo * 2, Di = Do * 2;
+  int64_t total = (int64_t)N * Do * Ho * Wo * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t row = i / cols;
+    int c0 = (int)(i - row * cols) * EPC;
+    int64_t t = row;
+    int ow = t % Wo;
+    t /= Wo;
+    int oh = t % Ho;
+    t /= Ho;
+    int od = t % Do;
+    int n = (int)(t / Do);
+    float g[EPC];
+    int bi[EPC];
+    load_chunk<T>(dout + row * dout_pitch + c0, g);
+#pragma unroll
+    for (int e = 0; e < EPC; e++) bi[e] = idx[row * C + c0 + e];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      int dz = k >> 2, dy = (k >> 1) & 1, dx = k & 1;
+      int64_t irow = (((int64_t)n * Di + 2 * od + dz) * Hi + 2 * oh + dy) * Wi + 2 * ow + dx;
+      T* p = din + irow * din_pitch + c0;
+      float f[EPC];
+      if (accumulate)
+        load_chunk<T>(p, f);
+      else {
+#pragma unroll
+        for (int e = 0; e < EPC; e++) f[e] = 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < EPC; e++)
+        if (bi[e] == k) f[e] += g[e];
+      store_chunk<T>(p, f);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------ trilinear x2
+// per dim, output o reads inputs (ia, wa), (ib, wb):  o=2i: (max(i-1,0), .25), (i, .75) ; o=2i+1: (i, .75), (min(i+1,n-1), .25)
+__device__ __forceinline__ void up_taps(int o, int n, int& ia, float& wa, int& ib, float& wb) {
+  int i = o >> 1;
+  if (o & 1) {
+    ia = i;
+    wa = 0.75f;
+    ib = min(i + 1, n - 1);
+    wb = 0.25f;
+  } else {
+    ia = max(i - 1, 0);
+    wa = 0.25f;
+    ib = i;
+    wb = 0.75f;
+  }
+}
+
+template <typename T>
+__global__ void upsample_fwd_kernel(const T* __restrict__ y, int64_t y_pitch, const float* __restrict__ scale,
+                                    const float* __restrict__ shift, T* __restrict__ out, int64_t out_pitch, int N,
+                                    int C, int Di, int Hi, int Wi) {
+  constexpr int EPC = ST<T>::EPC;
+  const int cols = C / EPC;
+  const int Do = 2 * Di, Ho = 2 * Hi, Wo = 2 * Wi;
+  int64_t total = (int64_t)N * Do * Ho * Wo * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t row = i / cols;
+    int c0 = (int)(i - row * cols) * EPC;
+    int64_t t = row;
+    int ow = t % Wo;
+    t /= Wo;
+    int oh = t % Ho;
+    t /= Ho;
+    int od = t % Do;
+    int n = (int)(t / Do);
+    int iz[2], iy[2], ix[2];
+    float wz[2], wy[2], wx[2];
+    up_taps(od, Di, iz[0], wz[0], iz[1], wz[1]);
+    up_taps(oh, Hi, iy[0], wy[0], iy[1], wy[1]);
+    up_taps(ow, Wi, ix[0], wx[0], ix[1], wx[1]);
+    float sc[EPC], sh[EPC], acc[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; e++) {
+      sc[e] = scale[(int64_t)n * C + c0 + e];
+      sh[e] = shift[(int64_t)n * C + c0 + e];
+      acc[e] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      int a = k >> 2, b = (k >> 1) & 1, c = k & 1;
+      float w = wz[a] * wy[b] * wx[c];
+      int64_t irow = (((int64_t)n * Di + iz[a]) * Hi + iy[b]) * Wi + ix[c];
+      float f[EPC];
+      load_chunk<T>(y + irow * y_pitch + c0, f);
+#pragma unroll
+      for (int e = 0; e < EPC; e++) acc[e] += w * fmaxf(f[e] * sc[e] + sh[e], 0.f);
+    }
+    store_chunk<T>(out + row * out_pitch + c0, acc);
+  }
+}
+
+// input i receives from outputs 2i-1 (.25, i>=1), 2i (.75 [+.25 at i==0]), 2i+1 (.75 [+.25 at i==n-1]), 2i+2 (.25, i<=n-2)
+__device__ __forceinline__ void up_bwd_taps(int i, int n, int* o, float* w) {
+  o[0] = 2 * i - 1;
+  w[0] = (i >= 1) ? 0.25f : 0.f;
+  o[1] = 2 * i;
+  w[1] = (i == 0) ? 1.0f : 0.75f;
+  o[2] = 2 * i + 1;
+  w[2] = (i == n - 1) ? 1.0f : 0.75f;
+  o[3] = 2 * i + 2;
+  w[3] = (i <= n - 2) ? 0.25f : 0.f;
+  if (i < 1) o[0] = 0;
+  if (i > n - 2) o[3] = 2 * n - 1;
+}
+
+template <typename T>
+__global__ void upsample_bwd_kernel(const T* __restrict__ dout, int64_t dout_pitch, T* __restrict__ din,
+                                    int64_t din_pitch, int N, int C, int Di, int Hi, int Wi) {
+  constexpr int EPC = ST<T>::EPC;
+  const int cols = C / EPC;
+  const int Do = 2 * Di, Ho = 2 * Hi, Wo = 2 * Wi;
+  int64_t total = (int64_t)N * Di * Hi * Wi * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t row = i / cols;
+    int c0 = (int)(i - row * cols) * EPC;
+    int64_t t = row;
+    int iw = t % Wi;
+    t /= Wi;
+    int ih = t % Hi;
+    t /= Hi;
+    int id = t % Di;
+    int n = (int)(t / Di);
+    int oz[4], oy[4], ox[4];
+    float wz[4], wy[4], wx[4];
+    up_bwd_taps(id, Di, oz, wz);
+    up_bwd_taps(ih, Hi, oy, wy);
+    up_bwd_taps(iw, Wi, ox, wx);
+    float acc[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; e++) acc[e] = 0.f;
+    for (int a = 0; a < 4; a++) {
+      if (wz[a] == 0.f) continue;
+      for (int b = 0; b < 4; b++) {
+        if (wy[b] == 0.f) continue;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          float w = wz[a] * wy[b] * wx[c];
+          if (w != 0.f) {
+            int64_t orow = (((int64_t)n * Do + oz[a]) * Ho + oy[b]) * Wo + ox[c];
+            float f[EPC];
+            load_chunk<T>(dout + orow * dout_pitch + c0, f);
+#pragma unroll
+            for (int e = 0; e < EPC; e++) acc[e] += w * f[e];
+          }
+        }
+      }
+    }
+    store_chunk<T>(din + row * din_pitch + c0, acc);
+  }
+}
+
+// ------------------------------------------------------------------------------ 1x1x1 heads
+constexpr int HEAD_MAXCLS = 8;
+
+template <typename T>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ in, int64_t in_pitch,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       const float* __restrict__ w, const float* __restrict__ b,
+                                                       T* __restrict__ logits, int N, int C, int ncls, int64_t vox) {
+  constexpr int EPC = ST<T>::EPC;
+  extern __shared__ float sm[];  // w[ncls][C], then scale[C], shift[C] for this block's n
+  float* sw = sm;
+  float* ssc = sm + ncls * C;
+  float* ssh = ssc + C;
+  const int n = blockIdx.y;
+  for (int i = threadIdx.x; i < ncls * C; i += 256) sw[i] = w[i];
+  for (int i = threadIdx.x; i < C; i += 256) {
+    ssc[i] = scale ? scale[(int64_t)n * C + i] : 1.f;
+    ssh[i] = scale ? shift[(int64_t)n * C + i] : 0.f;
+  }
+  __syncthreads();
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < vox; v += (int64_t)gridDim.x * 256) {
+    float acc[HEAD_MAXCLS];
+#pragma unroll
+    for (int o = 0; o < HEAD_MAXCLS; o++) acc[o] = (o < ncls) ? b[o] : 0.f;
+    const T* row = in + ((int64_t)n * vox + v) * in_pitch;
+    for (int c0 = 0; c0 < C; c0 += EPC) {
+      float f[EPC];
+      load_chunk<T>(row + c0, f);
+#pragma unroll
+      for (int e = 0; e < EPC; e++) {
+        float x = f[e];
+        if (scale) x = fmaxf(x * ssc[c0 + e] + ssh[c0 + e], 0.f);
+#pragma unroll
+        for (int o = 0; o < HEAD_MAXCLS; o++)
+          if (o < ncls) acc[o] += x * sw[o * C + c0 + e];
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < HEAD_MAXCLS; o++)
+      if (o < ncls) ST<T>::st(logits + ((int64_t)n * ncls + o) * vox + v, acc[o]);
+  }
+}
+
+// grid (blocks, N); loops channel chunks of 32 outermost so the (o,c) accumulators stay scalar
+template <typename T>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ dlogits, const T* __restrict__ in,
+                                                       int64_t in_pitch, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const float* __restrict__ w,
+                                                       T* __restrict__ dx, int64_t dx_pitch, int accumulate_dx,
+                                                       float* __restrict__ dw, float* __restrict__ db, int N, int C,
+                                                       int ncls, int64_t vox) {
+  constexpr int EPC = ST<T>::EPC;
+  __shared__ float xs[256][33];
+  __shared__ float dls[256][HEAD_MAXCLS];
+  __shared__ float sw[HEAD_MAXCLS][32];
+  const int n = blockIdx.y;
+  const int po = threadIdx.x >> 5, pc = threadIdx.x & 31;  // (o,c) pair owned for the dW reduction
+  for (int cb = 0; cb < C; cb += 32) {
+    const int cw = min(32, C - cb);
+    __syncthreads();
+    if (threadIdx.x < HEAD_MAXCLS * 32) {
+      int o = threadIdx.x >> 5, c = threadIdx.x & 31;
+      sw[o][c] = (o < ncls && c < cw) ? w[o * C + cb + c] : 0.f;
+    }
+    float accw = 0.f, accb = 0.f;
+    for (int64_t v0 = (int64_t)blockIdx.x * 256; v0 < vox; v0 += (int64_t)gridDim.x * 256) {
+      __syncthreads();
+      int64_t v = v0 + threadIdx.x;
+      float dl[HEAD_MAXCLS];
+#pragma unroll
+      for (int o = 0; o < HEAD_MAXCLS; o++) {
+        dl[o] = (o < ncls && v < vox) ? ST<T>::ld(dlogits + ((int64_t)n * ncls + o) * vox + v) : 0.f;
+        dls[threadIdx.x][o] = dl[o];
+      }
+      if (v < vox) {
+        const T* row = in + ((int64_t)n * vox + v) * in_pitch + cb;
+        T* drow = dx + ((int64_t)n * vox + v) * dx_pitch + cb;
+        for (int c0 = 0; c0 < cw; c0 += EPC) {
+          float f[EPC], g[EPC];
+          load_chunk<T>(row + c0, f);
+          if (accumulate_dx)
+            load_chunk<T>(drow + c0, g);
+          else {
+#pragma unroll
+            for (int e = 0; e < EPC; e++) g[e] = 0.f;
+          }
+#pragma unroll
+          for (int e = 0; e < EPC; e++) {
+            float x = f[e];
+            if (scale) x = fmaxf(x * scale[(int64_t)n * C + cb + c0 + e] + shift[(int64_t)n * C + cb + c0 + e], 0.f);
+            xs[threadIdx.x][c0 + e] = x;
+            float d = 0.f;
+#pragma unroll
+            for (int o = 0; o < HEAD_MAXCLS; o++) d += dl[o] * sw[o][c0 + e];
+            // relu of the producing norm is handled by the IN backward of that layer (dx is d/d activation)
+            g[e] += d;
+          }
+          store_chunk<T>(drow + c0, g);
+        }
+      } else {
+        for (int c = 0; c < 32; c++) xs[threadIdx.x][c] = 0.f;
+      }
+      __syncthreads();
+      if (po < ncls && pc < cw) {
+        float s = 0.f;
+        for (int k = 0; k < 256; k++) s += dls[k][po] * xs[k][pc];
+        accw += s;
+      }
+      if (cb == 0 && threadIdx.x < ncls) {
+        float s = 0.f;
+        for (int k = 0; k < 256; k++) s += dls[k][threadIdx.x];
+        accb += s;
+      }
+    }
+    if (po < ncls && pc < cw) atomicAdd(dw + po * C + cb + pc, accw);
+    if (cb == 0 && threadIdx.x < ncls) atomicAdd(db + threadIdx.x, accb);
+  }
+}
+
+// ------------------------------------------------------------------------------ IN + ReLU backward
+// grid (blocks, N).  thread = (voxel lane, channel chunk)
+template <typename T>
+__global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const T* __restrict__ da, int64_t da_pitch,
+                                                            const T* __restrict__ y, int64_t y_pitch,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, float* __restrict__ partials,
+                                                            int blocks, int C, int64_t vox) {
+  constexpr int EPC = ST<T>::EPC;
+  extern __shared__ float red[];  // [vlanes][C][2]
+  const int n = blockIdx.y;
+  const int cols = C / EPC;
+  const int vlanes = 256 / cols;
+  const int col = threadIdx.x % cols, vl = threadIdx.x / cols;
+  const int c0 = col * EPC;
+  float s1[EPC], s2[EPC], sc[EPC], sh[EPC], mu[EPC], rs[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; e++) {
+    s1[e] = s2[e] = 0.f;
+    int64_t o = (int64_t)n * C + c0 + e;
+    sc[e] = scale[o];
+    sh[e] = shift[o];
+    mu[e] = mean[o];
+    rs[e] = rstd[o];
+  }
+  if (vl < vlanes) {
+    int64_t per = (vox + blocks - 1) / blocks;
+    int64_t vb = (int64_t)blockIdx.x * per, ve = min(vox, vb + per);
+    for (int64_t v = vb + vl; v < ve; v += vlanes) {
+      int64_t row = (int64_t)n * vox + v;
+      float g[EPC], f[EPC];
+      load_chunk<T>(da + row * da_pitch + c0, g);
+      load_chunk<T>(y + row * y_pitch + c0, f);
+#pragma unroll
+      for (int e = 0; e < EPC; e++) {
+        float gg = (f[e] * sc[e] + sh[e] > 0.f) ? g[e] : 0.f;
+        s1[e] += gg;
+        s2[e] += gg * ((f[e] - mu[e]) * rs[e]);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; e++) {
+      red[(vl * C + c0 + e) * 2 + 0] = s1[e];
+      red[(vl * C + c0 + e) * 2 + 1] = s2[e];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C * 2; i += 256) {
+    float s = 0.f;
+    for (int k = 0; k < vlanes; k++) s += red[k * C * 2 + i];
+    partials[((int64_t)n * blocks + blockIdx.x) * C * 2 + i] = s;
+  }
+}
+
+// one thread per (n,c)
+__global__ void in_bwd_finalize_kernel(const float* __restrict__ partials, int blocks, int N, int C, int64_t vox,
+                                       const float* __restrict__ gamma, const float* __restrict__ rstd,
+                                       float* __restrict__ k1, float* __restrict__ ka, float* __restrict__ kb,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double tg = 0.0, tb = 0.0;
+  for (int n = 0; n < N; n++) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < blocks; b++) {
+      const float* p = partials + (((int64_t)n * blocks + b) * C + c) * 2;
+      s1 += (double)p[0];
+      s2 += (double)p[1];
+    }
+    int64_t o = (int64_t)n * C + c;
+    float g = gamma ? gamma[c] : 1.f;
+    k1[o] = g * rstd[o];
+    ka[o] = (float)(s1 / (double)vox);
+    kb[o] = (float)(s2 / (double)vox);
+    tb += s1;
+    tg += s2;
+  }
+  if (dgamma) dgamma[c] += (float)tg;
+  if (dbeta) dbeta[c] += (float)tb;
+}
+
+template <typename T>
+__global__ void in_bwd_apply_kernel(const T* __restrict__ da, int64_t da_pitch, const T* __restrict__ y,
+                                    int64_t y_pitch, const float* __restrict__ scale, const float* __restrict__ shift,
+                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                    const float* __restrict__ k1, const float* __restrict__ ka,
+                                    const float* __restrict__ kb, T* __restrict__ dy, int64_t dy_pitch, int N, int C,
+                                    int64_t vox) {
+  constexpr int EPC = ST<T>::EPC;
+  const int cols = C / EPC;
+  int64_t total = (int64_t)N * vox * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t row = i / cols;
+    int c0 = (int)(i - row * cols) * EPC;
+    int n = (int)(row / vox);
+    float g[EPC], f[EPC];
+    load_chunk<T>(da + row * da_pitch + c0, g);
+    load_chunk<T>(y + row * y_pitch + c0, f);
+#pragma unroll
+    for (int e = 0; e < EPC; e++) {
+      int64_t o = (int64_t)n * C + c0 + e;
+      float gg = (f[e] * scale[o] + shift[o] > 0.f) ? g[e] : 0.f;
+      float xh = (f[e] - mean[o]) * rstd[o];
+      g[e] = k1[o] * (gg - ka[o] - xh * kb[o]);
+    }
+    store_chunk<T>(dy + row * dy_pitch + c0, g);
+  }
+}
+
+template <typename T>
+__global__ void add_kernel(T* __restrict__ a, int64_t a_pitch, const T* __restrict__ b, int64_t b_pitch, int C,
+                           int64_t rows, int accumulate) {
+  constexpr int EPC = ST<T>::EPC;
+  const int cols = C / EPC;
+  int64_t total = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t row = i / cols;
+    int c0 = (int)(i - row * cols) * EPC;
+    float f[EPC], g[EPC];
+    load_chunk<T>(b + row * b_pitch + c0, g);
+    if (accumulate) {
+      load_chunk<T>(a + row * a_pitch + c0, f);
+#pragma unroll
+      for (int e = 0; e < EPC; e++) g[e] += f[e];
+    }
+    store_chunk<T>(a + row * a_pitch + c0, g);
+  }
+}
+
+// db[c] += sum over rows; block partial in LDS then one atomic per channel per block
+template <typename T>
+__global__ __launch_bounds__(256) void bias_grad_kernel(const T* __restrict__ dy, int64_t dy_pitch,
+                                                        float* __restrict__ db, int C, int64_t rows) {
+  constexpr int EPC = ST<T>::EPC;
+  extern __shared__ float red[];  // [C]
+  const int cols = C / EPC;
+  const int vlanes = 256 / cols;
+  const int col = threadIdx.x % cols, vl = threadIdx.x / cols;
+  for (int i = threadIdx.x; i < C; i += 256) red[i] = 0.f;
+  __syncthreads();
+  float s[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; e++) s[e] = 0.f;
+  if (vl < vlanes) {
+    for (int64_t r = (int64_t)blockIdx.x * vlanes + vl; r < rows; r += (int64_t)gridDim.x * vlanes) {
+      float f[EPC];
+      load_chunk<T>(dy + r * dy_pitch + col * EPC, f);
+#pragma unroll
+      for (int e = 0; e < EPC; e++) s[e] += f[e];
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; e++) atomicAdd(&red[col * EPC + e], s[e]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += 256) atomicAdd(db + i, red[i]);
+}
+
+inline unsigned grid_for(int64_t total, int block = 256) {
+  return (unsigned)std::min<int64_t>(ceil_div64(total, block), MAX_BLOCKS);
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, ...)                          \
+  do {                                                  \
+    if ((dtype) == HDF_BF16) {                          \
+      using T = bf16_t;                                 \
+      __VA_ARGS__;                                      \
+    } else if ((dtype) == HDF_F32) {                    \
+      using T = float;                                  \
+      __VA_ARGS__;                                      \
+    } else {                                            \
+      hdf_set_error("unsupported dtype %d", (dtype));   \
+      return HDF_ERR_UNSUPPORTED;                       \
+    }                                                   \
+  } while (0)
+
+int hdf_launch_nchw_to_ndhwc(int dtype, const float* x, void* out, int N, int C, int CP, int64_t vox, hipStream_t st) {
+  HDF_CHECK_ARG(CP % 16 == 0 && CP >= C, "nchw_to_ndhwc: CP=%d", CP);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(nchw_to_ndhwc_kernel<T>, dim3(grid_for((int64_t)N * vox)), dim3(256), 0, st, x,
+                                       (T*)out, N, C, CP, vox));
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
+int hdf_launch_in_finalize(const float* partials, int N, int tiles, int C, int CP, int64_t vox, const float* gamma,
+                           const float* beta, float eps, float* mean, float* rstd, float* scale, float* shift,
+                           hipStream_t st) {
+  hipLaunchKernelGGL(in_finalize_kernel, dim3(ceil_div(CP, 32), N), dim3(256), 0, st, partials, tiles, C, CP, vox, gamma,
+                     beta, eps, mean, rstd, scale, shift);
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
+int hdf_launch_norm_relu_add(int dtype, const void* y, int64_t y_pitch, const float* scale, const float* shift,
+                             const void* skip, int64_t skip_pitch, void* out, int64_t out_pitch, int N, int C,
+                             int64_t vox, hipStream_t st) {
+  HDF_CHECK_ARG(C % 16 == 0, "norm_relu_add: C=%d", C);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(norm_relu_add_kernel<T>, dim3(grid_for((int64_t)N * vox * (C / ST<T>::EPC))),
+                                       dim3(256), 0, st, (const T*)y, y_pitch, scale, shift, (const T*)skip, skip_pitch,
+                                       (T*)out, out_pitch, N, C, vox));
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
+int hdf_launch_maxpool_fwd(int dtype, const void* in, int64_t in_pitch, void* out, int64_t out_pitch, uint8_t* idx,
+                           int N, int C, int Do, int Ho, int Wo, hipStream_t st) {
+  HDF_CHECK_ARG(C % 16 == 0, "maxpool: C=%d", C);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(grid_for((int64_t)N * Do * Ho * Wo * (C / ST<T>::EPC))),
+                                dim3(256), 0, st, (const T*)in, in_pitch, (T*)out, out_pitch, idx, N, C, Do, Ho, Wo));
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
+int hdf_launch_maxpool_bwd(int dtype, const void* dout, int64_t dout_pitch, const uint8_t* idx, void* din,
+                           int64_t din_pitch, int N, int C, int Do, int Ho, int Wo, int accumulate, hipStream_t st) {
+  DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<T>,
+                                       dim3(grid_for((int64_t)N * Do * Ho * Wo * (C / ST<T>::EPC))), dim3(256), 0, st,
+                                       (const T*)dout, dout_pitch, idx, (T*)din, din_pitch, N, C, Do, Ho, Wo,
+                                       accumulate));
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
+int hdf_launch_upsample_fwd(int dtype, const void* y, int64_t y_pitch, const float* scale, const float* shift,
+                            void* out, int64_t out_pitch, int N, int C, int Di, int Hi, int Wi, hipStream_t st) {
+  HDF_CHECK_ARG(C % 16 == 0, "upsample: C=%d", C);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(upsample_fwd_kernel<T>,
+                                       dim3(grid_for((int64_t)N * 8 * Di * Hi * Wi * (C / ST<T>::EPC))), dim3(256), 0,
+                                       st, (const T*)y, y_pitch, scale, shift, (T*)out, out_pitch, N, C, Di, Hi, Wi));
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
+int hdf_launch_upsample_bwd(int dtype, const void* dout, int64_t dout_pitch, void* din, int64_t din_pitch, int N,
+                            int C, int Di, int Hi, int Wi, hipStream_t st) {
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(upsample_bwd_kernel<T>, dim3(grid_for((int64_t)N * Di * Hi * Wi * (C / ST<T>::EPC))),
+                                dim3(256), 0, st, (const T*)dout, dout_pitch, (T*)din, din_pitch, N, C, Di, Hi, Wi));
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
+int hdf_launch_head_fwd(int dtype, const void* in, int64_t in_pitch, const float* scale, const float* shift,
+                        const float* w, const float* b, void* logits, int N, int C, int ncls, int64_t vox,
+                        hipStream_t st) {
+  HDF_CHECK_ARG(ncls <= HEAD_MAXCLS, "head: n_cls=%d > %d", ncls, HEAD_MAXCLS);
+  size_t shm = (size_t)(ncls * C + 2 * C) * sizeof(float);
+  unsigned gx = (unsigned)std::min<int64_t>(ceil_div64(vox, 256), 2048);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(head_fwd_kernel<T>, dim3(gx, N), dim3(256), shm, st, (const T*)in, in_pitch,
+                                       scale, shift, w, b, (T*)logits, N, C, ncls, vox));
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
+int hdf_launch_head_bwd(int dtype, const void* dlogits, const void* in, int64_t in_pitch, const float* scale,
+                        const float* shift, const float* w, void* dx, int64_t dx_pitch, int accumulate_dx, float* dw,
+                        float* db, int N, int C, int ncls, int64_t vox, hipStream_t st) {
+  HDF_CHECK_ARG(ncls <= HEAD_MAXCLS, "head: n_cls=%d > %d", ncls, HEAD_MAXCLS);
+  unsigned gx = (unsigned)std::min<int64_t>(ceil_div64(vox, 256), 512);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(head_bwd_kernel<T>, dim3(gx, N), dim3(256), 0, st, (const T*)dlogits,
+                                       (const T*)in, in_pitch, scale, shift, w, (T*)dx, dx_pitch, accumulate_dx, dw, db,
+                                       N, C, ncls, vox));
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
+int hdf_in_bwd_blocks(int64_t vox) { return (int)std::max<int64_t>(1, std::min<int64_t>(256, vox / 1024)); }
+
+int hdf_launch_in_bwd_reduce(int dtype, const void* da, int64_t da_pitch, const void* y, int64_t y_pitch,
+                             const float* scale, const float* shift, const float* mean, const float* rstd,
+                             float* partials, int blocks, int N, int C, int64_t vox, hipStream_t st) {
+  HDF_CHECK_ARG(C % 16 == 0 && C <= 1024, "in_bwd: C=%d", C);
+  DISPATCH_T(dtype, {
+    int cols = C / ST<T>::EPC;
+    HDF_CHECK_ARG(cols <= 256, "in_bwd: C=%d too wide", C);
+    int vlanes = 256 / cols;
+    size_t shm = (size_t)vlanes * C * 2 * sizeof(float);
+    hipLaunchKernelGGL(in_bwd_reduce_kernel<T>, dim3(blocks, N), dim3(256), shm, st, (const T*)da, da_pitch,
+                       (const T*)y, y_pitch, scale, shift, mean, rstd, partials, blocks, C, vox);
+  });
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
+int hdf_launch_in_bwd_finalize(const float* partials, int blocks, int N, int C, int64_t vox, const float* gamma,
+                               const float* rstd, float* k1, float* ka, float* kb, float* dgamma, float* dbeta,
+                               hipStream_t st) {
+  hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, partials, blocks, N, C, vox, gamma,
+                     rstd, k1, ka, kb, dgamma, dbeta);
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
+int hdf_launch_in_bwd_apply(int dtype, const void* da, int64_t da_pitch, const void* y, int64_t y_pitch,
+                            const float* scale, const float* shift, const float* mean, const float* rstd,
+                            const float* k1, const float* ka, const float* kb, void* dy, int64_t dy_pitch, int N, int C,
+                            int64_t vox, hipStream_t st) {
+  DISPATCH_T(dtype, hipLaunchKernelGGL(in_bwd_apply_kernel<T>, dim3(grid_for((int64_t)N * vox * (C / ST<T>::EPC))),
+                                       dim3(256), 0, st, (const T*)da, da_pitch, (const T*)y, y_pitch, scale, shift,
+                                       mean, rstd, k1, ka, kb, (T*)dy, dy_pitch, N, C, vox));
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
+int hdf_launch_add(int dtype, void* a, int64_t a_pitch, const void* b, int64_t b_pitch, int N, int C, int64_t vox,
+                   int accumulate, hipStream_t st) {
+  DISPATCH_T(dtype, hipLaunchKernelGGL(add_kernel<T>, dim3(grid_for((int64_t)N * vox * (C / ST<T>::EPC))), dim3(256), 0,
+                                       st, (T*)a, a_pitch, (const T*)b, b_pitch, C, (int64_t)N * vox, accumulate));
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
+int hdf_launch_bias_grad(int dtype, const void* dy, int64_t dy_pitch, float* db, int C, int64_t nvox, hipStream_t st) {
+  HDF_CHECK_ARG(C % 16 == 0 && C <= 1024, "bias_grad: C=%d", C);
+  DISPATCH_T(dtype, {
+    int cols = C / ST<T>::EPC;
+    HDF_CHECK_ARG(cols <= 256, "bias_grad: C=%d too wide", C);
+    int vlanes = 256 / cols;
+    unsigned g = (unsigned)std::min<int64_t>(ceil_div64(nvox, (int64_t)vlanes * 8), 512);
+    hipLaunchKernelGGL(bias_grad_kernel<T>, dim3(g), dim3(256), C * sizeof(float), st, (const T*)dy, dy_pitch, db, C,
+                       nvox);
+  });
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}

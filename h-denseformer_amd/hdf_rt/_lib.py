@@ -1,0 +1,89 @@
+"""ctypes binding of libhdf_hip.so (C ABI declared in include/hdf.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, this module
+raises.  Build it with `python h-denseformer_amd/build.py` (or __graft_entry__.build())."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libhdf_hip.so")
+
+F32, BF16 = 0, 1
+
+_vp, _i, _i64, _f, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
+
+_PROTOS = {
+    "hdf_version": (C.c_char_p, []),
+    "hdf_last_error": (C.c_char_p, []),
+    "hdf_plan_create": (_i, [_i] * 8 + [C.POINTER(_vp)]),
+    "hdf_plan_destroy": (None, [_vp]),
+    "hdf_plan_num_params": (_i64, [_vp]),
+    "hdf_plan_param_floats": (_i64, [_vp]),
+    "hdf_plan_param_info": (_i, [_vp, _i64, C.c_char_p, _i, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i),
+                                 C.POINTER(_i64)]),
+    "hdf_plan_workspace_bytes": (_i64, [_vp, _i]),
+    "hdf_plan_buffer_info": (_i, [_vp, _i, C.c_char_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i),
+                                  C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "hdf_forward": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i, _i, _u64, _vp]),
+    "hdf_backward": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "hdf_backward_stages": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "hdf_loss_workspace_bytes": (_i64, [_i]),
+    "hdf_loss_forward": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "hdf_loss_backward": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+                               _vp]),
+    "hdf_dice_counts": (_i, [_i, _vp, _vp, _i, _i, _i64, _vp, _vp]),
+    "hdf_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _vp]),
+    "hdf_op_to_channels_last": (_i, [_i, _vp, _vp, _i, _i, _i, _i64, _vp]),
+    "hdf_op_pack_weights": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i, _vp]),
+    "hdf_op_conv3d": (_i, [_i, _i, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i64, _i, _vp, _i,
+                           _vp]),
+    "hdf_op_conv3d_stat_tiles": (_i, [_i, _i, _i]),
+    "hdf_op_wgrad_workspace_bytes": (_i64, [_i, _i, _i, _i, _i, _i, _i]),
+    "hdf_op_conv3d_wgrad": (_i, [_i, _i, _vp, _i64, _i, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i,
+                                 _vp, _i, _i, _i, _vp, _i64, _vp]),
+    "hdf_op_in_finalize": (_i, [_vp, _i, _i, _i, _i, _i64, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
+    "hdf_op_norm_relu_add": (_i, [_i, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _i64, _vp]),
+    "hdf_op_maxpool_fwd": (_i, [_i, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _i, _i, _vp]),
+    "hdf_op_maxpool_bwd": (_i, [_i, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp]),
+    "hdf_op_upsample_fwd": (_i, [_i, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp]),
+    "hdf_op_upsample_bwd": (_i, [_i, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _vp]),
+}
+
+EXPORTS = tuple(_PROTOS.keys())
+
+_lib = None
+
+
+class HdfError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the shared library once.  Raises if it has not been built -- there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HdfError(f"{LIB_PATH} not found: build the HIP extension first "
+                           f"(python h-denseformer_amd/build.py); there is no CPU/eager fallback")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise HdfError(f"{what} failed (rc={rc}): {lib().hdf_last_error().decode(errors='replace')}")
+
+
+def ptr(t):
+    """device/host pointer of a torch tensor (None -> NULL)"""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

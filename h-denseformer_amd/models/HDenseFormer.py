@@ -1,0 +1,271 @@
+"""Drop-in `models.HDenseFormer` for MI355X: same constructor, factories, state_dict keys and 4-output
+forward as the reference (models/HDenseFormer.py:177-261), with all arithmetic in libhdf_hip.so.
+
+The nn.Module tree below exists ONLY to own parameters under the reference's names (SURVEY.md appendix
+C: e.g. `attns.0.blocks.2.0.layers.1.1.fn.to_qkv.weight`) and to reproduce torch's default
+initialisation; none of the holder modules is ever called.  `forward` hands x and ONE flat fp32
+parameter buffer to the C ABI (hdf_forward / hdf_backward in include/hdf.h) through a single autograd
+node.  Precision: fp32 storage + exact-fp32 MFMA by default (like the reference without AMP); under
+`torch.autocast(device_type="cuda", dtype=torch.bfloat16)` (trainer.py:369 `autocast`) or with
+`net.compute_dtype = "bf16"` activations are stored in bf16 and the matrix cores run bf16 with fp32
+accumulation, and the four outputs come back in bf16 exactly as autocast would return them.
+
+There is no CPU or eager fallback: without the built extension or on a non-GPU tensor, forward raises.
+"""
+import torch
+from torch import nn
+
+from hdf_rt import _lib
+from hdf_rt.runtime import HDFFunction, Plan, Runtime
+
+__all__ = ["HDenseFormer", "HDenseFormer_32", "HDenseFormer_16"]
+
+_GROWTH, _HEADS, _LAYERS, _PATCH = 32, 8, 4, 16
+
+
+# ------------------------------------------------------------------ parameter holders (never called)
+class _Holder(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter holder: the computation lives in libhdf_hip.so (see HDenseFormer.forward)")
+
+
+class _Normed(_Holder):          # PreNorm: .norm + .fn
+    def __init__(self, width, fn):
+        super().__init__()
+        self.norm = nn.LayerNorm(width)
+        self.fn = fn
+
+
+class _TwoLinear(_Holder):       # DenseForward: net.0 / net.3 are the Linears
+    def __init__(self, d_in, d_hidden, d_out):
+        super().__init__()
+        self.net = nn.Sequential(nn.Linear(d_in, d_hidden), nn.GELU(), nn.Dropout(0.5), nn.Linear(d_hidden, d_out),
+                                 nn.Dropout(0.5))
+
+
+class _QKVOut(_Holder):          # Dense_Attention: to_qkv (no bias), to_out.0
+    def __init__(self, width):
+        super().__init__()
+        self.to_qkv = nn.Linear(width, 3 * width, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(width, width), nn.Dropout(0.5))
+
+
+class _DenseBlock(_Holder):
+    def __init__(self, dim):
+        super().__init__()
+        self.layers = nn.ModuleList([
+            nn.ModuleList([nn.Linear(dim + i * _GROWTH, _GROWTH), _Normed(_GROWTH, _QKVOut(_GROWTH)),
+                           _Normed(_GROWTH, _TwoLinear(_GROWTH, 2 * _GROWTH, _GROWTH))]) for i in range(_LAYERS)])
+        self.out_layer = _TwoLinear(dim + _LAYERS * _GROWTH, 2 * _GROWTH, dim)
+
+
+class _Branch(_Holder):
+    def __init__(self, dim, tokens, n_blocks):
+        super().__init__()
+        self.patch_embeddings = nn.Conv3d(1, dim, kernel_size=_PATCH, stride=_PATCH)
+        self.position_embeddings = nn.Parameter(torch.zeros(1, tokens, dim))
+        self.blocks = nn.ModuleList([nn.ModuleList([_DenseBlock(dim)]) for _ in range(n_blocks)])
+
+
+class _ConvNormAct(_Holder):     # BasicConv3d: conv (no bias) + affine InstanceNorm
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv = nn.Conv3d(cin, cout, kernel_size=3, stride=1, padding=1, bias=False)
+        self.norm = nn.InstanceNorm3d(cout, affine=True)
+
+
+class _ConvUp(_Holder):          # UpConv: double_conv.0 is the conv (with bias); the norm has no parameters
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.double_conv = nn.Sequential(nn.Conv3d(cin, cout, kernel_size=3, padding=1), nn.InstanceNorm3d(cout),
+                                         nn.ReLU(inplace=True))
+
+
+# ------------------------------------------------------------------------------------------- model
+class HDenseFormer(nn.Module):
+    def __init__(self, in_channels, n_cls, n_filters, image_size=(144, 144, 144), transformer_depth=12):
+        super().__init__()
+        if not isinstance(image_size, tuple):
+            image_size = (image_size,) * 3
+        self.in_channels, self.n_cls, self.n_filters = in_channels, n_cls, n_filters
+        self.image_size, self.transformer_depth = tuple(image_size), transformer_depth
+        nf = n_filters
+        tokens = 1
+        for s in self.image_size:
+            tokens *= s // _PATCH
+        # registration order == the reference's, so state_dict()/named_parameters() orders agree
+        self.attns = nn.ModuleList([_Branch(4 * nf, tokens, transformer_depth // 4) for _ in range(in_channels)])
+        self.deep_conv = _ConvUp(4 * nf * in_channels, 8 * nf)
+        self.up1 = _ConvUp(8 * nf, 4 * nf)
+        self.up2 = _ConvUp(4 * nf, 2 * nf)
+        self.up3 = _ConvUp(2 * nf, nf)
+        self.block_1_1_left = _ConvNormAct(in_channels, nf)
+        self.block_1_2_left = _ConvNormAct(nf, nf)
+        self.block_2_1_left = _ConvNormAct(nf, 2 * nf)
+        self.block_2_2_left = _ConvNormAct(2 * nf, 2 * nf)
+        self.block_3_1_left = _ConvNormAct(2 * nf, 4 * nf)
+        self.block_3_2_left = _ConvNormAct(4 * nf, 4 * nf)
+        self.block_4_1_left = _ConvNormAct(4 * nf, 8 * nf)
+        self.block_4_2_left = _ConvNormAct(8 * nf, 8 * nf)
+        self.upconv_3 = nn.ConvTranspose3d(8 * nf, 4 * nf, kernel_size=3, stride=2, padding=1, output_padding=1)
+        self.block_3_1_right = _ConvNormAct(8 * nf, 4 * nf)
+        self.block_3_2_right = _ConvNormAct(4 * nf, 4 * nf)
+        self.upconv_2 = nn.ConvTranspose3d(4 * nf, 2 * nf, kernel_size=3, stride=2, padding=1, output_padding=1)
+        self.block_2_1_right = _ConvNormAct(4 * nf, 2 * nf)
+        self.block_2_2_right = _ConvNormAct(2 * nf, 2 * nf)
+        self.upconv_1 = nn.ConvTranspose3d(2 * nf, nf, kernel_size=3, stride=2, padding=1, output_padding=1)
+        self.block_1_1_right = _ConvNormAct(2 * nf, nf)
+        self.block_1_2_right = _ConvNormAct(nf, nf)
+        self.conv1x1 = nn.Conv3d(nf, n_cls, kernel_size=1)
+        self.conv1x1_d1 = nn.Conv3d(2 * nf, n_cls, kernel_size=1)
+        self.conv1x1_d2 = nn.Conv3d(4 * nf, n_cls, kernel_size=1)
+        self.conv1x1_d3 = nn.Conv3d(8 * nf, n_cls, kernel_size=1)
+
+        self.compute_dtype = None        # None: follow autocast; "fp32" / "bf16": force
+        self.dropout_seed = 0            # base seed of the counter-hash dropout masks (train mode)
+        self._step = 0
+        self._flat = None                # flat fp32 parameter buffer (param.data are views of it)
+        self._flat_grad = None
+        self._plans, self._runtimes = {}, {}
+        self.grad_hook = None            # callable(stage:int) used by hdf_rt.parallel for comm/compute overlap
+
+    # -------------------------------------------------------------- flat parameter management
+    def _plan(self, dtype):
+        if dtype not in self._plans:
+            self._plans[dtype] = Plan(self.in_channels, self.n_cls, self.n_filters, self.image_size,
+                                      self.transformer_depth, dtype)
+        return self._plans[dtype]
+
+    def _aliased(self):
+        if self._flat is None:
+            return False
+        base = self._flat.data_ptr()
+        params = list(self.parameters())
+        tbl = self._plan(_lib.F32).table
+        for i in (0, len(params) // 2, len(params) - 1):      # sentinels; _apply/load paths re-flatten fully
+            p = params[i]
+            if p.device != self._flat.device or p.dtype != torch.float32 or p.data_ptr() != base + 4 * tbl[i][1]:
+                return False
+        return True
+
+    def _flatten(self):
+        """(Re)build the flat buffer from the current parameters and re-point every param.data at it."""
+        plan = self._plan(_lib.F32)
+        named = list(self.named_parameters())
+        if [n for n, _ in named] != [t[0] for t in plan.table]:
+            raise _lib.HdfError("parameter names/order differ from the plan's state_dict table")
+        dev = named[0][1].device
+        flat = torch.zeros(plan.param_floats, dtype=torch.float32, device=dev)
+        for (name, p), (_, off, numel, shape) in zip(named, plan.table):
+            if tuple(p.shape) != tuple(shape):
+                raise _lib.HdfError(f"{name}: shape {tuple(p.shape)} != plan {shape}")
+            if p.dtype != torch.float32:
+                raise _lib.HdfError(f"{name}: master parameters must stay fp32 (got {p.dtype}); use autocast or "
+                                    f"compute_dtype='bf16' for low-precision compute")
+            view = flat[off: off + numel].view(shape)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = None
+        self._flat, self._flat_grad = flat, None
+        self._grad_views = None
+        self._runtimes = {}
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._flat = None                 # .cuda()/.to()/.float() replaced param.data: re-flatten lazily
+        return out
+
+    def flat_parameters(self):
+        if not self._aliased():
+            self._flatten()
+        return self._flat
+
+    def flat_grads(self):
+        self.flat_parameters()
+        if self._flat_grad is None:
+            self._flat_grad = torch.zeros_like(self._flat)
+            tbl = self._plan(_lib.F32).table
+            self._grad_views = [self._flat_grad[off: off + numel].view(shape) for (_, off, numel, shape) in tbl]
+        return self._flat_grad
+
+    def weight_decay_mask(self):
+        """uint8 mask over the flat buffer: 1 where trainer.py:812-817 applies weight decay
+        (ndim > 1 and name not ending in '.bias')."""
+        flat = self.flat_parameters()
+        mask = torch.zeros(flat.numel(), dtype=torch.uint8)
+        for name, off, numel, shape in self._plan(_lib.F32).table:
+            if not (len(shape) == 1 or name.endswith(".bias")):
+                mask[off: off + numel] = 1
+        return mask.to(flat.device)
+
+    # ------------------------------------------------------------------------------ execution
+    def _pick_dtype(self, x):
+        if self.compute_dtype is not None:
+            return {"fp32": _lib.F32, "bf16": _lib.BF16}[self.compute_dtype]
+        if torch.is_autocast_enabled():
+            adt = torch.get_autocast_gpu_dtype()
+            if adt == torch.bfloat16:
+                return _lib.BF16
+            raise _lib.HdfError(f"autocast dtype {adt} is not supported by the HIP path (use torch.bfloat16)")
+        return _lib.F32
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise _lib.HdfError("HDenseFormer (MI355X build) needs a GPU tensor: there is no CPU fallback path")
+        if x.dim() != 5 or x.shape[1] != self.in_channels or tuple(x.shape[2:]) != self.image_size:
+            raise _lib.HdfError(f"input shape {tuple(x.shape)} does not match (B,{self.in_channels},"
+                                f"{self.image_size})")
+        flat = self.flat_parameters()
+        if flat.device != x.device:
+            raise _lib.HdfError(f"parameters on {flat.device}, input on {x.device}")
+        dtype = self._pick_dtype(x)
+        key = (dtype, x.device)
+        if key not in self._runtimes:
+            self._runtimes[key] = Runtime(self._plan(dtype), x.device)
+        rt = self._runtimes[key]
+        xin = x.detach().float().contiguous()
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if self.training:
+            self._step += 1
+        seed = (self.dropout_seed * 1000003 + self._step) & 0xFFFFFFFF
+        anchor = torch.zeros(1, device=x.device, requires_grad=need_grad)
+        outs = HDFFunction.apply(xin, anchor, self, rt, self.training, seed)
+        self._last_rt = rt
+        return list(outs)
+
+    def _run_backward(self, rt, x, douts):
+        gflat = self.flat_grads()
+        params = list(self.parameters())
+        # torch semantics: .grad accumulates over backward calls until zero_grad().  The C backward
+        # OVERWRITES the flat gradient buffer, so carry existing gradients over explicitly.
+        prev = None
+        if any(p.grad is not None for p in params):
+            if all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(params, self._grad_views)):
+                prev = gflat.clone()                          # usual case: zero_grad(set_to_none=False)
+            else:
+                prev = torch.zeros_like(gflat)
+                for p, (_, off, numel, shape) in zip(params, self._plan(_lib.F32).table):
+                    if p.grad is not None:
+                        prev[off: off + numel].view(shape).copy_(p.grad)
+        if self.grad_hook is None:
+            rt.backward(x, self._flat, douts, gflat, stages=3)
+        else:
+            rt.backward(x, self._flat, douts, gflat, stages=1)
+            self.grad_hook(1)
+            rt.backward(x, self._flat, douts, gflat, stages=2)
+            self.grad_hook(2)
+        if prev is not None:
+            gflat.add_(prev)
+        for p, v in zip(params, self._grad_views):
+            if p.requires_grad:
+                p.grad = v
+
+
+def HDenseFormer_32(in_channels, n_cls, image_size, transformer_depth):
+    return HDenseFormer(in_channels=in_channels, n_cls=n_cls, image_size=image_size, n_filters=32,
+                        transformer_depth=transformer_depth)
+
+
+def HDenseFormer_16(in_channels, n_cls, image_size, transformer_depth):
+    return HDenseFormer(in_channels=in_channels, n_cls=n_cls, image_size=image_size, n_filters=16,
+                        transformer_depth=transformer_depth)

@@ -161,7 +161,7 @@ def golden_model(ref, name, cfg, batch, train_seed=None, sample_step=1, inter_st
                train_seed=-1 if train_seed is None else train_seed, loss=loss.item(),
                sample_step=sample_step, inter_step=inter_step, torch_version=torch.__version__)
     for i, o in enumerate(outs):
-        rec[f"out{i}"] = _sample(o, sample_step if i == 0 else 1)
+        rec[f"out{i}"] = _sample(o, max(1, sample_step >> i))
         rec[f"out{i}_stats"] = _stats(o)
     for k, v in got.items():
         rec["inter_" + k] = _sample(v, inter_step if v.shape[-1] > 8 else 1)

@@ -1,0 +1,121 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol declared in
+include/hdf.h, the plan's parameter table equals the reference state_dict contract, the drop-in module
+keeps the reference's surface, and the product path fails loudly without a GPU (no fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from oracle import hdf_oracle as orc
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "hdf.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(hdf_[a-z0-9_]+)\s*\(", hdr)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from hdf_rt import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("hdf_build", os.path.join(ROOT, "h-denseformer_amd", "build.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.build(verbose=False)
+    return _lib.lib()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from hdf_rt import _lib
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/hdf.h but not exported"
+    assert sorted(_lib.EXPORTS) == declared, "ctypes prototypes out of sync with include/hdf.h"
+    assert b"gfx950" in lib.hdf_version()
+
+
+@pytest.mark.parametrize("cfg", [(4, 4, 32, (128, 128, 128), 24), (2, 3, 16, (32, 32, 32), 8),
+                                 (2, 3, 32, (144, 144, 144), 24), (4, 4, 48, (160, 160, 160), 24)])
+def test_plan_param_table_matches_reference_state_dict(lib, cfg):
+    from hdf_rt import _lib
+    from hdf_rt.runtime import Plan
+    plan = Plan(*cfg, _lib.F32)
+    shapes = orc.state_dict_shapes(*cfg)
+    assert [t[0] for t in plan.table] == list(shapes.keys())
+    for (name, off, numel, shape), ref in zip(plan.table, shapes.values()):
+        assert tuple(shape) == tuple(ref), name
+        assert off % 16 == 0 and numel == int(np.prod(ref))
+    # modality blocks are equally spaced (the kernels address branch m as base + m*stride)
+    o0 = dict((t[0], t[1]) for t in plan.table)
+    for m in range(1, cfg[0]):
+        assert (o0[f"attns.{m}.position_embeddings"] - o0[f"attns.{m-1}.position_embeddings"]
+                == o0["attns.1.position_embeddings"] - o0["attns.0.position_embeddings"])
+    assert plan.workspace_bytes(2) > 0
+
+
+def test_plan_rejects_bad_configs(lib):
+    from hdf_rt import _lib
+    h = C.c_void_p()
+    for bad in [(4, 4, 32, 120, 128, 128, 24), (4, 4, 20, 128, 128, 128, 24), (4, 4, 32, 16, 16, 16, 24),
+                (4, 9, 32, 128, 128, 128, 24)]:
+        rc = lib.hdf_plan_create(*bad, _lib.F32, C.byref(h))
+        assert rc != 0 and len(lib.hdf_last_error()) > 0
+
+
+def test_dropin_module_surface():
+    from models.HDenseFormer import HDenseFormer, HDenseFormer_16, HDenseFormer_32
+    net = HDenseFormer_16(in_channels=2, n_cls=3, image_size=(32, 32, 32), transformer_depth=8)
+    shapes = orc.state_dict_shapes(2, 3, 16, (32, 32, 32), 8)
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(shapes.keys())
+    assert all(tuple(sd[k].shape) == tuple(v) for k, v in shapes.items())
+    assert len(list(net.buffers())) == 0
+    assert [n for n, _ in net.named_parameters()] == list(shapes.keys())
+    # optimizer grouping rule of trainer.py:812-817 depends only on names/shapes
+    decay, no_decay = orc.param_groups([(n, tuple(p.shape)) for n, p in net.named_parameters()])
+    mask = net.weight_decay_mask()
+    tbl = {t[0]: t for t in net._plan(0).table}
+    for n in decay[:5] + no_decay[:5]:
+        _, off, numel, _s = tbl[n]
+        assert int(mask[off: off + numel].sum()) == (numel if n in decay else 0)
+    # torch default init statistics are those of the reference's layers (zeros pos-emb, unit norms)
+    assert float(sd["attns.0.position_embeddings"].abs().max()) == 0.0
+    assert float((sd["block_1_1_left.norm.weight"] - 1).abs().max()) == 0.0
+    # flat buffer aliasing survives load_state_dict
+    det = orc.det_model(2, 3, 16, (32, 32, 32), 8)
+    flat = net.flat_parameters()
+    net.load_state_dict(det)
+    assert net.flat_parameters() is flat
+    _, off, numel, shape = tbl["conv1x1_d2.weight"]
+    assert torch.equal(flat[off: off + numel].view(shape), det["conv1x1_d2.weight"])
+    assert isinstance(HDenseFormer_32(4, 4, (32, 32, 32), 4), HDenseFormer)
+
+
+def test_product_path_fails_loudly_without_gpu():
+    from hdf_rt import _lib
+    from loss.combine_loss import CEPlusDice, DeepSuperloss
+    from models.HDenseFormer import HDenseFormer_16
+    net = HDenseFormer_16(in_channels=2, n_cls=3, image_size=(32, 32, 32), transformer_depth=8)
+    with pytest.raises(_lib.HdfError):
+        net(torch.zeros(1, 2, 32, 32, 32))
+    crit = DeepSuperloss(criterion=CEPlusDice(weight=None, ignore_index=0))
+    with pytest.raises(_lib.HdfError):
+        crit([torch.zeros(1, 3, 8, 8, 8)], torch.zeros(1, 3, 8, 8, 8))
+    with pytest.raises(NotImplementedError):
+        DeepSuperloss(criterion=CEPlusDice(weight=None, ignore_index=None))([torch.zeros(1)], torch.zeros(1))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "h-denseformer_amd")
+    for dp, _dn, fn in os.walk(pkg):
+        for f in fn:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, os.path.join(dp, f)

@@ -1,0 +1,171 @@
+"""GPU parity of the operator-level C ABI (include/hdf.h hdf_op_*) against plain torch fp32 CPU ops --
+the same primitives the reference composes (HDenseFormer.py:148-175,199-227).
+Tolerances: fp32 storage 2e-5 relative (max-abs / max-ref); bf16 storage 2e-2 against the reference
+evaluated on bf16-rounded inputs (fp32 accumulate, bf16 output rounding)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from hdf_rt._lib import BF16, F32, check, lib, ptr  # noqa: E402
+from hip_util import DEV, conv3d, from_cl, pack_w, rel_err, rnd, rup, st, to_cl  # noqa: E402
+
+TOL = {F32: 2e-5, BF16: 2e-2}
+
+
+def _mk(shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("cin,cout,size,n", [(16, 16, (8, 8, 8), 1), (32, 32, (12, 16, 24), 2),
+                                            (64, 32, (32, 32, 32), 1), (32, 64, (36, 36, 40), 1),
+                                            (128, 96, (6, 10, 9), 2)])
+def test_conv3d_s1(dtype, cin, cout, size, n):
+    x, w, b = _mk((n, cin) + size, 1), _mk((cout, cin, 3, 3, 3), 2) * (cin * 27) ** -0.5, _mk((cout,), 3)
+    ref = F.conv3d(rnd(x, dtype), rnd(w, dtype), b, padding=1)
+    wp = pack_w(w, dtype, cout, cin, rup(cout, 32), cin, cin * 27, 27, 0)
+    out, part = conv3d(dtype, 0, to_cl(x, dtype), cin, wp, cout, bias=b.to(DEV), stats=True)
+    torch.cuda.synchronize()
+    got = from_cl(out)
+    assert rel_err(got, ref) < TOL[dtype]
+    # statistics partials: per (n, c) sum and sum of squares of the stored output
+    tiles = part.shape[0] // n
+    s = part.view(n, tiles, -1, 2).sum(1).cpu()[:, :cout]
+    assert rel_err(s[..., 0], ref.sum((2, 3, 4))) < 5e-3 + TOL[dtype]
+    assert rel_err(s[..., 1], (ref * ref).sum((2, 3, 4))) < 5e-3 + TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_conv3d_input_transform_and_pitch(dtype):
+    """producer's InstanceNorm+ReLU applied on load; input/output are channel slices of wider buffers."""
+    n, cin, cout, size = 2, 32, 32, (8, 16, 8)
+    x, w = _mk((n, cin) + size, 4), _mk((cout, cin, 3, 3, 3), 5) * (cin * 27) ** -0.5
+    scale, shift = _mk((n, cin), 6) * 0.5 + 1.0, _mk((n, cin), 7) * 0.3
+    xa = torch.relu(rnd(x, dtype) * scale[:, :, None, None, None] + shift[:, :, None, None, None])
+    ref = F.conv3d(rnd(xa, dtype), rnd(w, dtype), None, padding=1)
+    xcl = to_cl(x, dtype)
+    wide_in = torch.zeros((n,) + size + (2 * cin,), dtype=xcl.dtype, device=DEV)
+    wide_in[..., cin:] = xcl
+    wide_out = torch.full((n,) + size + (3 * cout,), 7.0, dtype=xcl.dtype, device=DEV)
+    wp = pack_w(w, dtype, cout, cin, rup(cout, 32), cin, cin * 27, 27, 0)
+    vin = wide_in.view(-1)[cin:]
+    vout = wide_out.view(-1)[cout:]
+    sc, sh = scale.to(DEV), shift.to(DEV)
+    check(lib().hdf_op_conv3d(dtype, 0, ptr(vin), 2 * cin, cin, n, *size, ptr(wp), None, ptr(sc), ptr(sh), 1,
+                              ptr(vout), 3 * cout, cout, None, 0, st()), "conv")
+    torch.cuda.synchronize()
+    got = from_cl(wide_out[..., cout:2 * cout])
+    assert rel_err(got, ref) < TOL[dtype] * 1.5
+    assert float((wide_out[..., :cout].float() - 7).abs().max()) == 0
+    assert float((wide_out[..., 2 * cout:].float() - 7).abs().max()) == 0
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("cin,cout,size", [(32, 16, (4, 4, 4)), (64, 32, (8, 8, 8)), (128, 64, (6, 5, 7))])
+def test_conv_transpose3d(dtype, cin, cout, size):
+    n = 2
+    x, w, b = _mk((n, cin) + size, 8), _mk((cin, cout, 3, 3, 3), 9) * (cin * 27 / 8) ** -0.5, _mk((cout,), 10)
+    ref = F.conv_transpose3d(rnd(x, dtype), rnd(w, dtype), b, stride=2, padding=1, output_padding=1)
+    wp = pack_w(w, dtype, cout, cin, rup(cout, 32), cin, 27, cout * 27, 0)
+    out, _ = conv3d(dtype, 2, to_cl(x, dtype), cin, wp, cout, bias=b.to(DEV))
+    torch.cuda.synchronize()
+    assert rel_err(from_cl(out), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("cin,cout,size", [(16, 32, (8, 8, 8)), (32, 64, (16, 8, 12)), (64, 128, (10, 12, 6))])
+def test_conv3d_stride2(dtype, cin, cout, size):
+    """stride-2 gather conv == dgrad of ConvTranspose3d(k3,s2,p1,op1)"""
+    n = 1
+    x, w = _mk((n, cin) + size, 11), _mk((cout, cin, 3, 3, 3), 12) * (cin * 27) ** -0.5
+    ref = F.conv3d(rnd(x, dtype), rnd(w, dtype), None, stride=2, padding=1)
+    wp = pack_w(w, dtype, cout, cin, rup(cout, 32), cin, cin * 27, 27, 0)
+    out, _ = conv3d(dtype, 1, to_cl(x, dtype), cin, wp, cout)
+    torch.cuda.synchronize()
+    assert rel_err(from_cl(out), ref) < TOL[dtype]
+
+
+def _wgrad(dtype, stride, s_cl, sc, l_cl, lc, dims, sc_store, lc_store):
+    n = s_cl.shape[0]
+    wsb = lib().hdf_op_wgrad_workspace_bytes(stride, n, *dims, sc, lc)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    dw = torch.zeros((sc_store, lc_store, 27), dtype=torch.float32, device=DEV)
+    check(lib().hdf_op_conv3d_wgrad(dtype, stride, ptr(s_cl), s_cl.shape[-1], sc, ptr(l_cl), l_cl.shape[-1], lc, n,
+                                    *dims, None, None, 0, None, None, 0, ptr(dw), sc_store, lc_store, 0, ptr(ws), wsb,
+                                    st()), "wgrad")
+    torch.cuda.synchronize()
+    return dw.cpu()
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("cin,cout,size,n", [(16, 16, (8, 8, 8), 1), (32, 32, (12, 16, 24), 2),
+                                            (64, 48, (9, 7, 10), 2)])
+def test_conv3d_wgrad(dtype, cin, cout, size, n):
+    x, dy = _mk((n, cin) + size, 13), _mk((n, cout) + size, 14)
+    w = torch.zeros(cout, cin, 3, 3, 3, requires_grad=True)
+    F.conv3d(rnd(x, dtype), w, None, padding=1).backward(rnd(dy, dtype))
+    got = _wgrad(dtype, 1, to_cl(dy, dtype), cout, to_cl(x, dtype), cin, size, cout, cin).view(cout, cin, 3, 3, 3)
+    assert rel_err(got, w.grad) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_conv3d_wgrad_first_layer_padded_input(dtype):
+    """Cin=4 input padded to 16 channels; only the 4 real input channels are stored."""
+    n, cin, cout, size = 1, 4, 32, (8, 8, 16)
+    x, dy = _mk((n, cin) + size, 15), _mk((n, cout) + size, 16)
+    w = torch.zeros(cout, cin, 3, 3, 3, requires_grad=True)
+    F.conv3d(rnd(x, dtype), w, None, padding=1).backward(rnd(dy, dtype))
+    got = _wgrad(dtype, 1, to_cl(dy, dtype), cout, to_cl(x, dtype, cp=16), 16, size, cout, cin)
+    assert rel_err(got.view(cout, cin, 3, 3, 3), w.grad) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("cin,cout,size", [(32, 16, (4, 4, 4)), (64, 32, (6, 5, 7))])
+def test_conv_transpose3d_wgrad(dtype, cin, cout, size):
+    n = 2
+    osz = tuple(2 * s for s in size)
+    x, dy = _mk((n, cin) + size, 17), _mk((n, cout) + osz, 18)
+    w = torch.zeros(cin, cout, 3, 3, 3, requires_grad=True)
+    F.conv_transpose3d(rnd(x, dtype), w, None, stride=2, padding=1, output_padding=1).backward(rnd(dy, dtype))
+    got = _wgrad(dtype, 2, to_cl(x, dtype), cin, to_cl(dy, dtype), cout, size, cin, cout).view(cin, cout, 3, 3, 3)
+    assert rel_err(got, w.grad) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_pool_upsample(dtype):
+    n, c, size = 2, 32, (8, 12, 16)
+    x = _mk((n, c) + size, 19)
+    x[:, :, :2] = 0.0                                  # exact ties: the FIRST max must win (torch rule)
+    xr = rnd(x, dtype).requires_grad_(True)
+    x_cl = to_cl(x, dtype)
+    # --- maxpool fwd/bwd
+    po = torch.empty((n,) + tuple(s // 2 for s in size) + (c,), dtype=x_cl.dtype, device=DEV)
+    idx = torch.empty(po.shape, dtype=torch.uint8, device=DEV)
+    check(lib().hdf_op_maxpool_fwd(dtype, ptr(x_cl), c, ptr(po), c, ptr(idx), n, c, *po.shape[1:4], st()), "pool")
+    ref = F.max_pool3d(xr, 2)
+    g = _mk(tuple(ref.shape), 20)
+    ref.backward(rnd(g, dtype))
+    din = torch.zeros_like(x_cl)
+    gcl = to_cl(g, dtype)
+    check(lib().hdf_op_maxpool_bwd(dtype, ptr(gcl), c, ptr(idx), ptr(din), c, n, c, *po.shape[1:4], 0, st()), "poolb")
+    torch.cuda.synchronize()
+    assert rel_err(from_cl(po), ref.detach()) == 0
+    assert rel_err(from_cl(din), xr.grad) < 1e-6
+    # --- trilinear x2 of relu(x*scale+shift), fwd/bwd
+    scale, shift = _mk((n, c), 21) * 0.5 + 1.0, _mk((n, c), 22) * 0.3
+    xa = torch.relu(rnd(x, dtype) * scale[:, :, None, None, None] + shift[:, :, None, None, None]).requires_grad_(True)
+    ref = F.interpolate(xa, scale_factor=2, mode="trilinear", align_corners=False)
+    up = torch.empty((n,) + tuple(2 * s for s in size) + (c,), dtype=x_cl.dtype, device=DEV)
+    sc, sh = scale.to(DEV), shift.to(DEV)
+    check(lib().hdf_op_upsample_fwd(dtype, ptr(x_cl), c, ptr(sc), ptr(sh), ptr(up), c, n, c, *size, st()), "up")
+    g2 = _mk(tuple(ref.shape), 23)
+    ref.backward(rnd(g2, dtype))
+    dlo = torch.empty_like(x_cl)
+    g2cl = to_cl(g2, dtype)
+    check(lib().hdf_op_upsample_bwd(dtype, ptr(g2cl), c, ptr(dlo), c, n, c, *size, st()), "upb")
+    torch.cuda.synchronize()
+    assert rel_err(from_cl(up), ref.detach()) < TOL[dtype]
+    assert rel_err(from_cl(dlo), xa.grad) < TOL[dtype]
