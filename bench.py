@@ -1,0 +1,231 @@
+"""Benchmark of the H-DenseFormer 3D training hot path on MI355X.
+
+Metric (BASELINE.json): train samples/sec on 4x128^3 volumes.  One step = forward (4 deep-supervision
+outputs) + DeepSuperloss(CEPlusDice) + backward + gradient all-reduce (N>1) + Adam step -- the body of
+the reference's inner loop, trainer.py:369-380 -- on synthetic BraTS-shape inputs already resident in HBM.
+Workload at every N: HDenseFormer_32(in=4, n_cls=4, 128^3, transformer_depth=24), per-GPU batch 2,
+bf16 storage / fp32 accumulate (BASELINE configs[1]; configs[2] is the same at N=8).  Weak scaling.
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (plus human-readable notes on stderr)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "h-denseformer_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+FWD_BWD_GFLOP_PER_SAMPLE = 2998.4      # FlopCounterMode, 4x128^3 nf32 td24
+BF16_MFMA_PEAK_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense bf16 MFMA peak
+CFG = dict(in_channels=4, n_cls=4, n_filters=32, image_size=(128, 128, 128), transformer_depth=24)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+CPU_THREADS = 16          # torch/oneDNN on all 256 host threads of the GPU box is pathologically slow (measured:
+#                           811 s/step vs 12.6 s/step on 8 threads elsewhere), so the baseline pins 16 threads
+CPU_BUDGET_S = 150
+
+
+def _cpu_baseline_child():
+    """Runs in a child process (no GPU): the oracle's train step -- the functional torch-CPU restatement of
+    the reference path, kind 'port' -- on a BOUNDED sample: batch 1 of a 4x64^3 crop (1/8 of the voxels of
+    the 4x128^3 workload; >99 % of the step's FLOPs are convolutions, linear in voxels), 1 warm-up + 2 timed
+    steps; if that predicts < 20 s per full-size step the full 4x128^3 step is timed as well."""
+    from oracle import hdf_oracle as orc
+    nt = min(os.cpu_count() or 1, CPU_THREADS)
+    torch.set_num_threads(nt)
+
+    def time_steps(size, n_timed):
+        cfg = (CFG["in_channels"], CFG["n_cls"], CFG["n_filters"], (size,) * 3, CFG["transformer_depth"])
+        tr = orc.OracleTrainer(orc.det_model(*cfg))
+        x = torch.rand(1, 4, size, size, size)
+        lab = torch.randint(0, 4, (1, size, size, size))
+        onehot = torch.nn.functional.one_hot(lab, 4).permute(0, 4, 1, 2, 3).float()
+        tr.step(x, onehot, drop_seed=1)
+        t0 = time.time()
+        for i in range(n_timed):
+            tr.step(x, onehot, drop_seed=2 + i)
+        return (time.time() - t0) / n_timed
+
+    t64 = time_steps(64, 2)
+    rec = {"value": 1.0 / (8.0 * t64), "unit": "samples/s", "cores": nt, "kind": "port",
+           "sample": f"oracle train step (fwd + DeepSuper CE+Dice + bwd + Adam), fp32, batch 1 of a 4x64^3 crop: "
+                     f"{t64:.2f} s/step on {nt} threads, scaled x8 voxels to 4x128^3"}
+    print(json.dumps(rec), flush=True)
+    if 8.0 * t64 < 20.0:
+        t128 = time_steps(128, 1)
+        rec["value"] = 1.0 / t128
+        rec["sample"] = (f"oracle train step (fwd + DeepSuper CE+Dice + bwd + Adam), fp32, batch 1 of 4x128^3: "
+                         f"{t128:.2f} s/step on {nt} threads (1 warm-up + 1 timed; 4x64^3 crop gave {t64:.2f} s)")
+        print(json.dumps(rec), flush=True)
+
+
+def cpu_baseline():
+    """Bounded CPU baseline in a subprocess with a hard wall-clock budget; the last JSON line it printed wins."""
+    import subprocess
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(CPU_THREADS))
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child"], env=env,
+                           capture_output=True, text=True, timeout=CPU_BUDGET_S)
+        out = r.stdout
+    except subprocess.TimeoutExpired as e:
+        out = (e.stdout or b"").decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    if not lines:
+        return {"value": None, "unit": "samples/s", "cores": CPU_THREADS, "kind": "port",
+                "sample": f"oracle train step did not finish a 4x64^3 crop within {CPU_BUDGET_S} s"}
+    return json.loads(lines[-1])
+
+
+def roofline_dominant_kernel(dev):
+    """Live HIP-event timing of the dominant kernel class of the step: the bf16 implicit-GEMM conv
+    (conv_igemm_kernel) on its largest layer, block_1_1_right: 64->32 channels at 128^3, batch 2.
+    Algorithmic FLOPs per launch = 2*27*Cin*Cout*voxels*batch."""
+    from hdf_rt._lib import BF16, check, lib, ptr
+    n, cin, cout, s = 2, 64, 32, 128
+    x = torch.randn(n, s, s, s, cin, device=dev).to(torch.bfloat16)
+    w = (torch.randn(27 * 32 * cin, device=dev) * 0.02).to(torch.bfloat16)
+    out = torch.empty(n, s, s, s, cout, device=dev, dtype=torch.bfloat16)
+    tiles = lib().hdf_op_conv3d_stat_tiles(s, s, s)
+    part = torch.empty(n * tiles * 32 * 2, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def launch():
+        check(lib().hdf_op_conv3d(BF16, 0, ptr(x), cin, cin, n, s, s, s, ptr(w), None, None, None, 0, ptr(out), cout,
+                                  cout, ptr(part), 0, st), "conv")
+    for _ in range(3):
+        launch()
+    reps = 10
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    flops = 2.0 * 27 * cin * cout * (s ** 3) * n
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": None,
+            "kernel": "conv_igemm_kernel<bf16,4x8x8 tile,64ch> (block_1_1_right fwd, 64->32 @128^3, batch 2)",
+            "avg_launch_ms": ms, "flops_per_launch": flops}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=2, help="per-GPU batch")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
+    a = ap.parse_args()
+    if a.cpu_baseline_child:
+        _cpu_baseline_child()
+        return
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and world == 1 and a.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from hdf_rt import _lib
+    _lib.lib()                                       # no fallback: fail here if the HIP extension is missing
+    from hdf_rt.optim import FlatAdam
+    from loss.combine_loss import CEPlusDice, DeepSuperloss
+    from models.HDenseFormer import HDenseFormer
+
+    torch.manual_seed(0)
+    net = HDenseFormer(CFG["in_channels"], CFG["n_cls"], CFG["n_filters"], image_size=CFG["image_size"],
+                       transformer_depth=CFG["transformer_depth"]).to(dev)
+    net.train()
+    net.compute_dtype = a.dtype
+    crit = DeepSuperloss(criterion=CEPlusDice(weight=None, ignore_index=0))
+    opt = FlatAdam(net, lr=1e-3, weight_decay=1e-4)
+    sync = None
+    if world > 1:
+        from hdf_rt.parallel import GradSync
+        sync = GradSync(net)
+        net.grad_hook = sync
+
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    x = torch.rand(a.batch, 4, 128, 128, 128, generator=g).to(dev)
+    lab = torch.randint(0, 4, (a.batch, 128, 128, 128), generator=g)
+    target = torch.nn.functional.one_hot(lab, 4).permute(0, 4, 1, 2, 3).float().contiguous().to(dev)
+
+    def step():
+        opt.zero_grad()
+        outs = net(x)
+        loss = crit(outs, target)
+        loss.backward()
+        if sync is not None:
+            sync.wait()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        loss = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    last_loss = float(loss.item())
+
+    if rank == 0:
+        global_batch = a.batch * world
+        sps = global_batch * a.steps / dt
+        rec = {
+            "metric": "train samples/sec on 4x128^3 volumes", "value": sps, "unit": "samples/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": "HDenseFormer_32 3D train step (fwd + DeepSuper CE+Dice + bwd + Adam), "
+                                   "in=4 n_cls=4 128^3 transformer_depth=24 (BASELINE configs[1])",
+                       "global_batch": global_batch, "per_gpu_batch": a.batch, "parallelism": f"dp{world}",
+                       "dropout": "on (train mode)", "loss": last_loss},
+            "step_tflops": FWD_BWD_GFLOP_PER_SAMPLE * sps / 1e3,
+        }
+        if world == 1:
+            rec["roofline"] = roofline_dominant_kernel(dev)
+            if not a.no_cpu_baseline:
+                del net, opt
+                torch.cuda.empty_cache()
+                rec["cpu_baseline"] = cpu_baseline()
+                if rec["cpu_baseline"]["value"]:
+                    rec["gpu_over_cpu"] = sps / rec["cpu_baseline"]["value"]
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -210,19 +210,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     s1 += __shfl_xor(s1, 32, 64);
     s2 += __shfl_xor(s2, 32, 64);
     __syncthreads();
-    if (threadIdx.x < WN * 32 * 2) s_red[threadIdx.x] = 0.f;
-    __syncthreads();
-    if (h == 0) {
-      atomicAdd(&s_red[(wn * 32 + r) * 2 + 0], s1);  // LDS float add; WM<=4 adders per word
-      atomicAdd(&s_red[(wn * 32 + r) * 2 + 1], s2);
+    if (h == 0) {  // one slot per wave, summed below in a fixed order: bitwise reproducible statistics
+      s_red[((wm * WN + wn) * 32 + r) * 2 + 0] = s1;
+      s_red[((wm * WN + wn) * 32 + r) * 2 + 1] = s2;
     }
     __syncthreads();
     if (threadIdx.x < WN * 32) {
       int c = blockIdx.y * (WN * 32) + threadIdx.x;
       if (c < a.CoutP) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < WM; k++) {
+          t1 += s_red[(k * WN * 32 + threadIdx.x) * 2 + 0];
+          t2 += s_red[(k * WN * 32 + threadIdx.x) * 2 + 1];
+        }
         float* q = a.stat_partials + ((int64_t)blockIdx.x * a.CoutP + c) * 2;
-        q[0] = s_red[threadIdx.x * 2 + 0];
-        q[1] = s_red[threadIdx.x * 2 + 1];
+        q[0] = t1;
+        q[1] = t2;
       }
     }
   }

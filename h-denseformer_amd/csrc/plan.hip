@@ -331,8 +331,8 @@ void layout(hdf_plan* p, int B) {
     p->gA[k] = mkview(p, bp, "", k, ch[k], B);
     p->gY[k] = mkview(p, bp, "", k, ch[k], B);
     if (k < 3) {
-      p->dCat[k] = mkview(p, bp, "", k, 2 * ch[k], B);
-      p->dP[k] = mkview(p, bp, "", k + 1, ch[k], B);
+      p->dCat[k] = mkview(p, bp, "g.cat" + std::to_string(k + 1), k, 2 * ch[k], B);
+      p->dP[k] = mkview(p, bp, "g.pool" + std::to_string(k + 1), k + 1, ch[k], B);
     }
   }
   // UpConv chain: conv outputs live at levels 4,3,2,1 with channels 8nf,4nf,2nf,nf
@@ -341,8 +341,8 @@ void layout(hdf_plan* p, int B) {
     p->dUa[k] = mkview(p, bp, "", 4 - k, uc[k], B);
     p->dUy[k] = mkview(p, bp, "", 4 - k, uc[k], B);
   }
-  p->dX4 = mkview(p, bp, "", 3, 8 * nf, B);
-  p->dAttnall = mkview(p, bp, "", 4, p->M * p->DM, B);
+  p->dX4 = mkview(p, bp, "g.attnout", 3, 8 * nf, B);
+  p->dAttnall = mkview(p, bp, "g.attnall", 4, p->M * p->DM, B);
   p->ws_bytes = bp.cur;
 }
 

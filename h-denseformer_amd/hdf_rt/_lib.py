@@ -62,6 +62,10 @@ def lib():
     """Load the shared library once.  Raises if it has not been built -- there is no fallback path."""
     global _lib
     if _lib is None:
+        # torch bundles its own libamdhip64.so.7; it must be the HIP runtime of the process (it owns the
+        # device memory and streams we are handed), so make sure it is loaded BEFORE libhdf_hip.so pulls in
+        # a second copy from /opt/rocm -- two runtimes in one process cannot see each other's devices.
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise HdfError(f"{LIB_PATH} not found: build the HIP extension first "
                            f"(python h-denseformer_amd/build.py); there is no CPU/eager fallback")

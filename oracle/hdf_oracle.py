@@ -176,16 +176,19 @@ def forward(x, sd, drop_seed=None, want_intermediates=False):
     bott = _basic(_basic(_pool(ds2), sd, "block_4_1_left"), sd, "block_4_2_left") + attnout
 
     out3 = _head(bott, sd, "conv1x1_d3")
-    dec3 = _basic(_basic(torch.cat([_up_t(bott, sd, "upconv_3"), ds2], 1), sd, "block_3_1_right"), sd, "block_3_2_right")
+    cat3 = torch.cat([_up_t(bott, sd, "upconv_3"), ds2], 1)
+    dec3 = _basic(_basic(cat3, sd, "block_3_1_right"), sd, "block_3_2_right")
     out2 = _head(dec3, sd, "conv1x1_d2")
-    dec2 = _basic(_basic(torch.cat([_up_t(dec3, sd, "upconv_2"), ds1], 1), sd, "block_2_1_right"), sd, "block_2_2_right")
+    cat2 = torch.cat([_up_t(dec3, sd, "upconv_2"), ds1], 1)
+    dec2 = _basic(_basic(cat2, sd, "block_2_1_right"), sd, "block_2_2_right")
     out1 = _head(dec2, sd, "conv1x1_d1")
-    dec1 = _basic(_basic(torch.cat([_up_t(dec2, sd, "upconv_1"), ds0], 1), sd, "block_1_1_right"), sd, "block_1_2_right")
+    cat1 = torch.cat([_up_t(dec2, sd, "upconv_1"), ds0], 1)
+    dec1 = _basic(_basic(cat1, sd, "block_1_1_right"), sd, "block_1_2_right")
     out0 = _head(dec1, sd, "conv1x1")
     outs = [out0, out1, out2, out3]
     if want_intermediates:
         inter = dict(attnall=attnall, attnout=attnout, at1=at1, at2=at2, at3=at3, ds0=ds0, ds1=ds1,
-                     ds2=ds2, bottleneck=bott, dec3=dec3, dec2=dec2, dec1=dec1)
+                     ds2=ds2, bottleneck=bott, dec3=dec3, dec2=dec2, dec1=dec1, cat3=cat3, cat2=cat2, cat1=cat1)
         return outs, inter
     return outs
 

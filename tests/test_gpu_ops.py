@@ -156,7 +156,7 @@ def test_pool_upsample(dtype):
     assert rel_err(from_cl(din), xr.grad) < 1e-6
     # --- trilinear x2 of relu(x*scale+shift), fwd/bwd
     scale, shift = _mk((n, c), 21) * 0.5 + 1.0, _mk((n, c), 22) * 0.3
-    xa = torch.relu(rnd(x, dtype) * scale[:, :, None, None, None] + shift[:, :, None, None, None]).requires_grad_(True)
+    xa = torch.relu(rnd(x, dtype) * scale[:, :, None, None, None] + shift[:, :, None, None, None]).detach().requires_grad_(True)
     ref = F.interpolate(xa, scale_factor=2, mode="trilinear", align_corners=False)
     up = torch.empty((n,) + tuple(2 * s for s in size) + (c,), dtype=x_cl.dtype, device=DEV)
     sc, sh = scale.to(DEV), shift.to(DEV)
