@@ -365,20 +365,36 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   }
 }
 
-// out[(sc*LC + lc)*27 + tap] (+)= sum_g partial[g][tap][sc][lc]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw, int G, int SCp, int LCp,
-                                    int SC, int LC, int accumulate) {
-  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int64_t per = (int64_t)27 * SCp * LCp;
-  if (idx >= per) return;
-  int lc = idx % LCp;
-  int sc = (idx / LCp) % SCp;
-  int tap = idx / ((int64_t)LCp * SCp);
-  if (lc >= LC || sc >= SC) return;
-  double s = 0.0;
-  for (int g = 0; g < G; g++) s += (double)partials[(int64_t)g * per + idx];
-  float* o = dw + ((int64_t)sc * LC + lc) * 27 + tap;
-  *o = accumulate ? (*o + (float)s) : (float)s;
+// out[(sc*LC + lc)*27 + tap] (+)= sum_g partial[g][tap][sc][lc].  256 threads = 8 group-lanes x 32 entries; fixed
+// summation order (bitwise reproducible)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw,
+                                                           int G, int SCp, int LCp, int SC, int LC, int accumulate) {
+  __shared__ float red[8][32];
+  const int el = threadIdx.x & 31, gl = threadIdx.x >> 5;
+  const int64_t idx = (int64_t)blockIdx.x * 32 + el;
+  const int64_t per = (int64_t)27 * SCp * LCp;
+  float s = 0.f;
+  if (idx < per) {
+    int g = gl;
+    for (; g + 24 < G; g += 32) {
+      float a0 = partials[(int64_t)g * per + idx], a1 = partials[(int64_t)(g + 8) * per + idx];
+      float a2 = partials[(int64_t)(g + 16) * per + idx], a3 = partials[(int64_t)(g + 24) * per + idx];
+      s += (a0 + a1) + (a2 + a3);
+    }
+    for (; g < G; g += 8) s += partials[(int64_t)g * per + idx];
+  }
+  red[gl][el] = s;
+  __syncthreads();
+  if (gl == 0 && idx < per) {
+    for (int k = 1; k < 8; k++) s += red[k][el];
+    int lc = idx % LCp;
+    int sc = (idx / LCp) % SCp;
+    int tap = idx / ((int64_t)LCp * SCp);
+    if (lc < LC && sc < SC) {
+      float* o = dw + ((int64_t)sc * LC + lc) * 27 + tap;
+      *o = accumulate ? (*o + s) : s;
+    }
+  }
 }
 
 // dst[t][o][i] = src[o*so + i*si + (flip ? 26-t : t)]  (zero for o>=O or i>=I); dst is [27][OP][IP]
@@ -430,7 +446,7 @@ int launch_wgrad_t(WgradArgs a, float* dw, int sc_store, int lc_store, int accum
   a.num_tiles = a.N * ceil_div(a.Ds, TD) * ceil_div(a.Hs, TH) * ceil_div(a.Ws, TW);
   const int pairs = (a.SCp / 32) * (a.LCp / 32);
   const int64_t per = (int64_t)27 * a.SCp * a.LCp * sizeof(float);
-  int G = ceil_div(1024, pairs);
+  int G = ceil_div(512, pairs);
   G = (int)std::min<int64_t>(G, std::max<int64_t>(1, (int64_t)ws_bytes / per));
   G = std::min(G, a.num_tiles);
   a.tiles_per_group = ceil_div(a.num_tiles, G);
@@ -442,7 +458,7 @@ int launch_wgrad_t(WgradArgs a, float* dw, int sc_store, int lc_store, int accum
   hipLaunchKernelGGL((conv_wgrad_kernel<T, TD, TH, TW, S>), grid, dim3(256), 0, st, a);
   HDF_LAUNCH_CHECK();
   int64_t n = (int64_t)27 * a.SCp * a.LCp;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, st, a.partials, dw, G,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div64(n, 32)), dim3(256), 0, st, a.partials, dw, G,
                      a.SCp, a.LCp, sc_store, lc_store, accumulate);
   HDF_LAUNCH_CHECK();
   return HDF_OK;

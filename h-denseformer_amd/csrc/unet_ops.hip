@@ -38,31 +38,43 @@ __global__ void nchw_to_ndhwc_kernel(const float* __restrict__ x, T* __restrict_
 }
 
 // ------------------------------------------------------------------------------ IN statistics
-// one workgroup per (n, 32-channel group): 8 tile lanes x 32 channels, double accumulation
-__global__ __launch_bounds__(256) void in_finalize_kernel(const float* __restrict__ partials, int tiles, int C, int CP,
-                                                          int64_t vox, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float eps,
-                                                          float* __restrict__ mean, float* __restrict__ rstd,
-                                                          float* __restrict__ scale, float* __restrict__ shift) {
-  __shared__ double red[8][32][2];
+// one workgroup per (n, 32-channel group): 32 tile lanes x 32 channels, 4 independent loads in flight per
+// thread, double accumulation in a fixed order (bitwise reproducible)
+constexpr int FIN_LANES = 32;
+__global__ __launch_bounds__(1024) void in_finalize_kernel(const float* __restrict__ partials, int tiles, int C, int CP,
+                                                           int64_t vox, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps,
+                                                           float* __restrict__ mean, float* __restrict__ rstd,
+                                                           float* __restrict__ scale, float* __restrict__ shift) {
+  __shared__ double red[FIN_LANES][32][2];
   const int n = blockIdx.y, cg = blockIdx.x;
-  const int c = cg * 32 + (threadIdx.x & 31), tl = threadIdx.x >> 5;
+  const int cl = threadIdx.x & 31, c = cg * 32 + cl, tl = threadIdx.x >> 5;
   double s1 = 0.0, s2 = 0.0;
   if (c < CP) {
     const float* p = partials + ((int64_t)n * tiles * CP + c) * 2;
-    for (int t = tl; t < tiles; t += 8) {
-      float2 v = *reinterpret_cast<const float2*>(p + (int64_t)t * CP * 2);
+    const int64_t ts = (int64_t)CP * 2;
+    int t = tl;
+    for (; t + 3 * FIN_LANES < tiles; t += 4 * FIN_LANES) {
+      float2 v0 = *reinterpret_cast<const float2*>(p + (int64_t)t * ts);
+      float2 v1 = *reinterpret_cast<const float2*>(p + (int64_t)(t + FIN_LANES) * ts);
+      float2 v2 = *reinterpret_cast<const float2*>(p + (int64_t)(t + 2 * FIN_LANES) * ts);
+      float2 v3 = *reinterpret_cast<const float2*>(p + (int64_t)(t + 3 * FIN_LANES) * ts);
+      s1 += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+      s2 += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+    }
+    for (; t < tiles; t += FIN_LANES) {
+      float2 v = *reinterpret_cast<const float2*>(p + (int64_t)t * ts);
       s1 += (double)v.x;
       s2 += (double)v.y;
     }
   }
-  red[tl][threadIdx.x & 31][0] = s1;
-  red[tl][threadIdx.x & 31][1] = s2;
+  red[tl][cl][0] = s1;
+  red[tl][cl][1] = s2;
   __syncthreads();
   if (tl == 0 && c < C) {
-    for (int k = 1; k < 8; k++) {
-      s1 += red[k][threadIdx.x][0];
-      s2 += red[k][threadIdx.x][1];
+    for (int k = 1; k < FIN_LANES; k++) {
+      s1 += red[k][cl][0];
+      s2 += red[k][cl][1];
     }
     double m = s1 / (double)vox;
     double var = s2 / (double)vox - m * m;  // biased variance
@@ -485,31 +497,38 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const T* __restrict_
   }
 }
 
-// one thread per (n,c)
-__global__ void in_bwd_finalize_kernel(const float* __restrict__ partials, int blocks, int N, int C, int64_t vox,
-                                       const float* __restrict__ gamma, const float* __restrict__ rstd,
-                                       float* __restrict__ k1, float* __restrict__ ka, float* __restrict__ kb,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double tg = 0.0, tb = 0.0;
-  for (int n = 0; n < N; n++) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < blocks; b++) {
+// grid (ceil(C/32), N), 256 threads = 8 block-lanes x 32 channels
+__global__ __launch_bounds__(256) void in_bwd_finalize_kernel(const float* __restrict__ partials, int blocks, int N,
+                                                              int C, int64_t vox, const float* __restrict__ gamma,
+                                                              const float* __restrict__ rstd, float* __restrict__ k1,
+                                                              float* __restrict__ ka, float* __restrict__ kb,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ double red[8][32][2];
+  const int n = blockIdx.y, cl = threadIdx.x & 31, c = blockIdx.x * 32 + cl, bl = threadIdx.x >> 5;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C) {
+    for (int b = bl; b < blocks; b += 8) {
       const float* p = partials + (((int64_t)n * blocks + b) * C + c) * 2;
       s1 += (double)p[0];
       s2 += (double)p[1];
+    }
+  }
+  red[bl][cl][0] = s1;
+  red[bl][cl][1] = s2;
+  __syncthreads();
+  if (bl == 0 && c < C) {
+    for (int k = 1; k < 8; k++) {
+      s1 += red[k][cl][0];
+      s2 += red[k][cl][1];
     }
     int64_t o = (int64_t)n * C + c;
     float g = gamma ? gamma[c] : 1.f;
     k1[o] = g * rstd[o];
     ka[o] = (float)(s1 / (double)vox);
     kb[o] = (float)(s2 / (double)vox);
-    tb += s1;
-    tg += s2;
+    if (dgamma) atomicAdd(dgamma + c, (float)s2);  // N adders per word
+    if (dbeta) atomicAdd(dbeta + c, (float)s1);
   }
-  if (dgamma) dgamma[c] += (float)tg;
-  if (dbeta) dbeta[c] += (float)tb;
 }
 
 template <typename T>
@@ -619,7 +638,7 @@ int hdf_launch_nchw_to_ndhwc(int dtype, const float* x, void* out, int N, int C,
 int hdf_launch_in_finalize(const float* partials, int N, int tiles, int C, int CP, int64_t vox, const float* gamma,
                            const float* beta, float eps, float* mean, float* rstd, float* scale, float* shift,
                            hipStream_t st) {
-  hipLaunchKernelGGL(in_finalize_kernel, dim3(ceil_div(CP, 32), N), dim3(256), 0, st, partials, tiles, C, CP, vox, gamma,
+  hipLaunchKernelGGL(in_finalize_kernel, dim3(ceil_div(CP, 32), N), dim3(1024), 0, st, partials, tiles, C, CP, vox, gamma,
                      beta, eps, mean, rstd, scale, shift);
   HDF_LAUNCH_CHECK();
   return HDF_OK;
@@ -720,7 +739,7 @@ int hdf_launch_in_bwd_reduce(int dtype, const void* da, int64_t da_pitch, const 
 int hdf_launch_in_bwd_finalize(const float* partials, int blocks, int N, int C, int64_t vox, const float* gamma,
                                const float* rstd, float* k1, float* ka, float* kb, float* dgamma, float* dbeta,
                                hipStream_t st) {
-  hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, partials, blocks, N, C, vox, gamma,
+  hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3(ceil_div(C, 32), N), dim3(256), 0, st, partials, blocks, N, C, vox, gamma,
                      rstd, k1, ka, kb, dgamma, dbeta);
   HDF_LAUNCH_CHECK();
   return HDF_OK;
