@@ -98,7 +98,7 @@ def roofline_dominant_kernel(dev):
     x = torch.randn(n, s, s, s, cin, device=dev).to(torch.bfloat16)
     w = (torch.randn(27 * 32 * cin, device=dev) * 0.02).to(torch.bfloat16)
     out = torch.empty(n, s, s, s, cout, device=dev, dtype=torch.bfloat16)
-    tiles = lib().hdf_op_conv3d_stat_tiles(s, s, s)
+    tiles = lib().hdf_op_conv3d_stat_tiles(BF16, cin, s, s, s)
     part = torch.empty(n * tiles * 32 * 2, device=dev)
     st = torch.cuda.current_stream().cuda_stream
 

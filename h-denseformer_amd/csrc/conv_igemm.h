@@ -45,7 +45,9 @@ struct WgradArgs {
 };
 
 int hdf_launch_conv(int dtype, int mode /*0 conv s1, 1 conv s2, 2 convT*/, const ConvArgs& a, hipStream_t st);
-int hdf_conv_stat_tiles(int mode, int Do, int Ho, int Wo);  // tiles per sample for the stat partials
+// tiles per sample of the stat partials; row_bytes = Cin*sizeof(storage) selects the kernel variant (pass a
+// large value for the upper bound used to size buffers)
+int hdf_conv_stat_tiles(int mode, int Do, int Ho, int Wo, int row_bytes);
 int hdf_launch_wgrad(int dtype, int stride, WgradArgs a, float* dw, int sc_store, int lc_store, int accumulate,
                      void* workspace, size_t workspace_bytes, hipStream_t st);
 size_t hdf_wgrad_workspace_bytes(int stride, int N, int Ds, int Hs, int Ws, int SC, int LC);

@@ -64,30 +64,43 @@ __device__ __forceinline__ void stage_box(char* lds, const T* __restrict__ src, 
     }
   }
   const bool chan_ok = cbase < C;  // C is a multiple of EPC
-#pragma unroll 4
-  for (int id = threadIdx.x; id < total; id += 256) {
-    int vox = id >> cpv_shift;
-    int bz = vox / (BH * BW);
-    int rem = vox - bz * (BH * BW);
-    int by = rem / BW;
-    int bx = rem - by * BW;
-    int iz = oz + bz, iy = oy + by, ix = ox + bx;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (chan_ok && (unsigned)iz < (unsigned)D && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
-      const T* p = src + ((((int64_t)n * D + iz) * H + iy) * W + ix) * pitch + cbase;
-      v = *reinterpret_cast<const u32x4*>(p);
+  // Batches of U chunks per thread: all U loads are issued back to back (UNCONDITIONAL, from a clamped address:
+  // a per-element `if (ok) v = load` makes hipcc branch around every load and wait for each one in turn --
+  // cdna_hip_programming.md, projection-GEMM trap (c)), then transformed and written to LDS.
+  constexpr int U = 5;
+  for (int id0 = threadIdx.x; id0 < total; id0 += 256 * U) {
+    u32x4 v[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      int id = min(id0 + 256 * u, total - 1);
+      int vox = id >> cpv_shift;
+      int bz = vox / (BH * BW);
+      int rem = vox - bz * (BH * BW);
+      int by = rem / BW;
+      int bx = rem - by * BW;
+      int iz = oz + bz, iy = oy + by, ix = ox + bx;
+      ok[u] = chan_ok && (unsigned)iz < (unsigned)D && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      const T* p = ok[u] ? src + ((((int64_t)n * D + iz) * H + iy) * W + ix) * pitch + cbase : src;
+      v[u] = *reinterpret_cast<const u32x4*>(p);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      int id = id0 + 256 * u;
+      u32x4 w = v[u];
       if (xf) {
         float f[EPC];
-        ST<T>::unpack(v, f);
+        ST<T>::unpack(w, f);
 #pragma unroll
         for (int e = 0; e < EPC; e++) {
           f[e] = f[e] * sc[e] + sh[e];
           if (relu) f[e] = fmaxf(f[e], 0.f);
         }
-        v = ST<T>::pack(f);
+        w = ST<T>::pack(f);
       }
+      if (!ok[u]) w = u32x4{0u, 0u, 0u, 0u};
+      if (id < total) *reinterpret_cast<u32x4*>(lds + (id >> cpv_shift) * LPITCH + part * 16) = w;
     }
-    *reinterpret_cast<u32x4*>(lds + vox * LPITCH + part * 16) = v;
   }
 }
 
@@ -233,6 +246,337 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Weights-stationary persistent variant of mode 0 for the high-resolution layers (Cin*sizeof(T) <= 128 B).
+//  * one workgroup per CU; the whole [27][32 cout][Cin] weight panel of its output-channel tile lives in LDS
+//    for the lifetime of the workgroup (XOR-swizzled 16-B chunks instead of padding: conflict-free ds_read_b128)
+//  * the workgroup walks a CONTIGUOUS range of spatial tiles (neighbouring halos come from the same XCD's L2)
+//  * the input box of the NEXT (tile, channel-chunk) is prefetched into registers while the MFMAs of the current
+//    one run; it is normalised/ReLU'd and written to LDS after the barrier that ends the current compute phase
+//  * fragment reads are software-pipelined three steps deep (one wave per SIMD: nothing else hides LDS latency)
+//  * an MFMA M-block is a 4(z) x 1(y) x 8(x) column of voxels and MFMA row -> voxel follows ws_row_to_zx, so the
+//    16 box rows touched by every ds_read_b128 lane group are distinct modulo 16 (80-byte pitch => no conflicts)
+//  * the epilogue goes through LDS: every lane stores whole 16-byte channel chunks of a voxel row
+
+// MFMA row (0..31) -> (dz in 0..3, x in 0..7).  ds_read_b128 services lanes {0-3,12-15,20-27} and {4-11,16-19,
+// 28-31} (and the same +32) as groups; group 1 gets z in {0,2}, group 2 z in {1,3}: box row = 100*z + 10*y + x
+// (BH = BW = 10) is then distinct mod 16 inside each group.
+__device__ __forceinline__ void ws_row_to_zx(int r, int& dz, int& x) {
+  const int g2 = ((r >= 4 && r < 12) || (r >= 16 && r < 20) || r >= 28) ? 1 : 0;
+  const int rank = g2 ? (r < 12 ? r - 4 : (r < 20 ? r - 8 : r - 16)) : (r < 4 ? r : (r < 16 ? r - 8 : r - 12));
+  dz = 2 * (rank >> 3) + g2;
+  x = rank & 7;
+}
+
+// workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain the vector-memory
+// counter, so prefetch loads and epilogue stores stay in flight across it
+#define WS_BARRIER()                                     \
+  do {                                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+    __builtin_amdgcn_s_barrier();                        \
+    asm volatile("" ::: "memory");                       \
+  } while (0)
+
+template <typename T, int TD, int TH, int TW, int MB, int RBMAX, int NFS>
+__global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int tiles_total, int tiles_per_wg) {
+  static_assert(TH == 8 && TW == 8 && TD % 4 == 0, "M-block = 4(z) x 1(y) x 8(x)");
+  static_assert(4 * MB * 32 == TD * TH * TW, "tile/wave decomposition");
+  constexpr int BD = TD + 2, BH = TH + 2, BW = TW + 2, BOX = BD * BH * BW;
+  constexpr int ESZ = sizeof(T), EPC = ST<T>::EPC;
+  constexpr int NJ = (BOX * 4 + 255) / 256;
+  constexpr int ZB = TD / 4;                       // M-blocks per y row
+  constexpr int OPITCH = 32 * ESZ + 16;            // epilogue staging pitch (32 channels per voxel row)
+  constexpr int MT = TD * TH * TW;
+  static_assert(MT * OPITCH <= BOX * PITCH, "epilogue staging fits in the tile buffer");
+  __shared__ __attribute__((aligned(16))) char lds[BOX * PITCH + 1024 + 27 * 32 * RBMAX];
+  char* a_lds = lds;
+  float* s_red = reinterpret_cast<float*>(lds + BOX * PITCH);
+  char* w_lds = lds + BOX * PITCH + 1024;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int n0 = blockIdx.y * 32;
+  const int RB = a.Cin * ESZ;              // weight row bytes: 32, 64 or 128
+  const int cpr = RB >> 4, rp256 = 16 / cpr;
+  const int chunk_bytes = min(64, RB);     // activation chunk staged per pass (== 32 * NFS)
+  const int nchunks = RB / chunk_bytes;
+  const int cpv = chunk_bytes >> 4, cpv_shift = (cpv == 4) ? 2 : 1;
+  const int total = BOX << cpv_shift;
+  const int part = threadIdx.x & (cpv - 1);
+  const bool xf = (a.in_scale != nullptr);
+
+  // ---- weights -> LDS, once
+  for (int id = threadIdx.x; id < 27 * 32 * cpr; id += 256) {
+    int row = id / cpr, ch = id - row * cpr;
+    int tap = row >> 5, rr = row & 31;
+    u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a.w) +
+                                              ((int64_t)(tap * a.CoutP + n0 + rr) * a.Cin) * ESZ + ch * 16);
+    int sw = ch ^ ((row / rp256) & (cpr - 1));
+    *reinterpret_cast<u32x4*>(w_lds + row * RB + sw * 16) = v;
+  }
+  const int bswz = (r / rp256) & (cpr - 1);  // (tap*32 + r)/rp256 & (cpr-1) == this, since 32/rp256 % cpr == 0
+
+  const int ntz = (a.Do + TD - 1) / TD, nty = (a.Ho + TH - 1) / TH, ntx = (a.Wo + TW - 1) / TW;
+  int rowbase[MB];
+  {
+    int dz, x;
+    ws_row_to_zx(r, dz, x);
+#pragma unroll
+    for (int mb = 0; mb < MB; mb++) {
+      const int mbi = wave * MB + mb, y = mbi / ZB, zb = 4 * (mbi % ZB);
+      rowbase[mb] = (((zb + dz) * BH + y) * BW + x) * PITCH + h * 16;
+    }
+  }
+  const int t_begin = blockIdx.x * tiles_per_wg, t_end = min(tiles_total, t_begin + tiles_per_wg);
+  const int nitems = (t_end - t_begin) * nchunks;
+  if (nitems <= 0) return;
+
+  // per-thread constants of the staging slots: element offset of the slot's voxel relative to the box origin and
+  // its packed box coordinates
+  int boff[NJ], bxyz[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
+    int vox = min((int)threadIdx.x + 256 * j, total - 1) >> cpv_shift;
+    int bz = vox / (BH * BW), rem = vox - bz * (BH * BW), by = rem / BW, bx = rem - by * BW;
+    boff[j] = ((bz * a.Hi + by) * a.Wi + bx) * (int)a.in_pitch;
+    bxyz[j] = (bz << 16) | (by << 8) | bx;
+  }
+
+  u32x4 pf[NJ];
+  uint32_t pf_valid = 0;
+  auto tile_origin = [&](int tile, int& n, int& z0, int& y0, int& x0) {
+    int t = tile;
+    x0 = (t % ntx) * TW;
+    t /= ntx;
+    y0 = (t % nty) * TH;
+    t /= nty;
+    z0 = (t % ntz) * TD;
+    n = t / ntz;
+  };
+  // interior tiles (box entirely inside the volume, ~70 % of them) skip every bounds test / select
+  auto is_interior = [&](int z0, int y0, int x0) {
+    return z0 >= 1 && y0 >= 1 && x0 >= 1 && z0 + TD + 1 <= a.Di && y0 + TH + 1 <= a.Hi && x0 + TW + 1 <= a.Wi;
+  };
+  bool pf_interior = false;
+  auto prefetch = [&](int item) {
+    int tile = t_begin + item / nchunks, c0 = (item % nchunks) * (chunk_bytes / ESZ);
+    int n, z0, y0, x0;
+    tile_origin(tile, n, z0, y0, x0);
+    const T* src = reinterpret_cast<const T*>(a.in) + c0 + part * EPC;
+    const T* org = src + ((((int64_t)n * a.Di + (z0 - 1)) * a.Hi + (y0 - 1)) * a.Wi + (x0 - 1)) * a.in_pitch;
+    pf_interior = is_interior(z0, y0, x0);
+#ifdef WS_DBG_SKIP_LOADS
+    pf_interior = true;
+    for (int j = 0; j < NJ; j++) pf[j] = u32x4{(uint32_t)item, 0u, 0u, 0u};
+    return;
+#endif
+    if (pf_interior) {
+#pragma unroll
+      for (int j = 0; j < NJ; j++) pf[j] = *reinterpret_cast<const u32x4*>(org + boff[j]);
+      return;
+    }
+    pf_valid = 0;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      int iz = z0 - 1 + (bxyz[j] >> 16), iy = y0 - 1 + ((bxyz[j] >> 8) & 255), ix = x0 - 1 + (bxyz[j] & 255);
+      bool ok = (int)threadIdx.x + 256 * j < total && (unsigned)iz < (unsigned)a.Di && (unsigned)iy < (unsigned)a.Hi &&
+                (unsigned)ix < (unsigned)a.Wi;
+      // unconditional load from a clamped address (never branch around a load: the loads of one prefetch must
+      // all be in flight together); out-of-volume voxels are zeroed at commit time through pf_valid
+      const T* p = ok ? org + boff[j] : src;
+      pf[j] = *reinterpret_cast<const u32x4*>(p);
+      pf_valid |= (ok ? 1u : 0u) << j;
+    }
+  };
+  auto commit = [&](int item) {  // registers -> (transform) -> LDS
+    int c0 = (item % nchunks) * (chunk_bytes / ESZ);
+    int n = 0;
+    float sc[EPC], sh[EPC];
+    if (xf) {
+      int z0, y0, x0;
+      tile_origin(t_begin + item / nchunks, n, z0, y0, x0);
+#pragma unroll
+      for (int e = 0; e < EPC; e++) {
+        sc[e] = a.in_scale[(int64_t)n * a.Cin + c0 + part * EPC + e];
+        sh[e] = a.in_shift[(int64_t)n * a.Cin + c0 + part * EPC + e];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      int id = threadIdx.x + 256 * j;
+      if (id < total) {
+        u32x4 v = pf[j];
+        if (xf) {
+          float f[EPC];
+          ST<T>::unpack(v, f);
+#pragma unroll
+          for (int e = 0; e < EPC; e++) {
+            f[e] = f[e] * sc[e] + sh[e];
+            if (a.in_relu) f[e] = fmaxf(f[e], 0.f);
+          }
+          v = ST<T>::pack(f);
+        }
+        if (!pf_interior && !((pf_valid >> j) & 1u)) v = u32x4{0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4*>(a_lds + (id >> cpv_shift) * PITCH + part * 16) = v;
+      }
+    }
+  };
+
+  f32x16 acc[MB];
+  const int ch = n0 + r;
+  const bool ch_ok = ch < a.Cout;
+  const float bias = (a.bias && ch_ok) ? a.bias[ch] : 0.f;
+  T* outp = reinterpret_cast<T*>(a.out);
+  // epilogue constants: staging offset and (dz,x) of accumulator register i of this lane
+  int erow[16], ezx[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    int dz, x;
+    ws_row_to_zx((i & 3) + 8 * (i >> 2) + 4 * h, dz, x);
+    erow[i] = ((dz * TH) * TW + x) * OPITCH;
+    ezx[i] = (dz << 4) | x;
+  }
+
+#ifdef WS_DBG_STAMPS
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP(k)                                                   \
+  {                                                                \
+    __builtin_amdgcn_sched_barrier(0);                             \
+    unsigned long long t_ = __builtin_amdgcn_s_memtime();          \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                            \
+    __builtin_amdgcn_sched_barrier(0);                             \
+    tacc[k] += t_ - tlast;                                         \
+    tlast = t_;                                                    \
+  }
+  unsigned long long tlast = __builtin_amdgcn_s_memtime();
+#else
+#define STAMP(k)
+#endif
+  prefetch(0);
+  for (int item = 0; item < nitems; item++) {
+    const int chunk = item % nchunks;
+    STAMP(7)
+    commit(item);
+    STAMP(0)
+    WS_BARRIER();
+    STAMP(1)
+    if (item + 1 < nitems) prefetch(item + 1);
+    STAMP(2)
+    if (chunk == 0) {
+#pragma unroll
+      for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[mb][i] = 0.f;
+    }
+    const int lc0 = (chunk * chunk_bytes) >> 4;  // first 16-B chunk of this pass within a weight row
+    {
+      constexpr int NS = 27 * NFS, DEPTH = 3;
+      u32x4 bq[DEPTH], aq[DEPTH][MB];
+      auto load_step = [&](int s_, u32x4& bf, u32x4 (&af)[MB]) {
+        const int tap = s_ / NFS, fs = s_ % NFS;
+        const int jz = tap / 9, jy = (tap / 3) % 3, jx = tap % 3;
+        const int tapoff = ((jz * BH + jy) * BW + jx) * PITCH + fs * 32;
+        bf = *reinterpret_cast<const u32x4*>(w_lds + (tap * 32 + r) * RB + (((lc0 + fs * 2 + h) ^ bswz) << 4));
+#pragma unroll
+        for (int mb = 0; mb < MB; mb++) af[mb] = *reinterpret_cast<const u32x4*>(a_lds + rowbase[mb] + tapoff);
+      };
+#pragma unroll
+      for (int s0 = 0; s0 < DEPTH - 1; s0++) load_step(s0, bq[s0], aq[s0]);
+#ifdef WS_DBG_SKIP_MMA
+      constexpr int NSRUN = 1;
+#else
+      constexpr int NSRUN = NS;
+#endif
+#pragma unroll
+      for (int s_ = 0; s_ < NSRUN; s_++) {
+        if (s_ + DEPTH - 1 < NS) load_step(s_ + DEPTH - 1, bq[(s_ + DEPTH - 1) % DEPTH], aq[(s_ + DEPTH - 1) % DEPTH]);
+        __builtin_amdgcn_sched_barrier(0);  // keep the look-ahead reads ABOVE this step's MFMAs
+#pragma unroll
+        for (int mb = 0; mb < MB; mb++) Mma<T>::run(aq[s_ % DEPTH][mb], bq[s_ % DEPTH], acc[mb]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    STAMP(3)
+    WS_BARRIER();  // every wave is done reading the tile buffer
+    STAMP(4)
+    if (chunk == nchunks - 1) {
+      // ---- epilogue: accumulators (+bias) -> LDS rows [voxel][32 ch] -> whole 16-byte chunks to HBM
+      const int tile = t_begin + item / nchunks;
+      int n, z0, y0, x0;
+      tile_origin(tile, n, z0, y0, x0);
+      float s1 = 0.f, s2 = 0.f;
+      const bool full = ch_ok && z0 + TD <= a.Do && y0 + TH <= a.Ho && x0 + TW <= a.Wo;  // whole tile in range
+#pragma unroll
+      for (int mb = 0; mb < MB; mb++) {
+        const int mbi = wave * MB + mb, y = mbi / ZB, zb = 4 * (mbi % ZB);
+        const bool y_ok = (y0 + y) < a.Ho;
+        char* orow = a_lds + ((zb * TH + y) * TW) * OPITCH + r * ESZ;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          float v = acc[mb][i] + bias;
+          T tv;
+          ST<T>::st(&tv, v);
+          *reinterpret_cast<T*>(orow + erow[i]) = tv;
+          if (full) {
+            s1 += v;
+            s2 += v * v;
+          } else if (ch_ok && y_ok && (z0 + zb + (ezx[i] >> 4)) < a.Do && (x0 + (ezx[i] & 15)) < a.Wo) {
+            s1 += v;
+            s2 += v * v;
+          }
+        }
+      }
+      if (a.stat_partials) {
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (h == 0) {
+          s_red[(wave * 32 + r) * 2 + 0] = s1;
+          s_red[(wave * 32 + r) * 2 + 1] = s2;
+        }
+      }
+      WS_BARRIER();
+      constexpr int CPO = 32 * ESZ / 16;  // 16-byte chunks per staged voxel row
+      const int opart = threadIdx.x & (CPO - 1);
+      const bool oc_ok = n0 + opart * EPC < a.Cout;
+#pragma unroll
+      for (int k = 0; k < MT * CPO / 256; k++) {
+        const int lv = (threadIdx.x + 256 * k) / CPO;
+        const int z = lv / (TH * TW), y = (lv / TW) % TH, x = lv % TW;
+        const int gz = z0 + z, gy = y0 + y, gx = x0 + x;
+        if (oc_ok && gz < a.Do && gy < a.Ho && gx < a.Wo) {
+          u32x4 v = *reinterpret_cast<const u32x4*>(a_lds + lv * OPITCH + opart * 16);
+          T* p = outp + ((((int64_t)n * a.Do + gz) * a.Ho + gy) * a.Wo + gx) * a.out_pitch + n0 + opart * EPC;
+          if (a.accumulate) {
+            float f[EPC], g[EPC];
+            ST<T>::unpack(v, f);
+            ST<T>::unpack(*reinterpret_cast<const u32x4*>(p), g);
+#pragma unroll
+            for (int e = 0; e < EPC; e++) f[e] += g[e];
+            v = ST<T>::pack(f);
+          }
+          *reinterpret_cast<u32x4*>(p) = v;
+        }
+      }
+      if (a.stat_partials && threadIdx.x < 32) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          t1 += s_red[(k * 32 + threadIdx.x) * 2 + 0];
+          t2 += s_red[(k * 32 + threadIdx.x) * 2 + 1];
+        }
+        float* q = a.stat_partials + ((int64_t)tile * a.CoutP + n0 + threadIdx.x) * 2;
+        q[0] = t1;
+        q[1] = t2;
+      }
+      WS_BARRIER();  // staging rows consumed before the next commit overwrites the tile buffer
+      STAMP(5)
+    }
+  }
+#ifdef WS_DBG_STAMPS
+  if (threadIdx.x == 0 && blockIdx.y == 0)
+    for (int k = 0; k < 8; k++) a.stat_partials[(int64_t)blockIdx.x * 8 + k] = (float)tacc[k];
+#endif
+}
+
 // weight gradient:  D[tap][sc][lc] = sum_{n,i} S[n,i][sc] * L[n, STRIDE*i-1+tap][lc]
 // bf16: both operands are contracted over VOXELS, which are the slow axis of the channels-last LDS
 // rows -> read with ds_read_b64_tr_b16 (hardware transpose, 4 voxels x 16 channels per 16 lanes).
@@ -423,10 +767,32 @@ int launch_cfg(const ConvArgs& a, hipStream_t st) {
 
 // tile-shape choice: shared by the launcher and by hdf_conv_stat_tiles (partials geometry)
 inline bool small_tile(int Do, int Ho, int Wo) { return (int64_t)Do * Ho * Wo <= 32 * 32 * 32 / 2; }
+// weights-stationary kernel: mode 0, whole Cin row <= 128 B, enough tiles to amortise the weight panel
+inline int ws_cfg(int mode, int Do, int Ho, int Wo, int row_bytes) {
+  if (mode != 0 || row_bytes > 128 || (int64_t)Do * Ho * Wo < 48 * 48 * 48) return 0;
+  return row_bytes <= 64 ? 2 : 1;  // 2: 8x8x8 tile, 4 M-blocks per wave; 1: 4x8x8 tile, 2 M-blocks per wave
+}
+
+template <typename T, int TD, int TH, int TW, int MB, int RBMAX, int NFS>
+int launch_ws(const ConvArgs& a, hipStream_t st) {
+  const int tiles = a.N * ceil_div(a.Do, TD) * ceil_div(a.Ho, TH) * ceil_div(a.Wo, TW);
+  const int cout_tiles = a.CoutP / 32;
+  int gx = std::min(tiles, std::max(1, 256 / cout_tiles));
+  const int tpw = ceil_div(tiles, gx);
+  gx = ceil_div(tiles, tpw);
+  hipLaunchKernelGGL((conv_ws_kernel<T, TD, TH, TW, MB, RBMAX, NFS>), dim3(gx, cout_tiles), dim3(256), 0, st, a, tiles,
+                     tpw);
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
 
 template <typename T>
 int launch_conv_t(int mode, const ConvArgs& a, hipStream_t st) {
   if (mode == 0) {
+    const int ws = ws_cfg(mode, a.Do, a.Ho, a.Wo, a.Cin * (int)sizeof(T));
+    if (ws == 2 && a.Cin * (int)sizeof(T) == 32) return launch_ws<T, 8, 8, 8, 4, 64, 1>(a, st);
+    if (ws == 2) return launch_ws<T, 8, 8, 8, 4, 64, 2>(a, st);
+    if (ws == 1) return launch_ws<T, 4, 8, 8, 2, 128, 2>(a, st);
     if (small_tile(a.Do, a.Ho, a.Wo)) return launch_cfg<T, 4, 4, 8, 2, 2, 2, 1, false>(a, st);  // 128 vox x 64 ch
     if (a.CoutP <= 32) return launch_cfg<T, 4, 8, 8, 4, 1, 2, 1, false>(a, st);                  // 256 vox x 32 ch
     return launch_cfg<T, 4, 8, 8, 2, 2, 4, 1, false>(a, st);                                     // 256 vox x 64 ch
@@ -466,8 +832,9 @@ int launch_wgrad_t(WgradArgs a, float* dw, int sc_store, int lc_store, int accum
 
 }  // namespace
 
-int hdf_conv_stat_tiles(int mode, int Do, int Ho, int Wo) {
+int hdf_conv_stat_tiles(int mode, int Do, int Ho, int Wo, int row_bytes) {
   if (mode != 0) return 0;
+  if (ws_cfg(mode, Do, Ho, Wo, row_bytes) == 2) return ceil_div(Do, 8) * ceil_div(Ho, 8) * ceil_div(Wo, 8);
   if (small_tile(Do, Ho, Wo)) return ceil_div(Do, 4) * ceil_div(Ho, 4) * ceil_div(Wo, 8);
   return ceil_div(Do, 4) * ceil_div(Ho, 8) * ceil_div(Wo, 8);
 }

@@ -318,7 +318,7 @@ void layout(hdf_plan* p, int B) {
   // ---- scratch shared by forward and backward
   size_t maxtiles = 0;
   for (int l = 0; l < 5; l++)
-    maxtiles = std::max<size_t>(maxtiles, hdf_conv_stat_tiles(0, p->dims[l][0], p->dims[l][1], p->dims[l][2]));
+    maxtiles = std::max<size_t>(maxtiles, hdf_conv_stat_tiles(0, p->dims[l][0], p->dims[l][1], p->dims[l][2], 1 << 20));
   p->stat_partials = bp.take((size_t)B * maxtiles * round_up(8 * nf, 32) * 2 * sizeof(float));
   // ---- backward scratch
   p->tf_scratch = bp.take((size_t)rows * std::max(160, p->DM) * sizeof(float));
@@ -394,7 +394,7 @@ int conv_forward(Exec& e, Conv3& c, const View& in, Xf xf) {
   a.stat_partials = e.f(p->stat_partials);
   a.accumulate = 0;
   HDF_TRY(hdf_launch_conv(p->dtype, 0, a, e.st));
-  int tiles = hdf_conv_stat_tiles(0, d[0], d[1], d[2]);
+  int tiles = hdf_conv_stat_tiles(0, d[0], d[1], d[2], c.CinP * p->esz);
   HDF_TRY(hdf_launch_in_finalize(e.f(p->stat_partials), e.B, tiles, c.Cout, CoutP, p->vox(c.lvl), e.P(c.gamma),
                                  e.P(c.beta), 1e-5f, e.f(c.st.mean), e.f(c.st.rstd), e.f(c.st.scale),
                                  e.f(c.st.shift), e.st));
@@ -953,7 +953,9 @@ int hdf_op_conv3d(int dtype, int mode, const void* in, int64_t in_pitch, int Cin
   a.accumulate = accumulate;
   return hdf_launch_conv(dtype, mode, a, (hipStream_t)stream);
 }
-int hdf_op_conv3d_stat_tiles(int Do, int Ho, int Wo) { return hdf_conv_stat_tiles(0, Do, Ho, Wo); }
+int hdf_op_conv3d_stat_tiles(int dtype, int Cin, int Do, int Ho, int Wo) {
+  return hdf_conv_stat_tiles(0, Do, Ho, Wo, Cin * (dtype == HDF_BF16 ? 2 : 4));
+}
 int64_t hdf_op_wgrad_workspace_bytes(int stride, int N, int Ds, int Hs, int Ws, int SC, int LC) {
   return (int64_t)hdf_wgrad_workspace_bytes(stride, N, Ds, Hs, Ws, SC, LC);
 }

@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libhdf_hip.so")
+LIB_PATH = os.environ.get("HDF_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libhdf_hip.so")
 
 F32, BF16 = 0, 1
 
@@ -37,7 +37,7 @@ _PROTOS = {
     "hdf_op_pack_weights": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i, _vp]),
     "hdf_op_conv3d": (_i, [_i, _i, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i64, _i, _vp, _i,
                            _vp]),
-    "hdf_op_conv3d_stat_tiles": (_i, [_i, _i, _i]),
+    "hdf_op_conv3d_stat_tiles": (_i, [_i, _i, _i, _i, _i]),
     "hdf_op_wgrad_workspace_bytes": (_i64, [_i, _i, _i, _i, _i, _i, _i]),
     "hdf_op_conv3d_wgrad": (_i, [_i, _i, _vp, _i64, _i, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i,
                                  _vp, _i, _i, _i, _vp, _i64, _vp]),

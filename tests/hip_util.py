@@ -56,7 +56,7 @@ def conv3d(dtype, mode, x_cl, cin, w_packed, cout, bias=None, scale=None, shift=
         out_pitch = cout
     part = None
     if stats:
-        tiles = lib().hdf_op_conv3d_stat_tiles(od, oh, ow)
+        tiles = lib().hdf_op_conv3d_stat_tiles(dtype, cin, od, oh, ow)
         part = torch.zeros((n * tiles, rup(cout, 32), 2), dtype=torch.float32, device=DEV)
     check(lib().hdf_op_conv3d(dtype, mode, ptr(x_cl), pitch, cin, n, d, h, w, ptr(w_packed), ptr(bias), ptr(scale),
                               ptr(shift), relu, ptr(out), out_pitch, cout, ptr(part), accumulate, st()), "conv3d")

@@ -22,7 +22,11 @@ def _mk(shape, seed):
 @pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("cin,cout,size,n", [(16, 16, (8, 8, 8), 1), (32, 32, (12, 16, 24), 2),
                                             (64, 32, (32, 32, 32), 1), (32, 64, (36, 36, 40), 1),
-                                            (128, 96, (6, 10, 9), 2)])
+                                            (128, 96, (6, 10, 9), 2),
+                                            # >= 48^3: the weights-stationary persistent kernel (conv_ws_kernel)
+                                            (16, 32, (48, 48, 48), 1), (32, 32, (48, 56, 64), 2),
+                                            (64, 32, (48, 48, 50), 1), (32, 64, (52, 48, 48), 1),
+                                            (16, 48, (49, 51, 53), 1)])
 def test_conv3d_s1(dtype, cin, cout, size, n):
     x, w, b = _mk((n, cin) + size, 1), _mk((cout, cin, 3, 3, 3), 2) * (cin * 27) ** -0.5, _mk((cout,), 3)
     ref = F.conv3d(rnd(x, dtype), rnd(w, dtype), b, padding=1)
@@ -39,9 +43,9 @@ def test_conv3d_s1(dtype, cin, cout, size, n):
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
-def test_conv3d_input_transform_and_pitch(dtype):
+@pytest.mark.parametrize("n,cin,cout,size", [(2, 32, 32, (8, 16, 8)), (2, 32, 32, (48, 48, 56)), (1, 64, 32, (50, 48, 48))])
+def test_conv3d_input_transform_and_pitch(dtype, n, cin, cout, size):
     """producer's InstanceNorm+ReLU applied on load; input/output are channel slices of wider buffers."""
-    n, cin, cout, size = 2, 32, 32, (8, 16, 8)
     x, w = _mk((n, cin) + size, 4), _mk((cout, cin, 3, 3, 3), 5) * (cin * 27) ** -0.5
     scale, shift = _mk((n, cin), 6) * 0.5 + 1.0, _mk((n, cin), 7) * 0.3
     xa = torch.relu(rnd(x, dtype) * scale[:, :, None, None, None] + shift[:, :, None, None, None])

@@ -1,0 +1,66 @@
+"""Micro-driver for profiling one conv / wgrad shape through the C ABI (used with rocprofv3 --pmc)."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "h-denseformer_amd")):
+    sys.path.insert(0, p)
+import torch
+
+from hdf_rt._lib import BF16, F32, check, lib, ptr
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--op", default="conv")
+ap.add_argument("--cin", type=int, default=64)
+ap.add_argument("--cout", type=int, default=32)
+ap.add_argument("--size", type=int, default=128)
+ap.add_argument("--n", type=int, default=2)
+ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--xf", type=int, default=0)
+ap.add_argument("--dtype", default="bf16")
+a = ap.parse_args()
+dt = BF16 if a.dtype == "bf16" else F32
+tdt = torch.bfloat16 if dt == BF16 else torch.float32
+dev = "cuda:0"
+n, cin, cout, s = a.n, a.cin, a.cout, a.size
+st = torch.cuda.current_stream().cuda_stream
+x = torch.randn(n, s, s, s, cin, device=dev).to(tdt)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+if a.op == "conv":
+    coutp = (cout + 31) // 32 * 32
+    w = (torch.randn(27 * coutp * cin, device=dev) * 0.02).to(tdt)
+    out = torch.empty(n, s, s, s, cout, device=dev, dtype=tdt)
+    tiles = lib().hdf_op_conv3d_stat_tiles(dt, cin, s, s, s)
+    part = torch.empty(n * tiles * coutp * 2, device=dev)
+    sc = torch.rand(n, cin, device=dev) + 0.5 if a.xf else None
+    sh = torch.randn(n, cin, device=dev) * 0.1 if a.xf else None
+
+    def launch():
+        check(lib().hdf_op_conv3d(dt, 0, ptr(x), cin, cin, n, s, s, s, ptr(w), None, ptr(sc), ptr(sh), 1, ptr(out), cout,
+                                  cout, ptr(part), 0, st), "conv")
+    flops = 2.0 * 27 * cin * cout * s ** 3 * n
+else:
+    dy = torch.randn(n, s, s, s, cout, device=dev).to(tdt)
+    wsb = lib().hdf_op_wgrad_workspace_bytes(1, n, s, s, s, cout, cin)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    dw = torch.zeros(cout, cin, 27, device=dev)
+
+    def launch():
+        check(lib().hdf_op_conv3d_wgrad(dt, 1, ptr(dy), cout, cout, ptr(x), cin, cin, n, s, s, s, None, None, 0, None,
+                                        None, 0, ptr(dw), cout, cin, 0, ptr(ws), wsb, st), "wgrad")
+    flops = 2.0 * 27 * cin * cout * s ** 3 * n
+launch()
+torch.cuda.synchronize()
+e0.record()
+for _ in range(a.reps):
+    launch()
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / a.reps
+if os.environ.get("WS_STAMPS") and a.op == "conv":
+    t = part[:256 * 8].view(256, 8).double().cpu()
+    names = ["commit", "barrier1", "prefetch-issue", "mfma-loop", "barrier2", "epilogue", "-", "loop-top"]
+    tot = t.sum(1).mean().item()
+    print("  per-WG cycles (mean over WGs):", {n: int(v) for n, v in zip(names, t.mean(0).tolist())}, "total", int(tot))
+print(f"{a.op} {cin}->{cout} @{s}^3 n={n} {a.dtype} xf={a.xf}: {ms*1e3:.1f} us  {flops/ms/1e9:.1f} TFLOP/s")
