@@ -617,6 +617,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
   for (int j = 0; j < TAPS_PER_WAVE; j++) {
     int tap = wave * TAPS_PER_WAVE + j;
+    if (tap >= 27) tap = 0;  // dummy slot of the last wave (never stored)
     int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
     tapoff[j] = ((kz * BH + ky) * BW + kx) * LP;
   }
@@ -624,29 +625,118 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 
   const int t_begin = blockIdx.x * a.tiles_per_group;
   const int t_end = min(a.num_tiles, t_begin + a.tiles_per_group);
-  for (int tile = t_begin; tile < t_end; tile++) {
+  auto tile_origin = [&](int tile, int& n, int& z0, int& y0, int& x0) {
     int t = tile;
-    const int tx = t % ntx;
+    x0 = (t % ntx) * TW;
     t /= ntx;
-    const int ty = t % nty;
+    y0 = (t % nty) * TH;
     t /= nty;
-    const int tz = t % ntz;
-    const int n = t / ntz;
-    const int z0 = tz * TD, y0 = ty * TH, x0 = tx * TW;
-    if (tile > t_begin) __syncthreads();
-    // S tile: MT voxels stored linearly (z,y,x) -> stage as a TDxTHxTW box at (z0,y0,x0)
-    stage_box<T, TD, TH, TW, ROWB, LP>(s_lds, reinterpret_cast<const T*>(a.sm), a.sm_pitch, a.SC, n, a.Ds, a.Hs, a.Ws,
-                                       z0, y0, x0, scb * 32, ROWB, a.sm_scale, a.sm_shift, a.sm_relu);
-    stage_box<T, BD, BH, BW, ROWB, LP>(l_lds, reinterpret_cast<const T*>(a.lg), a.lg_pitch, a.LC, n, a.Dl, a.Hl, a.Wl,
-                                       S * z0 - 1, S * y0 - 1, S * x0 - 1, lcb * 32, ROWB, a.lg_scale, a.lg_shift,
-                                       a.lg_relu);
-    __syncthreads();
+    z0 = (t % ntz) * TD;
+    n = t / ntz;
+  };
 
-    if constexpr (sizeof(T) == 2) {
-      // lane roles for ds_read_b64_tr_b16: group g4 = lane>>4 ; within group i = lane&15, q = i>>2, p = i&3
-      const int g4 = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
-      const int hh = g4 >> 1, cb = (g4 & 1) * 16;
-      const int colb = (cb + 4 * p) * 2;
+  if constexpr (sizeof(T) == 2) {
+    // ---- bf16: register-prefetched tiles (the next tile's global loads fly during this tile's MFMAs) ----------
+    constexpr int CPV = ROWB / 16;                       // 4 chunks of 16 B per voxel row
+    constexpr int BOXL = BD * BH * BW;
+    constexpr int NS_ = (MT * CPV + 255) / 256, NL_ = (BOXL * CPV + 255) / 256;
+    constexpr int EPC = ST<T>::EPC;
+    const int part = threadIdx.x & (CPV - 1);
+    u32x4 ps[NS_], pl[NL_];
+    uint32_t vs = 0, vl = 0;
+    auto prefetch = [&](int tile) {
+      int n, z0, y0, x0;
+      tile_origin(tile, n, z0, y0, x0);
+      const T* ssrc = reinterpret_cast<const T*>(a.sm) + scb * 32 + part * EPC;
+      const T* lsrc = reinterpret_cast<const T*>(a.lg) + lcb * 32 + part * EPC;
+      const bool sc_ok = scb * 32 + part * EPC < a.SC, lc_ok = lcb * 32 + part * EPC < a.LC;
+      vs = vl = 0;
+#pragma unroll
+      for (int j = 0; j < NS_; j++) {
+        int vox = min((int)threadIdx.x + 256 * j, MT * CPV - 1) / CPV;
+        int bz = vox / (TH * TW), rem = vox - bz * (TH * TW), by = rem / TW, bx = rem - by * TW;
+        int iz = z0 + bz, iy = y0 + by, ix = x0 + bx;
+        bool ok = sc_ok && iz < a.Ds && iy < a.Hs && ix < a.Ws;
+        const T* p = ok ? ssrc + ((((int64_t)n * a.Ds + iz) * a.Hs + iy) * a.Ws + ix) * a.sm_pitch : ssrc - part * EPC - scb * 32;
+        ps[j] = *reinterpret_cast<const u32x4*>(p);
+        vs |= (ok ? 1u : 0u) << j;
+      }
+#pragma unroll
+      for (int j = 0; j < NL_; j++) {
+        int vox = min((int)threadIdx.x + 256 * j, BOXL * CPV - 1) / CPV;
+        int bz = vox / (BH * BW), rem = vox - bz * (BH * BW), by = rem / BW, bx = rem - by * BW;
+        int iz = S * z0 - 1 + bz, iy = S * y0 - 1 + by, ix = S * x0 - 1 + bx;
+        bool ok = lc_ok && (unsigned)iz < (unsigned)a.Dl && (unsigned)iy < (unsigned)a.Hl && (unsigned)ix < (unsigned)a.Wl;
+        const T* p = ok ? lsrc + ((((int64_t)n * a.Dl + iz) * a.Hl + iy) * a.Wl + ix) * a.lg_pitch : lsrc - part * EPC - lcb * 32;
+        pl[j] = *reinterpret_cast<const u32x4*>(p);
+        vl |= (ok ? 1u : 0u) << j;
+      }
+    };
+    auto xform = [&](u32x4 v, const float* sc, const float* sh, int relu) {
+      float f[EPC];
+      ST<T>::unpack(v, f);
+#pragma unroll
+      for (int e = 0; e < EPC; e++) {
+        f[e] = f[e] * sc[e] + sh[e];
+        if (relu) f[e] = fmaxf(f[e], 0.f);
+      }
+      return ST<T>::pack(f);
+    };
+    auto commit = [&](int tile) {
+      int n, z0, y0, x0;
+      tile_origin(tile, n, z0, y0, x0);
+      float sc[EPC], sh[EPC];
+      if (a.sm_scale) {
+#pragma unroll
+        for (int e = 0; e < EPC; e++) {
+          int c = min(scb * 32 + part * EPC + e, a.SC - 1);
+          sc[e] = a.sm_scale[(int64_t)n * a.SC + c];
+          sh[e] = a.sm_shift[(int64_t)n * a.SC + c];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NS_; j++) {
+        int id = threadIdx.x + 256 * j;
+        if (id < MT * CPV) {
+          u32x4 v = ps[j];
+          if (a.sm_scale) v = xform(v, sc, sh, a.sm_relu);
+          if (!((vs >> j) & 1u)) v = u32x4{0u, 0u, 0u, 0u};
+          *reinterpret_cast<u32x4*>(s_lds + (id / CPV) * LP + part * 16) = v;
+        }
+      }
+      if (a.lg_scale) {
+#pragma unroll
+        for (int e = 0; e < EPC; e++) {
+          int c = min(lcb * 32 + part * EPC + e, a.LC - 1);
+          sc[e] = a.lg_scale[(int64_t)n * a.LC + c];
+          sh[e] = a.lg_shift[(int64_t)n * a.LC + c];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NL_; j++) {
+        int id = threadIdx.x + 256 * j;
+        if (id < BOXL * CPV) {
+          u32x4 v = pl[j];
+          if (a.lg_scale) v = xform(v, sc, sh, a.lg_relu);
+          if (!((vl >> j) & 1u)) v = u32x4{0u, 0u, 0u, 0u};
+          *reinterpret_cast<u32x4*>(l_lds + (id / CPV) * LP + part * 16) = v;
+        }
+      }
+    };
+    // lane roles for ds_read_b64_tr_b16: group g4 = lane>>4 ; within group i = lane&15, q = i>>2, p = i&3
+    const int g4 = lane >> 4, i16 = lane & 15, q = i16 >> 2, p4 = i16 & 3;
+    const int hh = g4 >> 1, cb = (g4 & 1) * 16;
+    const int colb = (cb + 4 * p4) * 2;
+    using lds_s16x4 = s16x4 __attribute__((address_space(3)));
+    auto tr_read = [&](const char* ptr) {
+      s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)ptr);
+      return __builtin_bit_cast(u32x2, v);
+    };
+    if (t_begin < t_end) prefetch(t_begin);
+    for (int tile = t_begin; tile < t_end; tile++) {
+      commit(tile);
+      WS_BARRIER();
+      if (tile + 1 < t_end) prefetch(tile + 1);
       for (int ks = 0; ks < MT / 16; ks++) {
         // the two 4-voxel groups this lane addresses: k = 8*hh + 4*t + q
         int sA[2], lB[2];
@@ -657,25 +747,38 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
           sA[tt] = lin * LP + colb;
           lB[tt] = (((S * lz) * BH + S * ly) * BW + S * lx) * LP + colb;
         }
-        s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(s_lds + sA[0]));
-        s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(s_lds + sA[1]));
-        u32x2 a0u = __builtin_bit_cast(u32x2, a0), a1u = __builtin_bit_cast(u32x2, a1);
+        // all 16 transposed reads of this k-step are requested before its 7 MFMAs (wave 3's 7th tap is a dummy
+        // pointing at tap 0: uniform instruction stream, its accumulator is never stored)
+        u32x2 a0u = tr_read(s_lds + sA[0]), a1u = tr_read(s_lds + sA[1]);
+        u32x2 b0u[TAPS_PER_WAVE], b1u[TAPS_PER_WAVE];
+#pragma unroll
+        for (int j = 0; j < TAPS_PER_WAVE; j++) {
+          b0u[j] = tr_read(l_lds + lB[0] + tapoff[j]);
+          b1u[j] = tr_read(l_lds + lB[1] + tapoff[j]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         u32x4 af = {a0u[0], a0u[1], a1u[0], a1u[1]};
 #pragma unroll
         for (int j = 0; j < TAPS_PER_WAVE; j++) {
-          if (j < ntaps_here) {
-            s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (s16x4 __attribute__((address_space(3)))*)(l_lds + lB[0] + tapoff[j]));
-            s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (s16x4 __attribute__((address_space(3)))*)(l_lds + lB[1] + tapoff[j]));
-            u32x2 b0u = __builtin_bit_cast(u32x2, b0), b1u = __builtin_bit_cast(u32x2, b1);
-            u32x4 bf = {b0u[0], b0u[1], b1u[0], b1u[1]};
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af),
-                                                             __builtin_bit_cast(bf16x8, bf), acc[j], 0, 0, 0);
-          }
+          u32x4 bf = {b0u[j][0], b0u[j][1], b1u[j][0], b1u[j][1]};
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf),
+                                                           acc[j], 0, 0, 0);
         }
       }
-    } else {
+      WS_BARRIER();
+    }
+  } else {
+    // ---- f32 (parity path): plain stage -> barrier -> compute -> barrier ------------------------------------------
+    for (int tile = t_begin; tile < t_end; tile++) {
+      int n, z0, y0, x0;
+      tile_origin(tile, n, z0, y0, x0);
+      if (tile > t_begin) __syncthreads();
+      stage_box<T, TD, TH, TW, ROWB, LP>(s_lds, reinterpret_cast<const T*>(a.sm), a.sm_pitch, a.SC, n, a.Ds, a.Hs, a.Ws,
+                                         z0, y0, x0, scb * 32, ROWB, a.sm_scale, a.sm_shift, a.sm_relu);
+      stage_box<T, BD, BH, BW, ROWB, LP>(l_lds, reinterpret_cast<const T*>(a.lg), a.lg_pitch, a.LC, n, a.Dl, a.Hl, a.Wl,
+                                         S * z0 - 1, S * y0 - 1, S * x0 - 1, lcb * 32, ROWB, a.lg_scale, a.lg_shift,
+                                         a.lg_relu);
+      __syncthreads();
       const int r = lane & 31, hh = lane >> 5;
       for (int ks = 0; ks < MT / 2; ks++) {
         int lin = ks * 2 + hh;
