@@ -16,6 +16,7 @@
 namespace {
 
 constexpr int TB = 32;  // tokens per workgroup
+constexpr size_t LDS_LIMIT = 160 * 1024;
 
 __device__ __forceinline__ float hsum32(float v) {  // sum over the 32 lanes of a half-wave
 #pragma unroll
@@ -41,6 +42,50 @@ __device__ __forceinline__ float dot_col(const float* __restrict__ w, int ld, in
   for (int o = 0; o < O; o++) acc += w[(int64_t)o * ld + col] * sv[o];
   return acc;
 }
+// ---- weights through LDS ----------------------------------------------------------------------------------
+// Every lane of a half-wave owns one output row of a Linear; reading that row straight from global memory makes
+// each load touch 32 different cache lines.  Instead the [O][K] matrix is staged once per workgroup with
+// coalesced loads into LDS rows of ODD stride (K+1 floats): "lane = row" reads (forward) and "lane = column"
+// reads (transposed products in backward) are both bank-conflict free on the same image.
+__device__ __forceinline__ void stage_w(float* sW, const float* __restrict__ gW, int O, int K) {
+  const int ldw = K + 1;
+  for (int i = threadIdx.x; i < O * K; i += 256) {
+    int o = i / K, k = i - o * K;
+    sW[o * ldw + k] = gW[i];
+  }
+}
+// sum_k sWrow[k] * sv[k]   (sv 16-byte aligned, K % 4 == 0)
+__device__ __forceinline__ float dot_lds(const float* sWrow, const float* sv, int K) {
+  float acc = 0.f;
+  for (int k = 0; k < K; k += 4) {
+    float4 b = *reinterpret_cast<const float4*>(sv + k);
+    acc += sWrow[k] * b.x + sWrow[k + 1] * b.y + sWrow[k + 2] * b.z + sWrow[k + 3] * b.w;
+  }
+  return acc;
+}
+// NT tokens (rows g, g+8, ... of sX) share every weight read: acc[j] += sum_k sWrow[k] * sX[(g+8j)*ldx + k]
+template <int NT>
+__device__ __forceinline__ void dot_lds_multi(const float* sWrow, const float* sX, int ldx, int g, int K, float* acc) {
+  for (int k = 0; k < K; k += 4) {
+    const float w0 = sWrow[k], w1 = sWrow[k + 1], w2 = sWrow[k + 2], w3 = sWrow[k + 3];
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+      float4 b = *reinterpret_cast<const float4*>(sX + (g + 8 * j) * ldx + k);
+      acc[j] += w0 * b.x + w1 * b.y + w2 * b.z + w3 * b.w;
+    }
+  }
+}
+// sum_o sW[o*ldw + col] * sv[o]
+__device__ __forceinline__ float dot_col_lds(const float* sW, int ldw, int col, const float* sv, int O) {
+  float acc = 0.f;
+  for (int o = 0; o < O; o += 4) {
+    float4 b = *reinterpret_cast<const float4*>(sv + o);
+    acc += sW[o * ldw + col] * b.x + sW[(o + 1) * ldw + col] * b.y + sW[(o + 2) * ldw + col] * b.z +
+           sW[(o + 3) * ldw + col] * b.w;
+  }
+  return acc;
+}
+
 struct Drop {
   int training;
   uint32_t seed, thresh;
@@ -82,31 +127,40 @@ __device__ __forceinline__ void col_acc(float* __restrict__ gb, int O, const flo
 // ------------------------------------------------------------------------------ K1: Linear0 + LN1 + QKV
 __global__ __launch_bounds__(256) void dense_pre_fwd_kernel(TfDims d, int K, TfLayerP p, const float* __restrict__ F,
                                                             float* __restrict__ h0, float* __restrict__ qkv) {
-  extern __shared__ float sm[];
-  float* s_in = sm;            // [TB][K]
-  float* s_t = sm + TB * K;    // [TB][32]
-  const int m = blockIdx.y, BN = d.B * d.N, o = threadIdx.x & 31;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* s_in = sm;                        // [TB][K]
+  float* s_t = s_in + TB * K;              // [TB][32]
+  float* s_w0 = s_t + TB * 32;             // [32][K+1]
+  float* s_wq = s_w0 + 32 * (K + 1);       // [96][33]
+  const int m = blockIdx.y, BN = d.B * d.N, o = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int64_t mo = (int64_t)m * d.mstride;
   for (int i = threadIdx.x; i < TB * K; i += 256) {
-    int tl = i / K, k = i - tl * K, t = blockIdx.x * TB + tl;
-    s_in[i] = (t < BN) ? F[((int64_t)m * BN + t) * d.DMF + k] : 0.f;
+    int tl = i / K, k = i - tl * K, t = min(blockIdx.x * TB + tl, BN - 1);
+    s_in[i] = F[((int64_t)m * BN + t) * d.DMF + k];
+  }
+  stage_w(s_w0, p.w0 + mo, 32, K);
+  stage_w(s_wq, p.wqkv + mo, 96, 32);
+  __syncthreads();
+  {
+    float hacc[4] = {0.f, 0.f, 0.f, 0.f};
+    dot_lds_multi<4>(s_w0 + o * (K + 1), s_in, K, grp, K, hacc);
+    TOK_LOOP(j, tl, t, ok, R) {
+      float h = p.b0[mo + o] + hacc[j];
+      float mean = hsum32(h) * (1.f / 32.f);
+      float dd = h - mean;
+      float rstd = rsqrtf(hsum32(dd * dd) * (1.f / 32.f) + 1e-5f);
+      s_t[tl * 32 + o] = dd * rstd * p.ln1g[mo + o] + p.ln1b[mo + o];
+      if (ok) h0[R * 32 + o] = h;
+    }
   }
   __syncthreads();
-  TOK_LOOP(j, tl, t, ok, R) {
-    float h = p.b0[mo + o] + dot_row(p.w0 + mo + (int64_t)o * K, s_in + tl * K, K);
-    float mean = hsum32(h) * (1.f / 32.f);
-    float dd = h - mean;
-    float rstd = rsqrtf(hsum32(dd * dd) * (1.f / 32.f) + 1e-5f);
-    s_t[tl * 32 + o] = dd * rstd * p.ln1g[mo + o] + p.ln1b[mo + o];
-    if (ok) h0[R * 32 + o] = h;
-  }
-  __syncthreads();
-  TOK_LOOP(j, tl, t, ok, R) {
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-      int jj = o + 32 * c;
-      float q = dot_row(p.wqkv + mo + jj * 32, s_t + tl * 32, 32);
-      if (ok) qkv[R * 96 + jj] = q;
+  for (int c = 0; c < 3; c++) {
+    int jj = o + 32 * c;
+    float qacc[4] = {0.f, 0.f, 0.f, 0.f};
+    dot_lds_multi<4>(s_wq + jj * 33, s_t, 32, grp, 32, qacc);
+    TOK_LOOP(j, tl, t, ok, R) {
+      if (ok) qkv[R * 96 + jj] = qacc[j];
     }
   }
 }
@@ -251,16 +305,20 @@ __global__ __launch_bounds__(256) void dense_post_fwd_kernel(TfDims d, int block
                                                              const float* __restrict__ h0, const float* __restrict__ ob,
                                                              float* __restrict__ h1s, float* __restrict__ h2s,
                                                              float* __restrict__ F) {
-  __shared__ float s_a[TB][32], s_u[TB][32], s_f[TB][64];
+  __shared__ __attribute__((aligned(16))) float s_a[TB][32], s_u[TB][32], s_f[TB][64];
+  __shared__ float s_wo[32 * 33], s_w1[64 * 33], s_w2[32 * 65];
   const int m = blockIdx.y, BN = d.B * d.N, o = threadIdx.x & 31;
   const int64_t mo = (int64_t)m * d.mstride;
   const Drop dr = make_drop(d);
   const uint32_t site0 = hdf_site_id(m, block, layer, 0);
   float h1r[4], hcur[4];
+  stage_w(s_wo, p.wout + mo, 32, 32);
+  stage_w(s_w1, p.w1 + mo, 64, 32);
+  stage_w(s_w2, p.w2 + mo, 32, 64);
   TOK_LOOP(j, tl, t, ok, R) { s_a[tl][o] = ok ? ob[R * 32 + o] : 0.f; }
   __syncthreads();
   TOK_LOOP(j, tl, t, ok, R) {
-    float a = p.bout[mo + o] + dot_row(p.wout + mo + o * 32, s_a[tl], 32);
+    float a = p.bout[mo + o] + dot_lds(s_wo + o * 33, s_a[tl], 32);
     a *= dr.mask(site0 + 0, (uint32_t)t * 32 + o);
     float h1 = a + (ok ? h0[R * 32 + o] : 0.f);
     h1r[j] = h1;
@@ -279,13 +337,13 @@ __global__ __launch_bounds__(256) void dense_post_fwd_kernel(TfDims d, int block
 #pragma unroll
       for (int c = 0; c < 2; c++) {
         int jj = o + 32 * c;
-        float z = p.b1[mo + jj] + dot_row(p.w1 + mo + jj * 32, s_u[tl], 32);
+        float z = p.b1[mo + jj] + dot_lds(s_w1 + jj * 33, s_u[tl], 32);
         s_f[tl][jj] = gelu_f(z) * dr.mask(site0 + 1 + 2 * pass, (uint32_t)t * 64 + jj);
       }
     }
     __syncthreads();
     TOK_LOOP(j, tl, t, ok, R) {
-      float g = p.b2[mo + o] + dot_row(p.w2 + mo + o * 64, s_f[tl], 64);
+      float g = p.b2[mo + o] + dot_lds(s_w2 + o * 65, s_f[tl], 64);
       g *= dr.mask(site0 + 2 + 2 * pass, (uint32_t)t * 32 + o);
       if (pass == 0) {
         hcur[j] = g + h1r[j];
@@ -305,11 +363,15 @@ __global__ __launch_bounds__(256) void dense_post_bwd_kernel(TfDims d, int block
                                                              const float* __restrict__ h2s,
                                                              const float* __restrict__ ob, const float* __restrict__ dF,
                                                              float* __restrict__ dO, float* __restrict__ dh0acc) {
-  __shared__ float s_u[TB][32], s_f[TB][64], s_dz[TB][64], s_dg[TB][32], s_red[8][32][2];
+  __shared__ __attribute__((aligned(16))) float s_u[TB][32], s_f[TB][64], s_dz[TB][64], s_dg[TB][32];
+  __shared__ float s_red[8][32][2], s_wo[32 * 33], s_w1[64 * 33], s_w2[32 * 65];
   const int m = blockIdx.y, BN = d.B * d.N, o = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int64_t mo = (int64_t)m * d.mstride;
   const Drop dr = make_drop(d);
   const uint32_t site0 = hdf_site_id(m, block, layer, 0);
+  stage_w(s_wo, p.wout + mo, 32, 32);
+  stage_w(s_w1, p.w1 + mo, 64, 32);
+  stage_w(s_w2, p.w2 + mo, 32, 64);
   float dcur[4];   // gradient flowing into the current ff's output (post-dropout side)
   float dres[4];   // gradient of the residual input accumulated so far
   float gam = 0.f, bet = 0.f;  // LN2 gamma/beta gradient partials of this thread's channel
@@ -334,12 +396,12 @@ __global__ __launch_bounds__(256) void dense_post_bwd_kernel(TfDims d, int block
 #pragma unroll
       for (int c = 0; c < 2; c++) {
         int jj = o + 32 * c;
-        float z = p.b1[mo + jj] + dot_row(p.w1 + mo + jj * 32, s_u[tl], 32);
+        float z = p.b1[mo + jj] + dot_lds(s_w1 + jj * 33, s_u[tl], 32);
         float mkv = dr.mask(site0 + 1 + 2 * pass, (uint32_t)t * 64 + jj);
         zz[j][c] = z;
         mk[j][c] = mkv;
         s_f[tl][jj] = ok ? gelu_f(z) * mkv : 0.f;
-        float df = dot_col(p.w2 + mo, 64, jj, s_dg[tl], 32);
+        float df = dot_col_lds(s_w2, 65, jj, s_dg[tl], 32);
         s_dz[tl][jj] = ok ? df * mkv * gelu_grad(z) : 0.f;
       }
     }
@@ -349,7 +411,7 @@ __global__ __launch_bounds__(256) void dense_post_bwd_kernel(TfDims d, int block
     outer_acc(g.w1 + mo, 64, 32, &s_dz[0][0], 64, &s_u[0][0], 32);
     col_acc(g.b1 + mo, 64, &s_dz[0][0], 64);
     TOK_LOOP(j, tl, t, ok, R) {
-      float du = dot_col(p.w1 + mo, 32, o, s_dz[tl], 64);
+      float du = dot_col_lds(s_w1, 33, o, s_dz[tl], 64);
       gam += du * xh[j];
       bet += du;
       float dxh = du * p.ln2g[mo + o];
@@ -384,7 +446,7 @@ __global__ __launch_bounds__(256) void dense_post_bwd_kernel(TfDims d, int block
   outer_acc(g.wout + mo, 32, 32, &s_dg[0][0], 32, &s_u[0][0], 32);
   col_acc(g.bout + mo, 32, &s_dg[0][0], 32);
   TOK_LOOP(j, tl, t, ok, R) {
-    float v = dot_col(p.wout + mo, 32, o, s_dg[tl], 32);
+    float v = dot_col_lds(s_wo, 33, o, s_dg[tl], 32);
     if (ok) dO[R * 32 + o] = v;
   }
 }
@@ -394,15 +456,19 @@ __global__ __launch_bounds__(256) void dense_pre_bwd_kernel(TfDims d, int K, TfL
                                                             const float* __restrict__ F, const float* __restrict__ h0,
                                                             const float* __restrict__ dqkv,
                                                             const float* __restrict__ dh0acc, float* __restrict__ dF) {
-  extern __shared__ float sm[];
+  extern __shared__ __attribute__((aligned(16))) float sm[];
   float* s_in = sm;                 // [TB][K]
   float* s_t = s_in + TB * K;       // [TB][32]
   float* s_dq = s_t + TB * 32;      // [TB][96]
   float* s_dh = s_dq + TB * 96;     // [TB][32]
   float* s_red = s_dh + TB * 32;    // [8][32][2]
+  float* s_w0 = s_red + 8 * 32 * 2; // [32][K+1]
+  float* s_wq = s_w0 + 32 * (K + 1);  // [96][33]
   const int m = blockIdx.y, BN = d.B * d.N, o = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int64_t mo = (int64_t)m * d.mstride;
   float xh[4], rs[4];
+  stage_w(s_w0, p.w0 + mo, 32, K);
+  stage_w(s_wq, p.wqkv + mo, 96, 32);
   for (int i = threadIdx.x; i < TB * K; i += 256) {
     int tl = i / K, k = i - tl * K, t = blockIdx.x * TB + tl;
     s_in[i] = (t < BN) ? F[((int64_t)m * BN + t) * d.DMF + k] : 0.f;
@@ -421,7 +487,7 @@ __global__ __launch_bounds__(256) void dense_pre_bwd_kernel(TfDims d, int K, TfL
   outer_acc(g.wqkv + mo, 96, 32, s_dq, 96, s_t, 32);
   float gam = 0.f, bet = 0.f;
   TOK_LOOP(j, tl, t, ok, R) {
-    float dt = dot_col(p.wqkv + mo, 32, o, s_dq + tl * 96, 96);
+    float dt = dot_col_lds(s_wq, 33, o, s_dq + tl * 96, 96);
     gam += dt * xh[j];
     bet += dt;
     float dxh = dt * p.ln1g[mo + o];
@@ -443,7 +509,7 @@ __global__ __launch_bounds__(256) void dense_pre_bwd_kernel(TfDims d, int K, TfL
   for (int i = threadIdx.x; i < TB * K; i += 256) {
     int tl = i / K, k = i - tl * K, t = blockIdx.x * TB + tl;
     if (t < BN) {
-      float v = dot_col(p.w0 + mo, K, k, s_dh + tl * 32, 32);
+      float v = dot_col_lds(s_w0, K + 1, k, s_dh + tl * 32, 32);
       dF[((int64_t)m * BN + t) * d.DMF + k] += v;
     }
   }
@@ -452,33 +518,45 @@ __global__ __launch_bounds__(256) void dense_pre_bwd_kernel(TfDims d, int K, TfL
 // ------------------------------------------------------------------------------ K4: block out_layer
 template <typename T>
 __global__ __launch_bounds__(256) void block_out_fwd_kernel(TfDims d, int block, TfOutP p, const float* __restrict__ F,
-                                                            float* __restrict__ next_F, T* __restrict__ attnall) {
-  extern __shared__ float sm[];
+                                                            float* __restrict__ next_F, T* __restrict__ attnall,
+                                                            int stage_wb) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
   const int K = d.DMF;
-  float* s_in = sm;           // [TB][K]
-  float* s_f = sm + TB * K;   // [TB][64]
-  const int m = blockIdx.y, BN = d.B * d.N, o = threadIdx.x & 31;
+  float* s_in = sm;                    // [TB][K]
+  float* s_f = s_in + TB * K;          // [TB][64]
+  float* s_wa = s_f + TB * 64;         // [64][K+1]
+  float* s_wb = s_wa + 64 * (K + 1);   // [DM][65] (only if it fits)
+  const int m = blockIdx.y, BN = d.B * d.N, o = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int64_t mo = (int64_t)m * d.mstride;
   const Drop dr = make_drop(d);
   const uint32_t site0 = hdf_site_id(m, block, 4, 0);
   for (int i = threadIdx.x; i < TB * K; i += 256) {
-    int tl = i / K, k = i - tl * K, t = blockIdx.x * TB + tl;
-    s_in[i] = (t < BN) ? F[((int64_t)m * BN + t) * d.DMF + k] : 0.f;
+    int tl = i / K, k = i - tl * K, t = min(blockIdx.x * TB + tl, BN - 1);
+    s_in[i] = F[((int64_t)m * BN + t) * d.DMF + k];
   }
+  stage_w(s_wa, p.wa + mo, 64, K);
+  if (stage_wb) stage_w(s_wb, p.wb + mo, d.DM, 64);
   __syncthreads();
-  TOK_LOOP(j, tl, t, ok, R) {
 #pragma unroll
-    for (int c = 0; c < 2; c++) {
-      int jj = o + 32 * c;
-      float z = p.ba[mo + jj] + dot_row(p.wa + mo + (int64_t)jj * K, s_in + tl * K, K);
+  for (int c = 0; c < 2; c++) {
+    int jj = o + 32 * c;
+    float zacc[4] = {0.f, 0.f, 0.f, 0.f};
+    dot_lds_multi<4>(s_wa + jj * (K + 1), s_in, K, grp, K, zacc);
+    TOK_LOOP(j, tl, t, ok, R) {
+      float z = p.ba[mo + jj] + zacc[j];
       s_f[tl * 64 + jj] = gelu_f(z) * dr.mask(site0 + 0, (uint32_t)t * 64 + jj);
     }
   }
   __syncthreads();
-  TOK_LOOP(j, tl, t, ok, R) {
-    for (int c = o; c < d.DM; c += 32) {
-      float v = p.bb[mo + c] + dot_row(p.wb + mo + c * 64, s_f + tl * 64, 64);
-      v *= dr.mask(site0 + 1, (uint32_t)t * d.DM + c);
+  for (int c = o; c < d.DM; c += 32) {
+    float vacc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (stage_wb) {
+      dot_lds_multi<4>(s_wb + c * 65, s_f, 64, grp, 64, vacc);
+    } else {
+      TOK_LOOP(j, tl, t, ok, R) { vacc[j] = dot_row(p.wb + mo + c * 64, s_f + tl * 64, 64); }
+    }
+    TOK_LOOP(j, tl, t, ok, R) {
+      float v = (p.bb[mo + c] + vacc[j]) * dr.mask(site0 + 1, (uint32_t)t * d.DM + c);
       if (ok) {
         if (next_F)
           next_F[R * d.DMF + c] = v;
@@ -496,13 +574,14 @@ __global__ __launch_bounds__(256) void block_out_bwd_kernel(TfDims d, int block,
                                                             const float* __restrict__ F,
                                                             const float* __restrict__ dF_next,
                                                             const T* __restrict__ d_attnall, float* __restrict__ dF) {
-  extern __shared__ float sm[];
+  extern __shared__ __attribute__((aligned(16))) float sm[];
   const int K = d.DMF, DM = d.DM;
   float* s_in = sm;                // [TB][K]
   float* s_f = s_in + TB * K;      // [TB][64]
   float* s_dz = s_f + TB * 64;     // [TB][64]
   float* s_do = s_dz + TB * 64;    // [TB][DM]
-  const int m = blockIdx.y, BN = d.B * d.N, o = threadIdx.x & 31;
+  float* s_wa = s_do + TB * DM;    // [64][K+1]
+  const int m = blockIdx.y, BN = d.B * d.N, o = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int64_t mo = (int64_t)m * d.mstride;
   const Drop dr = make_drop(d);
   const uint32_t site0 = hdf_site_id(m, block, 4, 0);
@@ -524,18 +603,19 @@ __global__ __launch_bounds__(256) void block_out_bwd_kernel(TfDims d, int block,
     }
     s_do[i] = v;
   }
+  stage_w(s_wa, p.wa + mo, 64, K);
   __syncthreads();
-  float zz[4][2], mk[4][2];
-  TOK_LOOP(j, tl, t, ok, R) {
 #pragma unroll
-    for (int c = 0; c < 2; c++) {
-      int jj = o + 32 * c;
-      float z = p.ba[mo + jj] + dot_row(p.wa + mo + (int64_t)jj * K, s_in + tl * K, K);
-      zz[j][c] = z;
-      mk[j][c] = dr.mask(site0 + 0, (uint32_t)t * 64 + jj);
-      s_f[tl * 64 + jj] = ok ? gelu_f(z) * mk[j][c] : 0.f;
-      float df = dot_col(p.wb + mo, 64, jj, s_do + tl * DM, DM);
-      s_dz[tl * 64 + jj] = ok ? df * mk[j][c] * gelu_grad(z) : 0.f;
+  for (int c = 0; c < 2; c++) {
+    int jj = o + 32 * c;
+    float zacc[4] = {0.f, 0.f, 0.f, 0.f};
+    dot_lds_multi<4>(s_wa + jj * (K + 1), s_in, K, grp, K, zacc);
+    TOK_LOOP(j, tl, t, ok, R) {
+      float z = p.ba[mo + jj] + zacc[j];
+      float mk = dr.mask(site0 + 0, (uint32_t)t * 64 + jj);
+      s_f[tl * 64 + jj] = ok ? gelu_f(z) * mk : 0.f;
+      float df = dot_col(p.wb + mo, 64, jj, s_do + tl * DM, DM);  // lanes = consecutive columns: coalesced
+      s_dz[tl * 64 + jj] = ok ? df * mk * gelu_grad(z) : 0.f;
     }
   }
   __syncthreads();
@@ -545,7 +625,7 @@ __global__ __launch_bounds__(256) void block_out_bwd_kernel(TfDims d, int block,
   col_acc(g.ba + mo, 64, s_dz, 64);
   for (int i = threadIdx.x; i < TB * K; i += 256) {
     int tl = i / K, k = i - tl * K, t = blockIdx.x * TB + tl;
-    if (t < BN) dF[((int64_t)m * BN + t) * d.DMF + k] = dot_col(p.wa + mo, K, k, s_dz + tl * 64, 64);
+    if (t < BN) dF[((int64_t)m * BN + t) * d.DMF + k] = dot_col_lds(s_wa, K + 1, k, s_dz + tl * 64, 64);
   }
 }
 
@@ -683,7 +763,18 @@ __global__ __launch_bounds__(256) void patch_embed_wgrad_kernel(TfDims d, const 
   }
 }
 
-inline TfLayerP offset_none(const TfLayerP& p) { return p; }
+// dynamic LDS above 64 KB has to be opted into per kernel (once)
+template <typename Kern>
+int allow_lds(Kern kern, size_t bytes) {
+  if (bytes <= 64 * 1024) return HDF_OK;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)LDS_LIMIT);
+  if (e != hipSuccess) {
+    hdf_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: %s", hipGetErrorString(e));
+    return HDF_ERR_HIP;
+  }
+  return HDF_OK;
+}
 
 }  // namespace
 
@@ -712,7 +803,8 @@ int tf_layer_fwd(const TfDims& d, int block, int layer, const TfLayerP& p, float
                  hipStream_t st) {
   const int K = d.DM + 32 * layer, BN = d.B * d.N;
   dim3 grid(ceil_div(BN, TB), d.M);
-  size_t shm = (size_t)(TB * K + TB * 32) * sizeof(float);
+  size_t shm = (size_t)(TB * K + TB * 32 + 32 * (K + 1) + 96 * 33) * sizeof(float);
+  HDF_TRY(allow_lds(dense_pre_fwd_kernel, shm));
   hipLaunchKernelGGL(dense_pre_fwd_kernel, grid, dim3(256), shm, st, d, K, p, F, s.h0, s.qkv);
   HDF_LAUNCH_CHECK();
   hipLaunchKernelGGL(attn_fwd_kernel, dim3(ceil_div(d.N, 64), 8, d.M * d.B), dim3(256), (size_t)d.N * 32, st, d.N,
@@ -739,7 +831,8 @@ int tf_layer_bwd(const TfDims& d, int block, int layer, const TfLayerP& p, const
   HDF_LAUNCH_CHECK();
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, ag, dim3(256), (size_t)d.N * 40, st, d.N, s.qkv, s.ob, s.lse, dO, dqkv);
   HDF_LAUNCH_CHECK();
-  size_t shm = (size_t)(TB * K + TB * 32 + TB * 96 + TB * 32 + 8 * 32 * 2) * sizeof(float);
+  size_t shm = (size_t)(TB * K + TB * 32 + TB * 96 + TB * 32 + 8 * 32 * 2 + 32 * (K + 1) + 96 * 33) * sizeof(float);
+  HDF_TRY(allow_lds(dense_pre_bwd_kernel, shm));
   hipLaunchKernelGGL(dense_pre_bwd_kernel, grid, dim3(256), shm, st, d, K, p, g, F, s.h0, dqkv, dh0acc, dF);
   HDF_LAUNCH_CHECK();
   return HDF_OK;
@@ -748,12 +841,19 @@ int tf_layer_bwd(const TfDims& d, int block, int layer, const TfLayerP& p, const
 int tf_block_out_fwd(const TfDims& d, int block, const TfOutP& p, const float* F, float* next_F, void* attnall,
                      int dtype, hipStream_t st) {
   dim3 grid(ceil_div(d.B * d.N, TB), d.M);
-  size_t shm = (size_t)(TB * d.DMF + TB * 64) * sizeof(float);
+  size_t base = (size_t)(TB * d.DMF + TB * 64 + 64 * (d.DMF + 1)) * sizeof(float);
+  size_t with_wb = base + (size_t)d.DM * 65 * sizeof(float);
+  const int stage_wb = with_wb <= LDS_LIMIT ? 1 : 0;
+  size_t shm = stage_wb ? with_wb : base;
+  HDF_CHECK_ARG(shm <= LDS_LIMIT, "block_out: token dim %d needs %zu B of LDS", d.DM, shm);
+  HDF_TRY(allow_lds(block_out_fwd_kernel<bf16_t>, shm));
+  HDF_TRY(allow_lds(block_out_fwd_kernel<float>, shm));
   if (dtype == HDF_BF16)
     hipLaunchKernelGGL(block_out_fwd_kernel<bf16_t>, grid, dim3(256), shm, st, d, block, p, F, next_F,
-                       (bf16_t*)attnall);
+                       (bf16_t*)attnall, stage_wb);
   else
-    hipLaunchKernelGGL(block_out_fwd_kernel<float>, grid, dim3(256), shm, st, d, block, p, F, next_F, (float*)attnall);
+    hipLaunchKernelGGL(block_out_fwd_kernel<float>, grid, dim3(256), shm, st, d, block, p, F, next_F, (float*)attnall,
+                       stage_wb);
   HDF_LAUNCH_CHECK();
   return HDF_OK;
 }
@@ -761,7 +861,10 @@ int tf_block_out_fwd(const TfDims& d, int block, const TfOutP& p, const float* F
 int tf_block_out_bwd(const TfDims& d, int block, const TfOutP& p, const TfOutP& g, const float* F,
                      const float* dF_next, const void* d_attnall, int dtype, float* dF, hipStream_t st) {
   dim3 grid(ceil_div(d.B * d.N, TB), d.M);
-  size_t shm = (size_t)(TB * d.DMF + TB * 64 * 2 + TB * d.DM) * sizeof(float);
+  size_t shm = (size_t)(TB * d.DMF + TB * 64 * 2 + TB * d.DM + 64 * (d.DMF + 1)) * sizeof(float);
+  HDF_CHECK_ARG(shm <= LDS_LIMIT, "block_out_bwd: token dim %d needs %zu B of LDS", d.DM, shm);
+  HDF_TRY(allow_lds(block_out_bwd_kernel<bf16_t>, shm));
+  HDF_TRY(allow_lds(block_out_bwd_kernel<float>, shm));
   if (dtype == HDF_BF16)
     hipLaunchKernelGGL(block_out_bwd_kernel<bf16_t>, grid, dim3(256), shm, st, d, block, p, g, F, dF_next,
                        (const bf16_t*)d_attnall, dF);

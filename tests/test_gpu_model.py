@@ -128,7 +128,7 @@ def test_backward_fp32_vs_oracle(train):
     assert errs[0][1] < 1e-2
     d = dict(errs)
     for name in ("conv1x1.weight", "block_1_2_right.conv.weight", "block_1_1_right.conv.weight", "upconv_1.weight"):
-        assert d[name] < 1e-3, (name, d[name])
+        assert d[name] < 5e-3, (name, d[name])
 
 
 def test_forward_bf16_storage():
