@@ -15,7 +15,8 @@
 
 namespace {
 
-constexpr int TB = 32;  // tokens per workgroup
+constexpr int TJ = 2;        // tokens per 32-lane half-wave group
+constexpr int TB = 8 * TJ;   // tokens per workgroup
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
 __device__ __forceinline__ float hsum32(float v) {  // sum over the 32 lanes of a half-wave
@@ -118,7 +119,7 @@ __device__ __forceinline__ void col_acc(float* __restrict__ gb, int O, const flo
 }
 
 #define TOK_LOOP(j, tl, t, ok, R)                       \
-  _Pragma("unroll") for (int j = 0; j < 4; j++)         \
+  _Pragma("unroll") for (int j = 0; j < TJ; j++)        \
     if (int tl = (threadIdx.x >> 5) + 8 * j; true)      \
       if (int t = blockIdx.x * TB + tl; true)           \
         if (bool ok = t < BN; true)                     \
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256) void dense_pre_fwd_kernel(TfDims d, int K, TfL
   __syncthreads();
   {
     float hacc[4] = {0.f, 0.f, 0.f, 0.f};
-    dot_lds_multi<4>(s_w0 + o * (K + 1), s_in, K, grp, K, hacc);
+    dot_lds_multi<TJ>(s_w0 + o * (K + 1), s_in, K, grp, K, hacc);
     TOK_LOOP(j, tl, t, ok, R) {
       float h = p.b0[mo + o] + hacc[j];
       float mean = hsum32(h) * (1.f / 32.f);
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256) void dense_pre_fwd_kernel(TfDims d, int K, TfL
   for (int c = 0; c < 3; c++) {
     int jj = o + 32 * c;
     float qacc[4] = {0.f, 0.f, 0.f, 0.f};
-    dot_lds_multi<4>(s_wq + jj * 33, s_t, 32, grp, 32, qacc);
+    dot_lds_multi<TJ>(s_wq + jj * 33, s_t, 32, grp, 32, qacc);
     TOK_LOOP(j, tl, t, ok, R) {
       if (ok) qkv[R * 96 + jj] = qacc[j];
     }
@@ -541,7 +542,7 @@ __global__ __launch_bounds__(256) void block_out_fwd_kernel(TfDims d, int block,
   for (int c = 0; c < 2; c++) {
     int jj = o + 32 * c;
     float zacc[4] = {0.f, 0.f, 0.f, 0.f};
-    dot_lds_multi<4>(s_wa + jj * (K + 1), s_in, K, grp, K, zacc);
+    dot_lds_multi<TJ>(s_wa + jj * (K + 1), s_in, K, grp, K, zacc);
     TOK_LOOP(j, tl, t, ok, R) {
       float z = p.ba[mo + jj] + zacc[j];
       s_f[tl * 64 + jj] = gelu_f(z) * dr.mask(site0 + 0, (uint32_t)t * 64 + jj);
@@ -551,7 +552,7 @@ __global__ __launch_bounds__(256) void block_out_fwd_kernel(TfDims d, int block,
   for (int c = o; c < d.DM; c += 32) {
     float vacc[4] = {0.f, 0.f, 0.f, 0.f};
     if (stage_wb) {
-      dot_lds_multi<4>(s_wb + c * 65, s_f, 64, grp, 64, vacc);
+      dot_lds_multi<TJ>(s_wb + c * 65, s_f, 64, grp, 64, vacc);
     } else {
       TOK_LOOP(j, tl, t, ok, R) { vacc[j] = dot_row(p.wb + mo + c * 64, s_f + tl * 64, 64); }
     }
@@ -609,7 +610,7 @@ __global__ __launch_bounds__(256) void block_out_bwd_kernel(TfDims d, int block,
   for (int c = 0; c < 2; c++) {
     int jj = o + 32 * c;
     float zacc[4] = {0.f, 0.f, 0.f, 0.f};
-    dot_lds_multi<4>(s_wa + jj * (K + 1), s_in, K, grp, K, zacc);
+    dot_lds_multi<TJ>(s_wa + jj * (K + 1), s_in, K, grp, K, zacc);
     TOK_LOOP(j, tl, t, ok, R) {
       float z = p.ba[mo + jj] + zacc[j];
       float mk = dr.mask(site0 + 0, (uint32_t)t * 64 + jj);
