@@ -872,6 +872,8 @@ int launch_cfg(const ConvArgs& a, hipStream_t st) {
 inline bool small_tile(int Do, int Ho, int Wo) { return (int64_t)Do * Ho * Wo <= 32 * 32 * 32 / 2; }
 // weights-stationary kernel: mode 0, whole Cin row <= 128 B, enough tiles to amortise the weight panel
 inline int ws_cfg(int mode, int Do, int Ho, int Wo, int row_bytes) {
+  static const int ws_max = getenv("HDF_WS_MAX_ROW_BYTES") ? atoi(getenv("HDF_WS_MAX_ROW_BYTES")) : 128;  // tuning knob
+  if (row_bytes > ws_max) return 0;
   if (mode != 0 || row_bytes > 128 || (int64_t)Do * Ho * Wo < 48 * 48 * 48) return 0;
   return row_bytes <= 64 ? 2 : 1;  // 2: 8x8x8 tile, 4 M-blocks per wave; 1: 4x8x8 tile, 2 M-blocks per wave
 }
