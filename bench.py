@@ -117,10 +117,16 @@ def roofline_dominant_kernel(dev):
     ms = e0.elapsed_time(e1) / reps
     flops = 2.0 * 27 * cin * cout * (s ** 3) * n
     achieved = flops / (ms * 1e-3) / 1e12
+    # HBM bytes per launch of exactly this kernel/shape from the committed PMC passes (FETCH_SIZE x2 correction +
+    # WRITE_SIZE, collected in separate rocprofv3 --pmc runs: profiles/r01_conv_traffic.json); not measurable live
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
+    if os.path.exists(tfile):
+        traffic = json.load(open(tfile)).get("traffic_bytes_per_launch")
     return {"bound": "mfma", "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": None,
-            "kernel": "conv_igemm_kernel<bf16,4x8x8 tile,64ch> (block_1_1_right fwd, 64->32 @128^3, batch 2)",
-            "avg_launch_ms": ms, "flops_per_launch": flops}
+            "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic,
+            "kernel": "conv_ws_kernel<bf16_t,4,8,8,2,128,2> (block_1_1_right fwd, 64->32 @128^3, batch 2)",
+            "avg_launch_ms": ms, "flops_per_launch": flops, "algorithmic_bytes_per_launch": 2.0 * n * s ** 3 * (cin + cout)}
 
 
 def main():
