@@ -17,6 +17,7 @@
 // bias, stores the raw conv output once and emits per-tile (sum, sum^2) partials for the following
 // InstanceNorm, reduced deterministically by in_finalize (no float atomics).
 #include "conv_igemm.h"
+#include <type_traits>
 
 namespace {
 
@@ -459,7 +460,23 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int tiles_tota
     STAMP(0)
     WS_BARRIER();
     STAMP(1)
-    if (item + 1 < nitems) prefetch(item + 1);
+    // prefetch of the next item: border tiles issue their (bounds-checked) loads in one burst here; interior
+    // tiles spread the NJ loads over the MFMA steps below so that their address/issue time hides under the MFMAs
+    const T* nxt_org = nullptr;
+    bool spread = false;
+    if (item + 1 < nitems) {
+      int tile = t_begin + (item + 1) / nchunks, c0n = ((item + 1) % nchunks) * (chunk_bytes / ESZ);
+      int n, z0, y0, x0;
+      tile_origin(tile, n, z0, y0, x0);
+      spread = is_interior(z0, y0, x0);
+      if (spread) {
+        pf_interior = true;
+        nxt_org = reinterpret_cast<const T*>(a.in) + c0n + part * EPC +
+                  ((((int64_t)n * a.Di + (z0 - 1)) * a.Hi + (y0 - 1)) * a.Wi + (x0 - 1)) * a.in_pitch;
+      } else {
+        prefetch(item + 1);
+      }
+    }
     STAMP(2)
     if (chunk == 0) {
 #pragma unroll
@@ -468,8 +485,10 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int tiles_tota
         for (int i = 0; i < 16; i++) acc[mb][i] = 0.f;
     }
     const int lc0 = (chunk * chunk_bytes) >> 4;  // first 16-B chunk of this pass within a weight row
-    {
+    auto mfma_phase = [&](auto spread_tag) {
+      constexpr bool SPREAD = decltype(spread_tag)::value;
       constexpr int NS = 27 * NFS, DEPTH = 3;
+      constexpr int PFS = (NS - 4) / NJ > 0 ? (NS - 4) / NJ : 1;  // one prefetch load every PFS steps
       u32x4 bq[DEPTH], aq[DEPTH][MB];
       auto load_step = [&](int s_, u32x4& bf, u32x4 (&af)[MB]) {
         const int tap = s_ / NFS, fs = s_ % NFS;
@@ -489,12 +508,24 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int tiles_tota
 #pragma unroll
       for (int s_ = 0; s_ < NSRUN; s_++) {
         if (s_ + DEPTH - 1 < NS) load_step(s_ + DEPTH - 1, bq[(s_ + DEPTH - 1) % DEPTH], aq[(s_ + DEPTH - 1) % DEPTH]);
+        if constexpr (SPREAD) {
+          if (s_ % PFS == 0 && s_ / PFS < NJ) pf[s_ / PFS] = *reinterpret_cast<const u32x4*>(nxt_org + boff[s_ / PFS]);
+        }
         __builtin_amdgcn_sched_barrier(0);  // keep the look-ahead reads ABOVE this step's MFMAs
 #pragma unroll
         for (int mb = 0; mb < MB; mb++) Mma<T>::run(aq[s_ % DEPTH][mb], bq[s_ % DEPTH], acc[mb]);
         __builtin_amdgcn_sched_barrier(0);
       }
-    }
+      if constexpr (SPREAD) {
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+          if (j * PFS >= NSRUN) pf[j] = *reinterpret_cast<const u32x4*>(nxt_org + boff[j]);
+      }
+    };
+    if (spread)
+      mfma_phase(std::true_type{});
+    else
+      mfma_phase(std::false_type{});
     STAMP(3)
     WS_BARRIER();  // every wave is done reading the tile buffer
     STAMP(4)
@@ -504,27 +535,41 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int tiles_tota
       int n, z0, y0, x0;
       tile_origin(tile, n, z0, y0, x0);
       float s1 = 0.f, s2 = 0.f;
-      const bool full = ch_ok && z0 + TD <= a.Do && y0 + TH <= a.Ho && x0 + TW <= a.Wo;  // whole tile in range
+      const bool full = z0 + TD <= a.Do && y0 + TH <= a.Ho && x0 + TW <= a.Wo;  // whole tile in range (uniform)
+      if (full) {  // branch hoisted out of the element loops: straight-line cvt + ds_write + 2 FMAs per element
 #pragma unroll
-      for (int mb = 0; mb < MB; mb++) {
-        const int mbi = wave * MB + mb, y = mbi / ZB, zb = 4 * (mbi % ZB);
-        const bool y_ok = (y0 + y) < a.Ho;
-        char* orow = a_lds + ((zb * TH + y) * TW) * OPITCH + r * ESZ;
+        for (int mb = 0; mb < MB; mb++) {
+          const int mbi = wave * MB + mb, y = mbi / ZB, zb = 4 * (mbi % ZB);
+          char* orow = a_lds + ((zb * TH + y) * TW) * OPITCH + r * ESZ;
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-          float v = acc[mb][i] + bias;
-          T tv;
-          ST<T>::st(&tv, v);
-          *reinterpret_cast<T*>(orow + erow[i]) = tv;
-          if (full) {
-            s1 += v;
-            s2 += v * v;
-          } else if (ch_ok && y_ok && (z0 + zb + (ezx[i] >> 4)) < a.Do && (x0 + (ezx[i] & 15)) < a.Wo) {
+          for (int i = 0; i < 16; i++) {
+            float v = acc[mb][i] + bias;
+            T tv;
+            ST<T>::st(&tv, v);
+            *reinterpret_cast<T*>(orow + erow[i]) = tv;
             s1 += v;
             s2 += v * v;
           }
         }
+      } else {
+#pragma unroll
+        for (int mb = 0; mb < MB; mb++) {
+          const int mbi = wave * MB + mb, y = mbi / ZB, zb = 4 * (mbi % ZB);
+          const float ymask = (y0 + y) < a.Ho ? 1.f : 0.f;
+          char* orow = a_lds + ((zb * TH + y) * TW) * OPITCH + r * ESZ;
+#pragma unroll
+          for (int i = 0; i < 16; i++) {
+            float v = acc[mb][i] + bias;
+            T tv;
+            ST<T>::st(&tv, v);
+            *reinterpret_cast<T*>(orow + erow[i]) = tv;
+            const float mk = ((z0 + zb + (ezx[i] >> 4)) < a.Do && (x0 + (ezx[i] & 15)) < a.Wo) ? ymask : 0.f;
+            s1 += mk * v;
+            s2 += mk * v * v;
+          }
+        }
       }
+      if (!ch_ok) s1 = s2 = 0.f;
       if (a.stat_partials) {
         s1 += __shfl_xor(s1, 32, 64);
         s2 += __shfl_xor(s2, 32, 64);
@@ -533,6 +578,7 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int tiles_tota
           s_red[(wave * 32 + r) * 2 + 1] = s2;
         }
       }
+      STAMP(5)
       WS_BARRIER();
       constexpr int CPO = 32 * ESZ / 16;  // 16-byte chunks per staged voxel row
       const int opart = threadIdx.x & (CPO - 1);
@@ -567,8 +613,9 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int tiles_tota
         q[0] = t1;
         q[1] = t2;
       }
+      STAMP(6)
       WS_BARRIER();  // staging rows consumed before the next commit overwrites the tile buffer
-      STAMP(5)
+      STAMP(4)
     }
   }
 #ifdef WS_DBG_STAMPS
