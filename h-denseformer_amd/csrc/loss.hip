@@ -71,24 +71,38 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(const T* __restrict__ log
         red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-// one block: loss scalar + backward coefficients.  coef[(i*N+n)*MAXC + c] = (A, B) of the Dice gradient
-__global__ void loss_finalize_kernel(const float* __restrict__ partials, int nscale, int N, int C, int blocks,
-                                     LossScales sc, float smooth, float* __restrict__ loss_out,
-                                     float* __restrict__ coefA, float* __restrict__ coefB) {
-  __shared__ double tot[4 * 64];  // per (scale, n) contribution
-  const int tid = threadIdx.x;
-  if (tid < nscale * N) {
-    int i = tid / N, n = tid % N;
-    const float* base = partials + (int64_t)i * N * blocks * NSTAT + (int64_t)n * blocks * NSTAT;
-    double s[NSTAT];
-    for (int k = 0; k < NSTAT; k++) s[k] = 0.0;
-    for (int b = 0; b < blocks; b++)
-      for (int k = 0; k < NSTAT; k++) s[k] += (double)base[(int64_t)b * NSTAT + k];
+// grid = nscale*N blocks of 256 threads (one per partial slot): per-(scale, sample) loss term + the backward
+// coefficients coef[(i*N+n)*MAXC + c] = (A, B) of the Dice gradient; terms[i*N+n] is summed by loss_total_kernel
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ partials, int nscale, int N, int C,
+                                                            int blocks, LossScales sc, float smooth,
+                                                            float* __restrict__ terms, float* __restrict__ coefA,
+                                                            float* __restrict__ coefB) {
+  __shared__ double red[4][NSTAT];
+  const int i = blockIdx.x / N, n = blockIdx.x % N;
+  const float* base = partials + ((int64_t)i * N + n) * blocks * NSTAT;
+  double s[NSTAT];
+#pragma unroll
+  for (int k = 0; k < NSTAT; k++) s[k] = 0.0;
+  for (int b = threadIdx.x; b < blocks; b += 256)
+#pragma unroll
+    for (int k = 0; k < NSTAT; k++) s[k] += (double)base[(int64_t)b * NSTAT + k];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NSTAT; k++) {
+    double v = s[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) red[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t[NSTAT];
+    for (int k = 0; k < NSTAT; k++) t[k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
     double V = (double)sc.V[i];
-    double ce = s[3 * MAXC] / (V * N);
+    double ce = t[3 * MAXC] / (V * N);
     double dice = 0.0;
     for (int c = 1; c < C; c++) {
-      double I = s[c], U = s[MAXC + c] + s[2 * MAXC + c];
+      double I = t[c], U = t[MAXC + c] + t[2 * MAXC + c];
       dice += (1.0 - (2.0 * I + smooth) / (U + smooth)) / (double)N;
       coefA[((int64_t)i * N + n) * MAXC + c] = (float)(2.0 / (U + smooth));
       coefB[((int64_t)i * N + n) * MAXC + c] = (float)((2.0 * I + smooth) / ((U + smooth) * (U + smooth)));
@@ -96,12 +110,15 @@ __global__ void loss_finalize_kernel(const float* __restrict__ partials, int nsc
     coefA[((int64_t)i * N + n) * MAXC] = 0.f;
     coefB[((int64_t)i * N + n) * MAXC] = 0.f;
     dice /= (double)(C - 1);
-    tot[tid] = (ce + dice) * (double)sc.weight[i];
+    // CE is already a mean over all N samples' voxels: every (scale, n) block contributes its own share
+    terms[blockIdx.x] = (float)((ce + dice) * (double)sc.weight[i]);
   }
-  __syncthreads();
-  if (tid == 0) {
+}
+
+__global__ void loss_total_kernel(const float* __restrict__ terms, int count, float* __restrict__ loss_out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
     double t = 0.0;
-    for (int k = 0; k < nscale * N; k++) t += tot[k];
+    for (int k = 0; k < count; k++) t += (double)terms[k];   // fixed order
     *loss_out = (float)t;
   }
 }
@@ -219,7 +236,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 
 int hdf_loss_blocks() { return LOSS_BLOCKS; }
 size_t hdf_loss_workspace_floats(int N, int nscale) {
-  return (size_t)nscale * N * LOSS_BLOCKS * NSTAT + 2 * (size_t)nscale * N * MAXC + 16;
+  return (size_t)nscale * N * LOSS_BLOCKS * NSTAT + 2 * (size_t)nscale * N * MAXC + (size_t)nscale * N + 16;
 }
 
 int hdf_launch_loss_fwd(int dtype, const void* const* logits, const float* target, int nscale, int N, int C, int D,
@@ -245,8 +262,11 @@ int hdf_launch_loss_fwd(int dtype, const void* const* logits, const float* targe
                          target, C, Ds, Hs, Ws, s, D, H, W, pi);
     HDF_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, partials, nscale, N, C, LOSS_BLOCKS, sc, 1e-5f,
-                     loss_out, coefA, coefB);
+  float* terms = coefB + (size_t)nscale * N * MAXC;
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(nscale * N), dim3(256), 0, st, partials, nscale, N, C, LOSS_BLOCKS, sc,
+                     1e-5f, terms, coefA, coefB);
+  HDF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(64), 0, st, terms, nscale * N, loss_out);
   HDF_LAUNCH_CHECK();
   return HDF_OK;
 }

@@ -153,8 +153,13 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ in, int64_t in_pitch, T
       }
     }
     store_chunk<T>(out + row * out_pitch + c0, best);
-#pragma unroll
-    for (int e = 0; e < EPC; e++) idx[row * C + c0 + e] = (uint8_t)bi[e];
+    if constexpr (EPC == 8) {
+      uint32_t lo = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+      uint32_t hi = bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24);
+      *reinterpret_cast<uint2*>(idx + row * C + c0) = make_uint2(lo, hi);
+    } else {
+      *reinterpret_cast<uint32_t*>(idx + row * C + c0) = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+    }
   }
 }
 
@@ -179,8 +184,15 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dout, int64_t dout_pitc
     float g[EPC];
     int bi[EPC];
     load_chunk<T>(dout + row * dout_pitch + c0, g);
+    if constexpr (EPC == 8) {
+      uint2 pk = *reinterpret_cast<const uint2*>(idx + row * C + c0);
 #pragma unroll
-    for (int e = 0; e < EPC; e++) bi[e] = idx[row * C + c0 + e];
+      for (int e = 0; e < 4; e++) bi[e] = (pk.x >> (8 * e)) & 255, bi[4 + e] = (pk.y >> (8 * e)) & 255;
+    } else {
+      uint32_t pk = *reinterpret_cast<const uint32_t*>(idx + row * C + c0);
+#pragma unroll
+      for (int e = 0; e < 4; e++) bi[e] = (pk >> (8 * e)) & 255;
+    }
 #pragma unroll
     for (int k = 0; k < 8; k++) {
       int dz = k >> 2, dy = (k >> 1) & 1, dx = k & 1;
@@ -301,21 +313,21 @@ __global__ void upsample_bwd_kernel(const T* __restrict__ dout, int64_t dout_pit
     float acc[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; e++) acc[e] = 0.f;
+    // all 64 taps unconditionally (indices are clamped into range, out-of-range taps carry weight 0): no
+    // branch around any load, so the loads of a thread are all in flight together
+#pragma unroll
     for (int a = 0; a < 4; a++) {
-      if (wz[a] == 0.f) continue;
+#pragma unroll
       for (int b = 0; b < 4; b++) {
-        if (wy[b] == 0.f) continue;
+        const float wzy = wz[a] * wy[b];
+        const int64_t rbase = (((int64_t)n * Do + oz[a]) * Ho + oy[b]) * Wo;
+        float f[4][EPC];
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-          float w = wz[a] * wy[b] * wx[c];
-          if (w != 0.f) {
-            int64_t orow = (((int64_t)n * Do + oz[a]) * Ho + oy[b]) * Wo + ox[c];
-            float f[EPC];
-            load_chunk<T>(dout + orow * dout_pitch + c0, f);
+        for (int c = 0; c < 4; c++) load_chunk<T>(dout + (rbase + ox[c]) * dout_pitch + c0, f[c]);
 #pragma unroll
-            for (int e = 0; e < EPC; e++) acc[e] += w * f[e];
-          }
-        }
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+          for (int e = 0; e < EPC; e++) acc[e] += (wzy * wx[c]) * f[c][e];
       }
     }
     store_chunk<T>(din + row * din_pitch + c0, acc);
@@ -377,6 +389,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ dlo
   __shared__ float xs[256][33];
   __shared__ float dls[256][HEAD_MAXCLS];
   __shared__ float sw[HEAD_MAXCLS][32];
+  __shared__ float ssc[32], ssh[32];
   const int n = blockIdx.y;
   const int po = threadIdx.x >> 5, pc = threadIdx.x & 31;  // (o,c) pair owned for the dW reduction
   for (int cb = 0; cb < C; cb += 32) {
@@ -385,6 +398,11 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ dlo
     if (threadIdx.x < HEAD_MAXCLS * 32) {
       int o = threadIdx.x >> 5, c = threadIdx.x & 31;
       sw[o][c] = (o < ncls && c < cw) ? w[o * C + cb + c] : 0.f;
+    }
+    if (threadIdx.x < 32) {
+      const bool ok = scale && (int)threadIdx.x < cw;
+      ssc[threadIdx.x] = ok ? scale[(int64_t)n * C + cb + threadIdx.x] : 1.f;
+      ssh[threadIdx.x] = ok ? shift[(int64_t)n * C + cb + threadIdx.x] : 0.f;
     }
     float accw = 0.f, accb = 0.f;
     for (int64_t v0 = (int64_t)blockIdx.x * 256; v0 < vox; v0 += (int64_t)gridDim.x * 256) {
@@ -411,7 +429,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ dlo
 #pragma unroll
           for (int e = 0; e < EPC; e++) {
             float x = f[e];
-            if (scale) x = fmaxf(x * scale[(int64_t)n * C + cb + c0 + e] + shift[(int64_t)n * C + cb + c0 + e], 0.f);
+            if (scale) x = fmaxf(x * ssc[c0 + e] + ssh[c0 + e], 0.f);
             xs[threadIdx.x][c0 + e] = x;
             float d = 0.f;
 #pragma unroll
@@ -471,16 +489,23 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const T* __restrict_
   if (vl < vlanes) {
     int64_t per = (vox + blocks - 1) / blocks;
     int64_t vb = (int64_t)blockIdx.x * per, ve = min(vox, vb + per);
-    for (int64_t v = vb + vl; v < ve; v += vlanes) {
-      int64_t row = (int64_t)n * vox + v;
-      float g[EPC], f[EPC];
-      load_chunk<T>(da + row * da_pitch + c0, g);
-      load_chunk<T>(y + row * y_pitch + c0, f);
+    for (int64_t v0 = vb + vl; v0 < ve; v0 += 4 * vlanes) {
+      float g[4][EPC], f[4][EPC];
 #pragma unroll
-      for (int e = 0; e < EPC; e++) {
-        float gg = (f[e] * sc[e] + sh[e] > 0.f) ? g[e] : 0.f;
-        s1[e] += gg;
-        s2[e] += gg * ((f[e] - mu[e]) * rs[e]);
+      for (int u = 0; u < 4; u++) {  // clamped (never branch around a load); the tail is masked below
+        int64_t row = (int64_t)n * vox + min(v0 + (int64_t)u * vlanes, ve - 1);
+        load_chunk<T>(da + row * da_pitch + c0, g[u]);
+        load_chunk<T>(y + row * y_pitch + c0, f[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const bool live = v0 + (int64_t)u * vlanes < ve;
+#pragma unroll
+        for (int e = 0; e < EPC; e++) {
+          float gg = (live && f[u][e] * sc[e] + sh[e] > 0.f) ? g[u][e] : 0.f;
+          s1[e] += gg;
+          s2[e] += gg * ((f[u][e] - mu[e]) * rs[e]);
+        }
       }
     }
 #pragma unroll
