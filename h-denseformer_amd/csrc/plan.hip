@@ -298,7 +298,7 @@ void layout(hdf_plan* p, int B) {
   for (int k = 0; k < 3; k++) conv_bufs(p->up[k]);
   p->at[2] = mkview(p, bp, "at1", 2, 4 * nf, B);
   p->at[1] = mkview(p, bp, "at2", 1, 2 * nf, B);
-  p->at[0] = mkview(p, bp, "at3", 0, nf, B);
+  p->at[0] = View();  // at3 is never materialised (fused into the encoder tail)
   for (int k = 0; k < 4; k++) {
     conv_bufs(p->enc[k][0]);
     conv_bufs(p->enc[k][1]);
@@ -748,6 +748,7 @@ int hdf_forward(hdf_plan* p, const float* x, const float* params, void* workspac
     for (int k = 0; k < 3; k++) {  // up1 -> at1 (lvl 2), up2 -> at2 (lvl 1), up3 -> at3 (lvl 0)
       Conv3& c = p->up[k];
       HDF_TRY(conv_forward(e, c, *src, none));
+      if (k == 2) break;  // at3 (full resolution) is never materialised: the encoder tail interpolates it on the fly
       const View& dst = p->at[2 - k];
       HDF_TRY(hdf_launch_upsample_fwd(p->dtype, e.at(c.y), c.y.pitch, e.f(c.st.scale), e.f(c.st.shift), e.at(dst),
                                       dst.pitch, batch, c.Cout, p->dims[c.lvl][0], p->dims[c.lvl][1],
@@ -764,12 +765,15 @@ int hdf_forward(hdf_plan* p, const float* x, const float* params, void* workspac
     Conv3& c = p->enc[k][1];
     if (k < 3) {
       View ds = subview(p, p->cat[k], ch[k], ch[k]);
-      HDF_TRY(hdf_launch_norm_relu_add(p->dtype, e.at(c.y), c.y.pitch, e.f(c.st.scale), e.f(c.st.shift),
-                                       e.at(p->at[k]), p->at[k].pitch, e.at(ds), ds.pitch, batch, ch[k], p->vox(k),
-                                       e.st));
-      HDF_TRY(hdf_launch_maxpool_fwd(p->dtype, e.at(ds), ds.pitch, e.at(p->pooled[k]), p->pooled[k].pitch,
-                                     (uint8_t*)(e.ws + p->pool_idx[k]), batch, ch[k], p->dims[k + 1][0],
-                                     p->dims[k + 1][1], p->dims[k + 1][2], e.st));
+      // ds_k = relu(IN(y)) + at_k ; pooled = MaxPool(ds_k): one fused pass.  Level 0 takes at3 straight from up3's
+      // raw conv output (trilinear x2 of relu(IN(.)) evaluated inside the kernel)
+      Conv3& u3 = p->up[2];
+      const bool ups = (k == 0);
+      HDF_TRY(hdf_launch_enc_tail(p->dtype, e.at(c.y), c.y.pitch, e.f(c.st.scale), e.f(c.st.shift),
+                                  ups ? e.at(u3.y) : e.at(p->at[k]), ups ? u3.y.pitch : p->at[k].pitch,
+                                  ups ? e.f(u3.st.scale) : nullptr, ups ? e.f(u3.st.shift) : nullptr, e.at(ds),
+                                  ds.pitch, e.at(p->pooled[k]), p->pooled[k].pitch, (uint8_t*)(e.ws + p->pool_idx[k]),
+                                  batch, ch[k], p->dims[k + 1][0], p->dims[k + 1][1], p->dims[k + 1][2], e.st));
       cur = &p->pooled[k];
     } else {
       HDF_TRY(hdf_launch_norm_relu_add(p->dtype, e.at(c.y), c.y.pitch, e.f(c.st.scale), e.f(c.st.shift),

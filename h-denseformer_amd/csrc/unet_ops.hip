@@ -213,6 +213,125 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dout, int64_t dout_pitc
   }
 }
 
+// ------------------------------------------------------------------------------ fused encoder tail
+// ds = relu(y*s+t) + skip ;  pooled, idx = MaxPool3d(2)(ds)        (HDenseFormer.py:237-243)
+// One thread owns a 2x2x2 block of ds voxels (one pooled voxel) x one 16-byte channel chunk, so ds is written
+// once and never re-read for pooling.  UPS: the skip is the trilinear x2 up-sampling of relu(ylo*ls+lt)
+// (UpConv, :162-175) evaluated on the fly from the 3x3x3 low-resolution neighbourhood (separable, plane by
+// plane) -- the full-resolution transformer feature at3 is never materialised.
+template <typename T, bool UPS>
+__global__ __launch_bounds__(256) void enc_tail_kernel(const T* __restrict__ y, int64_t y_pitch,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       const T* __restrict__ skip, int64_t skip_pitch,
+                                                       const float* __restrict__ lscale, const float* __restrict__ lshift,
+                                                       T* __restrict__ ds, int64_t ds_pitch, T* __restrict__ pooled,
+                                                       int64_t pooled_pitch, uint8_t* __restrict__ idx, int N, int C,
+                                                       int Do, int Ho, int Wo) {
+  constexpr int EPC = ST<T>::EPC;
+  const int cols = C / EPC;
+  const int Di = 2 * Do, Hi = 2 * Ho, Wi = 2 * Wo;
+  int64_t total = (int64_t)N * Do * Ho * Wo * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t row = i / cols;
+    const int c0 = (int)(i - row * cols) * EPC;
+    int64_t t = row;
+    const int ow = t % Wo;
+    t /= Wo;
+    const int oh = t % Ho;
+    t /= Ho;
+    const int od = t % Do;
+    const int n = (int)(t / Do);
+    float sk[8][EPC];  // skip value of the 8 block positions (k = dz*4 + dy*2 + dx)
+    if constexpr (UPS) {
+      float ls[EPC], lt[EPC];
+#pragma unroll
+      for (int e = 0; e < EPC; e++) {
+        ls[e] = lscale[(int64_t)n * C + c0 + e];
+        lt[e] = lshift[(int64_t)n * C + c0 + e];
+#pragma unroll
+        for (int k = 0; k < 8; k++) sk[k][e] = 0.f;
+      }
+      const int xs[3] = {max(ow - 1, 0), ow, min(ow + 1, Wo - 1)};
+      const int ys[3] = {max(oh - 1, 0), oh, min(oh + 1, Ho - 1)};
+      const int zs[3] = {max(od - 1, 0), od, min(od + 1, Do - 1)};
+#pragma unroll
+      for (int a = 0; a < 3; a++) {       // low-resolution z plane
+        float P[2][2][EPC];               // plane interpolated in y and x: [dy][dx]
+#pragma unroll
+        for (int q = 0; q < 4 * EPC; q++) (&P[0][0][0])[q] = 0.f;
+#pragma unroll
+        for (int b = 0; b < 3; b++) {     // low-resolution y row
+          float L[3][EPC];
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            float f[EPC];
+            load_chunk<T>(skip + ((((int64_t)n * Do + zs[a]) * Ho + ys[b]) * Wo + xs[c]) * skip_pitch + c0, f);
+#pragma unroll
+            for (int e = 0; e < EPC; e++) L[c][e] = fmaxf(f[e] * ls[e] + lt[e], 0.f);
+          }
+          const float wy0 = (b == 0) ? 0.25f : (b == 1 ? 0.75f : 0.f);   // weight of row b for dy = 0
+          const float wy1 = (b == 0) ? 0.f : (b == 1 ? 0.75f : 0.25f);    // ... for dy = 1
+#pragma unroll
+          for (int e = 0; e < EPC; e++) {
+            const float x0 = 0.25f * L[0][e] + 0.75f * L[1][e], x1 = 0.75f * L[1][e] + 0.25f * L[2][e];
+            P[0][0][e] += wy0 * x0, P[0][1][e] += wy0 * x1;
+            P[1][0][e] += wy1 * x0, P[1][1][e] += wy1 * x1;
+          }
+        }
+        const float wz0 = (a == 0) ? 0.25f : (a == 1 ? 0.75f : 0.f);
+        const float wz1 = (a == 0) ? 0.f : (a == 1 ? 0.75f : 0.25f);
+#pragma unroll
+        for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+          for (int dx = 0; dx < 2; dx++)
+#pragma unroll
+            for (int e = 0; e < EPC; e++) {
+              sk[dy * 2 + dx][e] += wz0 * P[dy][dx][e];
+              sk[4 + dy * 2 + dx][e] += wz1 * P[dy][dx][e];
+            }
+      }
+    }
+    float sc[EPC], sh[EPC], best[EPC];
+    int bi[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; e++) {
+      sc[e] = scale[(int64_t)n * C + c0 + e];
+      sh[e] = shift[(int64_t)n * C + c0 + e];
+      best[e] = -INFINITY;
+      bi[e] = 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {  // scan order d,h,w; strict > keeps the FIRST maximum (torch tie rule)
+      const int dz = k >> 2, dy = (k >> 1) & 1, dx = k & 1;
+      const int64_t irow = (((int64_t)n * Di + 2 * od + dz) * Hi + 2 * oh + dy) * Wi + 2 * ow + dx;
+      float f[EPC];
+      load_chunk<T>(y + irow * y_pitch + c0, f);
+      if constexpr (!UPS) load_chunk<T>(skip + irow * skip_pitch + c0, sk[k]);
+#pragma unroll
+      for (int e = 0; e < EPC; e++) f[e] = fmaxf(f[e] * sc[e] + sh[e], 0.f) + sk[k][e];
+      store_chunk<T>(ds + irow * ds_pitch + c0, f);
+      // pool over the STORED (storage-rounded) values so that backward/recompute sees the same maxima
+      float g[EPC];
+      ST<T>::unpack(ST<T>::pack(f), g);
+#pragma unroll
+      for (int e = 0; e < EPC; e++) {
+        if (g[e] > best[e] || g[e] != g[e]) {
+          best[e] = g[e];
+          bi[e] = k;
+        }
+      }
+    }
+    store_chunk<T>(pooled + row * pooled_pitch + c0, best);
+    if constexpr (EPC == 8) {
+      uint32_t lo = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+      uint32_t hi = bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24);
+      *reinterpret_cast<uint2*>(idx + row * C + c0) = make_uint2(lo, hi);
+    } else {
+      *reinterpret_cast<uint32_t*>(idx + row * C + c0) = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------ trilinear x2
 // per dim, output o reads inputs (ia, wa), (ib, wb):  o=2i: (max(i-1,0), .25), (i, .75) ; o=2i+1: (i, .75), (min(i+1,n-1), .25)
 __device__ __forceinline__ void up_taps(int o, int n, int& ia, float& wa, int& ib, float& wb) {
@@ -676,6 +795,27 @@ int hdf_launch_norm_relu_add(int dtype, const void* y, int64_t y_pitch, const fl
   DISPATCH_T(dtype, hipLaunchKernelGGL(norm_relu_add_kernel<T>, dim3(grid_for((int64_t)N * vox * (C / ST<T>::EPC))),
                                        dim3(256), 0, st, (const T*)y, y_pitch, scale, shift, (const T*)skip, skip_pitch,
                                        (T*)out, out_pitch, N, C, vox));
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
+int hdf_launch_enc_tail(int dtype, const void* y, int64_t y_pitch, const float* scale, const float* shift,
+                        const void* skip, int64_t skip_pitch, const float* lscale, const float* lshift, void* ds,
+                        int64_t ds_pitch, void* pooled, int64_t pooled_pitch, uint8_t* idx, int N, int C, int Do,
+                        int Ho, int Wo, hipStream_t st) {
+  HDF_CHECK_ARG(C % 16 == 0, "enc_tail: C=%d", C);
+  const bool ups = lscale != nullptr;
+  DISPATCH_T(dtype, {
+    unsigned g = grid_for((int64_t)N * Do * Ho * Wo * (C / ST<T>::EPC));
+    if (ups)
+      hipLaunchKernelGGL((enc_tail_kernel<T, true>), dim3(g), dim3(256), 0, st, (const T*)y, y_pitch, scale, shift,
+                         (const T*)skip, skip_pitch, lscale, lshift, (T*)ds, ds_pitch, (T*)pooled, pooled_pitch, idx,
+                         N, C, Do, Ho, Wo);
+    else
+      hipLaunchKernelGGL((enc_tail_kernel<T, false>), dim3(g), dim3(256), 0, st, (const T*)y, y_pitch, scale, shift,
+                         (const T*)skip, skip_pitch, lscale, lshift, (T*)ds, ds_pitch, (T*)pooled, pooled_pitch, idx,
+                         N, C, Do, Ho, Wo);
+  });
   HDF_LAUNCH_CHECK();
   return HDF_OK;
 }
