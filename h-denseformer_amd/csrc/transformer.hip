@@ -650,21 +650,57 @@ __global__ __launch_bounds__(256) void patch_embed_fwd_kernel(TfDims d, const fl
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[a][i] = 0.f;
   for (int kc = 0; kc < 4096; kc += KC) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < 32 * KC; i += 256) {
-      int tl = i >> 6, kk = i & 63, t = blockIdx.x * 32 + tl;
-      float v = 0.f;
-      if (t < BN) {
-        int b = t / d.N, n = t - b * d.N;
-        int gz = n / (gh * gw), gy = (n / gw) % gh, gx = n % gw;
-        int k = kc + kk, dz = k >> 8, dy = (k >> 4) & 15, dx = k & 15;
-        v = x[((((int64_t)b * d.M + m) * D + gz * 16 + dz) * H + gy * 16 + dy) * W + gx * 16 + dx];
-      }
-      sA[tl * LD + kk] = v;
+    // batched float4 staging: every load of the chunk is issued before the first LDS write (tokens beyond BN are
+    // clamped to the last token: their outputs are never stored)
+    float4 ra[2], rb[8];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      int i = (threadIdx.x + 256 * u) * 4;  // element index in the [32][64] A chunk
+      int tl = i >> 6, kk = i & 63, t = min(blockIdx.x * 32 + tl, BN - 1);
+      int b = t / d.N, n = t - b * d.N;
+      int gz = n / (gh * gw), gy = (n / gw) % gh, gx = n % gw;
+      int k = kc + kk, dz = k >> 8, dy = (k >> 4) & 15, dx = k & 15;
+      ra[u] = *reinterpret_cast<const float4*>(
+          x + ((((int64_t)b * d.M + m) * D + gz * 16 + dz) * H + gy * 16 + dy) * W + gx * 16 + dx);
     }
-    for (int i = threadIdx.x; i < DM * KC; i += 256) {
+    const int nbq = DM * KC / 4;  // float4 chunks of the B tile
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      int q = min((int)threadIdx.x + 256 * u, nbq - 1), i = q * 4;
       int c = i >> 6, kk = i & 63;
-      sB[c * LD + kk] = wm[(int64_t)c * 4096 + kc + kk];
+      rb[u] = *reinterpret_cast<const float4*>(wm + (int64_t)c * 4096 + kc + kk);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      int i = (threadIdx.x + 256 * u) * 4, tl = i >> 6, kk = i & 63;
+      float* dst = sA + tl * LD + kk;
+      dst[0] = ra[u].x, dst[1] = ra[u].y, dst[2] = ra[u].z, dst[3] = ra[u].w;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      int q = threadIdx.x + 256 * u;
+      if (q < nbq) {
+        int i = q * 4, c = i >> 6, kk = i & 63;
+        float* dst = sB + c * LD + kk;
+        dst[0] = rb[u].x, dst[1] = rb[u].y, dst[2] = rb[u].z, dst[3] = rb[u].w;
+      }
+    }
+    for (int base = 2048; base < nbq; base += 2048) {  // token dims > 128: remaining rows of the weight tile
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        int q = min(base + (int)threadIdx.x + 256 * u, nbq - 1), i = q * 4;
+        rb[u] = *reinterpret_cast<const float4*>(wm + (int64_t)(i >> 6) * 4096 + kc + (i & 63));
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        int q = base + threadIdx.x + 256 * u;
+        if (q < nbq) {
+          int i = q * 4;
+          float* dst = sB + (i >> 6) * LD + (i & 63);
+          dst[0] = rb[u].x, dst[1] = rb[u].y, dst[2] = rb[u].z, dst[3] = rb[u].w;
+        }
+      }
     }
     __syncthreads();
 #pragma unroll
@@ -734,21 +770,34 @@ __global__ __launch_bounds__(256) void patch_embed_wgrad_kernel(TfDims d, const 
 #pragma unroll
   for (int i = 0; i < 16; i++) acc[i] = 0.f;
   for (int t0 = 0; t0 < BN; t0 += TT) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < TT * 32; i += 256) {
-      int tl = i >> 5, c = i & 31, t = t0 + tl;
-      sD[tl * LDD + c] = (t < BN && cb + c < DM) ? dtok[((int64_t)m * BN + t) * DM + cb + c] : 0.f;
+    // batched staging (all loads first; tokens beyond BN contribute zeros)
+    float4 rd, rp[4];
+    {
+      int i = threadIdx.x * 4, tl = i >> 5, c = i & 31, t = min(t0 + tl, BN - 1);   // [32 tok][32 c]
+      rd = *reinterpret_cast<const float4*>(dtok + ((int64_t)m * BN + t) * DM + min(cb + c, DM - 4));
+      if (t0 + tl >= BN || cb + c >= DM) rd = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int i = threadIdx.x; i < TT * 128; i += 256) {
-      int tl = i >> 7, kk = i & 127, t = t0 + tl;
-      float v = 0.f;
-      if (t < BN) {
-        int b = t / d.N, n = t - b * d.N;
-        int gz = n / (gh * gw), gy = (n / gw) % gh, gx = n % gw;
-        int k = kb + kk, dz = k >> 8, dy = (k >> 4) & 15, dx = k & 15;
-        v = x[((((int64_t)b * d.M + m) * D + gz * 16 + dz) * H + gy * 16 + dy) * W + gx * 16 + dx];
-      }
-      sP[tl * LDP + kk] = v;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      int i = (threadIdx.x + 256 * u) * 4, tl = i >> 7, kk = i & 127, t = min(t0 + tl, BN - 1);  // [32 tok][128 kk]
+      int b = t / d.N, n = t - b * d.N;
+      int gz = n / (gh * gw), gy = (n / gw) % gh, gx = n % gw;
+      int k = kb + kk, dz = k >> 8, dy = (k >> 4) & 15, dx = k & 15;
+      rp[u] = *reinterpret_cast<const float4*>(
+          x + ((((int64_t)b * d.M + m) * D + gz * 16 + dz) * H + gy * 16 + dy) * W + gx * 16 + dx);
+      if (t0 + tl >= BN) rp[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    {
+      int i = threadIdx.x * 4, tl = i >> 5, c = i & 31;
+      float* dst = sD + tl * LDD + c;
+      dst[0] = rd.x, dst[1] = rd.y, dst[2] = rd.z, dst[3] = rd.w;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      int i = (threadIdx.x + 256 * u) * 4, tl = i >> 7, kk = i & 127;
+      float* dst = sP + tl * LDP + kk;
+      dst[0] = rp[u].x, dst[1] = rp[u].y, dst[2] = rp[u].z, dst[3] = rp[u].w;
     }
     __syncthreads();
     for (int t2 = 0; t2 < TT / 2; t2++) {
