@@ -87,6 +87,9 @@ __device__ __forceinline__ float dot_col_lds(const float* sW, int ldw, int col, 
   return acc;
 }
 
+// select AFTER an unconditional load (the argument is evaluated before the call): never branch around a load
+__device__ __forceinline__ float sel0(bool ok, float v) { return ok ? v : 0.f; }
+
 struct Drop {
   int training;
   uint32_t seed, thresh;
@@ -316,12 +319,12 @@ __global__ __launch_bounds__(256) void dense_post_fwd_kernel(TfDims d, int block
   stage_w(s_wo, p.wout + mo, 32, 32);
   stage_w(s_w1, p.w1 + mo, 64, 32);
   stage_w(s_w2, p.w2 + mo, 32, 64);
-  TOK_LOOP(j, tl, t, ok, R) { s_a[tl][o] = ok ? ob[R * 32 + o] : 0.f; }
+  TOK_LOOP(j, tl, t, ok, R) { s_a[tl][o] = sel0(ok, ob[R * 32 + o]); }
   __syncthreads();
   TOK_LOOP(j, tl, t, ok, R) {
     float a = p.bout[mo + o] + dot_lds(s_wo + o * 33, s_a[tl], 32);
     a *= dr.mask(site0 + 0, (uint32_t)t * 32 + o);
-    float h1 = a + (ok ? h0[R * 32 + o] : 0.f);
+    float h1 = a + sel0(ok, h0[R * 32 + o]);
     h1r[j] = h1;
     hcur[j] = h1;
     if (ok) h1s[R * 32 + o] = h1;
@@ -377,14 +380,14 @@ __global__ __launch_bounds__(256) void dense_post_bwd_kernel(TfDims d, int block
   float dres[4];   // gradient of the residual input accumulated so far
   float gam = 0.f, bet = 0.f;  // LN2 gamma/beta gradient partials of this thread's channel
   TOK_LOOP(j, tl, t, ok, R) {
-    dcur[j] = ok ? dF[R * d.DMF + d.DM + 32 * layer + o] : 0.f;
+    dcur[j] = sel0(ok, dF[R * d.DMF + d.DM + 32 * layer + o]);
     dres[j] = 0.f;
   }
   for (int pass = 1; pass >= 0; pass--) {  // pass 1: second ff on h2 ; pass 0: first ff on h1
     const float* hs = pass ? h2s : h1s;
     float xh[4], rs[4], zz[4][2], mk[4][2];
     TOK_LOOP(j, tl, t, ok, R) {
-      float h = ok ? hs[R * 32 + o] : 0.f;
+      float h = sel0(ok, hs[R * 32 + o]);
       float mean = hsum32(h) * (1.f / 32.f);
       float dd = h - mean;
       rs[j] = rsqrtf(hsum32(dd * dd) * (1.f / 32.f) + 1e-5f);
@@ -440,7 +443,7 @@ __global__ __launch_bounds__(256) void dense_post_bwd_kernel(TfDims d, int block
   // to_out: a = (Wout.ob + bout) * mask ; h1 = a + h0
   TOK_LOOP(j, tl, t, ok, R) {
     s_dg[tl][o] = ok ? dres[j] * dr.mask(site0 + 0, (uint32_t)t * 32 + o) : 0.f;
-    s_u[tl][o] = ok ? ob[R * 32 + o] : 0.f;
+    s_u[tl][o] = sel0(ok, ob[R * 32 + o]);
     if (ok) dh0acc[R * 32 + o] = dres[j];
   }
   __syncthreads();
@@ -472,17 +475,17 @@ __global__ __launch_bounds__(256) void dense_pre_bwd_kernel(TfDims d, int K, TfL
   stage_w(s_wq, p.wqkv + mo, 96, 32);
   for (int i = threadIdx.x; i < TB * K; i += 256) {
     int tl = i / K, k = i - tl * K, t = blockIdx.x * TB + tl;
-    s_in[i] = (t < BN) ? F[((int64_t)m * BN + t) * d.DMF + k] : 0.f;
+    s_in[i] = sel0(t < BN, F[((int64_t)m * BN + min(t, BN - 1)) * d.DMF + k]);
   }
   TOK_LOOP(j, tl, t, ok, R) {
-    float h = ok ? h0[R * 32 + o] : 0.f;
+    float h = sel0(ok, h0[R * 32 + o]);
     float mean = hsum32(h) * (1.f / 32.f);
     float dd = h - mean;
     rs[j] = rsqrtf(hsum32(dd * dd) * (1.f / 32.f) + 1e-5f);
     xh[j] = dd * rs[j];
     s_t[tl * 32 + o] = ok ? xh[j] * p.ln1g[mo + o] + p.ln1b[mo + o] : 0.f;
 #pragma unroll
-    for (int c = 0; c < 3; c++) s_dq[tl * 96 + o + 32 * c] = ok ? dqkv[R * 96 + o + 32 * c] : 0.f;
+    for (int c = 0; c < 3; c++) s_dq[tl * 96 + o + 32 * c] = sel0(ok, dqkv[R * 96 + o + 32 * c]);
   }
   __syncthreads();
   outer_acc(g.wqkv + mo, 96, 32, s_dq, 96, s_t, 32);
@@ -493,7 +496,7 @@ __global__ __launch_bounds__(256) void dense_pre_bwd_kernel(TfDims d, int K, TfL
     bet += dt;
     float dxh = dt * p.ln1g[mo + o];
     float m1 = hsum32(dxh) * (1.f / 32.f), m2 = hsum32(dxh * xh[j]) * (1.f / 32.f);
-    float dh = rs[j] * (dxh - m1 - xh[j] * m2) + (ok ? dh0acc[R * 32 + o] : 0.f);
+    float dh = rs[j] * (dxh - m1 - xh[j] * m2) + sel0(ok, dh0acc[R * 32 + o]);
     s_dh[tl * 32 + o] = ok ? dh : 0.f;
   }
   s_red[(grp * 32 + o) * 2 + 0] = gam;
@@ -588,7 +591,7 @@ __global__ __launch_bounds__(256) void block_out_bwd_kernel(TfDims d, int block,
   const uint32_t site0 = hdf_site_id(m, block, 4, 0);
   for (int i = threadIdx.x; i < TB * K; i += 256) {
     int tl = i / K, k = i - tl * K, t = blockIdx.x * TB + tl;
-    s_in[i] = (t < BN) ? F[((int64_t)m * BN + t) * d.DMF + k] : 0.f;
+    s_in[i] = sel0(t < BN, F[((int64_t)m * BN + min(t, BN - 1)) * d.DMF + k]);
   }
   for (int i = threadIdx.x; i < TB * DM; i += 256) {
     int tl = i / DM, c = i - tl * DM, t = blockIdx.x * TB + tl;
