@@ -530,7 +530,9 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ dlo
       float dl[HEAD_MAXCLS];
 #pragma unroll
       for (int o = 0; o < HEAD_MAXCLS; o++) {
-        dl[o] = (o < ncls && v < vox) ? ST<T>::ld(dlogits + ((int64_t)n * ncls + o) * vox + v) : 0.f;
+        // unconditional clamped load + select (never branch around a load)
+        float lv = ST<T>::ld(dlogits + ((int64_t)n * ncls + min(o, ncls - 1)) * vox + min(v, vox - 1));
+        dl[o] = (o < ncls && v < vox) ? lv : 0.f;
         dls[threadIdx.x][o] = dl[o];
       }
       if (v < vox) {
