@@ -624,6 +624,112 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int tiles_tota
 #endif
 }
 
+// ConvTranspose3d(k3,s2,p1,op1) forward with ALL 8 output-parity classes in one workgroup (Cin*sizeof(T) <= 128 B):
+// the (TD+1)x(TH+1)x(TW+1) input box is staged ONCE with full-Cin rows, then each class runs its 1..8 taps and
+// writes its 2x-strided outputs through an LDS staging tile as whole 16-byte chunks.  (The per-class launch of
+// conv_igemm_kernel<CONVT> restaged the same box 8 times for ~3 taps of work each.)
+template <typename T, int TD, int TH, int TW, int MB>
+__global__ __launch_bounds__(256) void convt_fused_kernel(ConvArgs a) {
+  static_assert(4 * MB * 32 == TD * TH * TW, "tile/wave decomposition");
+  constexpr int BD = TD + 1, BH = TH + 1, BW = TW + 1, BOX = BD * BH * BW;
+  constexpr int ESZ = sizeof(T), EPC = ST<T>::EPC;
+  constexpr int LP = 128 + 16;               // box row pitch (full Cin, up to 128 B)
+  constexpr int OP = 32 * ESZ + 16;          // output staging pitch
+  constexpr int MT = TD * TH * TW;
+  __shared__ __attribute__((aligned(16))) char lds[BOX * LP + MT * OP];
+  char* o_lds = lds + BOX * LP;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int ntz = (a.Di + TD - 1) / TD, nty = (a.Hi + TH - 1) / TH, ntx = (a.Wi + TW - 1) / TW;
+  int t = blockIdx.x;
+  const int tx = t % ntx;
+  t /= ntx;
+  const int ty = t % nty;
+  t /= nty;
+  const int tz = t % ntz;
+  const int n = t / ntz;
+  const int z0 = tz * TD, y0 = ty * TH, x0 = tx * TW;
+  const int n0 = blockIdx.y * 32;
+  const int RB = a.Cin * ESZ;                // 32, 64 or 128 bytes of channels per voxel
+  const int nfs = RB >> 5;
+
+  stage_box<T, BD, BH, BW, 128, LP>(lds, reinterpret_cast<const T*>(a.in), a.in_pitch, a.Cin, n, a.Di, a.Hi, a.Wi, z0,
+                                    y0, x0, 0, RB, a.in_scale, a.in_shift, a.in_relu);
+  __syncthreads();
+
+  int rowbase[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; mb++) {
+    int lin = (wave * MB + mb) * 32 + r;
+    int lz = lin / (TH * TW), ly = (lin / TW) % TH, lx = lin % TW;
+    rowbase[mb] = ((lz * BH + ly) * BW + lx) * LP + h * 16;
+  }
+  const int ch = n0 + r;
+  const bool ch_ok = ch < a.Cout;
+  const float bias = (a.bias && ch_ok) ? a.bias[ch] : 0.f;
+  const char* wrow = reinterpret_cast<const char*>(a.w) + ((int64_t)(n0 + r) * a.Cin) * ESZ + h * 16;
+  const int64_t wtap_stride = (int64_t)a.CoutP * a.Cin * ESZ;
+  T* outp = reinterpret_cast<T*>(a.out);
+  constexpr int CPO = 32 * ESZ / 16;
+  const int opart = threadIdx.x & (CPO - 1);
+  const bool oc_ok = n0 + opart * EPC < a.Cout;
+
+  for (int cls = 0; cls < 8; cls++) {
+    const int pz = (cls >> 2) & 1, py = (cls >> 1) & 1, px = cls & 1;
+    const int ntapz = pz ? 2 : 1, ntapy = py ? 2 : 1, ntapx = px ? 2 : 1;
+    f32x16 acc[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) acc[mb][i] = 0.f;
+    for (int jz = 0; jz < ntapz; jz++) {
+      const int offz = pz ? 1 - jz : 0, wz = pz ? 2 * jz : 1;
+      for (int jy = 0; jy < ntapy; jy++) {
+        const int offy = py ? 1 - jy : 0, wy = py ? 2 * jy : 1;
+        for (int jx = 0; jx < ntapx; jx++) {
+          const int offx = px ? 1 - jx : 0, wx = px ? 2 * jx : 1;
+          const int tapoff = ((offz * BH + offy) * BW + offx) * LP;
+          const char* wp = wrow + ((wz * 3 + wy) * 3 + wx) * wtap_stride;
+          for (int fs = 0; fs < nfs; fs++) {
+            u32x4 bfrag = *reinterpret_cast<const u32x4*>(wp + fs * 32);
+            u32x4 afrag[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; mb++)
+              afrag[mb] = *reinterpret_cast<const u32x4*>(lds + rowbase[mb] + tapoff + fs * 32);
+#pragma unroll
+            for (int mb = 0; mb < MB; mb++) Mma<T>::run(afrag[mb], bfrag, acc[mb]);
+          }
+        }
+      }
+    }
+    // stage this class's outputs as [tile voxel][32 ch] rows
+    if (cls > 0) __syncthreads();   // previous class's staging rows fully consumed
+#pragma unroll
+    for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        int lin = (wave * MB + mb) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        T tv;
+        ST<T>::st(&tv, acc[mb][i] + bias);
+        *reinterpret_cast<T*>(o_lds + lin * OP + r * ESZ) = tv;
+      }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MT * CPO / 256; k++) {
+      const int lv = (threadIdx.x + 256 * k) / CPO;
+      const int lz = lv / (TH * TW), ly = (lv / TW) % TH, lx = lv % TW;
+      const int gz = z0 + lz, gy = y0 + ly, gx = x0 + lx;
+      if (oc_ok && gz < a.Di && gy < a.Hi && gx < a.Wi) {
+        u32x4 v = *reinterpret_cast<const u32x4*>(o_lds + lv * OP + opart * 16);
+        T* p = outp + ((((int64_t)n * a.Do + 2 * gz + pz) * a.Ho + 2 * gy + py) * a.Wo + 2 * gx + px) * a.out_pitch + n0 +
+               opart * EPC;
+        *reinterpret_cast<u32x4*>(p) = v;
+      }
+    }
+  }
+}
+
 // weight gradient:  D[tap][sc][lc] = sum_{n,i} S[n,i][sc] * L[n, STRIDE*i-1+tap][lc]
 // bf16: both operands are contracted over VOXELS, which are the slow axis of the channels-last LDS
 // rows -> read with ds_read_b64_tr_b16 (hardware transpose, 4 voxels x 16 channels per 16 lanes).
@@ -951,6 +1057,12 @@ int launch_conv_t(int mode, const ConvArgs& a, hipStream_t st) {
   } else if (mode == 1) {
     return launch_cfg<T, 4, 4, 4, 1, 4, 2, 2, false>(a, st);  // 64 vox x 128 ch, stride 2
   } else {
+    if (a.Cin * (int)sizeof(T) <= 128 && !a.accumulate) {  // all 8 parity classes in one workgroup
+      dim3 grid(a.N * ceil_div(a.Di, 4) * ceil_div(a.Hi, 8) * ceil_div(a.Wi, 8), a.CoutP / 32);
+      hipLaunchKernelGGL((convt_fused_kernel<T, 4, 8, 8, 2>), grid, dim3(256), 0, st, a);
+      HDF_LAUNCH_CHECK();
+      return HDF_OK;
+    }
     if (a.CoutP <= 32) return launch_cfg<T, 4, 8, 8, 4, 1, 2, 1, true>(a, st);
     return launch_cfg<T, 4, 4, 8, 2, 2, 2, 1, true>(a, st);
   }
