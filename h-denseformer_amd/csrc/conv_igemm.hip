@@ -1055,6 +1055,7 @@ int launch_conv_t(int mode, const ConvArgs& a, hipStream_t st) {
     if (a.CoutP <= 32) return launch_cfg<T, 4, 8, 8, 4, 1, 2, 1, false>(a, st);                  // 256 vox x 32 ch
     return launch_cfg<T, 4, 8, 8, 2, 2, 4, 1, false>(a, st);                                     // 256 vox x 64 ch
   } else if (mode == 1) {
+    if (a.CoutP <= 64) return launch_cfg<T, 2, 4, 8, 2, 2, 1, 2, false>(a, st);  // 64 vox x 64 ch, stride 2
     return launch_cfg<T, 4, 4, 4, 1, 4, 2, 2, false>(a, st);  // 64 vox x 128 ch, stride 2
   } else {
     if (a.Cin * (int)sizeof(T) <= 128 && !a.accumulate) {  // all 8 parity classes in one workgroup
