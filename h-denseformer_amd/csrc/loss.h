@@ -14,5 +14,7 @@ int hdf_launch_loss_bwd(int dtype, const void* const* logits, const float* targe
                         int H, int W, const float* ws, const float* grad_out, void* const* dlogits, hipStream_t st);
 int hdf_launch_dice_counts(int dtype, const void* logits, const float* target, int N, int C, int64_t V,
                            unsigned long long* counts, hipStream_t st);
+int hdf_launch_confusion(int dtype, const void* logits, const float* target, int N, int C, int64_t V,
+                         unsigned long long* conf, int accumulate, hipStream_t st);
 int hdf_launch_adam(float* p, const float* g, float* m, float* v, const uint8_t* decay, int64_t n, float lr, float b1,
                     float b2, float eps, float wd, int step, float gscale, hipStream_t st);

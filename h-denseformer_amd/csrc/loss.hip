@@ -217,6 +217,33 @@ __global__ __launch_bounds__(256) void dice_count_kernel(const T* __restrict__ l
   if (threadIdx.x < C * 3) atomicAdd(counts + (int64_t)n * MAXC * 3 + threadIdx.x, (unsigned long long)red[threadIdx.x]);
 }
 
+// confusion[t][p] += #voxels with target class t and predicted class p, summed over the batch (the matrix that
+// metrics.RunningDice.update_matrix builds with sklearn on the CPU, metrics.py:104-133)
+template <typename T>
+__global__ __launch_bounds__(256) void confusion_kernel(const T* __restrict__ logits, const float* __restrict__ target,
+                                                        int C, int64_t V, unsigned long long* __restrict__ conf) {
+  __shared__ unsigned int red[MAXC * MAXC];
+  const int n = blockIdx.y;
+  if (threadIdx.x < MAXC * MAXC) red[threadIdx.x] = 0;
+  __syncthreads();
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < V; v += (int64_t)gridDim.x * 256) {
+    float bl = -INFINITY, bt = -INFINITY;
+    int pc = 0, tc = 0;
+#pragma unroll
+    for (int c = 0; c < MAXC; c++)
+      if (c < C) {
+        float l = ST<T>::ld(logits + ((int64_t)n * C + c) * V + v);
+        float t = target[((int64_t)n * C + c) * V + v];
+        if (l > bl) bl = l, pc = c;
+        if (t > bt) bt = t, tc = c;
+      }
+    atomicAdd(&red[tc * MAXC + pc], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < MAXC * MAXC && red[threadIdx.x])
+    atomicAdd(conf + threadIdx.x, (unsigned long long)red[threadIdx.x]);
+}
+
 // ---------------------------------------------------------------------------------- Adam
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, const uint8_t* __restrict__ decay, int64_t n, float lr, float b1,
@@ -308,6 +335,26 @@ int hdf_launch_dice_counts(int dtype, const void* logits, const float* target, i
   else
     hipLaunchKernelGGL(dice_count_kernel<float>, dim3(gx, N), dim3(256), 0, st, (const float*)logits, target, C, V,
                        counts);
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
+int hdf_launch_confusion(int dtype, const void* logits, const float* target, int N, int C, int64_t V,
+                         unsigned long long* conf, int accumulate, hipStream_t st) {
+  HDF_CHECK_ARG(C <= MAXC, "confusion: n_cls=%d", C);
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(conf, 0, (size_t)MAXC * MAXC * sizeof(unsigned long long), st);
+    if (e != hipSuccess) {
+      hdf_set_error("confusion: memset failed: %s", hipGetErrorString(e));
+      return HDF_ERR_HIP;
+    }
+  }
+  unsigned gx = (unsigned)std::min<int64_t>(ceil_div64(V, 256), 1024);
+  if (dtype == HDF_BF16)
+    hipLaunchKernelGGL(confusion_kernel<bf16_t>, dim3(gx, N), dim3(256), 0, st, (const bf16_t*)logits, target, C, V,
+                       conf);
+  else
+    hipLaunchKernelGGL(confusion_kernel<float>, dim3(gx, N), dim3(256), 0, st, (const float*)logits, target, C, V, conf);
   HDF_LAUNCH_CHECK();
   return HDF_OK;
 }

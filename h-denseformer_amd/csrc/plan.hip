@@ -912,6 +912,11 @@ int hdf_dice_counts(int dtype, const void* logits, const float* target_onehot, i
   return hdf_launch_dice_counts(dtype, logits, target_onehot, batch, n_cls, voxels, (unsigned long long*)counts,
                                 (hipStream_t)stream);
 }
+int hdf_confusion_matrix(int dtype, const void* logits, const float* target_onehot, int batch, int n_cls,
+                         int64_t voxels, uint64_t* confusion, int accumulate, hdf_stream stream) {
+  return hdf_launch_confusion(dtype, logits, target_onehot, batch, n_cls, voxels, (unsigned long long*)confusion,
+                              accumulate, (hipStream_t)stream);
+}
 int hdf_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* decay_mask,
                   int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                   float grad_scale, hdf_stream stream) {

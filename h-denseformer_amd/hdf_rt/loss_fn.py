@@ -76,3 +76,36 @@ def compute_dice(logits, target_onehot, ignore_index=0):
                     (cnt[:, k, 1].astype(np.float32) + cnt[:, k, 2].astype(np.float32) + np.float32(1e-5)))
         vals[k] = round(float(d), 4)
     return float(np.nanmean(vals[1:]))
+
+
+class RunningDice:
+    """Drop-in for metrics.RunningDice (metrics.py:82-151) with the confusion matrix accumulated on the GPU
+    (hdf_confusion_matrix): update_matrix takes the logits and the one-hot target directly -- no argmax maps are
+    copied to the host -- and compute_dice() does one 512-byte D2H."""
+
+    def __init__(self, labels, ignore_label=0):
+        self.labels = list(labels)
+        self.ignore_label = ignore_label
+        self.conf = None
+
+    def update_matrix(self, target_onehot, logits):
+        lg = logits.detach().contiguous()
+        tg = target_onehot.detach().float().contiguous()
+        b, c = lg.shape[:2]
+        first = self.conf is None
+        if first:
+            self.conf = torch.zeros((8, 8), dtype=torch.int64, device=lg.device)
+        check(lib().hdf_confusion_matrix(_DT[lg.dtype], ptr(lg), ptr(tg), b, c, lg[0, 0].numel(), ptr(self.conf),
+                                         0 if first else 1, stream_ptr()), "hdf_confusion_matrix")
+
+    def compute_dice(self, smooth=1e-5):
+        import numpy as np
+        c = len(self.labels)
+        m = self.conf.cpu().numpy()[:c, :c]
+        inter = np.diag(m)
+        union = m.sum(axis=1) + m.sum(axis=0)
+        iou = (2 * inter + smooth) / (union.astype(np.float32) + smooth)
+        return float(np.mean(iou[1:])), [round(float(v), 4) for v in iou]
+
+    def init_op(self):
+        self.conf = None

@@ -71,6 +71,12 @@ int hdf_loss_backward(int dtype, const void* out0, const void* out1, const void*
 int hdf_dice_counts(int dtype, const void* logits, const float* target_onehot, int batch, int n_cls, int64_t voxels,
                     uint64_t* counts, hdf_stream stream);
 
+/* running confusion matrix of metrics.RunningDice.update_matrix (metrics.py:104-133; the reference moves the argmax
+ * maps to the host and calls sklearn): confusion[8][8] uint64, rows = target class, cols = predicted class, summed
+ * over the batch; accumulate != 0 keeps the previous counts (running matrix over steps) */
+int hdf_confusion_matrix(int dtype, const void* logits, const float* target_onehot, int batch, int n_cls,
+                         int64_t voxels, uint64_t* confusion, int accumulate, hdf_stream stream);
+
 /* ---- optimizer: torch.optim.Adam as configured by trainer.py:793-840 (L2 weight decay on the mask) ---- */
 int hdf_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* decay_mask,
                   int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,

@@ -274,3 +274,21 @@ def test_full_size_forward_vs_reference_golden():
     d = compute_dice(outs[0], onehot.to(DEV))
     print("  dice", d, float(g["dice_rounded"]))
     assert abs(d - float(g["dice_rounded"])) <= 1e-4
+
+
+@pytest.mark.parametrize("tag", ["c4", "c4_absent", "c3"])
+def test_running_dice_confusion_matrix_vs_reference_golden(tag):
+    """metrics.RunningDice (sklearn confusion matrix on the host in the reference) from on-device counts."""
+    from hdf_rt.loss_fn import RunningDice
+    g = np.load(os.path.join(GOLDEN, "g7_metric.npz"))
+    logits = torch.from_numpy(g[tag + "_logits"]).to(DEV)
+    onehot = torch.from_numpy(g[tag + "_onehot"].astype(np.float32)).to(DEV)
+    c = logits.shape[1]
+    rd = RunningDice(labels=range(c), ignore_label=-1)
+    rd.update_matrix(onehot, logits)
+    mean, per = rd.compute_dice()
+    assert abs(mean - float(g[tag + "_run_dice"])) < 1e-6
+    assert np.allclose(per, g[tag + "_run_list"], atol=1e-4)
+    rd.update_matrix(onehot, logits)                       # running accumulation: doubling every count keeps the ratios
+    mean2, _ = rd.compute_dice()
+    assert abs(mean2 - mean) < 1e-5
