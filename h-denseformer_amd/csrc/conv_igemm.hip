@@ -624,6 +624,450 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int tiles_tota
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// conv_ws2: weights-stationary persistent kernel with a DOUBLE-BUFFERED activation tile.
+//
+// One wave per SIMD leaves nothing to hide the staging work behind, and in conv_ws_kernel the commit (global ->
+// InstanceNorm/ReLU transform -> LDS), the bounds logic and the prefetch issue cost as many cycles as the MFMAs.
+// Here a pass over item i (= one 4x8x8 tile x one CH-byte channel chunk) reads tile buffer i&1 while the SAME
+// instruction stream, in the gaps between its MFMAs, transforms and writes item i+1 into the other buffer and
+// re-loads the freed registers with item i+2: one workgroup barrier per pass, staging under the MFMAs.
+//  * unpadded rows (pitch == CH) + XOR swizzle of the 16-byte slots keep both buffers and the whole weight
+//    panel (27 x 32 x RB bytes) inside 160 KiB; a_swz makes every ds_read_b128 lane group conflict-free
+//  * a wave owns the M-blocks y = 2w, 2w+1: the A fragment of box row y' serves (mb, jy) with mb + jy == y', so a
+//    (jz, jx) group issues 4 A + 3 B fragment reads for 6 MFMAs (conv_ws_kernel: 9 reads)
+//  * the NCH passes of a tile are unrolled inside one "tile phase": chunk indices, buffer parities and the
+//    accumulators' lifetime are compile-time, tile coordinates advance incrementally once per tile (every
+//    instruction outside the MFMA shadow costs ~5 cycles with one wave per SIMD), scale/shift sit in an LDS table
+//  * bf16 epilogue: accumulators -> packed bf16 -> 2-byte global stores (32 lanes = one 64-byte voxel row), no LDS
+//    staging and no barrier; the cross-wave reduction of the InstanceNorm partials rides on the next pass's barrier
+template <int CH>
+__device__ __forceinline__ int a_swz(int row) {
+  return CH == 64 ? ((row >> 2) & 3) : ((row >> 3) & 1);
+}
+
+struct WsTile {
+  int n, z0, y0, x0, tile;
+};
+
+template <typename T, int CH, int RB, bool XF>
+__global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a, int tiles_total, int tiles_per_wg) {
+  constexpr int TD = 4, TH = 8, TW = 8, BD = TD + 2, BH = TH + 2, BW = TW + 2, BOX = BD * BH * BW;
+  constexpr int ESZ = sizeof(T), EPC = ST<T>::EPC;
+  constexpr int CIN = RB / ESZ;
+  constexpr int NCH = RB / CH, NFS = CH / 32, NG = 9 * NFS;
+  constexpr int CPV = CH / 16, CPV_SHIFT = (CPV == 4) ? 2 : 1;
+  constexpr int TOTAL = BOX * CPV, NJ = (TOTAL + 255) / 256;
+  constexpr int ABUF = BOX * CH;
+  constexpr int OFF_RED = 2 * ABUF, OFF_XF = OFF_RED + 2048, OFF_W = OFF_XF + 512;
+  constexpr int CPR = RB / 16, RP256 = 16 / CPR;
+  static_assert(CH == 32 || CH == 64, "chunk bytes");
+  static_assert(NCH == 1 || NCH % 2 == 0, "buffer parity at tile start must be compile-time");
+  static_assert(2 * CIN * 4 <= 512, "scale/shift table");
+  __shared__ __attribute__((aligned(256))) char lds[OFF_W + 27 * 32 * RB];
+  char* const a_lds = lds;
+  float* const s_red = reinterpret_cast<float*>(lds + OFF_RED);  // [2 tile parities][4 waves][32][2]
+  float* const s_xf = reinterpret_cast<float*>(lds + OFF_XF);
+  char* const w_lds = lds + OFF_W;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int n0 = blockIdx.y * 32;
+  const int part = tid & (CPV - 1);
+  constexpr bool xf = XF;  // input transform x*scale+shift (+relu) on the way into LDS; else a plain copy
+  const float relu_lo = (xf && a.in_relu) ? 0.f : -INFINITY;
+
+  // ---- weights -> LDS, once (rows [tap][cout 32][RB bytes], 16-byte slots XOR-swizzled by row)
+  for (int id = tid; id < 27 * 32 * CPR; id += 256) {
+    int row = id / CPR, ch = id - row * CPR;
+    int tap = row >> 5, rr = row & 31;
+    u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a.w) +
+                                              ((int64_t)(tap * a.CoutP + n0 + rr) * CIN) * ESZ + ch * 16);
+    int sw = ch ^ ((row / RP256) & (CPR - 1));
+    *reinterpret_cast<u32x4*>(w_lds + row * RB + sw * 16) = v;
+  }
+  const int bswz = (r / RP256) & (CPR - 1);
+
+  const int ntz = (a.Do + TD - 1) / TD, nty = (a.Ho + TH - 1) / TH, ntx = (a.Wo + TW - 1) / TW;
+  const int t_begin = blockIdx.x * tiles_per_wg, t_end = min(tiles_total, t_begin + tiles_per_wg);
+  if (t_begin >= t_end) return;
+
+  // ---- per-lane constants
+  // fragment read addresses: [jz][y'][jx] -> byte offset of this lane's 16-byte slot inside a tile buffer
+  int aaddr[3][4][3];
+  {
+    int dz, x;
+    ws_row_to_zx(r, dz, x);
+#pragma unroll
+    for (int jz = 0; jz < 3; jz++)
+#pragma unroll
+      for (int yp = 0; yp < 4; yp++)
+#pragma unroll
+        for (int jx = 0; jx < 3; jx++) {
+          int row = ((dz + jz) * BH + 2 * wave + yp) * BW + x + jx;
+          aaddr[jz][yp][jx] = row * CH + ((h ^ a_swz<CH>(row)) << 4);
+        }
+  }
+  int bvar[NCH];  // this lane's 16-byte slot inside a weight row, per channel chunk
+#pragma unroll
+  for (int c = 0; c < NCH; c++) bvar[c] = r * RB + (((c * CPV + h) ^ bswz) << 4);
+  // staging slots of this thread: source element offset, packed box coordinates, LDS byte offset
+  int boff[NJ], bxyz[NJ], woff[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
+    // threads past the end of the last slot redo the box's last voxel (same part): identical bytes to the same
+    // address, so neither the load nor the LDS write needs a predicate
+    int vox = min(tid + 256 * j, TOTAL - CPV + part) >> CPV_SHIFT;
+    int bz = vox / (BH * BW), rem = vox - bz * (BH * BW), by = rem / BW, bx = rem - by * BW;
+    boff[j] = ((bz * a.Hi + by) * a.Wi + bx) * (int)a.in_pitch;
+    bxyz[j] = (bz << 16) | (by << 8) | bx;
+    woff[j] = vox * CH + ((part ^ a_swz<CH>(vox)) << 4);
+  }
+
+  auto tile_init = [&](WsTile& c, int tile) {
+    int t = tile;
+    c.tile = tile;
+    c.x0 = (t % ntx) * TW;
+    t /= ntx;
+    c.y0 = (t % nty) * TH;
+    t /= nty;
+    c.z0 = (t % ntz) * TD;
+    c.n = t / ntz;
+  };
+  auto tile_next = [&](WsTile& c) {
+    c.tile++;
+    c.x0 += TW;
+    if (c.x0 >= a.Wo) {
+      c.x0 = 0;
+      c.y0 += TH;
+      if (c.y0 >= a.Ho) {
+        c.y0 = 0;
+        c.z0 += TD;
+        if (c.z0 >= a.Do) {
+          c.z0 = 0;
+          c.n++;
+        }
+      }
+    }
+  };
+  auto tile_valid = [&](const WsTile& c) { return c.tile < t_end; };
+  auto tile_interior = [&](const WsTile& c) {
+    return c.z0 >= 1 && c.y0 >= 1 && c.x0 >= 1 && c.z0 + TD + 1 <= a.Di && c.y0 + TH + 1 <= a.Hi &&
+           c.x0 + TW + 1 <= a.Wi;
+  };
+  const T* const src_safe = reinterpret_cast<const T*>(a.in) + part * EPC;
+  // first box voxel of the tile (channel chunk 0, this thread's part); may lie outside the tensor for border tiles
+  auto tile_org = [&](const WsTile& c) -> const T* {
+    return src_safe + ((((int64_t)c.n * a.Di + (c.z0 - 1)) * a.Hi + (c.y0 - 1)) * a.Wi + (c.x0 - 1)) * a.in_pitch;
+  };
+
+  u32x4 pf[NJ];
+  // box voxel of slot j inside the volume?  (border tiles only)
+  auto slot_ok = [&](int j, const WsTile& c) {
+    int iz = c.z0 - 1 + (bxyz[j] >> 16), iy = c.y0 - 1 + ((bxyz[j] >> 8) & 255), ix = c.x0 - 1 + (bxyz[j] & 255);
+    return ((unsigned)iz < (unsigned)a.Di) & ((unsigned)iy < (unsigned)a.Hi) & ((unsigned)ix < (unsigned)a.Wi);
+  };
+  // loads are UNCONDITIONAL (clamped address + select): one load per slot on every path, so the compiler's
+  // vmcnt bookkeeping stays exact and nothing ever branches around a load.
+  // FAST: the tile is a valid interior tile (no test at all); else `inter` (uniform) short-cuts the test.
+  auto load_one = [&](auto fast_tag, int j, int chunk, const WsTile& c, bool valid, bool inter, const T* org) {
+    if constexpr (decltype(fast_tag)::value) {
+      pf[j] = *reinterpret_cast<const u32x4*>(org + boff[j] + chunk * (CH / ESZ));
+    } else {
+      const bool ok = inter | (valid & slot_ok(j, c));  // bitwise: no short-circuit branches
+      const T* p = ok ? org + boff[j] + chunk * (CH / ESZ) : src_safe;
+      pf[j] = *reinterpret_cast<const u32x4*>(p);
+    }
+  };
+  float sc[EPC], sh[EPC];
+  auto read_xf = [&](int chunk) {
+    const int cb = chunk * (CH / ESZ) + part * EPC;
+#pragma unroll
+    for (int e = 0; e < EPC; e += 4) {
+      f32x4 u = *reinterpret_cast<const f32x4*>(s_xf + cb + e);
+      f32x4 v = *reinterpret_cast<const f32x4*>(s_xf + CIN + cb + e);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        sc[e + k] = u[k];
+        sh[e + k] = v[k];
+      }
+    }
+  };
+  // straight-line on purpose (no branch may split an MFMA group); relu_lo is -inf when there is no ReLU
+  auto commit_one = [&](auto fast_tag, int j, const WsTile& c, bool inter, char* dst) {
+    u32x4 v = pf[j];
+    if constexpr (XF) {
+      float f[EPC];
+      ST<T>::unpack(v, f);
+#pragma unroll
+      for (int e = 0; e < EPC; e++) f[e] = fmaxf(f[e] * sc[e] + sh[e], relu_lo);
+      v = ST<T>::pack(f);
+    }
+    if constexpr (!decltype(fast_tag)::value) {
+      const bool ok = inter | slot_ok(j, c);
+#pragma unroll
+      for (int k = 0; k < 4; k++) v[k] = ok ? v[k] : 0u;
+    }
+    *reinterpret_cast<u32x4*>(dst + woff[j]) = v;
+  };
+  int tbl_n = -1;
+  auto refresh_xf = [&](int n) {  // uniform; callers guarantee nobody still reads the old table
+    if (tid < CIN) {
+      s_xf[tid] = xf ? a.in_scale[(int64_t)n * CIN + tid] : 1.f;
+      s_xf[CIN + tid] = xf ? a.in_shift[(int64_t)n * CIN + tid] : 0.f;
+    }
+    tbl_n = n;
+    __syncthreads();
+  };
+
+  // T0: tile under the MFMAs, T1 / T2: the next two (T2 only feeds the loads when a tile is a single pass)
+  WsTile T0, T1, T2;
+  tile_init(T0, t_begin);
+  T1 = T0;
+  tile_next(T1);
+  T2 = T1;
+  tile_next(T2);
+  bool v1 = tile_valid(T1), v2 = tile_valid(T2);
+  bool i0 = tile_interior(T0), i1 = v1 && tile_interior(T1), i2 = v2 && tile_interior(T2);
+  const T* org0 = tile_org(T0);
+  const T* org1 = v1 ? tile_org(T1) : src_safe;
+  const T* org2 = v2 ? tile_org(T2) : src_safe;
+
+  // ---- prologue: item 0 -> buffer 0 (not overlapped), item 1 -> registers
+  {
+#pragma unroll
+    for (int j = 0; j < NJ; j++) load_one(std::false_type{}, j, 0, T0, true, i0, org0);
+    if constexpr (XF) {
+      refresh_xf(T0.n);
+      read_xf(0);
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; j++) commit_one(std::false_type{}, j, T0, i0, a_lds);
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      if (NCH > 1)
+        load_one(std::false_type{}, j, 1, T0, true, i0, org0);
+      else
+        load_one(std::false_type{}, j, 0, T1, v1, i1, org1);
+    }
+  }
+  WS_BARRIER();
+
+  const int ch = n0 + r;
+  const bool ch_ok = ch < a.Cout;
+  const float bias = (a.bias && ch_ok) ? a.bias[ch] : 0.f;
+  T* const outp = reinterpret_cast<T*>(a.out);
+  // accumulator register i of this lane: tile voxel (dz, 2w + mb, x) -> output element offset / packed (dz, x)
+  int eoff[16], ezx[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    int dz, x;
+    ws_row_to_zx((i & 3) + 8 * (i >> 2) + 4 * h, dz, x);
+    eoff[i] = ((dz * a.Ho) * a.Wo + x) * (int)a.out_pitch;
+    ezx[i] = (dz << 4) | x;
+  }
+  int pend_tile = -1;  // tile whose per-wave InstanceNorm partials wait in s_red for the next barrier
+  auto flush_stats = [&]() {
+    if (a.stat_partials && tid < 32) {
+      const float* sr = s_red + (pend_tile & 1) * 256;
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        t1 += sr[(k * 32 + tid) * 2 + 0];
+        t2 += sr[(k * 32 + tid) * 2 + 1];
+      }
+      float* q = a.stat_partials + ((int64_t)pend_tile * a.CoutP + n0 + tid) * 2;
+      q[0] = t1;
+      q[1] = t2;
+    }
+    pend_tile = -1;
+  };
+
+#ifdef WS_DBG_STAMPS
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = __builtin_amdgcn_s_memtime();
+#define WS2_STAMP(k)                                       \
+  {                                                        \
+    __builtin_amdgcn_sched_barrier(0);                     \
+    unsigned long long t_ = __builtin_amdgcn_s_memtime();  \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                    \
+    __builtin_amdgcn_sched_barrier(0);                     \
+    tacc[k] += t_ - tlast;                                 \
+    tlast = t_;                                            \
+  }
+#else
+#define WS2_STAMP(k)
+#endif
+
+  auto epilogue = [&](f32x16 (&acc)[2]) __attribute__((always_inline)) {
+    const int z0 = T0.z0, y0 = T0.y0, x0 = T0.x0;
+    float s1 = 0.f, s2 = 0.f;
+    const bool full = z0 + TD <= a.Do && y0 + TH <= a.Ho && x0 + TW <= a.Wo;
+    T* const obase = outp + ((((int64_t)T0.n * a.Do + z0) * a.Ho + y0 + 2 * wave) * a.Wo + x0) * a.out_pitch + ch;
+    if (full && ch_ok && !a.accumulate) {
+#pragma unroll
+      for (int mb = 0; mb < 2; mb++) {
+        T* const orow = obase + (int64_t)mb * a.Wo * a.out_pitch;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          const float v = acc[mb][i] + bias;
+          ST<T>::st(orow + eoff[i], v);
+          s1 += v;
+          s2 += v * v;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int mb = 0; mb < 2; mb++) {
+        const int gy = y0 + 2 * wave + mb;
+        T* const orow = obase + (int64_t)mb * a.Wo * a.out_pitch;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          const int gz = z0 + (ezx[i] >> 4), gx = x0 + (ezx[i] & 15);
+          const float v = acc[mb][i] + bias;
+          const bool ok = gz < a.Do && gy < a.Ho && gx < a.Wo;
+          if (ok && ch_ok) {
+            float o = v;
+            if (a.accumulate) o += ST<T>::ld(orow + eoff[i]);
+            ST<T>::st(orow + eoff[i], o);
+          }
+          const float mk = ok ? 1.f : 0.f;
+          s1 += mk * v;
+          s2 += mk * v * v;
+        }
+      }
+    }
+    if (a.stat_partials) {
+      if (!ch_ok) s1 = s2 = 0.f;
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (h == 0) {
+        float* sr = s_red + (T0.tile & 1) * 256;
+        sr[(wave * 32 + r) * 2 + 0] = s1;
+        sr[(wave * 32 + r) * 2 + 1] = s2;
+      }
+      pend_tile = T0.tile;
+    }
+  };
+
+  // One tile: NCH passes.  Pass c runs the MFMAs of chunk c out of buffer (PAR0 + c) & 1 and, in their shadow,
+  // commits item c+1 (chunk (c+1) % NCH of T0 or T1) into the other buffer and loads item c+2 into the freed pf.
+  auto tile_phase = [&](auto par_tag, auto fast_tag) __attribute__((always_inline)) {
+    constexpr int PAR0 = decltype(par_tag)::value;
+    f32x16 acc[2];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      constexpr int dummy = 0;
+      (void)dummy;
+      const int PAR = (PAR0 + c) & 1;
+      char* const a_rd = a_lds + PAR * ABUF;
+      char* const a_wr = a_lds + (1 - PAR) * ABUF;
+      // commit target: item c+1; load target: item c+2
+      const bool c_next = (c + 1 >= NCH);                  // commit goes to T1
+      const int c_chunk = (c + 1) % NCH;
+      const int l_tile = (c + 2) / NCH;                    // 0: T0, 1: T1, 2: T2
+      const int l_chunk = (c + 2) % NCH;
+      const WsTile& CT = c_next ? T1 : T0;
+      const bool c_int = c_next ? (i1 | !v1) : i0;         // an invalid next tile is committed as garbage, unchecked
+      const WsTile& LT = l_tile == 0 ? T0 : (l_tile == 1 ? T1 : T2);
+      const bool l_val = l_tile == 0 ? true : (l_tile == 1 ? v1 : v2);
+      const bool l_int = l_tile == 0 ? i0 : (l_tile == 1 ? i1 : i2);
+      const T* const l_org = l_tile == 0 ? org0 : (l_tile == 1 ? org1 : org2);
+      WS2_STAMP(3)
+      if constexpr (XF) {
+        if (CT.n != tbl_n && (!c_next || v1)) refresh_xf(CT.n);
+        read_xf(c_chunk);
+      }
+      WS2_STAMP(0)
+      u32x4 af[2][4], bf[2][3];
+      auto read_group = [&](int g, u32x4 (&A)[4], u32x4 (&B)[3]) {
+        const int t = g / NFS, fs = g % NFS, jz = t / 3, jx = t % 3;
+        auto rdA = [&](int yp) { A[yp] = *reinterpret_cast<const u32x4*>(a_rd + (aaddr[jz][yp][jx] ^ (fs * 32))); };
+        auto rdB = [&](int jy) {
+          B[jy] = *reinterpret_cast<const u32x4*>(w_lds + ((jz * 9 + jy * 3 + jx) * 32) * RB + (bvar[c] ^ (fs * 32)));
+        };
+        // in order of first use (LDS returns in order, the waits are counted)
+        rdB(0);
+        rdA(0);
+        rdA(1);
+        rdB(1);
+        rdA(2);
+        rdB(2);
+        rdA(3);
+      };
+      read_group(0, af[0], bf[0]);
+#pragma unroll
+      for (int g = 0; g < NG; g++) {
+        if (g + 1 < NG) read_group(g + 1, af[(g + 1) & 1], bf[(g + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);  // look-ahead reads stay ABOVE this group's MFMAs
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+          if ((j * NG) / NJ == g) {
+            commit_one(fast_tag, j, CT, c_int, a_wr);
+            load_one(fast_tag, j, l_chunk, LT, l_val, l_int, l_org);
+          }
+        }
+        u32x4(&A)[4] = af[g & 1];
+        u32x4(&B)[3] = bf[g & 1];
+        if (c == 0 && g == 0) {  // first MFMAs of the tile take a zero C operand: no accumulator clearing
+#pragma unroll
+          for (int i = 0; i < 16; i++) acc[0][i] = acc[1][i] = 0.f;
+        }
+        Mma<T>::run(A[0], B[0], acc[0]);
+        Mma<T>::run(A[1], B[0], acc[1]);
+        Mma<T>::run(A[1], B[1], acc[0]);
+        Mma<T>::run(A[2], B[1], acc[1]);
+        Mma<T>::run(A[2], B[2], acc[0]);
+        Mma<T>::run(A[3], B[2], acc[1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      WS2_STAMP(1)
+      WS_BARRIER();  // buffer PAR fully read, buffer 1-PAR fully written
+      WS2_STAMP(2)
+      if (c == 0 && pend_tile >= 0) flush_stats();  // previous tile's partials: every wave's s_red row is visible now
+    }
+    epilogue(acc);
+    WS2_STAMP(4)
+  };
+
+  int par = 0;
+  while (true) {
+    const bool fast = (NCH == 1) ? (i1 && i2) : (i0 && i1);
+    if (NCH > 1 || par == 0) {
+      if (fast)
+        tile_phase(std::integral_constant<int, 0>{}, std::true_type{});
+      else
+        tile_phase(std::integral_constant<int, 0>{}, std::false_type{});
+    } else {
+      if (fast)
+        tile_phase(std::integral_constant<int, 1>{}, std::true_type{});
+      else
+        tile_phase(std::integral_constant<int, 1>{}, std::false_type{});
+    }
+    if (NCH == 1) par ^= 1;
+    if (!v1) break;
+    T0 = T1;
+    T1 = T2;
+    i0 = i1;
+    i1 = i2;
+    v1 = v2;
+    org0 = org1;
+    org1 = org2;
+    tile_next(T2);
+    v2 = tile_valid(T2);
+    i2 = v2 && tile_interior(T2);
+    org2 = v2 ? tile_org(T2) : src_safe;
+  }
+  if (pend_tile >= 0) {
+    __syncthreads();
+    flush_stats();
+  }
+#ifdef WS_DBG_STAMPS
+  if (tid == 0 && blockIdx.y == 0)
+    for (int k = 0; k < 8; k++) a.stat_partials[(int64_t)blockIdx.x * 8 + k] = (float)tacc[k];
+#endif
+}
+
 // ConvTranspose3d(k3,s2,p1,op1) forward with ALL 8 output-parity classes in one workgroup (Cin*sizeof(T) <= 128 B):
 // the (TD+1)x(TH+1)x(TW+1) input box is staged ONCE with full-Cin rows, then each class runs its 1..8 taps and
 // writes its 2x-strided outputs through an LDS staging tile as whole 16-byte chunks.  (The per-class launch of
@@ -1044,11 +1488,38 @@ int launch_ws(const ConvArgs& a, hipStream_t st) {
   return HDF_OK;
 }
 
+// A/B knob: HDF_WS_OLD=1 selects the single-buffered conv_ws_kernel
+inline bool ws_use_old() {
+  static const bool v = getenv("HDF_WS_OLD") != nullptr;
+  return v;
+}
+
+template <typename T, int CH, int RB>
+int launch_ws2(const ConvArgs& a, hipStream_t st) {
+  const int tiles = a.N * ceil_div(a.Do, 4) * ceil_div(a.Ho, 8) * ceil_div(a.Wo, 8);
+  const int cout_tiles = a.CoutP / 32;
+  int gx = std::min(tiles, std::max(1, 256 / cout_tiles));
+  const int tpw = ceil_div(tiles, gx);
+  gx = ceil_div(tiles, tpw);
+  if (a.in_scale)
+    hipLaunchKernelGGL((conv_ws2_kernel<T, CH, RB, true>), dim3(gx, cout_tiles), dim3(256), 0, st, a, tiles, tpw);
+  else
+    hipLaunchKernelGGL((conv_ws2_kernel<T, CH, RB, false>), dim3(gx, cout_tiles), dim3(256), 0, st, a, tiles, tpw);
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
 template <typename T>
 int launch_conv_t(int mode, const ConvArgs& a, hipStream_t st) {
   if (mode == 0) {
-    const int ws = ws_cfg(mode, a.Do, a.Ho, a.Wo, a.Cin * (int)sizeof(T));
-    if (ws == 2 && a.Cin * (int)sizeof(T) == 32) return launch_ws<T, 8, 8, 8, 4, 64, 1>(a, st);
+    const int rb = a.Cin * (int)sizeof(T);
+    const int ws = ws_cfg(mode, a.Do, a.Ho, a.Wo, rb);
+    if (ws && !ws_use_old()) {
+      if (rb == 32) return launch_ws2<T, 32, 32>(a, st);
+      if (rb == 64) return launch_ws2<T, 64, 64>(a, st);
+      if (rb == 128) return launch_ws2<T, 32, 128>(a, st);
+    }
+    if (ws == 2 && rb == 32) return launch_ws<T, 8, 8, 8, 4, 64, 1>(a, st);
     if (ws == 2) return launch_ws<T, 8, 8, 8, 4, 64, 2>(a, st);
     if (ws == 1) return launch_ws<T, 4, 8, 8, 2, 128, 2>(a, st);
     if (small_tile(a.Do, a.Ho, a.Wo)) return launch_cfg<T, 4, 4, 8, 2, 2, 2, 1, false>(a, st);  // 128 vox x 64 ch
@@ -1099,7 +1570,7 @@ int launch_wgrad_t(WgradArgs a, float* dw, int sc_store, int lc_store, int accum
 
 int hdf_conv_stat_tiles(int mode, int Do, int Ho, int Wo, int row_bytes) {
   if (mode != 0) return 0;
-  if (ws_cfg(mode, Do, Ho, Wo, row_bytes) == 2) return ceil_div(Do, 8) * ceil_div(Ho, 8) * ceil_div(Wo, 8);
+  if (ws_cfg(mode, Do, Ho, Wo, row_bytes) == 2 && ws_use_old()) return ceil_div(Do, 8) * ceil_div(Ho, 8) * ceil_div(Wo, 8);
   if (small_tile(Do, Ho, Wo)) return ceil_div(Do, 4) * ceil_div(Ho, 4) * ceil_div(Wo, 8);
   return ceil_div(Do, 4) * ceil_div(Ho, 8) * ceil_div(Wo, 8);
 }

@@ -55,7 +55,13 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
   __bf16 h = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN preserved
   return __builtin_bit_cast(uint16_t, h);
 }
-__device__ __forceinline__ uint32_t pack_bf2(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+// one v_cvt_pk_bf16_f32 for the pair (two scalar converts + shift + or cost three times the issue slots)
+__device__ __forceinline__ uint32_t pack_bf2(float a, float b) {
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
 
 template <typename T>
 struct ST;  // storage traits

@@ -685,23 +685,36 @@ __global__ void in_bwd_apply_kernel(const T* __restrict__ da, int64_t da_pitch, 
                                     const float* __restrict__ kb, T* __restrict__ dy, int64_t dy_pitch, int N, int C,
                                     int64_t vox) {
   constexpr int EPC = ST<T>::EPC;
+  constexpr int U = 4;  // chunks per thread per iteration: 8 independent 16-byte loads in flight
   const int cols = C / EPC;
-  int64_t total = (int64_t)N * vox * cols;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t row = i / cols;
-    int c0 = (int)(i - row * cols) * EPC;
-    int n = (int)(row / vox);
-    float g[EPC], f[EPC];
-    load_chunk<T>(da + row * da_pitch + c0, g);
-    load_chunk<T>(y + row * y_pitch + c0, f);
+  const int64_t total = (int64_t)N * vox * cols;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < total; i0 += stride * U) {
+    float g[U][EPC], f[U][EPC];
+    int64_t rowv[U];
+    int c0v[U];
 #pragma unroll
-    for (int e = 0; e < EPC; e++) {
-      int64_t o = (int64_t)n * C + c0 + e;
-      float gg = (f[e] * scale[o] + shift[o] > 0.f) ? g[e] : 0.f;
-      float xh = (f[e] - mean[o]) * rstd[o];
-      g[e] = k1[o] * (gg - ka[o] - xh * kb[o]);
+    for (int u = 0; u < U; u++) {
+      int64_t i = min(i0 + u * stride, total - 1);  // clamped: never branch around a load
+      rowv[u] = i / cols;
+      c0v[u] = (int)(i - rowv[u] * cols) * EPC;
+      load_chunk<T>(da + rowv[u] * da_pitch + c0v[u], g[u]);
+      load_chunk<T>(y + rowv[u] * y_pitch + c0v[u], f[u]);
     }
-    store_chunk<T>(dy + row * dy_pitch + c0, g);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (i0 + u * stride < total) {
+        const int n = (int)(rowv[u] / vox);
+#pragma unroll
+        for (int e = 0; e < EPC; e++) {
+          int64_t o = (int64_t)n * C + c0v[u] + e;
+          float gg = (f[u][e] * scale[o] + shift[o] > 0.f) ? g[u][e] : 0.f;
+          float xh = (f[u][e] - mean[o]) * rstd[o];
+          g[u][e] = k1[o] * (gg - ka[o] - xh * kb[o]);
+        }
+        store_chunk<T>(dy + rowv[u] * dy_pitch + c0v[u], g[u]);
+      }
+    }
   }
 }
 

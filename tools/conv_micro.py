@@ -61,6 +61,8 @@ ms = e0.elapsed_time(e1) / a.reps
 if os.environ.get("WS_STAMPS") and a.op == "conv":
     t = part[:256 * 8].view(256, 8).double().cpu()
     names = ["commit", "barrier1", "prefetch-issue", "mfma-loop", "barriers2+3", "epi:stage+stats", "epi:barrier+stores", "loop-top"]
+    if not os.environ.get("HDF_WS_OLD"):
+        names = ["xf-read", "mfma-phase", "barrier", "pass/tile-top", "epilogue", "-", "-", "-"]
     tot = t.sum(1).mean().item()
     print("  per-WG cycles (mean over WGs):", {n: int(v) for n, v in zip(names, t.mean(0).tolist())}, "total", int(tot))
 print(f"{a.op} {cin}->{cout} @{s}^3 n={n} {a.dtype} xf={a.xf}: {ms*1e3:.1f} us  {flops/ms/1e9:.1f} TFLOP/s")
