@@ -1409,6 +1409,340 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// conv_wgrad2: bf16 stride-1 weight gradient with DOUBLE-BUFFERED tiles (same idea as conv_ws2_kernel).
+// conv_wgrad_kernel spends ~3 cycles outside the matrix pipe per MFMA cycle: per-slot index arithmetic in the
+// prefetch, the transform + LDS commit, and a transposed-read latency exposed in every k-step.  Here the tile
+// under the MFMAs (T0, buffer PAR) is read with a one-k-step look-ahead while, in the gaps of the same stream,
+// tile T1 goes registers -> (InstanceNorm/ReLU) -> the other buffer and tile T2's loads refill the registers.
+// One barrier per tile; slot offsets are per-thread constants; tile coordinates advance incrementally.
+template <bool XFL>
+__global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
+  using T = bf16_t;
+  constexpr int TD = 4, TH = 8, TW = 8, MT = TD * TH * TW, BD = TD + 2, BH = TH + 2, BW = TW + 2, BOXL = BD * BH * BW;
+  // unpadded 64-byte rows: the 4 voxel rows x 16 dwords a ds_read_b64_tr_b16 half-wave touches then tile the 64
+  // banks exactly (an 80-byte pitch wraps the 4th row onto the 1st: 2-way conflicts on every read)
+  constexpr int LP = 64, CPV = 4, EPC = 8;
+  constexpr int SBUF = MT * LP, LBUF = BOXL * LP, BUF = SBUF + LBUF;
+  constexpr int NS_ = MT * CPV / 256, NL_ = (BOXL * CPV + 255) / 256, NSLOT = NS_ + NL_;
+  constexpr int KS = MT / 16, NT = 7;  // k-steps per tile, taps per wave (7,7,7,6 + one dummy)
+  constexpr int PD = 6, NPF = PD + 1;  // a slot's global load is issued PD k-steps before its commit; register ring
+  static_assert(NSLOT + 2 <= KS && NSLOT >= PD, "slot schedule: commits at k-steps 0..NSLOT-1, loads PD steps ahead");
+  __shared__ __attribute__((aligned(256))) char lds[2 * BUF + 256];
+  float* const s_xf = reinterpret_cast<float*>(lds + 2 * BUF);  // [32 scale][32 shift] of the large operand
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int scb = blockIdx.y, lcb = blockIdx.z;
+  const int part = tid & (CPV - 1);
+  const int ntz = (a.Ds + TD - 1) / TD, nty = (a.Hs + TH - 1) / TH, ntx = (a.Ws + TW - 1) / TW;
+  const int t_begin = blockIdx.x * a.tiles_per_group;
+  const int t_end = min(a.num_tiles, t_begin + a.tiles_per_group);
+  const float relu_lo = (XFL && a.lg_relu) ? 0.f : -INFINITY;
+
+  // ---- transposed-read addresses (lane roles of ds_read_b64_tr_b16: 4 voxels x 16 channels per 16 lanes)
+  const int g4 = lane >> 4, i16 = lane & 15, q = i16 >> 2, p4 = i16 & 3;
+  const int hh = g4 >> 1, cb = (g4 & 1) * 16;
+  const int colb = (cb + 4 * p4) * 2;
+  // per tap; the voxel group tt and the k-step ride in the 16-bit immediate offset, the buffer is added per tile
+  int sA, lB[NT];
+  sA = (8 * hh + q) * LP + colb;
+#pragma unroll
+  for (int j = 0; j < NT; j++) {
+    int tap = wave * NT + j;
+    if (tap >= 27) tap = 0;  // dummy slot of the last wave (never stored)
+    const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+    lB[j] = SBUF + (((kz * BH + ky + hh) * BW) + kx + q) * LP + colb;
+  }
+  const int ntaps_here = min(NT, 27 - wave * NT);
+
+  // ---- staging slots (per-thread constants): slot s < NS_ -> small tile, else large box
+  // small tile: slot s holds voxel v0 + 64 s = one z-plane further (everything else is a compile-time offset);
+  // large box: explicit per-slot constants
+  const int v0 = tid >> 2, s_by = (v0 >> 3) & 7, s_bx = v0 & 7;  // v0 < 64: z-plane 0
+  const int s_goff0 = (s_by * a.Ws + s_bx) * (int)a.sm_pitch;
+  const int s_plane = a.Hs * a.Ws * (int)a.sm_pitch;
+  const int w0 = v0 * LP + part * 16;
+  int goffL[NL_], gxyzL[NL_];
+#pragma unroll
+  for (int k = 0; k < NL_; k++) {
+    // threads past the end of the last slot redo the box's last voxel (same part): no predicate needed
+    const int vox = min(tid + 256 * k, BOXL * CPV - CPV + part) >> 2;
+    const int bz = vox / (BH * BW), rem = vox - bz * (BH * BW), by = rem / BW, bx = rem - by * BW;
+    goffL[k] = ((bz * a.Hl + by) * a.Wl + bx) * (int)a.lg_pitch;
+    gxyzL[k] = (bz << 16) | (by << 8) | bx;
+  }
+  const int w_last = SBUF + (min(tid + 256 * (NL_ - 1), BOXL * CPV - CPV + part) >> 2) * LP + part * 16;
+  auto goff = [&](int s) { return s < NS_ ? s_goff0 + s * s_plane : goffL[s - NS_]; };
+  auto woff = [&](int s) {
+    return s < NS_ ? w0 + s * 64 * LP : (s < NSLOT - 1 ? SBUF + w0 + (s - NS_) * 64 * LP : w_last);
+  };
+  const bool sc_ok = scb * 32 + part * EPC < a.SC, lc_ok = lcb * 32 + part * EPC < a.LC;
+  const bool chan_all = (a.SC % 32 == 0) && (a.LC % 32 == 0);
+  const T* const s_safe = reinterpret_cast<const T*>(a.sm);
+  const T* const l_safe = reinterpret_cast<const T*>(a.lg);
+  const T* const s_src = s_safe + scb * 32 + part * EPC;
+  const T* const l_src = l_safe + lcb * 32 + part * EPC;
+
+  auto tile_init = [&](WsTile& c, int tile) {
+    int t = tile;
+    c.tile = tile;
+    c.x0 = (t % ntx) * TW;
+    t /= ntx;
+    c.y0 = (t % nty) * TH;
+    t /= nty;
+    c.z0 = (t % ntz) * TD;
+    c.n = t / ntz;
+  };
+  auto tile_next = [&](WsTile& c) {
+    c.tile++;
+    c.x0 += TW;
+    if (c.x0 >= a.Ws) {
+      c.x0 = 0;
+      c.y0 += TH;
+      if (c.y0 >= a.Hs) {
+        c.y0 = 0;
+        c.z0 += TD;
+        if (c.z0 >= a.Ds) {
+          c.z0 = 0;
+          c.n++;
+        }
+      }
+    }
+  };
+  auto tile_valid = [&](const WsTile& c) { return c.tile < t_end; };
+  // whole small tile and whole large box inside the tensors, every channel part real: no test anywhere
+  auto tile_interior = [&](const WsTile& c) {
+    return chan_all && c.z0 >= 1 && c.y0 >= 1 && c.x0 >= 1 && c.z0 + TD + 1 <= a.Dl && c.y0 + TH + 1 <= a.Hl &&
+           c.x0 + TW + 1 <= a.Wl;
+  };
+  auto s_org_of = [&](const WsTile& c) -> const T* {
+    return s_src + ((((int64_t)c.n * a.Ds + c.z0) * a.Hs + c.y0) * a.Ws + c.x0) * a.sm_pitch;
+  };
+  auto l_org_of = [&](const WsTile& c) -> const T* {
+    return l_src + ((((int64_t)c.n * a.Dl + (c.z0 - 1)) * a.Hl + (c.y0 - 1)) * a.Wl + (c.x0 - 1)) * a.lg_pitch;
+  };
+  auto slot_ok = [&](int s, const WsTile& c) {
+    if (s < NS_) return sc_ok & (c.z0 + s < a.Ds) & (c.y0 + s_by < a.Hs) & (c.x0 + s_bx < a.Ws);
+    const int g = gxyzL[s - NS_];
+    const int bz = g >> 16, by = (g >> 8) & 255, bx = g & 255;
+    return lc_ok & ((unsigned)(c.z0 - 1 + bz) < (unsigned)a.Dl) & ((unsigned)(c.y0 - 1 + by) < (unsigned)a.Hl) &
+           ((unsigned)(c.x0 - 1 + bx) < (unsigned)a.Wl);
+  };
+
+  u32x4 pf[NPF];  // slot s lives in pf[s % NPF] from its load to its commit PD k-steps later
+  // unconditional loads from a clamped address (never branch around a load)
+  auto load_one = [&](auto fast_tag, int s, const WsTile& c, bool valid, const T* sorg, const T* lorg) {
+    const T* org = (s < NS_) ? sorg : lorg;
+    if constexpr (decltype(fast_tag)::value) {
+      pf[s % NPF] = *reinterpret_cast<const u32x4*>(org + goff(s));
+    } else {
+      const bool ok = valid & slot_ok(s, c);
+      const T* p = ok ? org + goff(s) : ((s < NS_) ? s_safe : l_safe);
+      pf[s % NPF] = *reinterpret_cast<const u32x4*>(p);
+    }
+  };
+  float sc[EPC], sh[EPC];
+  auto read_xf = [&]() {
+#pragma unroll
+    for (int e = 0; e < EPC; e += 4) {
+      f32x4 u = *reinterpret_cast<const f32x4*>(s_xf + part * EPC + e);
+      f32x4 v = *reinterpret_cast<const f32x4*>(s_xf + 32 + part * EPC + e);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        sc[e + k] = u[k];
+        sh[e + k] = v[k];
+      }
+    }
+  };
+  auto commit_one = [&](auto fast_tag, int s, const WsTile& c, char* dst) {
+    u32x4 v = pf[s % NPF];
+    if constexpr (XFL) {
+      if (s >= NS_) {
+        float f[EPC];
+        ST<T>::unpack(v, f);
+#pragma unroll
+        for (int e = 0; e < EPC; e++) f[e] = fmaxf(f[e] * sc[e] + sh[e], relu_lo);
+        v = ST<T>::pack(f);
+      }
+    }
+    if constexpr (!decltype(fast_tag)::value) {
+      const bool ok = slot_ok(s, c);
+#pragma unroll
+      for (int k = 0; k < 4; k++) v[k] = ok ? v[k] : 0u;
+    }
+    *reinterpret_cast<u32x4*>(dst + woff(s)) = v;
+  };
+  int tbl_n = -1;
+  auto refresh_xf = [&](int n) {  // uniform; nobody reads the old table any more (its values live in sc/sh)
+    if (tid < 32) {
+      const int c = min(lcb * 32 + tid, a.LC - 1);
+      s_xf[tid] = a.lg_scale[(int64_t)n * a.LC + c];
+      s_xf[32 + tid] = a.lg_shift[(int64_t)n * a.LC + c];
+    }
+    tbl_n = n;
+    __syncthreads();
+    read_xf();
+  };
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; j++)
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[j][i] = 0.f;
+
+#ifdef WS_DBG_STAMPS
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = __builtin_amdgcn_s_memtime();
+#endif
+  if (t_begin < t_end) {
+    WsTile T0, T1, T2;
+    tile_init(T0, t_begin);
+    T1 = T0;
+    tile_next(T1);
+    T2 = T1;
+    tile_next(T2);
+    bool v1 = tile_valid(T1), v2 = tile_valid(T2);
+    bool i1 = v1 && tile_interior(T1), i2 = v2 && tile_interior(T2);
+    const T* so1 = v1 ? s_org_of(T1) : s_safe;
+    const T* lo1 = v1 ? l_org_of(T1) : l_safe;
+    const T* so2 = v2 ? s_org_of(T2) : s_safe;
+    const T* lo2 = v2 ? l_org_of(T2) : l_safe;
+    // ---- prologue: T0 -> buffer 0 (not overlapped, NPF slots at a time), first PD slots of T1 -> registers
+    {
+      const T* so0 = s_org_of(T0);
+      const T* lo0 = l_org_of(T0);
+      if constexpr (XFL) refresh_xf(T0.n);
+#pragma unroll
+      for (int s0 = 0; s0 < NSLOT; s0 += NPF) {
+#pragma unroll
+        for (int s = s0; s < s0 + NPF && s < NSLOT; s++) load_one(std::false_type{}, s, T0, true, so0, lo0);
+#pragma unroll
+        for (int s = s0; s < s0 + NPF && s < NSLOT; s++) commit_one(std::false_type{}, s, T0, lds);
+      }
+#pragma unroll
+      for (int s = 0; s < PD; s++) load_one(std::false_type{}, s, T1, v1, so1, lo1);
+    }
+    WS_BARRIER();
+
+    using lds_s16x4 = s16x4 __attribute__((address_space(3)));
+    auto tr_read = [&](int off) {
+      s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + off));
+      return __builtin_bit_cast(u32x2, v);
+    };
+    // The buffer parity is a RUN-TIME value folded into the 8 read-address registers: with it as a template
+    // parameter the four (parity x fast) copies of the phase disagreed on where the in-flight staging registers
+    // live, and the compiler drained every outstanding load (s_waitcnt vmcnt(0)) at the loop's back edge.
+    int par = 0;
+    auto tile_phase = [&](auto fast_tag) __attribute__((always_inline)) {
+      constexpr int FASTI = decltype(fast_tag)::value ? 0 : 4;
+      (void)FASTI;
+      char* const a_wr = lds + (1 - par) * BUF;
+      const int sAw = sA + par * BUF;
+      int lBw[NT];
+#pragma unroll
+      for (int j = 0; j < NT; j++) lBw[j] = lB[j] + par * BUF;
+      if constexpr (XFL) {
+        if (v1 && T1.n != tbl_n) refresh_xf(T1.n);
+      }
+      WS2_STAMP(0)
+      // B fragments: ONE register set, re-read for k-step ks+1 right behind the MFMA that consumed them (the arch
+      // VGPR file is 256 deep: a second set pushed the staging ring into AGPR/scratch spills); A: two sets
+      u32x2 A0[2], A1[2], B0[NT], B1[NT];
+      auto koff = [&](int ks) { return ((ks >> 2) * BH * BW + 2 * (ks & 3) * BW) * LP; };
+      auto read_a = [&](int ks) {
+        A0[ks & 1] = tr_read(sAw + ks * 16 * LP);
+        A1[ks & 1] = tr_read(sAw + ks * 16 * LP + 4 * LP);
+      };
+      auto read_b = [&](int ks, int j) {
+        B0[j] = tr_read(lBw[j] + koff(ks));
+        B1[j] = tr_read(lBw[j] + koff(ks) + 4 * LP);
+      };
+      read_a(0);
+#pragma unroll
+      for (int j = 0; j < NT; j++) read_b(0, j);
+#pragma unroll
+      for (int ks = 0; ks < KS; ks++) {
+        if (ks + 1 < KS) read_a(ks + 1);
+        // staging: commit slot ks of T1; load the slot that commits PD k-steps from now (T1's, or T2's when that
+        // falls into the next tile phase)
+        if (ks < NSLOT) commit_one(fast_tag, ks, T1, a_wr);
+        if (ks + PD < NSLOT)
+          load_one(fast_tag, ks + PD, T1, v1, so1, lo1);
+        else if (ks + PD >= KS)
+          load_one(fast_tag, ks + PD - KS, T2, v2, so2, lo2);
+        const u32x4 af = {A0[ks & 1][0], A0[ks & 1][1], A1[ks & 1][0], A1[ks & 1][1]};
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+          const u32x4 bf = {B0[j][0], B0[j][1], B1[j][0], B1[j][1]};
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf),
+                                                           acc[j], 0, 0, 0);
+          if (ks + 1 < KS) read_b(ks + 1, j);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      WS2_STAMP(1 + FASTI)
+      WS_BARRIER();  // buffer PAR fully read, buffer 1-PAR fully written
+      WS2_STAMP(2)
+      // pin the loop-carried accumulators to AGPRs: left alone the compiler carries them in VGPRs between tile
+      // phases and pays 2 x 112 v_accvgpr moves per tile
+#pragma unroll
+      for (int j = 0; j < NT; j++) asm volatile("" : "+a"(acc[j]));
+    };
+
+    auto advance = [&]() {
+      T0 = T1;
+      T1 = T2;
+      i1 = i2;
+      v1 = v2;
+      so1 = so2;
+      lo1 = lo2;
+      tile_next(T2);
+      v2 = tile_valid(T2);
+      i2 = v2 && tile_interior(T2);
+      so2 = v2 ? s_org_of(T2) : s_safe;
+      lo2 = v2 ? l_org_of(T2) : l_safe;
+    };
+    // runs of interior tiles loop inside the fast copy of the phase (its own back edge: the in-flight staging
+    // registers stay put, nothing is drained between tiles)
+    bool more = true;
+    while (more) {
+      if (i1 && i2) {
+        do {
+          tile_phase(std::true_type{});
+          par ^= 1;
+          more = v1;
+          if (more) advance();
+        } while (more && i1 && i2);
+      } else {
+        tile_phase(std::false_type{});
+        par ^= 1;
+        more = v1;
+        if (more) advance();
+      }
+    }
+  }
+
+  // partial[g][tap][SCp][LCp]
+  const int col = lane & 31, hh2 = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < NT; j++) {
+    if (j < ntaps_here) {
+      int tap = wave * NT + j;
+      float* base = a.partials + (((int64_t)blockIdx.x * 27 + tap) * a.SCp + scb * 32) * a.LCp + lcb * 32 + col;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        int row = (i & 3) + 8 * (i >> 2) + 4 * hh2;
+        base[(int64_t)row * a.LCp] = acc[j][i];
+      }
+    }
+  }
+#ifdef WS_DBG_STAMPS
+  __syncthreads();
+  if (tid == 0 && blockIdx.y == 0 && blockIdx.z == 0)  // debug only: overwrites the head of this group's slab
+    for (int k = 0; k < 8; k++) a.partials[(int64_t)blockIdx.x * 27 * a.SCp * a.LCp + k] = (float)tacc[k];
+#endif
+}
+
 // out[(sc*LC + lc)*27 + tap] (+)= sum_g partial[g][tap][sc][lc].  256 threads = 8 group-lanes x 32 entries; fixed
 // summation order (bitwise reproducible)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw,
@@ -1548,7 +1882,8 @@ int launch_wgrad_t(WgradArgs a, float* dw, int sc_store, int lc_store, int accum
   a.num_tiles = a.N * ceil_div(a.Ds, TD) * ceil_div(a.Hs, TH) * ceil_div(a.Ws, TW);
   const int pairs = (a.SCp / 32) * (a.LCp / 32);
   const int64_t per = (int64_t)27 * a.SCp * a.LCp * sizeof(float);
-  int G = ceil_div(512, pairs);
+  static const int wg_target = getenv("HDF_WGRAD_WGS") ? atoi(getenv("HDF_WGRAD_WGS")) : 256;  // one workgroup per CU
+  int G = ceil_div(wg_target, pairs);
   G = (int)std::min<int64_t>(G, std::max<int64_t>(1, (int64_t)ws_bytes / per));
   G = std::min(G, a.num_tiles);
   a.tiles_per_group = ceil_div(a.num_tiles, G);
@@ -1557,7 +1892,15 @@ int launch_wgrad_t(WgradArgs a, float* dw, int sc_store, int lc_store, int accum
                 ws_bytes);
   a.partials = reinterpret_cast<float*>(ws);
   dim3 grid(G, a.SCp / 32, a.LCp / 32);
-  hipLaunchKernelGGL((conv_wgrad_kernel<T, TD, TH, TW, S>), grid, dim3(256), 0, st, a);
+  static const bool wg_old = getenv("HDF_WGRAD_OLD") != nullptr;  // A/B knob: single-buffered conv_wgrad_kernel
+  if (sizeof(T) == 2 && S == 1 && !a.sm_scale && !wg_old) {
+    if (a.lg_scale)
+      hipLaunchKernelGGL(conv_wgrad2_kernel<true>, grid, dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL(conv_wgrad2_kernel<false>, grid, dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, TD, TH, TW, S>), grid, dim3(256), 0, st, a);
+  }
   HDF_LAUNCH_CHECK();
   int64_t n = (int64_t)27 * a.SCp * a.LCp;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div64(n, 32)), dim3(256), 0, st, a.partials, dw, G,

@@ -65,4 +65,9 @@ if os.environ.get("WS_STAMPS") and a.op == "conv":
         names = ["xf-read", "mfma-phase", "barrier", "pass/tile-top", "epilogue", "-", "-", "-"]
     tot = t.sum(1).mean().item()
     print("  per-WG cycles (mean over WGs):", {n: int(v) for n, v in zip(names, t.mean(0).tolist())}, "total", int(tot))
+if os.environ.get("WS_STAMPS") and a.op == "wgrad":
+    per = 27 * ((cout + 31) // 32 * 32) * ((cin + 31) // 32 * 32)
+    t = ws.view(torch.float32)[: 256 * per].view(256, per)[:, :8].double().cpu()
+    names = ["top", "kloop-fast", "barrier", "-", "-", "kloop-slow", "-", "-"]
+    print("  per-WG cycles (mean over groups):", {n: int(v) for n, v in zip(names, t.mean(0).tolist())}, "total", int(t.sum(1).mean().item()))
 print(f"{a.op} {cin}->{cout} @{s}^3 n={n} {a.dtype} xf={a.xf}: {ms*1e3:.1f} us  {flops/ms/1e9:.1f} TFLOP/s")
