@@ -1030,22 +1030,7 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a, int tiles_tot
     WS2_STAMP(4)
   };
 
-  int par = 0;
-  while (true) {
-    const bool fast = (NCH == 1) ? (i1 && i2) : (i0 && i1);
-    if (NCH > 1 || par == 0) {
-      if (fast)
-        tile_phase(std::integral_constant<int, 0>{}, std::true_type{});
-      else
-        tile_phase(std::integral_constant<int, 0>{}, std::false_type{});
-    } else {
-      if (fast)
-        tile_phase(std::integral_constant<int, 1>{}, std::true_type{});
-      else
-        tile_phase(std::integral_constant<int, 1>{}, std::false_type{});
-    }
-    if (NCH == 1) par ^= 1;
-    if (!v1) break;
+  auto advance = [&]() {
     T0 = T1;
     T1 = T2;
     i0 = i1;
@@ -1057,6 +1042,54 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a, int tiles_tot
     v2 = tile_valid(T2);
     i2 = v2 && tile_interior(T2);
     org2 = v2 ? tile_org(T2) : src_safe;
+  };
+  auto is_fast = [&]() { return (NCH == 1) ? (i1 && i2) : (i0 && i1); };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  // Runs of interior tiles stay inside ONE copy of the fast phase (two copies, alternating buffer parity, when a tile
+  // is a single pass): with its own back edge the in-flight staging registers keep their places.  Entering the
+  // phase copies from one shared loop head made the compiler drain every outstanding load (s_waitcnt vmcnt(0)) and
+  // shuffle the staging registers once per tile.
+  int par = 0;
+  bool more = true;
+  while (more) {
+    if (NCH > 1) {
+      if (is_fast()) {
+        do {
+          tile_phase(P0{}, std::true_type{});
+          more = v1;
+          if (more) advance();
+        } while (more && is_fast());
+      } else {
+        tile_phase(P0{}, std::false_type{});
+        more = v1;
+        if (more) advance();
+      }
+    } else {
+      if (is_fast() && par == 0) {
+        do {
+          tile_phase(P0{}, std::true_type{});
+          par = 1;
+          more = v1;
+          if (more) advance();
+          if (!(more && is_fast())) break;
+          tile_phase(P1{}, std::true_type{});
+          par = 0;
+          more = v1;
+          if (more) advance();
+        } while (more && is_fast());
+      } else {
+        if (par == 0)
+          tile_phase(P0{}, std::false_type{});
+        else if (is_fast())
+          tile_phase(P1{}, std::true_type{});
+        else
+          tile_phase(P1{}, std::false_type{});
+        par ^= 1;
+        more = v1;
+        if (more) advance();
+      }
+    }
   }
   if (pend_tile >= 0) {
     __syncthreads();

@@ -325,7 +325,7 @@ void layout(hdf_plan* p, int B) {
   p->tf_dF = bp.take((size_t)rows * p->DMF * sizeof(float));
   p->wgrad_ws_bytes = (size_t)128 << 20;
   p->wgrad_ws = bp.take(p->wgrad_ws_bytes);
-  p->inb_partials = bp.take((size_t)B * 256 * 8 * nf * 2 * sizeof(float));
+  p->inb_partials = bp.take((size_t)B * 1024 * 8 * nf * 2 * sizeof(float));  // hdf_in_bwd_blocks <= 1024, C <= 8 nf
   p->inb_k = bp.take((size_t)3 * B * 8 * nf * sizeof(float));
   for (int k = 0; k < 4; k++) {
     p->gA[k] = mkview(p, bp, "", k, ch[k], B);

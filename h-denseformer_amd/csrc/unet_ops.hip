@@ -677,42 +677,58 @@ __global__ __launch_bounds__(256) void in_bwd_finalize_kernel(const float* __res
   }
 }
 
+// grid (blocks, N); thread = (voxel lane, channel chunk): the 7 per-(n,channel) coefficient vectors are loaded ONCE
+// per thread (re-reading them per chunk made the kernel load-issue bound: 56 scalar loads per 2 streaming loads)
 template <typename T>
-__global__ void in_bwd_apply_kernel(const T* __restrict__ da, int64_t da_pitch, const T* __restrict__ y,
-                                    int64_t y_pitch, const float* __restrict__ scale, const float* __restrict__ shift,
-                                    const float* __restrict__ mean, const float* __restrict__ rstd,
-                                    const float* __restrict__ k1, const float* __restrict__ ka,
-                                    const float* __restrict__ kb, T* __restrict__ dy, int64_t dy_pitch, int N, int C,
-                                    int64_t vox) {
+__global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__ da, int64_t da_pitch,
+                                                           const T* __restrict__ y, int64_t y_pitch,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ shift,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ k1, const float* __restrict__ ka,
+                                                           const float* __restrict__ kb, T* __restrict__ dy,
+                                                           int64_t dy_pitch, int C, int64_t vox) {
   constexpr int EPC = ST<T>::EPC;
   constexpr int U = 4;  // chunks per thread per iteration: 8 independent 16-byte loads in flight
+  const int n = blockIdx.y;
   const int cols = C / EPC;
-  const int64_t total = (int64_t)N * vox * cols;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < total; i0 += stride * U) {
+  const int vlanes = 256 / cols;
+  const int col = threadIdx.x % cols, vl = threadIdx.x / cols;
+  const int c0 = col * EPC;
+  if (vl >= vlanes) return;
+  float sc[EPC], sh[EPC], mu[EPC], rs[EPC], c1[EPC], ca[EPC], cb[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; e++) {
+    const int64_t o = (int64_t)n * C + c0 + e;
+    sc[e] = scale[o];
+    sh[e] = shift[o];
+    mu[e] = mean[o];
+    rs[e] = rstd[o];
+    c1[e] = k1[o];
+    ca[e] = ka[o];
+    cb[e] = kb[o];
+  }
+  const int64_t per = (vox + gridDim.x - 1) / gridDim.x;
+  const int64_t vb = (int64_t)blockIdx.x * per, ve = min(vox, vb + per);
+  for (int64_t v0 = vb + vl; v0 < ve; v0 += (int64_t)U * vlanes) {
     float g[U][EPC], f[U][EPC];
     int64_t rowv[U];
-    int c0v[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      int64_t i = min(i0 + u * stride, total - 1);  // clamped: never branch around a load
-      rowv[u] = i / cols;
-      c0v[u] = (int)(i - rowv[u] * cols) * EPC;
-      load_chunk<T>(da + rowv[u] * da_pitch + c0v[u], g[u]);
-      load_chunk<T>(y + rowv[u] * y_pitch + c0v[u], f[u]);
+    for (int u = 0; u < U; u++) {  // clamped: never branch around a load
+      rowv[u] = (int64_t)n * vox + min(v0 + (int64_t)u * vlanes, ve - 1);
+      load_chunk<T>(da + rowv[u] * da_pitch + c0, g[u]);
+      load_chunk<T>(y + rowv[u] * y_pitch + c0, f[u]);
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      if (i0 + u * stride < total) {
-        const int n = (int)(rowv[u] / vox);
+      if (v0 + (int64_t)u * vlanes < ve) {
 #pragma unroll
         for (int e = 0; e < EPC; e++) {
-          int64_t o = (int64_t)n * C + c0v[u] + e;
-          float gg = (f[u][e] * scale[o] + shift[o] > 0.f) ? g[u][e] : 0.f;
-          float xh = (f[u][e] - mean[o]) * rstd[o];
-          g[u][e] = k1[o] * (gg - ka[o] - xh * kb[o]);
+          float gg = (f[u][e] * sc[e] + sh[e] > 0.f) ? g[u][e] : 0.f;
+          float xh = (f[u][e] - mu[e]) * rs[e];
+          g[u][e] = c1[e] * (gg - ca[e] - xh * cb[e]);
         }
-        store_chunk<T>(dy + rowv[u] * dy_pitch + c0v[u], g[u]);
+        store_chunk<T>(dy + rowv[u] * dy_pitch + c0, g[u]);
       }
     }
   }
@@ -898,7 +914,7 @@ int hdf_launch_head_bwd(int dtype, const void* dlogits, const void* in, int64_t 
   return HDF_OK;
 }
 
-int hdf_in_bwd_blocks(int64_t vox) { return (int)std::max<int64_t>(1, std::min<int64_t>(256, vox / 1024)); }
+int hdf_in_bwd_blocks(int64_t vox) { return (int)std::max<int64_t>(1, std::min<int64_t>(1024, vox / 1024)); }
 
 int hdf_launch_in_bwd_reduce(int dtype, const void* da, int64_t da_pitch, const void* y, int64_t y_pitch,
                              const float* scale, const float* shift, const float* mean, const float* rstd,
@@ -929,9 +945,12 @@ int hdf_launch_in_bwd_apply(int dtype, const void* da, int64_t da_pitch, const v
                             const float* scale, const float* shift, const float* mean, const float* rstd,
                             const float* k1, const float* ka, const float* kb, void* dy, int64_t dy_pitch, int N, int C,
                             int64_t vox, hipStream_t st) {
-  DISPATCH_T(dtype, hipLaunchKernelGGL(in_bwd_apply_kernel<T>, dim3(grid_for((int64_t)N * vox * (C / ST<T>::EPC))),
-                                       dim3(256), 0, st, (const T*)da, da_pitch, (const T*)y, y_pitch, scale, shift,
-                                       mean, rstd, k1, ka, kb, (T*)dy, dy_pitch, N, C, vox));
+  HDF_CHECK_ARG(C % 16 == 0 && C <= 1024, "in_bwd_apply: C=%d", C);
+  // ~2K voxels per workgroup, at most 2048 workgroups per sample
+  const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, vox / 2048));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(in_bwd_apply_kernel<T>, dim3(blocks, N), dim3(256), 0, st, (const T*)da,
+                                       da_pitch, (const T*)y, y_pitch, scale, shift, mean, rstd, k1, ka, kb, (T*)dy,
+                                       dy_pitch, C, vox));
   HDF_LAUNCH_CHECK();
   return HDF_OK;
 }
