@@ -247,15 +247,18 @@ class HDenseFormer(nn.Module):
                 for p, (_, off, numel, shape) in zip(params, self._plan(_lib.F32).table):
                     if p.grad is not None:
                         prev[off: off + numel].view(shape).copy_(p.grad)
-        if self.grad_hook is None:
+        if self.grad_hook is None or prev is not None:
             rt.backward(x, self._flat, douts, gflat, stages=3)
+            if prev is not None:
+                gflat.add_(prev)
+            if self.grad_hook is not None:           # accumulated gradients: reduce after the add, no overlap
+                self.grad_hook(1)
+                self.grad_hook(2)
         else:
             rt.backward(x, self._flat, douts, gflat, stages=1)
-            self.grad_hook(1)
+            self.grad_hook(1)                        # bucket 1 is final: its all-reduce overlaps stage 2
             rt.backward(x, self._flat, douts, gflat, stages=2)
             self.grad_hook(2)
-        if prev is not None:
-            gflat.add_(prev)
         for p, v in zip(params, self._grad_views):
             if p.requires_grad:
                 p.grad = v

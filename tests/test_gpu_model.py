@@ -292,3 +292,23 @@ def test_running_dice_confusion_matrix_vs_reference_golden(tag):
     rd.update_matrix(onehot, logits)                       # running accumulation: doubling every count keeps the ratios
     mean2, _ = rd.compute_dice()
     assert abs(mean2 - mean) < 1e-5
+
+
+@pytest.mark.gpu
+def test_two_rank_data_parallel_on_one_gpu():
+    """GradSync + staged backward + comm-stream overlap on the real HIP path: two processes share cuda:0 over gloo
+    (RCCL refuses two ranks on one device); synced gradient == mean of the local gradients, replicas stay equal."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", "29581", os.path.join(root, "tools", "ddp_check.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    recs = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(recs) == 2, r.stdout
+    for rec in recs:
+        assert rec["grad_rel_err"] < 1e-5, rec
+        assert rec["param_max_diff"] == 0.0, rec
