@@ -51,5 +51,13 @@ int hdf_conv_stat_tiles(int mode, int Do, int Ho, int Wo, int row_bytes);
 int hdf_launch_wgrad(int dtype, int stride, WgradArgs a, float* dw, int sc_store, int lc_store, int accumulate,
                      void* workspace, size_t workspace_bytes, hipStream_t st);
 size_t hdf_wgrad_workspace_bytes(int stride, int N, int Ds, int Hs, int Ws, int SC, int LC);
+// every weight pack of a training step in ONE launch (42 separate 6-us launches otherwise)
+struct PackJob {
+  int64_t src_off;  // floats from the parameter base
+  int64_t dst_off;  // bytes from the workspace base
+  int O, I, OP, IP, so, si, flip;
+};
+constexpr int HDF_MAX_PACK_JOBS = 64;
+int hdf_launch_pack_batch(int dtype, const float* params, char* ws, const PackJob* jobs, int njobs, hipStream_t st);
 int hdf_launch_pack_w(int dtype, const float* src, void* dst, int O, int I, int OP, int IP, int64_t so, int64_t si,
                       int flip, hipStream_t st);

@@ -1823,6 +1823,26 @@ __global__ void pack_w_kernel(const float* __restrict__ src, T* __restrict__ dst
   ST<T>::st(dst + idx, v);
 }
 
+struct PackBatch {
+  PackJob j[HDF_MAX_PACK_JOBS];
+};
+// grid (blocks, jobs): job blockIdx.y, grid-stride over its 27*OP*IP elements
+template <typename T>
+__global__ void pack_batch_kernel(PackBatch b, const float* __restrict__ params, char* __restrict__ ws) {
+  const PackJob& jb = b.j[blockIdx.y];
+  const float* src = params + jb.src_off;
+  T* dst = reinterpret_cast<T*>(ws + jb.dst_off);
+  const int64_t total = (int64_t)27 * jb.OP * jb.IP;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    int i = idx % jb.IP;
+    int o = (idx / jb.IP) % jb.OP;
+    int t = idx / ((int64_t)jb.IP * jb.OP);
+    float v = 0.f;
+    if (o < jb.O && i < jb.I) v = src[(int64_t)o * jb.so + (int64_t)i * jb.si + (jb.flip ? 26 - t : t)];
+    ST<T>::st(dst + idx, v);
+  }
+}
+
 template <typename T, int TD, int TH, int TW, int WM, int WN, int MB, int S, bool CONVT>
 int launch_cfg(const ConvArgs& a, hipStream_t st) {
   const int Td = CONVT ? a.Di : a.Do, Th = CONVT ? a.Hi : a.Ho, Tw = CONVT ? a.Wi : a.Wo;
@@ -1988,6 +2008,20 @@ int hdf_launch_wgrad(int dtype, int stride, WgradArgs a, float* dw, int sc_store
   }
   hdf_set_error("wgrad: unsupported dtype %d", dtype);
   return HDF_ERR_UNSUPPORTED;
+}
+
+int hdf_launch_pack_batch(int dtype, const float* params, char* ws, const PackJob* jobs, int njobs, hipStream_t st) {
+  HDF_CHECK_ARG(njobs >= 0 && njobs <= HDF_MAX_PACK_JOBS, "pack batch: %d jobs", njobs);
+  if (njobs == 0) return HDF_OK;
+  PackBatch b;
+  for (int k = 0; k < njobs; k++) b.j[k] = jobs[k];
+  dim3 grid(256, njobs);
+  if (dtype == HDF_BF16)
+    hipLaunchKernelGGL(pack_batch_kernel<bf16_t>, grid, dim3(256), 0, st, b, params, ws);
+  else
+    hipLaunchKernelGGL(pack_batch_kernel<float>, grid, dim3(256), 0, st, b, params, ws);
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
 }
 
 int hdf_launch_pack_w(int dtype, const float* src, void* dst, int O, int I, int OP, int IP, int64_t so, int64_t si,

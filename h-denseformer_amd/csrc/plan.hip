@@ -85,6 +85,7 @@ struct hdf_plan {
   Conv3 deep, up[3], enc[4][2], dec[3][2];  // dec[k]: level k (0..2) right blocks
   ConvT3 upc[3];                            // upc[k] produces level k from level k+1
   Head1 head[4];
+  std::vector<PackJob> pack_jobs;           // every conv's forward and dgrad weight pack (one launch per forward)
   // layout for the current batch
   int batch = -1;
   size_t ws_bytes = 0;
@@ -315,6 +316,29 @@ void layout(hdf_plan* p, int B) {
     }
   }
   p->x4 = mkview(p, bp, "bottleneck", 3, 8 * nf, B);
+  // ---- weight packs (see conv_forward / conv_backward / convt_* for the layouts)
+  p->pack_jobs.clear();
+  auto conv_jobs = [&](const Conv3& c) {
+    // forward [tap][CoutP][CinP] from torch [Cout][Cin][27]
+    p->pack_jobs.push_back(PackJob{c.w, (int64_t)c.wf, c.Cout, c.Cin, round_up(c.Cout, 32), c.CinP, c.Cin * 27, 27, 0});
+    // dgrad: taps reversed, channel roles swapped: Wd[t][ci][co] = W[co][ci][26-t]
+    p->pack_jobs.push_back(PackJob{c.w, (int64_t)c.wd, c.Cin, c.Cout, round_up(c.Cin, 32), c.Cout, 27, c.Cin * 27, 1});
+  };
+  conv_jobs(p->deep);
+  for (int k = 0; k < 3; k++) conv_jobs(p->up[k]);
+  for (int k = 0; k < 4; k++) {
+    conv_jobs(p->enc[k][0]);
+    conv_jobs(p->enc[k][1]);
+    if (k < 3) {
+      conv_jobs(p->dec[k][0]);
+      conv_jobs(p->dec[k][1]);
+      const ConvT3& t = p->upc[k];
+      // forward: torch ConvTranspose3d weight [Cin][Cout][27] -> [tap][CoutP][Cin]
+      p->pack_jobs.push_back(PackJob{t.w, (int64_t)t.wf, t.Cout, t.Cin, round_up(t.Cout, 32), t.Cin, 27, t.Cout * 27, 0});
+      // input gradient: stride-2 gather conv, [tap][CinP][Cout]
+      p->pack_jobs.push_back(PackJob{t.w, (int64_t)t.wd, t.Cin, t.Cout, round_up(t.Cin, 32), t.Cout, t.Cout * 27, 27, 0});
+    }
+  }
   // ---- scratch shared by forward and backward
   size_t maxtiles = 0;
   for (int l = 0; l < 5; l++)
@@ -372,9 +396,7 @@ int conv_forward(Exec& e, Conv3& c, const View& in, Xf xf) {
   hdf_plan* p = e.p;
   const int* d = e.dm(c.lvl);
   const int CoutP = round_up(c.Cout, 32);
-  HDF_TRY(hdf_launch_pack_w(p->dtype, e.P(c.w), e.ws + c.wf, c.Cout, c.Cin, CoutP, c.CinP, (int64_t)c.Cin * 27, 27, 0,
-                            e.st));
-  ConvArgs a{};
+  ConvArgs a{};  // weights: packed by hdf_forward's pack batch
   a.in = e.at(in);
   a.in_pitch = in.pitch;
   a.Cin = c.CinP;
@@ -405,9 +427,6 @@ int convt_forward(Exec& e, ConvT3& t, const View& in, Xf xf, const View& out) {
   hdf_plan* p = e.p;
   const int* d = e.dm(t.lvl_in);
   const int CoutP = round_up(t.Cout, 32);
-  // torch ConvTranspose3d weight [Cin][Cout][27] -> [tap][CoutP][Cin]
-  HDF_TRY(hdf_launch_pack_w(p->dtype, e.P(t.w), e.ws + t.wf, t.Cout, t.Cin, CoutP, t.Cin, 27, (int64_t)t.Cout * 27, 0,
-                            e.st));
   ConvArgs a{};
   a.in = e.at(in);
   a.in_pitch = in.pitch;
@@ -580,8 +599,6 @@ int conv_backward(Exec& e, Conv3& c, const View& dy, const View& in, Xf xf, cons
   if (din) {
     // dgrad = the same conv with taps reversed and channel roles swapped: Wd[t][ci][co] = W[co][ci][26-t]
     const int OP = round_up(c.Cin, 32);
-    HDF_TRY(hdf_launch_pack_w(p->dtype, e.P(c.w), e.ws + c.wd, c.Cin, c.Cout, OP, c.Cout, 27, (int64_t)c.Cin * 27, 1,
-                              e.st));
     ConvArgs a{};
     a.in = e.at(dy);
     a.in_pitch = dy.pitch;
@@ -623,8 +640,6 @@ int convt_backward(Exec& e, ConvT3& t, const View& dout, const View& in, Xf xf, 
   HDF_TRY(hdf_launch_wgrad(p->dtype, 2, w, e.G(t.w), t.Cin, t.Cout, 0, e.ws + p->wgrad_ws, p->wgrad_ws_bytes, e.st));
   // dX[i][ci] = sum_k sum_co dY[2i-1+k][co] * W[ci][co][k]  -> stride-2 gather conv, packed [tap][CinP][Cout]
   const int OP = round_up(t.Cin, 32);
-  HDF_TRY(hdf_launch_pack_w(p->dtype, e.P(t.w), e.ws + t.wd, t.Cin, t.Cout, OP, t.Cout, (int64_t)t.Cout * 27, 27, 0,
-                            e.st));
   ConvArgs a{};
   a.in = e.at(dout);
   a.in_pitch = dout.pitch;
@@ -737,6 +752,7 @@ int hdf_forward(hdf_plan* p, const float* x, const float* params, void* workspac
   void* outs[4] = {out0, out1, out2, out3};
   Xf none;
 
+  HDF_TRY(hdf_launch_pack_batch(p->dtype, params, e.ws, p->pack_jobs.data(), (int)p->pack_jobs.size(), e.st));
   // ---- multi-path transformer (HDenseFormer.py:230) -> attnall, then the UpConv chain (:231-235)
   HDF_TRY(transformer_forward(e, x));
   HDF_TRY(conv_forward(e, p->deep, p->attnall, none));

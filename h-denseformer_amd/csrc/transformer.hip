@@ -189,13 +189,35 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(int N, const float* __res
   float4 q = ok ? *reinterpret_cast<const float4*>(qkv + (rowbase + qi) * 96 + head * 4) : make_float4(0, 0, 0, 0);
   q.x *= 0.5f, q.y *= 0.5f, q.z *= 0.5f, q.w *= 0.5f;  // dim_head^-0.5 with dim_head = 4
   float mx = -INFINITY, l = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  for (int j = sub; j < N; j += 4) {
-    float4 k = sK[j], v = sV[j];
-    float s = q.x * k.x + q.y * k.y + q.z * k.z + q.w * k.w;
-    float mn = fmaxf(mx, s);
-    float c = __expf(mx - mn), pr = __expf(s - mn);
-    l = l * c + pr;
-    a0 = a0 * c + pr * v.x, a1 = a1 * c + pr * v.y, a2 = a2 * c + pr * v.z, a3 = a3 * c + pr * v.w;
+  // AU keys per trip: the loop is a latency chain (LDS read -> dot -> exp -> rescale) at 2 waves per SIMD, so the
+  // AU independent score/exp chains of one trip are what fills the pipes; one running-max update per trip
+  constexpr int AU = 4;
+  for (int j0 = sub; j0 < N; j0 += 4 * AU) {
+    float4 k[AU], v[AU];
+    float sc[AU];
+#pragma unroll
+    for (int u = 0; u < AU; u++) {
+      const int j = min(j0 + 4 * u, N - 1);
+      k[u] = sK[j];
+      v[u] = sV[j];
+    }
+    float mn = mx;
+#pragma unroll
+    for (int u = 0; u < AU; u++) {
+      float t = q.x * k[u].x + q.y * k[u].y + q.z * k[u].z + q.w * k[u].w;
+      sc[u] = (j0 + 4 * u < N) ? t : -INFINITY;
+      mn = fmaxf(mn, sc[u]);
+    }
+    const float c = __expf(mx - mn);
+    float ps = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+#pragma unroll
+    for (int u = 0; u < AU; u++) {
+      const float pr = __expf(sc[u] - mn);
+      ps += pr;
+      b0 += pr * v[u].x, b1 += pr * v[u].y, b2 += pr * v[u].z, b3 += pr * v[u].w;
+    }
+    l = l * c + ps;
+    a0 = a0 * c + b0, a1 = a1 * c + b1, a2 = a2 * c + b2, a3 = a3 * c + b3;
     mx = mn;
   }
 #pragma unroll
@@ -217,14 +239,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(int N, const float* __res
 }
 
 // dQ: same decomposition as forward
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(int N, const float* __restrict__ qkv,
-                                                          const float* __restrict__ ob, const float* __restrict__ lse,
-                                                          const float* __restrict__ dO, float* __restrict__ dqkv) {
-  extern __shared__ float4 skv[];
+__device__ __forceinline__ void attn_bwd_dq_body(int N, int seq, const float* __restrict__ qkv,
+                                                 const float* __restrict__ ob, const float* __restrict__ lse,
+                                                 const float* __restrict__ dO, float* __restrict__ dqkv, float4* skv) {
   float4* sK = skv;
   float4* sV = skv + N;
   const int head = blockIdx.y;
-  const int64_t rowbase = (int64_t)blockIdx.z * N;
+  const int64_t rowbase = (int64_t)seq * N;
   for (int i = threadIdx.x; i < N; i += 256) {
     const float* r = qkv + (rowbase + i) * 96;
     sK[i] = *reinterpret_cast<const float4*>(r + 32 + head * 4);
@@ -241,12 +262,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(int N, const float* __
   const float delta = go.x * oo.x + go.y * oo.y + go.z * oo.z + go.w * oo.w;
   const float ls = lse[R * 8 + head];
   float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
-  for (int j = sub; j < N; j += 4) {
-    float4 k = sK[j], v = sV[j];
-    float s = q.x * k.x + q.y * k.y + q.z * k.z + q.w * k.w;
-    float pr = __expf(s - ls);
-    float ds = pr * (go.x * v.x + go.y * v.y + go.z * v.z + go.w * v.w - delta);
-    d0 += ds * k.x, d1 += ds * k.y, d2 += ds * k.z, d3 += ds * k.w;
+  constexpr int AU = 4;  // independent chains per trip (see attn_fwd_kernel)
+  for (int j0 = sub; j0 < N; j0 += 4 * AU) {
+    float4 k[AU], v[AU];
+#pragma unroll
+    for (int u = 0; u < AU; u++) {
+      const int j = min(j0 + 4 * u, N - 1);
+      k[u] = sK[j];
+      v[u] = sV[j];
+    }
+#pragma unroll
+    for (int u = 0; u < AU; u++) {
+      float s = q.x * k[u].x + q.y * k[u].y + q.z * k[u].z + q.w * k[u].w;
+      float pr = (j0 + 4 * u < N) ? __expf(s - ls) : 0.f;
+      float ds = pr * (go.x * v[u].x + go.y * v[u].y + go.z * v[u].z + go.w * v[u].w - delta);
+      d0 += ds * k[u].x, d1 += ds * k[u].y, d2 += ds * k[u].z, d3 += ds * k[u].w;
+    }
   }
 #pragma unroll
   for (int off = 1; off <= 2; off <<= 1) {
@@ -258,15 +289,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(int N, const float* __
 }
 
 // dK, dV: 4 lanes per key, queries interleaved over the 4 lanes
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(int N, const float* __restrict__ qkv,
-                                                           const float* __restrict__ ob, const float* __restrict__ lse,
-                                                           const float* __restrict__ dO, float* __restrict__ dqkv) {
-  extern __shared__ float4 skv[];
+__device__ __forceinline__ void attn_bwd_dkv_body(int N, int seq, const float* __restrict__ qkv,
+                                                  const float* __restrict__ ob, const float* __restrict__ lse,
+                                                  const float* __restrict__ dO, float* __restrict__ dqkv, float4* skv) {
   float4* sQ = skv;        // pre-scaled by 0.5
   float4* sG = skv + N;    // dO
   float2* sL = reinterpret_cast<float2*>(skv + 2 * N);  // (lse, delta)
   const int head = blockIdx.y;
-  const int64_t rowbase = (int64_t)blockIdx.z * N;
+  const int64_t rowbase = (int64_t)seq * N;
   for (int i = threadIdx.x; i < N; i += 256) {
     float4 q = *reinterpret_cast<const float4*>(qkv + (rowbase + i) * 96 + head * 4);
     q.x *= 0.5f, q.y *= 0.5f, q.z *= 0.5f, q.w *= 0.5f;
@@ -283,13 +313,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(int N, const float* _
   const float4 k = *reinterpret_cast<const float4*>(qkv + R * 96 + 32 + head * 4);
   const float4 v = *reinterpret_cast<const float4*>(qkv + R * 96 + 64 + head * 4);
   float k0 = 0.f, k1 = 0.f, k2 = 0.f, k3 = 0.f, v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-  for (int i = sub; i < N; i += 4) {
-    float4 q = sQ[i], go = sG[i];
-    float2 ld = sL[i];
-    float pr = __expf(q.x * k.x + q.y * k.y + q.z * k.z + q.w * k.w - ld.x);
-    v0 += pr * go.x, v1 += pr * go.y, v2 += pr * go.z, v3 += pr * go.w;
-    float ds = pr * (go.x * v.x + go.y * v.y + go.z * v.z + go.w * v.w - ld.y);
-    k0 += ds * q.x, k1 += ds * q.y, k2 += ds * q.z, k3 += ds * q.w;
+  constexpr int AU = 4;  // independent chains per trip (see attn_fwd_kernel)
+  for (int i0 = sub; i0 < N; i0 += 4 * AU) {
+    float4 q[AU], go[AU];
+    float2 ld[AU];
+#pragma unroll
+    for (int u = 0; u < AU; u++) {
+      const int i = min(i0 + 4 * u, N - 1);
+      q[u] = sQ[i];
+      go[u] = sG[i];
+      ld[u] = sL[i];
+    }
+#pragma unroll
+    for (int u = 0; u < AU; u++) {
+      float pr = __expf(q[u].x * k.x + q[u].y * k.y + q[u].z * k.z + q[u].w * k.w - ld[u].x);
+      pr = (i0 + 4 * u < N) ? pr : 0.f;
+      v0 += pr * go[u].x, v1 += pr * go[u].y, v2 += pr * go[u].z, v3 += pr * go[u].w;
+      float ds = pr * (go[u].x * v.x + go[u].y * v.y + go[u].z * v.z + go[u].w * v.w - ld[u].y);
+      k0 += ds * q[u].x, k1 += ds * q[u].y, k2 += ds * q[u].z, k3 += ds * q[u].w;
+    }
   }
 #pragma unroll
   for (int off = 1; off <= 2; off <<= 1) {
@@ -302,6 +344,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(int N, const float* _
     *reinterpret_cast<float4*>(dqkv + R * 96 + 32 + head * 4) = make_float4(k0, k1, k2, k3);
     *reinterpret_cast<float4*>(dqkv + R * 96 + 64 + head * 4) = make_float4(v0, v1, v2, v3);
   }
+}
+
+// One launch for both halves of the attention backward: grid z = 2 * (M*B); the first M*B slices compute dQ, the
+// rest dK/dV.  The two are independent (both only read qkv / dO / lse / ob), each alone fills the chip once.
+__global__ __launch_bounds__(256) void attn_bwd_kernel(int N, int nseq, const float* __restrict__ qkv,
+                                                       const float* __restrict__ ob, const float* __restrict__ lse,
+                                                       const float* __restrict__ dO, float* __restrict__ dqkv) {
+  extern __shared__ float4 skv[];
+  if ((int)blockIdx.z < nseq)
+    attn_bwd_dq_body(N, blockIdx.z, qkv, ob, lse, dO, dqkv, skv);
+  else
+    attn_bwd_dkv_body(N, blockIdx.z - nseq, qkv, ob, lse, dO, dqkv, skv);
 }
 
 // ------------------------------------------------------------------------------ K3: to_out + residual + ff + ff
@@ -879,10 +933,8 @@ int tf_layer_bwd(const TfDims& d, int block, int layer, const TfLayerP& p, const
   hipLaunchKernelGGL(dense_post_bwd_kernel, grid, dim3(256), 0, st, d, block, layer, p, g, s.h1, s.h2, s.ob, dF, dO,
                      dh0acc);
   HDF_LAUNCH_CHECK();
-  dim3 ag(ceil_div(d.N, 64), 8, d.M * d.B);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, ag, dim3(256), (size_t)d.N * 32, st, d.N, s.qkv, s.ob, s.lse, dO, dqkv);
-  HDF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, ag, dim3(256), (size_t)d.N * 40, st, d.N, s.qkv, s.ob, s.lse, dO, dqkv);
+  dim3 ag(ceil_div(d.N, 64), 8, 2 * d.M * d.B);
+  hipLaunchKernelGGL(attn_bwd_kernel, ag, dim3(256), (size_t)d.N * 40, st, d.N, d.M * d.B, s.qkv, s.ob, s.lse, dO, dqkv);
   HDF_LAUNCH_CHECK();
   size_t shm = (size_t)(TB * K + TB * 32 + TB * 96 + TB * 32 + 8 * 32 * 2 + 32 * (K + 1) + 96 * 33) * sizeof(float);
   HDF_TRY(allow_lds(dense_pre_bwd_kernel, shm));
