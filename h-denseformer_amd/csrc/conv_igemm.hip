@@ -651,14 +651,19 @@ struct WsTile {
 };
 
 template <typename T, int CH, int RB, bool XF>
-__global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a, int tiles_total, int tiles_per_wg) {
+__global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
   constexpr int TD = 4, TH = 8, TW = 8, BD = TD + 2, BH = TH + 2, BW = TW + 2, BOX = BD * BH * BW;
   constexpr int ESZ = sizeof(T), EPC = ST<T>::EPC;
   constexpr int CIN = RB / ESZ;
   constexpr int NCH = RB / CH, NFS = CH / 32, NG = 9 * NFS;
   constexpr int CPV = CH / 16, CPV_SHIFT = (CPV == 4) ? 2 : 1;
   constexpr int TOTAL = BOX * CPV, NJ = (TOTAL + 255) / 256;
-  constexpr int ABUF = BOX * CH;
+  // tile-buffer row pitch: padded by 16 bytes (conflict-free as in conv_ws_kernel, fragment addresses = one lane
+  // base + compile-time offsets) whenever two padded buffers and the weight panel fit in 160 KiB; else unpadded
+  // rows with XOR-swizzled 16-byte slots (a 36-entry per-lane address table)
+  constexpr bool SWZ = (2 * BOX * (CH + 16) + 2048 + 512 + 27 * 32 * RB > 160 * 1024);
+  constexpr int AP = SWZ ? CH : CH + 16;
+  constexpr int ABUF = BOX * AP;
   constexpr int OFF_RED = 2 * ABUF, OFF_XF = OFF_RED + 2048, OFF_W = OFF_XF + 512;
   constexpr int CPR = RB / 16, RP256 = 16 / CPR;
   static_assert(CH == 32 || CH == 64, "chunk bytes");
@@ -688,31 +693,54 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a, int tiles_tot
   }
   const int bswz = (r / RP256) & (CPR - 1);
 
+  // Tile schedule: every workgroup first runs a contiguous share of the INTERIOR tiles (halo box inside the volume:
+  // no bounds logic, deferred epilogue, one long run inside the two hot copies of the phase), then a share of the
+  // BORDER tiles with the checked copy.  Walking all tiles in raster order switched between the copies at every
+  // x-row (two border tiles per 16), and each switch re-fetched cold code and drained the staging pipeline.
   const int ntz = (a.Do + TD - 1) / TD, nty = (a.Ho + TH - 1) / TH, ntx = (a.Wo + TW - 1) / TW;
-  const int t_begin = blockIdx.x * tiles_per_wg, t_end = min(tiles_total, t_begin + tiles_per_wg);
-  if (t_begin >= t_end) return;
+  const bool has_int = ntz >= 3 && nty >= 3 && ntx >= 3;
+  const int ipz = ntz - 2, ipy = nty - 2, ipx = ntx - 2;                // interior tile grid per sample
+  const int n_int = has_int ? a.N * ipz * ipy * ipx : 0;
+  const int per_all = ntz * nty * ntx, per_bor = per_all - (has_int ? ipz * ipy * ipx : 0);
+  const int n_bor = a.N * per_bor;
+  const int G = gridDim.x;
+  const int ci = (n_int + G - 1) / G, cb = (n_bor + G - 1) / G;
+  const int int_begin = min(n_int, (int)blockIdx.x * ci), int_cnt = min(n_int, int_begin + ci) - int_begin;
+  const int bor_begin = min(n_bor, (int)blockIdx.x * cb), bor_cnt = min(n_bor, bor_begin + cb) - bor_begin;
+  if (int_cnt + bor_cnt == 0) return;
 
   // ---- per-lane constants
   // fragment read addresses: [jz][y'][jx] -> byte offset of this lane's 16-byte slot inside a tile buffer
-  int aaddr[3][4][3];
+  // (swizzled layout: a table; padded layout: abase + a compile-time offset)
+  int aaddr[SWZ ? 3 : 1][SWZ ? 4 : 1][SWZ ? 3 : 1];
+  int abase;
   {
     int dz, x;
     ws_row_to_zx(r, dz, x);
+    abase = ((dz * BH + 2 * wave) * BW + x) * AP + h * 16;
+    if constexpr (SWZ) {
 #pragma unroll
-    for (int jz = 0; jz < 3; jz++)
+      for (int jz = 0; jz < 3; jz++)
 #pragma unroll
-      for (int yp = 0; yp < 4; yp++)
+        for (int yp = 0; yp < 4; yp++)
 #pragma unroll
-        for (int jx = 0; jx < 3; jx++) {
-          int row = ((dz + jz) * BH + 2 * wave + yp) * BW + x + jx;
-          aaddr[jz][yp][jx] = row * CH + ((h ^ a_swz<CH>(row)) << 4);
-        }
+          for (int jx = 0; jx < 3; jx++) {
+            int row = ((dz + jz) * BH + 2 * wave + yp) * BW + x + jx;
+            aaddr[jz][yp][jx] = row * CH + ((h ^ a_swz<CH>(row)) << 4);
+          }
+    }
   }
+  auto a_addr = [&](int jz, int yp, int jx, int fs) {
+    if constexpr (SWZ)
+      return aaddr[jz][yp][jx] ^ (fs * 32);
+    else
+      return abase + ((jz * BH + yp) * BW + jx) * AP + fs * 32;
+  };
   int bvar[NCH];  // this lane's 16-byte slot inside a weight row, per channel chunk
 #pragma unroll
   for (int c = 0; c < NCH; c++) bvar[c] = r * RB + (((c * CPV + h) ^ bswz) << 4);
   // staging slots of this thread: source element offset, packed box coordinates, LDS byte offset
-  int boff[NJ], bxyz[NJ], woff[NJ];
+  int boff[NJ], bxyz[NJ], woff_t[SWZ ? NJ : 2];
 #pragma unroll
   for (int j = 0; j < NJ; j++) {
     // threads past the end of the last slot redo the box's last voxel (same part): identical bytes to the same
@@ -721,36 +749,98 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a, int tiles_tot
     int bz = vox / (BH * BW), rem = vox - bz * (BH * BW), by = rem / BW, bx = rem - by * BW;
     boff[j] = ((bz * a.Hi + by) * a.Wi + bx) * (int)a.in_pitch;
     bxyz[j] = (bz << 16) | (by << 8) | bx;
-    woff[j] = vox * CH + ((part ^ a_swz<CH>(vox)) << 4);
+    if constexpr (SWZ) {
+      woff_t[j] = vox * CH + ((part ^ a_swz<CH>(vox)) << 4);
+    } else {  // slot j = slot 0 + 256/CPV voxels * j: a compile-time offset (the clamped last slot apart)
+      if (j == 0) woff_t[0] = vox * AP + part * 16;
+      if (j == NJ - 1) woff_t[1] = vox * AP + part * 16;
+    }
   }
-
-  auto tile_init = [&](WsTile& c, int tile) {
-    int t = tile;
-    c.tile = tile;
-    c.x0 = (t % ntx) * TW;
-    t /= ntx;
-    c.y0 = (t % nty) * TH;
-    t /= nty;
-    c.z0 = (t % ntz) * TD;
-    c.n = t / ntz;
+  auto woff = [&](int j) {
+    if constexpr (SWZ)
+      return woff_t[j];
+    else
+      return j == NJ - 1 ? woff_t[1] : woff_t[0] + j * (256 / CPV) * AP;
   };
-  auto tile_next = [&](WsTile& c) {
-    c.tile++;
+
+  // linear index of a tile in raster order (the InstanceNorm partial row it owns)
+  auto tile_lin = [&](const WsTile& c) { return ((c.n * ntz + (c.z0 >> 2)) * nty + (c.y0 >> 3)) * ntx + (c.x0 >> 3); };
+  // k-th interior tile / k-th border tile, in raster order
+  auto int_init = [&](WsTile& c, int k) {
+    int t = k;
+    c.x0 = (t % ipx + 1) * TW;
+    t /= ipx;
+    c.y0 = (t % ipy + 1) * TH;
+    t /= ipy;
+    c.z0 = (t % ipz + 1) * TD;
+    c.n = t / ipz;
+    c.tile = tile_lin(c);
+  };
+  auto int_next = [&](WsTile& c) {
     c.x0 += TW;
-    if (c.x0 >= a.Wo) {
+    if (c.x0 >= (ntx - 1) * TW) {
+      c.x0 = TW;
+      c.y0 += TH;
+      if (c.y0 >= (nty - 1) * TH) {
+        c.y0 = TH;
+        c.z0 += TD;
+        if (c.z0 >= (ntz - 1) * TD) {
+          c.z0 = TD;
+          c.n++;
+        }
+      }
+    }
+    c.tile = tile_lin(c);
+  };
+  auto bor_init = [&](WsTile& c, int k) {
+    int tz, ty, tx;
+    c.n = k / per_bor;
+    int rem = k - c.n * per_bor;
+    if (!has_int) {
+      tx = rem % ntx, ty = (rem / ntx) % nty, tz = rem / (ntx * nty);
+    } else {
+      const int plane = nty * ntx, ring = plane - ipy * ipx;  // border tiles of a z-plane: all of it / its rim
+      if (rem < plane) {
+        tz = 0, ty = rem / ntx, tx = rem % ntx;
+      } else if (rem - plane < ipz * ring) {
+        rem -= plane;
+        tz = 1 + rem / ring;
+        rem %= ring;
+        if (rem < ntx) {
+          ty = 0, tx = rem;
+        } else if (rem - ntx < 2 * ipy) {
+          rem -= ntx;
+          ty = 1 + (rem >> 1), tx = (rem & 1) ? ntx - 1 : 0;
+        } else {
+          ty = nty - 1, tx = rem - ntx - 2 * ipy;
+        }
+      } else {
+        rem -= plane + ipz * ring;
+        tz = ntz - 1, ty = rem / ntx, tx = rem % ntx;
+      }
+    }
+    c.z0 = tz * TD, c.y0 = ty * TH, c.x0 = tx * TW;
+    c.tile = tile_lin(c);
+  };
+  auto bor_next = [&](WsTile& c) {
+    c.x0 += TW;
+    if (c.x0 >= ntx * TW) {
       c.x0 = 0;
       c.y0 += TH;
-      if (c.y0 >= a.Ho) {
+      if (c.y0 >= nty * TH) {
         c.y0 = 0;
         c.z0 += TD;
-        if (c.z0 >= a.Do) {
+        if (c.z0 >= ntz * TD) {
           c.z0 = 0;
           c.n++;
         }
       }
     }
+    // the interior tiles of a row are its contiguous middle: one jump skips them
+    if (has_int && c.x0 == TW && c.y0 >= TH && c.y0 < (nty - 1) * TH && c.z0 >= TD && c.z0 < (ntz - 1) * TD)
+      c.x0 = (ntx - 1) * TW;
+    c.tile = tile_lin(c);
   };
-  auto tile_valid = [&](const WsTile& c) { return c.tile < t_end; };
   auto tile_interior = [&](const WsTile& c) {
     return c.z0 >= 1 && c.y0 >= 1 && c.x0 >= 1 && c.z0 + TD + 1 <= a.Di && c.y0 + TH + 1 <= a.Hi &&
            c.x0 + TW + 1 <= a.Wi;
@@ -808,7 +898,7 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a, int tiles_tot
 #pragma unroll
       for (int k = 0; k < 4; k++) v[k] = ok ? v[k] : 0u;
     }
-    *reinterpret_cast<u32x4*>(dst + woff[j]) = v;
+    *reinterpret_cast<u32x4*>(dst + woff(j)) = v;
   };
   int tbl_n = -1;
   auto refresh_xf = [&](int n) {  // uniform; callers guarantee nobody still reads the old table
@@ -822,19 +912,35 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a, int tiles_tot
 
   // T0: tile under the MFMAs, T1 / T2: the next two (T2 only feeds the loads when a tile is a single pass)
   WsTile T0, T1, T2;
-  tile_init(T0, t_begin);
-  T1 = T0;
-  tile_next(T1);
-  T2 = T1;
-  tile_next(T2);
-  bool v1 = tile_valid(T1), v2 = tile_valid(T2);
-  bool i0 = tile_interior(T0), i1 = v1 && tile_interior(T1), i2 = v2 && tile_interior(T2);
-  const T* org0 = tile_org(T0);
-  const T* org1 = v1 ? tile_org(T1) : src_safe;
-  const T* org2 = v2 ? tile_org(T2) : src_safe;
-
-  // ---- prologue: item 0 -> buffer 0 (not overlapped), item 1 -> registers
-  {
+  bool v1 = false, v2 = false, i0 = false, i1 = false, i2 = false;
+  const T *org0 = src_safe, *org1 = src_safe, *org2 = src_safe;
+  int left = 0;  // tiles of the current pass after T0
+  // start a pass at its k-th tile: T0 -> buffer 0 (not overlapped), the next item -> registers
+  auto begin_pass = [&](auto border_tag, int k, int count) __attribute__((always_inline)) {
+    constexpr bool BORDER = decltype(border_tag)::value;
+    auto next = [&](WsTile& c) {
+      if constexpr (BORDER)
+        bor_next(c);
+      else
+        int_next(c);
+    };
+    if constexpr (BORDER)
+      bor_init(T0, k);
+    else
+      int_init(T0, k);
+    left = count - 1;
+    T1 = T0;
+    next(T1);
+    T2 = T1;
+    next(T2);
+    v1 = left >= 1, v2 = left >= 2;
+    i0 = BORDER ? tile_interior(T0) : true;
+    i1 = v1 && (BORDER ? tile_interior(T1) : true);
+    i2 = v2 && (BORDER ? tile_interior(T2) : true);
+    org0 = tile_org(T0);
+    org1 = v1 ? tile_org(T1) : src_safe;
+    org2 = v2 ? tile_org(T2) : src_safe;
+    __syncthreads();  // the previous pass is done with both tile buffers
 #pragma unroll
     for (int j = 0; j < NJ; j++) load_one(std::false_type{}, j, 0, T0, true, i0, org0);
     if constexpr (XF) {
@@ -850,22 +956,24 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a, int tiles_tot
       else
         load_one(std::false_type{}, j, 0, T1, v1, i1, org1);
     }
-  }
-  WS_BARRIER();
+    WS_BARRIER();
+  };
 
   const int ch = n0 + r;
   const bool ch_ok = ch < a.Cout;
   const float bias = (a.bias && ch_ok) ? a.bias[ch] : 0.f;
   T* const outp = reinterpret_cast<T*>(a.out);
-  // accumulator register i of this lane: tile voxel (dz, 2w + mb, x) -> output element offset / packed (dz, x)
-  int eoff[16], ezx[16];
+  // accumulator register i of this lane: tile voxel (dz, 2w + mb, x) with x = (i & 3) + 4 * ((i >> 2) & 1) and
+  // dz = {0,1,3,2}[i >> 2] (h == 0) or {1,0,2,3}[i >> 2] (h == 1)   (ws_row_to_zx of row (i&3) + 8*(i>>2) + 4h)
+  int edz[4], eplane[4];
 #pragma unroll
-  for (int i = 0; i < 16; i++) {
+  for (int q4 = 0; q4 < 4; q4++) {
     int dz, x;
-    ws_row_to_zx((i & 3) + 8 * (i >> 2) + 4 * h, dz, x);
-    eoff[i] = ((dz * a.Ho) * a.Wo + x) * (int)a.out_pitch;
-    ezx[i] = (dz << 4) | x;
+    ws_row_to_zx(8 * q4 + 4 * h, dz, x);
+    edz[q4] = dz;
+    eplane[q4] = dz * a.Ho * a.Wo * (int)a.out_pitch;
   }
+  auto eoff = [&](int i) { return eplane[i >> 2] + ((i & 3) + 4 * ((i >> 2) & 1)) * (int)a.out_pitch; };
   int pend_tile = -1;  // tile whose per-wave InstanceNorm partials wait in s_red for the next barrier
   auto flush_stats = [&]() {
     if (a.stat_partials && tid < 32) {
@@ -899,11 +1007,15 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a, int tiles_tot
 #define WS2_STAMP(k)
 #endif
 
-  auto epilogue = [&](f32x16 (&acc)[2]) __attribute__((always_inline)) {
-    const int z0 = T0.z0, y0 = T0.y0, x0 = T0.x0;
+  // this lane's first output element of a tile: channel n0 + r, rows y0 + 2w (+ mb), voxel (z0, ., x0)
+  auto out_base = [&](const WsTile& t) -> T* {
+    return outp + ((((int64_t)t.n * a.Do + t.z0) * a.Ho + t.y0 + 2 * wave) * a.Wo + t.x0) * a.out_pitch + ch;
+  };
+  auto epilogue = [&](f32x16 (&acc)[2], const WsTile& ET) __attribute__((always_inline)) {
+    const int z0 = ET.z0, y0 = ET.y0, x0 = ET.x0;
     float s1 = 0.f, s2 = 0.f;
     const bool full = z0 + TD <= a.Do && y0 + TH <= a.Ho && x0 + TW <= a.Wo;
-    T* const obase = outp + ((((int64_t)T0.n * a.Do + z0) * a.Ho + y0 + 2 * wave) * a.Wo + x0) * a.out_pitch + ch;
+    T* const obase = out_base(ET);
     if (full && ch_ok && !a.accumulate) {
 #pragma unroll
       for (int mb = 0; mb < 2; mb++) {
@@ -911,7 +1023,7 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a, int tiles_tot
 #pragma unroll
         for (int i = 0; i < 16; i++) {
           const float v = acc[mb][i] + bias;
-          ST<T>::st(orow + eoff[i], v);
+          ST<T>::st(orow + eoff(i), v);
           s1 += v;
           s2 += v * v;
         }
@@ -923,13 +1035,13 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a, int tiles_tot
         T* const orow = obase + (int64_t)mb * a.Wo * a.out_pitch;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-          const int gz = z0 + (ezx[i] >> 4), gx = x0 + (ezx[i] & 15);
+          const int gz = z0 + edz[i >> 2], gx = x0 + (i & 3) + 4 * ((i >> 2) & 1);
           const float v = acc[mb][i] + bias;
           const bool ok = gz < a.Do && gy < a.Ho && gx < a.Wo;
           if (ok && ch_ok) {
             float o = v;
-            if (a.accumulate) o += ST<T>::ld(orow + eoff[i]);
-            ST<T>::st(orow + eoff[i], o);
+            if (a.accumulate) o += ST<T>::ld(orow + eoff(i));
+            ST<T>::st(orow + eoff(i), o);
           }
           const float mk = ok ? 1.f : 0.f;
           s1 += mk * v;
@@ -942,19 +1054,31 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a, int tiles_tot
       s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 32, 64);
       if (h == 0) {
-        float* sr = s_red + (T0.tile & 1) * 256;
+        float* sr = s_red + (ET.tile & 1) * 256;
         sr[(wave * 32 + r) * 2 + 0] = s1;
         sr[(wave * 32 + r) * 2 + 1] = s2;
       }
-      pend_tile = T0.tile;
+      pend_tile = ET.tile;
     }
   };
 
   // One tile: NCH passes.  Pass c runs the MFMAs of chunk c out of buffer (PAR0 + c) & 1 and, in their shadow,
   // commits item c+1 (chunk (c+1) % NCH of T0 or T1) into the other buffer and loads item c+2 into the freed pf.
-  auto tile_phase = [&](auto par_tag, auto fast_tag) __attribute__((always_inline)) {
+  //
+  // Deferred epilogue (single-pass tiles, runs of interior tiles): the accumulators alternate between two register
+  // sets with the buffer parity.  DOUT: the phase leaves its tile "pending" (coordinates in PT) instead of running
+  // the epilogue; DIN: the phase converts / stores / sums the pending tile out of the OTHER set, a few elements per
+  // MFMA group, and hands the per-wave InstanceNorm partials to the flush behind its barrier.
+  f32x16 accs[2][2];
+  WsTile PT = T0;
+  auto tile_phase = [&](auto par_tag, auto fast_tag, auto din_tag, auto dout_tag) __attribute__((always_inline)) {
     constexpr int PAR0 = decltype(par_tag)::value;
-    f32x16 acc[2];
+    constexpr bool DIN = decltype(din_tag)::value, DOUT = decltype(dout_tag)::value;
+    constexpr int EPG = (32 + NG - 1) / NG;  // pending elements per MFMA group
+    f32x16(&acc)[2] = accs[PAR0];
+    f32x16(&pacc)[2] = accs[1 - PAR0];
+    T* const pbase = out_base(PT);
+    float ds1 = 0.f, ds2 = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
       constexpr int dummy = 0;
@@ -982,7 +1106,7 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a, int tiles_tot
       u32x4 af[2][4], bf[2][3];
       auto read_group = [&](int g, u32x4 (&A)[4], u32x4 (&B)[3]) {
         const int t = g / NFS, fs = g % NFS, jz = t / 3, jx = t % 3;
-        auto rdA = [&](int yp) { A[yp] = *reinterpret_cast<const u32x4*>(a_rd + (aaddr[jz][yp][jx] ^ (fs * 32))); };
+        auto rdA = [&](int yp) { A[yp] = *reinterpret_cast<const u32x4*>(a_rd + a_addr(jz, yp, jx, fs)); };
         auto rdB = [&](int jy) {
           B[jy] = *reinterpret_cast<const u32x4*>(w_lds + ((jz * 9 + jy * 3 + jx) * 32) * RB + (bvar[c] ^ (fs * 32)));
         };
@@ -1007,6 +1131,27 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a, int tiles_tot
             load_one(fast_tag, j, l_chunk, LT, l_val, l_int, l_org);
           }
         }
+        if constexpr (DIN) {
+#pragma unroll
+          for (int u = 0; u < EPG; u++) {
+            const int e = g * EPG + u;
+            if (e < 32) {
+              const int mb = e >> 4, i = e & 15;
+              const float v = pacc[mb][i] + bias;
+              ST<T>::st(pbase + (int64_t)mb * a.Wo * a.out_pitch + eoff(i), v);
+              ds1 += v;
+              ds2 += v * v;
+            }
+          }
+          if (g == (31 / EPG)) {  // last pending element done: per-wave partials -> s_red (both halves hold the sum)
+            ds1 += __shfl_xor(ds1, 32, 64);
+            ds2 += __shfl_xor(ds2, 32, 64);
+            float* sr = s_red + (PT.tile & 1) * 256;
+            sr[(wave * 32 + r) * 2 + 0] = ds1;
+            sr[(wave * 32 + r) * 2 + 1] = ds2;
+            pend_tile = PT.tile;
+          }
+        }
         u32x4(&A)[4] = af[g & 1];
         u32x4(&B)[3] = bf[g & 1];
         if (c == 0 && g == 0) {  // first MFMAs of the tile take a zero C operand: no accumulator clearing
@@ -1026,11 +1171,25 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a, int tiles_tot
       WS2_STAMP(2)
       if (c == 0 && pend_tile >= 0) flush_stats();  // previous tile's partials: every wave's s_red row is visible now
     }
-    epilogue(acc);
+    if constexpr (DOUT)
+      PT = T0;
+    else
+      epilogue(acc, T0);
+    // pin the loop-carried accumulators to AGPRs (else they travel through VGPR copies between phases)
+    asm volatile("" : "+a"(accs[0][0]), "+a"(accs[0][1]), "+a"(accs[1][0]), "+a"(accs[1][1]));
     WS2_STAMP(4)
   };
 
-  auto advance = [&]() {
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  using Yes = std::true_type;
+  using No = std::false_type;
+  bool more = true;
+  auto step = [&](auto border_tag) __attribute__((always_inline)) {
+    constexpr bool BORDER = decltype(border_tag)::value;
+    more = v1;
+    if (!more) return;
+    left--;
     T0 = T1;
     T1 = T2;
     i0 = i1;
@@ -1038,57 +1197,67 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a, int tiles_tot
     v1 = v2;
     org0 = org1;
     org1 = org2;
-    tile_next(T2);
-    v2 = tile_valid(T2);
-    i2 = v2 && tile_interior(T2);
+    if constexpr (BORDER)
+      bor_next(T2);
+    else
+      int_next(T2);
+    v2 = left >= 2;
+    i2 = v2 && (BORDER ? tile_interior(T2) : true);
     org2 = v2 ? tile_org(T2) : src_safe;
   };
-  auto is_fast = [&]() { return (NCH == 1) ? (i1 && i2) : (i0 && i1); };
-  using P0 = std::integral_constant<int, 0>;
-  using P1 = std::integral_constant<int, 1>;
-  // Runs of interior tiles stay inside ONE copy of the fast phase (two copies, alternating buffer parity, when a tile
-  // is a single pass): with its own back edge the in-flight staging registers keep their places.  Entering the
-  // phase copies from one shared loop head made the compiler drain every outstanding load (s_waitcnt vmcnt(0)) and
-  // shuffle the staging registers once per tile.
-  int par = 0;
-  bool more = true;
-  while (more) {
+  const bool can_defer = !a.accumulate && (a.Cout % 32 == 0) && a.stat_partials != nullptr;
+
+  // ---- pass A: interior tiles.  Every phase is the unchecked copy; with single-pass tiles and a deferrable
+  // epilogue the run alternates between the two hot copies (P1 / P0, pending epilogue in, own epilogue out).
+  if (int_cnt > 0) {
+    begin_pass(No{}, int_begin, int_cnt);
+    more = true;
     if (NCH > 1) {
-      if (is_fast()) {
-        do {
-          tile_phase(P0{}, std::true_type{});
-          more = v1;
-          if (more) advance();
-        } while (more && is_fast());
-      } else {
-        tile_phase(P0{}, std::false_type{});
-        more = v1;
-        if (more) advance();
+      while (more) {
+        tile_phase(P0{}, Yes{}, No{}, No{});
+        step(No{});
       }
+    } else if (can_defer) {
+      tile_phase(P0{}, Yes{}, No{}, Yes{});
+      step(No{});
+      int last = 0;  // register set of the pending tile
+      while (more) {
+        tile_phase(P1{}, Yes{}, Yes{}, Yes{});
+        step(No{});
+        last = 1;
+        if (!more) break;
+        tile_phase(P0{}, Yes{}, Yes{}, Yes{});
+        step(No{});
+        last = 0;
+      }
+      if (last == 0)
+        epilogue(accs[0], PT);
+      else
+        epilogue(accs[1], PT);
     } else {
-      if (is_fast() && par == 0) {
-        do {
-          tile_phase(P0{}, std::true_type{});
-          par = 1;
-          more = v1;
-          if (more) advance();
-          if (!(more && is_fast())) break;
-          tile_phase(P1{}, std::true_type{});
-          par = 0;
-          more = v1;
-          if (more) advance();
-        } while (more && is_fast());
-      } else {
+      int par = 0;
+      while (more) {
         if (par == 0)
-          tile_phase(P0{}, std::false_type{});
-        else if (is_fast())
-          tile_phase(P1{}, std::true_type{});
+          tile_phase(P0{}, Yes{}, No{}, No{});
         else
-          tile_phase(P1{}, std::false_type{});
+          tile_phase(P1{}, Yes{}, No{}, No{});
         par ^= 1;
-        more = v1;
-        if (more) advance();
+        step(No{});
       }
+    }
+  }
+  // ---- pass B: border tiles (checked copy, immediate epilogue)
+  if (bor_cnt > 0) {
+    begin_pass(Yes{}, bor_begin, bor_cnt);
+    more = true;
+    int par = 0;
+    while (more) {
+      if (NCH > 1 || par == 0)
+        tile_phase(P0{}, No{}, No{}, No{});
+      else
+        tile_phase(P1{}, No{}, No{}, No{});
+      if (NCH == 1) par ^= 1;
+      step(Yes{});
     }
   }
   if (pend_tile >= 0) {
@@ -1885,13 +2054,11 @@ template <typename T, int CH, int RB>
 int launch_ws2(const ConvArgs& a, hipStream_t st) {
   const int tiles = a.N * ceil_div(a.Do, 4) * ceil_div(a.Ho, 8) * ceil_div(a.Wo, 8);
   const int cout_tiles = a.CoutP / 32;
-  int gx = std::min(tiles, std::max(1, 256 / cout_tiles));
-  const int tpw = ceil_div(tiles, gx);
-  gx = ceil_div(tiles, tpw);
+  const int gx = std::min(tiles, std::max(1, 256 / cout_tiles));  // one workgroup per CU; the kernel splits the tiles
   if (a.in_scale)
-    hipLaunchKernelGGL((conv_ws2_kernel<T, CH, RB, true>), dim3(gx, cout_tiles), dim3(256), 0, st, a, tiles, tpw);
+    hipLaunchKernelGGL((conv_ws2_kernel<T, CH, RB, true>), dim3(gx, cout_tiles), dim3(256), 0, st, a);
   else
-    hipLaunchKernelGGL((conv_ws2_kernel<T, CH, RB, false>), dim3(gx, cout_tiles), dim3(256), 0, st, a, tiles, tpw);
+    hipLaunchKernelGGL((conv_ws2_kernel<T, CH, RB, false>), dim3(gx, cout_tiles), dim3(256), 0, st, a);
   HDF_LAUNCH_CHECK();
   return HDF_OK;
 }
