@@ -648,6 +648,7 @@ __device__ __forceinline__ int a_swz(int row) {
 
 struct WsTile {
   int n, z0, y0, x0, tile;
+  int k;  // index in the list the tile came from (border pass)
 };
 
 template <typename T, int CH, int RB, bool XF>
@@ -703,11 +704,32 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
   const int n_int = has_int ? a.N * ipz * ipy * ipx : 0;
   const int per_all = ntz * nty * ntx, per_bor = per_all - (has_int ? ipz * ipy * ipx : 0);
   const int n_bor = a.N * per_bor;
+  // XCD-aware split: workgroup b runs on XCD b % 8 (round-robin dispatch), and each XCD has its own 4 MiB L2.  XCD x
+  // owns the x-th eighth of the raster-ordered tile list and its G/8 workgroups walk that range interleaved (tile
+  // r0 + slot, + G/8, ...): at any moment the XCD works on ~G/8 consecutive tiles, so the halo planes neighbouring
+  // tiles share are fetched from HBM once and hit in that L2 (a contiguous chunk per workgroup re-fetched them:
+  // FETCH_SIZE 2.8x the input).
   const int G = gridDim.x;
-  const int ci = (n_int + G - 1) / G, cb = (n_bor + G - 1) / G;
-  const int int_begin = min(n_int, (int)blockIdx.x * ci), int_cnt = min(n_int, int_begin + ci) - int_begin;
-  const int bor_begin = min(n_bor, (int)blockIdx.x * cb), bor_cnt = min(n_bor, bor_begin + cb) - bor_begin;
+  const int NX = (G % 8 == 0) ? 8 : 1;  // ranges
+  const int WPX = G / NX;               // workgroups per range = stride of a workgroup inside its range
+  const int xcd = blockIdx.x % NX, slot = blockIdx.x / NX;
+  auto split = [&](int total, int& begin, int& cnt) {
+    const int r0 = (int)((int64_t)total * xcd / NX), r1 = (int)((int64_t)total * (xcd + 1) / NX);
+    begin = r0 + slot;
+    cnt = (r1 - r0 > slot) ? (r1 - r0 - slot + WPX - 1) / WPX : 0;
+  };
+  int int_begin, int_cnt, bor_begin, bor_cnt;
+  split(n_int, int_begin, int_cnt);
+  split(n_bor, bor_begin, bor_cnt);
   if (int_cnt + bor_cnt == 0) return;
+  // mixed-radix digits of the stride WPX over the interior tile grid (x, y, z, n): int_next adds them with carries
+  int sdx = 0, sdy = 0, sdz = 0, sdn = 0;
+  if (has_int) {
+    int t = WPX;
+    sdx = t % ipx, t /= ipx;
+    sdy = t % ipy, t /= ipy;
+    sdz = t % ipz, sdn = t / ipz;
+  }
 
   // ---- per-lane constants
   // fragment read addresses: [jz][y'][jx] -> byte offset of this lane's 16-byte slot inside a tile buffer
@@ -776,24 +798,18 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
     c.n = t / ipz;
     c.tile = tile_lin(c);
   };
-  auto int_next = [&](WsTile& c) {
-    c.x0 += TW;
-    if (c.x0 >= (ntx - 1) * TW) {
-      c.x0 = TW;
-      c.y0 += TH;
-      if (c.y0 >= (nty - 1) * TH) {
-        c.y0 = TH;
-        c.z0 += TD;
-        if (c.z0 >= (ntz - 1) * TD) {
-          c.z0 = TD;
-          c.n++;
-        }
-      }
-    }
+  auto int_next = [&](WsTile& c) {  // + WPX tiles in raster order of the interior grid
+    int xi = (c.x0 >> 3) - 1 + sdx, yi = (c.y0 >> 3) - 1 + sdy, zi = (c.z0 >> 2) - 1 + sdz;
+    c.n += sdn;
+    if (xi >= ipx) xi -= ipx, yi++;
+    if (yi >= ipy) yi -= ipy, zi++;
+    if (zi >= ipz) zi -= ipz, c.n++;
+    c.x0 = (xi + 1) * TW, c.y0 = (yi + 1) * TH, c.z0 = (zi + 1) * TD;
     c.tile = tile_lin(c);
   };
   auto bor_init = [&](WsTile& c, int k) {
     int tz, ty, tx;
+    c.k = k;
     c.n = k / per_bor;
     int rem = k - c.n * per_bor;
     if (!has_int) {
@@ -822,25 +838,8 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
     c.z0 = tz * TD, c.y0 = ty * TH, c.x0 = tx * TW;
     c.tile = tile_lin(c);
   };
-  auto bor_next = [&](WsTile& c) {
-    c.x0 += TW;
-    if (c.x0 >= ntx * TW) {
-      c.x0 = 0;
-      c.y0 += TH;
-      if (c.y0 >= nty * TH) {
-        c.y0 = 0;
-        c.z0 += TD;
-        if (c.z0 >= ntz * TD) {
-          c.z0 = 0;
-          c.n++;
-        }
-      }
-    }
-    // the interior tiles of a row are its contiguous middle: one jump skips them
-    if (has_int && c.x0 == TW && c.y0 >= TH && c.y0 < (nty - 1) * TH && c.z0 >= TD && c.z0 < (ntz - 1) * TD)
-      c.x0 = (ntx - 1) * TW;
-    c.tile = tile_lin(c);
-  };
+  // border tiles are re-decoded from their list index (a few integer divisions per tile of the checked path)
+  auto bor_next = [&](WsTile& c) { bor_init(c, c.k + WPX); };
   auto tile_interior = [&](const WsTile& c) {
     return c.z0 >= 1 && c.y0 >= 1 && c.x0 >= 1 && c.z0 + TD + 1 <= a.Di && c.y0 + TH + 1 <= a.Hi &&
            c.x0 + TW + 1 <= a.Wi;
@@ -1122,13 +1121,19 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
       read_group(0, af[0], bf[0]);
 #pragma unroll
       for (int g = 0; g < NG; g++) {
+#ifdef WS2_DBG_NOREADS
+        if (g + 1 < 2) read_group(g + 1, af[(g + 1) & 1], bf[(g + 1) & 1]);
+#else
         if (g + 1 < NG) read_group(g + 1, af[(g + 1) & 1], bf[(g + 1) & 1]);
+#endif
         __builtin_amdgcn_sched_barrier(0);  // look-ahead reads stay ABOVE this group's MFMAs
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
           if ((j * NG) / NJ == g) {
+#ifndef WS2_DBG_NOSTAGE  // energy/cycle attribution experiments: drop the staging or the fragment reads
             commit_one(fast_tag, j, CT, c_int, a_wr);
             load_one(fast_tag, j, l_chunk, LT, l_val, l_int, l_org);
+#endif
           }
         }
         if constexpr (DIN) {
