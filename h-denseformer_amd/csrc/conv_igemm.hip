@@ -1642,8 +1642,6 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
   const int scb = blockIdx.y, lcb = blockIdx.z;
   const int part = tid & (CPV - 1);
   const int ntz = (a.Ds + TD - 1) / TD, nty = (a.Hs + TH - 1) / TH, ntx = (a.Ws + TW - 1) / TW;
-  const int t_begin = blockIdx.x * a.tiles_per_group;
-  const int t_end = min(a.num_tiles, t_begin + a.tiles_per_group);
   const float relu_lo = (XFL && a.lg_relu) ? 0.f : -INFINITY;
 
   // ---- transposed-read addresses (lane roles of ds_read_b64_tr_b16: 4 voxels x 16 channels per 16 lanes)
@@ -1690,38 +1688,82 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
   const T* const s_src = s_safe + scb * 32 + part * EPC;
   const T* const l_src = l_safe + lcb * 32 + part * EPC;
 
-  auto tile_init = [&](WsTile& c, int tile) {
-    int t = tile;
-    c.tile = tile;
-    c.x0 = (t % ntx) * TW;
-    t /= ntx;
-    c.y0 = (t % nty) * TH;
-    t /= nty;
-    c.z0 = (t % ntz) * TD;
-    c.n = t / ntz;
+  // Tile schedule (as in conv_ws2_kernel): an interior pass (unchecked copy of the phase, one long run) and a
+  // border pass (checked copy); inside each, XCD x owns the x-th eighth of the raster-ordered list and its
+  // gridDim.x/8 workgroups walk it interleaved, so neighbouring tiles' halos meet in that XCD's L2.
+  const bool has_int = chan_all && ntz >= 3 && nty >= 3 && ntx >= 3;
+  const int ipz = ntz - 2, ipy = nty - 2, ipx = ntx - 2;
+  const int n_int = has_int ? a.N * ipz * ipy * ipx : 0;
+  const int per_bor = ntz * nty * ntx - (has_int ? ipz * ipy * ipx : 0);
+  const int n_bor = a.N * per_bor;
+  const int G = gridDim.x;
+  const int NX = (G % 8 == 0) ? 8 : 1;
+  const int WPX = G / NX;
+  const int xcd = blockIdx.x % NX, slot = blockIdx.x / NX;
+  auto split = [&](int total, int& begin, int& cnt) {
+    const int r0 = (int)((int64_t)total * xcd / NX), r1 = (int)((int64_t)total * (xcd + 1) / NX);
+    begin = r0 + slot;
+    cnt = (r1 - r0 > slot) ? (r1 - r0 - slot + WPX - 1) / WPX : 0;
   };
-  auto tile_next = [&](WsTile& c) {
-    c.tile++;
-    c.x0 += TW;
-    if (c.x0 >= a.Ws) {
-      c.x0 = 0;
-      c.y0 += TH;
-      if (c.y0 >= a.Hs) {
-        c.y0 = 0;
-        c.z0 += TD;
-        if (c.z0 >= a.Ds) {
-          c.z0 = 0;
-          c.n++;
+  int int_begin, int_cnt, bor_begin, bor_cnt;
+  split(n_int, int_begin, int_cnt);
+  split(n_bor, bor_begin, bor_cnt);
+  int sdx = 0, sdy = 0, sdz = 0, sdn = 0;  // mixed-radix digits of the stride WPX over the interior tile grid
+  if (has_int) {
+    int t = WPX;
+    sdx = t % ipx, t /= ipx;
+    sdy = t % ipy, t /= ipy;
+    sdz = t % ipz, sdn = t / ipz;
+  }
+  auto int_init = [&](WsTile& c, int k) {
+    int t = k;
+    c.x0 = (t % ipx + 1) * TW;
+    t /= ipx;
+    c.y0 = (t % ipy + 1) * TH;
+    t /= ipy;
+    c.z0 = (t % ipz + 1) * TD;
+    c.n = t / ipz;
+    c.k = k;
+  };
+  auto int_next = [&](WsTile& c) {  // + WPX tiles in raster order of the interior grid
+    int xi = (c.x0 >> 3) - 1 + sdx, yi = (c.y0 >> 3) - 1 + sdy, zi = (c.z0 >> 2) - 1 + sdz;
+    c.n += sdn;
+    if (xi >= ipx) xi -= ipx, yi++;
+    if (yi >= ipy) yi -= ipy, zi++;
+    if (zi >= ipz) zi -= ipz, c.n++;
+    c.x0 = (xi + 1) * TW, c.y0 = (yi + 1) * TH, c.z0 = (zi + 1) * TD;
+  };
+  auto bor_init = [&](WsTile& c, int k) {
+    int tz, ty, tx;
+    c.k = k;
+    c.n = k / per_bor;
+    int rem = k - c.n * per_bor;
+    if (!has_int) {
+      tx = rem % ntx, ty = (rem / ntx) % nty, tz = rem / (ntx * nty);
+    } else {
+      const int plane = nty * ntx, ring = plane - ipy * ipx;  // border tiles of a z-plane: all of it / its rim
+      if (rem < plane) {
+        tz = 0, ty = rem / ntx, tx = rem % ntx;
+      } else if (rem - plane < ipz * ring) {
+        rem -= plane;
+        tz = 1 + rem / ring;
+        rem %= ring;
+        if (rem < ntx) {
+          ty = 0, tx = rem;
+        } else if (rem - ntx < 2 * ipy) {
+          rem -= ntx;
+          ty = 1 + (rem >> 1), tx = (rem & 1) ? ntx - 1 : 0;
+        } else {
+          ty = nty - 1, tx = rem - ntx - 2 * ipy;
         }
+      } else {
+        rem -= plane + ipz * ring;
+        tz = ntz - 1, ty = rem / ntx, tx = rem % ntx;
       }
     }
+    c.z0 = tz * TD, c.y0 = ty * TH, c.x0 = tx * TW;
   };
-  auto tile_valid = [&](const WsTile& c) { return c.tile < t_end; };
-  // whole small tile and whole large box inside the tensors, every channel part real: no test anywhere
-  auto tile_interior = [&](const WsTile& c) {
-    return chan_all && c.z0 >= 1 && c.y0 >= 1 && c.x0 >= 1 && c.z0 + TD + 1 <= a.Dl && c.y0 + TH + 1 <= a.Hl &&
-           c.x0 + TW + 1 <= a.Wl;
-  };
+  auto bor_next = [&](WsTile& c) { bor_init(c, c.k + WPX); };
   auto s_org_of = [&](const WsTile& c) -> const T* {
     return s_src + ((((int64_t)c.n * a.Ds + c.z0) * a.Hs + c.y0) * a.Ws + c.x0) * a.sm_pitch;
   };
@@ -1801,23 +1843,39 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tlast = __builtin_amdgcn_s_memtime();
 #endif
-  if (t_begin < t_end) {
+  {
     WsTile T0, T1, T2;
-    tile_init(T0, t_begin);
-    T1 = T0;
-    tile_next(T1);
-    T2 = T1;
-    tile_next(T2);
-    bool v1 = tile_valid(T1), v2 = tile_valid(T2);
-    bool i1 = v1 && tile_interior(T1), i2 = v2 && tile_interior(T2);
-    const T* so1 = v1 ? s_org_of(T1) : s_safe;
-    const T* lo1 = v1 ? l_org_of(T1) : l_safe;
-    const T* so2 = v2 ? s_org_of(T2) : s_safe;
-    const T* lo2 = v2 ? l_org_of(T2) : l_safe;
-    // ---- prologue: T0 -> buffer 0 (not overlapped, NPF slots at a time), first PD slots of T1 -> registers
-    {
+    bool v1 = false, v2 = false;
+    const T *so1 = s_safe, *lo1 = l_safe, *so2 = s_safe, *lo2 = l_safe;
+    int left = 0, par = 0;
+    // start a pass at its k-th tile: T0 -> buffer 0 (not overlapped, NPF slots at a time), first PD slots of T1 ->
+    // registers
+    auto begin_pass = [&](auto border_tag, int k, int count) __attribute__((always_inline)) {
+      constexpr bool BORDER = decltype(border_tag)::value;
+      auto next = [&](WsTile& c) {
+        if constexpr (BORDER)
+          bor_next(c);
+        else
+          int_next(c);
+      };
+      if constexpr (BORDER)
+        bor_init(T0, k);
+      else
+        int_init(T0, k);
+      left = count - 1;
+      T1 = T0;
+      next(T1);
+      T2 = T1;
+      next(T2);
+      v1 = left >= 1, v2 = left >= 2;
+      so1 = v1 ? s_org_of(T1) : s_safe;
+      lo1 = v1 ? l_org_of(T1) : l_safe;
+      so2 = v2 ? s_org_of(T2) : s_safe;
+      lo2 = v2 ? l_org_of(T2) : l_safe;
       const T* so0 = s_org_of(T0);
       const T* lo0 = l_org_of(T0);
+      __syncthreads();  // the previous pass is done with both buffers
+      par = 0;
       if constexpr (XFL) refresh_xf(T0.n);
 #pragma unroll
       for (int s0 = 0; s0 < NSLOT; s0 += NPF) {
@@ -1828,8 +1886,8 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
       }
 #pragma unroll
       for (int s = 0; s < PD; s++) load_one(std::false_type{}, s, T1, v1, so1, lo1);
-    }
-    WS_BARRIER();
+      WS_BARRIER();
+    };
 
     using lds_s16x4 = s16x4 __attribute__((address_space(3)));
     auto tr_read = [&](int off) {
@@ -1837,9 +1895,8 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
       return __builtin_bit_cast(u32x2, v);
     };
     // The buffer parity is a RUN-TIME value folded into the 8 read-address registers: with it as a template
-    // parameter the four (parity x fast) copies of the phase disagreed on where the in-flight staging registers
-    // live, and the compiler drained every outstanding load (s_waitcnt vmcnt(0)) at the loop's back edge.
-    int par = 0;
+    // parameter the copies of the phase disagreed on where the in-flight staging registers live, and the compiler
+    // drained every outstanding load (s_waitcnt vmcnt(0)) at the loop's back edge.
     auto tile_phase = [&](auto fast_tag) __attribute__((always_inline)) {
       constexpr int FASTI = decltype(fast_tag)::value ? 0 : 4;
       (void)FASTI;
@@ -1896,35 +1953,40 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
       for (int j = 0; j < NT; j++) asm volatile("" : "+a"(acc[j]));
     };
 
-    auto advance = [&]() {
+    bool more = true;
+    auto step = [&](auto border_tag) __attribute__((always_inline)) {
+      constexpr bool BORDER = decltype(border_tag)::value;
+      par ^= 1;
+      more = v1;
+      if (!more) return;
+      left--;
       T0 = T1;
       T1 = T2;
-      i1 = i2;
       v1 = v2;
       so1 = so2;
       lo1 = lo2;
-      tile_next(T2);
-      v2 = tile_valid(T2);
-      i2 = v2 && tile_interior(T2);
+      if constexpr (BORDER)
+        bor_next(T2);
+      else
+        int_next(T2);
+      v2 = left >= 2;
       so2 = v2 ? s_org_of(T2) : s_safe;
       lo2 = v2 ? l_org_of(T2) : l_safe;
     };
-    // runs of interior tiles loop inside the fast copy of the phase (its own back edge: the in-flight staging
-    // registers stay put, nothing is drained between tiles)
-    bool more = true;
-    while (more) {
-      if (i1 && i2) {
-        do {
-          tile_phase(std::true_type{});
-          par ^= 1;
-          more = v1;
-          if (more) advance();
-        } while (more && i1 && i2);
-      } else {
+    if (int_cnt > 0) {  // interior pass: the unchecked copy, one run (its own back edge: nothing drained per tile)
+      begin_pass(std::false_type{}, int_begin, int_cnt);
+      more = true;
+      while (more) {
+        tile_phase(std::true_type{});
+        step(std::false_type{});
+      }
+    }
+    if (bor_cnt > 0) {  // border pass: the checked copy
+      begin_pass(std::true_type{}, bor_begin, bor_cnt);
+      more = true;
+      while (more) {
         tile_phase(std::false_type{});
-        par ^= 1;
-        more = v1;
-        if (more) advance();
+        step(std::true_type{});
       }
     }
   }
