@@ -277,357 +277,11 @@ __device__ __forceinline__ void ws_row_to_zx(int r, int& dz, int& x) {
     asm volatile("" ::: "memory");                       \
   } while (0)
 
-template <typename T, int TD, int TH, int TW, int MB, int RBMAX, int NFS>
-__global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int tiles_total, int tiles_per_wg) {
-  static_assert(TH == 8 && TW == 8 && TD % 4 == 0, "M-block = 4(z) x 1(y) x 8(x)");
-  static_assert(4 * MB * 32 == TD * TH * TW, "tile/wave decomposition");
-  constexpr int BD = TD + 2, BH = TH + 2, BW = TW + 2, BOX = BD * BH * BW;
-  constexpr int ESZ = sizeof(T), EPC = ST<T>::EPC;
-  constexpr int NJ = (BOX * 4 + 255) / 256;
-  constexpr int ZB = TD / 4;                       // M-blocks per y row
-  constexpr int OPITCH = 32 * ESZ + 16;            // epilogue staging pitch (32 channels per voxel row)
-  constexpr int MT = TD * TH * TW;
-  static_assert(MT * OPITCH <= BOX * PITCH, "epilogue staging fits in the tile buffer");
-  __shared__ __attribute__((aligned(16))) char lds[BOX * PITCH + 1024 + 27 * 32 * RBMAX];
-  char* a_lds = lds;
-  float* s_red = reinterpret_cast<float*>(lds + BOX * PITCH);
-  char* w_lds = lds + BOX * PITCH + 1024;
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r = lane & 31, h = lane >> 5;
-  const int n0 = blockIdx.y * 32;
-  const int RB = a.Cin * ESZ;              // weight row bytes: 32, 64 or 128
-  const int cpr = RB >> 4, rp256 = 16 / cpr;
-  const int chunk_bytes = min(64, RB);     // activation chunk staged per pass (== 32 * NFS)
-  const int nchunks = RB / chunk_bytes;
-  const int cpv = chunk_bytes >> 4, cpv_shift = (cpv == 4) ? 2 : 1;
-  const int total = BOX << cpv_shift;
-  const int part = threadIdx.x & (cpv - 1);
-  const bool xf = (a.in_scale != nullptr);
-
-  // ---- weights -> LDS, once
-  for (int id = threadIdx.x; id < 27 * 32 * cpr; id += 256) {
-    int row = id / cpr, ch = id - row * cpr;
-    int tap = row >> 5, rr = row & 31;
-    u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a.w) +
-                                              ((int64_t)(tap * a.CoutP + n0 + rr) * a.Cin) * ESZ + ch * 16);
-    int sw = ch ^ ((row / rp256) & (cpr - 1));
-    *reinterpret_cast<u32x4*>(w_lds + row * RB + sw * 16) = v;
-  }
-  const int bswz = (r / rp256) & (cpr - 1);  // (tap*32 + r)/rp256 & (cpr-1) == this, since 32/rp256 % cpr == 0
-
-  const int ntz = (a.Do + TD - 1) / TD, nty = (a.Ho + TH - 1) / TH, ntx = (a.Wo + TW - 1) / TW;
-  int rowbase[MB];
-  {
-    int dz, x;
-    ws_row_to_zx(r, dz, x);
-#pragma unroll
-    for (int mb = 0; mb < MB; mb++) {
-      const int mbi = wave * MB + mb, y = mbi / ZB, zb = 4 * (mbi % ZB);
-      rowbase[mb] = (((zb + dz) * BH + y) * BW + x) * PITCH + h * 16;
-    }
-  }
-  const int t_begin = blockIdx.x * tiles_per_wg, t_end = min(tiles_total, t_begin + tiles_per_wg);
-  const int nitems = (t_end - t_begin) * nchunks;
-  if (nitems <= 0) return;
-
-  // per-thread constants of the staging slots: element offset of the slot's voxel relative to the box origin and
-  // its packed box coordinates
-  int boff[NJ], bxyz[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; j++) {
-    int vox = min((int)threadIdx.x + 256 * j, total - 1) >> cpv_shift;
-    int bz = vox / (BH * BW), rem = vox - bz * (BH * BW), by = rem / BW, bx = rem - by * BW;
-    boff[j] = ((bz * a.Hi + by) * a.Wi + bx) * (int)a.in_pitch;
-    bxyz[j] = (bz << 16) | (by << 8) | bx;
-  }
-
-  u32x4 pf[NJ];
-  uint32_t pf_valid = 0;
-  auto tile_origin = [&](int tile, int& n, int& z0, int& y0, int& x0) {
-    int t = tile;
-    x0 = (t % ntx) * TW;
-    t /= ntx;
-    y0 = (t % nty) * TH;
-    t /= nty;
-    z0 = (t % ntz) * TD;
-    n = t / ntz;
-  };
-  // interior tiles (box entirely inside the volume, ~70 % of them) skip every bounds test / select
-  auto is_interior = [&](int z0, int y0, int x0) {
-    return z0 >= 1 && y0 >= 1 && x0 >= 1 && z0 + TD + 1 <= a.Di && y0 + TH + 1 <= a.Hi && x0 + TW + 1 <= a.Wi;
-  };
-  bool pf_interior = false;
-  auto prefetch = [&](int item) {
-    int tile = t_begin + item / nchunks, c0 = (item % nchunks) * (chunk_bytes / ESZ);
-    int n, z0, y0, x0;
-    tile_origin(tile, n, z0, y0, x0);
-    const T* src = reinterpret_cast<const T*>(a.in) + c0 + part * EPC;
-    const T* org = src + ((((int64_t)n * a.Di + (z0 - 1)) * a.Hi + (y0 - 1)) * a.Wi + (x0 - 1)) * a.in_pitch;
-    pf_interior = is_interior(z0, y0, x0);
-#ifdef WS_DBG_SKIP_LOADS
-    pf_interior = true;
-    for (int j = 0; j < NJ; j++) pf[j] = u32x4{(uint32_t)item, 0u, 0u, 0u};
-    return;
-#endif
-    if (pf_interior) {
-#pragma unroll
-      for (int j = 0; j < NJ; j++) pf[j] = *reinterpret_cast<const u32x4*>(org + boff[j]);
-      return;
-    }
-    pf_valid = 0;
-#pragma unroll
-    for (int j = 0; j < NJ; j++) {
-      int iz = z0 - 1 + (bxyz[j] >> 16), iy = y0 - 1 + ((bxyz[j] >> 8) & 255), ix = x0 - 1 + (bxyz[j] & 255);
-      bool ok = (int)threadIdx.x + 256 * j < total && (unsigned)iz < (unsigned)a.Di && (unsigned)iy < (unsigned)a.Hi &&
-                (unsigned)ix < (unsigned)a.Wi;
-      // unconditional load from a clamped address (never branch around a load: the loads of one prefetch must
-      // all be in flight together); out-of-volume voxels are zeroed at commit time through pf_valid
-      const T* p = ok ? org + boff[j] : src;
-      pf[j] = *reinterpret_cast<const u32x4*>(p);
-      pf_valid |= (ok ? 1u : 0u) << j;
-    }
-  };
-  auto commit = [&](int item) {  // registers -> (transform) -> LDS
-    int c0 = (item % nchunks) * (chunk_bytes / ESZ);
-    int n = 0;
-    float sc[EPC], sh[EPC];
-    if (xf) {
-      int z0, y0, x0;
-      tile_origin(t_begin + item / nchunks, n, z0, y0, x0);
-#pragma unroll
-      for (int e = 0; e < EPC; e++) {
-        sc[e] = a.in_scale[(int64_t)n * a.Cin + c0 + part * EPC + e];
-        sh[e] = a.in_shift[(int64_t)n * a.Cin + c0 + part * EPC + e];
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < NJ; j++) {
-      int id = threadIdx.x + 256 * j;
-      if (id < total) {
-        u32x4 v = pf[j];
-        if (xf) {
-          float f[EPC];
-          ST<T>::unpack(v, f);
-#pragma unroll
-          for (int e = 0; e < EPC; e++) {
-            f[e] = f[e] * sc[e] + sh[e];
-            if (a.in_relu) f[e] = fmaxf(f[e], 0.f);
-          }
-          v = ST<T>::pack(f);
-        }
-        if (!pf_interior && !((pf_valid >> j) & 1u)) v = u32x4{0u, 0u, 0u, 0u};
-        *reinterpret_cast<u32x4*>(a_lds + (id >> cpv_shift) * PITCH + part * 16) = v;
-      }
-    }
-  };
-
-  f32x16 acc[MB];
-  const int ch = n0 + r;
-  const bool ch_ok = ch < a.Cout;
-  const float bias = (a.bias && ch_ok) ? a.bias[ch] : 0.f;
-  T* outp = reinterpret_cast<T*>(a.out);
-  // epilogue constants: staging offset and (dz,x) of accumulator register i of this lane
-  int erow[16], ezx[16];
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    int dz, x;
-    ws_row_to_zx((i & 3) + 8 * (i >> 2) + 4 * h, dz, x);
-    erow[i] = ((dz * TH) * TW + x) * OPITCH;
-    ezx[i] = (dz << 4) | x;
-  }
-
-#ifdef WS_DBG_STAMPS
-  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define STAMP(k)                                                   \
-  {                                                                \
-    __builtin_amdgcn_sched_barrier(0);                             \
-    unsigned long long t_ = __builtin_amdgcn_s_memtime();          \
-    __builtin_amdgcn_s_waitcnt(0xC07F);                            \
-    __builtin_amdgcn_sched_barrier(0);                             \
-    tacc[k] += t_ - tlast;                                         \
-    tlast = t_;                                                    \
-  }
-  unsigned long long tlast = __builtin_amdgcn_s_memtime();
-#else
-#define STAMP(k)
-#endif
-  prefetch(0);
-  for (int item = 0; item < nitems; item++) {
-    const int chunk = item % nchunks;
-    STAMP(7)
-    commit(item);
-    STAMP(0)
-    WS_BARRIER();
-    STAMP(1)
-    // prefetch of the next item: border tiles issue their (bounds-checked) loads in one burst here; interior
-    // tiles spread the NJ loads over the MFMA steps below so that their address/issue time hides under the MFMAs
-    const T* nxt_org = nullptr;
-    bool spread = false;
-    if (item + 1 < nitems) {
-      int tile = t_begin + (item + 1) / nchunks, c0n = ((item + 1) % nchunks) * (chunk_bytes / ESZ);
-      int n, z0, y0, x0;
-      tile_origin(tile, n, z0, y0, x0);
-      spread = is_interior(z0, y0, x0);
-      if (spread) {
-        pf_interior = true;
-        nxt_org = reinterpret_cast<const T*>(a.in) + c0n + part * EPC +
-                  ((((int64_t)n * a.Di + (z0 - 1)) * a.Hi + (y0 - 1)) * a.Wi + (x0 - 1)) * a.in_pitch;
-      } else {
-        prefetch(item + 1);
-      }
-    }
-    STAMP(2)
-    if (chunk == 0) {
-#pragma unroll
-      for (int mb = 0; mb < MB; mb++)
-#pragma unroll
-        for (int i = 0; i < 16; i++) acc[mb][i] = 0.f;
-    }
-    const int lc0 = (chunk * chunk_bytes) >> 4;  // first 16-B chunk of this pass within a weight row
-    auto mfma_phase = [&](auto spread_tag) {
-      constexpr bool SPREAD = decltype(spread_tag)::value;
-      constexpr int NS = 27 * NFS, DEPTH = 3;
-      constexpr int PFS = (NS - 4) / NJ > 0 ? (NS - 4) / NJ : 1;  // one prefetch load every PFS steps
-      u32x4 bq[DEPTH], aq[DEPTH][MB];
-      auto load_step = [&](int s_, u32x4& bf, u32x4 (&af)[MB]) {
-        const int tap = s_ / NFS, fs = s_ % NFS;
-        const int jz = tap / 9, jy = (tap / 3) % 3, jx = tap % 3;
-        const int tapoff = ((jz * BH + jy) * BW + jx) * PITCH + fs * 32;
-        bf = *reinterpret_cast<const u32x4*>(w_lds + (tap * 32 + r) * RB + (((lc0 + fs * 2 + h) ^ bswz) << 4));
-#pragma unroll
-        for (int mb = 0; mb < MB; mb++) af[mb] = *reinterpret_cast<const u32x4*>(a_lds + rowbase[mb] + tapoff);
-      };
-#pragma unroll
-      for (int s0 = 0; s0 < DEPTH - 1; s0++) load_step(s0, bq[s0], aq[s0]);
-#ifdef WS_DBG_SKIP_MMA
-      constexpr int NSRUN = 1;
-#else
-      constexpr int NSRUN = NS;
-#endif
-#pragma unroll
-      for (int s_ = 0; s_ < NSRUN; s_++) {
-        if (s_ + DEPTH - 1 < NS) load_step(s_ + DEPTH - 1, bq[(s_ + DEPTH - 1) % DEPTH], aq[(s_ + DEPTH - 1) % DEPTH]);
-        if constexpr (SPREAD) {
-          if (s_ % PFS == 0 && s_ / PFS < NJ) pf[s_ / PFS] = *reinterpret_cast<const u32x4*>(nxt_org + boff[s_ / PFS]);
-        }
-        __builtin_amdgcn_sched_barrier(0);  // keep the look-ahead reads ABOVE this step's MFMAs
-#pragma unroll
-        for (int mb = 0; mb < MB; mb++) Mma<T>::run(aq[s_ % DEPTH][mb], bq[s_ % DEPTH], acc[mb]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if constexpr (SPREAD) {
-#pragma unroll
-        for (int j = 0; j < NJ; j++)
-          if (j * PFS >= NSRUN) pf[j] = *reinterpret_cast<const u32x4*>(nxt_org + boff[j]);
-      }
-    };
-    if (spread)
-      mfma_phase(std::true_type{});
-    else
-      mfma_phase(std::false_type{});
-    STAMP(3)
-    WS_BARRIER();  // every wave is done reading the tile buffer
-    STAMP(4)
-    if (chunk == nchunks - 1) {
-      // ---- epilogue: accumulators (+bias) -> LDS rows [voxel][32 ch] -> whole 16-byte chunks to HBM
-      const int tile = t_begin + item / nchunks;
-      int n, z0, y0, x0;
-      tile_origin(tile, n, z0, y0, x0);
-      float s1 = 0.f, s2 = 0.f;
-      const bool full = z0 + TD <= a.Do && y0 + TH <= a.Ho && x0 + TW <= a.Wo;  // whole tile in range (uniform)
-      if (full) {  // branch hoisted out of the element loops: straight-line cvt + ds_write + 2 FMAs per element
-#pragma unroll
-        for (int mb = 0; mb < MB; mb++) {
-          const int mbi = wave * MB + mb, y = mbi / ZB, zb = 4 * (mbi % ZB);
-          char* orow = a_lds + ((zb * TH + y) * TW) * OPITCH + r * ESZ;
-#pragma unroll
-          for (int i = 0; i < 16; i++) {
-            float v = acc[mb][i] + bias;
-            T tv;
-            ST<T>::st(&tv, v);
-            *reinterpret_cast<T*>(orow + erow[i]) = tv;
-            s1 += v;
-            s2 += v * v;
-          }
-        }
-      } else {
-#pragma unroll
-        for (int mb = 0; mb < MB; mb++) {
-          const int mbi = wave * MB + mb, y = mbi / ZB, zb = 4 * (mbi % ZB);
-          const float ymask = (y0 + y) < a.Ho ? 1.f : 0.f;
-          char* orow = a_lds + ((zb * TH + y) * TW) * OPITCH + r * ESZ;
-#pragma unroll
-          for (int i = 0; i < 16; i++) {
-            float v = acc[mb][i] + bias;
-            T tv;
-            ST<T>::st(&tv, v);
-            *reinterpret_cast<T*>(orow + erow[i]) = tv;
-            const float mk = ((z0 + zb + (ezx[i] >> 4)) < a.Do && (x0 + (ezx[i] & 15)) < a.Wo) ? ymask : 0.f;
-            s1 += mk * v;
-            s2 += mk * v * v;
-          }
-        }
-      }
-      if (!ch_ok) s1 = s2 = 0.f;
-      if (a.stat_partials) {
-        s1 += __shfl_xor(s1, 32, 64);
-        s2 += __shfl_xor(s2, 32, 64);
-        if (h == 0) {
-          s_red[(wave * 32 + r) * 2 + 0] = s1;
-          s_red[(wave * 32 + r) * 2 + 1] = s2;
-        }
-      }
-      STAMP(5)
-      WS_BARRIER();
-      constexpr int CPO = 32 * ESZ / 16;  // 16-byte chunks per staged voxel row
-      const int opart = threadIdx.x & (CPO - 1);
-      const bool oc_ok = n0 + opart * EPC < a.Cout;
-#pragma unroll
-      for (int k = 0; k < MT * CPO / 256; k++) {
-        const int lv = (threadIdx.x + 256 * k) / CPO;
-        const int z = lv / (TH * TW), y = (lv / TW) % TH, x = lv % TW;
-        const int gz = z0 + z, gy = y0 + y, gx = x0 + x;
-        if (oc_ok && gz < a.Do && gy < a.Ho && gx < a.Wo) {
-          u32x4 v = *reinterpret_cast<const u32x4*>(a_lds + lv * OPITCH + opart * 16);
-          T* p = outp + ((((int64_t)n * a.Do + gz) * a.Ho + gy) * a.Wo + gx) * a.out_pitch + n0 + opart * EPC;
-          if (a.accumulate) {
-            float f[EPC], g[EPC];
-            ST<T>::unpack(v, f);
-            ST<T>::unpack(*reinterpret_cast<const u32x4*>(p), g);
-#pragma unroll
-            for (int e = 0; e < EPC; e++) f[e] += g[e];
-            v = ST<T>::pack(f);
-          }
-          *reinterpret_cast<u32x4*>(p) = v;
-        }
-      }
-      if (a.stat_partials && threadIdx.x < 32) {
-        float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          t1 += s_red[(k * 32 + threadIdx.x) * 2 + 0];
-          t2 += s_red[(k * 32 + threadIdx.x) * 2 + 1];
-        }
-        float* q = a.stat_partials + ((int64_t)tile * a.CoutP + n0 + threadIdx.x) * 2;
-        q[0] = t1;
-        q[1] = t2;
-      }
-      STAMP(6)
-      WS_BARRIER();  // staging rows consumed before the next commit overwrites the tile buffer
-      STAMP(4)
-    }
-  }
-#ifdef WS_DBG_STAMPS
-  if (threadIdx.x == 0 && blockIdx.y == 0)
-    for (int k = 0; k < 8; k++) a.stat_partials[(int64_t)blockIdx.x * 8 + k] = (float)tacc[k];
-#endif
-}
-
 // ------------------------------------------------------------------------------------------------
 // conv_ws2: weights-stationary persistent kernel with a DOUBLE-BUFFERED activation tile.
 //
-// One wave per SIMD leaves nothing to hide the staging work behind, and in conv_ws_kernel the commit (global ->
+// One wave per SIMD leaves nothing to hide the staging work behind, and in the single-buffered predecessor of this
+// kernel (round-1 conv_ws_kernel, see git history) the commit (global ->
 // InstanceNorm/ReLU transform -> LDS), the bounds logic and the prefetch issue cost as many cycles as the MFMAs.
 // Here a pass over item i (= one 4x8x8 tile x one CH-byte channel chunk) reads tile buffer i&1 while the SAME
 // instruction stream, in the gaps between its MFMAs, transforms and writes item i+1 into the other buffer and
@@ -635,12 +289,16 @@ __global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a, int tiles_tota
 //  * unpadded rows (pitch == CH) + XOR swizzle of the 16-byte slots keep both buffers and the whole weight
 //    panel (27 x 32 x RB bytes) inside 160 KiB; a_swz makes every ds_read_b128 lane group conflict-free
 //  * a wave owns the M-blocks y = 2w, 2w+1: the A fragment of box row y' serves (mb, jy) with mb + jy == y', so a
-//    (jz, jx) group issues 4 A + 3 B fragment reads for 6 MFMAs (conv_ws_kernel: 9 reads)
+//    (jz, jx) group issues 4 A + 3 B fragment reads for 6 MFMAs (one fragment pair per MFMA: 9 reads)
 //  * the NCH passes of a tile are unrolled inside one "tile phase": chunk indices, buffer parities and the
 //    accumulators' lifetime are compile-time, tile coordinates advance incrementally once per tile (every
 //    instruction outside the MFMA shadow costs ~5 cycles with one wave per SIMD), scale/shift sit in an LDS table
-//  * bf16 epilogue: accumulators -> packed bf16 -> 2-byte global stores (32 lanes = one 64-byte voxel row), no LDS
-//    staging and no barrier; the cross-wave reduction of the InstanceNorm partials rides on the next pass's barrier
+//  * epilogue: accumulators (+bias) -> storage type -> element stores (32 lanes = one voxel row of 32 channels), no
+//    LDS staging and no barrier; the cross-wave reduction of the InstanceNorm partials rides on the next pass's
+//    barrier.  In the interior run of single-pass tiles the epilogue of tile t is deferred into the MFMA gaps of
+//    tile t+1 (two accumulator register sets)
+//  * schedule: an interior pass (unchecked copy of the phase) then a border pass (checked copy) per workgroup, both
+//    split XCD-aware (see the kernel body)
 template <int CH>
 __device__ __forceinline__ int a_swz(int row) {
   return CH == 64 ? ((row >> 2) & 3) : ((row >> 3) & 1);
@@ -659,7 +317,7 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
   constexpr int NCH = RB / CH, NFS = CH / 32, NG = 9 * NFS;
   constexpr int CPV = CH / 16, CPV_SHIFT = (CPV == 4) ? 2 : 1;
   constexpr int TOTAL = BOX * CPV, NJ = (TOTAL + 255) / 256;
-  // tile-buffer row pitch: padded by 16 bytes (conflict-free as in conv_ws_kernel, fragment addresses = one lane
+  // tile-buffer row pitch: padded by 16 bytes (conflict-free, see ws_row_to_zx; fragment addresses = one lane
   // base + compile-time offsets) whenever two padded buffers and the weight panel fit in 160 KiB; else unpadded
   // rows with XOR-swizzled 16-byte slots (a 36-entry per-lane address table)
   constexpr bool SWZ = (2 * BOX * (CH + 16) + 2048 + 512 + 27 * 32 * RB > 160 * 1024);
@@ -2095,26 +1753,7 @@ inline int ws_cfg(int mode, int Do, int Ho, int Wo, int row_bytes) {
   static const int ws_max = getenv("HDF_WS_MAX_ROW_BYTES") ? atoi(getenv("HDF_WS_MAX_ROW_BYTES")) : 128;  // tuning knob
   if (row_bytes > ws_max) return 0;
   if (mode != 0 || row_bytes > 128 || (int64_t)Do * Ho * Wo < 48 * 48 * 48) return 0;
-  return row_bytes <= 64 ? 2 : 1;  // 2: 8x8x8 tile, 4 M-blocks per wave; 1: 4x8x8 tile, 2 M-blocks per wave
-}
-
-template <typename T, int TD, int TH, int TW, int MB, int RBMAX, int NFS>
-int launch_ws(const ConvArgs& a, hipStream_t st) {
-  const int tiles = a.N * ceil_div(a.Do, TD) * ceil_div(a.Ho, TH) * ceil_div(a.Wo, TW);
-  const int cout_tiles = a.CoutP / 32;
-  int gx = std::min(tiles, std::max(1, 256 / cout_tiles));
-  const int tpw = ceil_div(tiles, gx);
-  gx = ceil_div(tiles, tpw);
-  hipLaunchKernelGGL((conv_ws_kernel<T, TD, TH, TW, MB, RBMAX, NFS>), dim3(gx, cout_tiles), dim3(256), 0, st, a, tiles,
-                     tpw);
-  HDF_LAUNCH_CHECK();
-  return HDF_OK;
-}
-
-// A/B knob: HDF_WS_OLD=1 selects the single-buffered conv_ws_kernel
-inline bool ws_use_old() {
-  static const bool v = getenv("HDF_WS_OLD") != nullptr;
-  return v;
+  return (row_bytes == 32 || row_bytes == 64 || row_bytes == 128) ? 1 : 0;
 }
 
 template <typename T, int CH, int RB>
@@ -2135,14 +1774,11 @@ int launch_conv_t(int mode, const ConvArgs& a, hipStream_t st) {
   if (mode == 0) {
     const int rb = a.Cin * (int)sizeof(T);
     const int ws = ws_cfg(mode, a.Do, a.Ho, a.Wo, rb);
-    if (ws && !ws_use_old()) {
+    if (ws) {
       if (rb == 32) return launch_ws2<T, 32, 32>(a, st);
       if (rb == 64) return launch_ws2<T, 64, 64>(a, st);
       if (rb == 128) return launch_ws2<T, 32, 128>(a, st);
     }
-    if (ws == 2 && rb == 32) return launch_ws<T, 8, 8, 8, 4, 64, 1>(a, st);
-    if (ws == 2) return launch_ws<T, 8, 8, 8, 4, 64, 2>(a, st);
-    if (ws == 1) return launch_ws<T, 4, 8, 8, 2, 128, 2>(a, st);
     if (small_tile(a.Do, a.Ho, a.Wo)) return launch_cfg<T, 4, 4, 8, 2, 2, 2, 1, false>(a, st);  // 128 vox x 64 ch
     if (a.CoutP <= 32) return launch_cfg<T, 4, 8, 8, 4, 1, 2, 1, false>(a, st);                  // 256 vox x 32 ch
     return launch_cfg<T, 4, 8, 8, 2, 2, 4, 1, false>(a, st);                                     // 256 vox x 64 ch
@@ -2200,7 +1836,6 @@ int launch_wgrad_t(WgradArgs a, float* dw, int sc_store, int lc_store, int accum
 
 int hdf_conv_stat_tiles(int mode, int Do, int Ho, int Wo, int row_bytes) {
   if (mode != 0) return 0;
-  if (ws_cfg(mode, Do, Ho, Wo, row_bytes) == 2 && ws_use_old()) return ceil_div(Do, 8) * ceil_div(Ho, 8) * ceil_div(Wo, 8);
   if (small_tile(Do, Ho, Wo)) return ceil_div(Do, 4) * ceil_div(Ho, 4) * ceil_div(Wo, 8);
   return ceil_div(Do, 4) * ceil_div(Ho, 8) * ceil_div(Wo, 8);
 }
