@@ -1720,20 +1720,24 @@ __global__ void pack_w_kernel(const float* __restrict__ src, T* __restrict__ dst
 struct PackBatch {
   PackJob j[HDF_MAX_PACK_JOBS];
 };
-// grid (blocks, jobs): job blockIdx.y, grid-stride over its 27*OP*IP elements
+// grid (blocks, jobs): job blockIdx.y, grid-stride over its OP*IP (out, in) pairs; a thread reads the pair's 27 taps
+// (both source layouts keep them contiguous: 108 bytes) and writes one element of each of the 27 tap planes, where
+// consecutive threads are consecutive `in` indices, i.e. coalesced
 template <typename T>
 __global__ void pack_batch_kernel(PackBatch b, const float* __restrict__ params, char* __restrict__ ws) {
   const PackJob& jb = b.j[blockIdx.y];
   const float* src = params + jb.src_off;
   T* dst = reinterpret_cast<T*>(ws + jb.dst_off);
-  const int64_t total = (int64_t)27 * jb.OP * jb.IP;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    int i = idx % jb.IP;
-    int o = (idx / jb.IP) % jb.OP;
-    int t = idx / ((int64_t)jb.IP * jb.OP);
-    float v = 0.f;
-    if (o < jb.O && i < jb.I) v = src[(int64_t)o * jb.so + (int64_t)i * jb.si + (jb.flip ? 26 - t : t)];
-    ST<T>::st(dst + idx, v);
+  const int64_t pairs = (int64_t)jb.OP * jb.IP;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < pairs; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int i = idx % jb.IP, o = idx / jb.IP;
+    const bool live = o < jb.O && i < jb.I;
+    const float* sp = src + (live ? (int64_t)o * jb.so + (int64_t)i * jb.si : 0);
+    float v[27];
+#pragma unroll
+    for (int t = 0; t < 27; t++) v[t] = sp[t];
+#pragma unroll
+    for (int t = 0; t < 27; t++) ST<T>::st(dst + (int64_t)t * pairs + idx, live ? (jb.flip ? v[26 - t] : v[t]) : 0.f);
   }
 }
 
@@ -1884,7 +1888,7 @@ int hdf_launch_pack_batch(int dtype, const float* params, char* ws, const PackJo
   if (njobs == 0) return HDF_OK;
   PackBatch b;
   for (int k = 0; k < njobs; k++) b.j[k] = jobs[k];
-  dim3 grid(256, njobs);
+  dim3 grid(64, njobs);
   if (dtype == HDF_BF16)
     hipLaunchKernelGGL(pack_batch_kernel<bf16_t>, grid, dim3(256), 0, st, b, params, ws);
   else
