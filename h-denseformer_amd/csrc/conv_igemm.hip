@@ -632,9 +632,11 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
   }
   auto eoff = [&](int i) { return eplane[i >> 2] + ((i & 3) + 4 * ((i >> 2) & 1)) * (int)a.out_pitch; };
   int pend_tile = -1;  // tile whose per-wave InstanceNorm partials wait in s_red for the next barrier
+  int sr_sel = 0, pend_sel = 0;  // s_red halves alternate per WRITE (a workgroup's consecutive tiles are 32 apart
+                                 // in raster order, so their linear index has one parity)
   auto flush_stats = [&]() {
     if (a.stat_partials && tid < 32) {
-      const float* sr = s_red + (pend_tile & 1) * 256;
+      const float* sr = s_red + pend_sel * 256;
       float t1 = 0.f, t2 = 0.f;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
@@ -711,11 +713,13 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
       s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 32, 64);
       if (h == 0) {
-        float* sr = s_red + (ET.tile & 1) * 256;
+        float* sr = s_red + sr_sel * 256;
         sr[(wave * 32 + r) * 2 + 0] = s1;
         sr[(wave * 32 + r) * 2 + 1] = s2;
       }
       pend_tile = ET.tile;
+      pend_sel = sr_sel;
+      sr_sel ^= 1;
     }
   };
 
@@ -809,10 +813,12 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
           if (g == (31 / EPG)) {  // last pending element done: per-wave partials -> s_red (both halves hold the sum)
             ds1 += __shfl_xor(ds1, 32, 64);
             ds2 += __shfl_xor(ds2, 32, 64);
-            float* sr = s_red + (PT.tile & 1) * 256;
+            float* sr = s_red + sr_sel * 256;
             sr[(wave * 32 + r) * 2 + 0] = ds1;
             sr[(wave * 32 + r) * 2 + 1] = ds2;
             pend_tile = PT.tile;
+            pend_sel = sr_sel;
+            sr_sel ^= 1;
           }
         }
         u32x4(&A)[4] = af[g & 1];
