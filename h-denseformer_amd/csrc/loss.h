@@ -16,5 +16,9 @@ int hdf_launch_dice_counts(int dtype, const void* logits, const float* target, i
                            unsigned long long* counts, hipStream_t st);
 int hdf_launch_confusion(int dtype, const void* logits, const float* target, int N, int C, int64_t V,
                          unsigned long long* conf, int accumulate, hipStream_t st);
+int hdf_launch_sw_accumulate(int dtype, const void* logits, int C, int pd, int ph, int pw, float* psum, float* cnt,
+                             int D, int H, int W, int z0, int y0, int x0, hipStream_t st);
+int hdf_launch_sw_finalize(const float* psum, const float* cnt, int C, int64_t V, uint8_t* label, hipStream_t st);
+int hdf_launch_onehot(const uint8_t* lab, float* oh, int N, int C, int64_t V, hipStream_t st);
 int hdf_launch_adam(float* p, const float* g, float* m, float* v, const uint8_t* decay, int64_t n, float lr, float b1,
                     float b2, float eps, float wd, int step, float gscale, hipStream_t st);

@@ -359,6 +359,106 @@ int hdf_launch_confusion(int dtype, const void* logits, const float* target, int
   return HDF_OK;
 }
 
+// ------------------------------------------------------------------------------ sliding-window inference tail
+namespace {
+constexpr int SW_MAXC = 8;
+// one thread per window voxel: softmax over classes (fp32, max-subtracted like F.softmax) and accumulate
+template <typename T>
+__global__ void sw_accumulate_kernel(const T* __restrict__ logits, int C, int pd, int ph, int pw,
+                                     float* __restrict__ psum, float* __restrict__ cnt, int D, int H, int W, int z0,
+                                     int y0, int x0) {
+  const int64_t pv = (int64_t)pd * ph * pw;
+  const int64_t V = (int64_t)D * H * W;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < pv; i += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % pw), y = (int)((i / pw) % ph), z = (int)(i / ((int64_t)pw * ph));
+    float v[SW_MAXC], mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < SW_MAXC; c++)
+      if (c < C) {
+        v[c] = ST<T>::ld(logits + c * pv + i);
+        mx = fmaxf(mx, v[c]);
+      }
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < SW_MAXC; c++)
+      if (c < C) {
+        v[c] = expf(v[c] - mx);
+        sum += v[c];
+      }
+    const float inv = 1.f / sum;
+    const int64_t o = ((int64_t)(z0 + z) * H + (y0 + y)) * W + (x0 + x);
+#pragma unroll
+    for (int c = 0; c < SW_MAXC; c++)
+      if (c < C) psum[c * V + o] += v[c] * inv;
+    cnt[o] += 1.f;
+  }
+}
+__global__ void sw_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ cnt, int C, int64_t V,
+                                   uint8_t* __restrict__ label) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (int64_t)gridDim.x * blockDim.x) {
+    const float n = cnt[i];
+    float best = -INFINITY;
+    int bi = 0;
+    if (n > 0.f) {
+      // argmax(softmax(p / n)): softmax is monotonic, so the vote is the first maximum of the mean probabilities
+#pragma unroll
+      for (int c = 0; c < SW_MAXC; c++)
+        if (c < C) {
+          const float m = psum[c * V + i] / n;
+          if (m > best) best = m, bi = c;
+        }
+    }
+    label[i] = (uint8_t)bi;
+  }
+}
+__global__ void onehot_kernel(const uint8_t* __restrict__ lab, float* __restrict__ oh, int C, int64_t V) {
+  const int n = blockIdx.y;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (int64_t)gridDim.x * blockDim.x) {
+    const int l = lab[(int64_t)n * V + i];
+    float* o = oh + (int64_t)n * C * V + i;
+    const bool fg = l >= 1 && l < C;
+    o[0] = fg ? 0.f : 1.f;
+    for (int c = 1; c < C; c++) o[(int64_t)c * V] = (l == c) ? 1.f : 0.f;
+  }
+}
+}  // namespace
+
+int hdf_launch_sw_accumulate(int dtype, const void* logits, int C, int pd, int ph, int pw, float* psum, float* cnt,
+                             int D, int H, int W, int z0, int y0, int x0, hipStream_t st) {
+  HDF_CHECK_ARG(C >= 1 && C <= SW_MAXC, "sw_accumulate: n_cls=%d (max %d)", C, SW_MAXC);
+  HDF_CHECK_ARG(z0 >= 0 && y0 >= 0 && x0 >= 0 && z0 + pd <= D && y0 + ph <= H && x0 + pw <= W,
+                "sw_accumulate: window (%d,%d,%d)+(%d,%d,%d) outside the %dx%dx%d volume", z0, y0, x0, pd, ph, pw, D, H,
+                W);
+  const int64_t pv = (int64_t)pd * ph * pw;
+  dim3 grid((unsigned)std::min<int64_t>(ceil_div64(pv, 256), 4096));
+  if (dtype == HDF_BF16)
+    hipLaunchKernelGGL(sw_accumulate_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)logits, C, pd, ph, pw, psum,
+                       cnt, D, H, W, z0, y0, x0);
+  else if (dtype == HDF_F32)
+    hipLaunchKernelGGL(sw_accumulate_kernel<float>, grid, dim3(256), 0, st, (const float*)logits, C, pd, ph, pw, psum,
+                       cnt, D, H, W, z0, y0, x0);
+  else {
+    hdf_set_error("sw_accumulate: unsupported dtype %d", dtype);
+    return HDF_ERR_UNSUPPORTED;
+  }
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+int hdf_launch_sw_finalize(const float* psum, const float* cnt, int C, int64_t V, uint8_t* label, hipStream_t st) {
+  HDF_CHECK_ARG(C >= 1 && C <= SW_MAXC, "sw_finalize: n_cls=%d (max %d)", C, SW_MAXC);
+  dim3 grid((unsigned)std::min<int64_t>(ceil_div64(V, 256), 8192));
+  hipLaunchKernelGGL(sw_finalize_kernel, grid, dim3(256), 0, st, psum, cnt, C, V, label);
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+int hdf_launch_onehot(const uint8_t* lab, float* oh, int N, int C, int64_t V, hipStream_t st) {
+  HDF_CHECK_ARG(C >= 2 && C <= 255 && N >= 1, "onehot: n_cls=%d batch=%d", C, N);
+  dim3 grid((unsigned)std::min<int64_t>(ceil_div64(V, 256), 4096), N);
+  hipLaunchKernelGGL(onehot_kernel, grid, dim3(256), 0, st, lab, oh, C, V);
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
 int hdf_launch_adam(float* p, const float* g, float* m, float* v, const uint8_t* decay, int64_t n, float lr, float b1,
                     float b2, float eps, float wd, int step, float gscale, hipStream_t st) {
   float bc1 = 1.f - powf(b1, (float)step);

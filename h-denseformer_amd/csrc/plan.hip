@@ -933,6 +933,22 @@ int hdf_confusion_matrix(int dtype, const void* logits, const float* target_oneh
   return hdf_launch_confusion(dtype, logits, target_onehot, batch, n_cls, voxels, (unsigned long long*)confusion,
                               accumulate, (hipStream_t)stream);
 }
+int hdf_sw_accumulate(int dtype, const void* logits, int n_cls, int pd, int ph, int pw, float* prob_sum, float* count,
+                      int D, int H, int W, int z0, int y0, int x0, hdf_stream stream) {
+  HDF_CHECK_ARG(logits && prob_sum && count, "sw_accumulate: null argument");
+  return hdf_launch_sw_accumulate(dtype, logits, n_cls, pd, ph, pw, prob_sum, count, D, H, W, z0, y0, x0,
+                                  (hipStream_t)stream);
+}
+int hdf_sw_finalize(const float* prob_sum, const float* count, int n_cls, int64_t voxels, uint8_t* label,
+                    hdf_stream stream) {
+  HDF_CHECK_ARG(prob_sum && count && label, "sw_finalize: null argument");
+  return hdf_launch_sw_finalize(prob_sum, count, n_cls, voxels, label, (hipStream_t)stream);
+}
+int hdf_onehot_from_labels(const uint8_t* labels, float* onehot, int batch, int n_cls, int64_t voxels,
+                           hdf_stream stream) {
+  HDF_CHECK_ARG(labels && onehot, "onehot_from_labels: null argument");
+  return hdf_launch_onehot(labels, onehot, batch, n_cls, voxels, (hipStream_t)stream);
+}
 int hdf_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* decay_mask,
                   int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                   float grad_scale, hdf_stream stream) {

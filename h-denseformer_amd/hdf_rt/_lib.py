@@ -33,6 +33,9 @@ _PROTOS = {
                                _vp]),
     "hdf_dice_counts": (_i, [_i, _vp, _vp, _i, _i, _i64, _vp, _vp]),
     "hdf_confusion_matrix": (_i, [_i, _vp, _vp, _i, _i, _i64, _vp, _i, _vp]),
+    "hdf_sw_accumulate": (_i, [_i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "hdf_sw_finalize": (_i, [_vp, _vp, _i, _i64, _vp, _vp]),
+    "hdf_onehot_from_labels": (_i, [_vp, _vp, _i, _i, _i64, _vp]),
     "hdf_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _vp]),
     "hdf_op_to_channels_last": (_i, [_i, _vp, _vp, _i, _i, _i, _i64, _vp]),
     "hdf_op_pack_weights": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i, _vp]),

@@ -77,6 +77,23 @@ int hdf_dice_counts(int dtype, const void* logits, const float* target_onehot, i
 int hdf_confusion_matrix(int dtype, const void* logits, const float* target_onehot, int batch, int n_cls,
                          int64_t voxels, uint64_t* confusion, int accumulate, hdf_stream stream);
 
+/* ---- sliding-window inference (trainer.py:488-593): the per-window tail of the loop and the final vote.
+ * hdf_sw_accumulate: softmax over classes of one window's full-resolution logits [n_cls][pd][ph][pw] (NCDHW, the
+ * model's out0 for batch 1), added into prob_sum[n_cls][D][H][W] at (z0,y0,x0); count[D][H][W] += 1
+ * (trainer.py:559-576; the reference keeps n_cls identical count planes).
+ * hdf_sw_finalize: label[v] = argmax_c softmax(prob_sum[c][v] / count[v]) (trainer.py:580-584), uint8, first
+ * maximum wins; voxels no window covered (count 0) give 0. */
+int hdf_sw_accumulate(int dtype, const void* logits, int n_cls, int pd, int ph, int pw, float* prob_sum, float* count,
+                      int D, int H, int W, int z0, int y0, int x0, hdf_stream stream);
+int hdf_sw_finalize(const float* prob_sum, const float* count, int n_cls, int64_t voxels, uint8_t* label,
+                    hdf_stream stream);
+
+/* ---- label staging (data_utils/data_loader.py:126-159, To_Tensor): uint8 class map [N][voxels] -> fp32 one-hot
+ * [N][n_cls][voxels]; channel z>=1 is (label == z), channel 0 is "no other class" (so values >= n_cls count as
+ * background).  Ships 1 byte per voxel over PCIe instead of 4*n_cls. */
+int hdf_onehot_from_labels(const uint8_t* labels, float* onehot, int batch, int n_cls, int64_t voxels,
+                           hdf_stream stream);
+
 /* ---- optimizer: torch.optim.Adam as configured by trainer.py:793-840 (L2 weight decay on the mask) ---- */
 int hdf_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* decay_mask,
                   int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,

@@ -312,3 +312,42 @@ def test_two_rank_data_parallel_on_one_gpu():
     for rec in recs:
         assert rec["grad_rel_err"] < 1e-5, rec
         assert rec["param_max_diff"] == 0.0, rec
+
+
+@pytest.mark.gpu
+def test_sliding_window_inference_vs_reference_golden():
+    """window loop of trainer.py:527-584 on the HIP path (fp32) vs the reference's own result."""
+    from hdf_rt.inference import cal_steps, sliding_window_predict
+    from models.HDenseFormer import HDenseFormer
+    import json
+    g = np.load(os.path.join(GOLDEN, "g8_sliding_window.npz"), allow_pickle=False)
+    for case in json.loads(str(g["steps_json"])):
+        assert cal_steps(tuple(case["size"]), tuple(case["patch"]), tuple(case["step"])) == case["steps"], case
+    in_ch, n_cls, nf, td = [int(v) for v in g["cfg"]]
+    patch = tuple(int(v) for v in g["patch"])
+    step = tuple(int(v) for v in g["step"])
+    size = tuple(int(v) for v in g["image_size"])
+    net = HDenseFormer(in_ch, n_cls, nf, image_size=patch, transformer_depth=td)
+    net.load_state_dict(orc.det_model(in_ch, n_cls, nf, patch, td))
+    net = net.cuda()
+    net.compute_dtype = "fp32"
+    image = detgen.det_input(1, in_ch, size, tag="sw")[0]
+    lab, mean = sliding_window_predict(net, image, patch, step, return_probabilities=True)
+    mean = mean.cpu().numpy()
+    err = np.abs(mean[:, ::2, ::2, ::2] - g["mean_s2"]).max() / np.abs(g["mean_s2"]).max()
+    assert err < 1e-3, err                      # mean class probabilities, tolerance of the fp32 logits gate
+    agree = (lab.cpu().numpy() == g["argmax"]).mean()
+    assert agree > 0.999, agree                 # votes differ only where two mean probabilities tie to ~1e-6
+    with pytest.raises(ValueError):
+        sliding_window_predict(net, image[:, :16], patch, step)
+
+
+@pytest.mark.gpu
+def test_onehot_from_labels_vs_reference_golden():
+    """To_Tensor one-hot (data_loader.py:146-151) expanded on the device from the uint8 map."""
+    from hdf_rt.inference import onehot_from_labels
+    g = np.load(os.path.join(GOLDEN, "g9_to_tensor.npz"), allow_pickle=False)
+    lab = torch.from_numpy(np.stack([g["label"], g["label"][::-1].copy()])).cuda()
+    out = onehot_from_labels(lab, int(g["n_cls"])).cpu().numpy()
+    assert np.array_equal(out[0], g["onehot"])
+    assert np.array_equal(out[1], g["onehot"][:, ::-1])

@@ -128,3 +128,33 @@ def test_state_dict_count_full_config():
     assert len(shapes) == 1420
     assert sum(int(np.prod(s)) for s in shapes.values()) == 15_430_000 or \
         abs(sum(int(np.prod(s)) for s in shapes.values()) - 15.43e6) < 0.01e6
+
+
+# ---------------------------------------------------------------- sliding window, label staging
+def test_g8_cal_steps_vs_reference():
+    import json
+    from oracle import sw_oracle
+    g = _load("g8_sliding_window")
+    for case in json.loads(str(g["steps_json"])):
+        assert sw_oracle.cal_steps(tuple(case["size"]), tuple(case["patch"]), tuple(case["step"])) == case["steps"], case
+
+
+def test_g8_sliding_window_vs_reference():
+    from oracle import sw_oracle
+    g = _load("g8_sliding_window")
+    in_ch, n_cls, nf, td = [int(v) for v in g["cfg"]]
+    patch = tuple(int(v) for v in g["patch"])
+    step = tuple(int(v) for v in g["step"])
+    size = tuple(int(v) for v in g["image_size"])
+    sd = orc.det_model(in_ch, n_cls, nf, patch, td)
+    image = detgen.det_input(1, in_ch, size, tag="sw")[0]
+    with torch.no_grad():
+        lab, mean = sw_oracle.sliding_window(lambda p: orc.forward(p, sd)[0], image, n_cls, patch, step)
+    assert _rel(mean[:, ::2, ::2, ::2], g["mean_s2"]) < 1e-4
+    assert (lab == g["argmax"]).mean() > 0.9999
+
+
+def test_g9_to_tensor_onehot_vs_reference():
+    from oracle import sw_oracle
+    g = _load("g9_to_tensor")
+    assert np.array_equal(sw_oracle.to_onehot(g["label"], int(g["n_cls"])), g["onehot"])
