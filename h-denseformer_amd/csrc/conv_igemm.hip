@@ -159,7 +159,63 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   const int64_t wtap_stride = (int64_t)a.CoutP * a.Cin * ESZ;
   const int chunk_elems_max = 64 / ESZ;
 
-  for (int c0 = 0; c0 < a.Cin; c0 += chunk_elems_max) {
+  bool done = false;
+  if constexpr (!CONVT && S == 1) {
+    // Stride-1 conv with whole 64-byte channel chunks: the 27 taps x 2 fragment steps of a chunk are unrolled and
+    // software-pipelined.  The weight fragments come straight from L2 (~500+ cycles): a register ring keeps RING
+    // steps of them in flight, across chunk boundaries too (the loads of the next chunk's first steps are issued
+    // before its box is staged); the A fragments of step s+1 are read from LDS under the MFMAs of step s.  The
+    // plain loop below waited for one L2 round trip per step, which at the low resolutions (one or two workgroups
+    // per CU, nothing to switch to) left the matrix pipe idle 70-90 % of the time.
+    if ((a.Cin * ESZ) % 64 == 0) {
+      constexpr int NS = 54;                       // fragment steps per chunk
+      constexpr int RING = (MB >= 4) ? 6 : 9;      // divides 54: the ring position is the same in every chunk
+      const int nchunk = a.Cin * ESZ / 64;
+      u32x4 bq[RING];
+      auto b_load = [&](int chunk, int s_) -> u32x4 {
+        const int tap = s_ >> 1, fs = s_ & 1;
+        const char* p = wrow + tap * wtap_stride + (int64_t)chunk * 64 + fs * 32;
+        return *reinterpret_cast<const u32x4*>(n_active ? p : reinterpret_cast<const char*>(a.w));
+      };
+      auto a_off = [&](int s_) {
+        const int tap = s_ >> 1, fs = s_ & 1;
+        return ((tap / 9 * BH + (tap / 3) % 3) * BW + tap % 3) * PITCH + h * 16 + fs * 32;
+      };
+#pragma unroll
+      for (int k = 0; k < RING; k++) bq[k] = b_load(0, k);
+      for (int chunk = 0; chunk < nchunk; chunk++) {
+        if (chunk > 0) __syncthreads();
+        stage_box<T, BD, BH, BW, 64, PITCH>(lds, reinterpret_cast<const T*>(a.in), a.in_pitch, a.Cin, n, a.Di, a.Hi,
+                                            a.Wi, oz, oy, ox, chunk * chunk_elems_max, 64, a.in_scale, a.in_shift,
+                                            a.in_relu);
+        __syncthreads();
+        u32x4 af[2][MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; mb++) af[0][mb] = *reinterpret_cast<const u32x4*>(lds + rowbase[mb] * PITCH + a_off(0));
+        const bool more = chunk + 1 < nchunk;
+#pragma unroll
+        for (int s_ = 0; s_ < NS; s_++) {
+          if (s_ + 1 < NS) {
+#pragma unroll
+            for (int mb = 0; mb < MB; mb++)
+              af[(s_ + 1) & 1][mb] = *reinterpret_cast<const u32x4*>(lds + rowbase[mb] * PITCH + a_off(s_ + 1));
+          }
+          const u32x4 bcur = bq[s_ % RING];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int mb = 0; mb < MB; mb++) Mma<T>::run(af[s_ & 1][mb], bcur, acc[mb]);
+          // refill the slot just consumed: RING steps ahead, in this chunk or the next one
+          if (s_ + RING < NS)
+            bq[s_ % RING] = b_load(chunk, s_ + RING);
+          else if (more)
+            bq[s_ % RING] = b_load(chunk + 1, s_ + RING - NS);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      done = true;
+    }
+  }
+  for (int c0 = 0; !done && c0 < a.Cin; c0 += chunk_elems_max) {
     const int chunk_elems = min(chunk_elems_max, a.Cin - c0);
     const int row_bytes = chunk_elems * ESZ;  // 64 or 32
     if (c0 > 0) __syncthreads();
@@ -247,17 +303,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Weights-stationary persistent variant of mode 0 for the high-resolution layers (Cin*sizeof(T) <= 128 B).
-//  * one workgroup per CU; the whole [27][32 cout][Cin] weight panel of its output-channel tile lives in LDS
-//    for the lifetime of the workgroup (XOR-swizzled 16-B chunks instead of padding: conflict-free ds_read_b128)
-//  * the workgroup walks a CONTIGUOUS range of spatial tiles (neighbouring halos come from the same XCD's L2)
-//  * the input box of the NEXT (tile, channel-chunk) is prefetched into registers while the MFMAs of the current
-//    one run; it is normalised/ReLU'd and written to LDS after the barrier that ends the current compute phase
-//  * fragment reads are software-pipelined three steps deep (one wave per SIMD: nothing else hides LDS latency)
-//  * an MFMA M-block is a 4(z) x 1(y) x 8(x) column of voxels and MFMA row -> voxel follows ws_row_to_zx, so the
-//    16 box rows touched by every ds_read_b128 lane group are distinct modulo 16 (80-byte pitch => no conflicts)
-//  * the epilogue goes through LDS: every lane stores whole 16-byte channel chunks of a voxel row
-
 // MFMA row (0..31) -> (dz in 0..3, x in 0..7).  ds_read_b128 services lanes {0-3,12-15,20-27} and {4-11,16-19,
 // 28-31} (and the same +32) as groups; group 1 gets z in {0,2}, group 2 z in {1,3}: box row = 100*z + 10*y + x
 // (BH = BW = 10) is then distinct mod 16 inside each group.
