@@ -160,8 +160,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   const int chunk_elems_max = 64 / ESZ;
 
   bool done = false;
-  if constexpr (!CONVT && S == 1) {
-    // Stride-1 conv with whole 64-byte channel chunks: the 27 taps x 2 fragment steps of a chunk are unrolled and
+  if constexpr (!CONVT) {
+    // Conv (stride 1 or the stride-2 gather) with whole 64-byte channel chunks: the 27 taps x 2 fragment steps of a chunk are unrolled and
     // software-pipelined.  The weight fragments come straight from L2 (~500+ cycles): a register ring keeps RING
     // steps of them in flight, across chunk boundaries too (the loads of the next chunk's first steps are issued
     // before its box is staged); the A fragments of step s+1 are read from LDS under the MFMAs of step s.  The
