@@ -1110,7 +1110,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   constexpr int MT = TD * TH * TW;
   constexpr int BD = S * (TD - 1) + 3, BH = S * (TH - 1) + 3, BW = S * (TW - 1) + 3;
   constexpr int ROWB = 32 * sizeof(T);  // 32 channels per LDS row
-  constexpr int LP = ROWB + 16;
+  // LDS row pitch.  bf16 transposed reads touch 4 voxel rows x 16 dwords per half-wave: with stride 2 those rows are
+  // 2 box rows apart, and a 96-byte pitch (24 dwords: 0, 48, 32, 16 mod 64) tiles the 64 banks exactly; 80 bytes
+  // overlapped the 1st and 4th row (2-way conflicts).  (Stride 1 bf16 runs conv_wgrad2_kernel with 64-byte rows.)
+  constexpr int LP = (sizeof(T) == 2 && S == 2) ? ROWB + 32 : ROWB + 16;
   constexpr int TAPS_PER_WAVE = 7;
   __shared__ __attribute__((aligned(16))) char lds[(MT + BD * BH * BW) * LP];
   char* s_lds = lds;
