@@ -497,7 +497,12 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ in,
 }
 
 // grid (blocks, N); loops channel chunks of 32 outermost so the (o,c) accumulators stay scalar
-template <typename T>
+// Streaming form: thread = (voxel lane, 8-channel chunk), so a wave reads whole contiguous voxel rows; the weight-
+// gradient outer products accumulate in registers over the thread's voxels (ncls x 8 accumulators) and are reduced
+// across the block ONCE at the end (the first version rebuilt a 256-voxel LDS tile and ran a 256-deep serial LDS
+// reduction per tile: 3x the HBM time).  grid (blocks, N); C <= 256 (cols = C/8 <= 32).
+constexpr int HEAD_BWD_VOX = 2048;  // voxels per workgroup
+template <typename T, int MC>       // MC: class slots held in registers (4 or 8)
 __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ dlogits, const T* __restrict__ in,
                                                        int64_t in_pitch, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const float* __restrict__ w,
@@ -505,78 +510,102 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ dlo
                                                        float* __restrict__ dw, float* __restrict__ db, int N, int C,
                                                        int ncls, int64_t vox) {
   constexpr int EPC = ST<T>::EPC;
-  __shared__ float xs[256][33];
-  __shared__ float dls[256][HEAD_MAXCLS];
-  __shared__ float sw[HEAD_MAXCLS][32];
-  __shared__ float ssc[32], ssh[32];
+  // LDS: first the block's logit gradients [voxel][MC] (loaded class plane by class plane, coalesced, once), then
+  // reused as [vlanes][C + 1][MC] for the final reduction
+  extern __shared__ float red[];
   const int n = blockIdx.y;
-  const int po = threadIdx.x >> 5, pc = threadIdx.x & 31;  // (o,c) pair owned for the dW reduction
-  for (int cb = 0; cb < C; cb += 32) {
-    const int cw = min(32, C - cb);
-    __syncthreads();
-    if (threadIdx.x < HEAD_MAXCLS * 32) {
-      int o = threadIdx.x >> 5, c = threadIdx.x & 31;
-      sw[o][c] = (o < ncls && c < cw) ? w[o * C + cb + c] : 0.f;
-    }
-    if (threadIdx.x < 32) {
-      const bool ok = scale && (int)threadIdx.x < cw;
-      ssc[threadIdx.x] = ok ? scale[(int64_t)n * C + cb + threadIdx.x] : 1.f;
-      ssh[threadIdx.x] = ok ? shift[(int64_t)n * C + cb + threadIdx.x] : 0.f;
-    }
-    float accw = 0.f, accb = 0.f;
-    for (int64_t v0 = (int64_t)blockIdx.x * 256; v0 < vox; v0 += (int64_t)gridDim.x * 256) {
-      __syncthreads();
-      int64_t v = v0 + threadIdx.x;
-      float dl[HEAD_MAXCLS];
+  const int cols = C / EPC;
+  const int vlanes = 256 / cols;
+  const int col = threadIdx.x % cols, vl = threadIdx.x / cols;
+  const int c0 = col * EPC;
+  float sc[EPC], sh[EPC], wv[MC][EPC], accw[MC][EPC], accb[MC];
 #pragma unroll
-      for (int o = 0; o < HEAD_MAXCLS; o++) {
-        // unconditional clamped load + select (never branch around a load)
-        float lv = ST<T>::ld(dlogits + ((int64_t)n * ncls + min(o, ncls - 1)) * vox + min(v, vox - 1));
-        dl[o] = (o < ncls && v < vox) ? lv : 0.f;
-        dls[threadIdx.x][o] = dl[o];
+  for (int e = 0; e < EPC; e++) {
+    sc[e] = scale ? scale[(int64_t)n * C + c0 + e] : 1.f;
+    sh[e] = scale ? shift[(int64_t)n * C + c0 + e] : 0.f;
+  }
+#pragma unroll
+  for (int o = 0; o < MC; o++) {
+    accb[o] = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPC; e++) {
+      wv[o][e] = (o < ncls) ? w[min(o, ncls - 1) * C + c0 + e] : 0.f;
+      accw[o][e] = 0.f;
+    }
+  }
+  const int64_t vb = (int64_t)blockIdx.x * HEAD_BWD_VOX, ve = min(vox, vb + HEAD_BWD_VOX);
+  for (int o = 0; o < MC; o++) {
+    const T* src = dlogits + ((int64_t)n * ncls + min(o, ncls - 1)) * vox;
+#pragma unroll
+    for (int k = 0; k < HEAD_BWD_VOX / 256; k++) {
+      const int lv = threadIdx.x + 256 * k;
+      const float v = ST<T>::ld(src + min(vb + lv, vox - 1));
+      red[lv * MC + o] = (o < ncls && vb + lv < vox) ? v : 0.f;
+    }
+  }
+  __syncthreads();
+  if (vl < vlanes) {
+    constexpr int U = 4;
+    for (int64_t v0 = vb + vl; v0 < ve; v0 += (int64_t)U * vlanes) {
+      float f[U][EPC], g[U][EPC], dl[U][MC];
+      int64_t row[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {  // clamped: never branch around a load; the tail is masked below
+        const int64_t v = min(v0 + (int64_t)u * vlanes, ve - 1);
+        row[u] = (int64_t)n * vox + v;
+        load_chunk<T>(in + row[u] * in_pitch + c0, f[u]);
+        if (accumulate_dx) load_chunk<T>(dx + row[u] * dx_pitch + c0, g[u]);
+#pragma unroll
+        for (int o = 0; o < MC; o++) dl[u][o] = red[(int)(v - vb) * MC + o];
       }
-      if (v < vox) {
-        const T* row = in + ((int64_t)n * vox + v) * in_pitch + cb;
-        T* drow = dx + ((int64_t)n * vox + v) * dx_pitch + cb;
-        for (int c0 = 0; c0 < cw; c0 += EPC) {
-          float f[EPC], g[EPC];
-          load_chunk<T>(row + c0, f);
-          if (accumulate_dx)
-            load_chunk<T>(drow + c0, g);
-          else {
 #pragma unroll
-            for (int e = 0; e < EPC; e++) g[e] = 0.f;
+      for (int u = 0; u < U; u++) {
+        const bool live = v0 + (int64_t)u * vlanes < ve;
+#pragma unroll
+        for (int o = 0; o < MC; o++) dl[u][o] = live ? dl[u][o] : 0.f;
+        float d[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; e++) {
+          float x = f[u][e];
+          if (scale) x = fmaxf(x * sc[e] + sh[e], 0.f);
+          float t = accumulate_dx ? g[u][e] : 0.f;
+#pragma unroll
+          for (int o = 0; o < MC; o++) {
+            t += dl[u][o] * wv[o][e];
+            accw[o][e] += dl[u][o] * x;
           }
-#pragma unroll
-          for (int e = 0; e < EPC; e++) {
-            float x = f[e];
-            if (scale) x = fmaxf(x * ssc[c0 + e] + ssh[c0 + e], 0.f);
-            xs[threadIdx.x][c0 + e] = x;
-            float d = 0.f;
-#pragma unroll
-            for (int o = 0; o < HEAD_MAXCLS; o++) d += dl[o] * sw[o][c0 + e];
-            // relu of the producing norm is handled by the IN backward of that layer (dx is d/d activation)
-            g[e] += d;
-          }
-          store_chunk<T>(drow + c0, g);
+          // relu of the producing norm is handled by the IN backward of that layer (dx is d/d activation)
+          d[e] = t;
         }
-      } else {
-        for (int c = 0; c < 32; c++) xs[threadIdx.x][c] = 0.f;
-      }
-      __syncthreads();
-      if (po < ncls && pc < cw) {
-        float s = 0.f;
-        for (int k = 0; k < 256; k++) s += dls[k][po] * xs[k][pc];
-        accw += s;
-      }
-      if (cb == 0 && threadIdx.x < ncls) {
-        float s = 0.f;
-        for (int k = 0; k < 256; k++) s += dls[k][threadIdx.x];
-        accb += s;
+        if (live) store_chunk<T>(dx + row[u] * dx_pitch + c0, d);
+        if (col == 0) {
+#pragma unroll
+          for (int o = 0; o < MC; o++) accb[o] += dl[u][o];
+        }
       }
     }
-    if (po < ncls && pc < cw) atomicAdd(dw + po * C + cb + pc, accw);
-    if (cb == 0 && threadIdx.x < ncls) atomicAdd(db + threadIdx.x, accb);
+  }
+  // ---- block reduction over the voxel lanes, then one atomic per (class, channel) and block
+  __syncthreads();  // everybody is done with the logit gradients: the region is reused
+  const int ld = (C + 1) * MC;
+  if (vl < vlanes) {
+#pragma unroll
+    for (int o = 0; o < MC; o++) {
+#pragma unroll
+      for (int e = 0; e < EPC; e++) red[vl * ld + (c0 + e) * MC + o] = accw[o][e];
+      if (col == 0) red[vl * ld + C * MC + o] = accb[o];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < (C + 1) * MC; i += 256) {
+    const int c = i / MC, o = i - c * MC;
+    if (o >= ncls) continue;
+    float t = 0.f;
+    for (int k = 0; k < vlanes; k++) t += red[k * ld + i];
+    if (c < C)
+      atomicAdd(dw + o * C + c, t);
+    else
+      atomicAdd(db + o, t);
   }
 }
 
@@ -788,6 +817,17 @@ inline unsigned grid_for(int64_t total, int block = 256) {
 
 }  // namespace
 
+// dynamic LDS above 64 KiB has to be allowed per kernel
+static int allow_big_lds(const void* kern, size_t bytes) {
+  if (bytes <= 64 * 1024) return HDF_OK;
+  hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) {
+    hdf_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: %s", hipGetErrorString(e));
+    return HDF_ERR_HIP;
+  }
+  return HDF_OK;
+}
+
 #define DISPATCH_T(dtype, ...)                          \
   do {                                                  \
     if ((dtype) == HDF_BF16) {                          \
@@ -906,10 +946,22 @@ int hdf_launch_head_bwd(int dtype, const void* dlogits, const void* in, int64_t 
                         const float* shift, const float* w, void* dx, int64_t dx_pitch, int accumulate_dx, float* dw,
                         float* db, int N, int C, int ncls, int64_t vox, hipStream_t st) {
   HDF_CHECK_ARG(ncls <= HEAD_MAXCLS, "head: n_cls=%d > %d", ncls, HEAD_MAXCLS);
-  unsigned gx = (unsigned)std::min<int64_t>(ceil_div64(vox, 256), 512);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(head_bwd_kernel<T>, dim3(gx, N), dim3(256), 0, st, (const T*)dlogits,
-                                       (const T*)in, in_pitch, scale, shift, w, (T*)dx, dx_pitch, accumulate_dx, dw, db,
-                                       N, C, ncls, vox));
+  HDF_CHECK_ARG(C % 16 == 0 && C <= 256, "head_bwd: C=%d", C);
+  const unsigned gx = (unsigned)ceil_div64(vox, HEAD_BWD_VOX);
+  DISPATCH_T(dtype, {
+    const int cols = C / ST<T>::EPC, vlanes = 256 / cols;
+    const int mc = ncls <= 4 ? 4 : 8;
+    const size_t shm = std::max((size_t)vlanes * (C + 1) * mc, (size_t)HEAD_BWD_VOX * mc) * sizeof(float);
+    if (mc == 4) {
+      HDF_TRY(allow_big_lds((const void*)head_bwd_kernel<T, 4>, shm));
+      hipLaunchKernelGGL((head_bwd_kernel<T, 4>), dim3(gx, N), dim3(256), shm, st, (const T*)dlogits, (const T*)in,
+                         in_pitch, scale, shift, w, (T*)dx, dx_pitch, accumulate_dx, dw, db, N, C, ncls, vox);
+    } else {
+      HDF_TRY(allow_big_lds((const void*)head_bwd_kernel<T, 8>, shm));
+      hipLaunchKernelGGL((head_bwd_kernel<T, 8>), dim3(gx, N), dim3(256), shm, st, (const T*)dlogits, (const T*)in,
+                         in_pitch, scale, shift, w, (T*)dx, dx_pitch, accumulate_dx, dw, db, N, C, ncls, vox);
+    }
+  });
   HDF_LAUNCH_CHECK();
   return HDF_OK;
 }
