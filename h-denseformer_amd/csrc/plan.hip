@@ -816,7 +816,7 @@ int hdf_forward(hdf_plan* p, const float* x, const float* params, void* workspac
 int hdf_backward(hdf_plan* p, const float* x, const float* params, void* workspace, int64_t workspace_bytes,
                  const void* dout0, const void* dout1, const void* dout2, const void* dout3, float* grads, int batch,
                  hdf_stream stream) {
-  return hdf_backward_stages(p, x, params, workspace, workspace_bytes, dout0, dout1, dout2, dout3, grads, batch, 3,
+  return hdf_backward_stages(p, x, params, workspace, workspace_bytes, dout0, dout1, dout2, dout3, grads, batch, 7,
                              stream);
 }
 
@@ -876,7 +876,7 @@ int hdf_backward_stages(hdf_plan* p, const float* x, const float* params, void* 
   }
 
   }  // stage 1: every gradient of the encoder / decoder / head parameters is final here
-  if (!(stages & 2)) return HDF_OK;
+  if (stages & 2) {
 
   // ---- UpConv chain: at3 <- up3 <- at2 <- up2 <- at1 <- up1 <- attnout <- deep_conv <- attnall
   for (int k = 2; k >= 0; k--) {
@@ -901,7 +901,8 @@ int hdf_backward_stages(hdf_plan* p, const float* x, const float* params, void* 
     HDF_TRY(in_backward(e, c, p->dUa[0], p->dUy[0]));
     HDF_TRY(conv_backward(e, c, p->dUy[0], p->attnall, none, &p->dAttnall, 0));
   }
-  HDF_TRY(transformer_backward(e, x));
+  }  // stage 2: deep_conv / up1..3 gradients are final
+  if (stages & 4) HDF_TRY(transformer_backward(e, x));
   return HDF_OK;
 }
 

@@ -1,9 +1,10 @@
 """Data-parallel training, one process per GPU, RCCL over xGMI via torch.distributed (backend "nccl" on
 ROCm; "gloo" for the CPU tests).  Replaces the reference's single-process nn.DataParallel
 (trainer.py:228-229): the batch is sharded across ranks, every rank owns a full replica, and the only
-exchange is ONE gradient all-reduce per step over the module's flat fp32 gradient buffer, split in two
-buckets that follow the two backward stages so the first (encoder/decoder/heads, ~2/3 of the bytes) is
-in flight on a side stream while the transformer branches are still back-propagating.
+exchange is ONE gradient all-reduce per step over the module's flat fp32 gradient buffer, split in three
+buckets that follow the three backward stages (encoder/decoder/heads 26 MB, UpConv chain 19 MB, transformer
+branches 17 MB at n_filters=32): a bucket is in flight on a side stream while the next stage back-propagates, so only
+the last one is exposed.
 
 Loss terms are batch means (dice_loss.py:41, CrossEntropyLoss 'mean'), so with equal per-rank batches
 the global gradient is the mean of the rank gradients."""
@@ -16,12 +17,14 @@ def flat_allreduce_mean(flat, world, group=None):
     flat.div_(world)
 
 
-def bucket_bounds(table, split_name="block_1_1_left.conv.weight"):
-    """(lo, hi) float ranges of the two gradient buckets: [stage-2 params | stage-1 params]."""
-    split = next(off for (name, off, _n, _s) in table if name == split_name)
+def bucket_bounds(table, chain_name="deep_conv.double_conv.0.weight", unet_name="block_1_1_left.conv.weight"):
+    """(lo, hi) float ranges of the three gradient buckets in state_dict order:
+    [transformer branches | UpConv chain | encoder/decoder/heads]; returned as (stage1, stage2, stage3) ranges."""
+    chain = next(off for (name, off, _n, _s) in table if name == chain_name)
+    unet = next(off for (name, off, _n, _s) in table if name == unet_name)
     end = max(off + n for (_name, off, n, _s) in table)
     end = (end + 15) // 16 * 16
-    return (0, split), (split, end)
+    return (unet, end), (chain, unet), (0, chain)
 
 
 class GradSync:
@@ -35,11 +38,11 @@ class GradSync:
         flat = model.flat_parameters()
         dist.broadcast(flat, src=0, group=group)          # replicas start identical (trainer seeds after init)
         from . import _lib
-        self.b2, self.b1 = bucket_bounds(model._plan(_lib.F32).table)
+        self.buckets = bucket_bounds(model._plan(_lib.F32).table)   # index = stage - 1
 
     def __call__(self, stage):
         g = self.model.flat_grads()
-        lo, hi = self.b1 if stage == 1 else self.b2
+        lo, hi = self.buckets[stage - 1]
         hi = min(hi, g.numel())
         chunk = g[lo:hi]
         if self.comm is None:

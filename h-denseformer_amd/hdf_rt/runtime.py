@@ -84,7 +84,7 @@ class Runtime:
         self.gen += 1
         return outs
 
-    def backward(self, x, flat_params, douts, flat_grads, stages=3):
+    def backward(self, x, flat_params, douts, flat_grads, stages=7):
         b = x.shape[0]
         check(lib().hdf_backward_stages(self.plan.h, ptr(x), ptr(flat_params), ptr(self.ws), self.ws.numel(),
                                         ptr(douts[0]), ptr(douts[1]), ptr(douts[2]), ptr(douts[3]), ptr(flat_grads),

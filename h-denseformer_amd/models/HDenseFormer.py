@@ -248,17 +248,20 @@ class HDenseFormer(nn.Module):
                     if p.grad is not None:
                         prev[off: off + numel].view(shape).copy_(p.grad)
         if self.grad_hook is None or prev is not None:
-            rt.backward(x, self._flat, douts, gflat, stages=3)
+            rt.backward(x, self._flat, douts, gflat, stages=7)
             if prev is not None:
                 gflat.add_(prev)
             if self.grad_hook is not None:           # accumulated gradients: reduce after the add, no overlap
-                self.grad_hook(1)
-                self.grad_hook(2)
+                for stage in (1, 2, 3):
+                    self.grad_hook(stage)
         else:
-            rt.backward(x, self._flat, douts, gflat, stages=1)
-            self.grad_hook(1)                        # bucket 1 is final: its all-reduce overlaps stage 2
-            rt.backward(x, self._flat, douts, gflat, stages=2)
+            # each stage's parameter gradients are final when it returns: their all-reduce overlaps the next stage
+            rt.backward(x, self._flat, douts, gflat, stages=1)      # decoder / encoder / heads
+            self.grad_hook(1)
+            rt.backward(x, self._flat, douts, gflat, stages=2)      # UpConv chain
             self.grad_hook(2)
+            rt.backward(x, self._flat, douts, gflat, stages=4)      # transformer branches
+            self.grad_hook(3)
         for p, v in zip(params, self._grad_views):
             if p.requires_grad:
                 p.grad = v

@@ -52,9 +52,11 @@ int hdf_backward(hdf_plan* p, const float* x, const float* params, void* workspa
                  const void* dout0, const void* dout1, const void* dout2, const void* dout3, float* grads, int batch,
                  hdf_stream stream);
 
-/* the same in two stages so a caller can overlap the gradient all-reduce with the rest of backward:
+/* the same in stages so a caller can overlap the gradient all-reduce with the rest of backward (a stage needs the
+ * earlier ones to have run):
  * stages bit 0: zero grads + decoder/encoder/heads (their parameter gradients are final afterwards);
- * stages bit 1: UpConv chain + transformer branches.  Replaces nn.DataParallel's reduce (trainer.py:228-229). */
+ * stages bit 1: UpConv chain (deep_conv, up1..3);
+ * stages bit 2: transformer branches.  7 = everything.  Replaces nn.DataParallel's reduce (trainer.py:228-229). */
 int hdf_backward_stages(hdf_plan* p, const float* x, const float* params, void* workspace, int64_t workspace_bytes,
                         const void* dout0, const void* dout1, const void* dout2, const void* dout3, float* grads,
                         int batch, int stages, hdf_stream stream);

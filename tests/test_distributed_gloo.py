@@ -47,17 +47,20 @@ def _worker_gradsync(rank, world, port, ret):
     # views still alias the flat buffer after the broadcast
     p0 = next(net.parameters())
     ok_alias = p0.data_ptr() == after.data_ptr()
-    # two-bucket all-reduce: every element ends up as the mean over ranks
+    # three-bucket all-reduce (one per backward stage): every element ends up as the mean over ranks
     g = net.flat_grads()
     g.copy_(torch.arange(g.numel(), dtype=torch.float32) % 97 + 1000.0 * rank)
     expect = torch.arange(g.numel(), dtype=torch.float32) % 97 + 1000.0 * (world - 1) / 2.0
+    (lo1, hi1), (lo2, hi2), (lo3, hi3) = bucket_bounds(net._plan(_lib.F32).table)
     sync(1)
-    (lo2, hi2), (lo1, hi1) = bucket_bounds(net._plan(_lib.F32).table)
-    part_done = torch.allclose(g[lo1:hi1], expect[lo1:hi1]) and not torch.allclose(g[lo2:hi2], expect[lo2:hi2])
+    part_done = torch.allclose(g[lo1:hi1], expect[lo1:hi1]) and not torch.allclose(g[lo2:hi2], expect[lo2:hi2]) \
+        and not torch.allclose(g[lo3:hi3], expect[lo3:hi3])
     sync(2)
+    part_done = part_done and torch.allclose(g[lo2:hi2], expect[lo2:hi2]) and not torch.allclose(g[lo3:hi3], expect[lo3:hi3])
+    sync(3)
     sync.wait()
     ok_mean = torch.allclose(g, expect)
-    covers = lo2 == 0 and hi2 == lo1 and hi1 >= g.numel()
+    covers = lo3 == 0 and hi3 == lo2 and hi2 == lo1 and hi1 >= g.numel() and lo3 < hi3 < hi2 < hi1
     ret[rank] = bool(ok_bcast and ok_alias and part_done and ok_mean and covers)
     dist.destroy_process_group()
 
