@@ -23,7 +23,7 @@ def _mk(shape, seed):
 @pytest.mark.parametrize("cin,cout,size,n", [(16, 16, (8, 8, 8), 1), (32, 32, (12, 16, 24), 2),
                                             (64, 32, (32, 32, 32), 1), (32, 64, (36, 36, 40), 1),
                                             (128, 96, (6, 10, 9), 2),
-                                            # >= 48^3: the weights-stationary persistent kernel (conv_ws_kernel)
+                                            # >= 48^3: the weights-stationary persistent kernel (conv_ws2_kernel)
                                             (16, 32, (48, 48, 48), 1), (32, 32, (48, 56, 64), 2),
                                             (64, 32, (48, 48, 50), 1), (32, 64, (52, 48, 48), 1),
                                             (16, 48, (49, 51, 53), 1)])
@@ -40,6 +40,22 @@ def test_conv3d_s1(dtype, cin, cout, size, n):
     s = part.view(n, tiles, -1, 2).sum(1).cpu()[:, :cout]
     assert rel_err(s[..., 0], ref.sum((2, 3, 4))) < 5e-3 + TOL[dtype]
     assert rel_err(s[..., 1], (ref * ref).sum((2, 3, 4))) < 5e-3 + TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("cin,cout,size,n", [(32, 32, (8, 8, 16), 2), (32, 64, (48, 48, 52), 3), (64, 32, (52, 48, 48), 1),
+                                            (16, 48, (48, 50, 48), 1)])
+def test_conv3d_accumulate_into_existing_gradient(dtype, cin, cout, size, n):
+    """out += conv(x): the dgrad of the UpConv chain adds into a skip gradient (plan.hip conv_backward, accumulate=1).
+    >= 48^3 runs the persistent kernel's non-deferred epilogue (batch 3: the tile list crosses samples)."""
+    x, w = _mk((n, cin) + size, 11), _mk((cout, cin, 3, 3, 3), 12) * (cin * 27) ** -0.5
+    base = _mk((n, cout) + size, 13)
+    ref = rnd(base, dtype) + F.conv3d(rnd(x, dtype), rnd(w, dtype), None, padding=1)
+    wp = pack_w(w, dtype, cout, cin, rup(cout, 32), cin, cin * 27, 27, 0)
+    out = to_cl(base, dtype).contiguous()
+    conv3d(dtype, 0, to_cl(x, dtype), cin, wp, cout, out=out, out_pitch=cout, accumulate=1)
+    torch.cuda.synchronize()
+    assert rel_err(from_cl(out), ref) < TOL[dtype] * 1.5
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
