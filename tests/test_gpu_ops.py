@@ -122,7 +122,9 @@ def _wgrad(dtype, stride, s_cl, sc, l_cl, lc, dims, sc_store, lc_store):
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("cin,cout,size,n", [(16, 16, (8, 8, 8), 1), (32, 32, (12, 16, 24), 2),
-                                            (64, 48, (9, 7, 10), 2)])
+                                            (64, 48, (9, 7, 10), 2),
+                                            # 256+ tiles: the interior / border passes and the XCD-interleaved split
+                                            (32, 32, (32, 40, 48), 2), (64, 32, (21, 48, 50), 3)])
 def test_conv3d_wgrad(dtype, cin, cout, size, n):
     x, dy = _mk((n, cin) + size, 13), _mk((n, cout) + size, 14)
     w = torch.zeros(cout, cin, 3, 3, 3, requires_grad=True)
