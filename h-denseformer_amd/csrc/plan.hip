@@ -1023,6 +1023,26 @@ int hdf_op_in_finalize(const float* partials, int N, int tiles, int C, int CP, i
   return hdf_launch_in_finalize(partials, N, tiles, C, CP, voxels, gamma, beta, eps, mean, rstd, scale, shift,
                                 (hipStream_t)stream);
 }
+int64_t hdf_op_in_bwd_workspace_floats(int N, int C, int64_t voxels) {
+  return (int64_t)N * hdf_in_bwd_blocks(voxels) * C * 2 + (int64_t)3 * N * C;
+}
+int hdf_op_in_bwd(int dtype, const void* da, int64_t da_pitch, const void* y, int64_t y_pitch, const float* scale,
+                  const float* shift, const float* mean, const float* rstd, const float* gamma, void* dy,
+                  int64_t dy_pitch, float* dgamma, float* dbeta, int N, int C, int64_t voxels, float* workspace,
+                  hdf_stream stream) {
+  HDF_CHECK_ARG(da && y && scale && shift && mean && rstd && dy && workspace, "in_bwd: null argument");
+  const int blocks = hdf_in_bwd_blocks(voxels);
+  float* partials = workspace;
+  float* k1 = workspace + (int64_t)N * blocks * C * 2;
+  float* ka = k1 + (int64_t)N * C;
+  float* kb = ka + (int64_t)N * C;
+  hipStream_t st = (hipStream_t)stream;
+  HDF_TRY(hdf_launch_in_bwd_reduce(dtype, da, da_pitch, y, y_pitch, scale, shift, mean, rstd, partials, blocks, N, C,
+                                   voxels, st));
+  HDF_TRY(hdf_launch_in_bwd_finalize(partials, blocks, N, C, voxels, gamma, rstd, k1, ka, kb, dgamma, dbeta, st));
+  return hdf_launch_in_bwd_apply(dtype, da, da_pitch, y, y_pitch, scale, shift, mean, rstd, k1, ka, kb, dy, dy_pitch, N,
+                                 C, voxels, st);
+}
 int hdf_op_norm_relu_add(int dtype, const void* y, int64_t y_pitch, const float* scale, const float* shift,
                          const void* skip, int64_t skip_pitch, void* out, int64_t out_pitch, int N, int C,
                          int64_t voxels, hdf_stream stream) {

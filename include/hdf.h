@@ -125,6 +125,13 @@ int hdf_op_conv3d_wgrad(int dtype, int stride, const void* sm, int64_t sm_pitch,
 int hdf_op_in_finalize(const float* partials, int N, int tiles, int C, int CP, int64_t voxels, const float* gamma,
                        const float* beta, float eps, float* mean, float* rstd, float* scale, float* shift,
                        hdf_stream stream);
+/* InstanceNorm3d(+ReLU) backward of one layer (HDenseFormer.py:152-158): da = d/d(relu(IN(y))) -> dy = d/dy, plus
+ * dgamma / dbeta (accumulated; may be null).  workspace: hdf_op_in_bwd_workspace_floats(N, C, voxels) floats. */
+int64_t hdf_op_in_bwd_workspace_floats(int N, int C, int64_t voxels);
+int hdf_op_in_bwd(int dtype, const void* da, int64_t da_pitch, const void* y, int64_t y_pitch, const float* scale,
+                  const float* shift, const float* mean, const float* rstd, const float* gamma, void* dy,
+                  int64_t dy_pitch, float* dgamma, float* dbeta, int N, int C, int64_t voxels, float* workspace,
+                  hdf_stream stream);
 int hdf_op_norm_relu_add(int dtype, const void* y, int64_t y_pitch, const float* scale, const float* shift,
                          const void* skip, int64_t skip_pitch, void* out, int64_t out_pitch, int N, int C,
                          int64_t voxels, hdf_stream stream);

@@ -191,3 +191,32 @@ def test_pool_upsample(dtype):
     torch.cuda.synchronize()
     assert rel_err(from_cl(up), ref.detach()) < TOL[dtype]
     assert rel_err(from_cl(dlo), xa.grad) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("n,c,size", [(2, 32, (8, 12, 16)), (1, 64, (20, 16, 24)), (2, 16, (32, 32, 36))])
+def test_instance_norm_relu_backward(dtype, n, c, size):
+    """hdf_op_in_bwd (reduce + finalize + apply) vs autograd of relu(InstanceNorm3d(affine)(y)) (HDenseFormer.py:152-158)."""
+    y = rnd(_mk((n, c) + size, 21), dtype).requires_grad_(True)
+    gamma, beta = (_mk((c,), 22) * 0.3 + 1.0).requires_grad_(True), (_mk((c,), 23) * 0.2).requires_grad_(True)
+    da = rnd(_mk((n, c) + size, 24), dtype)
+    out = torch.relu(F.instance_norm(y, weight=gamma, bias=beta, eps=1e-5))
+    out.backward(da)
+    vox = size[0] * size[1] * size[2]
+    yd = y.detach()
+    mean = yd.mean((2, 3, 4))
+    rstd = (yd.var((2, 3, 4), unbiased=False) + 1e-5).rsqrt()
+    scale = (gamma.detach()[None] * rstd).contiguous()
+    shift = (beta.detach()[None] - mean * scale).contiguous()
+    dy = torch.empty((n,) + size + (c,), dtype=to_cl(yd, dtype).dtype, device=DEV)
+    dg, db = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
+    ws = torch.empty(lib().hdf_op_in_bwd_workspace_floats(n, c, vox), device=DEV)
+    dev = [t.to(DEV).contiguous() for t in (scale, shift, mean, rstd, gamma.detach())]
+    da_cl, y_cl = to_cl(da, dtype), to_cl(yd, dtype)          # keep the device tensors alive across the call
+    check(lib().hdf_op_in_bwd(dtype, ptr(da_cl), c, ptr(y_cl), c, ptr(dev[0]), ptr(dev[1]),
+                              ptr(dev[2]), ptr(dev[3]), ptr(dev[4]), ptr(dy), c, ptr(dg), ptr(db), n, c, vox, ptr(ws),
+                              st()), "in_bwd")
+    torch.cuda.synchronize()
+    tol = TOL[dtype] * (1.5 if dtype == BF16 else 20)   # fp32: cancellation in g - mean(g) - xhat*mean(g*xhat)
+    assert rel_err(from_cl(dy), y.grad) < tol
+    assert rel_err(dg.cpu(), gamma.grad) < 2e-3 and rel_err(db.cpu(), beta.grad) < 2e-3
