@@ -560,7 +560,7 @@ int transformer_backward(Exec& e, const float* x) {
 int in_backward(Exec& e, const Conv3& c, const View& da, const View& dy) {
   hdf_plan* p = e.p;
   const int64_t vox = p->vox(c.lvl);
-  const int blocks = hdf_in_bwd_blocks(vox);
+  const int blocks = hdf_in_bwd_blocks(vox, c.Cout);
   float* k = e.f(p->inb_k);
   float* k1 = k;
   float* ka = k + (size_t)e.B * c.Cout;
@@ -1024,14 +1024,14 @@ int hdf_op_in_finalize(const float* partials, int N, int tiles, int C, int CP, i
                                 (hipStream_t)stream);
 }
 int64_t hdf_op_in_bwd_workspace_floats(int N, int C, int64_t voxels) {
-  return (int64_t)N * hdf_in_bwd_blocks(voxels) * C * 2 + (int64_t)3 * N * C;
+  return (int64_t)N * hdf_in_bwd_blocks(voxels, C) * C * 2 + (int64_t)3 * N * C;
 }
 int hdf_op_in_bwd(int dtype, const void* da, int64_t da_pitch, const void* y, int64_t y_pitch, const float* scale,
                   const float* shift, const float* mean, const float* rstd, const float* gamma, void* dy,
                   int64_t dy_pitch, float* dgamma, float* dbeta, int N, int C, int64_t voxels, float* workspace,
                   hdf_stream stream) {
   HDF_CHECK_ARG(da && y && scale && shift && mean && rstd && dy && workspace, "in_bwd: null argument");
-  const int blocks = hdf_in_bwd_blocks(voxels);
+  const int blocks = hdf_in_bwd_blocks(voxels, C);
   float* partials = workspace;
   float* k1 = workspace + (int64_t)N * blocks * C * 2;
   float* ka = k1 + (int64_t)N * C;

@@ -59,7 +59,7 @@ int hdf_launch_in_bwd_apply(int dtype, const void* da, int64_t da_pitch, const v
                             const float* scale, const float* shift, const float* mean, const float* rstd,
                             const float* k1, const float* ka, const float* kb, void* dy, int64_t dy_pitch, int N, int C,
                             int64_t vox, hipStream_t st);
-int hdf_in_bwd_blocks(int64_t vox);
+int hdf_in_bwd_blocks(int64_t vox, int C);
 
 // a (+)= b over a pitched view;  or a = b when accumulate == 0
 int hdf_launch_add(int dtype, void* a, int64_t a_pitch, const void* b, int64_t b_pitch, int N, int C, int64_t vox,

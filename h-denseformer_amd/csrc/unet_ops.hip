@@ -968,7 +968,11 @@ int hdf_launch_head_bwd(int dtype, const void* dlogits, const void* in, int64_t 
   return HDF_OK;
 }
 
-int hdf_in_bwd_blocks(int64_t vox) { return (int)std::max<int64_t>(1, std::min<int64_t>(1024, vox / 1024)); }
+// workgroups per sample of the IN-backward passes: ~2K 16-byte chunks each, so the low-resolution levels (few
+// voxels, many channels) still fill the chip (with a voxel-only rule the 16^3 level ran on 4 workgroups: 85 us for 4 MB)
+int hdf_in_bwd_blocks(int64_t vox, int C) {
+  return (int)std::max<int64_t>(1, std::min<int64_t>(1024, vox * (C / 8) / 2048));
+}
 
 int hdf_launch_in_bwd_reduce(int dtype, const void* da, int64_t da_pitch, const void* y, int64_t y_pitch,
                              const float* scale, const float* shift, const float* mean, const float* rstd,
@@ -1000,8 +1004,8 @@ int hdf_launch_in_bwd_apply(int dtype, const void* da, int64_t da_pitch, const v
                             const float* k1, const float* ka, const float* kb, void* dy, int64_t dy_pitch, int N, int C,
                             int64_t vox, hipStream_t st) {
   HDF_CHECK_ARG(C % 16 == 0 && C <= 1024, "in_bwd_apply: C=%d", C);
-  // ~2K voxels per workgroup, at most 2048 workgroups per sample
-  const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, vox / 2048));
+  // ~1K chunks per workgroup, at most 2048 workgroups per sample
+  const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, vox * (C / 8) / 1024));
   DISPATCH_T(dtype, hipLaunchKernelGGL(in_bwd_apply_kernel<T>, dim3(blocks, N), dim3(256), 0, st, (const T*)da,
                                        da_pitch, (const T*)y, y_pitch, scale, shift, mean, rstd, k1, ka, kb, (T*)dy,
                                        dy_pitch, C, vox));
