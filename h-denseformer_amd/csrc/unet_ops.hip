@@ -456,59 +456,102 @@ __global__ void upsample_bwd_kernel(const T* __restrict__ dout, int64_t dout_pit
 // ------------------------------------------------------------------------------ 1x1x1 heads
 constexpr int HEAD_MAXCLS = 8;
 
-template <typename T>
+// Streaming form (as head_bwd below): thread = (voxel lane, 8-channel chunk) so a wave reads whole contiguous voxel
+// rows; the per-chunk partial dot products are summed over the `cols` chunk lanes of a voxel with xor shuffles
+// (cols is a power of two <= 32), the block's logits are staged in LDS as [class][voxel] and written plane by plane,
+// coalesced.  (One thread per voxel walked a 64..512-byte row alone: 58 us for the 4 MB of the 16^3 level.)
+template <typename T, int MC>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ in, int64_t in_pitch,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        const float* __restrict__ w, const float* __restrict__ b,
-                                                       T* __restrict__ logits, int N, int C, int ncls, int64_t vox) {
+                                                       T* __restrict__ logits, int N, int C, int ncls, int64_t vox,
+                                                       int per) {
   constexpr int EPC = ST<T>::EPC;
-  extern __shared__ float sm[];  // w[ncls][C], then scale[C], shift[C] for this block's n
-  float* sw = sm;
-  float* ssc = sm + ncls * C;
-  float* ssh = ssc + C;
+  extern __shared__ float outs[];  // [MC][per], then [256][MC] partials when cols is not a power of two
+  float* part = outs + MC * per;
   const int n = blockIdx.y;
-  for (int i = threadIdx.x; i < ncls * C; i += 256) sw[i] = w[i];
-  for (int i = threadIdx.x; i < C; i += 256) {
-    ssc[i] = scale ? scale[(int64_t)n * C + i] : 1.f;
-    ssh[i] = scale ? shift[(int64_t)n * C + i] : 0.f;
+  const int cols = C / EPC;
+  const bool pow2 = (cols & (cols - 1)) == 0;  // else (n_filters = 48: 6 chunk lanes) a voxel's lanes straddle waves
+  const int vlanes = 256 / cols;
+  const int col = threadIdx.x % cols, vl = min((int)threadIdx.x / cols, vlanes - 1);
+  const bool lane_on = (int)threadIdx.x < vlanes * cols;
+  const int c0 = col * EPC;
+  float sc[EPC], sh[EPC], wv[MC][EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; e++) {
+    sc[e] = scale ? scale[(int64_t)n * C + c0 + e] : 1.f;
+    sh[e] = scale ? shift[(int64_t)n * C + c0 + e] : 0.f;
+#pragma unroll
+    for (int o = 0; o < MC; o++) wv[o][e] = (o < ncls) ? w[min(o, ncls - 1) * C + c0 + e] : 0.f;
   }
-  __syncthreads();
-  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < vox; v += (int64_t)gridDim.x * 256) {
-    float acc[HEAD_MAXCLS];
+  const int64_t vb = (int64_t)blockIdx.x * per, ve = min(vox, vb + per);
+  constexpr int U = 4;
+  const int iters = (per + U * vlanes - 1) / (U * vlanes);  // the same for every thread: shuffles / barriers below
+  for (int it = 0; it < iters; it++) {
+    const int64_t v0 = vb + vl + (int64_t)it * U * vlanes;
+    float f[U][EPC];
 #pragma unroll
-    for (int o = 0; o < HEAD_MAXCLS; o++) acc[o] = (o < ncls) ? b[o] : 0.f;
-    const T* row = in + ((int64_t)n * vox + v) * in_pitch;
-    for (int c0 = 0; c0 < C; c0 += EPC) {
-      float f[EPC];
-      load_chunk<T>(row + c0, f);
-#pragma unroll
-      for (int e = 0; e < EPC; e++) {
-        float x = f[e];
-        if (scale) x = fmaxf(x * ssc[c0 + e] + ssh[c0 + e], 0.f);
-#pragma unroll
-        for (int o = 0; o < HEAD_MAXCLS; o++)
-          if (o < ncls) acc[o] += x * sw[o * C + c0 + e];
-      }
+    for (int u = 0; u < U; u++) {
+      const int64_t v = min(v0 + (int64_t)u * vlanes, ve - 1);  // clamped: never branch around a load
+      load_chunk<T>(in + ((int64_t)n * vox + v) * in_pitch + c0, f[u]);
     }
 #pragma unroll
-    for (int o = 0; o < HEAD_MAXCLS; o++)
-      if (o < ncls) ST<T>::st(logits + ((int64_t)n * ncls + o) * vox + v, acc[o]);
+    for (int u = 0; u < U; u++) {
+      float acc[MC];
+#pragma unroll
+      for (int o = 0; o < MC; o++) acc[o] = 0.f;
+#pragma unroll
+      for (int e = 0; e < EPC; e++) {
+        float x = f[u][e];
+        if (scale) x = fmaxf(x * sc[e] + sh[e], 0.f);
+#pragma unroll
+        for (int o = 0; o < MC; o++) acc[o] += x * wv[o][e];
+      }
+      if (pow2) {
+        for (int off = 1; off < cols; off <<= 1) {
+#pragma unroll
+          for (int o = 0; o < MC; o++) acc[o] += __shfl_xor(acc[o], off, 64);
+        }
+      } else {  // uniform branch and trip count: the barriers are reached by every thread
+        __syncthreads();
+#pragma unroll
+        for (int o = 0; o < MC; o++) part[threadIdx.x * MC + o] = acc[o];
+        __syncthreads();
+        if (col == 0) {
+          for (int k = 1; k < cols; k++)
+#pragma unroll
+            for (int o = 0; o < MC; o++) acc[o] += part[(threadIdx.x + k) * MC + o];
+        }
+      }
+      const int64_t lv = v0 + (int64_t)u * vlanes - vb;
+      if (col == 0 && lane_on && lv < per) {
+#pragma unroll
+        for (int o = 0; o < MC; o++) outs[o * per + (int)lv] = acc[o];
+      }
+    }
+  }
+  __syncthreads();
+  for (int o = 0; o < ncls; o++) {
+    const float bo = b[o];
+    for (int lv = threadIdx.x; lv < per; lv += 256)
+      if (vb + lv < vox) ST<T>::st(logits + ((int64_t)n * ncls + o) * vox + vb + lv, outs[o * per + lv] + bo);
   }
 }
 
-// grid (blocks, N); loops channel chunks of 32 outermost so the (o,c) accumulators stay scalar
 // Streaming form: thread = (voxel lane, 8-channel chunk), so a wave reads whole contiguous voxel rows; the weight-
 // gradient outer products accumulate in registers over the thread's voxels (ncls x 8 accumulators) and are reduced
 // across the block ONCE at the end (the first version rebuilt a 256-voxel LDS tile and ran a 256-deep serial LDS
 // reduction per tile: 3x the HBM time).  grid (blocks, N); C <= 256 (cols = C/8 <= 32).
-constexpr int HEAD_BWD_VOX = 2048;  // voxels per workgroup
+constexpr int HEAD_VOX_MAX = 2048;  // voxels per workgroup (fewer at the low-resolution levels: see head_vox)
+// voxels per workgroup: a multiple of 64, at least 128 workgroups per sample when the level has that many voxels
+inline int head_vox(int64_t vox) { return (int)std::max<int64_t>(64, std::min<int64_t>(HEAD_VOX_MAX, (vox / 128) & ~63)); }
 template <typename T, int MC>       // MC: class slots held in registers (4 or 8)
 __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ dlogits, const T* __restrict__ in,
                                                        int64_t in_pitch, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const float* __restrict__ w,
                                                        T* __restrict__ dx, int64_t dx_pitch, int accumulate_dx,
                                                        float* __restrict__ dw, float* __restrict__ db, int N, int C,
-                                                       int ncls, int64_t vox) {
+                                                       int ncls, int64_t vox, int per) {
   constexpr int EPC = ST<T>::EPC;
   // LDS: first the block's logit gradients [voxel][MC] (loaded class plane by class plane, coalesced, once), then
   // reused as [vlanes][C + 1][MC] for the final reduction
@@ -533,12 +576,10 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ dlo
       accw[o][e] = 0.f;
     }
   }
-  const int64_t vb = (int64_t)blockIdx.x * HEAD_BWD_VOX, ve = min(vox, vb + HEAD_BWD_VOX);
+  const int64_t vb = (int64_t)blockIdx.x * per, ve = min(vox, vb + per);
   for (int o = 0; o < MC; o++) {
     const T* src = dlogits + ((int64_t)n * ncls + min(o, ncls - 1)) * vox;
-#pragma unroll
-    for (int k = 0; k < HEAD_BWD_VOX / 256; k++) {
-      const int lv = threadIdx.x + 256 * k;
+    for (int lv = threadIdx.x; lv < per; lv += 256) {
       const float v = ST<T>::ld(src + min(vb + lv, vox - 1));
       red[lv * MC + o] = (o < ncls && vb + lv < vox) ? v : 0.f;
     }
@@ -936,10 +977,17 @@ int hdf_launch_head_fwd(int dtype, const void* in, int64_t in_pitch, const float
                         const float* w, const float* b, void* logits, int N, int C, int ncls, int64_t vox,
                         hipStream_t st) {
   HDF_CHECK_ARG(ncls <= HEAD_MAXCLS, "head: n_cls=%d > %d", ncls, HEAD_MAXCLS);
-  size_t shm = (size_t)(ncls * C + 2 * C) * sizeof(float);
-  unsigned gx = (unsigned)std::min<int64_t>(ceil_div64(vox, 256), 2048);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(head_fwd_kernel<T>, dim3(gx, N), dim3(256), shm, st, (const T*)in, in_pitch,
-                                       scale, shift, w, b, (T*)logits, N, C, ncls, vox));
+  HDF_CHECK_ARG(C % 16 == 0 && C <= 1024, "head_fwd: C=%d", C);
+  const int per = head_vox(vox);
+  const unsigned gx = (unsigned)ceil_div64(vox, per);
+  DISPATCH_T(dtype, {
+    if (ncls <= 4)
+      hipLaunchKernelGGL((head_fwd_kernel<T, 4>), dim3(gx, N), dim3(256), (size_t)4 * (per + 256) * sizeof(float), st,
+                         (const T*)in, in_pitch, scale, shift, w, b, (T*)logits, N, C, ncls, vox, per);
+    else
+      hipLaunchKernelGGL((head_fwd_kernel<T, 8>), dim3(gx, N), dim3(256), (size_t)8 * (per + 256) * sizeof(float), st,
+                         (const T*)in, in_pitch, scale, shift, w, b, (T*)logits, N, C, ncls, vox, per);
+  });
   HDF_LAUNCH_CHECK();
   return HDF_OK;
 }
@@ -948,20 +996,21 @@ int hdf_launch_head_bwd(int dtype, const void* dlogits, const void* in, int64_t 
                         const float* shift, const float* w, void* dx, int64_t dx_pitch, int accumulate_dx, float* dw,
                         float* db, int N, int C, int ncls, int64_t vox, hipStream_t st) {
   HDF_CHECK_ARG(ncls <= HEAD_MAXCLS, "head: n_cls=%d > %d", ncls, HEAD_MAXCLS);
-  HDF_CHECK_ARG(C % 16 == 0 && C <= 256, "head_bwd: C=%d", C);
-  const unsigned gx = (unsigned)ceil_div64(vox, HEAD_BWD_VOX);
+  HDF_CHECK_ARG(C % 16 == 0 && C <= 1024, "head_bwd: C=%d", C);
+  const int per = head_vox(vox);
+  const unsigned gx = (unsigned)ceil_div64(vox, per);
   DISPATCH_T(dtype, {
     const int cols = C / ST<T>::EPC, vlanes = 256 / cols;
     const int mc = ncls <= 4 ? 4 : 8;
-    const size_t shm = std::max((size_t)vlanes * (C + 1) * mc, (size_t)HEAD_BWD_VOX * mc) * sizeof(float);
+    const size_t shm = std::max((size_t)vlanes * (C + 1) * mc, (size_t)per * mc) * sizeof(float);
     if (mc == 4) {
       HDF_TRY(allow_big_lds((const void*)head_bwd_kernel<T, 4>, shm));
       hipLaunchKernelGGL((head_bwd_kernel<T, 4>), dim3(gx, N), dim3(256), shm, st, (const T*)dlogits, (const T*)in,
-                         in_pitch, scale, shift, w, (T*)dx, dx_pitch, accumulate_dx, dw, db, N, C, ncls, vox);
+                         in_pitch, scale, shift, w, (T*)dx, dx_pitch, accumulate_dx, dw, db, N, C, ncls, vox, per);
     } else {
       HDF_TRY(allow_big_lds((const void*)head_bwd_kernel<T, 8>, shm));
       hipLaunchKernelGGL((head_bwd_kernel<T, 8>), dim3(gx, N), dim3(256), shm, st, (const T*)dlogits, (const T*)in,
-                         in_pitch, scale, shift, w, (T*)dx, dx_pitch, accumulate_dx, dw, db, N, C, ncls, vox);
+                         in_pitch, scale, shift, w, (T*)dx, dx_pitch, accumulate_dx, dw, db, N, C, ncls, vox, per);
     }
   });
   HDF_LAUNCH_CHECK();

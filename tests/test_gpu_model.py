@@ -351,3 +351,35 @@ def test_onehot_from_labels_vs_reference_golden():
     out = onehot_from_labels(lab, int(g["n_cls"])).cpu().numpy()
     assert np.array_equal(out[0], g["onehot"])
     assert np.array_equal(out[1], g["onehot"][:, ::-1])
+
+
+@pytest.mark.gpu
+def test_n_filters_48_forward_backward_vs_oracle():
+    """BASELINE config #5 channel widths (n_filters = 48: 96-byte channel rows, 6 / 12 / 24 / 48 chunk lanes per
+    voxel, i.e. the non-power-of-two paths of the elementwise and head kernels) on a small volume."""
+    from loss.combine_loss import CEPlusDice, DeepSuperloss
+    cfg, batch, tag = (2, 3, 48, (32, 32, 32), 4), 1, "nf48"
+    net, sd = _build(cfg)
+    net.eval()
+    x, onehot = _data(cfg, batch, tag)
+    crit = DeepSuperloss(criterion=CEPlusDice(weight=None, ignore_index=0))
+    outs = net(x.to(DEV))
+    loss = crit(outs, onehot.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    tr = orc.OracleTrainer(sd)
+    ref_loss, ref_outs = tr.loss_and_grads(x, onehot, None)
+    for i in range(4):
+        assert _rel(outs[i].detach(), ref_outs[i]) < 1e-3, f"out{i}"
+    assert abs(loss.item() - ref_loss.item()) < 1e-4 * max(1.0, abs(ref_loss.item()))
+    errs = []
+    for name, p in net.named_parameters():
+        rg = tr.sd[name].grad
+        if rg.norm() < 1e-6:
+            continue
+        errs.append((name, _rl2(p.grad, rg)))
+    errs.sort(key=lambda kv: -kv[1])
+    assert errs[0][1] < 1e-2, errs[:5]                       # the reference's own fp32 noise floor (see above)
+    d = dict(errs)
+    for name in ("conv1x1.weight", "conv1x1_d3.weight", "block_1_2_right.conv.weight"):
+        assert d[name] < 5e-3, (name, d[name])
