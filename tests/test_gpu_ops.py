@@ -220,3 +220,22 @@ def test_instance_norm_relu_backward(dtype, n, c, size):
     tol = TOL[dtype] * (1.5 if dtype == BF16 else 20)   # fp32: cancellation in g - mean(g) - xhat*mean(g*xhat)
     assert rel_err(from_cl(dy), y.grad) < tol
     assert rel_err(dg.cpu(), gamma.grad) < 2e-3 and rel_err(db.cpu(), beta.grad) < 2e-3
+
+
+@pytest.mark.parametrize("dtype,c", [(F32, 16), (BF16, 32)])
+@pytest.mark.parametrize("n,size", [(2, (32, 32, 32)), (1, (33, 38, 41))])
+def test_upsample_bwd_large_pitched_vs_autograd(dtype, c, n, size):
+    """larger, odd extents; the gradient is read from a channel slice of a wider buffer (as the UpConv chain reads it
+    from the concat gradient)."""
+    xa = _mk((n, c) + size, 31).requires_grad_(True)
+    ref = F.interpolate(xa, scale_factor=2, mode="trilinear", align_corners=False)
+    g = _mk(tuple(ref.shape), 32)
+    ref.backward(rnd(g, dtype))
+    gcl = to_cl(g, dtype)
+    wide = torch.zeros(gcl.shape[:-1] + (2 * c,), dtype=gcl.dtype, device=DEV)
+    wide[..., c:] = gcl
+    view = wide.view(-1)[c:]
+    dlo = torch.empty((n,) + size + (c,), dtype=gcl.dtype, device=DEV)
+    check(lib().hdf_op_upsample_bwd(dtype, ptr(view), 2 * c, ptr(dlo), c, n, c, *size, st()), "upb")
+    torch.cuda.synchronize()
+    assert rel_err(from_cl(dlo), xa.grad) < TOL[dtype]
