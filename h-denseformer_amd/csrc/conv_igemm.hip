@@ -1806,6 +1806,8 @@ int launch_cfg(const ConvArgs& a, hipStream_t st) {
 
 // tile-shape choice: shared by the launcher and by hdf_conv_stat_tiles (partials geometry)
 inline bool small_tile(int Do, int Ho, int Wo) { return (int64_t)Do * Ho * Wo <= 32 * 32 * 32 / 2; }
+// 8^3-class volumes (the bottleneck UpConv): 64-voxel tiles, or a handful of workgroups would carry the whole layer
+inline bool tiny_tile(int Do, int Ho, int Wo) { return (int64_t)Do * Ho * Wo <= 8 * 8 * 16; }
 // weights-stationary kernel: mode 0, whole Cin row <= 128 B, enough tiles to amortise the weight panel
 inline int ws_cfg(int mode, int Do, int Ho, int Wo, int row_bytes) {
   static const int ws_max = getenv("HDF_WS_MAX_ROW_BYTES") ? atoi(getenv("HDF_WS_MAX_ROW_BYTES")) : 128;  // tuning knob
@@ -1837,6 +1839,7 @@ int launch_conv_t(int mode, const ConvArgs& a, hipStream_t st) {
       if (rb == 64) return launch_ws2<T, 64, 64>(a, st);
       if (rb == 128) return launch_ws2<T, 32, 128>(a, st);
     }
+    if (tiny_tile(a.Do, a.Ho, a.Wo)) return launch_cfg<T, 2, 4, 8, 2, 2, 1, 1, false>(a, st);   // 64 vox x 64 ch
     if (small_tile(a.Do, a.Ho, a.Wo)) return launch_cfg<T, 4, 4, 8, 2, 2, 2, 1, false>(a, st);  // 128 vox x 64 ch
     if (a.CoutP <= 32) return launch_cfg<T, 4, 8, 8, 4, 1, 2, 1, false>(a, st);                  // 256 vox x 32 ch
     return launch_cfg<T, 4, 8, 8, 2, 2, 4, 1, false>(a, st);                                     // 256 vox x 64 ch
@@ -1894,6 +1897,7 @@ int launch_wgrad_t(WgradArgs a, float* dw, int sc_store, int lc_store, int accum
 
 int hdf_conv_stat_tiles(int mode, int Do, int Ho, int Wo, int row_bytes) {
   if (mode != 0) return 0;
+  if (tiny_tile(Do, Ho, Wo)) return ceil_div(Do, 2) * ceil_div(Ho, 4) * ceil_div(Wo, 8);
   if (small_tile(Do, Ho, Wo)) return ceil_div(Do, 4) * ceil_div(Ho, 4) * ceil_div(Wo, 8);
   return ceil_div(Do, 4) * ceil_div(Ho, 8) * ceil_div(Wo, 8);
 }
