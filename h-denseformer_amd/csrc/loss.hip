@@ -9,7 +9,7 @@
 
 namespace {
 constexpr int MAXC = 8;
-constexpr int LOSS_BLOCKS = 256;
+constexpr int LOSS_BLOCKS = 1024;
 constexpr int NSTAT = 3 * MAXC + 1;
 
 template <typename T>
