@@ -354,7 +354,10 @@ struct WsTile {
   int k;  // index in the list the tile came from (border pass)
 };
 
-template <typename T, int CH, int RB, bool XF>
+// NB: 32-channel output blocks per workgroup.  NB = 2 (64-byte rows, Cout % 64 == 0) stages every tile once for both
+// blocks (two workgroups with 32 channels each staged it twice: the 32->64 dgrad at 128^3 was the costliest launch of
+// the step) and shares each A fragment between two MFMAs.
+template <typename T, int CH, int RB, bool XF, int NB>
 __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
   constexpr int TD = 4, TH = 8, TW = 8, BD = TD + 2, BH = TH + 2, BW = TW + 2, BOX = BD * BH * BW;
   constexpr int ESZ = sizeof(T), EPC = ST<T>::EPC;
@@ -365,31 +368,34 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
   // tile-buffer row pitch: padded by 16 bytes (conflict-free, see ws_row_to_zx; fragment addresses = one lane
   // base + compile-time offsets) whenever two padded buffers and the weight panel fit in 160 KiB; else unpadded
   // rows with XOR-swizzled 16-byte slots (a 36-entry per-lane address table)
-  constexpr bool SWZ = (2 * BOX * (CH + 16) + 2048 + 512 + 27 * 32 * RB > 160 * 1024);
+  constexpr bool SWZ = (2 * BOX * (CH + 16) + 4096 + 512 + 27 * 32 * NB * RB > 160 * 1024);
   constexpr int AP = SWZ ? CH : CH + 16;
   constexpr int ABUF = BOX * AP;
-  constexpr int OFF_RED = 2 * ABUF, OFF_XF = OFF_RED + 2048, OFF_W = OFF_XF + 512;
+  constexpr int OFF_RED = 2 * ABUF, OFF_XF = OFF_RED + 2048 * NB, OFF_W = OFF_XF + 512;
+  constexpr int NC = 32 * NB;  // output channels of the workgroup
   constexpr int CPR = RB / 16, RP256 = 16 / CPR;
   static_assert(CH == 32 || CH == 64, "chunk bytes");
   static_assert(NCH == 1 || NCH % 2 == 0, "buffer parity at tile start must be compile-time");
   static_assert(2 * CIN * 4 <= 512, "scale/shift table");
-  __shared__ __attribute__((aligned(256))) char lds[OFF_W + 27 * 32 * RB];
+  static_assert(OFF_W + 27 * NC * RB <= 160 * 1024, "LDS budget");
+  static_assert(NB == 1 || NCH > 1, "the deferred epilogue of single-pass tiles keeps one accumulator block");
+  __shared__ __attribute__((aligned(256))) char lds[OFF_W + 27 * NC * RB];
   char* const a_lds = lds;
-  float* const s_red = reinterpret_cast<float*>(lds + OFF_RED);  // [2 tile parities][4 waves][32][2]
+  float* const s_red = reinterpret_cast<float*>(lds + OFF_RED);  // [2 halves][4 waves][NC][2]
   float* const s_xf = reinterpret_cast<float*>(lds + OFF_XF);
   char* const w_lds = lds + OFF_W;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int n0 = blockIdx.y * 32;
+  const int n0 = blockIdx.y * NC;
   const int part = tid & (CPV - 1);
   constexpr bool xf = XF;  // input transform x*scale+shift (+relu) on the way into LDS; else a plain copy
   const float relu_lo = (xf && a.in_relu) ? 0.f : -INFINITY;
 
   // ---- weights -> LDS, once (rows [tap][cout 32][RB bytes], 16-byte slots XOR-swizzled by row)
-  for (int id = tid; id < 27 * 32 * CPR; id += 256) {
+  for (int id = tid; id < 27 * NC * CPR; id += 256) {
     int row = id / CPR, ch = id - row * CPR;
-    int tap = row >> 5, rr = row & 31;
+    int tap = row / NC, rr = row - tap * NC;
     u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a.w) +
                                               ((int64_t)(tap * a.CoutP + n0 + rr) * CIN) * ESZ + ch * 16);
     int sw = ch ^ ((row / RP256) & (CPR - 1));
@@ -661,9 +667,14 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
     WS_BARRIER();
   };
 
-  const int ch = n0 + r;
-  const bool ch_ok = ch < a.Cout;
-  const float bias = (a.bias && ch_ok) ? a.bias[ch] : 0.f;
+  const int ch = n0 + r;                 // channel of output block 0 (block nb: + 32 nb)
+  bool ch_ok[NB];
+  float bias[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; nb++) {
+    ch_ok[nb] = ch + 32 * nb < a.Cout;
+    bias[nb] = (a.bias && ch_ok[nb]) ? a.bias[ch + 32 * nb] : 0.f;
+  }
   T* const outp = reinterpret_cast<T*>(a.out);
   // accumulator register i of this lane: tile voxel (dz, 2w + mb, x) with x = (i & 3) + 4 * ((i >> 2) & 1) and
   // dz = {0,1,3,2}[i >> 2] (h == 0) or {1,0,2,3}[i >> 2] (h == 1)   (ws_row_to_zx of row (i&3) + 8*(i>>2) + 4h)
@@ -680,13 +691,13 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
   int sr_sel = 0, pend_sel = 0;  // s_red halves alternate per WRITE (a workgroup's consecutive tiles are 32 apart
                                  // in raster order, so their linear index has one parity)
   auto flush_stats = [&]() {
-    if (a.stat_partials && tid < 32) {
-      const float* sr = s_red + pend_sel * 256;
+    if (a.stat_partials && tid < NC) {
+      const float* sr = s_red + pend_sel * (256 * NB);
       float t1 = 0.f, t2 = 0.f;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        t1 += sr[(k * 32 + tid) * 2 + 0];
-        t2 += sr[(k * 32 + tid) * 2 + 1];
+        t1 += sr[(k * NC + tid) * 2 + 0];
+        t2 += sr[(k * NC + tid) * 2 + 1];
       }
       float* q = a.stat_partials + ((int64_t)pend_tile * a.CoutP + n0 + tid) * 2;
       q[0] = t1;
@@ -715,53 +726,58 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
   auto out_base = [&](const WsTile& t) -> T* {
     return outp + ((((int64_t)t.n * a.Do + t.z0) * a.Ho + t.y0 + 2 * wave) * a.Wo + t.x0) * a.out_pitch + ch;
   };
-  auto epilogue = [&](f32x16 (&acc)[2], const WsTile& ET) __attribute__((always_inline)) {
+  auto epilogue = [&](f32x16 (&acc)[2 * NB], const WsTile& ET) __attribute__((always_inline)) {
     const int z0 = ET.z0, y0 = ET.y0, x0 = ET.x0;
-    float s1 = 0.f, s2 = 0.f;
     const bool full = z0 + TD <= a.Do && y0 + TH <= a.Ho && x0 + TW <= a.Wo;
-    T* const obase = out_base(ET);
-    if (full && ch_ok && !a.accumulate) {
+    float* const sr = s_red + sr_sel * (256 * NB);
 #pragma unroll
-      for (int mb = 0; mb < 2; mb++) {
-        T* const orow = obase + (int64_t)mb * a.Wo * a.out_pitch;
+    for (int nb = 0; nb < NB; nb++) {
+      float s1 = 0.f, s2 = 0.f;
+      T* const obase = out_base(ET) + 32 * nb;
+      if (full && ch_ok[nb] && !a.accumulate) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-          const float v = acc[mb][i] + bias;
-          ST<T>::st(orow + eoff(i), v);
-          s1 += v;
-          s2 += v * v;
+        for (int mb = 0; mb < 2; mb++) {
+          T* const orow = obase + (int64_t)mb * a.Wo * a.out_pitch;
+#pragma unroll
+          for (int i = 0; i < 16; i++) {
+            const float v = acc[nb * 2 + mb][i] + bias[nb];
+            ST<T>::st(orow + eoff(i), v);
+            s1 += v;
+            s2 += v * v;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int mb = 0; mb < 2; mb++) {
+          const int gy = y0 + 2 * wave + mb;
+          T* const orow = obase + (int64_t)mb * a.Wo * a.out_pitch;
+#pragma unroll
+          for (int i = 0; i < 16; i++) {
+            const int gz = z0 + edz[i >> 2], gx = x0 + (i & 3) + 4 * ((i >> 2) & 1);
+            const float v = acc[nb * 2 + mb][i] + bias[nb];
+            const bool ok = gz < a.Do && gy < a.Ho && gx < a.Wo;
+            if (ok && ch_ok[nb]) {
+              float o = v;
+              if (a.accumulate) o += ST<T>::ld(orow + eoff(i));
+              ST<T>::st(orow + eoff(i), o);
+            }
+            const float mk = ok ? 1.f : 0.f;
+            s1 += mk * v;
+            s2 += mk * v * v;
+          }
         }
       }
-    } else {
-#pragma unroll
-      for (int mb = 0; mb < 2; mb++) {
-        const int gy = y0 + 2 * wave + mb;
-        T* const orow = obase + (int64_t)mb * a.Wo * a.out_pitch;
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-          const int gz = z0 + edz[i >> 2], gx = x0 + (i & 3) + 4 * ((i >> 2) & 1);
-          const float v = acc[mb][i] + bias;
-          const bool ok = gz < a.Do && gy < a.Ho && gx < a.Wo;
-          if (ok && ch_ok) {
-            float o = v;
-            if (a.accumulate) o += ST<T>::ld(orow + eoff(i));
-            ST<T>::st(orow + eoff(i), o);
-          }
-          const float mk = ok ? 1.f : 0.f;
-          s1 += mk * v;
-          s2 += mk * v * v;
+      if (a.stat_partials) {
+        if (!ch_ok[nb]) s1 = s2 = 0.f;
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (h == 0) {
+          sr[(wave * NC + 32 * nb + r) * 2 + 0] = s1;
+          sr[(wave * NC + 32 * nb + r) * 2 + 1] = s2;
         }
       }
     }
     if (a.stat_partials) {
-      if (!ch_ok) s1 = s2 = 0.f;
-      s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 32, 64);
-      if (h == 0) {
-        float* sr = s_red + sr_sel * 256;
-        sr[(wave * 32 + r) * 2 + 0] = s1;
-        sr[(wave * 32 + r) * 2 + 1] = s2;
-      }
       pend_tile = ET.tile;
       pend_sel = sr_sel;
       sr_sel ^= 1;
@@ -775,14 +791,14 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
   // sets with the buffer parity.  DOUT: the phase leaves its tile "pending" (coordinates in PT) instead of running
   // the epilogue; DIN: the phase converts / stores / sums the pending tile out of the OTHER set, a few elements per
   // MFMA group, and hands the per-wave InstanceNorm partials to the flush behind its barrier.
-  f32x16 accs[2][2];
+  f32x16 accs[2][2 * NB];  // [register set][nb * 2 + mb]
   WsTile PT = T0;
   auto tile_phase = [&](auto par_tag, auto fast_tag, auto din_tag, auto dout_tag) __attribute__((always_inline)) {
     constexpr int PAR0 = decltype(par_tag)::value;
     constexpr bool DIN = decltype(din_tag)::value, DOUT = decltype(dout_tag)::value;
     constexpr int EPG = (32 + NG - 1) / NG;  // pending elements per MFMA group
-    f32x16(&acc)[2] = accs[PAR0];
-    f32x16(&pacc)[2] = accs[1 - PAR0];
+    f32x16(&acc)[2 * NB] = accs[PAR0];
+    f32x16(&pacc)[2 * NB] = accs[1 - PAR0];
     T* const pbase = out_base(PT);
     float ds1 = 0.f, ds2 = 0.f;
 #pragma unroll
@@ -809,12 +825,15 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
         read_xf(c_chunk);
       }
       WS2_STAMP(0)
-      u32x4 af[2][4], bf[2][3];
-      auto read_group = [&](int g, u32x4 (&A)[4], u32x4 (&B)[3]) {
+      u32x4 af[2][4], bf[2][3 * NB];
+      auto read_group = [&](int g, u32x4 (&A)[4], u32x4 (&B)[3 * NB]) {
         const int t = g / NFS, fs = g % NFS, jz = t / 3, jx = t % 3;
         auto rdA = [&](int yp) { A[yp] = *reinterpret_cast<const u32x4*>(a_rd + a_addr(jz, yp, jx, fs)); };
         auto rdB = [&](int jy) {
-          B[jy] = *reinterpret_cast<const u32x4*>(w_lds + ((jz * 9 + jy * 3 + jx) * 32) * RB + (bvar[c] ^ (fs * 32)));
+#pragma unroll
+          for (int nb = 0; nb < NB; nb++)
+            B[jy * NB + nb] = *reinterpret_cast<const u32x4*>(w_lds + ((jz * 9 + jy * 3 + jx) * NC + 32 * nb) * RB +
+                                                              (bvar[c] ^ (fs * 32)));
         };
         // in order of first use (LDS returns in order, the waits are counted)
         rdB(0);
@@ -849,7 +868,7 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
             const int e = g * EPG + u;
             if (e < 32) {
               const int mb = e >> 4, i = e & 15;
-              const float v = pacc[mb][i] + bias;
+              const float v = pacc[mb][i] + bias[0];
               ST<T>::st(pbase + (int64_t)mb * a.Wo * a.out_pitch + eoff(i), v);
               ds1 += v;
               ds2 += v * v;
@@ -867,17 +886,20 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
           }
         }
         u32x4(&A)[4] = af[g & 1];
-        u32x4(&B)[3] = bf[g & 1];
+        u32x4(&B)[3 * NB] = bf[g & 1];
         if (c == 0 && g == 0) {  // first MFMAs of the tile take a zero C operand: no accumulator clearing
 #pragma unroll
-          for (int i = 0; i < 16; i++) acc[0][i] = acc[1][i] = 0.f;
+          for (int q2 = 0; q2 < 2 * NB; q2++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[q2][i] = 0.f;
         }
-        Mma<T>::run(A[0], B[0], acc[0]);
-        Mma<T>::run(A[1], B[0], acc[1]);
-        Mma<T>::run(A[1], B[1], acc[0]);
-        Mma<T>::run(A[2], B[1], acc[1]);
-        Mma<T>::run(A[2], B[2], acc[0]);
-        Mma<T>::run(A[3], B[2], acc[1]);
+#pragma unroll
+        for (int jy = 0; jy < 3; jy++)
+#pragma unroll
+          for (int nb = 0; nb < NB; nb++) {
+            Mma<T>::run(A[jy], B[jy * NB + nb], acc[nb * 2 + 0]);      // mb 0: box row y' = jy
+            Mma<T>::run(A[jy + 1], B[jy * NB + nb], acc[nb * 2 + 1]);  // mb 1: box row y' = jy + 1
+          }
         __builtin_amdgcn_sched_barrier(0);
       }
       WS2_STAMP(1)
@@ -890,7 +912,8 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
     else
       epilogue(acc, T0);
     // pin the loop-carried accumulators to AGPRs (else they travel through VGPR copies between phases)
-    asm volatile("" : "+a"(accs[0][0]), "+a"(accs[0][1]), "+a"(accs[1][0]), "+a"(accs[1][1]));
+    if constexpr (NB == 1 && NCH == 1)
+      asm volatile("" : "+a"(accs[0][0]), "+a"(accs[0][1]), "+a"(accs[1][0]), "+a"(accs[1][1]));
     WS2_STAMP(4)
   };
 
@@ -1816,15 +1839,15 @@ inline int ws_cfg(int mode, int Do, int Ho, int Wo, int row_bytes) {
   return (row_bytes == 32 || row_bytes == 64 || row_bytes == 128) ? 1 : 0;
 }
 
-template <typename T, int CH, int RB>
+template <typename T, int CH, int RB, int NB>
 int launch_ws2(const ConvArgs& a, hipStream_t st) {
   const int tiles = a.N * ceil_div(a.Do, 4) * ceil_div(a.Ho, 8) * ceil_div(a.Wo, 8);
-  const int cout_tiles = a.CoutP / 32;
+  const int cout_tiles = a.CoutP / (32 * NB);
   const int gx = std::min(tiles, std::max(1, 256 / cout_tiles));  // one workgroup per CU; the kernel splits the tiles
   if (a.in_scale)
-    hipLaunchKernelGGL((conv_ws2_kernel<T, CH, RB, true>), dim3(gx, cout_tiles), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_ws2_kernel<T, CH, RB, true, NB>), dim3(gx, cout_tiles), dim3(256), 0, st, a);
   else
-    hipLaunchKernelGGL((conv_ws2_kernel<T, CH, RB, false>), dim3(gx, cout_tiles), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_ws2_kernel<T, CH, RB, false, NB>), dim3(gx, cout_tiles), dim3(256), 0, st, a);
   HDF_LAUNCH_CHECK();
   return HDF_OK;
 }
@@ -1835,9 +1858,11 @@ int launch_conv_t(int mode, const ConvArgs& a, hipStream_t st) {
     const int rb = a.Cin * (int)sizeof(T);
     const int ws = ws_cfg(mode, a.Do, a.Ho, a.Wo, rb);
     if (ws) {
-      if (rb == 32) return launch_ws2<T, 32, 32>(a, st);
-      if (rb == 64) return launch_ws2<T, 64, 64>(a, st);
-      if (rb == 128) return launch_ws2<T, 32, 128>(a, st);
+      static const bool nb2 = getenv("HDF_WS_NB1") == nullptr;  // A/B knob
+      if (rb == 32) return launch_ws2<T, 32, 32, 1>(a, st);
+      if (rb == 64 && a.CoutP % 64 == 0 && nb2) return launch_ws2<T, 32, 64, 2>(a, st);
+      if (rb == 64) return launch_ws2<T, 64, 64, 1>(a, st);
+      if (rb == 128) return launch_ws2<T, 32, 128, 1>(a, st);
     }
     if (tiny_tile(a.Do, a.Ho, a.Wo)) return launch_cfg<T, 2, 4, 8, 2, 2, 1, 1, false>(a, st);   // 64 vox x 64 ch
     if (small_tile(a.Do, a.Ho, a.Wo)) return launch_cfg<T, 4, 4, 8, 2, 2, 2, 1, false>(a, st);  // 128 vox x 64 ch
