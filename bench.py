@@ -148,11 +148,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world and world == 1 and a.gpus > 1:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    # HDF_BENCH_ONE_DEVICE=1 (diagnostic): every rank on cuda:0 over gloo, to exercise the multi-rank path on a
+    # single-GPU box; the measured run is one rank per GPU over RCCL ("nccl")
+    one_dev = os.environ.get("HDF_BENCH_ONE_DEVICE") == "1"
+    if one_dev:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if one_dev:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from hdf_rt import _lib
     _lib.lib()                                       # no fallback: fail here if the HIP extension is missing
