@@ -306,6 +306,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 // MFMA row (0..31) -> (dz in 0..3, x in 0..7).  ds_read_b128 services lanes {0-3,12-15,20-27} and {4-11,16-19,
 // 28-31} (and the same +32) as groups; group 1 gets z in {0,2}, group 2 z in {1,3}: box row = 100*z + 10*y + x
 // (BH = BW = 10) is then distinct mod 16 inside each group.
+constexpr int WS_STAT_ROWS = 512;  // conv_ws2_kernel: InstanceNorm partial rows per sample (2 passes x 256 workgroup slots)
 __device__ __forceinline__ void ws_row_to_zx(int r, int& dz, int& x) {
   const int g2 = ((r >= 4 && r < 12) || (r >= 16 && r < 20) || r >= 28) ? 1 : 0;
   const int rank = g2 ? (r < 12 ? r - 4 : (r < 20 ? r - 8 : r - 16)) : (r < 4 ? r : (r < 16 ? r - 8 : r - 12));
@@ -687,21 +688,49 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
     eplane[q4] = dz * a.Ho * a.Wo * (int)a.out_pitch;
   }
   auto eoff = [&](int i) { return eplane[i >> 2] + ((i & 3) + 4 * ((i >> 2) & 1)) * (int)a.out_pitch; };
-  int pend_tile = -1;  // tile whose per-wave InstanceNorm partials wait in s_red for the next barrier
+  int pend_tile = -1;  // >= 0: a tile's per-wave InstanceNorm partials wait in s_red for the next barrier
+  int pend_n = 0;      // its sample
   int sr_sel = 0, pend_sel = 0;  // s_red halves alternate per WRITE (a workgroup's consecutive tiles are 32 apart
                                  // in raster order, so their linear index has one parity)
+  // InstanceNorm partial rows are per WORKGROUP, not per tile: sample n owns WS_STAT_ROWS rows, row
+  // pass * 256 + blockIdx.x (+ k gridDim.x for the slots no workgroup has) holds this workgroup's sums over its
+  // tiles of n in that pass.  Threads tid < NC keep the running sums in registers and add them to the row when the
+  // sample changes / the pass ends; the rows are zeroed here first, so in_finalize reads 512 rows instead of one per tile.
+  float racc1 = 0.f, racc2 = 0.f;
+  int racc_n = -1, cur_pass = 0;
+  auto stat_row = [&](int n, int pass, int b) {
+    return a.stat_partials + (((int64_t)n * WS_STAT_ROWS + pass * 256 + b) * a.CoutP + n0 + tid) * 2;
+  };
+  if (a.stat_partials && tid < NC) {
+    for (int n = 0; n < a.N; n++)
+      for (int pass = 0; pass < 2; pass++)
+        for (int b = blockIdx.x; b < 256; b += gridDim.x) {
+          float* q = stat_row(n, pass, b);
+          q[0] = 0.f;
+          q[1] = 0.f;
+        }
+  }
+  auto stats_to_row = [&]() {
+    if (a.stat_partials && tid < NC && racc_n >= 0) {
+      float* q = stat_row(racc_n, cur_pass, blockIdx.x);
+      q[0] += racc1;
+      q[1] += racc2;
+    }
+    racc1 = racc2 = 0.f;
+    racc_n = -1;
+  };
   auto flush_stats = [&]() {
+    if (pend_n != racc_n) {
+      stats_to_row();
+      racc_n = pend_n;
+    }
     if (a.stat_partials && tid < NC) {
       const float* sr = s_red + pend_sel * (256 * NB);
-      float t1 = 0.f, t2 = 0.f;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        t1 += sr[(k * NC + tid) * 2 + 0];
-        t2 += sr[(k * NC + tid) * 2 + 1];
+        racc1 += sr[(k * NC + tid) * 2 + 0];
+        racc2 += sr[(k * NC + tid) * 2 + 1];
       }
-      float* q = a.stat_partials + ((int64_t)pend_tile * a.CoutP + n0 + tid) * 2;
-      q[0] = t1;
-      q[1] = t2;
     }
     pend_tile = -1;
   };
@@ -779,6 +808,7 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
     }
     if (a.stat_partials) {
       pend_tile = ET.tile;
+      pend_n = ET.n;
       pend_sel = sr_sel;
       sr_sel ^= 1;
     }
@@ -881,6 +911,7 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
             sr[(wave * 32 + r) * 2 + 0] = ds1;
             sr[(wave * 32 + r) * 2 + 1] = ds2;
             pend_tile = PT.tile;
+            pend_n = PT.n;
             pend_sel = sr_sel;
             sr_sel ^= 1;
           }
@@ -985,7 +1016,10 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
   }
   // ---- pass B: border tiles (checked copy, immediate epilogue)
   if (bor_cnt > 0) {
-    begin_pass(Yes{}, bor_begin, bor_cnt);
+    begin_pass(Yes{}, bor_begin, bor_cnt);  // (its barrier publishes the last interior tile's s_red row)
+    if (pend_tile >= 0) flush_stats();
+    stats_to_row();
+    cur_pass = 1;
     more = true;
     int par = 0;
     while (more) {
@@ -1001,6 +1035,7 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
     __syncthreads();
     flush_stats();
   }
+  stats_to_row();
 #ifdef WS_DBG_STAMPS
   if (tid == 0 && blockIdx.y == 0)
     for (int k = 0; k < 8; k++) a.stat_partials[(int64_t)blockIdx.x * 8 + k] = (float)tacc[k];
@@ -1922,6 +1957,7 @@ int launch_wgrad_t(WgradArgs a, float* dw, int sc_store, int lc_store, int accum
 
 int hdf_conv_stat_tiles(int mode, int Do, int Ho, int Wo, int row_bytes) {
   if (mode != 0) return 0;
+  if (ws_cfg(mode, Do, Ho, Wo, row_bytes)) return WS_STAT_ROWS;  // per-workgroup rows (conv_ws2_kernel)
   if (tiny_tile(Do, Ho, Wo)) return ceil_div(Do, 2) * ceil_div(Ho, 4) * ceil_div(Wo, 8);
   if (small_tile(Do, Ho, Wo)) return ceil_div(Do, 4) * ceil_div(Ho, 4) * ceil_div(Wo, 8);
   return ceil_div(Do, 4) * ceil_div(Ho, 8) * ceil_div(Wo, 8);

@@ -342,7 +342,8 @@ void layout(hdf_plan* p, int B) {
   // ---- scratch shared by forward and backward
   size_t maxtiles = 0;
   for (int l = 0; l < 5; l++)
-    maxtiles = std::max<size_t>(maxtiles, hdf_conv_stat_tiles(0, p->dims[l][0], p->dims[l][1], p->dims[l][2], 1 << 20));
+    for (int rb : {32, 1 << 20})  // weights-stationary (per-workgroup rows) and tiled (per-tile rows) geometry
+      maxtiles = std::max<size_t>(maxtiles, hdf_conv_stat_tiles(0, p->dims[l][0], p->dims[l][1], p->dims[l][2], rb));
   p->stat_partials = bp.take((size_t)B * maxtiles * round_up(8 * nf, 32) * 2 * sizeof(float));
   // ---- backward scratch
   p->tf_scratch = bp.take((size_t)rows * std::max(160, p->DM) * sizeof(float));

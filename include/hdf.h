@@ -113,7 +113,8 @@ int hdf_op_pack_weights(int dtype, const float* src, void* dst, int O, int I, in
 int hdf_op_conv3d(int dtype, int mode, const void* in, int64_t in_pitch, int Cin, int N, int Di, int Hi, int Wi,
                   const void* w_packed, const float* bias, const float* in_scale, const float* in_shift, int in_relu,
                   void* out, int64_t out_pitch, int Cout, float* stat_partials, int accumulate, hdf_stream stream);
-/* tiles per sample of stat_partials ([N*tiles][Cout rounded up to 32][2] floats) for this layer shape */
+/* partial rows per sample of stat_partials ([N*rows][Cout rounded up to 32][2] floats: sum, sum of squares) for this
+ * layer shape: one row per output tile, or 512 per-workgroup rows when the weights-stationary kernel takes the layer */
 int hdf_op_conv3d_stat_tiles(int dtype, int Cin, int Do, int Ho, int Wo);
 int64_t hdf_op_wgrad_workspace_bytes(int stride, int N, int Ds, int Hs, int Ws, int SC, int LC);
 /* dW[sc][lc][27] = sum S[i][sc] * L[stride*i-1+tap][lc]  (torch weight layout for both Conv3d and ConvTranspose3d) */
