@@ -48,11 +48,46 @@ __device__ __forceinline__ float dot_col(const float* __restrict__ w, int ld, in
 // each load touch 32 different cache lines.  Instead the [O][K] matrix is staged once per workgroup with
 // coalesced loads into LDS rows of ODD stride (K+1 floats): "lane = row" reads (forward) and "lane = column"
 // reads (transposed products in backward) are both bank-conflict free on the same image.
+// The loads are float4 (every parameter starts on a 64-byte boundary, K % 4 == 0) and SU of them are in flight per
+// thread before the first LDS store: one memory round trip per 8192 floats instead of one per 256.
+constexpr int SU = 8;
 __device__ __forceinline__ void stage_w(float* sW, const float* __restrict__ gW, int O, int K) {
-  const int ldw = K + 1;
-  for (int i = threadIdx.x; i < O * K; i += 256) {
-    int o = i / K, k = i - o * K;
-    sW[o * ldw + k] = gW[i];
+  const int ldw = K + 1, total4 = (O * K) >> 2;
+  const float4* g4 = reinterpret_cast<const float4*>(gW);
+  for (int base = threadIdx.x; base < total4; base += 256 * SU) {
+    float4 v[SU];
+#pragma unroll
+    for (int u = 0; u < SU; u++) v[u] = g4[min(base + 256 * u, total4 - 1)];
+#pragma unroll
+    for (int u = 0; u < SU; u++) {
+      const int i = (base + 256 * u) * 4;
+      if (i < 4 * total4) {
+        const int o = i / K, k = i - o * K;
+        float* q = sW + o * ldw + k;
+        q[0] = v[u].x, q[1] = v[u].y, q[2] = v[u].z, q[3] = v[u].w;
+      }
+    }
+  }
+}
+// TB token rows of K floats (row t of the modality's [BN][ld] matrix, rows past BN: clamped or zero) -> sX[TB][K]
+template <bool ZERO>
+__device__ __forceinline__ void stage_rows(float* sX, const float* __restrict__ gX, int64_t ld, int K, int t0, int BN) {
+  const int total4 = (TB * K) >> 2;
+  for (int base = threadIdx.x; base < total4; base += 256 * SU) {
+    float4 v[SU];
+#pragma unroll
+    for (int u = 0; u < SU; u++) {
+      const int i = min(base + 256 * u, total4 - 1) * 4, tl = i / K, k = i - tl * K;
+      v[u] = *reinterpret_cast<const float4*>(gX + (int64_t)min(t0 + tl, BN - 1) * ld + k);
+    }
+#pragma unroll
+    for (int u = 0; u < SU; u++) {
+      const int i = (base + 256 * u) * 4;
+      if (i < 4 * total4) {
+        if (ZERO && t0 + i / K >= BN) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(sX + i) = v[u];
+      }
+    }
   }
 }
 // sum_k sWrow[k] * sv[k]   (sv 16-byte aligned, K % 4 == 0)
@@ -138,10 +173,7 @@ __global__ __launch_bounds__(256) void dense_pre_fwd_kernel(TfDims d, int K, TfL
   float* s_wq = s_w0 + 32 * (K + 1);       // [96][33]
   const int m = blockIdx.y, BN = d.B * d.N, o = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int64_t mo = (int64_t)m * d.mstride;
-  for (int i = threadIdx.x; i < TB * K; i += 256) {
-    int tl = i / K, k = i - tl * K, t = min(blockIdx.x * TB + tl, BN - 1);
-    s_in[i] = F[((int64_t)m * BN + t) * d.DMF + k];
-  }
+  stage_rows<false>(s_in, F + (int64_t)m * BN * d.DMF, d.DMF, K, blockIdx.x * TB, BN);
   stage_w(s_w0, p.w0 + mo, 32, K);
   stage_w(s_wq, p.wqkv + mo, 96, 32);
   __syncthreads();
@@ -170,7 +202,9 @@ __global__ __launch_bounds__(256) void dense_pre_fwd_kernel(TfDims d, int K, TfL
 }
 
 // ------------------------------------------------------------------------------ K2: attention
-// grid (ceil(N/64), 8 heads, M*B).  4 lanes per query, keys interleaved over the 4 lanes.
+// grid (ceil(N/AQ), 8 heads, M*B).  QL lanes per query, keys interleaved over the QL lanes (QL = 8: 4 workgroups
+// per CU at N = 512, and the serial key loop of a lane is N / (QL * AU) trips).
+constexpr int QL = 8, AQ = 256 / QL;
 __global__ __launch_bounds__(256) void attn_fwd_kernel(int N, const float* __restrict__ qkv, float* __restrict__ ob,
                                                        float* __restrict__ lse) {
   extern __shared__ float4 skv[];
@@ -184,7 +218,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(int N, const float* __res
     sV[i] = *reinterpret_cast<const float4*>(r + 64 + head * 4);
   }
   __syncthreads();
-  const int qi = blockIdx.x * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
+  const int qi = blockIdx.x * AQ + threadIdx.x / QL, sub = threadIdx.x % QL;
   const bool ok = qi < N;
   float4 q = ok ? *reinterpret_cast<const float4*>(qkv + (rowbase + qi) * 96 + head * 4) : make_float4(0, 0, 0, 0);
   q.x *= 0.5f, q.y *= 0.5f, q.z *= 0.5f, q.w *= 0.5f;  // dim_head^-0.5 with dim_head = 4
@@ -192,12 +226,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(int N, const float* __res
   // AU keys per trip: the loop is a latency chain (LDS read -> dot -> exp -> rescale) at 2 waves per SIMD, so the
   // AU independent score/exp chains of one trip are what fills the pipes; one running-max update per trip
   constexpr int AU = 4;
-  for (int j0 = sub; j0 < N; j0 += 4 * AU) {
+  for (int j0 = sub; j0 < N; j0 += QL * AU) {
     float4 k[AU], v[AU];
     float sc[AU];
 #pragma unroll
     for (int u = 0; u < AU; u++) {
-      const int j = min(j0 + 4 * u, N - 1);
+      const int j = min(j0 + QL * u, N - 1);
       k[u] = sK[j];
       v[u] = sV[j];
     }
@@ -205,14 +239,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(int N, const float* __res
 #pragma unroll
     for (int u = 0; u < AU; u++) {
       float t = q.x * k[u].x + q.y * k[u].y + q.z * k[u].z + q.w * k[u].w;
-      sc[u] = (j0 + 4 * u < N) ? t : -INFINITY;
+      sc[u] = (j0 + QL * u < N) ? t : -INFINITY;
       mn = fmaxf(mn, sc[u]);
     }
-    const float c = __expf(mx - mn);
+    const float mr = (mn == -INFINITY) ? 0.f : mn;  // a lane with no key yet (N < QL): exp(-inf - mr) = 0, not NaN
+    const float c = __expf(mx - mr);
     float ps = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
 #pragma unroll
     for (int u = 0; u < AU; u++) {
-      const float pr = __expf(sc[u] - mn);
+      const float pr = __expf(sc[u] - mr);
       ps += pr;
       b0 += pr * v[u].x, b1 += pr * v[u].y, b2 += pr * v[u].z, b3 += pr * v[u].w;
     }
@@ -221,12 +256,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(int N, const float* __res
     mx = mn;
   }
 #pragma unroll
-  for (int off = 1; off <= 2; off <<= 1) {
+  for (int off = 1; off < QL; off <<= 1) {
     float m2 = __shfl_xor(mx, off, 64), l2 = __shfl_xor(l, off, 64);
     float b0 = __shfl_xor(a0, off, 64), b1 = __shfl_xor(a1, off, 64), b2 = __shfl_xor(a2, off, 64),
           b3 = __shfl_xor(a3, off, 64);
     float mn = fmaxf(mx, m2);
-    float ca = __expf(mx - mn), cb = __expf(m2 - mn);
+    const float mr = (mn == -INFINITY) ? 0.f : mn;
+    float ca = __expf(mx - mr), cb = __expf(m2 - mr);
     l = l * ca + l2 * cb;
     a0 = a0 * ca + b0 * cb, a1 = a1 * ca + b1 * cb, a2 = a2 * ca + b2 * cb, a3 = a3 * ca + b3 * cb;
     mx = mn;
@@ -252,7 +288,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(int N, int seq, const float* __
     sV[i] = *reinterpret_cast<const float4*>(r + 64 + head * 4);
   }
   __syncthreads();
-  const int qi = blockIdx.x * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
+  const int qi = blockIdx.x * AQ + threadIdx.x / QL, sub = threadIdx.x % QL;
   const bool ok = qi < N;
   const int64_t R = rowbase + (ok ? qi : 0);
   float4 q = *reinterpret_cast<const float4*>(qkv + R * 96 + head * 4);
@@ -263,24 +299,24 @@ __device__ __forceinline__ void attn_bwd_dq_body(int N, int seq, const float* __
   const float ls = lse[R * 8 + head];
   float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
   constexpr int AU = 4;  // independent chains per trip (see attn_fwd_kernel)
-  for (int j0 = sub; j0 < N; j0 += 4 * AU) {
+  for (int j0 = sub; j0 < N; j0 += QL * AU) {
     float4 k[AU], v[AU];
 #pragma unroll
     for (int u = 0; u < AU; u++) {
-      const int j = min(j0 + 4 * u, N - 1);
+      const int j = min(j0 + QL * u, N - 1);
       k[u] = sK[j];
       v[u] = sV[j];
     }
 #pragma unroll
     for (int u = 0; u < AU; u++) {
       float s = q.x * k[u].x + q.y * k[u].y + q.z * k[u].z + q.w * k[u].w;
-      float pr = (j0 + 4 * u < N) ? __expf(s - ls) : 0.f;
+      float pr = (j0 + QL * u < N) ? __expf(s - ls) : 0.f;
       float ds = pr * (go.x * v[u].x + go.y * v[u].y + go.z * v[u].z + go.w * v[u].w - delta);
       d0 += ds * k[u].x, d1 += ds * k[u].y, d2 += ds * k[u].z, d3 += ds * k[u].w;
     }
   }
 #pragma unroll
-  for (int off = 1; off <= 2; off <<= 1) {
+  for (int off = 1; off < QL; off <<= 1) {
     d0 += __shfl_xor(d0, off, 64), d1 += __shfl_xor(d1, off, 64), d2 += __shfl_xor(d2, off, 64),
         d3 += __shfl_xor(d3, off, 64);
   }
@@ -288,7 +324,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(int N, int seq, const float* __
     *reinterpret_cast<float4*>(dqkv + R * 96 + head * 4) = make_float4(0.5f * d0, 0.5f * d1, 0.5f * d2, 0.5f * d3);
 }
 
-// dK, dV: 4 lanes per key, queries interleaved over the 4 lanes
+// dK, dV: QL lanes per key, queries interleaved over the QL lanes
 __device__ __forceinline__ void attn_bwd_dkv_body(int N, int seq, const float* __restrict__ qkv,
                                                   const float* __restrict__ ob, const float* __restrict__ lse,
                                                   const float* __restrict__ dO, float* __restrict__ dqkv, float4* skv) {
@@ -307,19 +343,19 @@ __device__ __forceinline__ void attn_bwd_dkv_body(int N, int seq, const float* _
     sL[i] = make_float2(lse[(rowbase + i) * 8 + head], go.x * oo.x + go.y * oo.y + go.z * oo.z + go.w * oo.w);
   }
   __syncthreads();
-  const int kj = blockIdx.x * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
+  const int kj = blockIdx.x * AQ + threadIdx.x / QL, sub = threadIdx.x % QL;
   const bool ok = kj < N;
   const int64_t R = rowbase + (ok ? kj : 0);
   const float4 k = *reinterpret_cast<const float4*>(qkv + R * 96 + 32 + head * 4);
   const float4 v = *reinterpret_cast<const float4*>(qkv + R * 96 + 64 + head * 4);
   float k0 = 0.f, k1 = 0.f, k2 = 0.f, k3 = 0.f, v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
   constexpr int AU = 4;  // independent chains per trip (see attn_fwd_kernel)
-  for (int i0 = sub; i0 < N; i0 += 4 * AU) {
+  for (int i0 = sub; i0 < N; i0 += QL * AU) {
     float4 q[AU], go[AU];
     float2 ld[AU];
 #pragma unroll
     for (int u = 0; u < AU; u++) {
-      const int i = min(i0 + 4 * u, N - 1);
+      const int i = min(i0 + QL * u, N - 1);
       q[u] = sQ[i];
       go[u] = sG[i];
       ld[u] = sL[i];
@@ -327,14 +363,14 @@ __device__ __forceinline__ void attn_bwd_dkv_body(int N, int seq, const float* _
 #pragma unroll
     for (int u = 0; u < AU; u++) {
       float pr = __expf(q[u].x * k.x + q[u].y * k.y + q[u].z * k.z + q[u].w * k.w - ld[u].x);
-      pr = (i0 + 4 * u < N) ? pr : 0.f;
+      pr = (i0 + QL * u < N) ? pr : 0.f;
       v0 += pr * go[u].x, v1 += pr * go[u].y, v2 += pr * go[u].z, v3 += pr * go[u].w;
       float ds = pr * (go[u].x * v.x + go[u].y * v.y + go[u].z * v.z + go[u].w * v.w - ld[u].y);
       k0 += ds * q[u].x, k1 += ds * q[u].y, k2 += ds * q[u].z, k3 += ds * q[u].w;
     }
   }
 #pragma unroll
-  for (int off = 1; off <= 2; off <<= 1) {
+  for (int off = 1; off < QL; off <<= 1) {
     k0 += __shfl_xor(k0, off, 64), k1 += __shfl_xor(k1, off, 64), k2 += __shfl_xor(k2, off, 64),
         k3 += __shfl_xor(k3, off, 64);
     v0 += __shfl_xor(v0, off, 64), v1 += __shfl_xor(v1, off, 64), v2 += __shfl_xor(v2, off, 64),
@@ -527,10 +563,7 @@ __global__ __launch_bounds__(256) void dense_pre_bwd_kernel(TfDims d, int K, TfL
   float xh[4], rs[4];
   stage_w(s_w0, p.w0 + mo, 32, K);
   stage_w(s_wq, p.wqkv + mo, 96, 32);
-  for (int i = threadIdx.x; i < TB * K; i += 256) {
-    int tl = i / K, k = i - tl * K, t = blockIdx.x * TB + tl;
-    s_in[i] = sel0(t < BN, F[((int64_t)m * BN + min(t, BN - 1)) * d.DMF + k]);
-  }
+  stage_rows<true>(s_in, F + (int64_t)m * BN * d.DMF, d.DMF, K, blockIdx.x * TB, BN);
   TOK_LOOP(j, tl, t, ok, R) {
     float h = sel0(ok, h0[R * 32 + o]);
     float mean = hsum32(h) * (1.f / 32.f);
@@ -564,11 +597,23 @@ __global__ __launch_bounds__(256) void dense_pre_bwd_kernel(TfDims d, int K, TfL
   }
   outer_acc(g.w0 + mo, 32, K, s_dh, 32, s_in, K);
   col_acc(g.b0 + mo, 32, s_dh, 32);
-  for (int i = threadIdx.x; i < TB * K; i += 256) {
-    int tl = i / K, k = i - tl * K, t = blockIdx.x * TB + tl;
-    if (t < BN) {
-      float v = dot_col_lds(s_w0, K + 1, k, s_dh + tl * 32, 32);
-      dF[((int64_t)m * BN + t) * d.DMF + k] += v;
+  // dF[:, 0:K] += W0^T dh0, SU read-modify-writes in flight per thread (each element has one owner)
+  for (int base = threadIdx.x; base < TB * K; base += 256 * SU) {
+    float cur[SU];
+    float* q[SU];
+    bool okv[SU];
+#pragma unroll
+    for (int u = 0; u < SU; u++) {
+      const int i = min(base + 256 * u, TB * K - 1), tl = i / K, k = i - tl * K, t = blockIdx.x * TB + tl;
+      okv[u] = (base + 256 * u < TB * K) & (t < BN);
+      q[u] = dF + ((int64_t)m * BN + min(t, BN - 1)) * d.DMF + k;
+      cur[u] = *q[u];
+    }
+#pragma unroll
+    for (int u = 0; u < SU; u++) {
+      const int i = min(base + 256 * u, TB * K - 1), tl = i / K, k = i - tl * K;
+      const float v = dot_col_lds(s_w0, K + 1, k, s_dh + tl * 32, 32);
+      if (okv[u]) *q[u] = cur[u] + v;
     }
   }
 }
@@ -588,10 +633,7 @@ __global__ __launch_bounds__(256) void block_out_fwd_kernel(TfDims d, int block,
   const int64_t mo = (int64_t)m * d.mstride;
   const Drop dr = make_drop(d);
   const uint32_t site0 = hdf_site_id(m, block, 4, 0);
-  for (int i = threadIdx.x; i < TB * K; i += 256) {
-    int tl = i / K, k = i - tl * K, t = min(blockIdx.x * TB + tl, BN - 1);
-    s_in[i] = F[((int64_t)m * BN + t) * d.DMF + k];
-  }
+  stage_rows<false>(s_in, F + (int64_t)m * BN * d.DMF, d.DMF, K, blockIdx.x * TB, BN);
   stage_w(s_wa, p.wa + mo, 64, K);
   if (stage_wb) stage_w(s_wb, p.wb + mo, d.DM, 64);
   __syncthreads();
@@ -631,7 +673,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void block_out_bwd_kernel(TfDims d, int block, TfOutP p, TfOutP g,
                                                             const float* __restrict__ F,
                                                             const float* __restrict__ dF_next,
-                                                            const T* __restrict__ d_attnall, float* __restrict__ dF) {
+                                                            const T* __restrict__ d_attnall, float* __restrict__ dF,
+                                                            int stage_wb) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int K = d.DMF, DM = d.DM;
   float* s_in = sm;                // [TB][K]
@@ -639,28 +682,39 @@ __global__ __launch_bounds__(256) void block_out_bwd_kernel(TfDims d, int block,
   float* s_dz = s_f + TB * 64;     // [TB][64]
   float* s_do = s_dz + TB * 64;    // [TB][DM]
   float* s_wa = s_do + TB * DM;    // [64][K+1]
+  float* s_wb = s_wa + 64 * (K + 1);  // [DM][65] (only if it fits)
   const int m = blockIdx.y, BN = d.B * d.N, o = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int64_t mo = (int64_t)m * d.mstride;
   const Drop dr = make_drop(d);
   const uint32_t site0 = hdf_site_id(m, block, 4, 0);
-  for (int i = threadIdx.x; i < TB * K; i += 256) {
-    int tl = i / K, k = i - tl * K, t = blockIdx.x * TB + tl;
-    s_in[i] = sel0(t < BN, F[((int64_t)m * BN + min(t, BN - 1)) * d.DMF + k]);
-  }
-  for (int i = threadIdx.x; i < TB * DM; i += 256) {
-    int tl = i / DM, c = i - tl * DM, t = blockIdx.x * TB + tl;
-    float v = 0.f;
-    if (t < BN) {
-      if (dF_next)
-        v = dF_next[((int64_t)m * BN + t) * d.DMF + c];
-      else {
-        int b = t / d.N, n = t - b * d.N;
-        v = ST<T>::ld(d_attnall + ((int64_t)b * d.N + n) * ((int64_t)d.M * DM) + (int64_t)m * DM + c);
+  stage_rows<true>(s_in, F + (int64_t)m * BN * d.DMF, d.DMF, K, blockIdx.x * TB, BN);
+  // upstream gradient rows (next block's dF, or the attnall gradient in the conv dtype), SU loads in flight
+  auto stage_do = [&](auto load) __attribute__((always_inline)) {
+    for (int base = threadIdx.x; base < TB * DM; base += 256 * SU) {
+      float v[SU];
+#pragma unroll
+      for (int u = 0; u < SU; u++) {
+        const int i = min(base + 256 * u, TB * DM - 1), tl = i / DM, c = i - tl * DM;
+        v[u] = load(min(blockIdx.x * TB + tl, BN - 1), c);
       }
-      v *= dr.mask(site0 + 1, (uint32_t)t * DM + c);
+#pragma unroll
+      for (int u = 0; u < SU; u++) {
+        const int i = base + 256 * u;
+        if (i < TB * DM) {
+          const int tl = i / DM, c = i - tl * DM, t = blockIdx.x * TB + tl;
+          s_do[i] = t < BN ? v[u] * dr.mask(site0 + 1, (uint32_t)t * DM + c) : 0.f;
+        }
+      }
     }
-    s_do[i] = v;
-  }
+  };
+  if (dF_next)
+    stage_do([&](int t, int c) { return dF_next[((int64_t)m * BN + t) * d.DMF + c]; });
+  else
+    stage_do([&](int t, int c) {
+      const int b = t / d.N, n = t - b * d.N;
+      return ST<T>::ld(d_attnall + ((int64_t)b * d.N + n) * ((int64_t)d.M * DM) + (int64_t)m * DM + c);
+    });
+  if (stage_wb) stage_w(s_wb, p.wb + mo, DM, 64);
   stage_w(s_wa, p.wa + mo, 64, K);
   __syncthreads();
 #pragma unroll
@@ -672,7 +726,8 @@ __global__ __launch_bounds__(256) void block_out_bwd_kernel(TfDims d, int block,
       float z = p.ba[mo + jj] + zacc[j];
       float mk = dr.mask(site0 + 0, (uint32_t)t * 64 + jj);
       s_f[tl * 64 + jj] = ok ? gelu_f(z) * mk : 0.f;
-      float df = dot_col(p.wb + mo, 64, jj, s_do + tl * DM, DM);  // lanes = consecutive columns: coalesced
+      float df = stage_wb ? dot_col_lds(s_wb, 65, jj, s_do + tl * DM, DM)
+                          : dot_col(p.wb + mo, 64, jj, s_do + tl * DM, DM);  // lanes = consecutive columns: coalesced
       s_dz[tl * 64 + jj] = ok ? df * mk * gelu_grad(z) : 0.f;
     }
   }
@@ -914,7 +969,7 @@ int tf_layer_fwd(const TfDims& d, int block, int layer, const TfLayerP& p, float
   HDF_TRY(allow_lds(dense_pre_fwd_kernel, shm));
   hipLaunchKernelGGL(dense_pre_fwd_kernel, grid, dim3(256), shm, st, d, K, p, F, s.h0, s.qkv);
   HDF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(ceil_div(d.N, 64), 8, d.M * d.B), dim3(256), (size_t)d.N * 32, st, d.N,
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(ceil_div(d.N, AQ), 8, d.M * d.B), dim3(256), (size_t)d.N * 32, st, d.N,
                      s.qkv, s.ob, s.lse);
   HDF_LAUNCH_CHECK();
   hipLaunchKernelGGL(dense_post_fwd_kernel, grid, dim3(256), 0, st, d, block, layer, p, s.h0, s.ob, s.h1, s.h2, F);
@@ -933,7 +988,7 @@ int tf_layer_bwd(const TfDims& d, int block, int layer, const TfLayerP& p, const
   hipLaunchKernelGGL(dense_post_bwd_kernel, grid, dim3(256), 0, st, d, block, layer, p, g, s.h1, s.h2, s.ob, dF, dO,
                      dh0acc);
   HDF_LAUNCH_CHECK();
-  dim3 ag(ceil_div(d.N, 64), 8, 2 * d.M * d.B);
+  dim3 ag(ceil_div(d.N, AQ), 8, 2 * d.M * d.B);
   hipLaunchKernelGGL(attn_bwd_kernel, ag, dim3(256), (size_t)d.N * 40, st, d.N, d.M * d.B, s.qkv, s.ob, s.lse, dO, dqkv);
   HDF_LAUNCH_CHECK();
   size_t shm = (size_t)(TB * K + TB * 32 + TB * 96 + TB * 32 + 8 * 32 * 2 + 32 * (K + 1) + 96 * 33) * sizeof(float);
@@ -966,16 +1021,19 @@ int tf_block_out_fwd(const TfDims& d, int block, const TfOutP& p, const float* F
 int tf_block_out_bwd(const TfDims& d, int block, const TfOutP& p, const TfOutP& g, const float* F,
                      const float* dF_next, const void* d_attnall, int dtype, float* dF, hipStream_t st) {
   dim3 grid(ceil_div(d.B * d.N, TB), d.M);
-  size_t shm = (size_t)(TB * d.DMF + TB * 64 * 2 + TB * d.DM + 64 * (d.DMF + 1)) * sizeof(float);
+  size_t base = (size_t)(TB * d.DMF + TB * 64 * 2 + TB * d.DM + 64 * (d.DMF + 1)) * sizeof(float);
+  size_t with_wb = base + (size_t)d.DM * 65 * sizeof(float);
+  const int stage_wb = with_wb <= LDS_LIMIT ? 1 : 0;
+  size_t shm = stage_wb ? with_wb : base;
   HDF_CHECK_ARG(shm <= LDS_LIMIT, "block_out_bwd: token dim %d needs %zu B of LDS", d.DM, shm);
   HDF_TRY(allow_lds(block_out_bwd_kernel<bf16_t>, shm));
   HDF_TRY(allow_lds(block_out_bwd_kernel<float>, shm));
   if (dtype == HDF_BF16)
     hipLaunchKernelGGL(block_out_bwd_kernel<bf16_t>, grid, dim3(256), shm, st, d, block, p, g, F, dF_next,
-                       (const bf16_t*)d_attnall, dF);
+                       (const bf16_t*)d_attnall, dF, stage_wb);
   else
     hipLaunchKernelGGL(block_out_bwd_kernel<float>, grid, dim3(256), shm, st, d, block, p, g, F, dF_next,
-                       (const float*)d_attnall, dF);
+                       (const float*)d_attnall, dF, stage_wb);
   HDF_LAUNCH_CHECK();
   return HDF_OK;
 }
