@@ -202,75 +202,119 @@ __global__ __launch_bounds__(256) void dense_pre_fwd_kernel(TfDims d, int K, TfL
 }
 
 // ------------------------------------------------------------------------------ K2: attention
-// grid (ceil(N/AQ), 8 heads, M*B).  QL lanes per query, keys interleaved over the QL lanes (QL = 8: 4 workgroups
-// per CU at N = 512, and the serial key loop of a lane is N / (QL * AU) trips).
-constexpr int QL = 8, AQ = 256 / QL;
+// grid (ceil(N/AQ), 8 heads, M*B).  QL lanes per query, keys interleaved over the QL lanes.  The pair loops are
+// VALU-bound (N^2 pairs x 8 heads x M*B sequences, head dim 4), so they are written on 2-wide fp32 vectors
+// (v_pk_mul/fma_f32), the exponentials are raw v_exp_f32 on scores pre-scaled by log2(e) (folded into the 0.5
+// query scale), and the LDS arrays are padded to whole trips so that only the fwd/dQ tail trip carries a mask
+// (dK/dV pads with lse = +inf: the probability of a padded query is exp2(-inf) = 0).
+constexpr int QL = 4, AQ = 256 / QL, AU = 4, ATRIP = QL * AU;
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 lo2(const float4& v) { return f2{v.x, v.y}; }
+__device__ __forceinline__ f2 hi2(const float4& v) { return f2{v.z, v.w}; }
+__device__ __forceinline__ float dot4(f2 a01, f2 a23, f2 b01, f2 b23) {
+  f2 t = a01 * b01;
+  t = __builtin_elementwise_fma(a23, b23, t);
+  return t.x + t.y;
+}
+__host__ __device__ inline int attn_rows(int N) { return (N + ATRIP - 1) / ATRIP * ATRIP; }
+
+// K and V rows of one (sequence, head) -> LDS, padded rows zero; 4 row pairs in flight per thread
+__device__ __forceinline__ void attn_stage_kv(int N, int NP, const float* __restrict__ qkv, int64_t rowbase, int head,
+                                              float4* sK, float4* sV) {
+  for (int base = threadIdx.x; base < NP; base += 256 * 4) {
+    float4 k[4], v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const float* r = qkv + (rowbase + min(base + 256 * u, N - 1)) * 96 + head * 4;
+      k[u] = *reinterpret_cast<const float4*>(r + 32);
+      v[u] = *reinterpret_cast<const float4*>(r + 64);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = base + 256 * u;
+      if (i < NP) {
+        const bool real = i < N;
+        sK[i] = real ? k[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        sV[i] = real ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void attn_fwd_kernel(int N, const float* __restrict__ qkv, float* __restrict__ ob,
                                                        float* __restrict__ lse) {
   extern __shared__ float4 skv[];
+  const int NP = attn_rows(N);
   float4* sK = skv;
-  float4* sV = skv + N;
+  float4* sV = skv + NP;
   const int head = blockIdx.y;
   const int64_t rowbase = (int64_t)blockIdx.z * N;
-  for (int i = threadIdx.x; i < N; i += 256) {
-    const float* r = qkv + (rowbase + i) * 96;
-    sK[i] = *reinterpret_cast<const float4*>(r + 32 + head * 4);
-    sV[i] = *reinterpret_cast<const float4*>(r + 64 + head * 4);
-  }
+  attn_stage_kv(N, NP, qkv, rowbase, head, sK, sV);
   __syncthreads();
   const int qi = blockIdx.x * AQ + threadIdx.x / QL, sub = threadIdx.x % QL;
   const bool ok = qi < N;
-  float4 q = ok ? *reinterpret_cast<const float4*>(qkv + (rowbase + qi) * 96 + head * 4) : make_float4(0, 0, 0, 0);
-  q.x *= 0.5f, q.y *= 0.5f, q.z *= 0.5f, q.w *= 0.5f;  // dim_head^-0.5 with dim_head = 4
-  float mx = -INFINITY, l = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  // AU keys per trip: the loop is a latency chain (LDS read -> dot -> exp -> rescale) at 2 waves per SIMD, so the
-  // AU independent score/exp chains of one trip are what fills the pipes; one running-max update per trip
-  constexpr int AU = 4;
-  for (int j0 = sub; j0 < N; j0 += QL * AU) {
+  const float4 q4 = *reinterpret_cast<const float4*>(qkv + (rowbase + (ok ? qi : 0)) * 96 + head * 4);
+  const f2 q01 = lo2(q4) * (0.5f * LOG2E), q23 = hi2(q4) * (0.5f * LOG2E);  // dim_head^-0.5 = 0.5; scores in log2 units
+  float mx = -INFINITY, l = 0.f;
+  f2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+  // AU keys per trip: the loop is a latency chain (LDS read -> dot -> exp -> rescale), so the AU independent
+  // score/exp chains of one trip are what fills the pipes; one running-max update per trip
+  auto trip = [&](int j0, auto masked) __attribute__((always_inline)) {
     float4 k[AU], v[AU];
     float sc[AU];
 #pragma unroll
     for (int u = 0; u < AU; u++) {
-      const int j = min(j0 + QL * u, N - 1);
-      k[u] = sK[j];
-      v[u] = sV[j];
+      k[u] = sK[j0 + QL * u];
+      v[u] = sV[j0 + QL * u];
     }
     float mn = mx;
 #pragma unroll
     for (int u = 0; u < AU; u++) {
-      float t = q.x * k[u].x + q.y * k[u].y + q.z * k[u].z + q.w * k[u].w;
-      sc[u] = (j0 + QL * u < N) ? t : -INFINITY;
+      sc[u] = dot4(q01, q23, lo2(k[u]), hi2(k[u]));
+      if (decltype(masked)::value) sc[u] = (j0 + QL * u < N) ? sc[u] : -INFINITY;
       mn = fmaxf(mn, sc[u]);
     }
-    const float mr = (mn == -INFINITY) ? 0.f : mn;  // a lane with no key yet (N < QL): exp(-inf - mr) = 0, not NaN
-    const float c = __expf(mx - mr);
-    float ps = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+    const float mr = (mn == -INFINITY) ? 0.f : mn;  // a lane with no key yet (N < QL): exp2(-inf - mr) = 0, not NaN
+    const float c = __builtin_amdgcn_exp2f(mx - mr);
+    float ps = 0.f;
+    f2 b01 = {0.f, 0.f}, b23 = {0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < AU; u++) {
-      const float pr = __expf(sc[u] - mr);
+      const float pr = __builtin_amdgcn_exp2f(sc[u] - mr);
+      const f2 pp = {pr, pr};
       ps += pr;
-      b0 += pr * v[u].x, b1 += pr * v[u].y, b2 += pr * v[u].z, b3 += pr * v[u].w;
+      b01 = __builtin_elementwise_fma(pp, lo2(v[u]), b01);
+      b23 = __builtin_elementwise_fma(pp, hi2(v[u]), b23);
     }
+    const f2 cc = {c, c};
     l = l * c + ps;
-    a0 = a0 * c + b0, a1 = a1 * c + b1, a2 = a2 * c + b2, a3 = a3 * c + b3;
+    a01 = __builtin_elementwise_fma(a01, cc, b01);
+    a23 = __builtin_elementwise_fma(a23, cc, b23);
     mx = mn;
-  }
+  };
+  const int nfull = N / ATRIP * ATRIP;
+  int j0 = sub;
+  for (; j0 < nfull; j0 += ATRIP) trip(j0, std::false_type{});
+  if (j0 < NP) trip(j0, std::true_type{});
 #pragma unroll
   for (int off = 1; off < QL; off <<= 1) {
-    float m2 = __shfl_xor(mx, off, 64), l2 = __shfl_xor(l, off, 64);
-    float b0 = __shfl_xor(a0, off, 64), b1 = __shfl_xor(a1, off, 64), b2 = __shfl_xor(a2, off, 64),
-          b3 = __shfl_xor(a3, off, 64);
-    float mn = fmaxf(mx, m2);
+    const float m2 = __shfl_xor(mx, off, 64), l2 = __shfl_xor(l, off, 64);
+    const f2 b01 = {__shfl_xor(a01.x, off, 64), __shfl_xor(a01.y, off, 64)};
+    const f2 b23 = {__shfl_xor(a23.x, off, 64), __shfl_xor(a23.y, off, 64)};
+    const float mn = fmaxf(mx, m2);
     const float mr = (mn == -INFINITY) ? 0.f : mn;
-    float ca = __expf(mx - mr), cb = __expf(m2 - mr);
+    const float ca = __builtin_amdgcn_exp2f(mx - mr), cb = __builtin_amdgcn_exp2f(m2 - mr);
     l = l * ca + l2 * cb;
-    a0 = a0 * ca + b0 * cb, a1 = a1 * ca + b1 * cb, a2 = a2 * ca + b2 * cb, a3 = a3 * ca + b3 * cb;
+    a01 = a01 * ca + b01 * cb;
+    a23 = a23 * ca + b23 * cb;
     mx = mn;
   }
   if (ok && sub == 0) {
-    float inv = 1.f / l;
-    *reinterpret_cast<float4*>(ob + (rowbase + qi) * 32 + head * 4) = make_float4(a0 * inv, a1 * inv, a2 * inv, a3 * inv);
-    lse[(rowbase + qi) * 8 + head] = mx + __logf(l);
+    const float inv = 1.f / l;
+    *reinterpret_cast<float4*>(ob + (rowbase + qi) * 32 + head * 4) =
+        make_float4(a01.x * inv, a01.y * inv, a23.x * inv, a23.y * inv);
+    lse[(rowbase + qi) * 8 + head] = mx * LN2 + __logf(l);  // natural-log units, as the backward expects
   }
 }
 
@@ -278,107 +322,132 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(int N, const float* __res
 __device__ __forceinline__ void attn_bwd_dq_body(int N, int seq, const float* __restrict__ qkv,
                                                  const float* __restrict__ ob, const float* __restrict__ lse,
                                                  const float* __restrict__ dO, float* __restrict__ dqkv, float4* skv) {
+  const int NP = attn_rows(N);
   float4* sK = skv;
-  float4* sV = skv + N;
+  float4* sV = skv + NP;
   const int head = blockIdx.y;
   const int64_t rowbase = (int64_t)seq * N;
-  for (int i = threadIdx.x; i < N; i += 256) {
-    const float* r = qkv + (rowbase + i) * 96;
-    sK[i] = *reinterpret_cast<const float4*>(r + 32 + head * 4);
-    sV[i] = *reinterpret_cast<const float4*>(r + 64 + head * 4);
-  }
+  attn_stage_kv(N, NP, qkv, rowbase, head, sK, sV);
   __syncthreads();
   const int qi = blockIdx.x * AQ + threadIdx.x / QL, sub = threadIdx.x % QL;
   const bool ok = qi < N;
   const int64_t R = rowbase + (ok ? qi : 0);
-  float4 q = *reinterpret_cast<const float4*>(qkv + R * 96 + head * 4);
-  q.x *= 0.5f, q.y *= 0.5f, q.z *= 0.5f, q.w *= 0.5f;
-  float4 go = *reinterpret_cast<const float4*>(dO + R * 32 + head * 4);
-  float4 oo = *reinterpret_cast<const float4*>(ob + R * 32 + head * 4);
-  const float delta = go.x * oo.x + go.y * oo.y + go.z * oo.z + go.w * oo.w;
-  const float ls = lse[R * 8 + head];
-  float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
-  constexpr int AU = 4;  // independent chains per trip (see attn_fwd_kernel)
-  for (int j0 = sub; j0 < N; j0 += QL * AU) {
+  const float4 q4 = *reinterpret_cast<const float4*>(qkv + R * 96 + head * 4);
+  const f2 q01 = lo2(q4) * (0.5f * LOG2E), q23 = hi2(q4) * (0.5f * LOG2E);
+  const float4 go = *reinterpret_cast<const float4*>(dO + R * 32 + head * 4);
+  const float4 oo = *reinterpret_cast<const float4*>(ob + R * 32 + head * 4);
+  const f2 g01 = lo2(go), g23 = hi2(go);
+  const float delta = dot4(g01, g23, lo2(oo), hi2(oo));
+  const float ls = lse[R * 8 + head] * LOG2E;
+  f2 d01 = {0.f, 0.f}, d23 = {0.f, 0.f};
+  auto trip = [&](int j0, auto masked) __attribute__((always_inline)) {
     float4 k[AU], v[AU];
 #pragma unroll
     for (int u = 0; u < AU; u++) {
-      const int j = min(j0 + QL * u, N - 1);
-      k[u] = sK[j];
-      v[u] = sV[j];
+      k[u] = sK[j0 + QL * u];
+      v[u] = sV[j0 + QL * u];
     }
 #pragma unroll
     for (int u = 0; u < AU; u++) {
-      float s = q.x * k[u].x + q.y * k[u].y + q.z * k[u].z + q.w * k[u].w;
-      float pr = (j0 + QL * u < N) ? __expf(s - ls) : 0.f;
-      float ds = pr * (go.x * v[u].x + go.y * v[u].y + go.z * v[u].z + go.w * v[u].w - delta);
-      d0 += ds * k[u].x, d1 += ds * k[u].y, d2 += ds * k[u].z, d3 += ds * k[u].w;
+      float pr = __builtin_amdgcn_exp2f(dot4(q01, q23, lo2(k[u]), hi2(k[u])) - ls);
+      if (decltype(masked)::value) pr = (j0 + QL * u < N) ? pr : 0.f;
+      const float ds = pr * (dot4(g01, g23, lo2(v[u]), hi2(v[u])) - delta);
+      const f2 dd = {ds, ds};
+      d01 = __builtin_elementwise_fma(dd, lo2(k[u]), d01);
+      d23 = __builtin_elementwise_fma(dd, hi2(k[u]), d23);
     }
-  }
+  };
+  const int nfull = N / ATRIP * ATRIP;
+  int j0 = sub;
+  for (; j0 < nfull; j0 += ATRIP) trip(j0, std::false_type{});
+  if (j0 < NP) trip(j0, std::true_type{});
 #pragma unroll
   for (int off = 1; off < QL; off <<= 1) {
-    d0 += __shfl_xor(d0, off, 64), d1 += __shfl_xor(d1, off, 64), d2 += __shfl_xor(d2, off, 64),
-        d3 += __shfl_xor(d3, off, 64);
+    d01.x += __shfl_xor(d01.x, off, 64), d01.y += __shfl_xor(d01.y, off, 64);
+    d23.x += __shfl_xor(d23.x, off, 64), d23.y += __shfl_xor(d23.y, off, 64);
   }
   if (ok && sub == 0)
-    *reinterpret_cast<float4*>(dqkv + R * 96 + head * 4) = make_float4(0.5f * d0, 0.5f * d1, 0.5f * d2, 0.5f * d3);
+    *reinterpret_cast<float4*>(dqkv + R * 96 + head * 4) =
+        make_float4(0.5f * d01.x, 0.5f * d01.y, 0.5f * d23.x, 0.5f * d23.y);
 }
 
 // dK, dV: QL lanes per key, queries interleaved over the QL lanes
 __device__ __forceinline__ void attn_bwd_dkv_body(int N, int seq, const float* __restrict__ qkv,
                                                   const float* __restrict__ ob, const float* __restrict__ lse,
                                                   const float* __restrict__ dO, float* __restrict__ dqkv, float4* skv) {
-  float4* sQ = skv;        // pre-scaled by 0.5
-  float4* sG = skv + N;    // dO
-  float2* sL = reinterpret_cast<float2*>(skv + 2 * N);  // (lse, delta)
+  const int NP = attn_rows(N);
+  float4* sQ = skv;        // pre-scaled by 0.5 log2(e)
+  float4* sG = skv + NP;   // dO
+  float2* sL = reinterpret_cast<float2*>(skv + 2 * NP);  // (lse log2(e), delta); padded rows: (+inf, 0)
   const int head = blockIdx.y;
   const int64_t rowbase = (int64_t)seq * N;
-  for (int i = threadIdx.x; i < N; i += 256) {
-    float4 q = *reinterpret_cast<const float4*>(qkv + (rowbase + i) * 96 + head * 4);
-    q.x *= 0.5f, q.y *= 0.5f, q.z *= 0.5f, q.w *= 0.5f;
-    float4 go = *reinterpret_cast<const float4*>(dO + (rowbase + i) * 32 + head * 4);
-    float4 oo = *reinterpret_cast<const float4*>(ob + (rowbase + i) * 32 + head * 4);
-    sQ[i] = q;
-    sG[i] = go;
-    sL[i] = make_float2(lse[(rowbase + i) * 8 + head], go.x * oo.x + go.y * oo.y + go.z * oo.z + go.w * oo.w);
+  for (int base = threadIdx.x; base < NP; base += 256 * 4) {
+    float4 q[4], go[4], oo[4];
+    float lv[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int64_t r = rowbase + min(base + 256 * u, N - 1);
+      q[u] = *reinterpret_cast<const float4*>(qkv + r * 96 + head * 4);
+      go[u] = *reinterpret_cast<const float4*>(dO + r * 32 + head * 4);
+      oo[u] = *reinterpret_cast<const float4*>(ob + r * 32 + head * 4);
+      lv[u] = lse[r * 8 + head];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = base + 256 * u;
+      if (i < NP) {
+        const bool real = i < N;
+        const float sc = real ? 0.5f * LOG2E : 0.f;
+        sQ[i] = make_float4(q[u].x * sc, q[u].y * sc, q[u].z * sc, q[u].w * sc);
+        sG[i] = real ? go[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        sL[i] = real ? make_float2(lv[u] * LOG2E, go[u].x * oo[u].x + go[u].y * oo[u].y + go[u].z * oo[u].z +
+                                                      go[u].w * oo[u].w)
+                     : make_float2(INFINITY, 0.f);
+      }
+    }
   }
   __syncthreads();
   const int kj = blockIdx.x * AQ + threadIdx.x / QL, sub = threadIdx.x % QL;
   const bool ok = kj < N;
   const int64_t R = rowbase + (ok ? kj : 0);
-  const float4 k = *reinterpret_cast<const float4*>(qkv + R * 96 + 32 + head * 4);
-  const float4 v = *reinterpret_cast<const float4*>(qkv + R * 96 + 64 + head * 4);
-  float k0 = 0.f, k1 = 0.f, k2 = 0.f, k3 = 0.f, v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-  constexpr int AU = 4;  // independent chains per trip (see attn_fwd_kernel)
-  for (int i0 = sub; i0 < N; i0 += QL * AU) {
+  const float4 k4 = *reinterpret_cast<const float4*>(qkv + R * 96 + 32 + head * 4);
+  const float4 v4 = *reinterpret_cast<const float4*>(qkv + R * 96 + 64 + head * 4);
+  const f2 k01 = lo2(k4), k23 = hi2(k4), v01 = lo2(v4), v23 = hi2(v4);
+  f2 dk01 = {0.f, 0.f}, dk23 = {0.f, 0.f}, dv01 = {0.f, 0.f}, dv23 = {0.f, 0.f};
+  for (int i0 = sub; i0 < NP; i0 += ATRIP) {
     float4 q[AU], go[AU];
     float2 ld[AU];
 #pragma unroll
     for (int u = 0; u < AU; u++) {
-      const int i = min(i0 + QL * u, N - 1);
-      q[u] = sQ[i];
-      go[u] = sG[i];
-      ld[u] = sL[i];
+      q[u] = sQ[i0 + QL * u];
+      go[u] = sG[i0 + QL * u];
+      ld[u] = sL[i0 + QL * u];
     }
 #pragma unroll
     for (int u = 0; u < AU; u++) {
-      float pr = __expf(q[u].x * k.x + q[u].y * k.y + q[u].z * k.z + q[u].w * k.w - ld[u].x);
-      pr = (i0 + QL * u < N) ? pr : 0.f;
-      v0 += pr * go[u].x, v1 += pr * go[u].y, v2 += pr * go[u].z, v3 += pr * go[u].w;
-      float ds = pr * (go[u].x * v.x + go[u].y * v.y + go[u].z * v.z + go[u].w * v.w - ld[u].y);
-      k0 += ds * q[u].x, k1 += ds * q[u].y, k2 += ds * q[u].z, k3 += ds * q[u].w;
+      const f2 q01 = lo2(q[u]), q23 = hi2(q[u]), g01 = lo2(go[u]), g23 = hi2(go[u]);
+      const float pr = __builtin_amdgcn_exp2f(dot4(q01, q23, k01, k23) - ld[u].x);
+      const f2 pp = {pr, pr};
+      dv01 = __builtin_elementwise_fma(pp, g01, dv01);
+      dv23 = __builtin_elementwise_fma(pp, g23, dv23);
+      const float ds = pr * (dot4(g01, g23, v01, v23) - ld[u].y);
+      const f2 dd = {ds, ds};
+      dk01 = __builtin_elementwise_fma(dd, q01, dk01);
+      dk23 = __builtin_elementwise_fma(dd, q23, dk23);
     }
   }
 #pragma unroll
   for (int off = 1; off < QL; off <<= 1) {
-    k0 += __shfl_xor(k0, off, 64), k1 += __shfl_xor(k1, off, 64), k2 += __shfl_xor(k2, off, 64),
-        k3 += __shfl_xor(k3, off, 64);
-    v0 += __shfl_xor(v0, off, 64), v1 += __shfl_xor(v1, off, 64), v2 += __shfl_xor(v2, off, 64),
-        v3 += __shfl_xor(v3, off, 64);
+    dk01.x += __shfl_xor(dk01.x, off, 64), dk01.y += __shfl_xor(dk01.y, off, 64);
+    dk23.x += __shfl_xor(dk23.x, off, 64), dk23.y += __shfl_xor(dk23.y, off, 64);
+    dv01.x += __shfl_xor(dv01.x, off, 64), dv01.y += __shfl_xor(dv01.y, off, 64);
+    dv23.x += __shfl_xor(dv23.x, off, 64), dv23.y += __shfl_xor(dv23.y, off, 64);
   }
   if (ok && sub == 0) {
-    *reinterpret_cast<float4*>(dqkv + R * 96 + 32 + head * 4) = make_float4(k0, k1, k2, k3);
-    *reinterpret_cast<float4*>(dqkv + R * 96 + 64 + head * 4) = make_float4(v0, v1, v2, v3);
+    const float un = 1.f / LOG2E;  // the staged queries carry log2(e)
+    *reinterpret_cast<float4*>(dqkv + R * 96 + 32 + head * 4) =
+        make_float4(dk01.x * un, dk01.y * un, dk23.x * un, dk23.y * un);
+    *reinterpret_cast<float4*>(dqkv + R * 96 + 64 + head * 4) = make_float4(dv01.x, dv01.y, dv23.x, dv23.y);
   }
 }
 
@@ -969,7 +1038,7 @@ int tf_layer_fwd(const TfDims& d, int block, int layer, const TfLayerP& p, float
   HDF_TRY(allow_lds(dense_pre_fwd_kernel, shm));
   hipLaunchKernelGGL(dense_pre_fwd_kernel, grid, dim3(256), shm, st, d, K, p, F, s.h0, s.qkv);
   HDF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(ceil_div(d.N, AQ), 8, d.M * d.B), dim3(256), (size_t)d.N * 32, st, d.N,
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(ceil_div(d.N, AQ), 8, d.M * d.B), dim3(256), (size_t)attn_rows(d.N) * 32, st, d.N,
                      s.qkv, s.ob, s.lse);
   HDF_LAUNCH_CHECK();
   hipLaunchKernelGGL(dense_post_fwd_kernel, grid, dim3(256), 0, st, d, block, layer, p, s.h0, s.ob, s.h1, s.h2, F);
@@ -989,7 +1058,7 @@ int tf_layer_bwd(const TfDims& d, int block, int layer, const TfLayerP& p, const
                      dh0acc);
   HDF_LAUNCH_CHECK();
   dim3 ag(ceil_div(d.N, AQ), 8, 2 * d.M * d.B);
-  hipLaunchKernelGGL(attn_bwd_kernel, ag, dim3(256), (size_t)d.N * 40, st, d.N, d.M * d.B, s.qkv, s.ob, s.lse, dO, dqkv);
+  hipLaunchKernelGGL(attn_bwd_kernel, ag, dim3(256), (size_t)attn_rows(d.N) * 40, st, d.N, d.M * d.B, s.qkv, s.ob, s.lse, dO, dqkv);
   HDF_LAUNCH_CHECK();
   size_t shm = (size_t)(TB * K + TB * 32 + TB * 96 + TB * 32 + 8 * 32 * 2 + 32 * (K + 1) + 96 * 33) * sizeof(float);
   HDF_TRY(allow_lds(dense_pre_bwd_kernel, shm));
