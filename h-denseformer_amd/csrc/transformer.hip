@@ -137,14 +137,35 @@ struct Drop {
 __device__ __forceinline__ Drop make_drop(const TfDims& d) { return Drop{d.training, d.seed, d.thresh24, d.keep_scale}; }
 
 // gW[o*K + k] += sum_t sA[t*lda + o] * sB[t*ldb + k]   (t < TB; padded tokens hold zeros)
+// One 32x32 block of gW per wave on v_mfma_f32_32x32x2_f32 (exact fp32 fma chains): TB/2 steps of two tokens, each
+// lane feeding one sA and one sB element per step (conflict-free rows), then 16 coalesced atomics per lane.  The
+// per-thread dot-product form of this read 2 * TB LDS words per output.  wrot rotates the block -> wave map so that
+// two small products issued back to back land on different waves.
 __device__ __forceinline__ void outer_acc(float* __restrict__ gW, int O, int K, const float* sA, int lda,
-                                          const float* sB, int ldb) {
-  for (int idx = threadIdx.x; idx < O * K; idx += 256) {
-    int o = idx / K, k = idx - o * K;
-    float s = 0.f;
-#pragma unroll 8
-    for (int t = 0; t < TB; t++) s += sA[t * lda + o] * sB[t * ldb + k];
-    atomicAdd(gW + idx, s);
+                                          const float* sB, int ldb, int wrot = 0) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  const int nbk = (K + 31) >> 5, nblk = ((O + 31) >> 5) * nbk;
+  for (int blk = (wave - wrot) & 3; blk < nblk; blk += 4) {
+    const int bo = blk / nbk, o0 = bo * 32, k0 = (blk - bo * nbk) * 32;
+    const bool aok = o0 + r < O, bok = k0 + r < K;
+    const float* pa = sA + h * lda + min(o0 + r, O - 1);
+    const float* pb = sB + h * ldb + min(k0 + r, K - 1);
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < TB / 2; s++) {
+      const float av = aok ? pa[2 * s * lda] : 0.f;
+      const float bv = bok ? pb[2 * s * ldb] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+    if (bok) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int o = o0 + (i & 3) + 8 * (i >> 2) + 4 * h;  // accumulator i of this lane: row o, column k0 + r
+        if (o < O) atomicAdd(gW + (int64_t)o * K + k0 + r, acc[i]);
+      }
+    }
   }
 }
 // gb[o] += sum_t sA[t*lda + o]
@@ -571,7 +592,7 @@ __global__ __launch_bounds__(256) void dense_post_bwd_kernel(TfDims d, int block
     __syncthreads();
     outer_acc(g.w2 + mo, 32, 64, &s_dg[0][0], 32, &s_f[0][0], 64);
     col_acc(g.b2 + mo, 32, &s_dg[0][0], 32);
-    outer_acc(g.w1 + mo, 64, 32, &s_dz[0][0], 64, &s_u[0][0], 32);
+    outer_acc(g.w1 + mo, 64, 32, &s_dz[0][0], 64, &s_u[0][0], 32, 2);
     col_acc(g.b1 + mo, 64, &s_dz[0][0], 64);
     TOK_LOOP(j, tl, t, ok, R) {
       float du = dot_col_lds(s_w1, 33, o, s_dz[tl], 64);
