@@ -1863,9 +1863,15 @@ int launch_cfg(const ConvArgs& a, hipStream_t st) {
 }
 
 // tile-shape choice: shared by the launcher and by hdf_conv_stat_tiles (partials geometry)
-inline bool small_tile(int Do, int Ho, int Wo) { return (int64_t)Do * Ho * Wo <= 32 * 32 * 32 / 2; }
+inline bool small_tile(int Do, int Ho, int Wo) {
+  static const int64_t mx = getenv("HDF_SMALL_TILE_MAX") ? atoll(getenv("HDF_SMALL_TILE_MAX")) : 32 * 32 * 32 / 2;  // tuning knob
+  return (int64_t)Do * Ho * Wo <= mx;
+}
 // 8^3-class volumes (the bottleneck UpConv): 64-voxel tiles, or a handful of workgroups would carry the whole layer
-inline bool tiny_tile(int Do, int Ho, int Wo) { return (int64_t)Do * Ho * Wo <= 8 * 8 * 16; }
+inline bool tiny_tile(int Do, int Ho, int Wo) {
+  static const int64_t mx = getenv("HDF_TINY_TILE_MAX") ? atoll(getenv("HDF_TINY_TILE_MAX")) : 8 * 8 * 16;  // tuning knob
+  return (int64_t)Do * Ho * Wo <= mx;
+}
 // weights-stationary kernel: mode 0, whole Cin row <= 128 B, enough tiles to amortise the weight panel
 inline int ws_cfg(int mode, int Do, int Ho, int Wo, int row_bytes) {
   static const int ws_max = getenv("HDF_WS_MAX_ROW_BYTES") ? atoi(getenv("HDF_WS_MAX_ROW_BYTES")) : 128;  // tuning knob

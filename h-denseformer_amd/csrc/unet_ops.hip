@@ -220,77 +220,27 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dout, int64_t dout_pitc
 // (UpConv, :162-175) evaluated on the fly from the 3x3x3 low-resolution neighbourhood (separable, plane by
 // plane) -- the full-resolution transformer feature at3 is never materialised.
 template <typename T, bool UPS>
-__global__ __launch_bounds__(256) void enc_tail_kernel(const T* __restrict__ y, int64_t y_pitch,
-                                                       const float* __restrict__ scale, const float* __restrict__ shift,
-                                                       const T* __restrict__ skip, int64_t skip_pitch,
-                                                       const float* __restrict__ lscale, const float* __restrict__ lshift,
-                                                       T* __restrict__ ds, int64_t ds_pitch, T* __restrict__ pooled,
-                                                       int64_t pooled_pitch, uint8_t* __restrict__ idx, int N, int C,
-                                                       int Do, int Ho, int Wo) {
+__global__ __launch_bounds__(256, 2) void enc_tail_kernel(const T* __restrict__ y, int64_t y_pitch,
+                                                          const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, const T* __restrict__ skip,
+                                                          int64_t skip_pitch, const float* __restrict__ lscale,
+                                                          const float* __restrict__ lshift, T* __restrict__ ds,
+                                                          int64_t ds_pitch, T* __restrict__ pooled,
+                                                          int64_t pooled_pitch, uint8_t* __restrict__ idx, int N, int C,
+                                                          int Do, int Ho, int Wo) {
   constexpr int EPC = ST<T>::EPC;
   const int cols = C / EPC;
-  const int Di = 2 * Do, Hi = 2 * Ho, Wi = 2 * Wo;
-  int64_t total = (int64_t)N * Do * Ho * Wo * cols;
+  const int Hi = 2 * Ho, Wi = 2 * Wo;
+  const int64_t total = (int64_t)N * Do * Ho * Wo * cols;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t row = i / cols;
+    const int64_t row = i / cols;
     const int c0 = (int)(i - row * cols) * EPC;
-    int64_t t = row;
-    const int ow = t % Wo;
-    t /= Wo;
-    const int oh = t % Ho;
-    t /= Ho;
-    const int od = t % Do;
-    const int n = (int)(t / Do);
-    float sk[8][EPC];  // skip value of the 8 block positions (k = dz*4 + dy*2 + dx)
-    if constexpr (UPS) {
-      float ls[EPC], lt[EPC];
-#pragma unroll
-      for (int e = 0; e < EPC; e++) {
-        ls[e] = lscale[(int64_t)n * C + c0 + e];
-        lt[e] = lshift[(int64_t)n * C + c0 + e];
-#pragma unroll
-        for (int k = 0; k < 8; k++) sk[k][e] = 0.f;
-      }
-      const int xs[3] = {max(ow - 1, 0), ow, min(ow + 1, Wo - 1)};
-      const int ys[3] = {max(oh - 1, 0), oh, min(oh + 1, Ho - 1)};
-      const int zs[3] = {max(od - 1, 0), od, min(od + 1, Do - 1)};
-#pragma unroll
-      for (int a = 0; a < 3; a++) {       // low-resolution z plane
-        float P[2][2][EPC];               // plane interpolated in y and x: [dy][dx]
-#pragma unroll
-        for (int q = 0; q < 4 * EPC; q++) (&P[0][0][0])[q] = 0.f;
-#pragma unroll
-        for (int b = 0; b < 3; b++) {     // low-resolution y row
-          float L[3][EPC];
-#pragma unroll
-          for (int c = 0; c < 3; c++) {
-            float f[EPC];
-            load_chunk<T>(skip + ((((int64_t)n * Do + zs[a]) * Ho + ys[b]) * Wo + xs[c]) * skip_pitch + c0, f);
-#pragma unroll
-            for (int e = 0; e < EPC; e++) L[c][e] = fmaxf(f[e] * ls[e] + lt[e], 0.f);
-          }
-          const float wy0 = (b == 0) ? 0.25f : (b == 1 ? 0.75f : 0.f);   // weight of row b for dy = 0
-          const float wy1 = (b == 0) ? 0.f : (b == 1 ? 0.75f : 0.25f);    // ... for dy = 1
-#pragma unroll
-          for (int e = 0; e < EPC; e++) {
-            const float x0 = 0.25f * L[0][e] + 0.75f * L[1][e], x1 = 0.75f * L[1][e] + 0.25f * L[2][e];
-            P[0][0][e] += wy0 * x0, P[0][1][e] += wy0 * x1;
-            P[1][0][e] += wy1 * x0, P[1][1][e] += wy1 * x1;
-          }
-        }
-        const float wz0 = (a == 0) ? 0.25f : (a == 1 ? 0.75f : 0.f);
-        const float wz1 = (a == 0) ? 0.f : (a == 1 ? 0.75f : 0.25f);
-#pragma unroll
-        for (int dy = 0; dy < 2; dy++)
-#pragma unroll
-          for (int dx = 0; dx < 2; dx++)
-#pragma unroll
-            for (int e = 0; e < EPC; e++) {
-              sk[dy * 2 + dx][e] += wz0 * P[dy][dx][e];
-              sk[4 + dy * 2 + dx][e] += wz1 * P[dy][dx][e];
-            }
-      }
-    }
+    // (n, od) by one 64-bit division, the in-plane coordinates in 32 bits
+    const int plane = Ho * Wo;
+    const int64_t nz = row / plane;
+    const int rem = (int)(row - nz * plane);
+    const int oh = rem / Wo, ow = rem - oh * Wo;
+    const int od = (int)(nz % Do), n = (int)(nz / Do);
     float sc[EPC], sh[EPC], best[EPC];
     int bi[EPC];
 #pragma unroll
@@ -300,25 +250,103 @@ __global__ __launch_bounds__(256) void enc_tail_kernel(const T* __restrict__ y, 
       best[e] = -INFINITY;
       bi[e] = 0;
     }
+    // one output z plane (dz) of the 2x2x2 block: ds = relu(y*s+t) + skip, stored, and folded into the running
+    // maximum in scan order d,h,w (strict > keeps the FIRST maximum: torch's tie rule)
+    const int64_t row0 = (((int64_t)nz * 2) * Hi + 2 * oh) * Wi + 2 * ow;  // first voxel of the 2x2x2 block
+    const T* const ybase = y + row0 * y_pitch + c0;
+    T* const dbase = ds + row0 * ds_pitch + c0;
+    auto finish_plane = [&](int dz, const float (&sk)[4][EPC]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int k = 0; k < 8; k++) {  // scan order d,h,w; strict > keeps the FIRST maximum (torch tie rule)
-      const int dz = k >> 2, dy = (k >> 1) & 1, dx = k & 1;
-      const int64_t irow = (((int64_t)n * Di + 2 * od + dz) * Hi + 2 * oh + dy) * Wi + 2 * ow + dx;
-      float f[EPC];
-      load_chunk<T>(y + irow * y_pitch + c0, f);
-      if constexpr (!UPS) load_chunk<T>(skip + irow * skip_pitch + c0, sk[k]);
+      for (int q = 0; q < 4; q++) {
+        const int dy = q >> 1, dx = q & 1, k = dz * 4 + q;
+        const int64_t orow = ((int64_t)dz * Hi + dy) * Wi + dx;  // uniform
+        float f[EPC];
+        load_chunk<T>(ybase + orow * y_pitch, f);
 #pragma unroll
-      for (int e = 0; e < EPC; e++) f[e] = fmaxf(f[e] * sc[e] + sh[e], 0.f) + sk[k][e];
-      store_chunk<T>(ds + irow * ds_pitch + c0, f);
-      // pool over the STORED (storage-rounded) values so that backward/recompute sees the same maxima
-      float g[EPC];
-      ST<T>::unpack(ST<T>::pack(f), g);
+        for (int e = 0; e < EPC; e++) f[e] = fmaxf(f[e] * sc[e] + sh[e], 0.f) + sk[q][e];
+        store_chunk<T>(dbase + orow * ds_pitch, f);
+        // pool over the STORED (storage-rounded) values so that backward/recompute sees the same maxima
+        float g[EPC];
+        ST<T>::unpack(ST<T>::pack(f), g);
+#pragma unroll
+        for (int e = 0; e < EPC; e++) {
+          if (g[e] > best[e] || g[e] != g[e]) {
+            best[e] = g[e];
+            bi[e] = k;
+          }
+        }
+      }
+    };
+    if constexpr (UPS) {
+      // skip = trilinear x2 of relu(ylo*ls+lt): low-resolution z planes a = 0,1,2 are interpolated in y and x
+      // (P[dy][dx]) one at a time; output plane dz = 0 is .25 P0 + .75 P1 and is finished before P2 is loaded,
+      // dz = 1 is .75 P1 + .25 P2 -- at most two planes and one plane of loads are live (2 waves per SIMD)
+      float ls[EPC], lt[EPC];
 #pragma unroll
       for (int e = 0; e < EPC; e++) {
-        if (g[e] > best[e] || g[e] != g[e]) {
-          best[e] = g[e];
-          bi[e] = k;
+        ls[e] = lscale[(int64_t)n * C + c0 + e];
+        lt[e] = lshift[(int64_t)n * C + c0 + e];
+      }
+      const int xs[3] = {max(ow - 1, 0), ow, min(ow + 1, Wo - 1)};
+      const int ys[3] = {max(oh - 1, 0), oh, min(oh + 1, Ho - 1)};
+      const int zs[3] = {max(od - 1, 0), od, min(od + 1, Do - 1)};
+      // one 64-bit sample base + 32-bit element offsets (a sample fits 2^31 elements: launcher check)
+      const T* const lbase = skip + (int64_t)n * Do * Ho * Wo * skip_pitch + c0;
+      const int lp = (int)skip_pitch;
+      int zo[3], yo[3], xo[3];
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        zo[q] = zs[q] * Ho * Wo * lp;
+        yo[q] = ys[q] * Wo * lp;
+        xo[q] = xs[q] * lp;
+      }
+      auto plane_yx = [&](int a, float (&P)[4][EPC]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+          for (int e = 0; e < EPC; e++) P[q][e] = 0.f;
+#pragma unroll
+        for (int b = 0; b < 3; b++) {  // low-resolution y row
+          float L[3][EPC];
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            float f[EPC];
+            load_chunk<T>(lbase + (zo[a] + yo[b] + xo[c]), f);
+#pragma unroll
+            for (int e = 0; e < EPC; e++) L[c][e] = fmaxf(f[e] * ls[e] + lt[e], 0.f);
+          }
+          const float wy0 = (b == 0) ? 0.25f : (b == 1 ? 0.75f : 0.f);  // weight of row b for dy = 0
+          const float wy1 = (b == 0) ? 0.f : (b == 1 ? 0.75f : 0.25f);   // ... for dy = 1
+#pragma unroll
+          for (int e = 0; e < EPC; e++) {
+            const float x0 = 0.25f * L[0][e] + 0.75f * L[1][e], x1 = 0.75f * L[1][e] + 0.25f * L[2][e];
+            P[0][e] += wy0 * x0, P[1][e] += wy0 * x1;
+            P[2][e] += wy1 * x0, P[3][e] += wy1 * x1;
+          }
         }
+      };
+      float P0[4][EPC], P1[4][EPC], sk[4][EPC];
+      plane_yx(0, P0);
+      plane_yx(1, P1);
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int e = 0; e < EPC; e++) sk[q][e] = 0.25f * P0[q][e] + 0.75f * P1[q][e];
+      finish_plane(0, sk);
+      plane_yx(2, P0);
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int e = 0; e < EPC; e++) sk[q][e] = 0.75f * P1[q][e] + 0.25f * P0[q][e];
+      finish_plane(1, sk);
+    } else {
+#pragma unroll
+      for (int dz = 0; dz < 2; dz++) {
+        float sk[4][EPC];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          load_chunk<T>(skip + (row0 + ((int64_t)dz * Hi + (q >> 1)) * Wi + (q & 1)) * skip_pitch + c0, sk[q]);
+        finish_plane(dz, sk);
       }
     }
     store_chunk<T>(pooled + row * pooled_pitch + c0, best);
@@ -434,15 +462,26 @@ __global__ void upsample_bwd_kernel(const T* __restrict__ dout, int64_t dout_pit
     for (int e = 0; e < EPC; e++) acc[e] = 0.f;
     // all 64 taps unconditionally (indices are clamped into range, out-of-range taps carry weight 0): no
     // branch around any load, so the loads of a thread are all in flight together
+    // addresses: one 64-bit sample base, then 32-bit element offsets z + y + x (the launcher checks that a sample
+    // fits 2^31 elements) -- 64 full 64-bit row products per thread cost more VALU time than the 64 loads
+    const T* const sbase = dout + (int64_t)n * Do * Ho * Wo * dout_pitch + c0;
+    const int pit = (int)dout_pitch;
+    int zo[4], yo[4], xo[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      zo[q] = oz[q] * Ho * Wo * pit;
+      yo[q] = oy[q] * Wo * pit;
+      xo[q] = ox[q] * pit;
+    }
 #pragma unroll
     for (int a = 0; a < 4; a++) {
 #pragma unroll
       for (int b = 0; b < 4; b++) {
         const float wzy = wz[a] * wy[b];
-        const int64_t rbase = (((int64_t)n * Do + oz[a]) * Ho + oy[b]) * Wo;
+        const int zy = zo[a] + yo[b];
         float f[4][EPC];
 #pragma unroll
-        for (int c = 0; c < 4; c++) load_chunk<T>(dout + (rbase + ox[c]) * dout_pitch + c0, f[c]);
+        for (int c = 0; c < 4; c++) load_chunk<T>(sbase + (zy + xo[c]), f[c]);
 #pragma unroll
         for (int c = 0; c < 4; c++)
 #pragma unroll
@@ -919,6 +958,9 @@ int hdf_launch_enc_tail(int dtype, const void* y, int64_t y_pitch, const float* 
                         int Ho, int Wo, hipStream_t st) {
   HDF_CHECK_ARG(C % 16 == 0, "enc_tail: C=%d", C);
   const bool ups = lscale != nullptr;
+  HDF_CHECK_ARG(!ups || (int64_t)Do * Ho * Wo * skip_pitch < ((int64_t)1 << 31),
+                "enc_tail: a low-resolution sample of %dx%dx%d voxels x pitch %lld exceeds 32-bit element offsets", Do,
+                Ho, Wo, (long long)skip_pitch);
   DISPATCH_T(dtype, {
     unsigned g = grid_for((int64_t)N * Do * Ho * Wo * (C / ST<T>::EPC));
     if (ups)
@@ -966,6 +1008,9 @@ int hdf_launch_upsample_fwd(int dtype, const void* y, int64_t y_pitch, const flo
 
 int hdf_launch_upsample_bwd(int dtype, const void* dout, int64_t dout_pitch, void* din, int64_t din_pitch, int N,
                             int C, int Di, int Hi, int Wi, hipStream_t st) {
+  HDF_CHECK_ARG((int64_t)8 * Di * Hi * Wi * dout_pitch < ((int64_t)1 << 31),
+                "upsample_bwd: a sample of %dx%dx%d voxels x pitch %lld exceeds 32-bit element offsets", 2 * Di, 2 * Hi,
+                2 * Wi, (long long)dout_pitch);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(upsample_bwd_kernel<T>, dim3(grid_for((int64_t)N * Di * Hi * Wi * (C / ST<T>::EPC))),
                                 dim3(256), 0, st, (const T*)dout, dout_pitch, (T*)din, din_pitch, N, C, Di, Hi, Wi));
