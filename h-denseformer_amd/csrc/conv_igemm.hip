@@ -169,7 +169,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     // per CU, nothing to switch to) left the matrix pipe idle 70-90 % of the time.
     if ((a.Cin * ESZ) % 64 == 0) {
       constexpr int NS = 54;                       // fragment steps per chunk
-      constexpr int RING = (MB >= 4) ? 6 : 9;      // divides 54: the ring position is the same in every chunk
+#ifndef V1_RING_BIG
+#define V1_RING_BIG 6
+#endif
+#ifndef V1_RING_SMALL
+#define V1_RING_SMALL 9
+#endif
+      constexpr int RING = (MB >= 4) ? V1_RING_BIG : V1_RING_SMALL;  // divides 54: the ring position is the same in every chunk
       const int nchunk = a.Cin * ESZ / 64;
       u32x4 bq[RING];
       auto b_load = [&](int chunk, int s_) -> u32x4 {
@@ -185,6 +191,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       for (int k = 0; k < RING; k++) bq[k] = b_load(0, k);
       for (int chunk = 0; chunk < nchunk; chunk++) {
         if (chunk > 0) __syncthreads();
+#ifdef V1_DBG_NOSTAGE  // attribution build: only the first chunk is staged
+        if (chunk == 0)
+#endif
         stage_box<T, BD, BH, BW, 64, PITCH>(lds, reinterpret_cast<const T*>(a.in), a.in_pitch, a.Cin, n, a.Di, a.Hi,
                                             a.Wi, oz, oy, ox, chunk * chunk_elems_max, 64, a.in_scale, a.in_shift,
                                             a.in_relu);
@@ -205,10 +214,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
           for (int mb = 0; mb < MB; mb++) Mma<T>::run(af[s_ & 1][mb], bcur, acc[mb]);
           // refill the slot just consumed: RING steps ahead, in this chunk or the next one
+#ifndef V1_DBG_NOB  // attribution build: the weight ring is never refilled
           if (s_ + RING < NS)
             bq[s_ % RING] = b_load(chunk, s_ + RING);
           else if (more)
             bq[s_ % RING] = b_load(chunk + 1, s_ + RING - NS);
+#endif
           __builtin_amdgcn_sched_barrier(0);
         }
       }

@@ -19,6 +19,7 @@ ap.add_argument("--n", type=int, default=2)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--xf", type=int, default=0)
 ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--cold", type=int, default=0, help="1: evict L2 / memory-side cache before every timed launch")
 a = ap.parse_args()
 dt = BF16 if a.dtype == "bf16" else F32
 tdt = torch.bfloat16 if dt == BF16 else torch.float32
@@ -52,12 +53,23 @@ else:
     flops = 2.0 * 27 * cin * cout * s ** 3 * n
 launch()
 torch.cuda.synchronize()
-e0.record()
-for _ in range(a.reps):
-    launch()
-e1.record()
-torch.cuda.synchronize()
-ms = e0.elapsed_time(e1) / a.reps
+if a.cold:
+    junk = torch.empty(1 << 30, dtype=torch.uint8, device=dev)   # 1 GiB > L2 + 256 MB memory-side cache
+    ms = 0.0
+    for _ in range(a.reps):
+        junk.add_(1)
+        e0.record()
+        launch()
+        e1.record()
+        torch.cuda.synchronize()
+        ms += e0.elapsed_time(e1) / a.reps
+else:
+    e0.record()
+    for _ in range(a.reps):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / a.reps
 if os.environ.get("WS_STAMPS") and a.op == "conv":
     t = part[:256 * 8].view(256, 8).double().cpu()
     names = ["commit", "barrier1", "prefetch-issue", "mfma-loop", "barriers2+3", "epi:stage+stats", "epi:barrier+stores", "loop-top"]
