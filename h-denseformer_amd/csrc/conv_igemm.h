@@ -22,6 +22,8 @@ struct ConvArgs {
   int CoutP;
   float* stat_partials;  // [N*tiles][CoutP][2] (sum, sum of squares) or null
   int accumulate;        // out += result
+  void* out2;            // split output (mode 0): channels >= split go to out2[...][ch - split], same pitch as out
+  int split;             // multiple of 32, 0 = single output
 };
 
 struct WgradArgs {

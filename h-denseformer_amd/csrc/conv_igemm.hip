@@ -266,7 +266,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   const bool ch_ok = n_active && ch < a.Cout;
   const float bias = (a.bias && ch_ok) ? a.bias[ch] : 0.f;
   float s1 = 0.f, s2 = 0.f;
-  T* outp = reinterpret_cast<T*>(a.out);
+  // split output: this wave's 32-channel block lies entirely on one side (split is a multiple of 32)
+  T* outp = (a.split && n_base >= a.split) ? reinterpret_cast<T*>(a.out2) - a.split : reinterpret_cast<T*>(a.out);
 #pragma unroll
   for (int mb = 0; mb < MB; mb++) {
 #pragma unroll
@@ -687,7 +688,10 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
     ch_ok[nb] = ch + 32 * nb < a.Cout;
     bias[nb] = (a.bias && ch_ok[nb]) ? a.bias[ch + 32 * nb] : 0.f;
   }
-  T* const outp = reinterpret_cast<T*>(a.out);
+  T* outp[NB];  // split output: a 32-channel block lies entirely on one side (split is a multiple of 32)
+#pragma unroll
+  for (int nb = 0; nb < NB; nb++)
+    outp[nb] = (a.split && n0 + 32 * nb >= a.split) ? reinterpret_cast<T*>(a.out2) - a.split : reinterpret_cast<T*>(a.out);
   // accumulator register i of this lane: tile voxel (dz, 2w + mb, x) with x = (i & 3) + 4 * ((i >> 2) & 1) and
   // dz = {0,1,3,2}[i >> 2] (h == 0) or {1,0,2,3}[i >> 2] (h == 1)   (ws_row_to_zx of row (i&3) + 8*(i>>2) + 4h)
   int edz[4], eplane[4];
@@ -763,8 +767,8 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
 #endif
 
   // this lane's first output element of a tile: channel n0 + r, rows y0 + 2w (+ mb), voxel (z0, ., x0)
-  auto out_base = [&](const WsTile& t) -> T* {
-    return outp + ((((int64_t)t.n * a.Do + t.z0) * a.Ho + t.y0 + 2 * wave) * a.Wo + t.x0) * a.out_pitch + ch;
+  auto out_base = [&](const WsTile& t, int nb) -> T* {
+    return outp[nb] + ((((int64_t)t.n * a.Do + t.z0) * a.Ho + t.y0 + 2 * wave) * a.Wo + t.x0) * a.out_pitch + ch + 32 * nb;
   };
   auto epilogue = [&](f32x16 (&acc)[2 * NB], const WsTile& ET) __attribute__((always_inline)) {
     const int z0 = ET.z0, y0 = ET.y0, x0 = ET.x0;
@@ -773,7 +777,7 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) {
       float s1 = 0.f, s2 = 0.f;
-      T* const obase = out_base(ET) + 32 * nb;
+      T* const obase = out_base(ET, nb);
       if (full && ch_ok[nb] && !a.accumulate) {
 #pragma unroll
         for (int mb = 0; mb < 2; mb++) {
@@ -840,7 +844,7 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
     constexpr int EPG = (32 + NG - 1) / NG;  // pending elements per MFMA group
     f32x16(&acc)[2 * NB] = accs[PAR0];
     f32x16(&pacc)[2 * NB] = accs[1 - PAR0];
-    T* const pbase = out_base(PT);
+    T* const pbase = out_base(PT, 0);
     float ds1 = 0.f, ds2 = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
@@ -1985,6 +1989,8 @@ int hdf_launch_conv(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
   HDF_CHECK_ARG(a.CoutP % 32 == 0 && a.CoutP >= a.Cout, "conv: bad CoutP=%d for Cout=%d", a.CoutP, a.Cout);
   HDF_CHECK_ARG(a.in_pitch % 8 == 0 && (((uintptr_t)a.in) & 15) == 0, "conv: input view must be 16-byte aligned");
   HDF_CHECK_ARG(mode == 0 || a.stat_partials == nullptr, "conv: stats only in mode 0");
+  HDF_CHECK_ARG(a.split == 0 || (mode == 0 && a.split % 32 == 0 && a.split < a.Cout && a.out2 != nullptr),
+                "conv: split output needs mode 0, split %% 32 == 0 and a second buffer (split=%d)", a.split);
   if (dtype == HDF_BF16) return launch_conv_t<bf16_t>(mode, a, st);
   if (dtype == HDF_F32) return launch_conv_t<float>(mode, a, st);
   hdf_set_error("conv: unsupported dtype %d", dtype);

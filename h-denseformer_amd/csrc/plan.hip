@@ -97,7 +97,8 @@ struct hdf_plan {
   size_t stat_partials, wgrad_ws, inb_partials, inb_k;
   size_t wgrad_ws_bytes = 0;
   // backward scratch
-  View gA[4], gY[4], dCat[3], dP[3], dUa[4], dUy[4], dX4, dAttnall;
+  View gA[4], gY[4], dCat[3], dUp[3], dSkip[3], dP[3], dUa[4], dUy[4], dX4, dAttnall;
+  bool dcat_split[3] = {false, false, false};
   // state carried from forward to backward
   int training = 0;
   uint32_t seed = 0;
@@ -356,7 +357,19 @@ void layout(hdf_plan* p, int B) {
     p->gA[k] = mkview(p, bp, "", k, ch[k], B);
     p->gY[k] = mkview(p, bp, "", k, ch[k], B);
     if (k < 3) {
-      p->dCat[k] = mkview(p, bp, "g.cat" + std::to_string(k + 1), k, 2 * ch[k], B);
+      // gradient of cat_k = [upconv | ds]: two dense buffers when the halves are whole 32-channel blocks (every
+      // consumer of a half -- InstanceNorm backward, max-pool backward, up-sampling backward, the transposed conv's
+      // backward -- then streams whole lines instead of 64 of every 128 bytes), else one buffer with views
+      p->dcat_split[k] = ch[k] % 32 == 0;
+      if (p->dcat_split[k]) {
+        p->dUp[k] = mkview(p, bp, "g.up" + std::to_string(k + 1), k, ch[k], B);
+        p->dSkip[k] = mkview(p, bp, "g.ds" + std::to_string(k), k, ch[k], B);
+        p->dCat[k] = p->dUp[k];
+      } else {
+        p->dCat[k] = mkview(p, bp, "g.cat" + std::to_string(k + 1), k, 2 * ch[k], B);
+        p->dUp[k] = subview(p, p->dCat[k], 0, ch[k]);
+        p->dSkip[k] = subview(p, p->dCat[k], ch[k], ch[k]);
+      }
       p->dP[k] = mkview(p, bp, "g.pool" + std::to_string(k + 1), k + 1, ch[k], B);
     }
   }
@@ -578,7 +591,8 @@ int in_backward(Exec& e, const Conv3& c, const View& da, const View& dy) {
 }
 
 // conv backward: weight (and bias) gradient from (dy, input) and optionally the input gradient
-int conv_backward(Exec& e, Conv3& c, const View& dy, const View& in, Xf xf, const View* din, int accumulate) {
+int conv_backward(Exec& e, Conv3& c, const View& dy, const View& in, Xf xf, const View* din, int accumulate,
+                  const View* din2 = nullptr) {
   hdf_plan* p = e.p;
   const int* d = e.dm(c.lvl);
   WgradArgs w{};
@@ -614,6 +628,10 @@ int conv_backward(Exec& e, Conv3& c, const View& dy, const View& in, Xf xf, cons
     a.Cout = c.Cin;
     a.CoutP = OP;
     a.accumulate = accumulate;
+    if (din2) {  // input channels [0, din->C) -> din, the rest -> din2 (two dense buffers of one pitch)
+      a.out2 = e.at(*din2);
+      a.split = din->C;
+    }
     HDF_TRY(hdf_launch_conv(p->dtype, 0, a, e.st));
   }
   return HDF_OK;
@@ -847,9 +865,12 @@ int hdf_backward_stages(hdf_plan* p, const float* x, const float* params, void* 
     HDF_TRY(in_backward(e, c2, p->gA[k], p->gY[k]));
     HDF_TRY(conv_backward(e, c2, p->gY[k], c1.y, xf_of(e, c1), &p->gA[k], 0));
     HDF_TRY(in_backward(e, c1, p->gA[k], p->gY[k]));
-    HDF_TRY(conv_backward(e, c1, p->gY[k], p->cat[k], none, &p->dCat[k], 0));
+    if (p->dcat_split[k])
+      HDF_TRY(conv_backward(e, c1, p->gY[k], p->cat[k], none, &p->dUp[k], 0, &p->dSkip[k]));
+    else
+      HDF_TRY(conv_backward(e, c1, p->gY[k], p->cat[k], none, &p->dCat[k], 0));
     // upconv_{k+1}: input is dec[k+1][1] activation (k<2) or the bottleneck x4 (k==2)
-    View dup = subview(p, p->dCat[k], 0, ch[k]);
+    const View& dup = p->dUp[k];
     if (k < 2)
       HDF_TRY(convt_backward(e, p->upc[k], dup, p->dec[k + 1][1].y, xf_of(e, p->dec[k + 1][1]), p->gA[k + 1]));
     else
@@ -860,7 +881,7 @@ int hdf_backward_stages(hdf_plan* p, const float* x, const float* params, void* 
   // ---- encoder, bottom (level 3) up to level 0.  dskip: gradient of ds_k (= of the transformer feature at_k too)
   for (int k = 3; k >= 0; k--) {
     Conv3 &c1 = p->enc[k][0], &c2 = p->enc[k][1];
-    View dskip = (k == 3) ? p->dX4 : subview(p, p->dCat[k], ch[k], ch[k]);
+    View dskip = (k == 3) ? p->dX4 : p->dSkip[k];
     if (k < 3) {
       // ds_k also feeds pool_{k+1}
       HDF_TRY(hdf_launch_maxpool_bwd(p->dtype, e.at(p->dP[k]), p->dP[k].pitch, (const uint8_t*)(e.ws + p->pool_idx[k]),
@@ -882,7 +903,7 @@ int hdf_backward_stages(hdf_plan* p, const float* x, const float* params, void* 
   // ---- UpConv chain: at3 <- up3 <- at2 <- up2 <- at1 <- up1 <- attnout <- deep_conv <- attnall
   for (int k = 2; k >= 0; k--) {
     Conv3& c = p->up[k];                                   // up[k] output level c.lvl, upsampled to level c.lvl-1
-    View dat = subview(p, p->dCat[c.lvl - 1], ch[c.lvl - 1], ch[c.lvl - 1]);  // gradient of at_{..} == of ds
+    View dat = p->dSkip[c.lvl - 1];  // gradient of at_{..} == of ds
     const int* d = p->dims[c.lvl];
     View& da = p->dUa[4 - c.lvl];
     View& dy = p->dUy[4 - c.lvl];
@@ -891,7 +912,7 @@ int hdf_backward_stages(hdf_plan* p, const float* x, const float* params, void* 
     HDF_TRY(in_backward(e, c, da, dy));
     // input of up[k]: attnout (k==0) or at_{lvl} ; its gradient buffer already holds the skip-path gradient
     const View& cin = (k == 0) ? p->attnout : p->at[c.lvl];
-    View din = (k == 0) ? p->dX4 : subview(p, p->dCat[c.lvl], ch[c.lvl], ch[c.lvl]);
+    View din = (k == 0) ? p->dX4 : p->dSkip[c.lvl];
     HDF_TRY(conv_backward(e, c, dy, cin, none, &din, 1));
   }
   {

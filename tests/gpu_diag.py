@@ -46,9 +46,20 @@ def main():
     print("loss", loss.item(), rloss.item())
     for i in range(4):
         print(f"dlogits{i} rel-l2 {rl2(outs[i].grad, routs[i].grad):.3e}")
+    def read(name):
+        # the gradient of cat_k is one buffer "g.cat{k}" or, when the halves are whole 32-channel blocks, the two
+        # dense buffers "g.up{k}" (upconv half) and "g.ds{k-1}" (skip half)
+        if name.startswith("g.cat"):
+            k = int(name[-1])
+            try:
+                return rt.read_buffer(name)
+            except Exception:
+                return torch.cat([rt.read_buffer(f"g.up{k}"), rt.read_buffer(f"g.ds{k - 1}")], dim=1)
+        return rt.read_buffer(name)
+
     pairs = [("g.cat1", "cat1"), ("g.cat2", "cat2"), ("g.cat3", "cat3"), ("g.attnout", "attnout"), ("g.attnall", "attnall")]
     for mine, theirs in pairs:
-        a, b = rt.read_buffer(mine), inter[theirs].grad
+        a, b = read(mine), inter[theirs].grad
         print(f"{mine:10s} rel-l2 {rl2(a, b):.3e}", end="")
         if "cat" in mine:
             c = a.shape[1] // 2
@@ -57,7 +68,7 @@ def main():
             print()
     # at_k grads live in the upper halves; compare with oracle at grads
     for mine, theirs in [("g.cat1", "at3"), ("g.cat2", "at2"), ("g.cat3", "at1")]:
-        a = rt.read_buffer(mine)
+        a = read(mine)
         c = a.shape[1] // 2
         print(f"{mine} upper vs d({theirs}) {rl2(a[:, c:], inter[theirs].grad):.3e}")
     for name, p in net.named_parameters():
