@@ -22,6 +22,9 @@ for p in (ROOT, os.path.join(ROOT, "h-denseformer_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# the host driver only supports dmabuf IPC: RCCL / cross-process device memory need this before HIP initialises
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch  # noqa: E402
 
 FWD_BWD_GFLOP_PER_SAMPLE = 2998.4      # FlopCounterMode, 4x128^3 nf32 td24
