@@ -24,6 +24,7 @@ struct ConvArgs {
   int accumulate;        // out += result
   void* out2;            // split output (mode 0): channels >= split go to out2[...][ch - split], same pitch as out
   int split;             // multiple of 32, 0 = single output
+  int wfrag;             // weight layout: 0 = [27][CoutP][Cin] rows, 1 = fragment-major (hdf_conv_weight_layout)
 };
 
 struct WgradArgs {
@@ -58,7 +59,13 @@ struct PackJob {
   int64_t src_off;  // floats from the parameter base
   int64_t dst_off;  // bytes from the workspace base
   int O, I, OP, IP, so, si, flip;
+  int frag;  // 1: fragment-major destination (hdf_conv_weight_layout)
 };
+// Weight layout the conv launch of this shape reads.  0: [27][CoutP][Cin] rows.  1: fragment-major, for the launches
+// that take conv_igemm_kernel's pipelined path (weight fragments straight from L2): per tap, per 32-channel output
+// block, per 32-byte step of the input-channel row, the 32 rows x 32 bytes one wave loads form ONE contiguous 1 KB
+// block -- a fragment load touches 8 full cache lines instead of 32 lines of which it uses 32 bytes each.
+int hdf_conv_weight_layout(int dtype, int mode, int Cin, int Do, int Ho, int Wo);
 constexpr int HDF_MAX_PACK_JOBS = 64;
 int hdf_launch_pack_batch(int dtype, const float* params, char* ws, const PackJob* jobs, int njobs, hipStream_t st);
 int hdf_launch_pack_w(int dtype, const float* src, void* dst, int O, int I, int OP, int IP, int64_t so, int64_t si,

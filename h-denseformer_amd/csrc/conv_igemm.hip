@@ -178,9 +178,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       constexpr int RING = (MB >= 4) ? V1_RING_BIG : V1_RING_SMALL;  // divides 54: the ring position is the same in every chunk
       const int nchunk = a.Cin * ESZ / 64;
       u32x4 bq[RING];
+      // fragment-major panels (a.wfrag, see hdf_conv_weight_layout): the 32 rows x 32 B of one fragment step are one
+      // contiguous 1 KB block, steps of a row follow each other, then the next 32-channel block; a tap plane has
+      // the same size in both layouts.  With row-major panels a fragment load touched 32 cache lines for 1 KB and
+      // the vector cache's line rate, not latency, bounded the low-resolution layers.
+      const char* const wfr = a.wfrag ? reinterpret_cast<const char*>(a.w) +
+                                            (int64_t)(n_base >> 5) * ((a.Cin * ESZ) >> 5) * 1024 + r * 32 + h * 16
+                                      : wrow;
+      const int cstride = a.wfrag ? 2048 : 64, fstride = a.wfrag ? 1024 : 32;
       auto b_load = [&](int chunk, int s_) -> u32x4 {
         const int tap = s_ >> 1, fs = s_ & 1;
-        const char* p = wrow + tap * wtap_stride + (int64_t)chunk * 64 + fs * 32;
+        const char* p = wfr + tap * wtap_stride + (int64_t)chunk * cstride + fs * fstride;
         return *reinterpret_cast<const u32x4*>(n_active ? p : reinterpret_cast<const char*>(a.w));
       };
       auto a_off = [&](int s_) {
@@ -1863,8 +1871,10 @@ __global__ void pack_batch_kernel(PackBatch b, const float* __restrict__ params,
     float v[27];
 #pragma unroll
     for (int t = 0; t < 27; t++) v[t] = sp[t];
+    constexpr int E32 = 32 / (int)sizeof(T);  // elements per 32-byte fragment step
+    const int64_t at = jb.frag ? (((int64_t)(o >> 5) * (jb.IP / E32) + i / E32) * 32 + (o & 31)) * E32 + i % E32 : idx;
 #pragma unroll
-    for (int t = 0; t < 27; t++) ST<T>::st(dst + (int64_t)t * pairs + idx, live ? (jb.flip ? v[26 - t] : v[t]) : 0.f);
+    for (int t = 0; t < 27; t++) ST<T>::st(dst + (int64_t)t * pairs + at, live ? (jb.flip ? v[26 - t] : v[t]) : 0.f);
   }
 }
 
@@ -1921,7 +1931,11 @@ int launch_conv_t(int mode, const ConvArgs& a, hipStream_t st) {
       if (rb == 128) return launch_ws2<T, 32, 128, 1>(a, st);
     }
     if (tiny_tile(a.Do, a.Ho, a.Wo)) return launch_cfg<T, 2, 4, 8, 2, 2, 1, 1, false>(a, st);   // 64 vox x 64 ch
-    if (small_tile(a.Do, a.Ho, a.Wo)) return launch_cfg<T, 4, 4, 8, 2, 2, 2, 1, false>(a, st);  // 128 vox x 64 ch
+    if (small_tile(a.Do, a.Ho, a.Wo)) {
+      static const bool wn1 = getenv("HDF_SMALL_WN1") != nullptr;  // tuning knob: 128 vox x 32 ch, twice the workgroups
+      if (wn1) return launch_cfg<T, 4, 4, 8, 4, 1, 1, 1, false>(a, st);
+      return launch_cfg<T, 4, 4, 8, 2, 2, 2, 1, false>(a, st);  // 128 vox x 64 ch
+    }
     if (a.CoutP <= 32) return launch_cfg<T, 4, 8, 8, 4, 1, 2, 1, false>(a, st);                  // 256 vox x 32 ch
     return launch_cfg<T, 4, 8, 8, 2, 2, 4, 1, false>(a, st);                                     // 256 vox x 64 ch
   } else if (mode == 1) {
@@ -1976,6 +1990,14 @@ int launch_wgrad_t(WgradArgs a, float* dw, int sc_store, int lc_store, int accum
 
 }  // namespace
 
+int hdf_conv_weight_layout(int dtype, int mode, int Cin, int Do, int Ho, int Wo) {
+  static const bool off = getenv("HDF_CONV_ROW_PANELS") != nullptr;  // A/B knob: row-major panels everywhere
+  const int rb = Cin * (dtype == HDF_BF16 ? 2 : 4);
+  if (off || rb % 64 != 0) return 0;                       // the pipelined path needs whole 64-byte chunks
+  if (mode == 0) return ws_cfg(mode, Do, Ho, Wo, rb) ? 0 : 1;  // conv_ws2_kernel stages row-major panels
+  return mode == 1 ? 1 : 0;                                // stride-2 gather conv: pipelined path; transposed conv: rows
+}
+
 int hdf_conv_stat_tiles(int mode, int Do, int Ho, int Wo, int row_bytes) {
   if (mode != 0) return 0;
   if (ws_cfg(mode, Do, Ho, Wo, row_bytes)) return WS_STAT_ROWS;  // per-workgroup rows (conv_ws2_kernel)
@@ -1989,6 +2011,8 @@ int hdf_launch_conv(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
   HDF_CHECK_ARG(a.CoutP % 32 == 0 && a.CoutP >= a.Cout, "conv: bad CoutP=%d for Cout=%d", a.CoutP, a.Cout);
   HDF_CHECK_ARG(a.in_pitch % 8 == 0 && (((uintptr_t)a.in) & 15) == 0, "conv: input view must be 16-byte aligned");
   HDF_CHECK_ARG(mode == 0 || a.stat_partials == nullptr, "conv: stats only in mode 0");
+  HDF_CHECK_ARG(a.wfrag == 0 || hdf_conv_weight_layout(dtype, mode, a.Cin, a.Do, a.Ho, a.Wo) == 1,
+                "conv: fragment-major weights given to a launch that reads row-major panels (mode %d Cin %d)", mode, a.Cin);
   HDF_CHECK_ARG(a.split == 0 || (mode == 0 && a.split % 32 == 0 && a.split < a.Cout && a.out2 != nullptr),
                 "conv: split output needs mode 0, split %% 32 == 0 and a second buffer (split=%d)", a.split);
   if (dtype == HDF_BF16) return launch_conv_t<bf16_t>(mode, a, st);

@@ -48,12 +48,14 @@ struct Conv3 {  // 3x3x3 conv + InstanceNorm (+ReLU)
   View y;
   Stats st;
   size_t wf = 0, wd = 0;  // packed forward / dgrad weights
+  int wf_frag = 0, wd_frag = 0;  // their layout (hdf_conv_weight_layout of the launch that reads them)
 };
 struct ConvT3 {
   std::string name;
   int Cin = 0, Cout = 0, lvl_in = 0;
   int64_t w = -1, b = -1;
   size_t wf = 0, wd = 0;
+  int wd_frag = 0;
 };
 struct Head1 {
   std::string name;
@@ -319,11 +321,16 @@ void layout(hdf_plan* p, int B) {
   p->x4 = mkview(p, bp, "bottleneck", 3, 8 * nf, B);
   // ---- weight packs (see conv_forward / conv_backward / convt_* for the layouts)
   p->pack_jobs.clear();
-  auto conv_jobs = [&](const Conv3& c) {
+  auto conv_jobs = [&](Conv3& c) {
+    const int* d = p->dims[c.lvl];
+    c.wf_frag = hdf_conv_weight_layout(p->dtype, 0, c.CinP, d[0], d[1], d[2]);
+    c.wd_frag = hdf_conv_weight_layout(p->dtype, 0, c.Cout, d[0], d[1], d[2]);
     // forward [tap][CoutP][CinP] from torch [Cout][Cin][27]
-    p->pack_jobs.push_back(PackJob{c.w, (int64_t)c.wf, c.Cout, c.Cin, round_up(c.Cout, 32), c.CinP, c.Cin * 27, 27, 0});
+    p->pack_jobs.push_back(
+        PackJob{c.w, (int64_t)c.wf, c.Cout, c.Cin, round_up(c.Cout, 32), c.CinP, c.Cin * 27, 27, 0, c.wf_frag});
     // dgrad: taps reversed, channel roles swapped: Wd[t][ci][co] = W[co][ci][26-t]
-    p->pack_jobs.push_back(PackJob{c.w, (int64_t)c.wd, c.Cin, c.Cout, round_up(c.Cin, 32), c.Cout, 27, c.Cin * 27, 1});
+    p->pack_jobs.push_back(
+        PackJob{c.w, (int64_t)c.wd, c.Cin, c.Cout, round_up(c.Cin, 32), c.Cout, 27, c.Cin * 27, 1, c.wd_frag});
   };
   conv_jobs(p->deep);
   for (int k = 0; k < 3; k++) conv_jobs(p->up[k]);
@@ -333,11 +340,15 @@ void layout(hdf_plan* p, int B) {
     if (k < 3) {
       conv_jobs(p->dec[k][0]);
       conv_jobs(p->dec[k][1]);
-      const ConvT3& t = p->upc[k];
+      ConvT3& t = p->upc[k];
+      const int* d = p->dims[t.lvl_in];
+      t.wd_frag = hdf_conv_weight_layout(p->dtype, 1, t.Cout, d[0], d[1], d[2]);
       // forward: torch ConvTranspose3d weight [Cin][Cout][27] -> [tap][CoutP][Cin]
-      p->pack_jobs.push_back(PackJob{t.w, (int64_t)t.wf, t.Cout, t.Cin, round_up(t.Cout, 32), t.Cin, 27, t.Cout * 27, 0});
+      p->pack_jobs.push_back(
+          PackJob{t.w, (int64_t)t.wf, t.Cout, t.Cin, round_up(t.Cout, 32), t.Cin, 27, t.Cout * 27, 0, 0});
       // input gradient: stride-2 gather conv, [tap][CinP][Cout]
-      p->pack_jobs.push_back(PackJob{t.w, (int64_t)t.wd, t.Cin, t.Cout, round_up(t.Cin, 32), t.Cout, t.Cout * 27, 27, 0});
+      p->pack_jobs.push_back(
+          PackJob{t.w, (int64_t)t.wd, t.Cin, t.Cout, round_up(t.Cin, 32), t.Cout, t.Cout * 27, 27, 0, t.wd_frag});
     }
   }
   // ---- scratch shared by forward and backward
@@ -419,6 +430,7 @@ int conv_forward(Exec& e, Conv3& c, const View& in, Xf xf) {
   a.Hi = a.Ho = d[1];
   a.Wi = a.Wo = d[2];
   a.w = e.ws + c.wf;
+  a.wfrag = c.wf_frag;
   a.bias = e.P(c.b);
   a.in_scale = xf.scale;
   a.in_shift = xf.shift;
@@ -623,6 +635,7 @@ int conv_backward(Exec& e, Conv3& c, const View& dy, const View& in, Xf xf, cons
     a.Hi = a.Ho = d[1];
     a.Wi = a.Wo = d[2];
     a.w = e.ws + c.wd;
+    a.wfrag = c.wd_frag;
     a.out = e.at(*din);
     a.out_pitch = din->pitch;
     a.Cout = c.Cin;
@@ -667,6 +680,7 @@ int convt_backward(Exec& e, ConvT3& t, const View& dout, const View& in, Xf xf, 
   a.Di = 2 * d[0], a.Hi = 2 * d[1], a.Wi = 2 * d[2];
   a.Do = d[0], a.Ho = d[1], a.Wo = d[2];
   a.w = e.ws + t.wd;
+  a.wfrag = t.wd_frag;
   a.out = e.at(din);
   a.out_pitch = din.pitch;
   a.Cout = t.Cin;
