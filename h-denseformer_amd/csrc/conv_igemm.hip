@@ -159,6 +159,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   const int64_t wtap_stride = (int64_t)a.CoutP * a.Cin * ESZ;
   const int chunk_elems_max = 64 / ESZ;
 
+  // weight fragment addressing: row-major panels [27][CoutP][Cin] or fragment-major (a.wfrag, see below)
+  const char* const wfr = a.wfrag ? reinterpret_cast<const char*>(a.w) +
+                                        (int64_t)(n_base >> 5) * ((a.Cin * ESZ) >> 5) * 1024 + r * 32 + h * 16
+                                  : wrow;
+  const int cstride = a.wfrag ? 2048 : 64, fstride = a.wfrag ? 1024 : 32;  // per 64-byte chunk / per 32-byte step
+
   bool done = false;
   if constexpr (!CONVT) {
     // Conv (stride 1 or the stride-2 gather) with whole 64-byte channel chunks: the 27 taps x 2 fragment steps of a chunk are unrolled and
@@ -182,10 +188,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       // contiguous 1 KB block, steps of a row follow each other, then the next 32-channel block; a tap plane has
       // the same size in both layouts.  With row-major panels a fragment load touched 32 cache lines for 1 KB and
       // the vector cache's line rate, not latency, bounded the low-resolution layers.
-      const char* const wfr = a.wfrag ? reinterpret_cast<const char*>(a.w) +
-                                            (int64_t)(n_base >> 5) * ((a.Cin * ESZ) >> 5) * 1024 + r * 32 + h * 16
-                                      : wrow;
-      const int cstride = a.wfrag ? 2048 : 64, fstride = a.wfrag ? 1024 : 32;
       auto b_load = [&](int chunk, int s_) -> u32x4 {
         const int tap = s_ >> 1, fs = s_ & 1;
         const char* p = wfr + tap * wtap_stride + (int64_t)chunk * cstride + fs * fstride;
@@ -252,9 +254,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             if (jx < ntapx) {
               const int offx = CONVT ? (px ? 1 - jx : 0) : jx, wx = CONVT ? (px ? 2 * jx : 1) : jx;
               const int tapoff = ((offz * BH + offy) * BW + offx) * PITCH + h * 16;
-              const char* wp = wrow + ((wz * 3 + wy) * 3 + wx) * wtap_stride + (int64_t)c0 * ESZ;
+              const char* wp = wfr + ((wz * 3 + wy) * 3 + wx) * wtap_stride + (int64_t)(c0 * ESZ / 64) * cstride;
               for (int fs = 0; fs < nfs; fs++) {
-                u32x4 bfrag = *reinterpret_cast<const u32x4*>(wp + fs * 32);
+                u32x4 bfrag = *reinterpret_cast<const u32x4*>(wp + fs * fstride);
                 u32x4 afrag[MB];
 #pragma unroll
                 for (int mb = 0; mb < MB; mb++)
@@ -1995,7 +1997,8 @@ int hdf_conv_weight_layout(int dtype, int mode, int Cin, int Do, int Ho, int Wo)
   const int rb = Cin * (dtype == HDF_BF16 ? 2 : 4);
   if (off || rb % 64 != 0) return 0;                       // the pipelined path needs whole 64-byte chunks
   if (mode == 0) return ws_cfg(mode, Do, Ho, Wo, rb) ? 0 : 1;  // conv_ws2_kernel stages row-major panels
-  return mode == 1 ? 1 : 0;                                // stride-2 gather conv: pipelined path; transposed conv: rows
+  if (mode == 1) return 1;                                 // stride-2 gather conv: pipelined path
+  return rb > 128 ? 1 : 0;  // transposed conv: convt_fused_kernel (rows <= 128 B) stages row-major panels, wider ones run per class
 }
 
 int hdf_conv_stat_tiles(int mode, int Do, int Ho, int Wo, int row_bytes) {

@@ -55,7 +55,7 @@ struct ConvT3 {
   int Cin = 0, Cout = 0, lvl_in = 0;
   int64_t w = -1, b = -1;
   size_t wf = 0, wd = 0;
-  int wd_frag = 0;
+  int wf_frag = 0, wd_frag = 0;
 };
 struct Head1 {
   std::string name;
@@ -342,10 +342,11 @@ void layout(hdf_plan* p, int B) {
       conv_jobs(p->dec[k][1]);
       ConvT3& t = p->upc[k];
       const int* d = p->dims[t.lvl_in];
+      t.wf_frag = hdf_conv_weight_layout(p->dtype, 2, t.Cin, d[0], d[1], d[2]);
       t.wd_frag = hdf_conv_weight_layout(p->dtype, 1, t.Cout, d[0], d[1], d[2]);
       // forward: torch ConvTranspose3d weight [Cin][Cout][27] -> [tap][CoutP][Cin]
       p->pack_jobs.push_back(
-          PackJob{t.w, (int64_t)t.wf, t.Cout, t.Cin, round_up(t.Cout, 32), t.Cin, 27, t.Cout * 27, 0, 0});
+          PackJob{t.w, (int64_t)t.wf, t.Cout, t.Cin, round_up(t.Cout, 32), t.Cin, 27, t.Cout * 27, 0, t.wf_frag});
       // input gradient: stride-2 gather conv, [tap][CinP][Cout]
       p->pack_jobs.push_back(
           PackJob{t.w, (int64_t)t.wd, t.Cin, t.Cout, round_up(t.Cin, 32), t.Cout, t.Cout * 27, 27, 0, t.wd_frag});
@@ -461,6 +462,7 @@ int convt_forward(Exec& e, ConvT3& t, const View& in, Xf xf, const View& out) {
   a.Di = d[0], a.Hi = d[1], a.Wi = d[2];
   a.Do = 2 * d[0], a.Ho = 2 * d[1], a.Wo = 2 * d[2];
   a.w = e.ws + t.wf;
+  a.wfrag = t.wf_frag;
   a.bias = e.P(t.b);
   a.in_scale = xf.scale;
   a.in_shift = xf.shift;
