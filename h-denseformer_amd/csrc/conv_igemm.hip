@@ -1963,7 +1963,12 @@ int launch_wgrad_t(WgradArgs a, float* dw, int sc_store, int lc_store, int accum
   a.num_tiles = a.N * ceil_div(a.Ds, TD) * ceil_div(a.Hs, TH) * ceil_div(a.Ws, TW);
   const int pairs = (a.SCp / 32) * (a.LCp / 32);
   const int64_t per = (int64_t)27 * a.SCp * a.LCp * sizeof(float);
-  static const int wg_target = getenv("HDF_WGRAD_WGS") ? atoi(getenv("HDF_WGRAD_WGS")) : 256;  // one workgroup per CU
+  static const int wg_new = getenv("HDF_WGRAD_WGS") ? atoi(getenv("HDF_WGRAD_WGS")) : 256;  // one workgroup per CU
+  // the single-buffered kernel (stride 2, f32) hides its staging only behind other workgroups of the same CU
+  static const int wg_old = getenv("HDF_WGRAD_OLD_WGS") ? atoi(getenv("HDF_WGRAD_OLD_WGS")) : 256;
+  static const bool force_old = getenv("HDF_WGRAD_OLD") != nullptr;
+  const bool use_new = sizeof(T) == 2 && S == 1 && !a.sm_scale && !force_old;
+  const int wg_target = use_new ? wg_new : wg_old;
   int G = ceil_div(wg_target, pairs);
   G = (int)std::min<int64_t>(G, std::max<int64_t>(1, (int64_t)ws_bytes / per));
   G = std::min(G, a.num_tiles);
@@ -1973,8 +1978,7 @@ int launch_wgrad_t(WgradArgs a, float* dw, int sc_store, int lc_store, int accum
                 ws_bytes);
   a.partials = reinterpret_cast<float*>(ws);
   dim3 grid(G, a.SCp / 32, a.LCp / 32);
-  static const bool wg_old = getenv("HDF_WGRAD_OLD") != nullptr;  // A/B knob: single-buffered conv_wgrad_kernel
-  if (sizeof(T) == 2 && S == 1 && !a.sm_scale && !wg_old) {
+  if (use_new) {  // HDF_WGRAD_OLD=1 (A/B knob): single-buffered conv_wgrad_kernel everywhere
     if (a.lg_scale)
       hipLaunchKernelGGL(conv_wgrad2_kernel<true>, grid, dim3(256), 0, st, a);
     else
