@@ -128,7 +128,7 @@ def roofline_dominant_kernel(dev):
         traffic = json.load(open(tfile)).get("traffic_bytes_per_launch")
     return {"bound": "mfma", "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic,
-            "kernel": "conv_ws2_kernel<bf16_t,32,128,false> (block_1_1_right fwd, 64->32 @128^3, batch 2)",
+            "kernel": "conv_ws2_kernel<bf16_t,32,128,false,1> (block_1_1_right fwd, 64->32 @128^3, batch 2)",
             "avg_launch_ms": ms, "flops_per_launch": flops, "algorithmic_bytes_per_launch": 2.0 * n * s ** 3 * (cin + cout)}
 
 
