@@ -140,10 +140,20 @@ def main():
     ap.add_argument("--batch", type=int, default=2, help="per-GPU batch")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="only the roofline leg (the dominant kernel's timed launches): the command profiled for "
+                         "profiles/*_roofline_kernel_stats.csv, whose per-kernel average must match avg_launch_ms")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.cpu_baseline_child:
         _cpu_baseline_child()
+        return
+
+    if a.roofline_only:
+        torch.cuda.set_device(0)
+        from hdf_rt import _lib
+        _lib.lib()
+        print(json.dumps({"roofline": roofline_dominant_kernel(torch.device("cuda", 0))}), flush=True)
         return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
