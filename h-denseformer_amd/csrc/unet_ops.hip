@@ -764,10 +764,21 @@ __global__ __launch_bounds__(1024) void in_bwd_finalize_kernel(const float* __re
   const int n = blockIdx.y, cl = threadIdx.x & 31, c = blockIdx.x * 32 + cl, bl = threadIdx.x >> 5;
   double s1 = 0.0, s2 = 0.0;
   if (c < C) {
-    for (int b = bl; b < blocks; b += BL) {
-      const float* p = partials + (((int64_t)n * blocks + b) * C + c) * 2;
-      s1 += (double)p[0];
-      s2 += (double)p[1];
+    const float* p = partials + ((int64_t)n * blocks * C + c) * 2;
+    const int64_t bs = (int64_t)C * 2;
+    int b = bl;
+    for (; b + 3 * BL < blocks; b += 4 * BL) {  // four independent loads in flight (the rows are L2 round trips)
+      const float2 v0 = *reinterpret_cast<const float2*>(p + (int64_t)b * bs);
+      const float2 v1 = *reinterpret_cast<const float2*>(p + (int64_t)(b + BL) * bs);
+      const float2 v2 = *reinterpret_cast<const float2*>(p + (int64_t)(b + 2 * BL) * bs);
+      const float2 v3 = *reinterpret_cast<const float2*>(p + (int64_t)(b + 3 * BL) * bs);
+      s1 += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+      s2 += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+    }
+    for (; b < blocks; b += BL) {
+      const float2 v = *reinterpret_cast<const float2*>(p + (int64_t)b * bs);
+      s1 += (double)v.x;
+      s2 += (double)v.y;
     }
   }
   red[bl][cl][0] = s1;
