@@ -101,6 +101,7 @@ struct hdf_plan {
   // backward scratch
   View gA[4], gY[4], dCat[3], dUp[3], dSkip[3], dP[3], dUa[4], dUy[4], dX4, dAttnall;
   bool dcat_split[3] = {false, false, false};
+  bool no_head_fuse = getenv("HDF_NO_HEAD_FUSE") != nullptr;  // A/B knob: separate in_bwd_reduce after the heads
   // state carried from forward to backward
   int training = 0;
   uint32_t seed = 0;
@@ -585,17 +586,19 @@ int transformer_backward(Exec& e, const float* x) {
 }
 
 // InstanceNorm(+ReLU) backward of conv layer c: da (grad w.r.t. the activation) -> dy (grad w.r.t. raw conv out)
-int in_backward(Exec& e, const Conv3& c, const View& da, const View& dy) {
+// pre_blocks > 0: the producer of da (head_backward) already wrote that many partial rows per sample
+int in_backward(Exec& e, const Conv3& c, const View& da, const View& dy, int pre_blocks = 0) {
   hdf_plan* p = e.p;
   const int64_t vox = p->vox(c.lvl);
-  const int blocks = hdf_in_bwd_blocks(vox, c.Cout);
+  const int blocks = pre_blocks > 0 ? pre_blocks : hdf_in_bwd_blocks(vox, c.Cout);
   float* k = e.f(p->inb_k);
   float* k1 = k;
   float* ka = k + (size_t)e.B * c.Cout;
   float* kb = k + (size_t)2 * e.B * c.Cout;
-  HDF_TRY(hdf_launch_in_bwd_reduce(p->dtype, e.at(da), da.pitch, e.at(c.y), c.y.pitch, e.f(c.st.scale),
-                                   e.f(c.st.shift), e.f(c.st.mean), e.f(c.st.rstd), e.f(p->inb_partials), blocks, e.B,
-                                   c.Cout, vox, e.st));
+  if (pre_blocks == 0)
+    HDF_TRY(hdf_launch_in_bwd_reduce(p->dtype, e.at(da), da.pitch, e.at(c.y), c.y.pitch, e.f(c.st.scale),
+                                     e.f(c.st.shift), e.f(c.st.mean), e.f(c.st.rstd), e.f(p->inb_partials), blocks, e.B,
+                                     c.Cout, vox, e.st));
   HDF_TRY(hdf_launch_in_bwd_finalize(e.f(p->inb_partials), blocks, e.B, c.Cout, vox, e.P(c.gamma), e.f(c.st.rstd), k1,
                                      ka, kb, e.G(c.gamma), e.G(c.beta), e.st));
   HDF_TRY(hdf_launch_in_bwd_apply(p->dtype, e.at(da), da.pitch, e.at(c.y), c.y.pitch, e.f(c.st.scale), e.f(c.st.shift),
@@ -690,9 +693,19 @@ int convt_backward(Exec& e, ConvT3& t, const View& dout, const View& in, Xf xf, 
   return hdf_launch_conv(p->dtype, 1, a, e.st);
 }
 
-int head_backward(Exec& e, const Head1& h, const void* dlogits, const View& in, Xf xf, const View& dx, int acc) {
-  return hdf_launch_head_bwd(e.p->dtype, dlogits, e.at(in), in.pitch, xf.scale, xf.shift, e.P(h.w), e.at(dx), dx.pitch,
-                             acc, e.G(h.w), e.G(h.b), e.B, h.C, e.p->ncls, e.p->vox(h.lvl), e.st);
+// fuse_in: the conv layer whose InstanceNorm+ReLU output the head reads -- the head gradient is then that activation's
+// complete gradient, and the kernel also writes the first pass of the layer's InstanceNorm backward (*pre_blocks rows
+// per sample in inb_partials; 0 when the table does not hold that many rows and the separate pass has to run)
+int head_backward(Exec& e, const Head1& h, const void* dlogits, const View& in, Xf xf, const View& dx, int acc,
+                  const Conv3* fuse_in = nullptr, int* pre_blocks = nullptr) {
+  hdf_plan* p = e.p;
+  const int hb = hdf_head_bwd_blocks(p->vox(h.lvl));
+  const bool fuse = fuse_in && pre_blocks && hb <= 1024 && !p->no_head_fuse;
+  if (pre_blocks) *pre_blocks = fuse ? hb : 0;
+  return hdf_launch_head_bwd(p->dtype, dlogits, e.at(in), in.pitch, xf.scale, xf.shift, e.P(h.w), e.at(dx), dx.pitch,
+                             acc, e.G(h.w), e.G(h.b), e.B, h.C, p->ncls, p->vox(h.lvl), e.st,
+                             fuse ? e.f(fuse_in->st.mean) : nullptr, fuse ? e.f(fuse_in->st.rstd) : nullptr,
+                             fuse ? e.f(p->inb_partials) : nullptr);
 }
 
 }  // namespace
@@ -877,8 +890,9 @@ int hdf_backward_stages(hdf_plan* p, const float* x, const float* params, void* 
   for (int k = 0; k <= 2; k++) {
     Conv3 &c1 = p->dec[k][0], &c2 = p->dec[k][1];
     // gA[k] holds d/d(activation of c2): head gradient (+ convT input gradient from the level above, k>0)
-    HDF_TRY(head_backward(e, p->head[k], douts[k], c2.y, xf_of(e, c2), p->gA[k], k > 0 ? 1 : 0));
-    HDF_TRY(in_backward(e, c2, p->gA[k], p->gY[k]));
+    int pre = 0;
+    HDF_TRY(head_backward(e, p->head[k], douts[k], c2.y, xf_of(e, c2), p->gA[k], k > 0 ? 1 : 0, &c2, &pre));
+    HDF_TRY(in_backward(e, c2, p->gA[k], p->gY[k], pre));
     HDF_TRY(conv_backward(e, c2, p->gY[k], c1.y, xf_of(e, c1), &p->gA[k], 0));
     HDF_TRY(in_backward(e, c1, p->gA[k], p->gY[k]));
     if (p->dcat_split[k])

@@ -41,9 +41,11 @@ int hdf_launch_head_fwd(int dtype, const void* in, int64_t in_pitch, const float
                         const float* w, const float* b, void* logits, int N, int C, int ncls, int64_t vox,
                         hipStream_t st);
 // dX (+)= W^T dlogits ; dW += dlogits . act(in)^T ; db += sum dlogits   (dW, db accumulated with float atomics)
+int hdf_head_bwd_blocks(int64_t vox);
 int hdf_launch_head_bwd(int dtype, const void* dlogits, const void* in, int64_t in_pitch, const float* scale,
                         const float* shift, const float* w, void* dx, int64_t dx_pitch, int accumulate_dx, float* dw,
-                        float* db, int N, int C, int ncls, int64_t vox, hipStream_t st);
+                        float* db, int N, int C, int ncls, int64_t vox, hipStream_t st, const float* in_mean = nullptr,
+                        const float* in_rstd = nullptr, float* inb_partials = nullptr);
 
 // InstanceNorm+ReLU backward, stage 1: g = da * [y*scale+shift > 0]; partial sums of g and g*xhat
 int hdf_launch_in_bwd_reduce(int dtype, const void* da, int64_t da_pitch, const void* y, int64_t y_pitch,

@@ -590,8 +590,15 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ dlo
                                                        const float* __restrict__ shift, const float* __restrict__ w,
                                                        T* __restrict__ dx, int64_t dx_pitch, int accumulate_dx,
                                                        float* __restrict__ dw, float* __restrict__ db, int N, int C,
-                                                       int ncls, int64_t vox, int per) {
+                                                       int ncls, int64_t vox, int per,
+                                                       const float* __restrict__ in_mean,
+                                                       const float* __restrict__ in_rstd,
+                                                       float* __restrict__ inb_partials) {
   constexpr int EPC = ST<T>::EPC;
+  // inb_partials (optional): this kernel produces the complete gradient dx of the activation relu(IN(in)), so it
+  // also writes the first pass of that InstanceNorm's backward -- per workgroup and channel (sum g, sum g*xhat) with
+  // g = dx where the activation is positive, row layout of in_bwd_reduce_kernel with gridDim.x rows per sample -- and
+  // saves a full read of dx and in.  The sums use the STORED (storage-rounded) dx, as a separate pass would.
   // LDS: first the block's logit gradients [voxel][MC] (loaded class plane by class plane, coalesced, once), then
   // reused as [vlanes][C + 1][MC] for the final reduction
   extern __shared__ float red[];
@@ -601,10 +608,14 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ dlo
   const int col = threadIdx.x % cols, vl = threadIdx.x / cols;
   const int c0 = col * EPC;
   float sc[EPC], sh[EPC], wv[MC][EPC], accw[MC][EPC], accb[MC];
+  float mu[EPC], rs[EPC], s1[EPC], s2[EPC];
 #pragma unroll
   for (int e = 0; e < EPC; e++) {
     sc[e] = scale ? scale[(int64_t)n * C + c0 + e] : 1.f;
     sh[e] = scale ? shift[(int64_t)n * C + c0 + e] : 0.f;
+    mu[e] = inb_partials ? in_mean[(int64_t)n * C + c0 + e] : 0.f;
+    rs[e] = inb_partials ? in_rstd[(int64_t)n * C + c0 + e] : 0.f;
+    s1[e] = s2[e] = 0.f;
   }
 #pragma unroll
   for (int o = 0; o < MC; o++) {
@@ -658,6 +669,16 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ dlo
           d[e] = t;
         }
         if (live) store_chunk<T>(dx + row[u] * dx_pitch + c0, d);
+        if (inb_partials) {
+          float dr[EPC];
+          ST<T>::unpack(ST<T>::pack(d), dr);
+#pragma unroll
+          for (int e = 0; e < EPC; e++) {
+            const float gg = (live && f[u][e] * sc[e] + sh[e] > 0.f) ? dr[e] : 0.f;
+            s1[e] += gg;
+            s2[e] += gg * ((f[u][e] - mu[e]) * rs[e]);
+          }
+        }
         if (col == 0) {
 #pragma unroll
           for (int o = 0; o < MC; o++) accb[o] += dl[u][o];
@@ -686,6 +707,22 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ dlo
       atomicAdd(dw + o * C + c, t);
     else
       atomicAdd(db + o, t);
+  }
+  if (inb_partials) {  // same fixed-order reduction over the voxel lanes as in_bwd_reduce_kernel
+    __syncthreads();
+    if (vl < vlanes) {
+#pragma unroll
+      for (int e = 0; e < EPC; e++) {
+        red[(vl * C + c0 + e) * 2 + 0] = s1[e];
+        red[(vl * C + c0 + e) * 2 + 1] = s2[e];
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * 2; i += 256) {
+      float t = 0.f;
+      for (int k = 0; k < vlanes; k++) t += red[k * C * 2 + i];
+      inb_partials[((int64_t)n * gridDim.x + blockIdx.x) * C * 2 + i] = t;
+    }
   }
 }
 
@@ -1048,25 +1085,33 @@ int hdf_launch_head_fwd(int dtype, const void* in, int64_t in_pitch, const float
   return HDF_OK;
 }
 
+// workgroups per sample of head_bwd_kernel (= rows per sample of its optional InstanceNorm-backward partials)
+int hdf_head_bwd_blocks(int64_t vox) { return (int)ceil_div64(vox, head_vox(vox)); }
+
 int hdf_launch_head_bwd(int dtype, const void* dlogits, const void* in, int64_t in_pitch, const float* scale,
                         const float* shift, const float* w, void* dx, int64_t dx_pitch, int accumulate_dx, float* dw,
-                        float* db, int N, int C, int ncls, int64_t vox, hipStream_t st) {
+                        float* db, int N, int C, int ncls, int64_t vox, hipStream_t st, const float* in_mean,
+                        const float* in_rstd, float* inb_partials) {
   HDF_CHECK_ARG(ncls <= HEAD_MAXCLS, "head: n_cls=%d > %d", ncls, HEAD_MAXCLS);
   HDF_CHECK_ARG(C % 16 == 0 && C <= 1024, "head_bwd: C=%d", C);
+  HDF_CHECK_ARG(inb_partials == nullptr || (scale && in_mean && in_rstd), "head_bwd: IN partials need the layer's statistics");
   const int per = head_vox(vox);
-  const unsigned gx = (unsigned)ceil_div64(vox, per);
+  const unsigned gx = (unsigned)hdf_head_bwd_blocks(vox);
   DISPATCH_T(dtype, {
     const int cols = C / ST<T>::EPC, vlanes = 256 / cols;
     const int mc = ncls <= 4 ? 4 : 8;
-    const size_t shm = std::max((size_t)vlanes * (C + 1) * mc, (size_t)per * mc) * sizeof(float);
+    const size_t shm =
+        std::max(std::max((size_t)vlanes * (C + 1) * mc, (size_t)per * mc), (size_t)vlanes * C * 2) * sizeof(float);
     if (mc == 4) {
       HDF_TRY(allow_big_lds((const void*)head_bwd_kernel<T, 4>, shm));
       hipLaunchKernelGGL((head_bwd_kernel<T, 4>), dim3(gx, N), dim3(256), shm, st, (const T*)dlogits, (const T*)in,
-                         in_pitch, scale, shift, w, (T*)dx, dx_pitch, accumulate_dx, dw, db, N, C, ncls, vox, per);
+                         in_pitch, scale, shift, w, (T*)dx, dx_pitch, accumulate_dx, dw, db, N, C, ncls, vox, per, in_mean,
+                         in_rstd, inb_partials);
     } else {
       HDF_TRY(allow_big_lds((const void*)head_bwd_kernel<T, 8>, shm));
       hipLaunchKernelGGL((head_bwd_kernel<T, 8>), dim3(gx, N), dim3(256), shm, st, (const T*)dlogits, (const T*)in,
-                         in_pitch, scale, shift, w, (T*)dx, dx_pitch, accumulate_dx, dw, db, N, C, ncls, vox, per);
+                         in_pitch, scale, shift, w, (T*)dx, dx_pitch, accumulate_dx, dw, db, N, C, ncls, vox, per, in_mean,
+                         in_rstd, inb_partials);
     }
   });
   HDF_LAUNCH_CHECK();
