@@ -857,28 +857,36 @@ __global__ __launch_bounds__(256) void patch_embed_fwd_kernel(TfDims d, const fl
   for (int a = 0; a < 2; a++)
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[a][i] = 0.f;
-  for (int kc = 0; kc < 4096; kc += KC) {
-    // batched float4 staging: every load of the chunk is issued before the first LDS write (tokens beyond BN are
-    // clamped to the last token: their outputs are never stored)
-    float4 ra[2], rb[8];
+  // Software pipeline over the 64 chunks: the global loads of chunk k+1 are issued right after chunk k's tile is
+  // in LDS and stay in flight under its 32 MFMAs per wave (the single-buffered loop exposed one HBM round trip per
+  // chunk: 170 us for 4 GFLOP).  Tokens beyond BN are clamped to the last token: their outputs are never stored.
+  float4 ra[2], rb[8];
+  const int nbq = DM * KC / 4;  // float4 chunks of the B tile
+  const float* xtok[2];         // this thread's two tokens: first voxel of their 16^3 bricks (loop invariant)
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    const int tl = ((threadIdx.x + 256 * u) * 4) >> 6, t = min(blockIdx.x * 32 + tl, BN - 1);
+    const int b = t / d.N, n = t - b * d.N;
+    const int gz = n / (gh * gw), gy = (n / gw) % gh, gx = n % gw;
+    xtok[u] = x + ((((int64_t)b * d.M + m) * D + gz * 16) * H + gy * 16) * W + gx * 16;
+  }
+  auto load_chunk_regs = [&](int kc) __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < 2; u++) {
-      int i = (threadIdx.x + 256 * u) * 4;  // element index in the [32][64] A chunk
-      int tl = i >> 6, kk = i & 63, t = min(blockIdx.x * 32 + tl, BN - 1);
-      int b = t / d.N, n = t - b * d.N;
-      int gz = n / (gh * gw), gy = (n / gw) % gh, gx = n % gw;
-      int k = kc + kk, dz = k >> 8, dy = (k >> 4) & 15, dx = k & 15;
-      ra[u] = *reinterpret_cast<const float4*>(
-          x + ((((int64_t)b * d.M + m) * D + gz * 16 + dz) * H + gy * 16 + dy) * W + gx * 16 + dx);
+      const int kk = ((threadIdx.x + 256 * u) * 4) & 63;  // element index in the [32][64] A chunk
+      const int k = kc + kk, dz = k >> 8, dy = (k >> 4) & 15, dx = k & 15;
+      ra[u] = *reinterpret_cast<const float4*>(xtok[u] + ((int64_t)dz * H + dy) * W + dx);
     }
-    const int nbq = DM * KC / 4;  // float4 chunks of the B tile
 #pragma unroll
     for (int u = 0; u < 8; u++) {
       int q = min((int)threadIdx.x + 256 * u, nbq - 1), i = q * 4;
       int c = i >> 6, kk = i & 63;
       rb[u] = *reinterpret_cast<const float4*>(wm + (int64_t)c * 4096 + kc + kk);
     }
-    __syncthreads();
+  };
+  load_chunk_regs(0);
+  for (int kc = 0; kc < 4096; kc += KC) {
+    __syncthreads();  // the previous chunk's MFMAs are done with the tile
 #pragma unroll
     for (int u = 0; u < 2; u++) {
       int i = (threadIdx.x + 256 * u) * 4, tl = i >> 6, kk = i & 63;
@@ -911,6 +919,7 @@ __global__ __launch_bounds__(256) void patch_embed_fwd_kernel(TfDims d, const fl
       }
     }
     __syncthreads();
+    if (kc + KC < 4096) load_chunk_regs(kc + KC);
 #pragma unroll
     for (int a = 0; a < 2; a++) {
       int nb = wave + 4 * a;
@@ -970,6 +979,8 @@ __global__ __launch_bounds__(256) void patch_embed_wgrad_kernel(TfDims d, const 
                                                                 float* __restrict__ dwpe) {
   constexpr int TT = 32, LDD = 33, LDP = 129;
   __shared__ float sD[TT * LDD], sP[TT * LDP];
+  extern __shared__ int sTok[];  // [BN]: element offset of every token's brick in x (the per-load divisions by the
+                                 // token grid cost more VALU time than the MFMAs: 25 runtime divisions per tile)
   const int m = blockIdx.z, BN = d.B * d.N, DM = d.DM;
   const int cb = blockIdx.y * 32, kb = blockIdx.x * 128;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
@@ -977,9 +988,22 @@ __global__ __launch_bounds__(256) void patch_embed_wgrad_kernel(TfDims d, const 
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; i++) acc[i] = 0.f;
-  for (int t0 = 0; t0 < BN; t0 += TT) {
-    // batched staging (all loads first; tokens beyond BN contribute zeros)
-    float4 rd, rp[4];
+  // software pipeline over the token tiles (as patch_embed_fwd_kernel): the loads of tile t+1 are in flight under
+  // the 16 MFMAs of tile t; tokens beyond BN contribute zeros
+  for (int t = threadIdx.x; t < BN; t += 256) {
+    const int b = t / d.N, n = t - b * d.N;
+    const int gz = n / (gh * gw), gy = (n / gw) % gh, gx = n % gw;
+    sTok[t] = (int)(((((int64_t)b * d.M + m) * D + gz * 16) * H + gy * 16) * W + gx * 16);
+  }
+  int koff[4];  // brick-local offset of this thread's four k positions (loop invariant)
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int kk = ((threadIdx.x + 256 * u) * 4) & 127, k = kb + kk;
+    koff[u] = ((k >> 8) * H + ((k >> 4) & 15)) * W + (k & 15);
+  }
+  __syncthreads();
+  float4 rd, rp[4];
+  auto load_tile_regs = [&](int t0) __attribute__((always_inline)) {
     {
       int i = threadIdx.x * 4, tl = i >> 5, c = i & 31, t = min(t0 + tl, BN - 1);   // [32 tok][32 c]
       rd = *reinterpret_cast<const float4*>(dtok + ((int64_t)m * BN + t) * DM + min(cb + c, DM - 4));
@@ -987,15 +1011,14 @@ __global__ __launch_bounds__(256) void patch_embed_wgrad_kernel(TfDims d, const 
     }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-      int i = (threadIdx.x + 256 * u) * 4, tl = i >> 7, kk = i & 127, t = min(t0 + tl, BN - 1);  // [32 tok][128 kk]
-      int b = t / d.N, n = t - b * d.N;
-      int gz = n / (gh * gw), gy = (n / gw) % gh, gx = n % gw;
-      int k = kb + kk, dz = k >> 8, dy = (k >> 4) & 15, dx = k & 15;
-      rp[u] = *reinterpret_cast<const float4*>(
-          x + ((((int64_t)b * d.M + m) * D + gz * 16 + dz) * H + gy * 16 + dy) * W + gx * 16 + dx);
+      const int tl = ((threadIdx.x + 256 * u) * 4) >> 7, t = min(t0 + tl, BN - 1);  // [32 tok][128 kk]
+      rp[u] = *reinterpret_cast<const float4*>(x + sTok[t] + koff[u]);
       if (t0 + tl >= BN) rp[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    __syncthreads();
+  };
+  load_tile_regs(0);
+  for (int t0 = 0; t0 < BN; t0 += TT) {
+    __syncthreads();  // the previous tile's MFMAs are done with the LDS tiles
     {
       int i = threadIdx.x * 4, tl = i >> 5, c = i & 31;
       float* dst = sD + tl * LDD + c;
@@ -1008,6 +1031,7 @@ __global__ __launch_bounds__(256) void patch_embed_wgrad_kernel(TfDims d, const 
       dst[0] = rp[u].x, dst[1] = rp[u].y, dst[2] = rp[u].z, dst[3] = rp[u].w;
     }
     __syncthreads();
+    if (t0 + TT < BN) load_tile_regs(t0 + TT);
     for (int t2 = 0; t2 < TT / 2; t2++) {
       float av = sD[(2 * t2 + h) * LDD + r];
       float bv = sP[(2 * t2 + h) * LDP + wave * 32 + r];
@@ -1051,8 +1075,9 @@ int tf_patch_embed_bwd(const TfDims& d, const float* x, int D, int H, int W, con
   hipLaunchKernelGGL(patch_embed_bwd_prep_kernel, dim3(ceil_div(d.N * d.DM, 256), d.M), dim3(256), 0, st, d, dF,
                      scratch, dbpe, dpos);
   HDF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(patch_embed_wgrad_kernel, dim3(4096 / 128, ceil_div(d.DM, 32), d.M), dim3(256), 0, st, d, x, D, H,
-                     W, scratch, dwpe);
+  HDF_CHECK_ARG((int64_t)d.B * d.M * D * H * W < ((int64_t)1 << 31), "patch_embed: volume exceeds 32-bit element offsets");
+  hipLaunchKernelGGL(patch_embed_wgrad_kernel, dim3(4096 / 128, ceil_div(d.DM, 32), d.M), dim3(256),
+                     (size_t)d.B * d.N * sizeof(int), st, d, x, D, H, W, scratch, dwpe);
   HDF_LAUNCH_CHECK();
   return HDF_OK;
 }
