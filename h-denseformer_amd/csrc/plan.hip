@@ -627,7 +627,10 @@ int conv_backward(Exec& e, Conv3& c, const View& dy, const View& in, Xf xf, cons
   w.lg_shift = xf.shift;
   w.lg_relu = xf.relu;
   HDF_TRY(hdf_launch_wgrad(p->dtype, 1, w, e.G(c.w), c.Cout, c.Cin, 0, e.ws + p->wgrad_ws, p->wgrad_ws_bytes, e.st));
-  if (c.b >= 0) HDF_TRY(hdf_launch_bias_grad(p->dtype, e.at(dy), dy.pitch, e.G(c.b), c.Cout, (int64_t)e.B * p->vox(c.lvl), e.st));
+  // Conv3 layers with a bias are the UpConvs (HDenseFormer.py:162-175): conv(bias) -> InstanceNorm3d(affine=False).
+  // The norm subtracts the per-(sample, channel) mean, so dL/dbias = sum_voxels dy is identically zero (the reference
+  // accumulates ~3e-8 of rounding noise there); the gradient buffer was zeroed at the start of backward,
+  // so the four reduction passes over dy are simply not run.
   if (din) {
     // dgrad = the same conv with taps reversed and channel roles swapped: Wd[t][ci][co] = W[co][ci][26-t]
     const int OP = round_up(c.Cin, 32);
