@@ -102,6 +102,7 @@ struct hdf_plan {
   View gA[4], gY[4], dCat[3], dUp[3], dSkip[3], dP[3], dUa[4], dUy[4], dX4, dAttnall;
   bool dcat_split[3] = {false, false, false};
   bool no_head_fuse = getenv("HDF_NO_HEAD_FUSE") != nullptr;  // A/B knob: separate in_bwd_reduce after the heads
+  bool no_bias_fuse = getenv("HDF_NO_BIAS_FUSE") != nullptr;  // A/B knob: separate pass for the ConvTranspose3d bias gradients
   // state carried from forward to backward
   int training = 0;
   uint32_t seed = 0;
@@ -608,8 +609,11 @@ int in_backward(Exec& e, const Conv3& c, const View& da, const View& dy, int pre
 }
 
 // conv backward: weight (and bias) gradient from (dy, input) and optionally the input gradient
+// din_colsum (optional, [colsum_C] floats): += the per-channel sums over (sample, voxel) of the first colsum_C channels of
+// the input gradient, taken from the dgrad conv's own InstanceNorm-partials epilogue (fp32 accumulators): the
+// ConvTranspose3d bias gradient of the layer that produced those channels, without a pass over the tensor
 int conv_backward(Exec& e, Conv3& c, const View& dy, const View& in, Xf xf, const View* din, int accumulate,
-                  const View* din2 = nullptr) {
+                  const View* din2 = nullptr, float* din_colsum = nullptr, int colsum_C = 0) {
   hdf_plan* p = e.p;
   const int* d = e.dm(c.lvl);
   WgradArgs w{};
@@ -653,7 +657,12 @@ int conv_backward(Exec& e, Conv3& c, const View& dy, const View& in, Xf xf, cons
       a.out2 = e.at(*din2);
       a.split = din->C;
     }
+    if (din_colsum) a.stat_partials = e.f(p->stat_partials);  // forward scratch, free during backward
     HDF_TRY(hdf_launch_conv(p->dtype, 0, a, e.st));
+    if (din_colsum) {
+      const int rows = e.B * hdf_conv_stat_tiles(0, d[0], d[1], d[2], a.Cin * p->esz);
+      HDF_TRY(hdf_launch_stat_rows_sum(e.f(p->stat_partials), rows, colsum_C, OP, din_colsum, e.st));
+    }
   }
   return HDF_OK;
 }
@@ -662,8 +671,9 @@ int conv_backward(Exec& e, Conv3& c, const View& dy, const View& in, Xf xf, cons
 int convt_backward(Exec& e, ConvT3& t, const View& dout, const View& in, Xf xf, const View& din) {
   hdf_plan* p = e.p;
   const int* d = e.dm(t.lvl_in);
-  HDF_TRY(hdf_launch_bias_grad(p->dtype, e.at(dout), dout.pitch, e.G(t.b), t.Cout, (int64_t)e.B * p->vox(t.lvl_in - 1),
-                               e.st));
+  if (p->no_bias_fuse)  // else: taken from the epilogue of the dgrad conv that produced dout (conv_backward)
+    HDF_TRY(hdf_launch_bias_grad(p->dtype, e.at(dout), dout.pitch, e.G(t.b), t.Cout,
+                                 (int64_t)e.B * p->vox(t.lvl_in - 1), e.st));
   WgradArgs w{};
   w.sm = e.at(in);
   w.sm_pitch = in.pitch;
@@ -898,10 +908,12 @@ int hdf_backward_stages(hdf_plan* p, const float* x, const float* params, void* 
     HDF_TRY(in_backward(e, c2, p->gA[k], p->gY[k], pre));
     HDF_TRY(conv_backward(e, c2, p->gY[k], c1.y, xf_of(e, c1), &p->gA[k], 0));
     HDF_TRY(in_backward(e, c1, p->gA[k], p->gY[k]));
+    // the upconv half of d(cat) is the gradient of upconv_{k+1}'s output: its bias gradient rides on this conv
+    float* up_db = p->no_bias_fuse ? nullptr : e.G(p->upc[k].b);
     if (p->dcat_split[k])
-      HDF_TRY(conv_backward(e, c1, p->gY[k], p->cat[k], none, &p->dUp[k], 0, &p->dSkip[k]));
+      HDF_TRY(conv_backward(e, c1, p->gY[k], p->cat[k], none, &p->dUp[k], 0, &p->dSkip[k], up_db, ch[k]));
     else
-      HDF_TRY(conv_backward(e, c1, p->gY[k], p->cat[k], none, &p->dCat[k], 0));
+      HDF_TRY(conv_backward(e, c1, p->gY[k], p->cat[k], none, &p->dCat[k], 0, nullptr, up_db, ch[k]));
     // upconv_{k+1}: input is dec[k+1][1] activation (k<2) or the bottleneck x4 (k==2)
     const View& dup = p->dUp[k];
     if (k < 2)

@@ -67,4 +67,6 @@ int hdf_in_bwd_blocks(int64_t vox, int C);
 int hdf_launch_add(int dtype, void* a, int64_t a_pitch, const void* b, int64_t b_pitch, int N, int C, int64_t vox,
                    int accumulate, hipStream_t st);
 // bias gradient of a conv output gradient: db[c] += sum_{n,v} dy[n,v,c]
+// out[c] += column sums (sum column) of a conv InstanceNorm partial table [rows][CP][2], c < C
+int hdf_launch_stat_rows_sum(const float* partials, int rows, int C, int CP, float* out, hipStream_t st);
 int hdf_launch_bias_grad(int dtype, const void* dy, int64_t dy_pitch, float* db, int C, int64_t nvox, hipStream_t st);

@@ -980,6 +980,36 @@ int hdf_launch_nchw_to_ndhwc(int dtype, const float* x, void* out, int N, int C,
   return HDF_OK;
 }
 
+// out[c] += sum over `rows` partial rows of partials[row][c][0] (the per-channel SUM column of the conv kernels'
+// InstanceNorm partial table), c < C.  grid ceil(C/32), 1024 threads = 32 row lanes x 32 channels, fixed order.
+__global__ __launch_bounds__(1024) void stat_rows_sum_kernel(const float* __restrict__ partials, int rows, int C, int CP,
+                                                             float* __restrict__ out) {
+  __shared__ double red[32][32];
+  const int cl = threadIdx.x & 31, c = blockIdx.x * 32 + cl, rl = threadIdx.x >> 5;
+  double s = 0.0;
+  if (c < C) {
+    const float* p = partials + (int64_t)c * 2;
+    const int64_t rs = (int64_t)CP * 2;
+    int r = rl;
+    for (; r + 96 < rows; r += 128)
+      s += ((double)p[(int64_t)r * rs] + (double)p[(int64_t)(r + 32) * rs]) +
+           ((double)p[(int64_t)(r + 64) * rs] + (double)p[(int64_t)(r + 96) * rs]);
+    for (; r < rows; r += 32) s += (double)p[(int64_t)r * rs];
+  }
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    for (int k = 1; k < 32; k++) s += red[k][cl];
+    out[c] += (float)s;
+  }
+}
+
+int hdf_launch_stat_rows_sum(const float* partials, int rows, int C, int CP, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(stat_rows_sum_kernel, dim3(ceil_div(C, 32)), dim3(1024), 0, st, partials, rows, C, CP, out);
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
 int hdf_launch_in_finalize(const float* partials, int N, int tiles, int C, int CP, int64_t vox, const float* gamma,
                            const float* beta, float eps, float* mean, float* rstd, float* scale, float* shift,
                            hipStream_t st) {
