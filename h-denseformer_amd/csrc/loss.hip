@@ -74,8 +74,8 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(const T* __restrict__ log
 // grid = nscale*N blocks of 256 threads (one per partial slot): per-(scale, sample) loss term + the backward
 // coefficients coef[(i*N+n)*MAXC + c] = (A, B) of the Dice gradient; terms[i*N+n] is summed by loss_total_kernel
 __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ partials, int nscale, int N, int C,
-                                                            int blocks, LossScales sc, float smooth,
-                                                            float* __restrict__ terms, float* __restrict__ coefA,
+                                                            int blocks, LossScales sc, float smooth, float w_ce,
+                                                            float w_dice, float* __restrict__ terms, float* __restrict__ coefA,
                                                             float* __restrict__ coefB) {
   __shared__ double red[4][NSTAT];
   const int i = blockIdx.x / N, n = blockIdx.x % N;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
     coefB[((int64_t)i * N + n) * MAXC] = 0.f;
     dice /= (double)(C - 1);
     // CE is already a mean over all N samples' voxels: every (scale, n) block contributes its own share
-    terms[blockIdx.x] = (float)((ce + dice) * (double)sc.weight[i]);
+    terms[blockIdx.x] = (float)(((double)w_ce * ce + (double)w_dice * dice) * (double)sc.weight[i]);
   }
 }
 
@@ -127,13 +127,14 @@ template <typename T>
 __global__ __launch_bounds__(256) void loss_bwd_kernel(const T* __restrict__ logits, const float* __restrict__ target,
                                                        int N, int C, int Ds, int Hs, int Ws, int stride, int D, int H,
                                                        int W, const float* __restrict__ coefA,
-                                                       const float* __restrict__ coefB, float weight,
-                                                       const float* __restrict__ gup, T* __restrict__ dlogits) {
+                                                       const float* __restrict__ coefB, float weight, float w_ce,
+                                                       float w_dice, const float* __restrict__ gup,
+                                                       T* __restrict__ dlogits) {
   const int n = blockIdx.y;
   const int64_t V = (int64_t)Ds * Hs * Ws, Vf = (int64_t)D * H * W;
   const float g = (*gup) * weight;
-  const float kce = g / ((float)V * (float)N);
-  const float kd = g / ((float)(C - 1) * (float)N);
+  const float kce = w_ce * g / ((float)V * (float)N);
+  const float kd = w_dice * g / ((float)(C - 1) * (float)N);
   float cA[MAXC], cB[MAXC];
 #pragma unroll
   for (int c = 0; c < MAXC; c++) {
@@ -244,6 +245,95 @@ __global__ __launch_bounds__(256) void confusion_kernel(const T* __restrict__ lo
     atomicAdd(conf + threadIdx.x, (unsigned long long)red[threadIdx.x]);
 }
 
+// the same from two uint8 class maps (the reference's call signature: RunningDice.update_matrix(ground_truth,
+// prediction), metrics.py:104); labels >= C are not counted (sklearn's confusion_matrix(labels=...) drops them)
+__global__ __launch_bounds__(256) void confusion_labels_kernel(const uint8_t* __restrict__ tgt,
+                                                               const uint8_t* __restrict__ pred, int C, int64_t n,
+                                                               unsigned long long* __restrict__ conf) {
+  __shared__ unsigned int red[MAXC * MAXC];
+  if (threadIdx.x < MAXC * MAXC) red[threadIdx.x] = 0;
+  __syncthreads();
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < n; v += (int64_t)gridDim.x * 256) {
+    const int tc = tgt[v], pc = pred[v];
+    if (tc < C && pc < C) atomicAdd(&red[tc * MAXC + pc], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < MAXC * MAXC && red[threadIdx.x])
+    atomicAdd(conf + threadIdx.x, (unsigned long long)red[threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------------- input normalisation
+// data_utils/data_loader.py:39-68.  Per-channel reductions over the volume in a fixed order (block partials in
+// fp64, then one block), then one elementwise pass.  stats[c] = (max, sum, sum of squares, unused).
+constexpr int NORM_BLOCKS = 512;
+__global__ __launch_bounds__(256) void norm_reduce_kernel(const float* __restrict__ img, int64_t V,
+                                                          double* __restrict__ part /*[C][NORM_BLOCKS][3]*/) {
+  __shared__ double red[4][3];
+  const int c = blockIdx.y;
+  const float* p = img + (int64_t)c * V;
+  double mx = -INFINITY, s = 0.0, ss = 0.0;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < V; v += (int64_t)gridDim.x * 256) {
+    const double x = (double)p[v];
+    mx = fmax(mx, x);
+    s += x;
+    ss += x * x;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mx = fmax(mx, __shfl_xor(mx, o, 64));
+    s += __shfl_xor(s, o, 64);
+    ss += __shfl_xor(ss, o, 64);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) red[wave][0] = mx, red[wave][1] = s, red[wave][2] = ss;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double* o = part + ((int64_t)c * gridDim.x + blockIdx.x) * 3;
+    o[0] = fmax(fmax(red[0][0], red[1][0]), fmax(red[2][0], red[3][0]));
+    o[1] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+    o[2] = red[0][2] + red[1][2] + red[2][2] + red[3][2];
+  }
+}
+__global__ void norm_finalize_kernel(const double* __restrict__ part, int blocks, int64_t V,
+                                     double* __restrict__ stats /*[C][4]: max, mean, std (population), 0*/) {
+  const int c = blockIdx.x;
+  if (threadIdx.x == 0) {
+    double mx = -INFINITY, s = 0.0, ss = 0.0;
+    for (int b = 0; b < blocks; b++) {
+      const double* q = part + ((int64_t)c * blocks + b) * 3;
+      mx = fmax(mx, q[0]);
+      s += q[1];
+      ss += q[2];
+    }
+    const double mean = s / (double)V;
+    stats[c * 4 + 0] = mx;
+    stats[c * 4 + 1] = mean;
+    stats[c * 4 + 2] = sqrt(fmax(ss / (double)V - mean * mean, 0.0));
+    stats[c * 4 + 3] = 0.0;
+  }
+}
+// mode 0 (MRNormalize, data_loader.py:39-50): x / max(channel) when the max is non-zero, then negatives -> 0.
+// mode 1 (PETandCTNormalize, :53-68): channel 0 -> (clip(x, mean-w, mean+w) - mean) / w ; channel 1 -> (x - mean_1)
+//         / (std_1 + 1e-3) ; further channels untouched.
+__global__ void norm_apply_kernel(float* __restrict__ img, int64_t V, const double* __restrict__ stats, int mode,
+                                  float pmean, float pw) {
+  const int c = blockIdx.y;
+  float* p = img + (int64_t)c * V;
+  const float mx = (float)stats[c * 4 + 0], mean = (float)stats[c * 4 + 1], sd = (float)stats[c * 4 + 2];
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (int64_t)gridDim.x * blockDim.x) {
+    float x = p[v];
+    if (mode == 0) {
+      if (mx != 0.f) x = x / mx;
+      x = x < 0.f ? 0.f : x;
+    } else if (c == 0) {
+      x = (fminf(fmaxf(x, pmean - pw), pmean + pw) - pmean) / pw;
+    } else if (c == 1) {
+      x = (x - mean) / (sd + 1e-3f);
+    }
+    p[v] = x;
+  }
+}
+
 // ---------------------------------------------------------------------------------- Adam
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, const uint8_t* __restrict__ decay, int64_t n, float lr, float b1,
@@ -267,7 +357,7 @@ size_t hdf_loss_workspace_floats(int N, int nscale) {
 }
 
 int hdf_launch_loss_fwd(int dtype, const void* const* logits, const float* target, int nscale, int N, int C, int D,
-                        int H, int W, float* ws, float* loss_out, hipStream_t st) {
+                        int H, int W, float* ws, float* loss_out, hipStream_t st, float w_ce, float w_dice) {
   HDF_CHECK_ARG(C <= MAXC && C >= 2, "loss: n_cls=%d unsupported (2..%d)", C, MAXC);
   HDF_CHECK_ARG(nscale <= 4 && nscale * N <= 256, "loss: nscale=%d N=%d", nscale, N);
   float* partials = ws;
@@ -291,7 +381,7 @@ int hdf_launch_loss_fwd(int dtype, const void* const* logits, const float* targe
   }
   float* terms = coefB + (size_t)nscale * N * MAXC;
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(nscale * N), dim3(256), 0, st, partials, nscale, N, C, LOSS_BLOCKS, sc,
-                     1e-5f, terms, coefA, coefB);
+                     1e-5f, w_ce, w_dice, terms, coefA, coefB);
   HDF_LAUNCH_CHECK();
   hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(64), 0, st, terms, nscale * N, loss_out);
   HDF_LAUNCH_CHECK();
@@ -299,7 +389,8 @@ int hdf_launch_loss_fwd(int dtype, const void* const* logits, const float* targe
 }
 
 int hdf_launch_loss_bwd(int dtype, const void* const* logits, const float* target, int nscale, int N, int C, int D,
-                        int H, int W, const float* ws, const float* grad_out, void* const* dlogits, hipStream_t st) {
+                        int H, int W, const float* ws, const float* grad_out, void* const* dlogits, hipStream_t st,
+                        float w_ce, float w_dice) {
   const float* coefA = ws + (size_t)nscale * N * LOSS_BLOCKS * NSTAT;
   const float* coefB = coefA + (size_t)nscale * N * MAXC;
   for (int i = 0; i < nscale; i++) {
@@ -310,11 +401,11 @@ int hdf_launch_loss_bwd(int dtype, const void* const* logits, const float* targe
     if (dtype == HDF_BF16)
       hipLaunchKernelGGL(loss_bwd_kernel<bf16_t>, dim3(gx, N), dim3(256), 0, st, (const bf16_t*)logits[i], target, N, C,
                          Ds, Hs, Ws, s, D, H, W, coefA + (size_t)i * N * MAXC, coefB + (size_t)i * N * MAXC,
-                         1.f / (float)s, grad_out, (bf16_t*)dlogits[i]);
+                         1.f / (float)s, w_ce, w_dice, grad_out, (bf16_t*)dlogits[i]);
     else
       hipLaunchKernelGGL(loss_bwd_kernel<float>, dim3(gx, N), dim3(256), 0, st, (const float*)logits[i], target, N, C,
                          Ds, Hs, Ws, s, D, H, W, coefA + (size_t)i * N * MAXC, coefB + (size_t)i * N * MAXC,
-                         1.f / (float)s, grad_out, (float*)dlogits[i]);
+                         1.f / (float)s, w_ce, w_dice, grad_out, (float*)dlogits[i]);
     HDF_LAUNCH_CHECK();
   }
   return HDF_OK;
@@ -355,6 +446,39 @@ int hdf_launch_confusion(int dtype, const void* logits, const float* target, int
                        conf);
   else
     hipLaunchKernelGGL(confusion_kernel<float>, dim3(gx, N), dim3(256), 0, st, (const float*)logits, target, C, V, conf);
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
+int hdf_launch_confusion_labels(const uint8_t* tgt, const uint8_t* pred, int C, int64_t n, unsigned long long* conf,
+                                int accumulate, hipStream_t st) {
+  HDF_CHECK_ARG(C >= 1 && C <= MAXC, "confusion: n_cls=%d", C);
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(conf, 0, (size_t)MAXC * MAXC * sizeof(unsigned long long), st);
+    if (e != hipSuccess) {
+      hdf_set_error("confusion: memset failed: %s", hipGetErrorString(e));
+      return HDF_ERR_HIP;
+    }
+  }
+  unsigned gx = (unsigned)std::min<int64_t>(std::max<int64_t>(ceil_div64(n, 256), 1), 1024);
+  hipLaunchKernelGGL(confusion_labels_kernel, dim3(gx), dim3(256), 0, st, tgt, pred, C, n, conf);
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
+size_t hdf_norm_ws_bytes(int C) { return ((size_t)C * NORM_BLOCKS * 3 + (size_t)C * 4) * sizeof(double); }
+int hdf_launch_normalize(float* img, int C, int64_t V, int mode, float pmean, float pw, void* ws, hipStream_t st) {
+  HDF_CHECK_ARG(C >= 1 && C <= 64 && V >= 1, "normalize: channels=%d voxels=%lld", C, (long long)V);
+  HDF_CHECK_ARG(mode == 0 || mode == 1, "normalize: mode %d", mode);
+  HDF_CHECK_ARG(mode == 0 || (C >= 2 && pw != 0.f), "normalize: PET/CT mode needs >= 2 channels and w != 0");
+  double* part = (double*)ws;
+  double* stats = part + (size_t)C * NORM_BLOCKS * 3;
+  hipLaunchKernelGGL(norm_reduce_kernel, dim3(NORM_BLOCKS, C), dim3(256), 0, st, img, V, part);
+  HDF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3(C), dim3(64), 0, st, part, NORM_BLOCKS, V, stats);
+  HDF_LAUNCH_CHECK();
+  unsigned gx = (unsigned)std::min<int64_t>(ceil_div64(V, 256), 4096);
+  hipLaunchKernelGGL(norm_apply_kernel, dim3(gx, C), dim3(256), 0, st, img, V, stats, mode, pmean, pw);
   HDF_LAUNCH_CHECK();
   return HDF_OK;
 }

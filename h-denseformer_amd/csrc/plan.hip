@@ -991,6 +991,22 @@ int hdf_loss_backward(int dtype, const void* out0, const void* out1, const void*
   return hdf_launch_loss_bwd(dtype, outs, target_onehot, nscale, batch, n_cls, D, H, W, (const float*)workspace,
                              grad_out, douts, (hipStream_t)stream);
 }
+int hdf_loss_terms_forward(int dtype, const void* out0, const void* out1, const void* out2, const void* out3, int nscale,
+                           const float* target_onehot, int batch, int n_cls, int D, int H, int W, float ce_weight,
+                           float dice_weight, void* workspace, float* loss_out, hdf_stream stream) {
+  const void* outs[4] = {out0, out1, out2, out3};
+  return hdf_launch_loss_fwd(dtype, outs, target_onehot, nscale, batch, n_cls, D, H, W, (float*)workspace, loss_out,
+                             (hipStream_t)stream, ce_weight, dice_weight);
+}
+int hdf_loss_terms_backward(int dtype, const void* out0, const void* out1, const void* out2, const void* out3,
+                            int nscale, const float* target_onehot, int batch, int n_cls, int D, int H, int W,
+                            float ce_weight, float dice_weight, const void* workspace, const float* grad_out,
+                            void* dout0, void* dout1, void* dout2, void* dout3, hdf_stream stream) {
+  const void* outs[4] = {out0, out1, out2, out3};
+  void* douts[4] = {dout0, dout1, dout2, dout3};
+  return hdf_launch_loss_bwd(dtype, outs, target_onehot, nscale, batch, n_cls, D, H, W, (const float*)workspace,
+                             grad_out, douts, (hipStream_t)stream, ce_weight, dice_weight);
+}
 int hdf_dice_counts(int dtype, const void* logits, const float* target_onehot, int batch, int n_cls, int64_t voxels,
                     uint64_t* counts, hdf_stream stream) {
   return hdf_launch_dice_counts(dtype, logits, target_onehot, batch, n_cls, voxels, (unsigned long long*)counts,
@@ -1000,6 +1016,22 @@ int hdf_confusion_matrix(int dtype, const void* logits, const float* target_oneh
                          int64_t voxels, uint64_t* confusion, int accumulate, hdf_stream stream) {
   return hdf_launch_confusion(dtype, logits, target_onehot, batch, n_cls, voxels, (unsigned long long*)confusion,
                               accumulate, (hipStream_t)stream);
+}
+int hdf_confusion_matrix_labels(const uint8_t* target, const uint8_t* prediction, int n_cls, int64_t n,
+                                uint64_t* confusion, int accumulate, hdf_stream stream) {
+  HDF_CHECK_ARG(target && prediction && confusion, "confusion_matrix_labels: null argument");
+  return hdf_launch_confusion_labels(target, prediction, n_cls, n, (unsigned long long*)confusion, accumulate,
+                                     (hipStream_t)stream);
+}
+int64_t hdf_normalize_workspace_bytes(int channels) { return (int64_t)hdf_norm_ws_bytes(channels); }
+int hdf_normalize_mr(float* image, int channels, int64_t voxels, void* workspace, hdf_stream stream) {
+  HDF_CHECK_ARG(image && workspace, "normalize_mr: null argument");
+  return hdf_launch_normalize(image, channels, voxels, 0, 0.f, 1.f, workspace, (hipStream_t)stream);
+}
+int hdf_normalize_petct(float* image, int channels, int64_t voxels, float mean, float w, void* workspace,
+                        hdf_stream stream) {
+  HDF_CHECK_ARG(image && workspace, "normalize_petct: null argument");
+  return hdf_launch_normalize(image, channels, voxels, 1, mean, w, workspace, (hipStream_t)stream);
 }
 int hdf_sw_accumulate(int dtype, const void* logits, int n_cls, int pd, int ph, int pw, float* prob_sum, float* count,
                       int D, int H, int W, int z0, int y0, int x0, hdf_stream stream) {
@@ -1133,6 +1165,119 @@ int hdf_op_upsample_fwd(int dtype, const void* y, int64_t y_pitch, const float* 
 int hdf_op_upsample_bwd(int dtype, const void* dout, int64_t dout_pitch, void* din, int64_t din_pitch, int N, int C,
                         int Di, int Hi, int Wi, hdf_stream stream) {
   return hdf_launch_upsample_bwd(dtype, dout, dout_pitch, din, din_pitch, N, C, Di, Hi, Wi, (hipStream_t)stream);
+}
+
+
+// ---- transformer / head operator level (HDenseFormer.py:47-145,223-227) -------------------------------------------
+namespace {
+TfDims op_dims(int M, int B, int N, int DM, int64_t mstride, int training, uint64_t seed) {
+  TfDims d;
+  d.M = M, d.B = B, d.N = N, d.DM = DM, d.DMF = DM + 128;
+  d.mstride = mstride;
+  d.training = training ? 1 : 0;
+  d.seed = (uint32_t)(seed & 0xffffffffu);
+  d.thresh24 = 1u << 23;
+  d.keep_scale = 2.0f;
+  return d;
+}
+int op_dims_ok(int M, int B, int N, int DM) {
+  HDF_CHECK_ARG(M >= 1 && B >= 1 && N >= 1, "transformer op: M=%d B=%d N=%d", M, B, N);
+  HDF_CHECK_ARG(DM >= 32 && DM <= 256 && DM % 32 == 0, "transformer op: token dim %d unsupported (32..256, x32)", DM);
+  return HDF_OK;
+}
+TfLayerP layer_ptrs(float* const* q) {
+  return TfLayerP{q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9], q[10], q[11], q[12]};
+}
+TfLayerSave save_ptrs(float* base, int64_t rows) {
+  TfLayerSave s;
+  s.h0 = base, s.qkv = base + rows * 32, s.ob = base + rows * 128, s.lse = base + rows * 160;
+  s.h1 = base + rows * 168, s.h2 = base + rows * 200;
+  return s;
+}
+}  // namespace
+
+int hdf_op_attention_fwd(const float* qkv, int nseq, int N, float* ob, float* lse, hdf_stream stream) {
+  HDF_CHECK_ARG(qkv && ob && lse && nseq >= 1, "attention_fwd: null argument");
+  return tf_attention_fwd(N, nseq, qkv, ob, lse, (hipStream_t)stream);
+}
+int hdf_op_attention_bwd(const float* qkv, const float* ob, const float* lse, const float* d_ob, float* dqkv, int nseq,
+                         int N, hdf_stream stream) {
+  HDF_CHECK_ARG(qkv && ob && lse && d_ob && dqkv && nseq >= 1, "attention_bwd: null argument");
+  return tf_attention_bwd(N, nseq, qkv, ob, lse, d_ob, dqkv, (hipStream_t)stream);
+}
+int hdf_op_patch_embed_fwd(const float* x, int M, int B, int D, int H, int W, int DM, const float* weight,
+                           const float* bias, const float* pos, int64_t mstride, float* F, int training, uint64_t seed,
+                           hdf_stream stream) {
+  HDF_CHECK_ARG(x && weight && bias && pos && F, "patch_embed_fwd: null argument");
+  HDF_CHECK_ARG(D % 16 == 0 && H % 16 == 0 && W % 16 == 0, "patch_embed_fwd: size (%d,%d,%d) not x16", D, H, W);
+  const int N = (D / 16) * (H / 16) * (W / 16);
+  HDF_TRY(op_dims_ok(M, B, N, DM));
+  return tf_patch_embed_fwd(op_dims(M, B, N, DM, mstride, training, seed), x, D, H, W, weight, bias, pos, F,
+                            (hipStream_t)stream);
+}
+int hdf_op_patch_embed_bwd(const float* x, int M, int B, int D, int H, int W, int DM, const float* dF, int64_t mstride,
+                           float* dweight, float* dbias, float* dpos, float* scratch, int training, uint64_t seed,
+                           hdf_stream stream) {
+  HDF_CHECK_ARG(x && dF && dweight && dbias && dpos && scratch, "patch_embed_bwd: null argument");
+  const int N = (D / 16) * (H / 16) * (W / 16);
+  HDF_TRY(op_dims_ok(M, B, N, DM));
+  return tf_patch_embed_bwd(op_dims(M, B, N, DM, mstride, training, seed), x, D, H, W, dF, dweight, dbias, dpos, scratch,
+                            (hipStream_t)stream);
+}
+int hdf_op_dense_layer_fwd(int M, int B, int N, int DM, int block, int layer, const float* const* params13,
+                           int64_t mstride, float* F, float* save, int training, uint64_t seed, hdf_stream stream) {
+  HDF_CHECK_ARG(params13 && F && save && layer >= 0 && layer < 4, "dense_layer_fwd: bad argument");
+  HDF_TRY(op_dims_ok(M, B, N, DM));
+  return tf_layer_fwd(op_dims(M, B, N, DM, mstride, training, seed), block, layer,
+                      layer_ptrs(const_cast<float* const*>(reinterpret_cast<const float* const*>(params13))), F,
+                      save_ptrs(save, (int64_t)M * B * N), (hipStream_t)stream);
+}
+int hdf_op_dense_layer_bwd(int M, int B, int N, int DM, int block, int layer, const float* const* params13,
+                           float* const* grads13, int64_t mstride, const float* F, float* dF, const float* save,
+                           float* scratch, int training, uint64_t seed, hdf_stream stream) {
+  HDF_CHECK_ARG(params13 && grads13 && F && dF && save && scratch && layer >= 0 && layer < 4,
+                "dense_layer_bwd: bad argument");
+  HDF_TRY(op_dims_ok(M, B, N, DM));
+  return tf_layer_bwd(op_dims(M, B, N, DM, mstride, training, seed), block, layer,
+                      layer_ptrs(const_cast<float* const*>(reinterpret_cast<const float* const*>(params13))),
+                      layer_ptrs(grads13), F, dF, save_ptrs(const_cast<float*>(save), (int64_t)M * B * N), scratch,
+                      (hipStream_t)stream);
+}
+int hdf_op_block_out_fwd(int M, int B, int N, int DM, int block, const float* const* params4, int64_t mstride,
+                         const float* F, float* next_F, void* attnall, int dtype, int training, uint64_t seed,
+                         hdf_stream stream) {
+  HDF_CHECK_ARG(params4 && F && ((next_F != nullptr) != (attnall != nullptr)), "block_out_fwd: bad argument");
+  HDF_TRY(op_dims_ok(M, B, N, DM));
+  TfOutP o{const_cast<float*>(params4[0]), const_cast<float*>(params4[1]), const_cast<float*>(params4[2]),
+           const_cast<float*>(params4[3])};
+  return tf_block_out_fwd(op_dims(M, B, N, DM, mstride, training, seed), block, o, F, next_F, attnall, dtype,
+                          (hipStream_t)stream);
+}
+int hdf_op_block_out_bwd(int M, int B, int N, int DM, int block, const float* const* params4, float* const* grads4,
+                         int64_t mstride, const float* F, const float* dF_next, const void* d_attnall, int dtype,
+                         float* dF, int training, uint64_t seed, hdf_stream stream) {
+  HDF_CHECK_ARG(params4 && grads4 && F && dF && ((dF_next != nullptr) != (d_attnall != nullptr)),
+                "block_out_bwd: bad argument");
+  HDF_TRY(op_dims_ok(M, B, N, DM));
+  TfOutP o{const_cast<float*>(params4[0]), const_cast<float*>(params4[1]), const_cast<float*>(params4[2]),
+           const_cast<float*>(params4[3])};
+  TfOutP g{grads4[0], grads4[1], grads4[2], grads4[3]};
+  return tf_block_out_bwd(op_dims(M, B, N, DM, mstride, training, seed), block, o, g, F, dF_next, d_attnall, dtype, dF,
+                          (hipStream_t)stream);
+}
+int hdf_op_head_fwd(int dtype, const void* in, int64_t in_pitch, const float* in_scale, const float* in_shift,
+                    const float* weight, const float* bias, void* logits, int N, int C, int n_cls, int64_t voxels,
+                    hdf_stream stream) {
+  HDF_CHECK_ARG(in && weight && bias && logits, "head_fwd: null argument");
+  return hdf_launch_head_fwd(dtype, in, in_pitch, in_scale, in_shift, weight, bias, logits, N, C, n_cls, voxels,
+                             (hipStream_t)stream);
+}
+int hdf_op_head_bwd(int dtype, const void* dlogits, const void* in, int64_t in_pitch, const float* in_scale,
+                    const float* in_shift, const float* weight, void* dx, int64_t dx_pitch, int accumulate_dx,
+                    float* dweight, float* dbias, int N, int C, int n_cls, int64_t voxels, hdf_stream stream) {
+  HDF_CHECK_ARG(dlogits && in && weight && dx && dweight && dbias, "head_bwd: null argument");
+  return hdf_launch_head_bwd(dtype, dlogits, in, in_pitch, in_scale, in_shift, weight, dx, dx_pitch, accumulate_dx,
+                             dweight, dbias, N, C, n_cls, voxels, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -42,6 +42,13 @@ int tf_patch_embed_fwd(const TfDims& d, const float* x /*[B][M][D][H][W]*/, int 
 int tf_patch_embed_bwd(const TfDims& d, const float* x, int D, int H, int W, const float* dF /*[rows][DMF]*/,
                        float* dwpe, float* dbpe, float* dpos, float* scratch /*[rows][DM]*/, hipStream_t st);
 
+// Dense_Attention core (HDenseFormer.py:67-74): qkv [nseq*N][96] (q | k | v, 8 heads x 4) -> ob [nseq*N][32] (heads
+// merged, before to_out), lse [nseq*N][8] (natural-log row log-sum-exp of the 0.5-scaled scores)
+int tf_attention_fwd(int N, int nseq, const float* qkv, float* ob, float* lse, hipStream_t st);
+// dO [nseq*N][32] -> dqkv [nseq*N][96]
+int tf_attention_bwd(int N, int nseq, const float* qkv, const float* ob, const float* lse, const float* dO, float* dqkv,
+                     hipStream_t st);
+
 int tf_layer_fwd(const TfDims& d, int block, int layer, const TfLayerP& p, float* F, const TfLayerSave& s,
                  hipStream_t st);
 int tf_layer_bwd(const TfDims& d, int block, int layer, const TfLayerP& p, const TfLayerP& g, const float* F, float* dF,

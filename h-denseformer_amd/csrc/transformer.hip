@@ -1064,6 +1064,7 @@ int tf_patch_embed_fwd(const TfDims& d, const float* x, int D, int H, int W, con
                        const float* pos, float* F, hipStream_t st) {
   HDF_CHECK_ARG(d.DM <= 256 && d.DM % 32 == 0, "patch_embed: token dim %d unsupported", d.DM);
   size_t shm = (size_t)(32 + d.DM) * 65 * sizeof(float);
+  HDF_TRY(allow_lds(patch_embed_fwd_kernel, shm));
   hipLaunchKernelGGL(patch_embed_fwd_kernel, dim3(ceil_div(d.B * d.N, 32), d.M), dim3(256), shm, st, d, x, D, H, W, wpe,
                      bpe, pos, F);
   HDF_LAUNCH_CHECK();
@@ -1082,6 +1083,26 @@ int tf_patch_embed_bwd(const TfDims& d, const float* x, int D, int H, int W, con
   return HDF_OK;
 }
 
+int tf_attention_fwd(int N, int nseq, const float* qkv, float* ob, float* lse, hipStream_t st) {
+  const size_t shm = (size_t)attn_rows(N) * 32;
+  HDF_CHECK_ARG(N >= 1 && shm <= LDS_LIMIT, "attention: %d tokens need %zu B of LDS", N, shm);
+  HDF_TRY(allow_lds(attn_fwd_kernel, shm));
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(ceil_div(N, AQ), 8, nseq), dim3(256), shm, st, N, qkv, ob, lse);
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
+int tf_attention_bwd(int N, int nseq, const float* qkv, const float* ob, const float* lse, const float* dO, float* dqkv,
+                     hipStream_t st) {
+  const size_t shm = (size_t)attn_rows(N) * 40;
+  HDF_CHECK_ARG(N >= 1 && shm <= LDS_LIMIT, "attention backward: %d tokens need %zu B of LDS", N, shm);
+  HDF_TRY(allow_lds(attn_bwd_kernel, shm));
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(ceil_div(N, AQ), 8, 2 * nseq), dim3(256), shm, st, N, nseq, qkv, ob, lse, dO,
+                     dqkv);
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
 int tf_layer_fwd(const TfDims& d, int block, int layer, const TfLayerP& p, float* F, const TfLayerSave& s,
                  hipStream_t st) {
   const int K = d.DM + 32 * layer, BN = d.B * d.N;
@@ -1090,9 +1111,7 @@ int tf_layer_fwd(const TfDims& d, int block, int layer, const TfLayerP& p, float
   HDF_TRY(allow_lds(dense_pre_fwd_kernel, shm));
   hipLaunchKernelGGL(dense_pre_fwd_kernel, grid, dim3(256), shm, st, d, K, p, F, s.h0, s.qkv);
   HDF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(ceil_div(d.N, AQ), 8, d.M * d.B), dim3(256), (size_t)attn_rows(d.N) * 32, st, d.N,
-                     s.qkv, s.ob, s.lse);
-  HDF_LAUNCH_CHECK();
+  HDF_TRY(tf_attention_fwd(d.N, d.M * d.B, s.qkv, s.ob, s.lse, st));
   hipLaunchKernelGGL(dense_post_fwd_kernel, grid, dim3(256), 0, st, d, block, layer, p, s.h0, s.ob, s.h1, s.h2, F);
   HDF_LAUNCH_CHECK();
   return HDF_OK;
@@ -1109,9 +1128,7 @@ int tf_layer_bwd(const TfDims& d, int block, int layer, const TfLayerP& p, const
   hipLaunchKernelGGL(dense_post_bwd_kernel, grid, dim3(256), 0, st, d, block, layer, p, g, s.h1, s.h2, s.ob, dF, dO,
                      dh0acc);
   HDF_LAUNCH_CHECK();
-  dim3 ag(ceil_div(d.N, AQ), 8, 2 * d.M * d.B);
-  hipLaunchKernelGGL(attn_bwd_kernel, ag, dim3(256), (size_t)attn_rows(d.N) * 40, st, d.N, d.M * d.B, s.qkv, s.ob, s.lse, dO, dqkv);
-  HDF_LAUNCH_CHECK();
+  HDF_TRY(tf_attention_bwd(d.N, d.M * d.B, s.qkv, s.ob, s.lse, dO, dqkv, st));
   size_t shm = (size_t)(TB * K + TB * 32 + TB * 96 + TB * 32 + 8 * 32 * 2 + 32 * (K + 1) + 96 * 33) * sizeof(float);
   HDF_TRY(allow_lds(dense_pre_bwd_kernel, shm));
   hipLaunchKernelGGL(dense_pre_bwd_kernel, grid, dim3(256), shm, st, d, K, p, g, F, s.h0, dqkv, dh0acc, dF);

@@ -31,8 +31,15 @@ _PROTOS = {
     "hdf_loss_forward": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "hdf_loss_backward": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                _vp]),
+    "hdf_loss_terms_forward": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
+    "hdf_loss_terms_backward": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp,
+                                     _vp, _vp, _vp]),
     "hdf_dice_counts": (_i, [_i, _vp, _vp, _i, _i, _i64, _vp, _vp]),
     "hdf_confusion_matrix": (_i, [_i, _vp, _vp, _i, _i, _i64, _vp, _i, _vp]),
+    "hdf_confusion_matrix_labels": (_i, [_vp, _vp, _i, _i64, _vp, _i, _vp]),
+    "hdf_normalize_workspace_bytes": (_i64, [_i]),
+    "hdf_normalize_mr": (_i, [_vp, _i, _i64, _vp, _vp]),
+    "hdf_normalize_petct": (_i, [_vp, _i, _i64, _f, _f, _vp, _vp]),
     "hdf_sw_accumulate": (_i, [_i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "hdf_sw_finalize": (_i, [_vp, _vp, _i, _i64, _vp, _vp]),
     "hdf_onehot_from_labels": (_i, [_vp, _vp, _i, _i, _i64, _vp]),
@@ -54,6 +61,16 @@ _PROTOS = {
     "hdf_op_maxpool_bwd": (_i, [_i, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp]),
     "hdf_op_upsample_fwd": (_i, [_i, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp]),
     "hdf_op_upsample_bwd": (_i, [_i, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _vp]),
+    "hdf_op_attention_fwd": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+    "hdf_op_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "hdf_op_patch_embed_fwd": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _i, _u64, _vp]),
+    "hdf_op_patch_embed_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _i, _u64, _vp]),
+    "hdf_op_dense_layer_fwd": (_i, [_i, _i, _i, _i, _i, _i, _vp, _i64, _vp, _vp, _i, _u64, _vp]),
+    "hdf_op_dense_layer_bwd": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i, _u64, _vp]),
+    "hdf_op_block_out_fwd": (_i, [_i, _i, _i, _i, _i, _vp, _i64, _vp, _vp, _vp, _i, _i, _u64, _vp]),
+    "hdf_op_block_out_bwd": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _i64, _vp, _vp, _vp, _i, _vp, _i, _u64, _vp]),
+    "hdf_op_head_fwd": (_i, [_i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp]),
+    "hdf_op_head_bwd": (_i, [_i, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _i, _i, _i, _i64, _vp]),
 }
 
 EXPORTS = tuple(_PROTOS.keys())

@@ -9,8 +9,14 @@ _DT = {torch.float32: F32, torch.bfloat16: BF16}
 
 
 class DeepSuperCEDice(torch.autograd.Function):
+    """apply(target, *outs) = DeepSuperloss(CEPlusDice); apply((target, w_ce, w_dice), *outs) weights the two terms
+    (0,1: DiceLoss(ignore_index=0); 1,0: CrossentropyLoss)."""
+
     @staticmethod
     def forward(ctx, target, *outs):
+        w_ce, w_dice = 1.0, 1.0
+        if isinstance(target, tuple):
+            target, w_ce, w_dice = target
         if not all(o.is_cuda for o in outs) or not target.is_cuda:
             raise _lib.HdfError("fused loss needs GPU tensors (no CPU fallback)")
         dt = outs[0].dtype
@@ -28,10 +34,11 @@ class DeepSuperCEDice(torch.autograd.Function):
         ws = torch.empty(lib().hdf_loss_workspace_bytes(b), dtype=torch.uint8, device=tgt.device)
         loss = torch.empty((), dtype=torch.float32, device=tgt.device)
         po = [ptr(o) for o in outs] + [None] * (4 - n)
-        check(lib().hdf_loss_forward(_DT[dt], po[0], po[1], po[2], po[3], n, ptr(tgt), b, c, d, h, w, ptr(ws),
-                                     ptr(loss), stream_ptr()), "hdf_loss_forward")
+        check(lib().hdf_loss_terms_forward(_DT[dt], po[0], po[1], po[2], po[3], n, ptr(tgt), b, c, d, h, w,
+                                           float(w_ce), float(w_dice), ptr(ws), ptr(loss), stream_ptr()),
+              "hdf_loss_terms_forward")
         ctx.save_for_backward(tgt, ws, *outs)
-        ctx.n = n
+        ctx.n, ctx.w = n, (float(w_ce), float(w_dice))
         return loss
 
     @staticmethod
@@ -43,8 +50,9 @@ class DeepSuperCEDice(torch.autograd.Function):
         gg = g.detach().float().reshape(1).contiguous()
         po = [ptr(o) for o in outs] + [None] * (4 - n)
         pd = [ptr(o) for o in douts] + [None] * (4 - n)
-        check(lib().hdf_loss_backward(_DT[outs[0].dtype], po[0], po[1], po[2], po[3], n, ptr(tgt), b, c, d, h, w,
-                                      ptr(ws), ptr(gg), pd[0], pd[1], pd[2], pd[3], stream_ptr()), "hdf_loss_backward")
+        check(lib().hdf_loss_terms_backward(_DT[outs[0].dtype], po[0], po[1], po[2], po[3], n, ptr(tgt), b, c, d, h, w,
+                                            ctx.w[0], ctx.w[1], ptr(ws), ptr(gg), pd[0], pd[1], pd[2], pd[3],
+                                            stream_ptr()), "hdf_loss_terms_backward")
         return (None, *douts)
 
 
@@ -75,28 +83,63 @@ def compute_dice(logits, target_onehot, ignore_index=0):
         d = np.mean((2 * cnt[:, k, 0].astype(np.float32) + np.float32(1e-5)) /
                     (cnt[:, k, 1].astype(np.float32) + cnt[:, k, 2].astype(np.float32) + np.float32(1e-5)))
         vals[k] = round(float(d), 4)
-    return float(np.nanmean(vals[1:]))
+    return np.nanmean(vals[1:])          # numpy scalar like the reference's (its call site does dice.item())
 
 
 class RunningDice:
-    """Drop-in for metrics.RunningDice (metrics.py:82-151) with the confusion matrix accumulated on the GPU
-    (hdf_confusion_matrix): update_matrix takes the logits and the one-hot target directly -- no argmax maps are
-    copied to the host -- and compute_dice() does one 512-byte D2H."""
+    """Drop-in for metrics.RunningDice (metrics.py:82-151) with the confusion matrix accumulated on the GPU.
+
+    update_matrix(ground_truth, prediction) takes what the reference takes -- two class maps (numpy arrays or
+    tensors of any integer / float dtype, any shape; trainer.py:393-398 passes the argmax maps) -- and also the
+    pair (one-hot target, logits) straight from the step, in which case no argmax map is ever materialised.  As in
+    the reference, an update whose ground truth consists only of `ignore_label` is dropped (metrics.py:122-124).
+    compute_dice() does one 512-byte D2H."""
 
     def __init__(self, labels, ignore_label=0):
         self.labels = list(labels)
         self.ignore_label = ignore_label
         self.conf = None
 
-    def update_matrix(self, target_onehot, logits):
-        lg = logits.detach().contiguous()
-        tg = target_onehot.detach().float().contiguous()
-        b, c = lg.shape[:2]
-        first = self.conf is None
-        if first:
-            self.conf = torch.zeros((8, 8), dtype=torch.int64, device=lg.device)
-        check(lib().hdf_confusion_matrix(_DT[lg.dtype], ptr(lg), ptr(tg), b, c, lg[0, 0].numel(), ptr(self.conf),
-                                         0 if first else 1, stream_ptr()), "hdf_confusion_matrix")
+    @staticmethod
+    def _is_scores(a, b):
+        return (torch.is_tensor(a) and torch.is_tensor(b) and a.dim() >= 3 and a.shape == b.shape
+                and a.is_floating_point() and b.is_floating_point())
+
+    def update_matrix(self, ground_truth, prediction):
+        c = len(self.labels)
+        if self._is_scores(ground_truth, prediction):
+            lg = prediction.detach().contiguous()
+            tg = ground_truth.detach().float().contiguous()
+            if lg.dtype not in _DT:
+                raise _lib.HdfError(f"RunningDice: unsupported logits dtype {lg.dtype}")
+            dev = lg.device
+            cur = torch.zeros((8, 8), dtype=torch.int64, device=dev)
+            check(lib().hdf_confusion_matrix(_DT[lg.dtype], ptr(lg), ptr(tg), lg.shape[0], lg.shape[1],
+                                             lg[0, 0].numel(), ptr(cur), 0, stream_ptr()), "hdf_confusion_matrix")
+        else:
+            dev = self.conf.device if self.conf is not None else (
+                prediction.device if torch.is_tensor(prediction) and prediction.is_cuda else
+                ground_truth.device if torch.is_tensor(ground_truth) and ground_truth.is_cuda else
+                torch.device("cuda", torch.cuda.current_device()))
+            if dev.type != "cuda":
+                raise _lib.HdfError("RunningDice needs a GPU (there is no CPU path)")
+            gt = torch.as_tensor(ground_truth).to(dev).flatten()
+            pr = torch.as_tensor(prediction).to(dev).flatten()
+            if gt.numel() != pr.numel():
+                raise ValueError("ground_truth and prediction differ in size")
+            # labels outside [0, 255) (e.g. a negative ignore value) must not alias a class after the uint8 cast
+            gt = torch.where((gt >= 0) & (gt < 255), gt, torch.full_like(gt, 255)).to(torch.uint8).contiguous()
+            pr = torch.where((pr >= 0) & (pr < 255), pr, torch.full_like(pr, 255)).to(torch.uint8).contiguous()
+            cur = torch.zeros((8, 8), dtype=torch.int64, device=dev)
+            check(lib().hdf_confusion_matrix_labels(ptr(gt), ptr(pr), c, gt.numel(), ptr(cur), 0, stream_ptr()),
+                  "hdf_confusion_matrix_labels")
+        # `if (ground_truth == self.ignore_label).all(): return` without a host sync: the update is multiplied by 0
+        # when every counted ground-truth voxel sits in the ignore_label row
+        ig = self.ignore_label
+        if isinstance(ig, int) and 0 <= ig < 8:
+            rows = cur.sum(1)
+            cur = cur * (rows.sum() != rows[ig]).to(cur.dtype)
+        self.conf = cur if self.conf is None else self.conf + cur
 
     def compute_dice(self, smooth=1e-5):
         import numpy as np
@@ -105,7 +148,7 @@ class RunningDice:
         inter = np.diag(m)
         union = m.sum(axis=1) + m.sum(axis=0)
         iou = (2 * inter + smooth) / (union.astype(np.float32) + smooth)
-        return float(np.mean(iou[1:])), [round(float(v), 4) for v in iou]
+        return np.mean(iou[1:]), [round(v, 4) for v in iou]
 
     def init_op(self):
         self.conf = None

@@ -1,5 +1,9 @@
-"""`loss.cross_entropy` names of the reference (loss/cross_entropy.py:8-22); fused into CEPlusDice here."""
+"""Drop-in `loss.cross_entropy.CrossentropyLoss` (reference loss/cross_entropy.py:8-22): mean cross-entropy of the
+logits against argmax(one-hot target), on the fused HIP loss kernels (the Dice term weighted 0) -- no permuted copy
+of the logits.  weight=None only; there is no eager fallback."""
 from torch import nn
+
+from hdf_rt.loss_fn import DeepSuperCEDice
 
 
 class CrossentropyLoss(nn.Module):
@@ -8,5 +12,6 @@ class CrossentropyLoss(nn.Module):
         self.weight = weight
 
     def forward(self, inp, target):
-        raise NotImplementedError("stand-alone CrossentropyLoss is not part of the MI355X hot path; use "
-                                  "CEPlusDice / DeepSuperloss(CEPlusDice) from loss.combine_loss")
+        if self.weight is not None:
+            raise NotImplementedError("fused CrossentropyLoss supports weight=None")
+        return DeepSuperCEDice.apply((target, 1.0, 0.0), inp)

@@ -1,14 +1,20 @@
-"""`loss.dice_loss` names of the reference (loss/dice_loss.py:53-87).  On the MI355X build the Dice term
-only exists fused with the cross-entropy (see loss/combine_loss.py); a stand-alone DiceLoss is outside
-the hot path and raises."""
+"""Drop-in `loss.dice_loss.DiceLoss` (reference loss/dice_loss.py:53-87) on the fused HIP loss kernels: softmax over
+classes, per-class soft Dice (BinaryDiceLoss defaults: smooth 1e-5, p 1, batch mean, :5-50) over classes != 0,
+divided by C-1.  One pass over the logits (hdf_loss_terms_forward with the cross-entropy term weighted 0).
+Supported: weight=None, ignore_index=0 and the BinaryDiceLoss defaults -- what trainer.py:763-765 builds; anything
+else raises (there is no eager fallback)."""
 from torch import nn
+
+from hdf_rt.loss_fn import DeepSuperCEDice
 
 
 class DiceLoss(nn.Module):
     def __init__(self, weight=None, ignore_index=None, **kwargs):
         super().__init__()
-        self.class_weight, self.ignore_index, self.kwargs = weight, ignore_index, kwargs
+        self.weight, self.ignore_index, self.kwargs = weight, ignore_index, kwargs
 
     def forward(self, predict, target):
-        raise NotImplementedError("stand-alone DiceLoss is not part of the MI355X hot path; use "
-                                  "CEPlusDice / DeepSuperloss(CEPlusDice) from loss.combine_loss")
+        assert predict.shape == target.shape, "predict & target shape do not match"
+        if self.weight is not None or self.ignore_index != 0 or self.kwargs:
+            raise NotImplementedError("fused DiceLoss supports weight=None, ignore_index=0, default BinaryDiceLoss kwargs")
+        return DeepSuperCEDice.apply((target, 0.0, 1.0), predict)

@@ -69,6 +69,16 @@ int hdf_loss_forward(int dtype, const void* out0, const void* out1, const void* 
 int hdf_loss_backward(int dtype, const void* out0, const void* out1, const void* out2, const void* out3, int nscale,
                       const float* target_onehot, int batch, int n_cls, int D, int H, int W, const void* workspace,
                       const float* grad_out, void* dout0, void* dout1, void* dout2, void* dout3, hdf_stream stream);
+/* the same with the two terms weighted (ce_weight * CE + dice_weight * Dice per scale): 1,1 is CEPlusDice
+ * (loss/combine_loss.py:8-35); 0,1 is the stand-alone DiceLoss(ignore_index=0) of loss/dice_loss.py:53-87; 1,0 is
+ * CrossentropyLoss (loss/cross_entropy.py:8-22).  nscale = 1 gives the un-supervised (single output) forms. */
+int hdf_loss_terms_forward(int dtype, const void* out0, const void* out1, const void* out2, const void* out3, int nscale,
+                           const float* target_onehot, int batch, int n_cls, int D, int H, int W, float ce_weight,
+                           float dice_weight, void* workspace, float* loss_out, hdf_stream stream);
+int hdf_loss_terms_backward(int dtype, const void* out0, const void* out1, const void* out2, const void* out3,
+                            int nscale, const float* target_onehot, int batch, int n_cls, int D, int H, int W,
+                            float ce_weight, float dice_weight, const void* workspace, const float* grad_out,
+                            void* dout0, void* dout1, void* dout2, void* dout3, hdf_stream stream);
 /* hard-argmax Dice counts of trainer.py:919-945: counts[batch][8][3] = (|P&T|, |P|, |T|) per class, uint64 */
 int hdf_dice_counts(int dtype, const void* logits, const float* target_onehot, int batch, int n_cls, int64_t voxels,
                     uint64_t* counts, hdf_stream stream);
@@ -78,6 +88,21 @@ int hdf_dice_counts(int dtype, const void* logits, const float* target_onehot, i
  * over the batch; accumulate != 0 keeps the previous counts (running matrix over steps) */
 int hdf_confusion_matrix(int dtype, const void* logits, const float* target_onehot, int batch, int n_cls,
                          int64_t voxels, uint64_t* confusion, int accumulate, hdf_stream stream);
+
+/* the reference's own call signature, RunningDice.update_matrix(ground_truth, prediction) (metrics.py:104): two uint8
+ * class maps of n voxels each; labels >= n_cls are dropped like sklearn's confusion_matrix(labels=...) does */
+int hdf_confusion_matrix_labels(const uint8_t* target, const uint8_t* prediction, int n_cls, int64_t n,
+                                uint64_t* confusion, int accumulate, hdf_stream stream);
+
+/* ---- input normalisation on the device, in place on one fp32 sample [channels][voxels] -----------------------
+ * hdf_normalize_mr: MRNormalize (data_utils/data_loader.py:39-50): every channel divided by its maximum when that is
+ * non-zero, then negatives clamped to 0.  hdf_normalize_petct: PETandCTNormalize (:53-68): channel 0 ->
+ * (clip(x, mean-w, mean+w) - mean) / w, channel 1 -> (x - mean_1) / (std_1 + 1e-3) (population std), others untouched.
+ * workspace: hdf_normalize_workspace_bytes(channels) bytes. */
+int64_t hdf_normalize_workspace_bytes(int channels);
+int hdf_normalize_mr(float* image, int channels, int64_t voxels, void* workspace, hdf_stream stream);
+int hdf_normalize_petct(float* image, int channels, int64_t voxels, float mean, float w, void* workspace,
+                        hdf_stream stream);
 
 /* ---- sliding-window inference (trainer.py:488-593): the per-window tail of the loop and the final vote.
  * hdf_sw_accumulate: softmax over classes of one window's full-resolution logits [n_cls][pd][ph][pw] (NCDHW, the
@@ -144,6 +169,58 @@ int hdf_op_upsample_fwd(int dtype, const void* y, int64_t y_pitch, const float* 
                         int64_t out_pitch, int N, int C, int Di, int Hi, int Wi, hdf_stream stream);
 int hdf_op_upsample_bwd(int dtype, const void* dout, int64_t dout_pitch, void* din, int64_t din_pitch, int N, int C,
                         int Di, int Hi, int Wi, hdf_stream stream);
+
+
+/* ---- operator level, transformer branch and heads (what nn.Linear / LayerNorm / GELU / Softmax / matmul / Dropout and
+ *      the 1x1x1 nn.Conv3d bind in the reference, HDenseFormer.py:11-145,223-227).  All fp32.
+ * Token rows are ordered row = (m*B + b)*N + n (modality, sample, token); the parameters of modality m live at
+ * pointer + m*mstride floats (the flat state_dict layout of the plan; pass M = 1 for a single Linear stack).
+ * A block's dense feature buffer F is [rows][DM+128]: columns [0,DM) the block input, [DM+32l, DM+32l+32) the feature
+ * dense layer l appends (HDenseFormer.py:91-101).  training != 0 applies the p = 0.5 hash dropout of (seed). */
+
+/* Dense_Attention core (:67-74): qkv [nseq*N][96] = (q | k | v), 8 heads x 4 -> ob [nseq*N][32] (heads merged, before
+ * to_out) and lse [nseq*N][8] (row log-sum-exp of the 0.5-scaled scores, natural log) */
+int hdf_op_attention_fwd(const float* qkv, int nseq, int N, float* ob, float* lse, hdf_stream stream);
+int hdf_op_attention_bwd(const float* qkv, const float* ob, const float* lse, const float* d_ob, float* dqkv, int nseq,
+                         int N, hdf_stream stream);
+/* Dense_TransformerBlock front (:115-119,133-138): Conv3d(1 -> DM, k16, s16) + flatten + position embedding + dropout.
+ * x: [B][M][D][H][W]; writes F[:, 0:DM].  backward: dF -> dweight, dpos (+=), dbias (+=); scratch rows*DM floats */
+int hdf_op_patch_embed_fwd(const float* x, int M, int B, int D, int H, int W, int DM, const float* weight,
+                           const float* bias, const float* pos, int64_t mstride, float* F, int training, uint64_t seed,
+                           hdf_stream stream);
+int hdf_op_patch_embed_bwd(const float* x, int M, int B, int D, int H, int W, int DM, const float* dF, int64_t mstride,
+                           float* dweight, float* dbias, float* dpos, float* scratch, int training, uint64_t seed,
+                           hdf_stream stream);
+/* one dense layer of DensePreConv_AttentionBlock (:93-98): h0 = Linear(F[:, 0:DM+32l]); h1 = attn(LN(h0)) + h0;
+ * h2 = ff(LN(h1)) + h1; F[:, DM+32l : +32] = ff(LN(h2)).  params13 / grads13: HOST arrays of 13 device pointers in
+ * state_dict order (0.weight, 0.bias, 1.norm.weight, 1.norm.bias, 1.fn.to_qkv.weight, 1.fn.to_out.0.weight,
+ * 1.fn.to_out.0.bias, 2.norm.weight, 2.norm.bias, 2.fn.net.0.weight, .bias, 2.fn.net.3.weight, .bias).
+ * save: rows*232 floats kept for backward.  backward: dF[:, DM+32l..] is read, dF[:, 0:DM+32l] += ; parameter
+ * gradients are ACCUMULATED; scratch rows*160 floats. */
+int hdf_op_dense_layer_fwd(int M, int B, int N, int DM, int block, int layer, const float* const* params13,
+                           int64_t mstride, float* F, float* save, int training, uint64_t seed, hdf_stream stream);
+int hdf_op_dense_layer_bwd(int M, int B, int N, int DM, int block, int layer, const float* const* params13,
+                           float* const* grads13, int64_t mstride, const float* F, float* dF, const float* save,
+                           float* scratch, int training, uint64_t seed, hdf_stream stream);
+/* out_layer of a block (:89,99-100): DenseForward(DM+128 -> 64 -> DM) of the whole feature buffer.  Exactly one of
+ * next_F (fp32, next block's F[:, 0:DM]) / attnall (storage dtype, channels-last [B][N][M*DM], the 'b (d h w) c'
+ * rearrange + modality concat of :144,230) is written.  params4 / grads4: net.0.weight, net.0.bias, net.3.weight,
+ * net.3.bias.  backward writes dF[:, 0:DM+128] (overwrites) and accumulates the parameter gradients. */
+int hdf_op_block_out_fwd(int M, int B, int N, int DM, int block, const float* const* params4, int64_t mstride,
+                         const float* F, float* next_F, void* attnall, int dtype, int training, uint64_t seed,
+                         hdf_stream stream);
+int hdf_op_block_out_bwd(int M, int B, int N, int DM, int block, const float* const* params4, float* const* grads4,
+                         int64_t mstride, const float* F, const float* dF_next, const void* d_attnall, int dtype,
+                         float* dF, int training, uint64_t seed, hdf_stream stream);
+/* 1x1x1 head (:223-227): logits [N][n_cls][voxels] (NCDHW, storage dtype) = W . act(in) + b with in channels-last,
+ * act = relu(in*scale+shift) when in_scale is given.  backward: dx (+)= W^T dlogits (gradient w.r.t. act(in)),
+ * dweight / dbias accumulated. */
+int hdf_op_head_fwd(int dtype, const void* in, int64_t in_pitch, const float* in_scale, const float* in_shift,
+                    const float* weight, const float* bias, void* logits, int N, int C, int n_cls, int64_t voxels,
+                    hdf_stream stream);
+int hdf_op_head_bwd(int dtype, const void* dlogits, const void* in, int64_t in_pitch, const float* in_scale,
+                    const float* in_shift, const float* weight, void* dx, int64_t dx_pitch, int accumulate_dx,
+                    float* dweight, float* dbias, int N, int C, int n_cls, int64_t voxels, hdf_stream stream);
 
 #ifdef __cplusplus
 }

@@ -121,18 +121,30 @@ def _hook_intermediates(net):
     return got, hooks
 
 
-def _grad_summary(net):
+def _grad_summary(net, n_samples=8):
     names, norms, samples = [], [], []
     for k, p in net.named_parameters():
         g = p.grad.detach().flatten()
         names.append(k)
         norms.append(g.double().norm().item())
-        idx = np.linspace(0, g.numel() - 1, 8).astype(np.int64)
+        idx = np.linspace(0, g.numel() - 1, n_samples).astype(np.int64)
         samples.append(g[idx].numpy())
     return np.array(names), np.array(norms), np.stack(samples)
 
 
-def golden_model(ref, name, cfg, batch, train_seed=None, sample_step=1, inter_step=4, with_grads=True, full_grads=()):
+def _param_samples(net, n_samples):
+    out = []
+    for k, p in net.named_parameters():
+        v = p.detach().flatten()
+        out.append(v[np.linspace(0, v.numel() - 1, n_samples).astype(np.int64)].numpy().copy())
+    return np.stack(out)
+
+
+def golden_model(ref, name, cfg, batch, train_seed=None, sample_step=1, inter_step=4, with_grads=True, full_grads=(),
+                 n_samples=8, adam_step=False):
+    """adam_step: also run ONE optimizer step built by the reference's own SemanticSeg._get_optimizer
+    (trainer.py:793-840; Adam, lr 1e-3, weight_decay 1e-4, its two parameter groups) and record the
+    updated parameters at the sampled positions."""
     in_ch, n_cls, nf, size, td = cfg
     net = ref["HDenseFormer"](in_ch, n_cls, nf, image_size=size, transformer_depth=td)
     _load(net, cfg)
@@ -170,10 +182,17 @@ def golden_model(ref, name, cfg, batch, train_seed=None, sample_step=1, inter_st
     rec["dice_rounded"] = float(tr.compute_dice(outs[0].detach(), onehot))
     rec["dice_unrounded"] = orc.compute_dice(outs[0].detach(), onehot, rounded=False)
     if with_grads:
-        names, norms, samples = _grad_summary(net)
+        names, norms, samples = _grad_summary(net, n_samples)
         rec["grad_names"], rec["grad_norms"], rec["grad_samples"] = names, norms, samples
         for k in full_grads:
             rec["gradfull_" + k] = dict(net.named_parameters())[k].grad.detach().numpy()
+        if adam_step:
+            from types import SimpleNamespace
+            rec["param_samples_before"] = _param_samples(net, n_samples)
+            opt = tr.SemanticSeg._get_optimizer(SimpleNamespace(momentum=0.99, weight_decay=1e-4), "Adam", net, 1e-3)
+            opt.step()
+            rec["param_samples_after"] = _param_samples(net, n_samples)
+            rec["adam_lr"], rec["adam_wd"] = 1e-3, 1e-4
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
     print(f"{name}: loss={loss.item():.6f} dice={rec['dice_rounded']:.4f}")
 
@@ -237,7 +256,7 @@ def golden_2d(ref):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also the 4x128^3 nf32 td24 fixture (needs ~9 GB, ~1 min)")
-    ap.add_argument("--only", default="")
+    ap.add_argument("--only", default="", help="comma list of g1,g2,g3,g4,g5,g5t,g6,g7")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -258,6 +277,18 @@ def main():
         golden_2d(ref)
     if "g7" in todo:
         golden_metric(ref)
+    if "g4" in todo:
+        # the ws2 / wgrad2 / split-dgrad plan paths need >= 48^3 and n_filters 32: train mode, B=2, dropout on
+        golden_model(ref, "g4_mid_train", (4, 4, 32, (64, 64, 64), 8), 2, 4321, sample_step=4, inter_step=8,
+                     n_samples=16, adam_step=True,
+                     full_grads=("conv1x1.weight", "upconv_1.bias", "upconv_2.bias", "upconv_3.bias",
+                                 "block_1_1_right.norm.weight", "attns.2.blocks.1.0.layers.3.1.fn.to_qkv.weight"))
+    if "g5t" in todo:
+        # the exact computation bench.py times (BASELINE configs[1]): 4x128^3, nf32, td24, B=2, train mode
+        golden_model(ref, "g5_full_train", (4, 4, 32, (128, 128, 128), 24), 2, 2024, sample_step=8, inter_step=16,
+                     n_samples=16, adam_step=True,
+                     full_grads=("conv1x1.weight", "upconv_1.bias", "upconv_2.bias", "upconv_3.bias",
+                                 "block_1_1_right.norm.weight", "attns.3.blocks.5.0.layers.3.1.fn.to_qkv.weight"))
     if "g5" in todo:
         golden_model(ref, "g5_full_eval", (4, 4, 32, (128, 128, 128), 24), 1, None, sample_step=8, inter_step=8)
 

@@ -7,6 +7,8 @@ Usage:   python -m oracle.make_goldens_sw
                       `inference_slidingwindow` (trainer.py:527-580: net(patch)[0] -> softmax -> += into the window,
                       count += 1, output = argmax(softmax(sum / count))) run with the reference model
                       HDenseFormer(2,3,16,(32,)*3,td=8) on a 2x48x40x32 volume: argmax map + strided mean probabilities
+  g10_normalize       reference `MRNormalize` / `PETandCTNormalize` (data_utils/data_loader.py:39-68) on seeded volumes
+                      (one all-zero channel, negative values, values beyond the CT clip window)
   g9_to_tensor        reference `To_Tensor` (data_utils/data_loader.py:126-159) one-hot of a uint8 label map that also
                       holds values >= n_cls (they fall into the background channel)
 """
@@ -78,6 +80,22 @@ def main():
     s = To_Tensor(num_class=4, input_channel=4)({"image": img, "label": lab})
     np.savez_compressed(os.path.join(OUT, "g9_to_tensor.npz"), label=lab, onehot=s["label"].numpy(), n_cls=np.array(4))
     print("g9_to_tensor: label values", np.unique(lab), "background voxels", int(s["label"][0].sum()))
+
+    # ---- MRNormalize / PETandCTNormalize
+    from data_utils.data_loader import MRNormalize, PETandCTNormalize
+    shape = (4, 12, 20, 24)
+    n = int(np.prod(shape))
+    mr = ((detgen._uniform("g10.mr", n) * 900.0 + 700.0).astype(np.float32)).reshape(shape)    # mostly positive, some < 0
+    mr[2] = 0.0                                                                                # all-zero channel: untouched
+    mr_out = MRNormalize()({"image": mr.copy(), "label": None})["image"]
+    pc = np.stack([(detgen._uniform("g10.ct", n // 4) * 1800.0).astype(np.float32),           # beyond +-1024: clipped
+                   (detgen._uniform("g10.pet", n // 4) * 3.0 + 5.0).astype(np.float32)]).reshape((2,) + shape[1:])
+    pc_out = PETandCTNormalize()({"image": pc.copy(), "label": None})["image"]
+    pc2_out = PETandCTNormalize(mean=40, w=400)({"image": pc.copy(), "label": None})["image"]
+    np.savez_compressed(os.path.join(OUT, "g10_normalize.npz"), mr_in=mr, mr_out=mr_out, petct_in=pc, petct_out=pc_out,
+                        petct_m40_w400_out=pc2_out)
+    print("g10_normalize: mr range", mr_out.min(), mr_out.max(), "petct ch0 range", pc_out[0].min(), pc_out[0].max(),
+          "ch1 mean/std", pc_out[1].mean(), pc_out[1].std())
 
 
 if __name__ == "__main__":

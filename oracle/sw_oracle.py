@@ -52,3 +52,25 @@ def to_onehot(label, n_cls):
         out[z] = (label == z).astype(np.float32)
     out[0] = np.amax(out[1:], axis=0) == 0
     return out
+
+
+def mr_normalize(image):
+    """data_loader.py:39-50 (MRNormalize): per channel divide by the channel maximum when it is non-zero, then clamp
+    negatives to 0.  fp32 arithmetic like the reference's numpy."""
+    image = np.array(image, dtype=np.float32, copy=True)
+    for i in range(image.shape[0]):
+        m = np.max(image[i])
+        if m != 0:
+            image[i] = image[i] / m
+    image[image < 0] = 0
+    return image
+
+
+def pet_ct_normalize(image, mean=0, w=1024):
+    """data_loader.py:53-68 (PETandCTNormalize): channel 0 clipped to mean +- w and mapped to [-1, 1]; channel 1
+    z-scored with the population std + 1e-3."""
+    image = np.array(image, dtype=np.float32, copy=True)
+    image[0] = (np.clip(image[0], mean - w, mean + w) - mean) / w
+    mu, sd = np.mean(image[1]), np.std(image[1])
+    image[1] = (image[1] - mu) / (sd + 1e-3)
+    return image

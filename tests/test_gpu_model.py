@@ -198,7 +198,9 @@ def test_dice_metric_vs_reference_golden(tag):
     g = np.load(os.path.join(GOLDEN, "g7_metric.npz"))
     logits = torch.from_numpy(g[tag + "_logits"]).to(DEV)
     onehot = torch.from_numpy(g[tag + "_onehot"].astype(np.float32)).to(DEV)
-    assert abs(compute_dice(logits, onehot) - float(g[tag + "_dice"])) < 1e-6
+    d = compute_dice(logits, onehot)
+    assert abs(d - float(g[tag + "_dice"])) < 1e-6
+    assert abs(d.item() - float(g[tag + "_dice"])) < 1e-6      # trainer.py:391 calls dice.item()
 
 
 def test_flat_adam_matches_torch_adam():
@@ -292,6 +294,23 @@ def test_running_dice_confusion_matrix_vs_reference_golden(tag):
     rd.update_matrix(onehot, logits)                       # running accumulation: doubling every count keeps the ratios
     mean2, _ = rd.compute_dice()
     assert abs(mean2 - mean) < 1e-5
+    # the reference's own call signature (metrics.py:104; trainer.py:393-398 passes numpy argmax maps)
+    rd2 = RunningDice(labels=range(c), ignore_label=-1)
+    rd2.update_matrix(onehot.argmax(1).cpu().numpy(), logits.argmax(1).cpu().numpy())
+    mean3, per3 = rd2.compute_dice()
+    assert abs(mean3 - float(g[tag + "_run_dice"])) < 1e-6 and np.allclose(per3, g[tag + "_run_list"], atol=1e-4)
+    assert hasattr(mean3, "item")
+    # metrics.py:122-124: an update whose ground truth is all `ignore_label` is dropped (default ignore_label = 0)
+    rd3 = RunningDice(labels=range(c), ignore_label=0)
+    rd3.update_matrix(onehot, logits)
+    before = rd3.conf.clone()
+    bg = torch.zeros_like(onehot)
+    bg[:, 0] = 1.0
+    rd3.update_matrix(bg, logits)
+    rd3.update_matrix(np.zeros((2, 8, 8, 8), dtype=np.int64), logits.argmax(1).cpu().numpy())
+    assert torch.equal(rd3.conf, before)
+    rd3.update_matrix(onehot, logits)
+    assert torch.equal(rd3.conf, 2 * before)
 
 
 @pytest.mark.gpu
@@ -338,8 +357,26 @@ def test_sliding_window_inference_vs_reference_golden():
     assert err < 1e-3, err                      # mean class probabilities, tolerance of the fp32 logits gate
     agree = (lab.cpu().numpy() == g["argmax"]).mean()
     assert agree > 0.999, agree                 # votes differ only where two mean probabilities tie to ~1e-6
+    # windows batched through one forward give the same accumulators as one at a time
+    lab1, mean1 = sliding_window_predict(net, image, patch, step, return_probabilities=True, window_batch=1)
+    assert torch.equal(lab1, lab) and float((mean1.cpu() - torch.from_numpy(mean)).abs().max()) < 1e-6
+    # a volume shorter than the patch along one axis: clipped window (trainer.py:529-541), zero-padded for the plan
+    from oracle import sw_oracle
+    small = image[:, :20]
+    lab_s, mean_s = sliding_window_predict(net, small, patch, step, return_probabilities=True)
+    sd = orc.det_model(in_ch, n_cls, nf, patch, td)
+
+    def fwd(p):
+        pad = torch.zeros((1, in_ch) + patch)
+        pad[:, :, :p.shape[2], :p.shape[3], :p.shape[4]] = p
+        return orc.forward(pad, sd)[0][:, :, :p.shape[2], :p.shape[3], :p.shape[4]]
+    with torch.no_grad():
+        ref_lab, ref_mean = sw_oracle.sliding_window(fwd, small, n_cls, patch, step)
+    assert tuple(lab_s.shape) == (20,) + size[1:]
+    assert np.abs(mean_s.cpu().numpy() - ref_mean).max() < 1e-3
+    assert (lab_s.cpu().numpy() == ref_lab).mean() > 0.999
     with pytest.raises(ValueError):
-        sliding_window_predict(net, image[:, :16], patch, step)
+        sliding_window_predict(net, image, (16, 32, 32), step)       # patch must be the model's image_size
 
 
 @pytest.mark.gpu
@@ -383,3 +420,49 @@ def test_n_filters_48_forward_backward_vs_oracle():
     d = dict(errs)
     for name in ("conv1x1.weight", "conv1x1_d3.weight", "block_1_2_right.conv.weight"):
         assert d[name] < 5e-3, (name, d[name])
+
+
+@pytest.mark.gpu
+def test_device_normalisation_vs_reference_golden():
+    """SURVEY 8f-3, second half: MRNormalize / PETandCTNormalize (data_utils/data_loader.py:39-68) on the device."""
+    from hdf_rt.inference import mr_normalize_, pet_ct_normalize_
+    g = np.load(os.path.join(GOLDEN, "g10_normalize.npz"), allow_pickle=False)
+    mr = mr_normalize_(torch.from_numpy(g["mr_in"]).cuda()).cpu().numpy()
+    assert np.array_equal(mr, g["mr_out"])                                   # max and one IEEE division: bit-exact
+    pc = pet_ct_normalize_(torch.from_numpy(g["petct_in"]).cuda()).cpu().numpy()
+    assert np.array_equal(pc[0], g["petct_out"][0])
+    assert np.abs(pc[1] - g["petct_out"][1]).max() < 1e-5                    # mean / std: fp64 here, fp32 pairwise in numpy
+    pc2 = pet_ct_normalize_(torch.from_numpy(g["petct_in"]).cuda(), mean=40, w=400).cpu().numpy()
+    assert np.abs(pc2 - g["petct_m40_w400_out"]).max() < 1e-5
+    with pytest.raises(Exception):
+        mr_normalize_(torch.from_numpy(g["mr_in"]))                          # CPU tensor: no fallback
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["c3", "c4_absent"])
+def test_standalone_dice_and_ce_losses_vs_plain_torch(tag):
+    """loss.dice_loss.DiceLoss(ignore_index=0) and loss.cross_entropy.CrossentropyLoss (reference loss/dice_loss.py:
+    53-87, loss/cross_entropy.py:8-22) as stand-alone drop-ins; their sum is CEPlusDice (pinned by g3)."""
+    from loss.combine_loss import CEPlusDice
+    from loss.cross_entropy import CrossentropyLoss
+    from loss.dice_loss import DiceLoss
+    g = np.load(os.path.join(GOLDEN, "g3_loss.npz"))
+    logits = torch.from_numpy(g[f"{tag}_logits0"])
+    onehot = torch.from_numpy(g[tag + "_onehot"].astype(np.float32))
+    c = logits.shape[1]
+    lr = logits.clone().requires_grad_(True)
+    prob = torch.softmax(lr, 1)
+    dice = sum((1 - (2 * (prob[:, k] * onehot[:, k]).flatten(1).sum(1) + 1e-5) /
+                ((prob[:, k] + onehot[:, k]).flatten(1).sum(1) + 1e-5)).mean() for k in range(1, c)) / (c - 1)
+    ce = torch.nn.functional.cross_entropy(lr, onehot.argmax(1))
+    gd, = torch.autograd.grad(dice, lr, retain_graph=True)
+    gc, = torch.autograd.grad(ce, lr)
+    for mod, ref, gref in ((DiceLoss(weight=None, ignore_index=0), dice, gd), (CrossentropyLoss(), ce, gc)):
+        x = logits.to(DEV).requires_grad_(True)
+        out = mod(x, onehot.to(DEV))
+        out.backward()
+        assert abs(out.item() - ref.item()) < 2e-5
+        assert _rel(x.grad, gref) < 1e-4
+    x = logits.to(DEV).requires_grad_(True)
+    both = CEPlusDice(weight=None, ignore_index=0)(x, onehot.to(DEV))
+    assert abs(both.item() - (dice + ce).item()) < 4e-5

@@ -63,6 +63,22 @@ def _run_model_fixture(name, grads=True):
             assert abs(gr.double().norm().item() - ref_n) < tol, (k, gr.norm().item(), ref_n)
         for k in [f[len("gradfull_"):] for f in g.files if f.startswith("gradfull_")]:
             assert _rel(tr.sd[k].grad.numpy(), g["gradfull_" + k]) < 2e-4, k
+        ns = g["grad_samples"].shape[1]
+        for j, k in enumerate(names):
+            gr = tr.sd[k].grad.flatten()
+            idx = np.linspace(0, gr.numel() - 1, ns).astype(np.int64)
+            scale = float(g["grad_norms"][j]) / np.sqrt(gr.numel()) + 1e-9      # rms entry of this tensor
+            assert np.abs(gr[idx].numpy() - g["grad_samples"][j]).max() < 2e-2 * scale + 1e-7, k
+        if "param_samples_after" in g.files:
+            # ONE Adam step of the reference's own _get_optimizer (trainer.py:793-840) on these gradients
+            tr.opt.step()
+            for j, k in enumerate(names):
+                v = tr.sd[k].detach().flatten()
+                idx = np.linspace(0, v.numel() - 1, ns).astype(np.int64)
+                # a step is +-lr = 1e-3 per entry; entries whose gradient is at the rounding floor may flip direction
+                d = np.abs(v[idx].numpy() - g["param_samples_after"][j])
+                live = np.abs(g["grad_samples"][j]) > 1e-3 * (float(g["grad_norms"][j]) / np.sqrt(v.numel()) + 1e-12)
+                assert (d[live] < 2e-5).all(), (k, d.max())
 
 
 def test_g1_tiny_eval():
@@ -81,6 +97,18 @@ def test_g2_odd_token_grid():
 
 def test_g5_full_size_eval():
     _run_model_fixture("g5_full_eval", grads=False)
+
+
+def test_g4_mid_train_step():
+    """nf32 @ 64^3, B=2, train mode (hash dropout), gradients + one Adam step of the reference's optimizer."""
+    _run_model_fixture("g4_mid_train")
+
+
+def test_g5_full_size_train_step():
+    """The computation bench.py times (BASELINE configs[1]: 4x128^3, nf32, td24, B=2, train mode): loss, strided
+    logits, 1420 gradient norms, 16 gradient samples per tensor and the Adam-updated samples from the real reference.
+    ~17 GB and about a minute of CPU."""
+    _run_model_fixture("g5_full_train")
 
 
 @pytest.mark.parametrize("tag", ["c3", "c4", "c4_absent"])
@@ -158,3 +186,12 @@ def test_g9_to_tensor_onehot_vs_reference():
     from oracle import sw_oracle
     g = _load("g9_to_tensor")
     assert np.array_equal(sw_oracle.to_onehot(g["label"], int(g["n_cls"])), g["onehot"])
+
+
+def test_g10_normalize_vs_reference():
+    """SURVEY 8f-3, second half: MRNormalize / PETandCTNormalize restatement against the reference's own classes."""
+    from oracle import sw_oracle
+    g = _load("g10_normalize")
+    assert np.array_equal(sw_oracle.mr_normalize(g["mr_in"]), g["mr_out"])
+    assert np.array_equal(sw_oracle.pet_ct_normalize(g["petct_in"]), g["petct_out"])
+    assert np.array_equal(sw_oracle.pet_ct_normalize(g["petct_in"], 40, 400), g["petct_m40_w400_out"])
