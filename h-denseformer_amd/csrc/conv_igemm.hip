@@ -32,6 +32,12 @@ struct Mma<bf16_t> {
   }
 };
 template <>
+struct Mma<f16_t> {
+  static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+template <>
 struct Mma<float> {
   // lane (r, h) holds channels 4h..4h+3 of an 8-channel group: step s contracts channels {s, 4+s}
   static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
@@ -1184,6 +1190,10 @@ struct WG<bf16_t> {
   static constexpr int KV = 16;  // voxels contracted per MFMA step
 };
 template <>
+struct WG<f16_t> {
+  static constexpr int KV = 16;
+};
+template <>
 struct WG<float> {
   static constexpr int KV = 2;
 };
@@ -1360,8 +1370,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int j = 0; j < TAPS_PER_WAVE; j++) {
           u32x4 bf = {b0u[j][0], b0u[j][1], b1u[j][0], b1u[j][1]};
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf),
-                                                           acc[j], 0, 0, 0);
+          Mma<T>::run(af, bf, acc[j]);
         }
       }
       WS_BARRIER();
@@ -1418,9 +1427,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 // under the MFMAs (T0, buffer PAR) is read with a one-k-step look-ahead while, in the gaps of the same stream,
 // tile T1 goes registers -> (InstanceNorm/ReLU) -> the other buffer and tile T2's loads refill the registers.
 // One barrier per tile; slot offsets are per-thread constants; tile coordinates advance incrementally.
-template <bool XFL>
+template <typename T, bool XFL>
 __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
-  using T = bf16_t;
+  static_assert(sizeof(T) == 2, "16-bit storage only");
   constexpr int TD = 4, TH = 8, TW = 8, MT = TD * TH * TW, BD = TD + 2, BH = TH + 2, BW = TW + 2, BOXL = BD * BH * BW;
   // unpadded 64-byte rows: the 4 voxel rows x 16 dwords a ds_read_b64_tr_b16 half-wave touches then tile the 64
   // banks exactly (an 80-byte pitch wraps the 4th row onto the 1st: 2-way conflicts on every read)
@@ -1733,8 +1742,7 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
 #pragma unroll
         for (int j = 0; j < NT; j++) {
           const u32x4 bf = {B0[j][0], B0[j][1], B1[j][0], B1[j][1]};
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf),
-                                                           acc[j], 0, 0, 0);
+          Mma<T>::run(af, bf, acc[j]);
           if (ks + 1 < KS) read_b(ks + 1, j);
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -1978,12 +1986,15 @@ int launch_wgrad_t(WgradArgs a, float* dw, int sc_store, int lc_store, int accum
                 ws_bytes);
   a.partials = reinterpret_cast<float*>(ws);
   dim3 grid(G, a.SCp / 32, a.LCp / 32);
-  if (use_new) {  // HDF_WGRAD_OLD=1 (A/B knob): single-buffered conv_wgrad_kernel everywhere
-    if (a.lg_scale)
-      hipLaunchKernelGGL(conv_wgrad2_kernel<true>, grid, dim3(256), 0, st, a);
-    else
-      hipLaunchKernelGGL(conv_wgrad2_kernel<false>, grid, dim3(256), 0, st, a);
-  } else {
+  if constexpr (sizeof(T) == 2 && S == 1) {
+    if (use_new) {  // HDF_WGRAD_OLD=1 (A/B knob): single-buffered conv_wgrad_kernel everywhere
+      if (a.lg_scale)
+        hipLaunchKernelGGL((conv_wgrad2_kernel<T, true>), grid, dim3(256), 0, st, a);
+      else
+        hipLaunchKernelGGL((conv_wgrad2_kernel<T, false>), grid, dim3(256), 0, st, a);
+    }
+  }
+  if (!use_new) {
     hipLaunchKernelGGL((conv_wgrad_kernel<T, TD, TH, TW, S>), grid, dim3(256), 0, st, a);
   }
   HDF_LAUNCH_CHECK();
@@ -1998,7 +2009,7 @@ int launch_wgrad_t(WgradArgs a, float* dw, int sc_store, int lc_store, int accum
 
 int hdf_conv_weight_layout(int dtype, int mode, int Cin, int Do, int Ho, int Wo) {
   static const bool off = getenv("HDF_CONV_ROW_PANELS") != nullptr;  // A/B knob: row-major panels everywhere
-  const int rb = Cin * (dtype == HDF_BF16 ? 2 : 4);
+  const int rb = Cin * hdf_esz(dtype);
   if (off || rb % 64 != 0) return 0;                       // the pipelined path needs whole 64-byte chunks
   if (mode == 0) return ws_cfg(mode, Do, Ho, Wo, rb) ? 0 : 1;  // conv_ws2_kernel stages row-major panels
   if (mode == 1) return 1;                                 // stride-2 gather conv: pipelined path
@@ -2022,9 +2033,7 @@ int hdf_launch_conv(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
                 "conv: fragment-major weights given to a launch that reads row-major panels (mode %d Cin %d)", mode, a.Cin);
   HDF_CHECK_ARG(a.split == 0 || (mode == 0 && a.split % 32 == 0 && a.split < a.Cout && a.out2 != nullptr),
                 "conv: split output needs mode 0, split %% 32 == 0 and a second buffer (split=%d)", a.split);
-  if (dtype == HDF_BF16) return launch_conv_t<bf16_t>(mode, a, st);
-  if (dtype == HDF_F32) return launch_conv_t<float>(mode, a, st);
-  hdf_set_error("conv: unsupported dtype %d", dtype);
+  HDF_DISPATCH_T(dtype, return launch_conv_t<T>(mode, a, st));
   return HDF_ERR_UNSUPPORTED;
 }
 
@@ -2044,15 +2053,11 @@ int hdf_launch_wgrad(int dtype, int stride, WgradArgs a, float* dw, int sc_store
   HDF_CHECK_ARG(a.SC % 16 == 0 && a.LC % 16 == 0, "wgrad: channel counts must be multiples of 16 (SC=%d LC=%d)", a.SC,
                 a.LC);
   HDF_CHECK_ARG(stride == 1 || stride == 2, "wgrad: stride %d", stride);
-  if (dtype == HDF_BF16) {
-    if (stride == 1) return launch_wgrad_t<bf16_t, 4, 8, 8, 1>(a, dw, sc_store, lc_store, accumulate, workspace, workspace_bytes, st);
-    return launch_wgrad_t<bf16_t, 4, 4, 4, 2>(a, dw, sc_store, lc_store, accumulate, workspace, workspace_bytes, st);
-  }
-  if (dtype == HDF_F32) {
-    if (stride == 1) return launch_wgrad_t<float, 4, 8, 8, 1>(a, dw, sc_store, lc_store, accumulate, workspace, workspace_bytes, st);
-    return launch_wgrad_t<float, 4, 4, 4, 2>(a, dw, sc_store, lc_store, accumulate, workspace, workspace_bytes, st);
-  }
-  hdf_set_error("wgrad: unsupported dtype %d", dtype);
+  HDF_DISPATCH_T(dtype, {
+    if (stride == 1)
+      return launch_wgrad_t<T, 4, 8, 8, 1>(a, dw, sc_store, lc_store, accumulate, workspace, workspace_bytes, st);
+    return launch_wgrad_t<T, 4, 4, 4, 2>(a, dw, sc_store, lc_store, accumulate, workspace, workspace_bytes, st);
+  });
   return HDF_ERR_UNSUPPORTED;
 }
 
@@ -2062,10 +2067,7 @@ int hdf_launch_pack_batch(int dtype, const float* params, char* ws, const PackJo
   PackBatch b;
   for (int k = 0; k < njobs; k++) b.j[k] = jobs[k];
   dim3 grid(64, njobs);
-  if (dtype == HDF_BF16)
-    hipLaunchKernelGGL(pack_batch_kernel<bf16_t>, grid, dim3(256), 0, st, b, params, ws);
-  else
-    hipLaunchKernelGGL(pack_batch_kernel<float>, grid, dim3(256), 0, st, b, params, ws);
+  HDF_DISPATCH_T(dtype, hipLaunchKernelGGL(pack_batch_kernel<T>, grid, dim3(256), 0, st, b, params, ws));
   HDF_LAUNCH_CHECK();
   return HDF_OK;
 }
@@ -2074,10 +2076,8 @@ int hdf_launch_pack_w(int dtype, const float* src, void* dst, int O, int I, int 
                       int flip, hipStream_t st) {
   int64_t total = (int64_t)27 * OP * IP;
   dim3 grid((unsigned)ceil_div64(total, 256));
-  if (dtype == HDF_BF16)
-    hipLaunchKernelGGL(pack_w_kernel<bf16_t>, grid, dim3(256), 0, st, src, (bf16_t*)dst, O, I, OP, IP, so, si, flip);
-  else
-    hipLaunchKernelGGL(pack_w_kernel<float>, grid, dim3(256), 0, st, src, (float*)dst, O, I, OP, IP, so, si, flip);
+  HDF_DISPATCH_T(dtype, hipLaunchKernelGGL(pack_w_kernel<T>, grid, dim3(256), 0, st, src, (T*)dst, O, I, OP, IP, so, si,
+                                           flip));
   HDF_LAUNCH_CHECK();
   return HDF_OK;
 }

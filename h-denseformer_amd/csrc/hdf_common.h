@@ -10,7 +10,8 @@
 #define HDF_ERR_HIP 2
 #define HDF_ERR_UNSUPPORTED 3
 
-enum { HDF_F32 = 0, HDF_BF16 = 1 };
+enum { HDF_F32 = 0, HDF_BF16 = 1, HDF_F16 = 2 };
+static inline int hdf_esz(int dtype) { return dtype == HDF_F32 ? 4 : 2; }  // bytes per stored activation element
 
 void hdf_set_error(const char* fmt, ...);
 
@@ -42,6 +43,9 @@ void hdf_set_error(const char* fmt, ...);
 struct bf16_t {
   uint16_t v;
 };
+struct f16_t {  // IEEE binary16 storage (torch.float16 autocast, trainer.py:20-21,369): v_mfma_f32_32x32x16_f16
+  uint16_t v;
+};
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -61,6 +65,15 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 __device__ __forceinline__ uint32_t pack_bf2(float a, float b) {
   f32x2 v = {a, b};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+__device__ __forceinline__ float h2f(uint16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
+__device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }  // RNE
+__device__ __forceinline__ uint32_t pack_h2(float a, float b) {
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
 }
 
 template <typename T>
@@ -103,6 +116,46 @@ struct ST<bf16_t> {
     return c;
   }
 };
+
+template <>
+struct ST<f16_t> {
+  static constexpr int EPC = 8;
+  static constexpr int DT = HDF_F16;
+  __device__ static __forceinline__ float ld(const f16_t* p) { return h2f(p->v); }
+  __device__ static __forceinline__ void st(f16_t* p, float v) { p->v = f2h(v); }
+  __device__ static __forceinline__ void unpack(const u32x4& c, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const f16x2 h = __builtin_bit_cast(f16x2, c[i]);
+      f[2 * i] = (float)h.x;
+      f[2 * i + 1] = (float)h.y;
+    }
+  }
+  __device__ static __forceinline__ u32x4 pack(const float* f) {
+    u32x4 c;
+#pragma unroll
+    for (int i = 0; i < 4; i++) c[i] = pack_h2(f[2 * i], f[2 * i + 1]);
+    return c;
+  }
+};
+
+// one dispatch for every kernel family templated on the storage type
+#define HDF_DISPATCH_T(dtype, ...)                      \
+  do {                                                  \
+    if ((dtype) == HDF_BF16) {                          \
+      using T = bf16_t;                                 \
+      __VA_ARGS__;                                      \
+    } else if ((dtype) == HDF_F32) {                    \
+      using T = float;                                  \
+      __VA_ARGS__;                                      \
+    } else if ((dtype) == HDF_F16) {                    \
+      using T = f16_t;                                  \
+      __VA_ARGS__;                                      \
+    } else {                                            \
+      hdf_set_error("unsupported dtype %d", (dtype));   \
+      return HDF_ERR_UNSUPPORTED;                       \
+    }                                                   \
+  } while (0)
 
 // ---------------------------------------------------------------------------------------------
 // dropout hash (same integer recipe as oracle/detgen.py: mix32 / dropout_keep)

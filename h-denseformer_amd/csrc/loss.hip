@@ -371,12 +371,8 @@ int hdf_launch_loss_fwd(int dtype, const void* const* logits, const float* targe
     sc.V[i] = (float)((int64_t)Ds * Hs * Ws);
     sc.weight[i] = 1.f / (float)s;
     float* pi = partials + (size_t)i * N * LOSS_BLOCKS * NSTAT;
-    if (dtype == HDF_BF16)
-      hipLaunchKernelGGL(loss_fwd_kernel<bf16_t>, dim3(LOSS_BLOCKS, N), dim3(256), 0, st, (const bf16_t*)logits[i],
-                         target, C, Ds, Hs, Ws, s, D, H, W, pi);
-    else
-      hipLaunchKernelGGL(loss_fwd_kernel<float>, dim3(LOSS_BLOCKS, N), dim3(256), 0, st, (const float*)logits[i],
-                         target, C, Ds, Hs, Ws, s, D, H, W, pi);
+    HDF_DISPATCH_T(dtype, hipLaunchKernelGGL(loss_fwd_kernel<T>, dim3(LOSS_BLOCKS, N), dim3(256), 0, st,
+                                             (const T*)logits[i], target, C, Ds, Hs, Ws, s, D, H, W, pi));
     HDF_LAUNCH_CHECK();
   }
   float* terms = coefB + (size_t)nscale * N * MAXC;
@@ -398,14 +394,10 @@ int hdf_launch_loss_bwd(int dtype, const void* const* logits, const float* targe
     int Ds = D / s, Hs = H / s, Ws = W / s;
     int64_t V = (int64_t)Ds * Hs * Ws;
     unsigned gx = (unsigned)std::min<int64_t>(ceil_div64(V, 256), 2048);
-    if (dtype == HDF_BF16)
-      hipLaunchKernelGGL(loss_bwd_kernel<bf16_t>, dim3(gx, N), dim3(256), 0, st, (const bf16_t*)logits[i], target, N, C,
-                         Ds, Hs, Ws, s, D, H, W, coefA + (size_t)i * N * MAXC, coefB + (size_t)i * N * MAXC,
-                         1.f / (float)s, w_ce, w_dice, grad_out, (bf16_t*)dlogits[i]);
-    else
-      hipLaunchKernelGGL(loss_bwd_kernel<float>, dim3(gx, N), dim3(256), 0, st, (const float*)logits[i], target, N, C,
-                         Ds, Hs, Ws, s, D, H, W, coefA + (size_t)i * N * MAXC, coefB + (size_t)i * N * MAXC,
-                         1.f / (float)s, w_ce, w_dice, grad_out, (float*)dlogits[i]);
+    HDF_DISPATCH_T(dtype, hipLaunchKernelGGL(loss_bwd_kernel<T>, dim3(gx, N), dim3(256), 0, st, (const T*)logits[i],
+                                             target, N, C, Ds, Hs, Ws, s, D, H, W, coefA + (size_t)i * N * MAXC,
+                                             coefB + (size_t)i * N * MAXC, 1.f / (float)s, w_ce, w_dice, grad_out,
+                                             (T*)dlogits[i]));
     HDF_LAUNCH_CHECK();
   }
   return HDF_OK;
@@ -420,12 +412,8 @@ int hdf_launch_dice_counts(int dtype, const void* logits, const float* target, i
     return HDF_ERR_HIP;
   }
   unsigned gx = (unsigned)std::min<int64_t>(ceil_div64(V, 256), 1024);
-  if (dtype == HDF_BF16)
-    hipLaunchKernelGGL(dice_count_kernel<bf16_t>, dim3(gx, N), dim3(256), 0, st, (const bf16_t*)logits, target, C, V,
-                       counts);
-  else
-    hipLaunchKernelGGL(dice_count_kernel<float>, dim3(gx, N), dim3(256), 0, st, (const float*)logits, target, C, V,
-                       counts);
+  HDF_DISPATCH_T(dtype, hipLaunchKernelGGL(dice_count_kernel<T>, dim3(gx, N), dim3(256), 0, st, (const T*)logits, target,
+                                           C, V, counts));
   HDF_LAUNCH_CHECK();
   return HDF_OK;
 }
@@ -441,11 +429,8 @@ int hdf_launch_confusion(int dtype, const void* logits, const float* target, int
     }
   }
   unsigned gx = (unsigned)std::min<int64_t>(ceil_div64(V, 256), 1024);
-  if (dtype == HDF_BF16)
-    hipLaunchKernelGGL(confusion_kernel<bf16_t>, dim3(gx, N), dim3(256), 0, st, (const bf16_t*)logits, target, C, V,
-                       conf);
-  else
-    hipLaunchKernelGGL(confusion_kernel<float>, dim3(gx, N), dim3(256), 0, st, (const float*)logits, target, C, V, conf);
+  HDF_DISPATCH_T(dtype, hipLaunchKernelGGL(confusion_kernel<T>, dim3(gx, N), dim3(256), 0, st, (const T*)logits, target, C,
+                                           V, conf));
   HDF_LAUNCH_CHECK();
   return HDF_OK;
 }
@@ -555,16 +540,8 @@ int hdf_launch_sw_accumulate(int dtype, const void* logits, int C, int pd, int p
                 W);
   const int64_t pv = (int64_t)pd * ph * pw;
   dim3 grid((unsigned)std::min<int64_t>(ceil_div64(pv, 256), 4096));
-  if (dtype == HDF_BF16)
-    hipLaunchKernelGGL(sw_accumulate_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)logits, C, pd, ph, pw, psum,
-                       cnt, D, H, W, z0, y0, x0);
-  else if (dtype == HDF_F32)
-    hipLaunchKernelGGL(sw_accumulate_kernel<float>, grid, dim3(256), 0, st, (const float*)logits, C, pd, ph, pw, psum,
-                       cnt, D, H, W, z0, y0, x0);
-  else {
-    hdf_set_error("sw_accumulate: unsupported dtype %d", dtype);
-    return HDF_ERR_UNSUPPORTED;
-  }
+  HDF_DISPATCH_T(dtype, hipLaunchKernelGGL(sw_accumulate_kernel<T>, grid, dim3(256), 0, st, (const T*)logits, C, pd, ph, pw,
+                                           psum, cnt, D, H, W, z0, y0, x0));
   HDF_LAUNCH_CHECK();
   return HDF_OK;
 }

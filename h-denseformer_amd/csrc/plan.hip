@@ -739,7 +739,7 @@ int hdf_plan_create(int in_channels, int n_cls, int n_filters, int D, int H, int
   HDF_CHECK_ARG(D % 16 == 0 && H % 16 == 0 && W % 16 == 0 && D >= 32 && H >= 32 && W >= 32,
                 "plan_create: image_size (%d,%d,%d) must be multiples of 16 and >= 32", D, H, W);
   HDF_CHECK_ARG(transformer_depth >= 4, "plan_create: transformer_depth=%d < 4", transformer_depth);
-  HDF_CHECK_ARG(dtype == HDF_F32 || dtype == HDF_BF16, "plan_create: dtype %d", dtype);
+  HDF_CHECK_ARG(dtype == HDF_F32 || dtype == HDF_BF16 || dtype == HDF_F16, "plan_create: dtype %d", dtype);
   hdf_plan* p = new hdf_plan();
   p->M = in_channels;
   p->ncls = n_cls;
@@ -748,7 +748,7 @@ int hdf_plan_create(int in_channels, int n_cls, int n_filters, int D, int H, int
   p->td = transformer_depth;
   p->nb = transformer_depth / 4;
   p->dtype = dtype;
-  p->esz = dtype == HDF_BF16 ? 2 : 4;
+  p->esz = hdf_esz(dtype);
   for (int l = 0; l < 5; l++) p->dims[l][0] = D >> l, p->dims[l][1] = H >> l, p->dims[l][2] = W >> l;
   p->DM = 4 * n_filters;
   p->DMF = p->DM + 128;
@@ -1095,7 +1095,7 @@ int hdf_op_conv3d(int dtype, int mode, const void* in, int64_t in_pitch, int Cin
   return hdf_launch_conv(dtype, mode, a, (hipStream_t)stream);
 }
 int hdf_op_conv3d_stat_tiles(int dtype, int Cin, int Do, int Ho, int Wo) {
-  return hdf_conv_stat_tiles(0, Do, Ho, Wo, Cin * (dtype == HDF_BF16 ? 2 : 4));
+  return hdf_conv_stat_tiles(0, Do, Ho, Wo, Cin * hdf_esz(dtype));
 }
 int64_t hdf_op_wgrad_workspace_bytes(int stride, int N, int Ds, int Hs, int Ws, int SC, int LC) {
   return (int64_t)hdf_wgrad_workspace_bytes(stride, N, Ds, Hs, Ws, SC, LC);

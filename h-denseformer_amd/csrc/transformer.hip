@@ -1144,14 +1144,10 @@ int tf_block_out_fwd(const TfDims& d, int block, const TfOutP& p, const float* F
   const int stage_wb = with_wb <= LDS_LIMIT ? 1 : 0;
   size_t shm = stage_wb ? with_wb : base;
   HDF_CHECK_ARG(shm <= LDS_LIMIT, "block_out: token dim %d needs %zu B of LDS", d.DM, shm);
-  HDF_TRY(allow_lds(block_out_fwd_kernel<bf16_t>, shm));
-  HDF_TRY(allow_lds(block_out_fwd_kernel<float>, shm));
-  if (dtype == HDF_BF16)
-    hipLaunchKernelGGL(block_out_fwd_kernel<bf16_t>, grid, dim3(256), shm, st, d, block, p, F, next_F,
-                       (bf16_t*)attnall, stage_wb);
-  else
-    hipLaunchKernelGGL(block_out_fwd_kernel<float>, grid, dim3(256), shm, st, d, block, p, F, next_F, (float*)attnall,
-                       stage_wb);
+  HDF_DISPATCH_T(dtype, {
+    HDF_TRY(allow_lds(block_out_fwd_kernel<T>, shm));
+    hipLaunchKernelGGL(block_out_fwd_kernel<T>, grid, dim3(256), shm, st, d, block, p, F, next_F, (T*)attnall, stage_wb);
+  });
   HDF_LAUNCH_CHECK();
   return HDF_OK;
 }
@@ -1164,14 +1160,11 @@ int tf_block_out_bwd(const TfDims& d, int block, const TfOutP& p, const TfOutP& 
   const int stage_wb = with_wb <= LDS_LIMIT ? 1 : 0;
   size_t shm = stage_wb ? with_wb : base;
   HDF_CHECK_ARG(shm <= LDS_LIMIT, "block_out_bwd: token dim %d needs %zu B of LDS", d.DM, shm);
-  HDF_TRY(allow_lds(block_out_bwd_kernel<bf16_t>, shm));
-  HDF_TRY(allow_lds(block_out_bwd_kernel<float>, shm));
-  if (dtype == HDF_BF16)
-    hipLaunchKernelGGL(block_out_bwd_kernel<bf16_t>, grid, dim3(256), shm, st, d, block, p, g, F, dF_next,
-                       (const bf16_t*)d_attnall, dF, stage_wb);
-  else
-    hipLaunchKernelGGL(block_out_bwd_kernel<float>, grid, dim3(256), shm, st, d, block, p, g, F, dF_next,
-                       (const float*)d_attnall, dF, stage_wb);
+  HDF_DISPATCH_T(dtype, {
+    HDF_TRY(allow_lds(block_out_bwd_kernel<T>, shm));
+    hipLaunchKernelGGL(block_out_bwd_kernel<T>, grid, dim3(256), shm, st, d, block, p, g, F, dF_next,
+                       (const T*)d_attnall, dF, stage_wb);
+  });
   HDF_LAUNCH_CHECK();
   return HDF_OK;
 }

@@ -958,19 +958,7 @@ static int allow_big_lds(const void* kern, size_t bytes) {
   return HDF_OK;
 }
 
-#define DISPATCH_T(dtype, ...)                          \
-  do {                                                  \
-    if ((dtype) == HDF_BF16) {                          \
-      using T = bf16_t;                                 \
-      __VA_ARGS__;                                      \
-    } else if ((dtype) == HDF_F32) {                    \
-      using T = float;                                  \
-      __VA_ARGS__;                                      \
-    } else {                                            \
-      hdf_set_error("unsupported dtype %d", (dtype));   \
-      return HDF_ERR_UNSUPPORTED;                       \
-    }                                                   \
-  } while (0)
+#define DISPATCH_T HDF_DISPATCH_T
 
 int hdf_launch_nchw_to_ndhwc(int dtype, const float* x, void* out, int N, int C, int CP, int64_t vox, hipStream_t st) {
   HDF_CHECK_ARG(CP % 16 == 0 && CP >= C, "nchw_to_ndhwc: CP=%d", CP);

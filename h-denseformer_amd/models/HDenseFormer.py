@@ -203,6 +203,10 @@ class HDenseFormer(nn.Module):
             self._flatten()
         return self._flat
 
+    def step_seed(self, step, rank=0):
+        """32-bit dropout seed of training forward number `step` on data-parallel rank `rank`."""
+        return (self.dropout_seed * 1000003 + step + rank * 0x9E3779B1) & 0xFFFFFFFF
+
     def set_dropout_seed(self, seed):
         """The next train-mode forward draws its dropout masks from exactly this 32-bit seed (reproducible runs and
         the parity tests against fixtures generated with a given seed); later forwards continue from the counter."""
@@ -264,7 +268,7 @@ class HDenseFormer(nn.Module):
             rank = 0
             if torch.distributed.is_available() and torch.distributed.is_initialized():
                 rank = torch.distributed.get_rank()
-            seed = (self.dropout_seed * 1000003 + self._step + rank * 0x9E3779B1) & 0xFFFFFFFF
+            seed = self.step_seed(self._step, rank)
         anchor = torch.zeros(1, device=x.device, requires_grad=need_grad)
         outs = HDFFunction.apply(xin, anchor, self, rt, self.training, seed)
         self._last_rt = rt

@@ -141,21 +141,23 @@ def _check_adam_vs_fixture(g, net):
     opt.step()
     torch.cuda.synchronize()
     ns = g["grad_samples"].shape[1]
+    decay = {k for k, p in net.named_parameters() if not (p.dim() == 1 or k.endswith(".bias"))}
+    wd = float(g["adam_wd"])
     bad = 0
     live_n = 0
     for j, (k, p) in enumerate(net.named_parameters()):
         v = p.detach().flatten().cpu()
         idx = np.linspace(0, v.numel() - 1, ns).astype(np.int64)
         d = np.abs(v[idx].numpy() - g["param_samples_after"][j])
-        # Adam's first step moves every entry by lr * sign(g) (+ weight decay): entries whose gradient sits at the
-        # rounding floor may take the other sign; all others must land on the reference's value
-        live = np.abs(g["grad_samples"][j]) > 1e-2 * (float(g["grad_norms"][j]) / np.sqrt(v.numel()) + 1e-12)
-        bad += int((d[live] > 5e-5).sum())
+        # Adam's first step moves an entry by lr * ge / (|ge| + eps) with ge = g + wd * p on the decayed group: +-lr
+        # when |ge| >> eps = 1e-8.  Only its SIGN matters then, so an entry is comparable when the reference's |ge|
+        # clears what two correct fp32 gradients may differ by (a fifth of the tensor's rms entry)
+        ge = g["grad_samples"][j] + (wd * g["param_samples_before"][j] if k in decay else 0.0)
+        live = np.abs(ge) > 0.2 * (float(g["grad_norms"][j]) / np.sqrt(v.numel())) + 2e-6
+        bad += int((d[live] > 2e-5).sum())
         live_n += int(live.sum())
-        moved = np.abs(g["param_samples_after"][j] - g["param_samples_before"][j])
-        assert np.abs(np.abs(v[idx].numpy() - g["param_samples_before"][j]) - moved)[live].max(initial=0.0) < 5e-5, k
     print(f"  adam: {bad} of {live_n} sampled live entries off the reference's updated value")
-    assert bad <= max(2, live_n // 500)
+    assert live_n > 5000 and bad <= max(2, live_n // 500)
 
 
 def _grads_vs_oracle(net, sd, x, onehot, seed, tol, tight=()):

@@ -77,7 +77,8 @@ def _run_model_fixture(name, grads=True):
                 idx = np.linspace(0, v.numel() - 1, ns).astype(np.int64)
                 # a step is +-lr = 1e-3 per entry; entries whose gradient is at the rounding floor may flip direction
                 d = np.abs(v[idx].numpy() - g["param_samples_after"][j])
-                live = np.abs(g["grad_samples"][j]) > 1e-3 * (float(g["grad_norms"][j]) / np.sqrt(v.numel()) + 1e-12)
+                ga = np.abs(g["grad_samples"][j])
+                live = (ga > 1e-3 * (float(g["grad_norms"][j]) / np.sqrt(v.numel()) + 1e-12)) & (ga > 2e-6)
                 assert (d[live] < 2e-5).all(), (k, d.max())
 
 

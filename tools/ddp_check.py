@@ -54,6 +54,7 @@ def main():
     for r in range(world):
         xr, tr = data(r)
         net._step = 4
+        net.set_dropout_seed(net.step_seed(5, r))   # rank r's masks (the seed folds the rank in)
         opt.zero_grad()
         crit(net(xr), tr).backward()
         torch.cuda.synchronize()
