@@ -126,9 +126,10 @@ struct ST<f16_t> {
   __device__ static __forceinline__ void unpack(const u32x4& c, float* f) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const f16x2 h = __builtin_bit_cast(f16x2, c[i]);
-      f[2 * i] = (float)h.x;
-      f[2 * i + 1] = (float)h.y;
+      // (bit_cast straight from the vector element c[i] makes hipcc read element 0 four times: go through a scalar)
+      const uint32_t w = c[i];
+      f[2 * i] = h2f((uint16_t)(w & 0xffffu));
+      f[2 * i + 1] = h2f((uint16_t)(w >> 16));
     }
   }
   __device__ static __forceinline__ u32x4 pack(const float* f) {

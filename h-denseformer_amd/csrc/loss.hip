@@ -366,8 +366,9 @@ int hdf_launch_loss_fwd(int dtype, const void* const* logits, const float* targe
   LossScales sc;
   for (int i = 0; i < nscale; i++) {
     int s = 1 << i;
-    HDF_CHECK_ARG(D % s == 0 && H % s == 0 && W % s == 0, "loss: size not divisible by %d", s);
-    int Ds = D / s, Hs = H / s, Ws = W / s;
+    // D == 1: 2-D logits [N][C][H][W] (models/HDenseFormer_2D.py); the nearest down-sampling then strides H and W only
+    HDF_CHECK_ARG((D == 1 || D % s == 0) && H % s == 0 && W % s == 0, "loss: size not divisible by %d", s);
+    int Ds = D == 1 ? 1 : D / s, Hs = H / s, Ws = W / s;
     sc.V[i] = (float)((int64_t)Ds * Hs * Ws);
     sc.weight[i] = 1.f / (float)s;
     float* pi = partials + (size_t)i * N * LOSS_BLOCKS * NSTAT;
@@ -391,7 +392,7 @@ int hdf_launch_loss_bwd(int dtype, const void* const* logits, const float* targe
   const float* coefB = coefA + (size_t)nscale * N * MAXC;
   for (int i = 0; i < nscale; i++) {
     int s = 1 << i;
-    int Ds = D / s, Hs = H / s, Ws = W / s;
+    int Ds = D == 1 ? 1 : D / s, Hs = H / s, Ws = W / s;
     int64_t V = (int64_t)Ds * Hs * Ws;
     unsigned gx = (unsigned)std::min<int64_t>(ceil_div64(V, 256), 2048);
     HDF_DISPATCH_T(dtype, hipLaunchKernelGGL(loss_bwd_kernel<T>, dim3(gx, N), dim3(256), 0, st, (const T*)logits[i],

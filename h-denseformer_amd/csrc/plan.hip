@@ -74,6 +74,84 @@ struct Bump {
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------- 2-D embedding
+// HDenseFormer_2D (reference models/HDenseFormer_2D.py:172-250) is the 3-D graph with 2-D primitives.  It equals,
+// EXACTLY, the 3-D network applied to the image replicated along a depth axis of 16 when its parameters are embedded as
+//   Conv2d [o,i,3,3]            -> Conv3d [o,i,3,3,3]   with the 2-D kernel on depth tap 1, zeros on taps 0 and 2
+//   ConvTranspose2d [i,o,3,3]   -> ConvTranspose3d      with the 2-D kernel on depth taps 1 AND 2 (output slice 2z
+//                                  takes tap 1 of input slice z, slice 2z+1 takes tap 2 of the same slice), zero on tap 0
+//   patch Conv2d [c,1,16,16]    -> Conv3d [c,1,16,16,16] with the 2-D kernel on depth slice 0, zeros elsewhere
+//   everything else             -> unchanged
+// Every activation then consists of identical depth slices (InstanceNorm statistics, MaxPool3d, trilinear x2 and the
+// token grid all reduce to their 2-D forms), the 2-D logits are depth slice 0 of the 3-D logits, and by the chain
+// rule the 2-D parameter gradient is the sum of the 3-D gradient over the embedded positions.  The cost is the 16
+// (at level 0) .. 2 (level 3) redundant slices; a native depth-1 mode of the pooling / up-sampling / transposed-conv
+// kernels would remove it.
+struct Embed2dJob {
+  int64_t off3, off2;  // float offsets in the 3-D / 2-D flat parameter (or gradient) buffers
+  int64_t n3;          // 3-D elements of the job
+  int inner;           // elements of one 2-D kernel (9, 256) or 1
+  short rep;           // depth taps / slices of the 3-D kernel (3, 16) or 1
+  char kind;           // 0 copy, 1 conv (tap 1), 2 transposed conv (taps 1 and 2), 3 patch (slice 0)
+  char stage;          // backward stage bit (1 U-Net, 2 UpConv chain, 4 transformer) whose gradients it carries
+};
+constexpr int HDF_MAX_EMBED_JOBS = 96;
+struct Embed2dBatch {
+  Embed2dJob j[HDF_MAX_EMBED_JOBS];
+};
+__device__ __forceinline__ bool embed_live(int kind, int z) {
+  return kind == 0 || (kind == 1 && z == 1) || (kind == 2 && (z == 1 || z == 2)) || (kind == 3 && z == 0);
+}
+// 3-D parameters from the 2-D ones (grid (blocks, jobs))
+__global__ void embed2d_kernel(Embed2dBatch b, const float* __restrict__ p2, float* __restrict__ p3) {
+  const Embed2dJob& jb = b.j[blockIdx.y];
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < jb.n3; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t outer = e / ((int64_t)jb.rep * jb.inner);
+    const int z = (int)((e / jb.inner) % jb.rep), r = (int)(e % jb.inner);
+    p3[jb.off3 + e] = embed_live(jb.kind, z) ? p2[jb.off2 + outer * jb.inner + r] : 0.f;
+  }
+}
+// 2-D gradients from the 3-D ones: the transpose of the embedding (sum over the embedded positions)
+__global__ void extract2d_kernel(Embed2dBatch b, const float* __restrict__ g3, float* __restrict__ g2) {
+  const Embed2dJob& jb = b.j[blockIdx.y];
+  const int64_t n2 = jb.n3 / jb.rep;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n2; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t outer = e / jb.inner;
+    const int r = (int)(e % jb.inner);
+    float s = 0.f;
+    for (int z = 0; z < jb.rep; z++)
+      if (embed_live(jb.kind, z)) s += g3[jb.off3 + (outer * jb.rep + z) * jb.inner + r];
+    g2[jb.off2 + e] = s;
+  }
+}
+// x [rows][HW] -> [rows][reps][HW]
+__global__ void replicate_depth_kernel(const float* __restrict__ x2, float* __restrict__ x3, int64_t rows, int reps,
+                                       int64_t hw) {
+  const int64_t total = rows * reps * hw;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x)
+    x3[e] = x2[(e / (reps * hw)) * hw + e % hw];
+}
+// depth slice 0 of [rows][reps][HW] -> [rows][HW]  (to2d) or its transpose: slice 0 <- src, other slices <- 0
+template <typename T>
+__global__ void depth_slice_kernel(T* __restrict__ t3, T* __restrict__ t2, int64_t rows, int reps, int64_t hw,
+                                   int to2d) {
+  if (to2d) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < rows * hw; e += (int64_t)gridDim.x * blockDim.x)
+      t2[e] = t3[(e / hw) * reps * hw + e % hw];
+  } else {
+    T zero;
+    zero.v = 0;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < rows * reps * hw;
+         e += (int64_t)gridDim.x * blockDim.x) {
+      const int64_t row = e / (reps * hw), rem = e % (reps * hw);
+      t3[e] = rem < hw ? t2[row * hw + rem] : zero;
+    }
+  }
+}
+struct f32w {  // float wrapper with the .v member the 16-bit storage structs have
+  float v;
+};
+
 struct hdf_plan {
   int M, ncls, nf, D, H, W, td, nb, dtype;
   int esz;
@@ -103,6 +181,12 @@ struct hdf_plan {
   bool dcat_split[3] = {false, false, false};
   bool no_head_fuse = getenv("HDF_NO_HEAD_FUSE") != nullptr;  // A/B knob: separate in_bwd_reduce after the heads
   bool no_bias_fuse = getenv("HDF_NO_BIAS_FUSE") != nullptr;  // A/B knob: separate pass for the ConvTranspose3d bias gradients
+  // ---- 2-D model (models/HDenseFormer_2D.py) run as its exact depth-replicated 3-D embedding (see embed2d below)
+  bool is2d = false;
+  std::vector<ParamInfo> params2d;  // the 2-D reference state_dict: conv kernels [..,3,3], patch kernels [..,16,16]
+  int64_t total_floats2d = 0;
+  std::vector<Embed2dJob> ejobs;
+  size_t e_x3d = 0, e_params3d = 0, e_grads3d = 0, e_out3d[4] = {0, 0, 0, 0}, e_dout3d[4] = {0, 0, 0, 0};
   // state carried from forward to backward
   int training = 0;
   uint32_t seed = 0;
@@ -259,6 +343,77 @@ void build_layers(hdf_plan* p) {
   }
 }
 
+// the 2-D state_dict (conv kernels lose their depth axis) and the embedding jobs; consecutive unchanged tensors are
+// merged into one copy job (both flat layouts pad every tensor to 16 floats, so such runs have equal lengths)
+int build_params2d(hdf_plan* p) {
+  p->params2d.clear();
+  p->ejobs.clear();
+  p->total_floats2d = 0;
+  int64_t unet0 = p->P("block_1_1_left.conv.weight"), chain0 = p->P("deep_conv.double_conv.0.weight");
+  for (const ParamInfo& pi : p->params) {
+    ParamInfo q = pi;
+    int kind = 0, rep = 1, inner = 1;
+    if (pi.shape.size() == 5) {
+      rep = (int)pi.shape[2];
+      inner = (int)(pi.shape[3] * pi.shape[4]);
+      q.shape.erase(q.shape.begin() + 2);
+      q.numel = pi.numel / rep;
+      if (rep == 3)
+        kind = pi.name.rfind("upconv_", 0) == 0 ? 2 : 1;
+      else if (rep == 16)
+        kind = 3;
+      else
+        rep = 1, inner = 1;  // 1x1x1 heads: plain copy
+    }
+    q.offset = p->total_floats2d;
+    p->total_floats2d += (q.numel + 15) / 16 * 16;
+    const char stage = pi.offset >= unet0 ? 1 : pi.offset >= chain0 ? 2 : 4;
+    const int64_t n3 = kind ? pi.numel : (pi.numel + 15) / 16 * 16;
+    if (kind == 0 && !p->ejobs.empty()) {
+      Embed2dJob& last = p->ejobs.back();
+      if (last.kind == 0 && last.stage == stage && last.off3 + last.n3 == pi.offset && last.off2 + last.n3 == q.offset) {
+        last.n3 += n3;
+        p->params2d.push_back(q);
+        continue;
+      }
+    }
+    p->ejobs.push_back(Embed2dJob{pi.offset, q.offset, n3, inner, (short)rep, (char)kind, stage});
+    p->params2d.push_back(q);
+  }
+  HDF_CHECK_ARG((int)p->ejobs.size() <= HDF_MAX_EMBED_JOBS, "2-D plan: %d embedding jobs (max %d)", (int)p->ejobs.size(),
+                HDF_MAX_EMBED_JOBS);
+  return HDF_OK;
+}
+
+int launch_embed2d(hdf_plan* p, const float* p2, float* p3, hipStream_t st) {
+  Embed2dBatch b;
+  for (size_t k = 0; k < p->ejobs.size(); k++) b.j[k] = p->ejobs[k];
+  hipLaunchKernelGGL(embed2d_kernel, dim3(64, (unsigned)p->ejobs.size()), dim3(256), 0, st, b, p2, p3);
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+int launch_extract2d(hdf_plan* p, int stages, const float* g3, float* g2, hipStream_t st) {
+  Embed2dBatch b;
+  unsigned n = 0;
+  for (const Embed2dJob& j : p->ejobs)
+    if (j.stage & stages) b.j[n++] = j;
+  if (n == 0) return HDF_OK;
+  hipLaunchKernelGGL(extract2d_kernel, dim3(64, n), dim3(256), 0, st, b, g3, g2);
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+// depth slice 0 of a [rows][reps][hw] tensor of the plan's storage type <-> [rows][hw]
+int launch_depth_slice(int dtype, void* t3, void* t2, int64_t rows, int reps, int64_t hw, int to2d, hipStream_t st) {
+  const unsigned gx = (unsigned)std::min<int64_t>(ceil_div64(rows * (to2d ? 1 : reps) * hw, 256), 4096);
+  if (dtype == HDF_F32)
+    hipLaunchKernelGGL(depth_slice_kernel<f32w>, dim3(gx), dim3(256), 0, st, (f32w*)t3, (f32w*)t2, rows, reps, hw, to2d);
+  else  // bf16 / f16: same 2-byte moves
+    hipLaunchKernelGGL(depth_slice_kernel<bf16_t>, dim3(gx), dim3(256), 0, st, (bf16_t*)t3, (bf16_t*)t2, rows, reps, hw,
+                       to2d);
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
 View mkview(hdf_plan* p, Bump& bp, const std::string& name, int lvl, int C, int batch) {
   View v;
   v.C = C;
@@ -321,6 +476,15 @@ void layout(hdf_plan* p, int B) {
     }
   }
   p->x4 = mkview(p, bp, "bottleneck", 3, 8 * nf, B);
+  if (p->is2d) {  // depth-replicated input, embedded parameters / their gradients, 3-D logits and logit gradients
+    p->e_x3d = bp.take((size_t)B * p->M * p->vox(0) * sizeof(float));
+    p->e_params3d = bp.take((size_t)p->total_floats * sizeof(float));
+    p->e_grads3d = bp.take((size_t)p->total_floats * sizeof(float));
+    for (int i = 0; i < 4; i++) {
+      p->e_out3d[i] = bp.take((size_t)B * p->ncls * p->vox(i) * p->esz);
+      p->e_dout3d[i] = bp.take((size_t)B * p->ncls * p->vox(i) * p->esz);
+    }
+  }
   // ---- weight packs (see conv_forward / conv_backward / convt_* for the layouts)
   p->pack_jobs.clear();
   auto conv_jobs = [&](Conv3& c) {
@@ -729,14 +893,14 @@ extern "C" {
 const char* hdf_version(void) { return "hdf-hip 0.1 (gfx950)"; }
 const char* hdf_last_error(void) { return g_err; }
 
-int hdf_plan_create(int in_channels, int n_cls, int n_filters, int D, int H, int W, int transformer_depth, int dtype,
-                    hdf_plan** out) {
+static int create_plan(int in_channels, int n_cls, int n_filters, int D, int H, int W, int transformer_depth, int dtype,
+                       bool is2d, hdf_plan** out) {
   HDF_CHECK_ARG(out != nullptr, "plan_create: null out");
   HDF_CHECK_ARG(in_channels >= 1 && in_channels <= 8, "plan_create: in_channels=%d unsupported (1..8)", in_channels);
   HDF_CHECK_ARG(n_cls >= 2 && n_cls <= 8, "plan_create: n_cls=%d unsupported (2..8)", n_cls);
   HDF_CHECK_ARG(n_filters >= 16 && n_filters % 16 == 0 && n_filters <= 64,
                 "plan_create: n_filters=%d unsupported (multiple of 16, 16..64)", n_filters);
-  HDF_CHECK_ARG(D % 16 == 0 && H % 16 == 0 && W % 16 == 0 && D >= 32 && H >= 32 && W >= 32,
+  HDF_CHECK_ARG(D % 16 == 0 && H % 16 == 0 && W % 16 == 0 && (D >= 32 || is2d) && H >= 32 && W >= 32,
                 "plan_create: image_size (%d,%d,%d) must be multiples of 16 and >= 32", D, H, W);
   HDF_CHECK_ARG(transformer_depth >= 4, "plan_create: transformer_depth=%d < 4", transformer_depth);
   HDF_CHECK_ARG(dtype == HDF_F32 || dtype == HDF_BF16 || dtype == HDF_F16, "plan_create: dtype %d", dtype);
@@ -755,18 +919,36 @@ int hdf_plan_create(int in_channels, int n_cls, int n_filters, int D, int H, int
   p->Ntok = (D / 16) * (H / 16) * (W / 16);
   build_params(p);
   build_layers(p);
+  p->is2d = is2d;
+  if (is2d) {
+    int rc = build_params2d(p);
+    if (rc != HDF_OK) {
+      delete p;
+      return rc;
+    }
+  }
   *out = p;
   return HDF_OK;
 }
 
+int hdf_plan_create(int in_channels, int n_cls, int n_filters, int D, int H, int W, int transformer_depth, int dtype,
+                    hdf_plan** out) {
+  return create_plan(in_channels, n_cls, n_filters, D, H, W, transformer_depth, dtype, false, out);
+}
+int hdf_plan_create_2d(int in_channels, int n_cls, int n_filters, int H, int W, int transformer_depth, int dtype,
+                       hdf_plan** out) {
+  return create_plan(in_channels, n_cls, n_filters, 16, H, W, transformer_depth, dtype, true, out);
+}
+
 void hdf_plan_destroy(hdf_plan* p) { delete p; }
-int64_t hdf_plan_num_params(const hdf_plan* p) { return (int64_t)p->params.size(); }
-int64_t hdf_plan_param_floats(const hdf_plan* p) { return p->total_floats; }
+int64_t hdf_plan_num_params(const hdf_plan* p) { return (int64_t)(p->is2d ? p->params2d : p->params).size(); }
+int64_t hdf_plan_param_floats(const hdf_plan* p) { return p->is2d ? p->total_floats2d : p->total_floats; }
 
 int hdf_plan_param_info(const hdf_plan* p, int64_t idx, char* name, int name_cap, int64_t* offset, int64_t* numel,
                         int* ndim, int64_t* shape5) {
-  HDF_CHECK_ARG(idx >= 0 && idx < (int64_t)p->params.size(), "param_info: index %lld", (long long)idx);
-  const ParamInfo& pi = p->params[idx];
+  const std::vector<ParamInfo>& tbl = p->is2d ? p->params2d : p->params;
+  HDF_CHECK_ARG(idx >= 0 && idx < (int64_t)tbl.size(), "param_info: index %lld", (long long)idx);
+  const ParamInfo& pi = tbl[idx];
   if (name && name_cap > 0) {
     strncpy(name, pi.name.c_str(), name_cap - 1);
     name[name_cap - 1] = 0;
@@ -799,9 +981,43 @@ int hdf_plan_buffer_info(hdf_plan* p, int batch, const char* name, int64_t* byte
   return HDF_OK;
 }
 
+static int forward3d(hdf_plan* p, const float* x, const float* params, void* workspace, int64_t workspace_bytes,
+                     void* out0, void* out1, void* out2, void* out3, int batch, int training, uint64_t seed,
+                     hdf_stream stream);
+static int backward3d(hdf_plan* p, const float* x, const float* params, void* workspace, int64_t workspace_bytes,
+                      const void* dout0, const void* dout1, const void* dout2, const void* dout3, float* grads,
+                      int batch, int stages, hdf_stream stream);
+
 int hdf_forward(hdf_plan* p, const float* x, const float* params, void* workspace, int64_t workspace_bytes, void* out0,
                 void* out1, void* out2, void* out3, int batch, int training, uint64_t seed, hdf_stream stream) {
   HDF_CHECK_ARG(p && x && params && workspace, "forward: null argument");
+  if (!p->is2d)
+    return forward3d(p, x, params, workspace, workspace_bytes, out0, out1, out2, out3, batch, training, seed, stream);
+  // 2-D model: x [B,C,H,W], params = the 2-D flat buffer, outputs [B,n_cls,H/2^i,W/2^i]
+  layout(p, batch);
+  HDF_CHECK_ARG((size_t)workspace_bytes >= p->ws_bytes, "forward: workspace %lld < %zu bytes", (long long)workspace_bytes,
+                p->ws_bytes);
+  char* ws = (char*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  float* p3 = (float*)(ws + p->e_params3d);
+  float* x3 = (float*)(ws + p->e_x3d);
+  HDF_TRY(launch_embed2d(p, params, p3, st));
+  const int64_t hw = (int64_t)p->H * p->W;
+  hipLaunchKernelGGL(replicate_depth_kernel, dim3(2048), dim3(256), 0, st, x, x3, (int64_t)batch * p->M, p->D, hw);
+  HDF_LAUNCH_CHECK();
+  void* o3[4];
+  for (int i = 0; i < 4; i++) o3[i] = ws + p->e_out3d[i];
+  HDF_TRY(forward3d(p, x3, p3, workspace, workspace_bytes, o3[0], o3[1], o3[2], o3[3], batch, training, seed, stream));
+  void* o2[4] = {out0, out1, out2, out3};
+  for (int i = 0; i < 4; i++)
+    HDF_TRY(launch_depth_slice(p->dtype, o3[i], o2[i], (int64_t)batch * p->ncls, p->dims[i][0],
+                               (int64_t)p->dims[i][1] * p->dims[i][2], 1, st));
+  return HDF_OK;
+}
+
+static int forward3d(hdf_plan* p, const float* x, const float* params, void* workspace, int64_t workspace_bytes,
+                     void* out0, void* out1, void* out2, void* out3, int batch, int training, uint64_t seed,
+                     hdf_stream stream) {
   layout(p, batch);
   HDF_CHECK_ARG((size_t)workspace_bytes >= p->ws_bytes, "forward: workspace %lld < %zu bytes", (long long)workspace_bytes,
                 p->ws_bytes);
@@ -885,6 +1101,29 @@ int hdf_backward_stages(hdf_plan* p, const float* x, const float* params, void* 
                         const void* dout0, const void* dout1, const void* dout2, const void* dout3, float* grads,
                         int batch, int stages, hdf_stream stream) {
   HDF_CHECK_ARG(p && x && params && workspace && grads, "backward: null argument");
+  if (!p->is2d)
+    return backward3d(p, x, params, workspace, workspace_bytes, dout0, dout1, dout2, dout3, grads, batch, stages, stream);
+  // 2-D model: the forward left the replicated input and the embedded parameters in the workspace
+  HDF_CHECK_ARG(p->batch == batch && (size_t)workspace_bytes >= p->ws_bytes, "backward: batch / workspace mismatch");
+  char* ws = (char*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  void* d3[4];
+  const void* d2[4] = {dout0, dout1, dout2, dout3};
+  for (int i = 0; i < 4; i++) {
+    d3[i] = ws + p->e_dout3d[i];
+    if (stages & 1)  // the loss sees depth slice 0 only
+      HDF_TRY(launch_depth_slice(p->dtype, d3[i], const_cast<void*>(d2[i]), (int64_t)batch * p->ncls, p->dims[i][0],
+                                 (int64_t)p->dims[i][1] * p->dims[i][2], 0, st));
+  }
+  float* g3 = (float*)(ws + p->e_grads3d);
+  HDF_TRY(backward3d(p, (const float*)(ws + p->e_x3d), (const float*)(ws + p->e_params3d), workspace, workspace_bytes,
+                     d3[0], d3[1], d3[2], d3[3], g3, batch, stages, stream));
+  return launch_extract2d(p, stages, g3, grads, st);
+}
+
+static int backward3d(hdf_plan* p, const float* x, const float* params, void* workspace, int64_t workspace_bytes,
+                      const void* dout0, const void* dout1, const void* dout2, const void* dout3, float* grads,
+                      int batch, int stages, hdf_stream stream) {
   HDF_CHECK_ARG(p->batch == batch, "backward: batch %d differs from the forward's %d", batch, p->batch);
   HDF_CHECK_ARG((size_t)workspace_bytes >= p->ws_bytes, "backward: workspace too small");
   Exec e{p, (char*)workspace, params, grads, batch, (hipStream_t)stream};

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HDF_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libhdf_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 
 _vp, _i, _i64, _f, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 
@@ -16,6 +16,7 @@ _PROTOS = {
     "hdf_version": (C.c_char_p, []),
     "hdf_last_error": (C.c_char_p, []),
     "hdf_plan_create": (_i, [_i] * 8 + [C.POINTER(_vp)]),
+    "hdf_plan_create_2d": (_i, [_i] * 7 + [C.POINTER(_vp)]),
     "hdf_plan_destroy": (None, [_vp]),
     "hdf_plan_num_params": (_i64, [_vp]),
     "hdf_plan_param_floats": (_i64, [_vp]),

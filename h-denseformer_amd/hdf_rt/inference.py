@@ -9,7 +9,7 @@ import torch
 from . import _lib
 from ._lib import check, lib, ptr, stream_ptr
 
-_SW_DT = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
+_SW_DT = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.float16: _lib.F16}
 
 
 def cal_steps(image_size, patch_size, step_size):

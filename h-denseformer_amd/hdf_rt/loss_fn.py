@@ -3,9 +3,9 @@
 import torch
 
 from . import _lib
-from ._lib import BF16, F32, check, lib, ptr, stream_ptr
+from ._lib import BF16, F16, F32, check, lib, ptr, stream_ptr
 
-_DT = {torch.float32: F32, torch.bfloat16: BF16}
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 
 
 class DeepSuperCEDice(torch.autograd.Function):
@@ -21,13 +21,17 @@ class DeepSuperCEDice(torch.autograd.Function):
             raise _lib.HdfError("fused loss needs GPU tensors (no CPU fallback)")
         dt = outs[0].dtype
         if dt not in _DT or any(o.dtype != dt for o in outs):
-            raise _lib.HdfError(f"fused loss: logits must all be float32 or all bfloat16 (got {[o.dtype for o in outs]})")
+            raise _lib.HdfError(f"fused loss: logits must all be float32, all bfloat16 or all float16 (got {[o.dtype for o in outs]})")
         n = len(outs)
         if not 1 <= n <= 4:
             raise _lib.HdfError("fused loss handles 1..4 deep-supervision scales")
-        b, c, d, h, w = target.shape
+        if target.dim() not in (4, 5):
+            raise _lib.HdfError(f"fused loss: target must be [B,C,D,H,W] or [B,C,H,W], got {tuple(target.shape)}")
+        sp = tuple(target.shape[2:])
+        b, c = target.shape[:2]
+        d, h, w = ((1,) + sp) if len(sp) == 2 else sp        # 2-D logits (HDenseFormer_2D): depth 1
         for i, o in enumerate(outs):
-            if tuple(o.shape) != (b, c, d >> i, h >> i, w >> i):
+            if tuple(o.shape) != (b, c) + tuple(v >> i for v in sp):
                 raise AssertionError(f"predict & target shape do not match at scale {i}: {tuple(o.shape)}")
         outs = [o.contiguous() for o in outs]
         tgt = target.float().contiguous()
@@ -38,14 +42,15 @@ class DeepSuperCEDice(torch.autograd.Function):
                                            float(w_ce), float(w_dice), ptr(ws), ptr(loss), stream_ptr()),
               "hdf_loss_terms_forward")
         ctx.save_for_backward(tgt, ws, *outs)
-        ctx.n, ctx.w = n, (float(w_ce), float(w_dice))
+        ctx.n, ctx.w, ctx.dhw = n, (float(w_ce), float(w_dice)), (d, h, w)
         return loss
 
     @staticmethod
     def backward(ctx, g):
         tgt, ws, *outs = ctx.saved_tensors
         n = ctx.n
-        b, c, d, h, w = tgt.shape
+        b, c = tgt.shape[:2]
+        d, h, w = ctx.dhw
         douts = [torch.empty_like(o) for o in outs]
         gg = g.detach().float().reshape(1).contiguous()
         po = [ptr(o) for o in outs] + [None] * (4 - n)

@@ -9,7 +9,11 @@ from ._lib import check, lib, ptr, stream_ptr
 class FlatAdam:
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4):
         self.model = model
-        self.param_groups = [{"lr": lr, "betas": betas, "eps": eps, "weight_decay": weight_decay}]
+        # "params" lets torch.cuda.amp.GradScaler.unscale_/step (trainer.py:374-377) walk the gradients like it does
+        # for a torch optimizer; the update itself is one kernel over the flat buffer
+        self.param_groups = [{"lr": lr, "betas": betas, "eps": eps, "weight_decay": weight_decay,
+                              "params": list(model.parameters())}]
+        self.state = {}
         self.step_count = 0
         self._state_for = None
 

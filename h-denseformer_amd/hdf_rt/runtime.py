@@ -7,9 +7,9 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import BF16, F32, check, lib, ptr, stream_ptr
+from ._lib import BF16, F16, F32, check, lib, ptr, stream_ptr
 
-_TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16}
+_TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
 
 
 class Plan:
@@ -20,9 +20,14 @@ class Plan:
                     int(transformer_depth))
         self.dtype = dtype
         h = C.c_void_p()
-        d, hh, w = self.cfg[3]
-        check(lib().hdf_plan_create(self.cfg[0], self.cfg[1], self.cfg[2], d, hh, w, self.cfg[4], dtype, C.byref(h)),
-              "hdf_plan_create")
+        if len(self.cfg[3]) == 2:      # HDenseFormer_2D: the plan's parameter table is the 2-D state_dict
+            hh, w = self.cfg[3]
+            check(lib().hdf_plan_create_2d(self.cfg[0], self.cfg[1], self.cfg[2], hh, w, self.cfg[4], dtype,
+                                           C.byref(h)), "hdf_plan_create_2d")
+        else:
+            d, hh, w = self.cfg[3]
+            check(lib().hdf_plan_create(self.cfg[0], self.cfg[1], self.cfg[2], d, hh, w, self.cfg[4], dtype,
+                                        C.byref(h)), "hdf_plan_create")
         self.h = h
         self.param_floats = lib().hdf_plan_param_floats(h)
         self.table = []          # (name, offset, numel, shape)
@@ -76,8 +81,8 @@ class Runtime:
         b = x.shape[0]
         self._ensure_ws(b)
         tdt = _TORCH_DTYPE[self.plan.dtype]
-        d, h, w = cfg[3]
-        outs = [torch.empty((b, cfg[1], d >> i, h >> i, w >> i), dtype=tdt, device=self.device) for i in range(4)]
+        outs = [torch.empty((b, cfg[1]) + tuple(s >> i for s in cfg[3]), dtype=tdt, device=self.device)
+                for i in range(4)]
         check(lib().hdf_forward(self.plan.h, ptr(x), ptr(flat_params), ptr(self.ws), self.ws.numel(),
                                 ptr(outs[0]), ptr(outs[1]), ptr(outs[2]), ptr(outs[3]), b, int(bool(training)),
                                 int(seed) & 0xFFFFFFFFFFFFFFFF, stream_ptr()), "hdf_forward")
@@ -91,9 +96,10 @@ class Runtime:
                                         b, stages, stream_ptr()), "hdf_backward")
 
     def read_buffer(self, name):
-        """Debug / parity helper: copy a named channels-last activation out of the workspace as NCDHW fp32."""
+        """Debug / parity helper: copy a named channels-last activation out of the workspace as NCDHW fp32
+        (2-D plans: the buffers of the depth-replicated 3-D embedding)."""
         off, pitch, c, (d, h, w) = self.plan.buffer_info(self.ws_batch, name)
-        esz = 2 if self.plan.dtype == BF16 else 4
+        esz = 4 if self.plan.dtype == F32 else 2
         tdt = _TORCH_DTYPE[self.plan.dtype]
         n = self.ws_batch * d * h * w
         # a channel sub-view of a wider buffer starts at `off`; rows are `pitch` elements apart
@@ -124,11 +130,10 @@ class HDFFunction(torch.autograd.Function):
         tdt = _TORCH_DTYPE[rt.plan.dtype]
         b = x.shape[0]
         cfg = rt.plan.cfg
-        d, h, w = cfg[3]
         douts = []
         for i, g in enumerate(gouts):
             if g is None:
-                g = torch.zeros((b, cfg[1], d >> i, h >> i, w >> i), dtype=tdt, device=x.device)
+                g = torch.zeros((b, cfg[1]) + tuple(s >> i for s in cfg[3]), dtype=tdt, device=x.device)
             douts.append(g.to(tdt).contiguous())
         module._run_backward(rt, x, douts)
         return None, None, None, None, None, None

@@ -8,7 +8,11 @@ parameter buffer to the C ABI (hdf_forward / hdf_backward in include/hdf.h) thro
 node.  Precision: fp32 storage + exact-fp32 MFMA by default (like the reference without AMP); under
 `torch.autocast(device_type="cuda", dtype=torch.bfloat16)` (trainer.py:369 `autocast`) or with
 `net.compute_dtype = "bf16"` activations are stored in bf16 and the matrix cores run bf16 with fp32
-accumulation, and the four outputs come back in bf16 exactly as autocast would return them.
+accumulation, and the four outputs come back in bf16 exactly as autocast would return them.  The
+reference's own mixed precision is `torch.cuda.amp.autocast(True)` = float16 with a GradScaler
+(trainer.py:20-21,257,369-377): under float16 autocast (or `compute_dtype = "fp16"`) storage is IEEE
+half with v_mfma_f32_32x32x16_f16 (same rate as bf16), outputs come back in float16, and the scaled
+backward runs unchanged (parameter gradients stay fp32, so GradScaler.unscale_/step see what they expect).
 
 There is no CPU or eager fallback: without the built extension or on a non-GPU tensor, forward raises.
 """
@@ -59,34 +63,44 @@ class _DenseBlock(_Holder):
         self.out_layer = _TwoLinear(dim + _LAYERS * _GROWTH, 2 * _GROWTH, dim)
 
 
+_CONV = {2: nn.Conv2d, 3: nn.Conv3d}
+_CONVT = {2: nn.ConvTranspose2d, 3: nn.ConvTranspose3d}
+_INORM = {2: nn.InstanceNorm2d, 3: nn.InstanceNorm3d}
+
+
 class _Branch(_Holder):
-    def __init__(self, dim, tokens, n_blocks):
+    def __init__(self, dim, tokens, n_blocks, nd=3):
         super().__init__()
-        self.patch_embeddings = nn.Conv3d(1, dim, kernel_size=_PATCH, stride=_PATCH)
+        self.patch_embeddings = _CONV[nd](1, dim, kernel_size=_PATCH, stride=_PATCH)
         self.position_embeddings = nn.Parameter(torch.zeros(1, tokens, dim))
         self.blocks = nn.ModuleList([nn.ModuleList([_DenseBlock(dim)]) for _ in range(n_blocks)])
 
 
-class _ConvNormAct(_Holder):     # BasicConv3d: conv (no bias) + affine InstanceNorm
-    def __init__(self, cin, cout):
+class _ConvNormAct(_Holder):     # BasicConv3d / BasicConv2d: conv (no bias) + affine InstanceNorm
+    def __init__(self, cin, cout, nd=3):
         super().__init__()
-        self.conv = nn.Conv3d(cin, cout, kernel_size=3, stride=1, padding=1, bias=False)
-        self.norm = nn.InstanceNorm3d(cout, affine=True)
+        self.conv = _CONV[nd](cin, cout, kernel_size=3, stride=1, padding=1, bias=False)
+        self.norm = _INORM[nd](cout, affine=True)
 
 
 class _ConvUp(_Holder):          # UpConv: double_conv.0 is the conv (with bias); the norm has no parameters
-    def __init__(self, cin, cout):
+    def __init__(self, cin, cout, nd=3):
         super().__init__()
-        self.double_conv = nn.Sequential(nn.Conv3d(cin, cout, kernel_size=3, padding=1), nn.InstanceNorm3d(cout),
+        self.double_conv = nn.Sequential(_CONV[nd](cin, cout, kernel_size=3, padding=1), _INORM[nd](cout),
                                          nn.ReLU(inplace=True))
 
 
 # ------------------------------------------------------------------------------------------- model
 class HDenseFormer(nn.Module):
+    _ND = 3          # models/HDenseFormer_2D.py derives the 2-D model from this class with _ND = 2
+
     def __init__(self, in_channels, n_cls, n_filters, image_size=(144, 144, 144), transformer_depth=12):
         super().__init__()
+        nd = self._ND
         if not isinstance(image_size, tuple):
-            image_size = (image_size,) * 3
+            image_size = (image_size,) * nd
+        if len(image_size) != nd:
+            raise ValueError(f"image_size {image_size} must have {nd} entries")
         self.in_channels, self.n_cls, self.n_filters = in_channels, n_cls, n_filters
         self.image_size, self.transformer_depth = tuple(image_size), transformer_depth
         nf = n_filters
@@ -94,34 +108,34 @@ class HDenseFormer(nn.Module):
         for s in self.image_size:
             tokens *= s // _PATCH
         # registration order == the reference's, so state_dict()/named_parameters() orders agree
-        self.attns = nn.ModuleList([_Branch(4 * nf, tokens, transformer_depth // 4) for _ in range(in_channels)])
-        self.deep_conv = _ConvUp(4 * nf * in_channels, 8 * nf)
-        self.up1 = _ConvUp(8 * nf, 4 * nf)
-        self.up2 = _ConvUp(4 * nf, 2 * nf)
-        self.up3 = _ConvUp(2 * nf, nf)
-        self.block_1_1_left = _ConvNormAct(in_channels, nf)
-        self.block_1_2_left = _ConvNormAct(nf, nf)
-        self.block_2_1_left = _ConvNormAct(nf, 2 * nf)
-        self.block_2_2_left = _ConvNormAct(2 * nf, 2 * nf)
-        self.block_3_1_left = _ConvNormAct(2 * nf, 4 * nf)
-        self.block_3_2_left = _ConvNormAct(4 * nf, 4 * nf)
-        self.block_4_1_left = _ConvNormAct(4 * nf, 8 * nf)
-        self.block_4_2_left = _ConvNormAct(8 * nf, 8 * nf)
-        self.upconv_3 = nn.ConvTranspose3d(8 * nf, 4 * nf, kernel_size=3, stride=2, padding=1, output_padding=1)
-        self.block_3_1_right = _ConvNormAct(8 * nf, 4 * nf)
-        self.block_3_2_right = _ConvNormAct(4 * nf, 4 * nf)
-        self.upconv_2 = nn.ConvTranspose3d(4 * nf, 2 * nf, kernel_size=3, stride=2, padding=1, output_padding=1)
-        self.block_2_1_right = _ConvNormAct(4 * nf, 2 * nf)
-        self.block_2_2_right = _ConvNormAct(2 * nf, 2 * nf)
-        self.upconv_1 = nn.ConvTranspose3d(2 * nf, nf, kernel_size=3, stride=2, padding=1, output_padding=1)
-        self.block_1_1_right = _ConvNormAct(2 * nf, nf)
-        self.block_1_2_right = _ConvNormAct(nf, nf)
-        self.conv1x1 = nn.Conv3d(nf, n_cls, kernel_size=1)
-        self.conv1x1_d1 = nn.Conv3d(2 * nf, n_cls, kernel_size=1)
-        self.conv1x1_d2 = nn.Conv3d(4 * nf, n_cls, kernel_size=1)
-        self.conv1x1_d3 = nn.Conv3d(8 * nf, n_cls, kernel_size=1)
+        self.attns = nn.ModuleList([_Branch(4 * nf, tokens, transformer_depth // 4, nd) for _ in range(in_channels)])
+        self.deep_conv = _ConvUp(4 * nf * in_channels, 8 * nf, nd)
+        self.up1 = _ConvUp(8 * nf, 4 * nf, nd)
+        self.up2 = _ConvUp(4 * nf, 2 * nf, nd)
+        self.up3 = _ConvUp(2 * nf, nf, nd)
+        self.block_1_1_left = _ConvNormAct(in_channels, nf, nd)
+        self.block_1_2_left = _ConvNormAct(nf, nf, nd)
+        self.block_2_1_left = _ConvNormAct(nf, 2 * nf, nd)
+        self.block_2_2_left = _ConvNormAct(2 * nf, 2 * nf, nd)
+        self.block_3_1_left = _ConvNormAct(2 * nf, 4 * nf, nd)
+        self.block_3_2_left = _ConvNormAct(4 * nf, 4 * nf, nd)
+        self.block_4_1_left = _ConvNormAct(4 * nf, 8 * nf, nd)
+        self.block_4_2_left = _ConvNormAct(8 * nf, 8 * nf, nd)
+        self.upconv_3 = _CONVT[nd](8 * nf, 4 * nf, kernel_size=3, stride=2, padding=1, output_padding=1)
+        self.block_3_1_right = _ConvNormAct(8 * nf, 4 * nf, nd)
+        self.block_3_2_right = _ConvNormAct(4 * nf, 4 * nf, nd)
+        self.upconv_2 = _CONVT[nd](4 * nf, 2 * nf, kernel_size=3, stride=2, padding=1, output_padding=1)
+        self.block_2_1_right = _ConvNormAct(4 * nf, 2 * nf, nd)
+        self.block_2_2_right = _ConvNormAct(2 * nf, 2 * nf, nd)
+        self.upconv_1 = _CONVT[nd](2 * nf, nf, kernel_size=3, stride=2, padding=1, output_padding=1)
+        self.block_1_1_right = _ConvNormAct(2 * nf, nf, nd)
+        self.block_1_2_right = _ConvNormAct(nf, nf, nd)
+        self.conv1x1 = _CONV[nd](nf, n_cls, kernel_size=1)
+        self.conv1x1_d1 = _CONV[nd](2 * nf, n_cls, kernel_size=1)
+        self.conv1x1_d2 = _CONV[nd](4 * nf, n_cls, kernel_size=1)
+        self.conv1x1_d3 = _CONV[nd](8 * nf, n_cls, kernel_size=1)
 
-        self.compute_dtype = None        # None: follow autocast; "fp32" / "bf16": force
+        self.compute_dtype = None        # None: follow autocast; "fp32" / "bf16" / "fp16": force
         self.dropout_seed = 0            # base seed of the counter-hash dropout masks (train mode)
         self._step = 0
         self._forced_seed = None
@@ -233,18 +247,20 @@ class HDenseFormer(nn.Module):
     # ------------------------------------------------------------------------------ execution
     def _pick_dtype(self, x):
         if self.compute_dtype is not None:
-            return {"fp32": _lib.F32, "bf16": _lib.BF16}[self.compute_dtype]
-        if torch.is_autocast_enabled():
-            adt = torch.get_autocast_gpu_dtype()
+            return {"fp32": _lib.F32, "bf16": _lib.BF16, "fp16": _lib.F16}[self.compute_dtype]
+        if torch.is_autocast_enabled("cuda"):
+            adt = torch.get_autocast_dtype("cuda")
             if adt == torch.bfloat16:
                 return _lib.BF16
-            raise _lib.HdfError(f"autocast dtype {adt} is not supported by the HIP path (use torch.bfloat16)")
+            if adt == torch.float16:
+                return _lib.F16
+            raise _lib.HdfError(f"autocast dtype {adt} is not supported by the HIP path (bfloat16 / float16)")
         return _lib.F32
 
     def forward(self, x):
         if not x.is_cuda:
             raise _lib.HdfError("HDenseFormer (MI355X build) needs a GPU tensor: there is no CPU fallback path")
-        if x.dim() != 5 or x.shape[1] != self.in_channels or tuple(x.shape[2:]) != self.image_size:
+        if x.dim() != 2 + self._ND or x.shape[1] != self.in_channels or tuple(x.shape[2:]) != self.image_size:
             raise _lib.HdfError(f"input shape {tuple(x.shape)} does not match (B,{self.in_channels},"
                                 f"{self.image_size})")
         params = self._walk_params()

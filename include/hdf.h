@@ -9,7 +9,9 @@
  * message (thread-local).  No C++ exception crosses this boundary.
  *
  * dtype enum: 0 = float32 storage (v_mfma_f32_32x32x2_f32, exact fp32 -- the parity path),
- *             1 = bfloat16 storage with fp32 accumulation (v_mfma_f32_32x32x16_bf16 -- the bench path).
+ *             1 = bfloat16 storage with fp32 accumulation (v_mfma_f32_32x32x16_bf16 -- the bench path),
+ *             2 = float16 storage with fp32 accumulation (v_mfma_f32_32x32x16_f16 -- what the reference's
+ *                 torch.cuda.amp.autocast(True) + GradScaler run, trainer.py:20-21,257,369-377).
  */
 #ifndef HDF_H
 #define HDF_H
@@ -29,6 +31,12 @@ const char* hdf_last_error(void);
 /* ---- model plan: models/HDenseFormer.py:177-227 (HDenseFormer.__init__) ------------------------------- */
 int hdf_plan_create(int in_channels, int n_cls, int n_filters, int D, int H, int W, int transformer_depth, int dtype,
                     hdf_plan** out);
+/* models/HDenseFormer_2D.py:172-229 (HDenseFormer_2D.__init__): the 2-D model.  The plan's parameter table is then the
+ * 2-D reference state_dict (Conv2d / ConvTranspose2d kernels [..,3,3], patch kernels [..,16,16]); hdf_forward takes
+ * x [B,C,H,W] and returns out_i [B,n_cls,H/2^i,W/2^i]; hdf_backward* take 2-D logit gradients and write 2-D parameter
+ * gradients.  Internally the model runs as its exact depth-replicated 3-D embedding (csrc/plan.hip "2-D embedding"). */
+int hdf_plan_create_2d(int in_channels, int n_cls, int n_filters, int H, int W, int transformer_depth, int dtype,
+                       hdf_plan** out);
 void hdf_plan_destroy(hdf_plan* p);
 /* parameter table = the reference state_dict, in registration order; the flat fp32
  * parameter / gradient buffers place tensor i at offset_i (64-byte aligned) */

@@ -11,6 +11,7 @@ What is captured:
   g3_loss         DeepSuperloss(CEPlusDice) values + dL/dlogits on random 4-scale logits (C=3,4; absent class)
   g5_full_eval    HDenseFormer_32(4,4,(128,)*3,td=24) B=1 eval: strided logits, stats, Dice, loss  (--full)
   g6_2d           HDenseFormer_2D_32(4,2,(256,256),24) single forward: shapes + strided logits  (config #1)
+  g6_2d_train     HDenseFormer_2D(2,3,16,(64,96),td=8) B=2 train step: logits, loss, gradients, Adam-updated samples
   g7_metric       trainer.compute_dice / metrics.RunningDice on seeded cases incl. absent class
 Weights/inputs are the closed-form generators of oracle/detgen.py, so nothing but (config, seed) is
 needed to regenerate the inputs on the GPU box.
@@ -40,11 +41,12 @@ def _import_reference():
               "transforms3d.affines", "SimpleITK", "cv2"]:
         sys.modules.setdefault(n, MagicMock())
     from models.HDenseFormer import HDenseFormer, HDenseFormer_32
-    from models.HDenseFormer_2D import HDenseFormer_2D_32
+    from models.HDenseFormer_2D import HDenseFormer_2D, HDenseFormer_2D_32
     from loss.combine_loss import CEPlusDice, DeepSuperloss
     import trainer
     import metrics
     return dict(HDenseFormer=HDenseFormer, HDenseFormer_32=HDenseFormer_32, HDenseFormer_2D_32=HDenseFormer_2D_32,
+                HDenseFormer_2D=HDenseFormer_2D,
                 CEPlusDice=CEPlusDice, DeepSuperloss=DeepSuperloss, trainer=trainer, metrics=metrics)
 
 
@@ -140,18 +142,31 @@ def _param_samples(net, n_samples):
     return np.stack(out)
 
 
+def _det_batch(name, cfg, batch):
+    """closed-form input / label map for a 3-D or 2-D config (2-D: depth-1 volumes squeezed)"""
+    in_ch, n_cls, nf, size, td = cfg
+    vol = size if len(size) == 3 else (1,) + tuple(size)
+    x = detgen.det_input(batch, in_ch, vol, tag=name)
+    lab = detgen.det_labels(batch, n_cls, vol, tag=name)
+    if len(size) == 2:
+        x, lab = x[:, :, 0], lab[:, 0]
+    return x, lab
+
+
 def golden_model(ref, name, cfg, batch, train_seed=None, sample_step=1, inter_step=4, with_grads=True, full_grads=(),
                  n_samples=8, adam_step=False):
     """adam_step: also run ONE optimizer step built by the reference's own SemanticSeg._get_optimizer
     (trainer.py:793-840; Adam, lr 1e-3, weight_decay 1e-4, its two parameter groups) and record the
     updated parameters at the sampled positions."""
     in_ch, n_cls, nf, size, td = cfg
-    net = ref["HDenseFormer"](in_ch, n_cls, nf, image_size=size, transformer_depth=td)
+    is2d = len(size) == 2
+    cls = ref["HDenseFormer_2D"] if is2d else ref["HDenseFormer"]
+    net = cls(in_ch, n_cls, nf, image_size=size, transformer_depth=td)
     _load(net, cfg)
     crit = ref["DeepSuperloss"](criterion=ref["CEPlusDice"](weight=None, ignore_index=0))
-    x = torch.from_numpy(detgen.det_input(batch, in_ch, size, tag=name))
-    lab = detgen.det_labels(batch, n_cls, size, tag=name)
-    onehot = torch.from_numpy(detgen.one_hot(lab, n_cls))
+    xn, lab = _det_batch(name, cfg, batch)
+    x = torch.from_numpy(xn)
+    onehot = torch.from_numpy(detgen.one_hot(lab[:, None], n_cls)[:, :, 0] if is2d else detgen.one_hot(lab, n_cls))
     got, hooks = _hook_intermediates(net)
     import torch.nn.functional as F
     orig = F.dropout
@@ -256,7 +271,7 @@ def golden_2d(ref):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also the 4x128^3 nf32 td24 fixture (needs ~9 GB, ~1 min)")
-    ap.add_argument("--only", default="", help="comma list of g1,g2,g3,g4,g5,g5t,g6,g7")
+    ap.add_argument("--only", default="", help="comma list of g1,g2,g3,g4,g5,g5t,g6,g6t,g7")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -283,6 +298,12 @@ def main():
                      n_samples=16, adam_step=True,
                      full_grads=("conv1x1.weight", "upconv_1.bias", "upconv_2.bias", "upconv_3.bias",
                                  "block_1_1_right.norm.weight", "attns.2.blocks.1.0.layers.3.1.fn.to_qkv.weight"))
+    if "g6t" in todo:
+        # the 2-D model's train step (hash dropout on), gradients + one Adam step of the reference optimizer
+        golden_model(ref, "g6_2d_train", (2, 3, 16, (64, 96), 8), 2, 606, sample_step=2, inter_step=4, n_samples=16,
+                     adam_step=True, full_grads=("conv1x1.weight", "upconv_1.weight", "upconv_2.bias",
+                                                 "block_2_1_left.conv.weight", "attns.1.patch_embeddings.weight",
+                                                 "deep_conv.double_conv.0.weight"))
     if "g5t" in todo:
         # the exact computation bench.py times (BASELINE configs[1]): 4x128^3, nf32, td24, B=2, train mode
         golden_model(ref, "g5_full_train", (4, 4, 32, (128, 128, 128), 24), 2, 2024, sample_step=8, inter_step=16,

@@ -1,9 +1,9 @@
 """Helpers for the GPU parity tests: call the C ABI (through hdf_rt._lib) on torch tensors."""
 import torch
 
-from hdf_rt._lib import BF16, F32, check, lib, ptr
+from hdf_rt._lib import BF16, F16, F32, check, lib, ptr
 
-TDT = {F32: torch.float32, BF16: torch.bfloat16}
+TDT = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
 DEV = "cuda:0"
 
 

@@ -468,3 +468,79 @@ def test_standalone_dice_and_ce_losses_vs_plain_torch(tag):
     x = logits.to(DEV).requires_grad_(True)
     both = CEPlusDice(weight=None, ignore_index=0)(x, onehot.to(DEV))
     assert abs(both.item() - (dice + ce).item()) < 4e-5
+
+
+@pytest.mark.gpu
+def test_fp16_autocast_with_gradscaler_like_the_reference_trainer():
+    """The reference's mixed precision is torch.cuda.amp.autocast(True) = float16 plus a GradScaler
+    (trainer.py:20-21,257,369-377).  Same lines here: float16 storage (v_mfma_f32_32x32x16_f16), scaled backward,
+    scaler.step() with the optimizer _get_optimizer builds (torch.optim.Adam over the named parameters), and an
+    overflowing loss scale must skip the step and back off."""
+    from loss.combine_loss import CEPlusDice, DeepSuperloss
+    cfg, batch, tag = CFG_TINY, 2, "g1_tiny_eval"
+    net, sd = _build(cfg)
+    net.eval()                                    # dropout off: compare with the fp32 oracle gradients
+    x, onehot = _data(cfg, batch, tag)
+    crit = DeepSuperloss(criterion=CEPlusDice(weight=None, ignore_index=0))
+    decay, no_decay = orc.param_groups([(k, tuple(v.shape)) for k, v in sd.items()])
+    named = dict(net.named_parameters())
+    opt = torch.optim.Adam([{"params": [named[k] for k in decay]},
+                            {"params": [named[k] for k in no_decay], "weight_decay": 0.0}], lr=1e-3, weight_decay=1e-4)
+    scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+    with torch.autocast(device_type="cuda", dtype=torch.float16):
+        outs = net(x.to(DEV))
+    assert outs[0].dtype == torch.float16
+    loss = crit(outs, onehot.to(DEV))
+    opt.zero_grad()
+    scaler.scale(loss).backward()
+    tr = orc.OracleTrainer(sd)
+    ref_loss, ref_outs = tr.loss_and_grads(x, onehot, None)
+    assert abs(loss.item() - ref_loss.item()) < 5e-3 * abs(ref_loss.item())
+    for i in range(4):
+        assert _rl2(outs[i].float(), ref_outs[i]) < 4e-3, f"out{i}"          # 8x tighter than the bf16 gate
+    scaler.unscale_(opt)
+    mine = torch.cat([p.grad.flatten().cpu() for _, p in net.named_parameters()]).double()
+    theirs = torch.cat([tr.sd[n].grad.flatten() for n, _ in net.named_parameters()]).double()
+    cos = float((mine @ theirs) / (mine.norm() * theirs.norm()))
+    print("  fp16 whole-gradient cosine", cos, "norm ratio", float(mine.norm() / theirs.norm()))
+    assert cos > 0.995 and abs(float(mine.norm() / theirs.norm()) - 1) < 2e-2
+    before = net.flat_parameters().clone()
+    scaler.step(opt)
+    scaler.update()
+    assert not torch.equal(before, net.flat_parameters())                    # finite gradients: the step was taken
+    # overflow: a loss scale beyond the float16 range gives inf gradients -> step skipped, scale halved
+    scaler2 = torch.amp.GradScaler("cuda", init_scale=2.0 ** 40)
+    with torch.autocast(device_type="cuda", dtype=torch.float16):
+        outs = net(x.to(DEV))
+    loss = crit(outs, onehot.to(DEV))
+    opt.zero_grad()
+    scaler2.scale(loss).backward()
+    before = net.flat_parameters().clone()
+    scaler2.step(opt)
+    scaler2.update()
+    assert torch.equal(before, net.flat_parameters())
+    assert scaler2.get_scale() == 2.0 ** 39
+
+
+@pytest.mark.gpu
+def test_fp16_storage_flat_adam_with_gradscaler():
+    """FlatAdam under GradScaler (the scaler walks param_groups[..]['params'] to unscale and to look for infs)."""
+    from hdf_rt.optim import FlatAdam
+    from loss.combine_loss import CEPlusDice, DeepSuperloss
+    cfg, batch, tag = CFG_TINY, 2, "g1_tiny_eval"
+    net, sd = _build(cfg, "fp16")
+    net.train()
+    x, onehot = _data(cfg, batch, tag)
+    crit = DeepSuperloss(criterion=CEPlusDice(weight=None, ignore_index=0))
+    opt = FlatAdam(net)
+    scaler = torch.amp.GradScaler("cuda", init_scale=256.0)
+    losses = []
+    for _ in range(4):
+        opt.zero_grad()
+        loss = crit(net(x.to(DEV)), onehot.to(DEV))
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        losses.append(loss.item())
+    print("  fp16 losses", losses)
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]

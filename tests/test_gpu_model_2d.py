@@ -1,0 +1,110 @@
+"""GPU parity of the 2-D model (reference models/HDenseFormer_2D.py:172-256) through the drop-in
+surface models.HDenseFormer_2D / loss.combine_loss, against the real reference's fixtures (g6_2d: BASELINE configs[0],
+4-ch 256x256 forward; g6_2d_train: train step with gradients and one Adam step) and against the oracle.
+
+The library runs the 2-D model as its exact depth-replicated 3-D embedding (csrc/plan.hip "2-D embedding"), so the
+tolerances are those of the 3-D path: logits <= 1e-3 relative, loss 1e-4, gradients at the reference's own fp32
+noise floor (<= 2e-2 rel-L2 per tensor, last decoder level <= 5e-3)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from conftest import GOLDEN  # noqa: E402
+from oracle import detgen  # noqa: E402
+from oracle import hdf_oracle as orc  # noqa: E402
+from test_gpu_bench_geometry import _check_adam_vs_fixture, _check_forward, _check_grads_vs_fixture, _rel, _rl2  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _build(cfg, dtype):
+    from models.HDenseFormer_2D import HDenseFormer_2D
+    in_ch, n_cls, nf, size, td = cfg
+    net = HDenseFormer_2D(in_ch, n_cls, nf, image_size=size, transformer_depth=td)
+    sd = orc.det_model(*cfg)
+    assert list(net.state_dict().keys()) == list(sd.keys())
+    net.load_state_dict(sd)
+    net = net.to(DEV)
+    net.compute_dtype = dtype
+    return net, sd
+
+
+def _data(cfg, batch, tag):
+    in_ch, n_cls, nf, size, td = cfg
+    vol = (1,) + tuple(size)
+    x = torch.from_numpy(detgen.det_input(batch, in_ch, vol, tag=tag))[:, :, 0].contiguous()
+    onehot = torch.from_numpy(detgen.one_hot(detgen.det_labels(batch, n_cls, vol, tag=tag), n_cls))[:, :, 0].contiguous()
+    return x, onehot
+
+
+def test_2d_forward_config0_vs_reference_golden():
+    """BASELINE configs[0]: HDenseFormer_2D 4-ch 256x256 single forward (the reference's CPU-runnable case)."""
+    from models.HDenseFormer_2D import HDenseFormer_2D_32
+    g = np.load(os.path.join(GOLDEN, "g6_2d.npz"))
+    cfg = (4, 2, 32, (256, 256), 24)
+    net = HDenseFormer_2D_32(4, 2, (256, 256), 24)
+    sd = orc.det_model(*cfg)
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval()
+    x = torch.from_numpy(detgen.det_input(1, 4, (1, 256, 256), tag="g6")[:, :, 0].copy())
+    with torch.no_grad():
+        outs = net(x.to(DEV))
+    for i, o in enumerate(outs):
+        assert tuple(o.shape) == tuple(int(v) for v in g[f"shape{i}"])
+        step = 4 if i == 0 else 1
+        e = _rel(o[:, :, ::step, ::step], torch.from_numpy(g[f"out{i}"]))
+        print(f"  2d out{i} rel {e:.3e}")
+        assert e < 1e-3
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_2d_train_step_vs_reference_golden(dtype):
+    from loss.combine_loss import CEPlusDice, DeepSuperloss
+    g = np.load(os.path.join(GOLDEN, "g6_2d_train.npz"), allow_pickle=False)
+    in_ch, n_cls, nf, td = [int(v) for v in g["cfg"][:4]]
+    cfg = (in_ch, n_cls, nf, tuple(int(v) for v in g["cfg"][4:]), td)
+    batch, seed = int(g["batch"]), int(g["train_seed"])
+    net, sd = _build(cfg, dtype)
+    x, onehot = _data(cfg, batch, "g6_2d_train")
+    crit = DeepSuperloss(criterion=CEPlusDice(weight=None, ignore_index=0))
+    net.train()
+    net.set_dropout_seed(seed)
+    outs = net(x.to(DEV))
+    loss = crit(outs, onehot.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    if dtype == "fp32":
+        for i in range(4):
+            s = max(1, int(g["sample_step"]) >> i)
+            e = _rel(outs[i].detach()[:, :, ::s, ::s], torch.from_numpy(g[f"out{i}"]))
+            print(f"  2d out{i} rel {e:.3e}")
+            assert e < 1e-3
+        assert abs(loss.item() - float(g["loss"])) < 1e-4 * max(1.0, abs(float(g["loss"])))
+        _check_grads_vs_fixture(g, net, 2e-2, 5e-2, tight=("conv1x1.weight",))
+        tr = orc.OracleTrainer(sd)
+        tr.loss_and_grads(x, onehot, seed)
+        errs = []
+        for name, p in net.named_parameters():
+            rg = tr.sd[name].grad
+            if rg.norm() < 1e-6:
+                continue
+            errs.append((name, _rl2(p.grad, rg)))
+        errs.sort(key=lambda kv: -kv[1])
+        for k, e in errs[:6]:
+            print(f"  2d grad {k:60s} rel-l2={e:.3e}")
+        assert errs[0][1] < 2e-2, errs[:4]
+        _check_adam_vs_fixture(g, net, min_live=1500)
+    else:
+        assert outs[0].dtype == torch.bfloat16 and outs[0].dim() == 4
+        assert abs(loss.item() - float(g["loss"])) < 3e-2 * abs(float(g["loss"]))
+        tr = orc.OracleTrainer(sd)
+        tr.loss_and_grads(x, onehot, seed)
+        mine = torch.cat([p.grad.flatten().cpu() for _, p in net.named_parameters()]).double()
+        theirs = torch.cat([tr.sd[n].grad.flatten() for n, _ in net.named_parameters()]).double()
+        cos = float((mine @ theirs) / (mine.norm() * theirs.norm()))
+        print("  2d bf16 whole-gradient cosine", cos)
+        assert cos > 0.98

@@ -35,8 +35,11 @@ def _run_model_fixture(name, grads=True):
     batch = int(g["batch"])
     seed = int(g["train_seed"])
     sd = orc.det_model(in_ch, n_cls, nf, size, td)
-    x = torch.from_numpy(detgen.det_input(batch, in_ch, size, tag=name))
-    onehot = torch.from_numpy(detgen.one_hot(detgen.det_labels(batch, n_cls, size, tag=name), n_cls))
+    vol = size if len(size) == 3 else (1,) + size             # 2-D configs: depth-1 volumes, squeezed
+    x = torch.from_numpy(detgen.det_input(batch, in_ch, vol, tag=name))
+    onehot = torch.from_numpy(detgen.one_hot(detgen.det_labels(batch, n_cls, vol, tag=name), n_cls))
+    if len(size) == 2:
+        x, onehot = x[:, :, 0], onehot[:, :, 0]
     tr = orc.OracleTrainer(sd)
     drop_seed = None if seed < 0 else seed
     outs, inter = orc.forward(x, tr.sd, drop_seed, want_intermediates=True)
@@ -103,6 +106,11 @@ def test_g5_full_size_eval():
 def test_g4_mid_train_step():
     """nf32 @ 64^3, B=2, train mode (hash dropout), gradients + one Adam step of the reference's optimizer."""
     _run_model_fixture("g4_mid_train")
+
+
+def test_g6_2d_train_step():
+    """HDenseFormer_2D train step (reference models/HDenseFormer_2D.py) incl. gradients and Adam."""
+    _run_model_fixture("g6_2d_train")
 
 
 def test_g5_full_size_train_step():
