@@ -77,8 +77,9 @@ def _data(cfg, batch, tag):
     return x, onehot
 
 
-def _step(net, x, onehot, seed):
-    """forward + DeepSuper(CE+Dice) + backward through the drop-in surface; seed < 0: eval mode."""
+def _step(net, x, onehot, seed, loss_scale=1.0):
+    """forward + DeepSuper(CE+Dice) + backward through the drop-in surface; seed < 0: eval mode.  loss_scale: what
+    GradScaler does for float16 storage (trainer.py:374-377); the parameter gradients come back scaled by it."""
     from loss.combine_loss import CEPlusDice, DeepSuperloss
     crit = DeepSuperloss(criterion=CEPlusDice(weight=None, ignore_index=0))
     if seed < 0:
@@ -90,7 +91,7 @@ def _step(net, x, onehot, seed):
         p.grad = None
     outs = net(x.to(DEV))
     loss = crit(outs, onehot.to(DEV))
-    loss.backward()
+    (loss * loss_scale if loss_scale != 1.0 else loss).backward()
     torch.cuda.synchronize()
     return outs, loss
 
@@ -308,7 +309,9 @@ def test_baseline_config_shapes_forward_vs_oracle_and_low_precision_step(name, c
     del net, outs
     torch.cuda.empty_cache()
     net, _ = _build(cfg, low)
-    outs, loss = _step(net, x, onehot, 777)
+    # float16 needs the reference's loss scaling: d loss / d logits is ~1/voxels = 2.4e-7 at 160^3, below the smallest
+    # normal half (6.1e-5); GradScaler's default initial scale is 65536 (cosines are scale-invariant)
+    outs, loss = _step(net, x, onehot, 777, loss_scale=65536.0 if low == "fp16" else 1.0)
     assert outs[0].dtype == (torch.bfloat16 if low == "bf16" else torch.float16)
     print(f"  {name} {low} loss {loss.item():.5f} fp32 {loss32.item():.5f}")
     assert np.isfinite(loss.item()) and abs(loss.item() - loss32.item()) < 3e-2 * abs(loss32.item())
