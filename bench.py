@@ -38,40 +38,51 @@ def log(*a):
 
 CPU_THREADS = 16          # torch/oneDNN on all 256 host threads of the GPU box is pathologically slow (measured:
 #                           811 s/step vs 12.6 s/step on 8 threads elsewhere), so the baseline pins 16 threads
-CPU_BUDGET_S = 150
+CPU_BUDGET_S = 240
 
 
 def _cpu_baseline_child():
     """Runs in a child process (no GPU): the oracle's train step -- the functional torch-CPU restatement of
-    the reference path, kind 'port' -- on a BOUNDED sample: batch 1 of a 4x64^3 crop (1/8 of the voxels of
-    the 4x128^3 workload; >99 % of the step's FLOPs are convolutions, linear in voxels), 1 warm-up + 2 timed
-    steps; if that predicts < 20 s per full-size step the full 4x128^3 step is timed as well."""
+    the reference path, kind 'port' -- on a BOUNDED sample.  First batch 1 of a 4x64^3 crop (1/8 of the voxels of
+    the 4x128^3 workload; >99 % of the step's FLOPs are convolutions, linear in voxels), 1 warm-up + 2 timed steps; if
+    that predicts a full-size step under 12 s, the real 4x128^3 step at batch 1 and at batch 2 (the benchmarked
+    batch), 1 warm-up + 3 timed steps each.  Every stage prints a JSON line; the last one wins."""
     from oracle import hdf_oracle as orc
     nt = min(os.cpu_count() or 1, CPU_THREADS)
     torch.set_num_threads(nt)
 
-    def time_steps(size, n_timed):
+    def time_steps(size, batch, n_timed):
         cfg = (CFG["in_channels"], CFG["n_cls"], CFG["n_filters"], (size,) * 3, CFG["transformer_depth"])
         tr = orc.OracleTrainer(orc.det_model(*cfg))
-        x = torch.rand(1, 4, size, size, size)
-        lab = torch.randint(0, 4, (1, size, size, size))
+        x = torch.rand(batch, 4, size, size, size)
+        lab = torch.randint(0, 4, (batch, size, size, size))
         onehot = torch.nn.functional.one_hot(lab, 4).permute(0, 4, 1, 2, 3).float()
         tr.step(x, onehot, drop_seed=1)
-        t0 = time.time()
+        ts = []
         for i in range(n_timed):
+            t0 = time.time()
             tr.step(x, onehot, drop_seed=2 + i)
-        return (time.time() - t0) / n_timed
+            ts.append(time.time() - t0)
+        return sorted(ts)[len(ts) // 2]
 
-    t64 = time_steps(64, 2)
+    what = "oracle train step (fwd + DeepSuper CE+Dice + bwd + Adam), fp32"
+    t64 = time_steps(64, 1, 2)
     rec = {"value": 1.0 / (8.0 * t64), "unit": "samples/s", "cores": nt, "kind": "port",
-           "sample": f"oracle train step (fwd + DeepSuper CE+Dice + bwd + Adam), fp32, batch 1 of a 4x64^3 crop: "
-                     f"{t64:.2f} s/step on {nt} threads, scaled x8 voxels to 4x128^3"}
+           "sample": f"{what}, batch 1 of a 4x64^3 crop: {t64:.2f} s/step on {nt} threads, scaled x8 voxels to 4x128^3"}
     print(json.dumps(rec), flush=True)
-    if 8.0 * t64 < 20.0:
-        t128 = time_steps(128, 1)
-        rec["value"] = 1.0 / t128
-        rec["sample"] = (f"oracle train step (fwd + DeepSuper CE+Dice + bwd + Adam), fp32, batch 1 of 4x128^3: "
-                         f"{t128:.2f} s/step on {nt} threads (1 warm-up + 1 timed; 4x64^3 crop gave {t64:.2f} s)")
+    if 8.0 * t64 < 12.0:
+        t1 = time_steps(128, 1, 3)
+        rec["value"] = 1.0 / t1
+        rec["sample"] = (f"{what}, 4x128^3: batch 1 {t1:.2f} s/step (median of 3 after 1 warm-up) on {nt} threads; "
+                         f"4x64^3 crop gave {t64:.2f} s")
+        rec["batch1_s_per_step"] = t1
+        print(json.dumps(rec), flush=True)
+        t2 = time_steps(128, 2, 3)
+        rec["value"] = max(1.0 / t1, 2.0 / t2)
+        rec["batch2_s_per_step"] = t2
+        rec["sample"] = (f"{what}, 4x128^3 on {nt} threads, median of 3 timed steps after 1 warm-up: batch 1 "
+                         f"{t1:.2f} s/step ({1.0 / t1:.3f} samples/s), batch 2 {t2:.2f} s/step ({2.0 / t2:.3f} samples/s); "
+                         f"value = the better of the two")
         print(json.dumps(rec), flush=True)
 
 
@@ -90,6 +101,16 @@ def cpu_baseline():
         return {"value": None, "unit": "samples/s", "cores": CPU_THREADS, "kind": "port",
                 "sample": f"oracle train step did not finish a 4x64^3 crop within {CPU_BUDGET_S} s"}
     return json.loads(lines[-1])
+
+
+def conv_source_digest():
+    """sha256 over the sources the dominant conv kernel is compiled from (what a PMC traffic profile is valid for)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("conv_igemm.hip", "conv_igemm.h", "hdf_common.h"):
+        with open(os.path.join(ROOT, "h-denseformer_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
 
 
 def roofline_dominant_kernel(dev):
@@ -121,13 +142,21 @@ def roofline_dominant_kernel(dev):
     flops = 2.0 * 27 * cin * cout * (s ** 3) * n
     achieved = flops / (ms * 1e-3) / 1e12
     # HBM bytes per launch of exactly this kernel/shape from the committed PMC passes (FETCH_SIZE x2 correction +
-    # WRITE_SIZE, collected in separate rocprofv3 --pmc runs: profiles/r01_conv_traffic.json); not measurable live
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
-    if os.path.exists(tfile):
-        traffic = json.load(open(tfile)).get("traffic_bytes_per_launch")
+    # WRITE_SIZE, collected in separate rocprofv3 --pmc runs by tools/conv_traffic.py); not measurable live.  The
+    # profile records the digest of the conv kernel sources it was taken on: a profile of another build is refused.
+    traffic, traffic_src = None, None
+    digest = conv_source_digest()
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+        if name.endswith("_conv_traffic.json"):
+            rec = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if rec.get("conv_source_digest") == digest:
+                traffic, traffic_src = rec.get("traffic_bytes_per_launch"), "profiles/" + name
+                break
+    if traffic is None:
+        log("roofline.traffic: no profiles/*_conv_traffic.json taken on this build's conv kernels "
+            f"(digest {digest[:12]}); reporting null")
     return {"bound": "mfma", "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic,
+            "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
             "kernel": "conv_ws2_kernel<bf16_t,32,128,false,1> (block_1_1_right fwd, 64->32 @128^3, batch 2)",
             "avg_launch_ms": ms, "flops_per_launch": flops, "algorithmic_bytes_per_launch": 2.0 * n * s ** 3 * (cin + cout)}
 
@@ -217,11 +246,18 @@ def main():
     for _ in range(a.warmup):
         loss = step()
     fence()
+    # wall clock around EXACTLY K steps between two barrier + synchronize fences (the contract's `value`), plus a HIP
+    # event after every step on the stream the kernels run on: their median is the per-step device time
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    evs[0].record()
+    for k in range(a.steps):
         loss = step()
+        evs[k + 1].record()
     fence()
     dt = time.perf_counter() - t0
+    per_step = sorted(evs[k].elapsed_time(evs[k + 1]) for k in range(a.steps))
+    median_ms = per_step[len(per_step) // 2]
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -240,6 +276,7 @@ def main():
                        "global_batch": global_batch, "per_gpu_batch": a.batch, "parallelism": f"dp{world}",
                        "dropout": "on (train mode)", "loss": last_loss},
             "step_tflops": FWD_BWD_GFLOP_PER_SAMPLE * sps / 1e3,
+            "hip_event_ms_per_step": {"median": median_ms, "min": per_step[0], "max": per_step[-1]},
         }
         if world == 1:
             rec["roofline"] = roofline_dominant_kernel(dev)

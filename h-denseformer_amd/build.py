@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib")
 OBJ = os.path.join(HERE, "build")
-SOURCES = ["conv_igemm.hip", "unet_ops.hip", "transformer.hip", "loss.hip", "plan.hip"]
+SOURCES = ["conv_igemm.hip", "unet_ops.hip", "transformer.hip", "transformer_fused.hip", "loss.hip", "plan.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 

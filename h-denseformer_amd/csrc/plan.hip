@@ -705,6 +705,38 @@ int transformer_forward(Exec& e, const float* x) {
   HDF_TRY(tf_patch_embed_fwd(d, x, p->D, p->H, p->W, pm + p->P("attns.0.patch_embeddings.weight"),
                              pm + p->P("attns.0.patch_embeddings.bias"), pm + p->P("attns.0.position_embeddings"), F0,
                              e.st));
+  if (tf_use_fused()) {
+    // token kernel, attention, token kernel, ...: between two attention launches ONE kernel finishes the previous
+    // dense layer (and, at a block boundary, runs the block's out_layer) and starts the next one
+    TfLayerP prev{}, cur{};
+    TfOutP o{};
+    for (int b = 0; b < p->nb; b++) {
+      float* F = F0 + (int64_t)b * rows * p->DMF;
+      for (int l = 0; l < 4; l++) {
+        tf_layer_ptrs(p, pm, b, l, cur);
+        TfTokenFwd t;
+        if (l > 0) {
+          t.post = &prev, t.post_save = tf_save(p, e, b, l - 1), t.bp = b, t.lp = l - 1, t.F_post = F;
+        } else if (b > 0) {
+          float* Fp = F0 + (int64_t)(b - 1) * rows * p->DMF;
+          t.post = &prev, t.post_save = tf_save(p, e, b - 1, 3), t.bp = b - 1, t.lp = 3, t.F_post = Fp;
+          tf_out_ptrs(p, pm, b - 1, o);
+          t.out = &o, t.next_F = F;
+        }
+        t.pre = &cur, t.pre_save = tf_save(p, e, b, l), t.bq = b, t.lq = l, t.F_pre = F;
+        HDF_TRY(tf_token_fwd(d, t, p->dtype, e.st));
+        TfLayerSave s = tf_save(p, e, b, l);
+        HDF_TRY(tf_attention_fwd(d.N, d.M * d.B, s.qkv, s.ob, s.lse, e.st));
+        prev = cur;
+      }
+    }
+    TfTokenFwd t;
+    const int b = p->nb - 1;
+    t.post = &prev, t.post_save = tf_save(p, e, b, 3), t.bp = b, t.lp = 3, t.F_post = F0 + (int64_t)b * rows * p->DMF;
+    tf_out_ptrs(p, pm, b, o);
+    t.out = &o, t.attnall = e.at(p->attnall);
+    return tf_token_fwd(d, t, p->dtype, e.st);
+  }
   for (int b = 0; b < p->nb; b++) {
     float* F = F0 + (int64_t)b * rows * p->DMF;
     for (int l = 0; l < 4; l++) {

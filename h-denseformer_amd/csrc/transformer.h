@@ -61,3 +61,22 @@ int tf_block_out_fwd(const TfDims& d, int block, const TfOutP& p, const float* F
 // dout comes from dF_next[rows][0:DM] (fp32, pitch DMF) or from d_attnall (storage type).  Writes dF[rows][0:DMF].
 int tf_block_out_bwd(const TfDims& d, int block, const TfOutP& p, const TfOutP& g, const float* F,
                      const float* dF_next, const void* d_attnall, int dtype, float* dF, hipStream_t st);
+
+// ---- fused token kernels (transformer_fused.hip): everything between two attention launches in ONE launch -----------
+// Forward: [finish dense layer (bp, lp): to_out + residual + ff + ff] -> [block bp's out_layer] -> [start layer (bq, lq):
+// Linear0 + LN1 + to_qkv], any non-empty contiguous selection of the three stages (null pointer = stage absent).
+struct TfTokenFwd {
+  const TfLayerP* post = nullptr;  // layer (bp, lp); reads post_save.h0 / .ob, writes .h1 / .h2 and the feature column
+  TfLayerSave post_save{};
+  int bp = 0, lp = 0;
+  float* F_post = nullptr;         // block bp's feature buffer [rows][DMF] (POST writes it, OUT reads it)
+  const TfOutP* out = nullptr;     // block bp's out_layer
+  float* next_F = nullptr;         // -> next block's feature buffer columns [0, DM) ...
+  void* attnall = nullptr;         // ... or the channels-last attnall tensor in the storage dtype (last block)
+  const TfLayerP* pre = nullptr;   // layer (bq, lq); writes pre_save.h0 / .qkv
+  TfLayerSave pre_save{};
+  int bq = 0, lq = 0;
+  const float* F_pre = nullptr;    // feature buffer PRE reads when it runs alone (else next_F / F_post)
+};
+int tf_token_fwd(const TfDims& d, const TfTokenFwd& t, int dtype, hipStream_t st);
+bool tf_use_fused();  // false under HDF_TF_OLD=1 (A/B knob: the unfused VALU token kernels)

@@ -1103,8 +1103,22 @@ int tf_attention_bwd(int N, int nseq, const float* qkv, const float* ob, const f
   return HDF_OK;
 }
 
+bool tf_use_fused() {
+  static const bool old = getenv("HDF_TF_OLD") != nullptr;  // A/B knob: the round-1 VALU token kernels
+  return !old;
+}
+
 int tf_layer_fwd(const TfDims& d, int block, int layer, const TfLayerP& p, float* F, const TfLayerSave& s,
                  hipStream_t st) {
+  if (tf_use_fused()) {  // one dense layer on its own: PRE, attention, POST as three launches of the fused kernels
+    TfTokenFwd pre;
+    pre.pre = &p, pre.pre_save = s, pre.bq = block, pre.lq = layer, pre.F_pre = F;
+    HDF_TRY(tf_token_fwd(d, pre, HDF_F32, st));
+    HDF_TRY(tf_attention_fwd(d.N, d.M * d.B, s.qkv, s.ob, s.lse, st));
+    TfTokenFwd post;
+    post.post = &p, post.post_save = s, post.bp = block, post.lp = layer, post.F_post = F;
+    return tf_token_fwd(d, post, HDF_F32, st);
+  }
   const int K = d.DM + 32 * layer, BN = d.B * d.N;
   dim3 grid(ceil_div(BN, FWD_TB), d.M);
   size_t shm = (size_t)(FWD_TB * K + FWD_TB * 32 + 32 * (K + 1) + 96 * 33) * sizeof(float);
@@ -1138,6 +1152,11 @@ int tf_layer_bwd(const TfDims& d, int block, int layer, const TfLayerP& p, const
 
 int tf_block_out_fwd(const TfDims& d, int block, const TfOutP& p, const float* F, float* next_F, void* attnall,
                      int dtype, hipStream_t st) {
+  if (tf_use_fused()) {
+    TfTokenFwd o;
+    o.out = &p, o.bp = block, o.F_post = const_cast<float*>(F), o.next_F = next_F, o.attnall = attnall;
+    return tf_token_fwd(d, o, dtype, st);
+  }
   dim3 grid(ceil_div(d.B * d.N, TB), d.M);
   size_t base = (size_t)(TB * d.DMF + TB * 64 + 64 * (d.DMF + 1)) * sizeof(float);
   size_t with_wb = base + (size_t)d.DM * 65 * sizeof(float);
