@@ -761,6 +761,51 @@ int transformer_backward(Exec& e, const float* x) {
   float* F0 = e.f(p->tf_F);
   float* dF = e.f(p->tf_dF);
   float* scratch = e.f(p->tf_scratch);
+  if (tf_use_fused()) {
+    // token kernel, attention backward, token kernel, ...: one launch runs the Linear0 / LN1 / to_qkv backward of the
+    // layer whose attention backward just finished, (at a block boundary) the previous block's out_layer backward, and
+    // the ff / to_out backward of the next layer down
+    float* dO = scratch;
+    float* dh0acc = scratch + rows * 32;
+    float* dqkv = scratch + rows * 64;
+    TfLayerP up{}, gup{}, cur{}, gcur{};
+    TfOutP o{}, go{};
+    bool have_up = false;
+    int ub = 0, ul = 0;
+    for (int b = p->nb - 1; b >= 0; b--) {
+      float* F = F0 + (int64_t)b * rows * p->DMF;
+      for (int l = 3; l >= 0; l--) {
+        tf_layer_ptrs(p, pm, b, l, cur);
+        tf_layer_ptrs(p, e.grads, b, l, gcur);
+        TfTokenBwd t;
+        t.dF = dF;
+        if (have_up) {
+          t.pre = &up, t.pre_grad = &gup, t.pre_save = tf_save(p, e, ub, ul), t.bq = ub, t.lq = ul;
+          t.F_pre = F0 + (int64_t)ub * rows * p->DMF, t.dqkv = dqkv, t.dh0acc = dh0acc;
+        }
+        if (l == 3) {
+          tf_out_ptrs(p, pm, b, o);
+          tf_out_ptrs(p, e.grads, b, go);
+          t.out = &o, t.out_grad = &go, t.bo = b, t.F_out = F;
+          if (!have_up) t.d_attnall = e.at(p->dAttnall);
+        }
+        t.post = &cur, t.post_grad = &gcur, t.post_save = tf_save(p, e, b, l), t.bp = b, t.lp = l;
+        t.dO = dO, t.dh0acc_out = dh0acc;
+        HDF_TRY(tf_token_bwd(d, t, p->dtype, e.st));
+        TfLayerSave s = tf_save(p, e, b, l);
+        HDF_TRY(tf_attention_bwd(d.N, d.M * d.B, s.qkv, s.ob, s.lse, dO, dqkv, e.st));
+        up = cur, gup = gcur, ub = b, ul = l, have_up = true;
+      }
+    }
+    TfTokenBwd t;
+    t.dF = dF, t.pre = &up, t.pre_grad = &gup, t.pre_save = tf_save(p, e, 0, 0), t.bq = 0, t.lq = 0, t.F_pre = F0;
+    t.dqkv = dqkv, t.dh0acc = dh0acc;
+    HDF_TRY(tf_token_bwd(d, t, p->dtype, e.st));
+    HDF_TRY(tf_patch_embed_bwd(d, x, p->D, p->H, p->W, dF, e.grads + p->P("attns.0.patch_embeddings.weight"),
+                               e.grads + p->P("attns.0.patch_embeddings.bias"),
+                               e.grads + p->P("attns.0.position_embeddings"), scratch, e.st));
+    return HDF_OK;
+  }
   for (int b = p->nb - 1; b >= 0; b--) {
     float* F = F0 + (int64_t)b * rows * p->DMF;
     TfOutP o, go;

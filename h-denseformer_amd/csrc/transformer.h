@@ -79,4 +79,31 @@ struct TfTokenFwd {
   const float* F_pre = nullptr;    // feature buffer PRE reads when it runs alone (else next_F / F_post)
 };
 int tf_token_fwd(const TfDims& d, const TfTokenFwd& t, int dtype, hipStream_t st);
+// Backward, in execution order: [PREB: Linear0 / LN1 / to_qkv backward of layer (bq, lq), after its attention backward]
+// -> [OUTB: out_layer backward of block bo] -> [POSTB: ff / ff / to_out backward of layer (bp, lp), before its attention
+// backward].  PREB + POSTB: consecutive layers of one block; PREB + OUTB (+ POSTB): block boundary (lq = 0, bo = bq - 1,
+// POSTB = layer 3 of block bo).  Parameter gradients are accumulated with fp32 atomics.
+struct TfTokenBwd {
+  float* dF = nullptr;              // [rows][DMF] gradient of the (current block's) feature buffer
+  const TfLayerP* pre = nullptr;    // layer (bq, lq)
+  const TfLayerP* pre_grad = nullptr;
+  TfLayerSave pre_save{};
+  int bq = 0, lq = 0;
+  const float* F_pre = nullptr;     // block bq's feature buffer
+  const float* dqkv = nullptr;      // [rows][96] from the attention backward
+  const float* dh0acc = nullptr;    // [rows][32] residual-path gradient left by this layer's POSTB
+  const TfOutP* out = nullptr;      // out_layer of block bo
+  const TfOutP* out_grad = nullptr;
+  int bo = 0;
+  const float* F_out = nullptr;     // block bo's feature buffer
+  const float* dF_next = nullptr;   // OUTB without PREB: gradient of the next block's input (fp32 [rows][DMF]) or
+  const void* d_attnall = nullptr;  // the attnall gradient (storage dtype)
+  const TfLayerP* post = nullptr;   // layer (bp, lp)
+  const TfLayerP* post_grad = nullptr;
+  TfLayerSave post_save{};
+  int bp = 0, lp = 0;
+  float* dO = nullptr;              // [rows][32] -> attention backward of layer (bp, lp)
+  float* dh0acc_out = nullptr;      // [rows][32] -> PREB of layer (bp, lp)
+};
+int tf_token_bwd(const TfDims& d, const TfTokenBwd& t, int dtype, hipStream_t st);
 bool tf_use_fused();  // false under HDF_TF_OLD=1 (A/B knob: the unfused VALU token kernels)

@@ -1138,6 +1138,17 @@ int tf_layer_bwd(const TfDims& d, int block, int layer, const TfLayerP& p, const
   float* dO = scratch;
   float* dh0acc = scratch + rows * 32;
   float* dqkv = scratch + rows * 64;
+  if (tf_use_fused()) {  // one dense layer on its own: POSTB, attention backward, PREB
+    TfTokenBwd post;
+    post.dF = dF, post.post = &p, post.post_grad = &g, post.post_save = s, post.bp = block, post.lp = layer;
+    post.dO = dO, post.dh0acc_out = dh0acc;
+    HDF_TRY(tf_token_bwd(d, post, HDF_F32, st));
+    HDF_TRY(tf_attention_bwd(d.N, d.M * d.B, s.qkv, s.ob, s.lse, dO, dqkv, st));
+    TfTokenBwd pre;
+    pre.dF = dF, pre.pre = &p, pre.pre_grad = &g, pre.pre_save = s, pre.bq = block, pre.lq = layer, pre.F_pre = F;
+    pre.dqkv = dqkv, pre.dh0acc = dh0acc;
+    return tf_token_bwd(d, pre, HDF_F32, st);
+  }
   dim3 grid(ceil_div(BN, TB), d.M);
   hipLaunchKernelGGL(dense_post_bwd_kernel, grid, dim3(256), 0, st, d, block, layer, p, g, s.h1, s.h2, s.ob, dF, dO,
                      dh0acc);
@@ -1173,6 +1184,11 @@ int tf_block_out_fwd(const TfDims& d, int block, const TfOutP& p, const float* F
 
 int tf_block_out_bwd(const TfDims& d, int block, const TfOutP& p, const TfOutP& g, const float* F,
                      const float* dF_next, const void* d_attnall, int dtype, float* dF, hipStream_t st) {
+  if (tf_use_fused()) {
+    TfTokenBwd o;
+    o.dF = dF, o.out = &p, o.out_grad = &g, o.bo = block, o.F_out = F, o.dF_next = dF_next, o.d_attnall = d_attnall;
+    return tf_token_bwd(d, o, dtype, st);
+  }
   dim3 grid(ceil_div(d.B * d.N, TB), d.M);
   size_t base = (size_t)(TB * d.DMF + TB * 64 * 2 + TB * d.DM + 64 * (d.DMF + 1)) * sizeof(float);
   size_t with_wb = base + (size_t)d.DM * 65 * sizeof(float);

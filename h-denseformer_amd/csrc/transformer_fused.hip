@@ -343,6 +343,448 @@ __global__ __launch_bounds__(256) void tok_fwd_kernel(TokFwd a) {
   }
 }
 
+// ================================================================================================ backward
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+// Data-gradient GEMMs contract over the OUTPUT index of a Linear: dX[16][I] = dY[16][O] * W[O][I].  The B operand of
+// lane (n = lane & 15, g = lane >> 4) is then W[o][n0 + n] for the o range of lane group g -- one scalar per step,
+// 16 lanes reading 64 contiguous bytes.  NS scalars per lane, requested at kernel entry like the row fragments.
+template <int NS>
+struct CFrag {
+  float v[NS];
+};
+// rows [g*OQ + s0, .. + ns) of W[.][ldw], column n0 + (lane & 15) (clamped to ncols - 1)
+template <int NS>
+__device__ __forceinline__ void cload(CFrag<NS>& f, const float* __restrict__ W, int ldw, int n0, int ncols, int OQ,
+                                      int s0, int ns) {
+  const int lane = threadIdx.x & 63;
+  const float* p = W + (int64_t)((lane >> 4) * OQ + s0) * ldw + min(n0 + (lane & 15), ncols - 1);
+#pragma unroll
+  for (int s = 0; s < NS; s++) f.v[s] = p[(int64_t)(s < ns ? s : 0) * ldw];
+}
+// acc += dY[16][.] * W over this lane group's o range; sA = dY tile in LDS (pitch lda), ns % 4 == 0
+template <int NS>
+__device__ __forceinline__ void cmma(f32x4& acc, const CFrag<NS>& f, const float* sA, int lda, int OQ, int s0, int ns) {
+  const int lane = threadIdx.x & 63;
+  const float4* pa = reinterpret_cast<const float4*>(sA + (lane & 15) * lda + (lane >> 4) * OQ + s0);
+#pragma unroll
+  for (int j = 0; j < NS / 4; j++) {
+    if (4 * j < ns) {
+      const float4 a = pa[j];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, f.v[4 * j + 0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, f.v[4 * j + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, f.v[4 * j + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, f.v[4 * j + 3], acc, 0, 0, 0);
+    }
+  }
+}
+// the same with the weights fetched on the spot (block out-layer: wide, six launches per step)
+__device__ __forceinline__ void cmma_stream(f32x4& acc, const float* __restrict__ W, int ldw, int n0, int ncols,
+                                            const float* sA, int lda, int OQ) {
+  const int lane = threadIdx.x & 63;
+  const float* pw = W + (int64_t)((lane >> 4) * OQ) * ldw + min(n0 + (lane & 15), ncols - 1);
+  const float4* pa = reinterpret_cast<const float4*>(sA + (lane & 15) * lda + (lane >> 4) * OQ);
+  for (int c = 0; c < OQ; c += 8) {
+    float w[8];
+#pragma unroll
+    for (int s = 0; s < 8; s++) w[s] = pw[(int64_t)min(c + s, OQ - 1) * ldw];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      if (c + 4 * j < OQ) {
+        const float4 a = pa[(c >> 2) + j];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w[4 * j + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w[4 * j + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w[4 * j + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w[4 * j + 3], acc, 0, 0, 0);
+      }
+    }
+  }
+}
+// Weight gradient of a Linear: gW[o][i] += sum over the tile's 16 tokens of dY[t][o] * X[t][i], all [O/16] x [I/16]
+// tiles of it spread over the 4 waves.  The contraction runs over tokens (t = 4g + s at step s), both operands come
+// from LDS rows (conflict-free: every pitch here is 4 mod 64 words or 36), the 16 x 16 result goes out with fp32 atomics
+// (lane: 4 rows x 1 column, 16 lanes = 64 contiguous bytes).
+__device__ __forceinline__ void wgrad_tiles(float* __restrict__ gW, int O, int I, const float* sY, int ldy,
+                                            const float* sX, int ldx, int wrot = 0) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+  const int ti = I >> 4, nt = (O >> 4) * ti;
+  for (int tile = (wave + wrot) & 3; tile < nt; tile += 4) {
+    const int to = tile / ti, o0 = to * 16, i0 = (tile - to * ti) * 16;
+    const float* py = sY + 4 * g * ldy + o0 + n;
+    const float* px = sX + 4 * g * ldx + i0 + n;
+    f32x4 acc = zero4();
+#pragma unroll
+    for (int s2 = 0; s2 < 4; s2++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(py[s2 * ldy], px[s2 * ldx], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; r++) atomicAdd(gW + (int64_t)(o0 + 4 * g + r) * I + i0 + n, acc[r]);
+  }
+}
+// gb[c] += sum over the 16 token rows of s[row][c]  (threads [tbase, tbase + width))
+__device__ __forceinline__ void colsum_atomic(float* __restrict__ gb, int width, const float* sv, int ld, int tbase) {
+  const int c = (int)threadIdx.x - tbase;
+  if (c >= 0 && c < width) {
+    float a = 0.f;
+#pragma unroll
+    for (int r = 0; r < TT; r++) a += sv[r * ld + c];
+    atomicAdd(gb + c, a);
+  }
+}
+// LayerNorm(32) forward pieces kept for its backward: u = xh*gamma + beta -> sU ; xh -> sXh ; rstd -> return value
+__device__ __forceinline__ float ln32_keep(const float* sIn, float* sU, float* sXh, const float* __restrict__ gam,
+                                           const float* __restrict__ bet) {
+  const int row = threadIdx.x >> 4, c = (threadIdx.x & 15) * 2;
+  const float v0 = sIn[row * LD32 + c], v1 = sIn[row * LD32 + c + 1];
+  float s = v0 + v1;
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mean = s * (1.f / 32.f);
+  const float d0 = v0 - mean, d1 = v1 - mean;
+  float q = d0 * d0 + d1 * d1;
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  const float rstd = rsqrtf(q * (1.f / 32.f) + 1e-5f);
+  sXh[row * LD32 + c] = d0 * rstd, sXh[row * LD32 + c + 1] = d1 * rstd;
+  sU[row * LD32 + c] = d0 * rstd * gam[c] + bet[c];
+  sU[row * LD32 + c + 1] = d1 * rstd * gam[c + 1] + bet[c + 1];
+  return rstd;
+}
+// LayerNorm backward of this thread's two columns: du (gradient w.r.t. the LN output) -> dh; the products du*xh are left
+// in sGx (for the gamma gradient column sums; du itself stays in sDu for beta)
+__device__ __forceinline__ void ln32_bwd(const float* sDu, const float* sXh, float* sGx, float rstd,
+                                         const float* __restrict__ gam, float& dh0, float& dh1) {
+  const int row = threadIdx.x >> 4, c = (threadIdx.x & 15) * 2;
+  const float u0 = sDu[row * LD32 + c], u1 = sDu[row * LD32 + c + 1];
+  const float x0 = sXh[row * LD32 + c], x1 = sXh[row * LD32 + c + 1];
+  sGx[row * LD32 + c] = u0 * x0, sGx[row * LD32 + c + 1] = u1 * x1;
+  const float a0 = u0 * gam[c], a1 = u1 * gam[c + 1];
+  float s1 = a0 + a1, s2 = a0 * x0 + a1 * x1;
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) s1 += __shfl_xor(s1, o, 64), s2 += __shfl_xor(s2, o, 64);
+  const float m1 = s1 * (1.f / 32.f), m2 = s2 * (1.f / 32.f);
+  dh0 = rstd * (a0 - m1 - x0 * m2);
+  dh1 = rstd * (a1 - m1 - x1 * m2);
+}
+
+struct TokBwd {
+  TfDims d;
+  // PREB: layer lq of block bq (after its attention backward)
+  TfLayerP pq, gq;
+  int bq, lq;
+  const float* Fq;       // block bq's feature buffer
+  const float* h0;       // saved
+  const float* dqkv;     // from the attention backward
+  const float* dh0acc;   // residual-path gradient left by this layer's POSTB
+  float* dF;             // [rows][DMF] gradient of the feature buffer (shared by all blocks)
+  // OUTB: out_layer of block bo
+  TfOutP po, go;
+  int bo;
+  const float* Fo;       // block bo's feature buffer
+  const float* dF_next;  // gradient of the next block's input (fp32, pitch DMF) when OUTB runs without PREB, or
+  const void* d_attnall; // the attnall gradient (storage dtype) for the last block
+  // POSTB: layer lp of block bp
+  TfLayerP pp, gp;
+  int bp, lp;
+  const float* h1s;
+  const float* h2s;
+  const float* ob;
+  float* dO;             // -> attention backward of layer lp
+  float* dh0acc_out;     // -> PREB of layer lp
+};
+
+template <bool PREB, bool OUTB, bool POSTB, typename T>
+__global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwd a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const TfDims& d = a.d;
+  const int DM = d.DM, DMF = d.DMF, ldF = DMF + 4, ldD = DM + 4;
+  float* s_F = sm;                      // [16][ldF]  feature rows (PREB: block bq; OUTB: block bo)
+  float* s_do = s_F + TT * ldF;         // [16][ldD]  OUTB: masked gradient of the out_layer output
+  float* s_dq = s_do + TT * ldD;        // [16][100]  PREB: dqkv tile
+  float* s_a = s_dq + TT * 100;         // [16][36] x 6 small tiles
+  float* s_b = s_a + TT * LD32;
+  float* s_c = s_b + TT * LD32;
+  float* s_e = s_c + TT * LD32;
+  float* s_dg = s_e + TT * LD32;        // gradient of the feature column handed from PREB / OUTB to POSTB
+  float* s_gx = s_dg + TT * LD32;
+  float* s_f = s_gx + TT * LD32;        // [16][68]
+  float* s_dz = s_f + TT * LD64;        // [16][68]
+  float* s_red = s_dz + TT * LD64;      // [2][16][16]
+  const int m = blockIdx.y, BN = d.B * d.N, t0 = blockIdx.x * TT;
+  const int64_t mo = (int64_t)m * d.mstride, rb = (int64_t)m * BN;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, col = lane & 15, g = lane >> 4;
+  const int lrow = threadIdx.x >> 4, lc = (threadIdx.x & 15) * 2;   // the "LayerNorm" thread map: row, 2 columns
+  const DropF dr{d.training, d.seed, d.thresh24, d.keep_scale};
+  auto tok = [&](int row) { return min(t0 + row, BN - 1); };
+
+  // ------------------------------------------------------------------ requests issued at kernel entry
+  const int Kq = PREB ? DM + 32 * a.lq : 0;
+  CFrag<12> c_q;            // dt = dqkv * Wqkv: tile wave & 1, o half wave >> 1 (24 of 96 / 4 ... 12 per half)
+  CFrag<8> c_w0[6];         // dF += dh0 * W0: tiles wave + 4j (Kq <= 352: 22 tiles)
+  WFrag<2> f_w1;            // POSTB: ff net.0 rows (recompute)
+  CFrag<8> c_w2, c_w1;      // df = dg * W2 (tile wave) ; du = dz * W1 (tile wave & 1, o half wave >> 1)
+  CFrag<4> c_wo;            // dO = dgo * Wout (tile wave & 1, o half)
+  if (PREB) {
+    cload(c_q, a.pq.wqkv + mo, 32, 16 * (wave & 1), 32, 24, 12 * (wave >> 1), 12);
+#pragma unroll
+    for (int j = 0; j < 6; j++) cload(c_w0[j], a.pq.w0 + mo, Kq, 16 * (wave + 4 * j), Kq, 8, 0, 8);
+  }
+  if (POSTB) {
+    wload(f_w1, a.pp.w1 + mo, 32, 16 * wave, 8, 0, 2);
+    cload(c_w2, a.pp.w2 + mo, 64, 16 * wave, 64, 8, 0, 8);
+    cload(c_w1, a.pp.w1 + mo, 32, 16 * (wave & 1), 32, 16, 8 * (wave >> 1), 8);
+    cload(c_wo, a.pp.wout + mo, 32, 16 * (wave & 1), 32, 8, 4 * (wave >> 1), 4);
+  }
+  if (PREB) {
+    for (int i = threadIdx.x; i < TT * 24; i += 256) {      // dqkv tile (zero rows beyond BN)
+      const int row = i / 24, c4 = (i - row * 24) * 4;
+      float4 v = *reinterpret_cast<const float4*>(a.dqkv + (rb + tok(row)) * 96 + c4);
+      if (t0 + row >= BN) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(s_dq + row * 100 + c4) = v;
+    }
+    const int c4n = Kq >> 2;
+    for (int i = threadIdx.x; i < TT * c4n; i += 256) {     // feature rows [0, Kq)
+      const int row = i / c4n, c4 = (i - row * c4n) * 4;
+      *reinterpret_cast<float4*>(s_F + row * ldF + c4) =
+          *reinterpret_cast<const float4*>(a.Fq + (rb + tok(row)) * DMF + c4);
+    }
+    s_a[lrow * LD32 + lc] = a.h0[(rb + tok(lrow)) * 32 + lc];
+    s_a[lrow * LD32 + lc + 1] = a.h0[(rb + tok(lrow)) * 32 + lc + 1];
+  }
+  __syncthreads();
+
+  // ------------------------------------------------------------------ PREB(lq)
+  if (PREB) {
+    // t = LN1(h0) -> s_b, xh -> s_c
+    const float rs1 = ln32_keep(s_a, s_b, s_c, a.pq.ln1g + mo, a.pq.ln1b + mo);
+    __syncthreads();
+    wgrad_tiles(a.gq.wqkv + mo, 96, 32, s_dq, 100, s_b, LD32);
+    {  // dt = dqkv * Wqkv -> s_e
+      f32x4 acc = zero4();
+      cmma(acc, c_q, s_dq, 100, 24, 12 * (wave >> 1), 12);
+      if (wave >= 2) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) s_red[((wave & 1) * 16 + 4 * g + r) * 16 + col] = acc[r];
+      }
+      __syncthreads();
+      if (wave < 2) {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          s_e[(4 * g + r) * LD32 + 16 * wave + col] = acc[r] + s_red[(wave * 16 + 4 * g + r) * 16 + col];
+      }
+    }
+    __syncthreads();
+    {  // LN1 backward + the residual-path gradient -> dh0 (s_a)
+      float dh0v, dh1v;
+      ln32_bwd(s_e, s_c, s_gx, rs1, a.pq.ln1g + mo, dh0v, dh1v);
+      const int t = t0 + lrow;
+      const bool ok = t < BN;
+      const float r0 = ok ? a.dh0acc[(rb + t) * 32 + lc] : 0.f, r1 = ok ? a.dh0acc[(rb + t) * 32 + lc + 1] : 0.f;
+      s_a[lrow * LD32 + lc] = ok ? dh0v + r0 : 0.f;
+      s_a[lrow * LD32 + lc + 1] = ok ? dh1v + r1 : 0.f;
+    }
+    __syncthreads();
+    colsum_atomic(a.gq.ln1g + mo, 32, s_gx, LD32, 0);
+    colsum_atomic(a.gq.ln1b + mo, 32, s_e, LD32, 64);
+    colsum_atomic(a.gq.b0 + mo, 32, s_a, LD32, 128);
+    wgrad_tiles(a.gq.w0 + mo, 32, Kq, s_a, LD32, s_F, ldF, 2);
+    // dF[:, 0:Kq] += dh0 * W0 ; the last 32 columns are the complete gradient of feature lq - 1 (POSTB), the first DM
+    // ones at lq = 0 the gradient of the block input (OUTB of the previous block)
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      const int n0 = 16 * (wave + 4 * j);
+      if (n0 < Kq) {
+        f32x4 acc = zero4();
+        cmma(acc, c_w0[j], s_a, LD32, 8, 0, 8);
+        const int c = n0 + col;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int row = 4 * g + r, t = t0 + row;
+          const bool ok = t < BN;
+          float* q = a.dF + (rb + tok(row)) * DMF + c;
+          const float v = ok ? *q + acc[r] : 0.f;
+          if (OUTB) {
+            s_do[row * ldD + c] = v;          // (lq = 0: Kq = DM) consumed below, not written back
+          } else {
+            if (ok) *q = v;
+            if (POSTB && c >= Kq - 32) s_dg[row * LD32 + c - (Kq - 32)] = v;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ------------------------------------------------------------------ OUTB(bo)
+  if (OUTB) {
+    const uint32_t siteo = hdf_site_id(m, a.bo, 4, 0);
+    {  // feature rows of block bo; the upstream gradient (masked by the out_layer's second dropout)
+      const int c4n = DMF >> 2;
+      for (int i = threadIdx.x; i < TT * c4n; i += 256) {
+        const int row = i / c4n, c4 = (i - row * c4n) * 4;
+        *reinterpret_cast<float4*>(s_F + row * ldF + c4) =
+            *reinterpret_cast<const float4*>(a.Fo + (rb + tok(row)) * DMF + c4);
+      }
+      for (int i = threadIdx.x; i < TT * DM; i += 256) {
+        const int row = i / DM, c = i - row * DM, t = t0 + row;
+        float v;
+        if (PREB)
+          v = s_do[row * ldD + c];
+        else if (a.dF_next)
+          v = a.dF_next[(rb + tok(row)) * DMF + c];
+        else {
+          const int tt = tok(row), b = tt / d.N, n = tt - b * d.N;
+          v = ST<T>::ld(reinterpret_cast<const T*>(a.d_attnall) + ((int64_t)b * d.N + n) * ((int64_t)d.M * DM) +
+                        (int64_t)m * DM + c);
+        }
+        s_do[row * ldD + c] = t < BN ? v * dr.mask(siteo + 1, (uint32_t)t * DM + c) : 0.f;
+      }
+    }
+    __syncthreads();
+    float zr[4], mk[4];
+    {  // z = Wa F + ba (recomputed), f = gelu(z) * mask -> s_f
+      f32x4 acc = zero4();
+      wmma_stream(acc, a.po.wa + mo, DMF, 16 * wave, s_F, ldF, DMF >> 2);
+      const int c = 16 * wave + col;
+      const float ba = a.po.ba[mo + c];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = 4 * g + r, t = t0 + row;
+        zr[r] = acc[r] + ba;
+        mk[r] = dr.mask(siteo + 0, (uint32_t)t * 64 + c);
+        s_f[row * LD64 + c] = t < BN ? gelu_f(zr[r]) * mk[r] : 0.f;
+      }
+    }
+    {  // df = do * Wb ; dz = df * mask * gelu'(z) -> s_dz
+      f32x4 acc = zero4();
+      cmma_stream(acc, a.po.wb + mo, 64, 16 * wave, 64, s_do, ldD, DM >> 2);
+      const int c = 16 * wave + col;
+#pragma unroll
+      for (int r = 0; r < 4; r++) s_dz[(4 * g + r) * LD64 + c] = acc[r] * mk[r] * gelu_grad_f(zr[r]);
+    }
+    __syncthreads();
+    wgrad_tiles(a.go.wb + mo, DM, 64, s_do, ldD, s_f, LD64);
+    wgrad_tiles(a.go.wa + mo, 64, DMF, s_dz, LD64, s_F, ldF, 1);
+    for (int c0 = 0; c0 < DM; c0 += 128) colsum_atomic(a.go.bb + mo + c0, min(128, DM - c0), s_do + c0, ldD, 0);
+    colsum_atomic(a.go.ba + mo, 64, s_dz, LD64, 128);
+    // dF[:, 0:DMF] = dz * Wa  (overwrites: the first writer of block bo's feature gradient)
+    for (int n0 = 16 * wave; n0 < DMF; n0 += 64) {
+      f32x4 acc = zero4();
+      cmma_stream(acc, a.po.wa + mo, DMF, n0, DMF, s_dz, LD64, 16);
+      const int c = n0 + col;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = 4 * g + r, t = t0 + row;
+        if (t < BN) a.dF[(rb + t) * DMF + c] = acc[r];
+        if (POSTB && c >= DMF - 32) s_dg[row * LD32 + c - (DMF - 32)] = t < BN ? acc[r] : 0.f;
+      }
+    }
+    __syncthreads();
+  }
+
+  // ------------------------------------------------------------------ POSTB(lp)
+  if (POSTB) {
+    const uint32_t site0 = hdf_site_id(m, a.bp, a.lp, 0);
+    const int t = t0 + lrow;
+    const bool ok = t < BN;
+    if (!PREB && !OUTB) {  // stand-alone: the feature gradient comes from memory
+      const int fc = DM + 32 * a.lp;
+      s_dg[lrow * LD32 + lc] = ok ? a.dF[(rb + t) * DMF + fc + lc] : 0.f;
+      s_dg[lrow * LD32 + lc + 1] = ok ? a.dF[(rb + t) * DMF + fc + lc + 1] : 0.f;
+      __syncthreads();
+    }
+    float dcur0 = s_dg[lrow * LD32 + lc], dcur1 = s_dg[lrow * LD32 + lc + 1];  // gradient into the current ff's output
+    float dres0 = 0.f, dres1 = 0.f;
+#pragma unroll
+    for (int pass = 1; pass >= 0; pass--) {  // pass 1: the second ff (on h2) ; pass 0: the first ff (on h1)
+      const float* hs = pass ? a.h2s : a.h1s;
+      __syncthreads();
+      s_a[lrow * LD32 + lc] = hs[(rb + tok(lrow)) * 32 + lc];
+      s_a[lrow * LD32 + lc + 1] = hs[(rb + tok(lrow)) * 32 + lc + 1];
+      // the 16 lanes of a token row sit in one wave and read only what they wrote: no barrier needed before the LN
+      const float rs = ln32_keep(s_a, s_b, s_c, a.pp.ln2g + mo, a.pp.ln2b + mo);   // u -> s_b, xh -> s_c
+      s_dg[lrow * LD32 + lc] = ok ? dcur0 * dr.mask(site0 + 2 + 2 * pass, (uint32_t)t * 32 + lc) : 0.f;
+      s_dg[lrow * LD32 + lc + 1] = ok ? dcur1 * dr.mask(site0 + 2 + 2 * pass, (uint32_t)t * 32 + lc + 1) : 0.f;
+      __syncthreads();
+      {
+        f32x4 accz = zero4(), accd = zero4();
+        wmma(accz, f_w1, s_b, LD32, 8, 0, 2);            // z = W1 u  (tile wave)
+        cmma(accd, c_w2, s_dg, LD32, 8, 0, 8);           // df = dg * W2 (tile wave)
+        const int c = 16 * wave + col;
+        const float b1 = a.pp.b1[mo + c];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int row = 4 * g + r, tt = t0 + row;
+          const float z = accz[r] + b1, mkv = dr.mask(site0 + 1 + 2 * pass, (uint32_t)tt * 64 + c);
+          s_f[row * LD64 + c] = tt < BN ? gelu_f(z) * mkv : 0.f;
+          s_dz[row * LD64 + c] = tt < BN ? accd[r] * mkv * gelu_grad_f(z) : 0.f;
+        }
+      }
+      __syncthreads();
+      wgrad_tiles(a.gp.w2 + mo, 32, 64, s_dg, LD32, s_f, LD64);
+      wgrad_tiles(a.gp.w1 + mo, 64, 32, s_dz, LD64, s_b, LD32, 2);
+      colsum_atomic(a.gp.b2 + mo, 32, s_dg, LD32, 0);
+      colsum_atomic(a.gp.b1 + mo, 64, s_dz, LD64, 64);
+      {  // du = dz * W1 -> s_e
+        f32x4 acc = zero4();
+        cmma(acc, c_w1, s_dz, LD64, 16, 8 * (wave >> 1), 8);
+        if (wave >= 2) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) s_red[((wave & 1) * 16 + 4 * g + r) * 16 + col] = acc[r];
+        }
+        __syncthreads();
+        if (wave < 2) {
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            s_e[(4 * g + r) * LD32 + 16 * wave + col] = acc[r] + s_red[(wave * 16 + 4 * g + r) * 16 + col];
+        }
+      }
+      __syncthreads();
+      float dh0v, dh1v;
+      ln32_bwd(s_e, s_c, s_gx, rs, a.pp.ln2g + mo, dh0v, dh1v);
+      dh0v = ok ? dh0v : 0.f, dh1v = ok ? dh1v : 0.f;
+      __syncthreads();
+      colsum_atomic(a.gp.ln2g + mo, 32, s_gx, LD32, 0);
+      colsum_atomic(a.gp.ln2b + mo, 32, s_e, LD32, 64);
+      if (pass == 1) {
+        dcur0 = dh0v, dcur1 = dh1v;   // h2 feeds only the second ff: its gradient flows into ff#1's output ...
+        dres0 = dh0v, dres1 = dh1v;   // ... and into the residual h1
+      } else {
+        dres0 += dh0v, dres1 += dh1v;
+      }
+    }
+    // to_out: a = (Wout ob + bout) * mask ; h1 = a + h0
+    __syncthreads();
+    s_dg[lrow * LD32 + lc] = ok ? dres0 * dr.mask(site0 + 0, (uint32_t)t * 32 + lc) : 0.f;
+    s_dg[lrow * LD32 + lc + 1] = ok ? dres1 * dr.mask(site0 + 0, (uint32_t)t * 32 + lc + 1) : 0.f;
+    s_b[lrow * LD32 + lc] = a.ob[(rb + tok(lrow)) * 32 + lc];
+    s_b[lrow * LD32 + lc + 1] = a.ob[(rb + tok(lrow)) * 32 + lc + 1];
+    if (ok) {
+      a.dh0acc_out[(rb + t) * 32 + lc] = dres0;
+      a.dh0acc_out[(rb + t) * 32 + lc + 1] = dres1;
+    }
+    __syncthreads();
+    wgrad_tiles(a.gp.wout + mo, 32, 32, s_dg, LD32, s_b, LD32);
+    colsum_atomic(a.gp.bout + mo, 32, s_dg, LD32, 0);
+    {
+      f32x4 acc = zero4();
+      cmma(acc, c_wo, s_dg, LD32, 8, 4 * (wave >> 1), 4);
+      if (wave >= 2) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) s_red[((wave & 1) * 16 + 4 * g + r) * 16 + col] = acc[r];
+      }
+      __syncthreads();
+      if (wave < 2) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int tt = t0 + 4 * g + r;
+          if (tt < BN) a.dO[(rb + tt) * 32 + 16 * wave + col] = acc[r] + s_red[(wave * 16 + 4 * g + r) * 16 + col];
+        }
+      }
+    }
+  }
+}
+
 template <typename Kern>
 int allow_lds_f(Kern kern, size_t bytes) {
   if (bytes <= 64 * 1024) return HDF_OK;
@@ -366,7 +808,59 @@ int launch_tok_fwd(const TokFwd& a, hipStream_t st) {
   return HDF_OK;
 }
 
+template <bool PREB, bool OUTB, bool POSTB, typename T>
+int launch_tok_bwd(const TokBwd& a, hipStream_t st) {
+  const TfDims& d = a.d;
+  dim3 grid(ceil_div(d.B * d.N, TT), d.M);
+  const size_t shm = (size_t)(TT * (d.DMF + 4) + TT * (d.DM + 4) + TT * 100 + 7 * TT * LD32 + 2 * TT * LD64 + 2 * 16 * 16) *
+                     sizeof(float);
+  HDF_TRY(allow_lds_f(tok_bwd_kernel<PREB, OUTB, POSTB, T>, shm));
+  hipLaunchKernelGGL((tok_bwd_kernel<PREB, OUTB, POSTB, T>), grid, dim3(256), shm, st, a);
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
 }  // namespace
+
+int tf_token_bwd(const TfDims& d, const TfTokenBwd& t, int dtype, hipStream_t st) {
+  HDF_CHECK_ARG(d.DM % 32 == 0 && d.DM >= 32 && d.DM <= 256, "token kernel: token dim %d unsupported", d.DM);
+  TokBwd a{};
+  a.d = d;
+  a.dF = t.dF;
+  if (t.pre) {
+    a.pq = *t.pre, a.gq = *t.pre_grad, a.bq = t.bq, a.lq = t.lq;
+    a.Fq = t.F_pre, a.h0 = t.pre_save.h0, a.dqkv = t.dqkv, a.dh0acc = t.dh0acc;
+  }
+  if (t.out) {
+    a.po = *t.out, a.go = *t.out_grad, a.bo = t.bo;
+    a.Fo = t.F_out, a.dF_next = t.dF_next, a.d_attnall = t.d_attnall;
+  }
+  if (t.post) {
+    a.pp = *t.post, a.gp = *t.post_grad, a.bp = t.bp, a.lp = t.lp;
+    a.h1s = t.post_save.h1, a.h2s = t.post_save.h2, a.ob = t.post_save.ob;
+    a.dO = t.dO, a.dh0acc_out = t.dh0acc_out;
+  }
+  const bool Q = t.pre != nullptr, O = t.out != nullptr, P = t.post != nullptr;
+  HDF_CHECK_ARG(!(Q && O) || t.lq == 0, "token kernel: PREB + OUTB only at a block boundary (layer 0)");
+  HDF_CHECK_ARG(!(Q && P) || O || (t.bp == t.bq && t.lp == t.lq - 1), "token kernel: PREB + POSTB must be consecutive layers");
+#define TOKB_CASE(QQ, OO, PP)                                                  \
+  if (Q == QQ && O == OO && P == PP) {                                         \
+    if constexpr (OO && !QQ) {                                                 \
+      if (!t.dF_next) HDF_DISPATCH_T(dtype, return (launch_tok_bwd<QQ, OO, PP, T>(a, st))); \
+    }                                                                          \
+    return launch_tok_bwd<QQ, OO, PP, float>(a, st);                           \
+  }
+  TOKB_CASE(true, false, false)
+  TOKB_CASE(false, false, true)
+  TOKB_CASE(true, false, true)
+  TOKB_CASE(true, true, true)
+  TOKB_CASE(false, true, true)
+  TOKB_CASE(false, true, false)
+  TOKB_CASE(true, true, false)
+#undef TOKB_CASE
+  hdf_set_error("token kernel: empty stage selection");
+  return HDF_ERR_ARG;
+}
 
 // post: finish dense layer (bp, lp) [null layer pointers: none]; out: block bp's out_layer; pre: start layer (bq, lq)
 int tf_token_fwd(const TfDims& d, const TfTokenFwd& t, int dtype, hipStream_t st) {
