@@ -99,8 +99,16 @@ __device__ __forceinline__ void wmma_stream(f32x4& acc, const float* __restrict_
 }
 
 // LayerNorm(32) of the 16 token rows of sIn (pitch LD32) -> sOut; 16 lanes per token, 2 columns per lane
-__device__ __forceinline__ void ln32(const float* sIn, float* sOut, const float* __restrict__ gam,
-                                     const float* __restrict__ bet) {
+// small per-column parameters of a stage, requested at kernel entry (a load at its point of use would expose one
+// memory round trip per stage: the stages themselves are a few hundred cycles long)
+struct LnP {
+  float g0, g1, b0, b1;
+};
+__device__ __forceinline__ LnP ln_load(const float* __restrict__ gam, const float* __restrict__ bet) {
+  const int c = (threadIdx.x & 15) * 2;
+  return LnP{gam[c], gam[c + 1], bet[c], bet[c + 1]};
+}
+__device__ __forceinline__ void ln32(const float* sIn, float* sOut, const LnP& p) {
   const int row = threadIdx.x >> 4, c = (threadIdx.x & 15) * 2;
   const float v0 = sIn[row * LD32 + c], v1 = sIn[row * LD32 + c + 1];
   float s = v0 + v1;
@@ -112,8 +120,8 @@ __device__ __forceinline__ void ln32(const float* sIn, float* sOut, const float*
 #pragma unroll
   for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
   const float rstd = rsqrtf(q * (1.f / 32.f) + 1e-5f);
-  sOut[row * LD32 + c] = d0 * rstd * gam[c] + bet[c];
-  sOut[row * LD32 + c + 1] = d1 * rstd * gam[c + 1] + bet[c + 1];
+  sOut[row * LD32 + c] = d0 * rstd * p.g0 + p.b0;
+  sOut[row * LD32 + c + 1] = d1 * rstd * p.g1 + p.b1;
 }
 
 struct TokFwd {
@@ -161,6 +169,9 @@ __global__ __launch_bounds__(256) void tok_fwd_kernel(TokFwd a) {
   WFrag<11> f_w0;          // Linear0 [32][Kq], split in two k halves over wave pairs: <= 44 floats per lane (Kq <= 352)
   WFrag<2> f_q0, f_q1;     // to_qkv [96][32]: tiles wave and wave + 4
   float h0r[4];
+  float p_bout = 0.f, p_b1 = 0.f, p_b2 = 0.f, p_b0 = 0.f;
+  LnP ln2{}, ln1{};
+  const int cw = 16 * (wave & 1) + col, c4w = 16 * wave + col;   // this lane's column in a 2-tile / 4-tile product
   if (POST) {
     if (wave < 2) {
       wload(f_wo, a.pp.wout + mo, 32, 16 * wave, 8, 0, 2);
@@ -169,11 +180,15 @@ __global__ __launch_bounds__(256) void tok_fwd_kernel(TokFwd a) {
       for (int r = 0; r < 4; r++) h0r[r] = a.h0_in[(rb + tok(4 * g + r)) * 32 + 16 * wave + col];
     }
     wload(f_w1, a.pp.w1 + mo, 32, 16 * wave, 8, 0, 2);
+    p_bout = a.pp.bout[mo + cw], p_b2 = a.pp.b2[mo + cw], p_b1 = a.pp.b1[mo + c4w];
+    ln2 = ln_load(a.pp.ln2g + mo, a.pp.ln2b + mo);
   }
   if (PRE) {
     wload(f_w0, a.pq.w0 + mo, Kq, 16 * (wave & 1), Kq >> 2, (wave >> 1) * (Kq >> 3), Kq >> 5);
     wload(f_q0, a.pq.wqkv + mo, 32, 16 * wave, 8, 0, 2);
     if (wave < 2) wload(f_q1, a.pq.wqkv + mo, 32, 16 * (wave + 4), 8, 0, 2);
+    p_b0 = a.pq.b0[mo + cw];
+    ln1 = ln_load(a.pq.ln1g + mo, a.pq.ln1b + mo);
   }
   // token rows -> LDS.  POST: ob; the feature rows the later stages contract over (the columns written by this kernel
   // are filled in from registers)
@@ -210,7 +225,7 @@ __global__ __launch_bounds__(256) void tok_fwd_kernel(TokFwd a) {
       f32x4 acc = zero4();
       wmma(acc, f_wo, s_x, LD32, 8, 0, 2);
       const int c = 16 * wave + col;
-      const float bo = a.pp.bout[mo + c];
+      const float bo = p_bout;
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int row = 4 * g + r, t = t0 + row;
@@ -223,13 +238,13 @@ __global__ __launch_bounds__(256) void tok_fwd_kernel(TokFwd a) {
     __syncthreads();
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {  // pass 0: h2 = ff(LN2(h1)) + h1 ; pass 1: feature = ff(LN2(h2))
-      ln32(s_h, s_x, a.pp.ln2g + mo, a.pp.ln2b + mo);
+      ln32(s_h, s_x, ln2);
       __syncthreads();
       {
         f32x4 acc = zero4();
         wmma(acc, f_w1, s_x, LD32, 8, 0, 2);
         const int c = 16 * wave + col;
-        const float b1 = a.pp.b1[mo + c];
+        const float b1 = p_b1;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const int row = 4 * g + r, t = t0 + row;
@@ -241,7 +256,7 @@ __global__ __launch_bounds__(256) void tok_fwd_kernel(TokFwd a) {
         f32x4 acc = zero4();
         wmma(acc, f_w2, s_z, LD64, 16, 0, 4);
         const int c = 16 * wave + col;
-        const float b2 = a.pp.b2[mo + c];
+        const float b2 = p_b2;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const int row = 4 * g + r, t = t0 + row;
@@ -309,7 +324,7 @@ __global__ __launch_bounds__(256) void tok_fwd_kernel(TokFwd a) {
       __syncthreads();
       if (wave < 2) {
         const int c = 16 * wave + col;
-        const float b0 = a.pq.b0[mo + c];
+        const float b0 = p_b0;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const int row = 4 * g + r, t = t0 + row;
@@ -320,7 +335,7 @@ __global__ __launch_bounds__(256) void tok_fwd_kernel(TokFwd a) {
       }
     }
     __syncthreads();
-    ln32(s_h, s_x, a.pq.ln1g + mo, a.pq.ln1b + mo);
+    ln32(s_h, s_x, ln1);
     __syncthreads();
     {
       f32x4 acc = zero4();
@@ -406,19 +421,47 @@ __device__ __forceinline__ void cmma_stream(f32x4& acc, const float* __restrict_
 // tiles of it spread over the 4 waves.  The contraction runs over tokens (t = 4g + s at step s), both operands come
 // from LDS rows (conflict-free: every pitch here is 4 mod 64 words or 36), the 16 x 16 result goes out with fp32 atomics
 // (lane: 4 rows x 1 column, 16 lanes = 64 contiguous bytes).
+// attribution builds: -DTF_DBG_NOATOMIC drops the weight-gradient atomics, -DTF_DBG_NOWGRAD the products too (measured on
+// the inner backward kernel at N = 512: 31 us -> 25 us -> 19 us)
+__device__ __forceinline__ void wgrad_emit(float* __restrict__ gW, int I, int o0, int i0, const f32x4& acc) {
+  const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+#ifdef TF_DBG_NOATOMIC
+    if (acc[r] == 12345.678f) gW[0] = acc[r];   // keeps the products alive without the atomics
+#else
+    atomicAdd(gW + (int64_t)(o0 + 4 * g + r) * I + i0 + n, acc[r]);
+#endif
+  }
+}
 __device__ __forceinline__ void wgrad_tiles(float* __restrict__ gW, int O, int I, const float* sY, int ldy,
                                             const float* sX, int ldx, int wrot = 0) {
+#ifdef TF_DBG_NOWGRAD
+  return;
+#endif
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
   const int ti = I >> 4, nt = (O >> 4) * ti;
-  for (int tile = (wave + wrot) & 3; tile < nt; tile += 4) {
+  // two tiles per trip: their 4-step MFMA chains (40 cycles of dependent latency per step) interleave
+  for (int tile = (wave + wrot) & 3; tile < nt; tile += 8) {
+    const int tile2 = tile + 4;
+    const bool two = tile2 < nt;
     const int to = tile / ti, o0 = to * 16, i0 = (tile - to * ti) * 16;
+    const int tq = two ? tile2 / ti : to, o1 = tq * 16, i1 = two ? (tile2 - tq * ti) * 16 : i0;
     const float* py = sY + 4 * g * ldy + o0 + n;
     const float* px = sX + 4 * g * ldx + i0 + n;
-    f32x4 acc = zero4();
+    const float* qy = sY + 4 * g * ldy + o1 + n;
+    const float* qx = sX + 4 * g * ldx + i1 + n;
+    float ya[4], xa[4], yb[4], xb[4];
 #pragma unroll
-    for (int s2 = 0; s2 < 4; s2++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(py[s2 * ldy], px[s2 * ldx], acc, 0, 0, 0);
+    for (int s2 = 0; s2 < 4; s2++) ya[s2] = py[s2 * ldy], xa[s2] = px[s2 * ldx], yb[s2] = qy[s2 * ldy], xb[s2] = qx[s2 * ldx];
+    f32x4 acc = zero4(), acc2 = zero4();
 #pragma unroll
-    for (int r = 0; r < 4; r++) atomicAdd(gW + (int64_t)(o0 + 4 * g + r) * I + i0 + n, acc[r]);
+    for (int s2 = 0; s2 < 4; s2++) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[s2], xa[s2], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(yb[s2], xb[s2], acc2, 0, 0, 0);
+    }
+    wgrad_emit(gW, I, o0, i0, acc);
+    if (two) wgrad_emit(gW, I, o1, i1, acc2);
   }
 }
 // gb[c] += sum over the 16 token rows of s[row][c]  (threads [tbase, tbase + width))
@@ -432,8 +475,7 @@ __device__ __forceinline__ void colsum_atomic(float* __restrict__ gb, int width,
   }
 }
 // LayerNorm(32) forward pieces kept for its backward: u = xh*gamma + beta -> sU ; xh -> sXh ; rstd -> return value
-__device__ __forceinline__ float ln32_keep(const float* sIn, float* sU, float* sXh, const float* __restrict__ gam,
-                                           const float* __restrict__ bet) {
+__device__ __forceinline__ float ln32_keep(const float* sIn, float* sU, float* sXh, const LnP& p) {
   const int row = threadIdx.x >> 4, c = (threadIdx.x & 15) * 2;
   const float v0 = sIn[row * LD32 + c], v1 = sIn[row * LD32 + c + 1];
   float s = v0 + v1;
@@ -446,19 +488,19 @@ __device__ __forceinline__ float ln32_keep(const float* sIn, float* sU, float* s
   for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
   const float rstd = rsqrtf(q * (1.f / 32.f) + 1e-5f);
   sXh[row * LD32 + c] = d0 * rstd, sXh[row * LD32 + c + 1] = d1 * rstd;
-  sU[row * LD32 + c] = d0 * rstd * gam[c] + bet[c];
-  sU[row * LD32 + c + 1] = d1 * rstd * gam[c + 1] + bet[c + 1];
+  sU[row * LD32 + c] = d0 * rstd * p.g0 + p.b0;
+  sU[row * LD32 + c + 1] = d1 * rstd * p.g1 + p.b1;
   return rstd;
 }
 // LayerNorm backward of this thread's two columns: du (gradient w.r.t. the LN output) -> dh; the products du*xh are left
 // in sGx (for the gamma gradient column sums; du itself stays in sDu for beta)
-__device__ __forceinline__ void ln32_bwd(const float* sDu, const float* sXh, float* sGx, float rstd,
-                                         const float* __restrict__ gam, float& dh0, float& dh1) {
+__device__ __forceinline__ void ln32_bwd(const float* sDu, const float* sXh, float* sGx, float rstd, const LnP& p,
+                                         float& dh0, float& dh1) {
   const int row = threadIdx.x >> 4, c = (threadIdx.x & 15) * 2;
   const float u0 = sDu[row * LD32 + c], u1 = sDu[row * LD32 + c + 1];
   const float x0 = sXh[row * LD32 + c], x1 = sXh[row * LD32 + c + 1];
   sGx[row * LD32 + c] = u0 * x0, sGx[row * LD32 + c + 1] = u1 * x1;
-  const float a0 = u0 * gam[c], a1 = u1 * gam[c + 1];
+  const float a0 = u0 * p.g0, a1 = u1 * p.g1;
   float s1 = a0 + a1, s2 = a0 * x0 + a1 * x1;
 #pragma unroll
   for (int o = 8; o > 0; o >>= 1) s1 += __shfl_xor(s1, o, 64), s2 += __shfl_xor(s2, o, 64);
@@ -524,16 +566,32 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwd a) {
   WFrag<2> f_w1;            // POSTB: ff net.0 rows (recompute)
   CFrag<8> c_w2, c_w1;      // df = dg * W2 (tile wave) ; du = dz * W1 (tile wave & 1, o half wave >> 1)
   CFrag<4> c_wo;            // dO = dgo * Wout (tile wave & 1, o half)
+  LnP ln1{}, ln2{};
+  float p_b1 = 0.f, r_acc0 = 0.f, r_acc1 = 0.f, r_h[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, r_ob[2] = {0.f, 0.f};
+  float r_dF[6][4];        // the tile's dF entries this lane read-modify-writes (only this workgroup touches them)
+  const bool lok = t0 + lrow < BN;
+  const int64_t lr = (rb + tok(lrow)) * 32 + lc;   // this thread's two columns of a [rows][32] tensor
   if (PREB) {
     cload(c_q, a.pq.wqkv + mo, 32, 16 * (wave & 1), 32, 24, 12 * (wave >> 1), 12);
 #pragma unroll
-    for (int j = 0; j < 6; j++) cload(c_w0[j], a.pq.w0 + mo, Kq, 16 * (wave + 4 * j), Kq, 8, 0, 8);
+    for (int j = 0; j < 6; j++) {
+      cload(c_w0[j], a.pq.w0 + mo, Kq, 16 * (wave + 4 * j), Kq, 8, 0, 8);
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        r_dF[j][r] = a.dF[(rb + tok(4 * g + r)) * DMF + min(16 * (wave + 4 * j) + col, Kq - 1)];
+    }
+    ln1 = ln_load(a.pq.ln1g + mo, a.pq.ln1b + mo);
+    r_acc0 = a.dh0acc[lr], r_acc1 = a.dh0acc[lr + 1];
   }
   if (POSTB) {
     wload(f_w1, a.pp.w1 + mo, 32, 16 * wave, 8, 0, 2);
     cload(c_w2, a.pp.w2 + mo, 64, 16 * wave, 64, 8, 0, 8);
     cload(c_w1, a.pp.w1 + mo, 32, 16 * (wave & 1), 32, 16, 8 * (wave >> 1), 8);
     cload(c_wo, a.pp.wout + mo, 32, 16 * (wave & 1), 32, 8, 4 * (wave >> 1), 4);
+    ln2 = ln_load(a.pp.ln2g + mo, a.pp.ln2b + mo);
+    p_b1 = a.pp.b1[mo + 16 * wave + col];
+    r_h[0][0] = a.h1s[lr], r_h[0][1] = a.h1s[lr + 1], r_h[1][0] = a.h2s[lr], r_h[1][1] = a.h2s[lr + 1];
+    r_ob[0] = a.ob[lr], r_ob[1] = a.ob[lr + 1];
   }
   if (PREB) {
     for (int i = threadIdx.x; i < TT * 24; i += 256) {      // dqkv tile (zero rows beyond BN)
@@ -548,15 +606,15 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwd a) {
       *reinterpret_cast<float4*>(s_F + row * ldF + c4) =
           *reinterpret_cast<const float4*>(a.Fq + (rb + tok(row)) * DMF + c4);
     }
-    s_a[lrow * LD32 + lc] = a.h0[(rb + tok(lrow)) * 32 + lc];
-    s_a[lrow * LD32 + lc + 1] = a.h0[(rb + tok(lrow)) * 32 + lc + 1];
+    s_a[lrow * LD32 + lc] = a.h0[lr];
+    s_a[lrow * LD32 + lc + 1] = a.h0[lr + 1];
   }
   __syncthreads();
 
   // ------------------------------------------------------------------ PREB(lq)
   if (PREB) {
     // t = LN1(h0) -> s_b, xh -> s_c
-    const float rs1 = ln32_keep(s_a, s_b, s_c, a.pq.ln1g + mo, a.pq.ln1b + mo);
+    const float rs1 = ln32_keep(s_a, s_b, s_c, ln1);
     __syncthreads();
     wgrad_tiles(a.gq.wqkv + mo, 96, 32, s_dq, 100, s_b, LD32);
     {  // dt = dqkv * Wqkv -> s_e
@@ -576,12 +634,9 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwd a) {
     __syncthreads();
     {  // LN1 backward + the residual-path gradient -> dh0 (s_a)
       float dh0v, dh1v;
-      ln32_bwd(s_e, s_c, s_gx, rs1, a.pq.ln1g + mo, dh0v, dh1v);
-      const int t = t0 + lrow;
-      const bool ok = t < BN;
-      const float r0 = ok ? a.dh0acc[(rb + t) * 32 + lc] : 0.f, r1 = ok ? a.dh0acc[(rb + t) * 32 + lc + 1] : 0.f;
-      s_a[lrow * LD32 + lc] = ok ? dh0v + r0 : 0.f;
-      s_a[lrow * LD32 + lc + 1] = ok ? dh1v + r1 : 0.f;
+      ln32_bwd(s_e, s_c, s_gx, rs1, ln1, dh0v, dh1v);
+      s_a[lrow * LD32 + lc] = lok ? dh0v + r_acc0 : 0.f;
+      s_a[lrow * LD32 + lc + 1] = lok ? dh1v + r_acc1 : 0.f;
     }
     __syncthreads();
     colsum_atomic(a.gq.ln1g + mo, 32, s_gx, LD32, 0);
@@ -602,7 +657,7 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwd a) {
           const int row = 4 * g + r, t = t0 + row;
           const bool ok = t < BN;
           float* q = a.dF + (rb + tok(row)) * DMF + c;
-          const float v = ok ? *q + acc[r] : 0.f;
+          const float v = ok ? r_dF[j][r] + acc[r] : 0.f;
           if (OUTB) {
             s_do[row * ldD + c] = v;          // (lq = 0: Kq = DM) consumed below, not written back
           } else {
@@ -697,12 +752,11 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwd a) {
     float dres0 = 0.f, dres1 = 0.f;
 #pragma unroll
     for (int pass = 1; pass >= 0; pass--) {  // pass 1: the second ff (on h2) ; pass 0: the first ff (on h1)
-      const float* hs = pass ? a.h2s : a.h1s;
       __syncthreads();
-      s_a[lrow * LD32 + lc] = hs[(rb + tok(lrow)) * 32 + lc];
-      s_a[lrow * LD32 + lc + 1] = hs[(rb + tok(lrow)) * 32 + lc + 1];
-      // the 16 lanes of a token row sit in one wave and read only what they wrote: no barrier needed before the LN
-      const float rs = ln32_keep(s_a, s_b, s_c, a.pp.ln2g + mo, a.pp.ln2b + mo);   // u -> s_b, xh -> s_c
+      s_a[lrow * LD32 + lc] = r_h[pass][0];
+      s_a[lrow * LD32 + lc + 1] = r_h[pass][1];
+      // a thread reads back only the two values it wrote: no barrier needed before the LN
+      const float rs = ln32_keep(s_a, s_b, s_c, ln2);   // u -> s_b, xh -> s_c
       s_dg[lrow * LD32 + lc] = ok ? dcur0 * dr.mask(site0 + 2 + 2 * pass, (uint32_t)t * 32 + lc) : 0.f;
       s_dg[lrow * LD32 + lc + 1] = ok ? dcur1 * dr.mask(site0 + 2 + 2 * pass, (uint32_t)t * 32 + lc + 1) : 0.f;
       __syncthreads();
@@ -711,7 +765,7 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwd a) {
         wmma(accz, f_w1, s_b, LD32, 8, 0, 2);            // z = W1 u  (tile wave)
         cmma(accd, c_w2, s_dg, LD32, 8, 0, 8);           // df = dg * W2 (tile wave)
         const int c = 16 * wave + col;
-        const float b1 = a.pp.b1[mo + c];
+        const float b1 = p_b1;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const int row = 4 * g + r, tt = t0 + row;
@@ -741,7 +795,7 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwd a) {
       }
       __syncthreads();
       float dh0v, dh1v;
-      ln32_bwd(s_e, s_c, s_gx, rs, a.pp.ln2g + mo, dh0v, dh1v);
+      ln32_bwd(s_e, s_c, s_gx, rs, ln2, dh0v, dh1v);
       dh0v = ok ? dh0v : 0.f, dh1v = ok ? dh1v : 0.f;
       __syncthreads();
       colsum_atomic(a.gp.ln2g + mo, 32, s_gx, LD32, 0);
@@ -757,8 +811,8 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwd a) {
     __syncthreads();
     s_dg[lrow * LD32 + lc] = ok ? dres0 * dr.mask(site0 + 0, (uint32_t)t * 32 + lc) : 0.f;
     s_dg[lrow * LD32 + lc + 1] = ok ? dres1 * dr.mask(site0 + 0, (uint32_t)t * 32 + lc + 1) : 0.f;
-    s_b[lrow * LD32 + lc] = a.ob[(rb + tok(lrow)) * 32 + lc];
-    s_b[lrow * LD32 + lc + 1] = a.ob[(rb + tok(lrow)) * 32 + lc + 1];
+    s_b[lrow * LD32 + lc] = r_ob[0];
+    s_b[lrow * LD32 + lc + 1] = r_ob[1];
     if (ok) {
       a.dh0acc_out[(rb + t) * 32 + lc] = dres0;
       a.dh0acc_out[(rb + t) * 32 + lc + 1] = dres1;
