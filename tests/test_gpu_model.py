@@ -544,3 +544,108 @@ def test_fp16_storage_flat_adam_with_gradscaler():
         losses.append(loss.item())
     print("  fp16 losses", losses)
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+@pytest.mark.gpu
+def test_gradsync_overlaps_bucket_reduce_with_next_backward_stage():
+    """bucket k's all-reduce runs on a side stream while stage k+1 back-propagates.  gloo is host
+    synchronous (it cannot overlap) and RCCL needs one GPU per rank, so the collective is replaced by an asynchronous
+    device-side stand-in of known length (a spin kernel on the comm stream, like an RCCL kernel would be) and the STREAM
+    logic of GradSync is asserted with HIP events: (1) every bucket's reduce starts after its stage and before the
+    backward ends, (2) the reduces of buckets 1 and 2 are over before the last stage is (they ran in its shadow),
+    (3) wait() orders the optimizer after all of them, (4) the staged gradient equals the one-shot gradient."""
+    import torch.distributed as dist
+    from hdf_rt import parallel
+    from loss.combine_loss import CEPlusDice, DeepSuperloss
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29583")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        cfg, batch = (4, 4, 32, (64, 64, 64), 8), 2
+        net, sd = _build(cfg, "bf16")
+        net.train()
+        x, onehot = _data(cfg, batch, "overlap")
+        crit = DeepSuperloss(criterion=CEPlusDice(weight=None, ignore_index=0))
+        # reference gradient: one-shot backward, no hook
+        net.set_dropout_seed(5)
+        crit(net(x.to(DEV)), onehot.to(DEV)).backward()
+        torch.cuda.synchronize()
+        g_ref = net.flat_grads().clone()
+
+        marks = []
+        spin = int(150e3 * 2.0)          # ~150 us at ~2 GHz: comparable with a 26 MB bucket over xGMI
+
+        def fake_allreduce(flat, world, group=None):
+            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s0.record()
+            torch.cuda._sleep(spin)
+            flat.mul_(1.0)               # touches the bucket on the comm stream, like the collective would
+            s1.record()
+            marks.append((s0, s1))
+        orig = parallel.flat_allreduce_mean
+        parallel.flat_allreduce_mean = fake_allreduce
+        try:
+            sync = parallel.GradSync(net)
+            stage_end = []
+            calls = []
+
+            def hook(stage):
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()               # main stream: end of backward stage `stage`
+                stage_end.append(e)
+                calls.append(stage)
+                sync(stage)
+            net.grad_hook = hook
+            for p in net.parameters():
+                p.grad = None
+            net.set_dropout_seed(5)
+            t_begin = torch.cuda.Event(enable_timing=True)
+            t_begin.record()
+            crit(net(x.to(DEV)), onehot.to(DEV)).backward()
+            sync.wait()
+            t_after_wait = torch.cuda.Event(enable_timing=True)
+            t_after_wait.record()
+            torch.cuda.synchronize()
+        finally:
+            parallel.flat_allreduce_mean = orig
+            net.grad_hook = None
+        assert calls == [1, 2, 3] and len(marks) == 3
+        ms = lambda a, b: a.elapsed_time(b)      # noqa: E731
+        for k in range(3):
+            assert ms(stage_end[k], marks[k][0]) >= 0.0                     # reduce k starts after its stage ended
+        assert ms(marks[0][0], stage_end[1]) > 0.0 and ms(marks[1][0], stage_end[2]) > 0.0   # ... and while the next runs
+        # buckets 1 and 2 finished before the LAST stage did: they were hidden behind backward
+        print("  stage ends (ms from begin):", [round(ms(t_begin, e), 3) for e in stage_end],
+              "reduce spans:", [(round(ms(t_begin, a), 3), round(ms(t_begin, b), 3)) for a, b in marks])
+        assert ms(marks[0][1], stage_end[2]) > 0.0
+        assert ms(marks[1][1], stage_end[2]) > -0.05
+        for k in range(3):
+            assert ms(marks[k][1], t_after_wait) >= 0.0                    # wait(): the main stream continues after them
+        torch.testing.assert_close(net.flat_grads(), g_ref, rtol=0, atol=0)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_device_exercises_the_multi_gpu_code_path():
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), with both ranks on
+    cuda:0 over gloo (HDF_BENCH_ONE_DEVICE=1; a GPU box here has one device): the barrier + synchronize fences, the MAX
+    over ranks of the wall time, GradSync in the step and the single JSON line of rank 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HDF_BENCH_ONE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", "29585", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                   # exactly one JSON line, from rank 0
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["scaling"] == "weak"
+    assert rec["config"]["global_batch"] == 4 and rec["config"]["parallelism"] == "dp2"
+    assert rec["value"] > 0 and abs(rec["value"] - 4 * 3 / (rec["ms_per_step"] * 3e-3)) < 1e-6 * rec["value"]
+    assert "roofline" not in rec and "cpu_baseline" not in rec        # N = 1 only
