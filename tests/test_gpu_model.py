@@ -622,7 +622,9 @@ def test_gradsync_overlaps_bucket_reduce_with_next_backward_stage():
         assert ms(marks[1][1], stage_end[2]) > -0.05
         for k in range(3):
             assert ms(marks[k][1], t_after_wait) >= 0.0                    # wait(): the main stream continues after them
-        torch.testing.assert_close(net.flat_grads(), g_ref, rtol=0, atol=0)
+        # same gradient as the one-shot backward (the transformer / head parameter gradients use fp32 atomics: equal up
+        # to summation order)
+        assert _rl2(net.flat_grads(), g_ref) < 1e-5
     finally:
         dist.destroy_process_group()
 
