@@ -1077,16 +1077,17 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
 // the (TD+1)x(TH+1)x(TW+1) input box is staged ONCE with full-Cin rows, then each class runs its 1..8 taps and
 // writes its 2x-strided outputs through an LDS staging tile as whole 16-byte chunks.  (The per-class launch of
 // conv_igemm_kernel<CONVT> restaged the same box 8 times for ~3 taps of work each.)
-template <typename T, int TD, int TH, int TW, int MB>
+// NFS = 32-byte fragment steps per voxel row (Cin*sizeof(T)/32): with the class and tap loops unrolled at compile time
+// a class is straight-line code.  Written as run-time loops, hipcc carried the accumulators in VGPRs and bracketed
+// EVERY pair of MFMAs with 64 v_accvgpr moves (SQ_INSTS_VALU 88 M against 57 M MFMA-busy cycles per launch: the kernel
+// was VALU-bound at 280 TF); an `asm("" : "+a"(acc))` pin does not survive the dynamic-trip-count loop nest.
+template <typename T, int TD, int TH, int TW, int MB, int NFS>
 __global__ __launch_bounds__(256) void convt_fused_kernel(ConvArgs a) {
   static_assert(4 * MB * 32 == TD * TH * TW, "tile/wave decomposition");
   constexpr int BD = TD + 1, BH = TH + 1, BW = TW + 1, BOX = BD * BH * BW;
   constexpr int ESZ = sizeof(T), EPC = ST<T>::EPC;
   constexpr int LP = 128 + 16;               // box row pitch (full Cin, up to 128 B)
-  constexpr int OP = 32 * ESZ + 16;          // output staging pitch
-  constexpr int MT = TD * TH * TW;
-  __shared__ __attribute__((aligned(16))) char lds[BOX * LP + MT * OP];
-  char* o_lds = lds + BOX * LP;
+  __shared__ __attribute__((aligned(16))) char lds[BOX * LP];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -1100,8 +1101,7 @@ __global__ __launch_bounds__(256) void convt_fused_kernel(ConvArgs a) {
   const int n = t / ntz;
   const int z0 = tz * TD, y0 = ty * TH, x0 = tx * TW;
   const int n0 = blockIdx.y * 32;
-  const int RB = a.Cin * ESZ;                // 32, 64 or 128 bytes of channels per voxel
-  const int nfs = RB >> 5;
+  const int RB = a.Cin * ESZ;                // 32, 64 or 128 bytes of channels per voxel (= 32 * NFS)
 
   stage_box<T, BD, BH, BW, 128, LP>(lds, reinterpret_cast<const T*>(a.in), a.in_pitch, a.Cin, n, a.Di, a.Hi, a.Wi, z0,
                                     y0, x0, 0, RB, a.in_scale, a.in_shift, a.in_relu);
@@ -1119,28 +1119,43 @@ __global__ __launch_bounds__(256) void convt_fused_kernel(ConvArgs a) {
   const float bias = (a.bias && ch_ok) ? a.bias[ch] : 0.f;
   const char* wrow = reinterpret_cast<const char*>(a.w) + ((int64_t)(n0 + r) * a.Cin) * ESZ + h * 16;
   const int64_t wtap_stride = (int64_t)a.CoutP * a.Cin * ESZ;
-  T* outp = reinterpret_cast<T*>(a.out);
-  constexpr int CPO = 32 * ESZ / 16;
-  const int opart = threadIdx.x & (CPO - 1);
-  const bool oc_ok = n0 + opart * EPC < a.Cout;
+  // output voxel (2z, 2y, 2x) of every accumulator row of this lane, as an element offset inside the sample (-1: the
+  // tile voxel lies outside the volume); a class adds its parity offset
+  T* obase = reinterpret_cast<T*>(a.out) + (int64_t)n * a.Do * a.Ho * a.Wo * a.out_pitch + ch;
+  int voff[MB][16];
+#pragma unroll
+  for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int lin = (wave * MB + mb) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+      const int gz = z0 + lin / (TH * TW), gy = y0 + (lin / TW) % TH, gx = x0 + lin % TW;
+      voff[mb][i] = (gz < a.Di && gy < a.Hi && gx < a.Wi) ? ((2 * gz * a.Ho + 2 * gy) * a.Wo + 2 * gx) * (int)a.out_pitch : -1;
+    }
 
-  for (int cls = 0; cls < 8; cls++) {
-    const int pz = (cls >> 2) & 1, py = (cls >> 1) & 1, px = cls & 1;
-    const int ntapz = pz ? 2 : 1, ntapy = py ? 2 : 1, ntapx = px ? 2 : 1;
+  auto do_class = [&](auto cls_tag) __attribute__((always_inline)) {
+    constexpr int cls = decltype(cls_tag)::value;
+    constexpr int pz = (cls >> 2) & 1, py = (cls >> 1) & 1, px = cls & 1;
+    constexpr int ntapz = pz ? 2 : 1, ntapy = py ? 2 : 1, ntapx = px ? 2 : 1;
     f32x16 acc[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; mb++)
 #pragma unroll
       for (int i = 0; i < 16; i++) acc[mb][i] = 0.f;
+#pragma unroll
     for (int jz = 0; jz < ntapz; jz++) {
+      constexpr int dummy = 0;
+      (void)dummy;
       const int offz = pz ? 1 - jz : 0, wz = pz ? 2 * jz : 1;
+#pragma unroll
       for (int jy = 0; jy < ntapy; jy++) {
         const int offy = py ? 1 - jy : 0, wy = py ? 2 * jy : 1;
+#pragma unroll
         for (int jx = 0; jx < ntapx; jx++) {
           const int offx = px ? 1 - jx : 0, wx = px ? 2 * jx : 1;
           const int tapoff = ((offz * BH + offy) * BW + offx) * LP;
           const char* wp = wrow + ((wz * 3 + wy) * 3 + wx) * wtap_stride;
-          for (int fs = 0; fs < nfs; fs++) {
+#pragma unroll
+          for (int fs = 0; fs < NFS; fs++) {
             u32x4 bfrag = *reinterpret_cast<const u32x4*>(wp + fs * 32);
             u32x4 afrag[MB];
 #pragma unroll
@@ -1152,31 +1167,24 @@ __global__ __launch_bounds__(256) void convt_fused_kernel(ConvArgs a) {
         }
       }
     }
-    // stage this class's outputs as [tile voxel][32 ch] rows
-    if (cls > 0) __syncthreads();   // previous class's staging rows fully consumed
+    // epilogue straight from the accumulators (lane = channel r, 16 tile voxels per M-block): 2-byte stores, 32 lanes =
+    // one 64-byte voxel row.  No LDS staging, no barrier: a wave's stores of class c run under its MFMAs of class c+1
+    // and under the other waves' work (the staged form cost two workgroup barriers and an LDS round trip per class)
+    const int coff = ((pz * a.Ho + py) * a.Wo + px) * (int)a.out_pitch;
 #pragma unroll
     for (int mb = 0; mb < MB; mb++)
 #pragma unroll
-      for (int i = 0; i < 16; i++) {
-        int lin = (wave * MB + mb) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        T tv;
-        ST<T>::st(&tv, acc[mb][i] + bias);
-        *reinterpret_cast<T*>(o_lds + lin * OP + r * ESZ) = tv;
-      }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < MT * CPO / 256; k++) {
-      const int lv = (threadIdx.x + 256 * k) / CPO;
-      const int lz = lv / (TH * TW), ly = (lv / TW) % TH, lx = lv % TW;
-      const int gz = z0 + lz, gy = y0 + ly, gx = x0 + lx;
-      if (oc_ok && gz < a.Di && gy < a.Hi && gx < a.Wi) {
-        u32x4 v = *reinterpret_cast<const u32x4*>(o_lds + lv * OP + opart * 16);
-        T* p = outp + ((((int64_t)n * a.Do + 2 * gz + pz) * a.Ho + 2 * gy + py) * a.Wo + 2 * gx + px) * a.out_pitch + n0 +
-               opart * EPC;
-        *reinterpret_cast<u32x4*>(p) = v;
-      }
-    }
-  }
+      for (int i = 0; i < 16; i++)
+        if (ch_ok && voff[mb][i] >= 0) ST<T>::st(obase + voff[mb][i] + coff, acc[mb][i] + bias);
+  };
+  do_class(std::integral_constant<int, 0>{});
+  do_class(std::integral_constant<int, 1>{});
+  do_class(std::integral_constant<int, 2>{});
+  do_class(std::integral_constant<int, 3>{});
+  do_class(std::integral_constant<int, 4>{});
+  do_class(std::integral_constant<int, 5>{});
+  do_class(std::integral_constant<int, 6>{});
+  do_class(std::integral_constant<int, 7>{});
 }
 
 // weight gradient:  D[tap][sc][lc] = sum_{n,i} S[n,i][sc] * L[n, STRIDE*i-1+tap][lc]
@@ -1954,7 +1962,14 @@ int launch_conv_t(int mode, const ConvArgs& a, hipStream_t st) {
   } else {
     if (a.Cin * (int)sizeof(T) <= 128 && !a.accumulate) {  // all 8 parity classes in one workgroup
       dim3 grid(a.N * ceil_div(a.Di, 4) * ceil_div(a.Hi, 8) * ceil_div(a.Wi, 8), a.CoutP / 32);
-      hipLaunchKernelGGL((convt_fused_kernel<T, 4, 8, 8, 2>), grid, dim3(256), 0, st, a);
+      const int nfs = a.Cin * (int)sizeof(T) / 32;
+      HDF_CHECK_ARG(nfs == 1 || nfs == 2 || nfs == 4, "convT: Cin=%d rows are not 32, 64 or 128 bytes", a.Cin);
+      if (nfs == 4)
+        hipLaunchKernelGGL((convt_fused_kernel<T, 4, 8, 8, 2, 4>), grid, dim3(256), 0, st, a);
+      else if (nfs == 2)
+        hipLaunchKernelGGL((convt_fused_kernel<T, 4, 8, 8, 2, 2>), grid, dim3(256), 0, st, a);
+      else
+        hipLaunchKernelGGL((convt_fused_kernel<T, 4, 8, 8, 2, 1>), grid, dim3(256), 0, st, a);
       HDF_LAUNCH_CHECK();
       return HDF_OK;
     }

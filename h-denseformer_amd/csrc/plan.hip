@@ -179,6 +179,7 @@ struct hdf_plan {
   // backward scratch
   View gA[4], gY[4], dCat[3], dUp[3], dSkip[3], dP[3], dUa[4], dUy[4], dX4, dAttnall;
   bool dcat_split[3] = {false, false, false};
+  bool materialise_at3 = getenv("HDF_MATERIALISE_AT3") != nullptr;
   bool no_head_fuse = getenv("HDF_NO_HEAD_FUSE") != nullptr;  // A/B knob: separate in_bwd_reduce after the heads
   bool no_bias_fuse = getenv("HDF_NO_BIAS_FUSE") != nullptr;  // A/B knob: separate pass for the ConvTranspose3d bias gradients
   // ---- 2-D model (models/HDenseFormer_2D.py) run as its exact depth-replicated 3-D embedding (see embed2d below)
@@ -459,7 +460,9 @@ void layout(hdf_plan* p, int B) {
   for (int k = 0; k < 3; k++) conv_bufs(p->up[k]);
   p->at[2] = mkview(p, bp, "at1", 2, 4 * nf, B);
   p->at[1] = mkview(p, bp, "at2", 1, 2 * nf, B);
-  p->at[0] = View();  // at3 is never materialised (fused into the encoder tail)
+  // at3 (full resolution): by default never materialised (the encoder tail interpolates it on the fly from up3's raw
+  // output); HDF_MATERIALISE_AT3=1 (A/B knob) writes it with upsample_fwd and runs the plain encoder tail
+  p->at[0] = p->materialise_at3 ? mkview(p, bp, "at3", 0, nf, B) : View();
   for (int k = 0; k < 4; k++) {
     conv_bufs(p->enc[k][0]);
     conv_bufs(p->enc[k][1]);
@@ -1118,7 +1121,7 @@ static int forward3d(hdf_plan* p, const float* x, const float* params, void* wor
     for (int k = 0; k < 3; k++) {  // up1 -> at1 (lvl 2), up2 -> at2 (lvl 1), up3 -> at3 (lvl 0)
       Conv3& c = p->up[k];
       HDF_TRY(conv_forward(e, c, *src, none));
-      if (k == 2) break;  // at3 (full resolution) is never materialised: the encoder tail interpolates it on the fly
+      if (k == 2 && !p->materialise_at3) break;  // at3 is not materialised: the encoder tail interpolates it on the fly
       const View& dst = p->at[2 - k];
       HDF_TRY(hdf_launch_upsample_fwd(p->dtype, e.at(c.y), c.y.pitch, e.f(c.st.scale), e.f(c.st.shift), e.at(dst),
                                       dst.pitch, batch, c.Cout, p->dims[c.lvl][0], p->dims[c.lvl][1],
@@ -1138,7 +1141,7 @@ static int forward3d(hdf_plan* p, const float* x, const float* params, void* wor
       // ds_k = relu(IN(y)) + at_k ; pooled = MaxPool(ds_k): one fused pass.  Level 0 takes at3 straight from up3's
       // raw conv output (trilinear x2 of relu(IN(.)) evaluated inside the kernel)
       Conv3& u3 = p->up[2];
-      const bool ups = (k == 0);
+      const bool ups = (k == 0) && !p->materialise_at3;
       HDF_TRY(hdf_launch_enc_tail(p->dtype, e.at(c.y), c.y.pitch, e.f(c.st.scale), e.f(c.st.shift),
                                   ups ? e.at(u3.y) : e.at(p->at[k]), ups ? u3.y.pitch : p->at[k].pitch,
                                   ups ? e.f(u3.st.scale) : nullptr, ups ? e.f(u3.st.shift) : nullptr, e.at(ds),
