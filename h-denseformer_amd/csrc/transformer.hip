@@ -268,40 +268,49 @@ __device__ __forceinline__ void attn_stage_kv(int N, int NP, const float* __rest
   }
 }
 
+// QK^T on the matrix core.  One v_mfma_f32_16x16x4_f32 (exact fp32, K = 4 = the head width) gives the 16 x 16 scores of a
+// block of 16 keys (A rows) against the wave's 16 queries (B columns): lane (q = lane & 15, g = lane >> 4) receives the
+// scores of keys j0 + 4g .. 4g + 3 for its query -- exactly the "4 lanes per query, keys interleaved" decomposition of
+// the VALU version, with the packed dot products (3 of its 14 instruction slots per pair) gone.  The exponentials, the
+// running max / rescale and the 4-wide P.V update stay on the VALU (P.V as an MFMA would fill 4 of the 16 tile rows).
+// The MFMA of block j0 + 16 is issued before the exponentials of block j0 (40 cycles of dependent latency).
+__device__ __forceinline__ f32x4 attn_scores(const float* sKf, int j0, float bq) {
+  const int lane = threadIdx.x & 63;
+  f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(sKf[(j0 + (lane & 15)) * 4 + (lane >> 4)], bq, z, 0, 0, 0);
+}
+
 __global__ __launch_bounds__(256) void attn_fwd_kernel(int N, const float* __restrict__ qkv, float* __restrict__ ob,
                                                        float* __restrict__ lse) {
   extern __shared__ float4 skv[];
   const int NP = attn_rows(N);
   float4* sK = skv;
   float4* sV = skv + NP;
+  const float* sKf = reinterpret_cast<const float*>(sK);
   const int head = blockIdx.y;
   const int64_t rowbase = (int64_t)blockIdx.z * N;
   attn_stage_kv(N, NP, qkv, rowbase, head, sK, sV);
   __syncthreads();
-  const int qi = blockIdx.x * AQ + threadIdx.x / QL, sub = threadIdx.x % QL;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+  const int qi = blockIdx.x * AQ + 16 * wave + (lane & 15);
   const bool ok = qi < N;
-  const float4 q4 = *reinterpret_cast<const float4*>(qkv + (rowbase + (ok ? qi : 0)) * 96 + head * 4);
-  const f2 q01 = lo2(q4) * (0.5f * LOG2E), q23 = hi2(q4) * (0.5f * LOG2E);  // dim_head^-0.5 = 0.5; scores in log2 units
+  // B operand of every score MFMA: this lane's query, component g, pre-scaled (dim_head^-0.5 = 0.5; log2 units)
+  const float bq = qkv[(rowbase + (ok ? qi : 0)) * 96 + head * 4 + g] * (0.5f * LOG2E);
   float mx = -INFINITY, l = 0.f;
   f2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
-  // AU keys per trip: the loop is a latency chain (LDS read -> dot -> exp -> rescale), so the AU independent
-  // score/exp chains of one trip are what fills the pipes; one running-max update per trip
-  auto trip = [&](int j0, auto masked) __attribute__((always_inline)) {
-    float4 k[AU], v[AU];
+  auto trip = [&](int j0, const f32x4& sc4, auto masked) __attribute__((always_inline)) {
+    float4 v[AU];
     float sc[AU];
 #pragma unroll
-    for (int u = 0; u < AU; u++) {
-      k[u] = sK[j0 + QL * u];
-      v[u] = sV[j0 + QL * u];
-    }
+    for (int u = 0; u < AU; u++) v[u] = sV[j0 + 4 * g + u];
     float mn = mx;
 #pragma unroll
     for (int u = 0; u < AU; u++) {
-      sc[u] = dot4(q01, q23, lo2(k[u]), hi2(k[u]));
-      if (decltype(masked)::value) sc[u] = (j0 + QL * u < N) ? sc[u] : -INFINITY;
+      sc[u] = sc4[u];
+      if (decltype(masked)::value) sc[u] = (j0 + 4 * g + u < N) ? sc[u] : -INFINITY;
       mn = fmaxf(mn, sc[u]);
     }
-    const float mr = (mn == -INFINITY) ? 0.f : mn;  // a lane with no key yet (N < QL): exp2(-inf - mr) = 0, not NaN
+    const float mr = (mn == -INFINITY) ? 0.f : mn;  // a lane with no key yet: exp2(-inf - mr) = 0, not NaN
     const float c = __builtin_amdgcn_exp2f(mx - mr);
     float ps = 0.f;
     f2 b01 = {0.f, 0.f}, b23 = {0.f, 0.f};
@@ -319,12 +328,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(int N, const float* __res
     a23 = __builtin_elementwise_fma(a23, cc, b23);
     mx = mn;
   };
+  static_assert(AU == 4 && ATRIP == 16, "one 16-key MFMA block per trip, 4 keys per lane");
   const int nfull = N / ATRIP * ATRIP;
-  int j0 = sub;
-  for (; j0 < nfull; j0 += ATRIP) trip(j0, std::false_type{});
-  if (j0 < NP) trip(j0, std::true_type{});
+  f32x4 cur = attn_scores(sKf, 0, bq);
+  int j0 = 0;
+  for (; j0 < nfull; j0 += ATRIP) {
+    const f32x4 nxt = attn_scores(sKf, min(j0 + ATRIP, NP - ATRIP), bq);
+    trip(j0, cur, std::false_type{});
+    cur = nxt;
+  }
+  if (j0 < NP) trip(j0, cur, std::true_type{});
+  // merge the 4 key subsets of a query (lanes q, q + 16, q + 32, q + 48)
 #pragma unroll
-  for (int off = 1; off < QL; off <<= 1) {
+  for (int off = 16; off < 64; off <<= 1) {
     const float m2 = __shfl_xor(mx, off, 64), l2 = __shfl_xor(l, off, 64);
     const f2 b01 = {__shfl_xor(a01.x, off, 64), __shfl_xor(a01.y, off, 64)};
     const f2 b23 = {__shfl_xor(a23.x, off, 64), __shfl_xor(a23.y, off, 64)};
@@ -336,7 +352,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(int N, const float* __res
     a23 = a23 * ca + b23 * cb;
     mx = mn;
   }
-  if (ok && sub == 0) {
+  if (ok && g == 0) {
     const float inv = 1.f / l;
     *reinterpret_cast<float4*>(ob + (rowbase + qi) * 32 + head * 4) =
         make_float4(a01.x * inv, a01.y * inv, a23.x * inv, a23.y * inv);
@@ -344,60 +360,66 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(int N, const float* __res
   }
 }
 
-// dQ: same decomposition as forward
+// dQ: same decomposition as forward; the two 16 x 16 x 4 products per block (scores K.Q and T = V.dO) on the matrix core
 __device__ __forceinline__ void attn_bwd_dq_body(int N, int seq, const float* __restrict__ qkv,
                                                  const float* __restrict__ ob, const float* __restrict__ lse,
                                                  const float* __restrict__ dO, float* __restrict__ dqkv, float4* skv) {
   const int NP = attn_rows(N);
   float4* sK = skv;
   float4* sV = skv + NP;
+  const float* sKf = reinterpret_cast<const float*>(sK);
+  const float* sVf = reinterpret_cast<const float*>(sV);
   const int head = blockIdx.y;
   const int64_t rowbase = (int64_t)seq * N;
   attn_stage_kv(N, NP, qkv, rowbase, head, sK, sV);
   __syncthreads();
-  const int qi = blockIdx.x * AQ + threadIdx.x / QL, sub = threadIdx.x % QL;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+  const int qi = blockIdx.x * AQ + 16 * wave + (lane & 15);
   const bool ok = qi < N;
   const int64_t R = rowbase + (ok ? qi : 0);
-  const float4 q4 = *reinterpret_cast<const float4*>(qkv + R * 96 + head * 4);
-  const f2 q01 = lo2(q4) * (0.5f * LOG2E), q23 = hi2(q4) * (0.5f * LOG2E);
   const float4 go = *reinterpret_cast<const float4*>(dO + R * 32 + head * 4);
   const float4 oo = *reinterpret_cast<const float4*>(ob + R * 32 + head * 4);
-  const f2 g01 = lo2(go), g23 = hi2(go);
-  const float delta = dot4(g01, g23, lo2(oo), hi2(oo));
+  const float delta = go.x * oo.x + go.y * oo.y + go.z * oo.z + go.w * oo.w;
   const float ls = lse[R * 8 + head] * LOG2E;
+  const float bq = qkv[R * 96 + head * 4 + g] * (0.5f * LOG2E);   // B operands: query / dO component g of this lane's row
+  const float bg = dO[R * 32 + head * 4 + g];
   f2 d01 = {0.f, 0.f}, d23 = {0.f, 0.f};
-  auto trip = [&](int j0, auto masked) __attribute__((always_inline)) {
-    float4 k[AU], v[AU];
+  auto trip = [&](int j0, const f32x4& s4, const f32x4& t4, auto masked) __attribute__((always_inline)) {
+    float4 k[AU];
+#pragma unroll
+    for (int u = 0; u < AU; u++) k[u] = sK[j0 + 4 * g + u];
 #pragma unroll
     for (int u = 0; u < AU; u++) {
-      k[u] = sK[j0 + QL * u];
-      v[u] = sV[j0 + QL * u];
-    }
-#pragma unroll
-    for (int u = 0; u < AU; u++) {
-      float pr = __builtin_amdgcn_exp2f(dot4(q01, q23, lo2(k[u]), hi2(k[u])) - ls);
-      if (decltype(masked)::value) pr = (j0 + QL * u < N) ? pr : 0.f;
-      const float ds = pr * (dot4(g01, g23, lo2(v[u]), hi2(v[u])) - delta);
+      float pr = __builtin_amdgcn_exp2f(s4[u] - ls);
+      if (decltype(masked)::value) pr = (j0 + 4 * g + u < N) ? pr : 0.f;
+      const float ds = pr * (t4[u] - delta);
       const f2 dd = {ds, ds};
       d01 = __builtin_elementwise_fma(dd, lo2(k[u]), d01);
       d23 = __builtin_elementwise_fma(dd, hi2(k[u]), d23);
     }
   };
   const int nfull = N / ATRIP * ATRIP;
-  int j0 = sub;
-  for (; j0 < nfull; j0 += ATRIP) trip(j0, std::false_type{});
-  if (j0 < NP) trip(j0, std::true_type{});
+  f32x4 cs = attn_scores(sKf, 0, bq), ct = attn_scores(sVf, 0, bg);
+  int j0 = 0;
+  for (; j0 < nfull; j0 += ATRIP) {
+    const int jn = min(j0 + ATRIP, NP - ATRIP);
+    const f32x4 ns = attn_scores(sKf, jn, bq), nt = attn_scores(sVf, jn, bg);
+    trip(j0, cs, ct, std::false_type{});
+    cs = ns, ct = nt;
+  }
+  if (j0 < NP) trip(j0, cs, ct, std::true_type{});
 #pragma unroll
-  for (int off = 1; off < QL; off <<= 1) {
+  for (int off = 16; off < 64; off <<= 1) {
     d01.x += __shfl_xor(d01.x, off, 64), d01.y += __shfl_xor(d01.y, off, 64);
     d23.x += __shfl_xor(d23.x, off, 64), d23.y += __shfl_xor(d23.y, off, 64);
   }
-  if (ok && sub == 0)
+  if (ok && g == 0)
     *reinterpret_cast<float4*>(dqkv + R * 96 + head * 4) =
         make_float4(0.5f * d01.x, 0.5f * d01.y, 0.5f * d23.x, 0.5f * d23.y);
 }
 
-// dK, dV: QL lanes per key, queries interleaved over the QL lanes
+// dK, dV: a lane owns one key (16 per wave) and every fourth group of 4 queries of each 16-query block; scores and
+// T = dO.V per block on the matrix core (A = the staged query / dO block, B = this lane's key / value component)
 __device__ __forceinline__ void attn_bwd_dkv_body(int N, int seq, const float* __restrict__ qkv,
                                                   const float* __restrict__ ob, const float* __restrict__ lse,
                                                   const float* __restrict__ dO, float* __restrict__ dqkv, float4* skv) {
@@ -405,6 +427,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(int N, int seq, const float* _
   float4* sQ = skv;        // pre-scaled by 0.5 log2(e)
   float4* sG = skv + NP;   // dO
   float2* sL = reinterpret_cast<float2*>(skv + 2 * NP);  // (lse log2(e), delta); padded rows: (+inf, 0)
+  const float* sQf = reinterpret_cast<const float*>(sQ);
+  const float* sGf = reinterpret_cast<const float*>(sG);
   const int head = blockIdx.y;
   const int64_t rowbase = (int64_t)seq * N;
   for (int base = threadIdx.x; base < NP; base += 256 * 4) {
@@ -433,43 +457,45 @@ __device__ __forceinline__ void attn_bwd_dkv_body(int N, int seq, const float* _
     }
   }
   __syncthreads();
-  const int kj = blockIdx.x * AQ + threadIdx.x / QL, sub = threadIdx.x % QL;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+  const int kj = blockIdx.x * AQ + 16 * wave + (lane & 15);
   const bool ok = kj < N;
   const int64_t R = rowbase + (ok ? kj : 0);
-  const float4 k4 = *reinterpret_cast<const float4*>(qkv + R * 96 + 32 + head * 4);
-  const float4 v4 = *reinterpret_cast<const float4*>(qkv + R * 96 + 64 + head * 4);
-  const f2 k01 = lo2(k4), k23 = hi2(k4), v01 = lo2(v4), v23 = hi2(v4);
+  const float bk = qkv[R * 96 + 32 + head * 4 + g], bv = qkv[R * 96 + 64 + head * 4 + g];
   f2 dk01 = {0.f, 0.f}, dk23 = {0.f, 0.f}, dv01 = {0.f, 0.f}, dv23 = {0.f, 0.f};
-  for (int i0 = sub; i0 < NP; i0 += ATRIP) {
+  f32x4 cs = attn_scores(sQf, 0, bk), ct = attn_scores(sGf, 0, bv);
+  for (int i0 = 0; i0 < NP; i0 += ATRIP) {
+    const int in = min(i0 + ATRIP, NP - ATRIP);
+    const f32x4 ns = attn_scores(sQf, in, bk), nt = attn_scores(sGf, in, bv);
     float4 q[AU], go[AU];
     float2 ld[AU];
 #pragma unroll
     for (int u = 0; u < AU; u++) {
-      q[u] = sQ[i0 + QL * u];
-      go[u] = sG[i0 + QL * u];
-      ld[u] = sL[i0 + QL * u];
+      q[u] = sQ[i0 + 4 * g + u];
+      go[u] = sG[i0 + 4 * g + u];
+      ld[u] = sL[i0 + 4 * g + u];
     }
 #pragma unroll
     for (int u = 0; u < AU; u++) {
-      const f2 q01 = lo2(q[u]), q23 = hi2(q[u]), g01 = lo2(go[u]), g23 = hi2(go[u]);
-      const float pr = __builtin_amdgcn_exp2f(dot4(q01, q23, k01, k23) - ld[u].x);
+      const float pr = __builtin_amdgcn_exp2f(cs[u] - ld[u].x);   // padded queries: exp2(-inf) = 0
       const f2 pp = {pr, pr};
-      dv01 = __builtin_elementwise_fma(pp, g01, dv01);
-      dv23 = __builtin_elementwise_fma(pp, g23, dv23);
-      const float ds = pr * (dot4(g01, g23, v01, v23) - ld[u].y);
+      dv01 = __builtin_elementwise_fma(pp, lo2(go[u]), dv01);
+      dv23 = __builtin_elementwise_fma(pp, hi2(go[u]), dv23);
+      const float ds = pr * (ct[u] - ld[u].y);
       const f2 dd = {ds, ds};
-      dk01 = __builtin_elementwise_fma(dd, q01, dk01);
-      dk23 = __builtin_elementwise_fma(dd, q23, dk23);
+      dk01 = __builtin_elementwise_fma(dd, lo2(q[u]), dk01);
+      dk23 = __builtin_elementwise_fma(dd, hi2(q[u]), dk23);
     }
+    cs = ns, ct = nt;
   }
 #pragma unroll
-  for (int off = 1; off < QL; off <<= 1) {
+  for (int off = 16; off < 64; off <<= 1) {
     dk01.x += __shfl_xor(dk01.x, off, 64), dk01.y += __shfl_xor(dk01.y, off, 64);
     dk23.x += __shfl_xor(dk23.x, off, 64), dk23.y += __shfl_xor(dk23.y, off, 64);
     dv01.x += __shfl_xor(dv01.x, off, 64), dv01.y += __shfl_xor(dv01.y, off, 64);
     dv23.x += __shfl_xor(dv23.x, off, 64), dv23.y += __shfl_xor(dv23.y, off, 64);
   }
-  if (ok && sub == 0) {
+  if (ok && g == 0) {
     const float un = 1.f / LOG2E;  // the staged queries carry log2(e)
     *reinterpret_cast<float4*>(dqkv + R * 96 + 32 + head * 4) =
         make_float4(dk01.x * un, dk01.y * un, dk23.x * un, dk23.y * un);
