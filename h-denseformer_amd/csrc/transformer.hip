@@ -334,6 +334,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(int N, const float* __res
   int j0 = 0;
   for (; j0 < nfull; j0 += ATRIP) {
     const f32x4 nxt = attn_scores(sKf, min(j0 + ATRIP, NP - ATRIP), bq);
+    __builtin_amdgcn_sched_barrier(0);   // keep the next block's MFMA ahead of this block's exponentials
     trip(j0, cur, std::false_type{});
     cur = nxt;
   }
@@ -404,6 +405,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(int N, int seq, const float* __
   for (; j0 < nfull; j0 += ATRIP) {
     const int jn = min(j0 + ATRIP, NP - ATRIP);
     const f32x4 ns = attn_scores(sKf, jn, bq), nt = attn_scores(sVf, jn, bg);
+    __builtin_amdgcn_sched_barrier(0);
     trip(j0, cs, ct, std::false_type{});
     cs = ns, ct = nt;
   }
@@ -467,6 +469,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(int N, int seq, const float* _
   for (int i0 = 0; i0 < NP; i0 += ATRIP) {
     const int in = min(i0 + ATRIP, NP - ATRIP);
     const f32x4 ns = attn_scores(sQf, in, bk), nt = attn_scores(sGf, in, bv);
+    __builtin_amdgcn_sched_barrier(0);
     float4 q[AU], go[AU];
     float2 ld[AU];
 #pragma unroll

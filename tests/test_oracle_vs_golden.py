@@ -204,3 +204,32 @@ def test_g10_normalize_vs_reference():
     assert np.array_equal(sw_oracle.mr_normalize(g["mr_in"]), g["mr_out"])
     assert np.array_equal(sw_oracle.pet_ct_normalize(g["petct_in"]), g["petct_out"])
     assert np.array_equal(sw_oracle.pet_ct_normalize(g["petct_in"], 40, 400), g["petct_m40_w400_out"])
+
+
+def test_dropout_hash_mask_statistics():
+    """SURVEY 8c 'Dropout': the counter-hash masks (oracle/detgen.py:dropout_keep == csrc/hdf_common.h:hdf_keep) must
+    behave like the reference's Bernoulli(0.5) masks: keep probability 0.5 (scale 2.0 keeps the mean), and the masks of
+    different sites / seeds / steps (the two ff calls of a layer, to_out, the embedding, consecutive steps) independent."""
+    n = 1 << 18
+    sites = [detgen.site_id(0, 0, 0, k) for k in range(5)] + [detgen.site_id(1, 2, 3, detgen.KIND_FF2_B),
+                                                              detgen.site_id(0, 0, detgen.LAYER_OUT, detgen.KIND_OUT_A),
+                                                              detgen.site_emb(0), detgen.site_emb(3)]
+    masks = [detgen.dropout_keep(1234, s, n, 0.5).astype(np.float64) for s in sites]
+    masks += [detgen.dropout_keep(seed, sites[1], n, 0.5).astype(np.float64) for seed in (1235, 99991, 1234 + 1000003)]
+    for m in masks:
+        assert abs(m.mean() - 0.5) < 4e-3                      # 4 sigma of a fair coin at n = 2^18 is 3.9e-3
+        # no short-range structure along the element index (lag-1 .. lag-32 autocorrelation)
+        c = m - m.mean()
+        for lag in (1, 2, 7, 32):
+            assert abs((c[:-lag] * c[lag:]).mean() / c.var()) < 1e-2
+    z = np.stack([m - m.mean() for m in masks])
+    corr = (z @ z.T) / n / 0.25
+    off = corr - np.diag(np.diag(corr))
+    assert np.abs(off).max() < 1e-2, np.abs(off).max()         # pairwise independent sites / seeds / steps
+    # other keep probabilities come out right too (threshold arithmetic)
+    for p in (0.1, 0.25, 0.9):
+        assert abs(detgen.dropout_keep(7, 3, n, p).mean() - (1 - p)) < 4e-3
+    # the oracle's Dropper scales kept entries by 1/(1-p)
+    x = torch.ones(4, 8, 32)
+    y = orc.Dropper(5)(x, sites[0])
+    assert set(np.unique(y.numpy()).tolist()) <= {0.0, 2.0} and abs(float(y.mean()) - 1.0) < 0.15
