@@ -510,7 +510,9 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ in,
   float* part = outs + MC * per;
   const int n = blockIdx.y;
   const int cols = C / EPC;
-  const bool pow2 = (cols & (cols - 1)) == 0;  // else (n_filters = 48: 6 chunk lanes) a voxel's lanes straddle waves
+  // shuffle reduction when a voxel's chunk lanes are a power of two within one wave; else (n_filters = 48: 6 chunk
+  // lanes straddle waves; fp32 storage at 512 channels: 128 lanes per voxel) through LDS
+  const bool pow2 = (cols & (cols - 1)) == 0 && cols <= 64;
   const int vlanes = 256 / cols;
   const int col = threadIdx.x % cols, vl = min((int)threadIdx.x / cols, vlanes - 1);
   const bool lane_on = (int)threadIdx.x < vlanes * cols;

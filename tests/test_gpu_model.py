@@ -393,6 +393,36 @@ def test_onehot_from_labels_vs_reference_golden():
 
 
 @pytest.mark.gpu
+def test_n_filters_64_forward_backward_vs_oracle():
+    """The widest supported model (n_filters = 64: token dim 256, Linear0 up to 352 inputs, 512-channel bottleneck)."""
+    from loss.combine_loss import CEPlusDice, DeepSuperloss
+    cfg, batch, tag = (2, 3, 64, (32, 32, 32), 8), 1, "nf64"
+    net, sd = _build(cfg)
+    net.train()
+    net.set_dropout_seed(31)
+    x, onehot = _data(cfg, batch, tag)
+    crit = DeepSuperloss(criterion=CEPlusDice(weight=None, ignore_index=0))
+    outs = net(x.to(DEV))
+    loss = crit(outs, onehot.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    tr = orc.OracleTrainer(sd)
+    ref_loss, ref_outs = tr.loss_and_grads(x, onehot, 31)
+    for i in range(4):
+        assert _rel(outs[i].detach(), ref_outs[i]) < 1e-3, f"out{i}"
+    assert abs(loss.item() - ref_loss.item()) < 1e-4 * max(1.0, abs(ref_loss.item()))
+    errs = []
+    for name, p in net.named_parameters():
+        rg = tr.sd[name].grad
+        if rg.norm() < 1e-6:
+            continue
+        errs.append((name, _rl2(p.grad, rg)))
+    errs.sort(key=lambda kv: -kv[1])
+    print("  nf64 worst grads", errs[:4])
+    assert errs[0][1] < 2e-2, errs[:5]
+
+
+@pytest.mark.gpu
 def test_n_filters_48_forward_backward_vs_oracle():
     """BASELINE config #5 channel widths (n_filters = 48: 96-byte channel rows, 6 / 12 / 24 / 48 chunk lanes per
     voxel, i.e. the non-power-of-two paths of the elementwise and head kernels) on a small volume."""

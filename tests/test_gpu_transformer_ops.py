@@ -108,7 +108,8 @@ def _ref_layer(Fin, P, m, layer, DM, B, N, seed, block):
 @pytest.mark.parametrize("DM,N,B,M,layer,train", [(64, 8, 2, 2, 0, False), (64, 27, 1, 2, 3, True),
                                                   (128, 64, 2, 1, 1, True), (128, 512, 2, 2, 3, True),
                                                   (128, 512, 1, 1, 0, False), (128, 729, 1, 2, 2, False),
-                                                  (192, 1000, 1, 1, 3, True), (192, 27, 2, 3, 2, False)])
+                                                  (192, 1000, 1, 1, 3, True), (192, 27, 2, 3, 2, False),
+                                                  (256, 64, 1, 2, 3, True), (256, 27, 2, 1, 0, False)])
 def test_dense_layer_fwd_bwd(DM, N, B, M, layer, train):
     DMF = DM + 128
     rows = B * N
@@ -164,7 +165,7 @@ def test_dense_layer_fwd_bwd(DM, N, B, M, layer, train):
 # ------------------------------------------------------------------------------------------------ block out layer
 @pytest.mark.parametrize("DM,N,B,M,train,last,dtype", [(64, 8, 2, 2, True, False, F32), (128, 512, 2, 2, True, True, F32),
                                                        (128, 27, 1, 1, False, True, BF16), (192, 1000, 1, 1, False, False, F32),
-                                                       (128, 729, 1, 2, True, True, F32)])
+                                                       (128, 729, 1, 2, True, True, F32), (256, 64, 2, 1, True, False, F32)])
 def test_block_out_fwd_bwd(DM, N, B, M, train, last, dtype):
     DMF, rows, block = DM + 128, B * N, 1
     seed = 99 if train else None
@@ -235,7 +236,8 @@ def test_block_out_fwd_bwd(DM, N, B, M, train, last, dtype):
 
 # ------------------------------------------------------------------------------------------------ patch embedding
 @pytest.mark.parametrize("DM,size,B,M,train", [(64, (32, 32, 32), 2, 2, False), (128, (48, 32, 64), 1, 3, True),
-                                               (192, (32, 48, 32), 2, 1, True), (128, (128, 128, 128), 1, 2, False)])
+                                               (192, (32, 48, 32), 2, 1, True), (128, (128, 128, 128), 1, 2, False),
+                                               (256, (32, 32, 48), 1, 2, True)])
 def test_patch_embed_fwd_bwd(DM, size, B, M, train):
     D, H, W = size
     N = (D // 16) * (H // 16) * (W // 16)
@@ -287,7 +289,7 @@ def test_patch_embed_fwd_bwd(DM, size, B, M, train):
 @pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("C_,ncls,size,n,xf", [(32, 4, (16, 16, 16), 2, True), (64, 3, (8, 12, 10), 1, False),
                                               (48, 2, (9, 7, 5), 2, True), (256, 4, (4, 4, 4), 2, False),
-                                              (384, 3, (2, 3, 4), 1, True)])
+                                              (384, 3, (2, 3, 4), 1, True), (512, 3, (4, 4, 4), 1, False)])
 def test_head_fwd_bwd(dtype, C_, ncls, size, n, xf):
     g = _g(C_ + ncls)
     tdt = torch.bfloat16 if dtype == BF16 else torch.float32
