@@ -173,7 +173,8 @@ struct hdf_plan {
   // forward buffers
   View xin, attnall, attnout, at[3] /*at[k] lives at level k*/, cat[3], pooled[3], x4;
   size_t pool_idx[3];
-  size_t tf_F, tf_save, tf_scratch, tf_dF;
+  size_t tf_F, tf_save, tf_scratch, tf_dF, tf_tape = 0, tf_otape = 0;
+  bool tf_atomics = getenv("HDF_TF_ATOMICS") != nullptr;  // A/B knob: per-tile weight-gradient products + fp32 atomics
   size_t stat_partials, wgrad_ws, inb_partials, inb_k;
   size_t wgrad_ws_bytes = 0;
   // backward scratch
@@ -530,6 +531,9 @@ void layout(hdf_plan* p, int B) {
   // ---- backward scratch
   p->tf_scratch = bp.take((size_t)rows * std::max(160, p->DM) * sizeof(float));
   p->tf_dF = bp.take((size_t)rows * p->DMF * sizeof(float));
+  // weight-gradient operand tapes of the transformer branches (contracted by tf_wgrad at the end of backward)
+  p->tf_tape = bp.take((size_t)p->nb * 4 * rows * TF_TAPE_W * sizeof(float));
+  p->tf_otape = bp.take((size_t)p->nb * rows * p->DMF * sizeof(float));
   p->wgrad_ws_bytes = (size_t)128 << 20;
   p->wgrad_ws = bp.take(p->wgrad_ws_bytes);
   p->inb_partials = bp.take((size_t)B * 1024 * 8 * nf * 2 * sizeof(float));  // hdf_in_bwd_blocks <= 1024, C <= 8 nf
@@ -782,17 +786,22 @@ int transformer_backward(Exec& e, const float* x) {
         tf_layer_ptrs(p, e.grads, b, l, gcur);
         TfTokenBwd t;
         t.dF = dF;
+        float* tape = p->tf_atomics ? nullptr : e.f(p->tf_tape);
+        float* otape = p->tf_atomics ? nullptr : e.f(p->tf_otape);
         if (have_up) {
           t.pre = &up, t.pre_grad = &gup, t.pre_save = tf_save(p, e, ub, ul), t.bq = ub, t.lq = ul;
           t.F_pre = F0 + (int64_t)ub * rows * p->DMF, t.dqkv = dqkv, t.dh0acc = dh0acc;
+          if (tape) t.tape_pre = tape + (int64_t)(ub * 4 + ul) * rows * TF_TAPE_W;
         }
         if (l == 3) {
           tf_out_ptrs(p, pm, b, o);
           tf_out_ptrs(p, e.grads, b, go);
           t.out = &o, t.out_grad = &go, t.bo = b, t.F_out = F;
           if (!have_up) t.d_attnall = e.at(p->dAttnall);
+          if (otape) t.tape_out = otape + (int64_t)b * rows * p->DMF;
         }
         t.post = &cur, t.post_grad = &gcur, t.post_save = tf_save(p, e, b, l), t.bp = b, t.lp = l;
+        if (tape) t.tape_post = tape + (int64_t)(b * 4 + l) * rows * TF_TAPE_W;
         t.dO = dO, t.dh0acc_out = dh0acc;
         HDF_TRY(tf_token_bwd(d, t, p->dtype, e.st));
         TfLayerSave s = tf_save(p, e, b, l);
@@ -803,7 +812,32 @@ int transformer_backward(Exec& e, const float* x) {
     TfTokenBwd t;
     t.dF = dF, t.pre = &up, t.pre_grad = &gup, t.pre_save = tf_save(p, e, 0, 0), t.bq = 0, t.lq = 0, t.F_pre = F0;
     t.dqkv = dqkv, t.dh0acc = dh0acc;
+    if (!p->tf_atomics) t.tape_pre = e.f(p->tf_tape);
     HDF_TRY(tf_token_bwd(d, t, p->dtype, e.st));
+    if (!p->tf_atomics) {
+      // every weight-matrix gradient of the branches: one launch over the tapes (fixed-order reductions, no atomics)
+      TfWgradArgs w{};
+      const int64_t blk0 = p->P("attns.0.blocks.0.0.layers.0.0.weight");
+      const int64_t blk_stride = p->nb > 1 ? p->P("attns.0.blocks.1.0.layers.0.0.weight") - blk0 : 0;
+      int k = 0;
+      auto rel = [&](const std::string& n) { return p->P("attns.0.blocks.0.0." + n) - blk0; };
+      for (int l = 0; l < 4; l++) {
+        const std::string pre = "layers." + std::to_string(l);
+        w.e[k++] = TfWgradEntry{rel(pre + ".1.fn.to_qkv.weight"), 96, 32, l, 0, 0, TF_T_DQ, TF_T_T, -1, -1, 96, 32};
+        w.e[k++] = TfWgradEntry{rel(pre + ".0.weight"), 32, p->DM + 32 * l, l, 0, 1, TF_T_DH0, 0, -1, -1, 32, p->DMF};
+        w.e[k++] = TfWgradEntry{rel(pre + ".2.fn.net.3.weight"), 32, 64, l, 0, 0, TF_T_P1, TF_T_P1 + 32, TF_T_P0, TF_T_P0 + 32,
+                                32, 64};
+        w.e[k++] = TfWgradEntry{rel(pre + ".2.fn.net.0.weight"), 64, 32, l, 0, 0, TF_T_P1 + 96, TF_T_P1 + 160, TF_T_P0 + 96,
+                                TF_T_P0 + 160, 64, 32};
+        w.e[k++] = TfWgradEntry{rel(pre + ".1.fn.to_out.0.weight"), 32, 32, l, 0, 2, TF_T_DGO, 0, -1, -1, 32, 32};
+      }
+      w.e[k++] = TfWgradEntry{rel("out_layer.net.3.weight"), p->DM, 64, 0, 3, 3, 0, p->DM, -1, -1, p->DM, 64};
+      w.e[k++] = TfWgradEntry{rel("out_layer.net.0.weight"), 64, p->DMF, 0, 3, 1, p->DM + 64, 0, -1, -1, 64, p->DMF};
+      w.grads = e.grads, w.mstride = p->mstride, w.block0 = blk0, w.block_stride = blk_stride;
+      w.tape = e.f(p->tf_tape), w.otape = e.f(p->tf_otape), w.F = F0, w.save = e.f(p->tf_save);
+      w.rows = rows, w.BN = e.B * p->Ntok, w.DMF = p->DMF, w.b0 = 0;
+      HDF_TRY(tf_wgrad(w, p->nb, p->M, e.st));
+    }
     HDF_TRY(tf_patch_embed_bwd(d, x, p->D, p->H, p->W, dF, e.grads + p->P("attns.0.patch_embeddings.weight"),
                                e.grads + p->P("attns.0.patch_embeddings.bias"),
                                e.grads + p->P("attns.0.position_embeddings"), scratch, e.st));

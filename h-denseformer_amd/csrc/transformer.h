@@ -83,7 +83,45 @@ int tf_token_fwd(const TfDims& d, const TfTokenFwd& t, int dtype, hipStream_t st
 // -> [OUTB: out_layer backward of block bo] -> [POSTB: ff / ff / to_out backward of layer (bp, lp), before its attention
 // backward].  PREB + POSTB: consecutive layers of one block; PREB + OUTB (+ POSTB): block boundary (lq = 0, bo = bq - 1,
 // POSTB = layer 3 of block bo).  Parameter gradients are accumulated with fp32 atomics.
+// Tape of a dense layer's weight-gradient operands, TF_TAPE_W floats per token (written by the token kernels,
+// contracted over all tokens by tf_wgrad).  Segment-major: segment c of width w is the dense array [rows][w] at float
+// offset rows * c.  Segments:
+constexpr int TF_TAPE_W = 576;
+constexpr int TF_T_DQ = 0;      // [96] dqkv                         (x t       -> to_qkv.weight)
+constexpr int TF_T_T = 96;      // [32] t = LN1(h0)
+constexpr int TF_T_DH0 = 128;   // [32] dh0                          (x F[:, :K] -> Linear0.weight)
+constexpr int TF_T_P1 = 160;    // second ff (on h2): dg [32] | f [64] | dz [64] | u [32]   (dg x f -> net.3, dz x u -> net.0)
+constexpr int TF_T_P0 = 352;    // first ff (on h1):  same layout
+constexpr int TF_T_DGO = 544;   // [32] masked gradient of the to_out output   (x ob -> to_out.weight)
+// a block's out_layer tape (DM + 128 floats per token, segment-major): do [DM] at 0 | f [64] at DM | dz [64] at DM + 64
+// (do x f -> net.3, dz x F -> net.0)
+
+constexpr int TF_WG_ENTRIES = 22;  // 4 layers x 5 matrices + 2 out_layer matrices per block
+struct TfWgradEntry {
+  int64_t poff;        // floats from the block's first parameter to this matrix
+  int O, I, layer;     // O = 0: entry switched off
+  int ysrc, xsrc;      // operand sources: 0 layer tape, 1 block feature buffer, 2 saved ob, 3 block out tape
+  int y0, x0, y1, x1;  // segment (sources 0 / 3) or column (1 / 2) of the (first, second) operand pair; y1 < 0: one pair
+  int yld, xld;        // row pitch of the operands: the segment width (0 / 3), DMF (1), 32 (2)
+};
+struct TfWgradArgs {
+  TfWgradEntry e[TF_WG_ENTRIES];
+  float* grads;                    // modality 0's gradient block base is grads + block0
+  int64_t mstride, block0, block_stride;
+  const float* tape;               // [nb*4][rows][TF_TAPE_W], indexed from block b0
+  const float* otape;              // [nb][rows][DMF]
+  const float* F;                  // [nb][rows][DMF]
+  const float* save;               // [nb*4][rows][232]
+  int64_t rows;                    // M * B * N
+  int BN, DMF, b0;
+};
+// all weight-matrix gradients of blocks [b0, b0 + nblocks) in one launch (overwrites them)
+int tf_wgrad(const TfWgradArgs& a, int nblocks, int M, hipStream_t st);
+
 struct TfTokenBwd {
+  float* tape_pre = nullptr;        // layer (bq, lq)'s tape / layer (bp, lp)'s tape / block bo's out tape: when set the
+  float* tape_post = nullptr;       // weight-matrix gradients are left to tf_wgrad (biases and LayerNorm parameters are
+  float* tape_out = nullptr;        // still accumulated here)
   float* dF = nullptr;              // [rows][DMF] gradient of the (current block's) feature buffer
   const TfLayerP* pre = nullptr;    // layer (bq, lq)
   const TfLayerP* pre_grad = nullptr;

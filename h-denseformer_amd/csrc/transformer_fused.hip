@@ -15,6 +15,8 @@
 // pitch = 4 mod 64 words keeps the 16 rows of a quarter-wave on distinct bank groups).  All weights of the POST and
 // PRE stages are requested at kernel entry (<= 92 registers), so a launch pays one memory round trip, not one per stage.
 // C/D layout: lane holds C[4g + r][i], r = 0..3: bias, dropout mask, GELU and residuals are applied in registers.
+#include <algorithm>
+
 #include "transformer.h"
 
 namespace {
@@ -509,8 +511,26 @@ __device__ __forceinline__ void ln32_bwd(const float* sDu, const float* sXh, flo
   dh1 = rstd * (a1 - m1 - x1 * m2);
 }
 
+// 16-token LDS tile [16][width] -> the tile's rows of tape segment `col0`: a tape is segment-major, segment c of width w
+// is the dense array [rows][w] at float offset rows * c (tf_wgrad then streams whole contiguous rows of a segment; with
+// token-major 576-float rows its 128-byte column slices were 2.3 KB apart and the launch took 358 us)
+__device__ __forceinline__ void tape_store(float* __restrict__ tape, int64_t rows, int col0, const float* sT, int lds_ld,
+                                           int width, int64_t row0, int nvalid) {
+  const int w4 = width >> 2;
+  float* seg = tape + rows * col0 + row0 * width;
+  for (int i = threadIdx.x; i < TT * w4; i += 256) {
+    const int row = i / w4, c4 = (i - row * w4) * 4;
+    if (row < nvalid) *reinterpret_cast<float4*>(seg + i * 4) = *reinterpret_cast<const float4*>(sT + row * lds_ld + c4);
+  }
+}
+
 struct TokBwd {
   TfDims d;
+  // weight-gradient operands go to a tape (tf_wgrad: one batched product per weight matrix over ALL tokens) instead of
+  // per-tile products + fp32 atomics when these are set
+  float* tape_q;   // layer (bq, lq): [rows][TF_TAPE_W]
+  float* tape_p;   // layer (bp, lp)
+  float* otape;    // block bo: [rows][DM + 128]
   // PREB: layer lq of block bq (after its attention backward)
   TfLayerP pq, gq;
   int bq, lq;
@@ -558,6 +578,7 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwd a) {
   const int lrow = threadIdx.x >> 4, lc = (threadIdx.x & 15) * 2;   // the "LayerNorm" thread map: row, 2 columns
   const DropF dr{d.training, d.seed, d.thresh24, d.keep_scale};
   auto tok = [&](int row) { return min(t0 + row, BN - 1); };
+  const int64_t trows = (int64_t)d.M * BN;   // rows of a tape segment
 
   // ------------------------------------------------------------------ requests issued at kernel entry
   const int Kq = PREB ? DM + 32 * a.lq : 0;
@@ -616,7 +637,13 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwd a) {
     // t = LN1(h0) -> s_b, xh -> s_c
     const float rs1 = ln32_keep(s_a, s_b, s_c, ln1);
     __syncthreads();
-    wgrad_tiles(a.gq.wqkv + mo, 96, 32, s_dq, 100, s_b, LD32);
+    const int nvalid = min(TT, BN - t0);
+    if (a.tape_q) {
+      tape_store(a.tape_q, trows, TF_T_DQ, s_dq, 100, 96, rb + t0, nvalid);
+      tape_store(a.tape_q, trows, TF_T_T, s_b, LD32, 32, rb + t0, nvalid);
+    } else {
+      wgrad_tiles(a.gq.wqkv + mo, 96, 32, s_dq, 100, s_b, LD32);
+    }
     {  // dt = dqkv * Wqkv -> s_e
       f32x4 acc = zero4();
       cmma(acc, c_q, s_dq, 100, 24, 12 * (wave >> 1), 12);
@@ -642,7 +669,10 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwd a) {
     colsum_atomic(a.gq.ln1g + mo, 32, s_gx, LD32, 0);
     colsum_atomic(a.gq.ln1b + mo, 32, s_e, LD32, 64);
     colsum_atomic(a.gq.b0 + mo, 32, s_a, LD32, 128);
-    wgrad_tiles(a.gq.w0 + mo, 32, Kq, s_a, LD32, s_F, ldF, 2);
+    if (a.tape_q)
+      tape_store(a.tape_q, trows, TF_T_DH0, s_a, LD32, 32, rb + t0, nvalid);
+    else
+      wgrad_tiles(a.gq.w0 + mo, 32, Kq, s_a, LD32, s_F, ldF, 2);
     // dF[:, 0:Kq] += dh0 * W0 ; the last 32 columns are the complete gradient of feature lq - 1 (POSTB), the first DM
     // ones at lq = 0 the gradient of the block input (OUTB of the previous block)
 #pragma unroll
@@ -718,8 +748,15 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwd a) {
       for (int r = 0; r < 4; r++) s_dz[(4 * g + r) * LD64 + c] = acc[r] * mk[r] * gelu_grad_f(zr[r]);
     }
     __syncthreads();
-    wgrad_tiles(a.go.wb + mo, DM, 64, s_do, ldD, s_f, LD64);
-    wgrad_tiles(a.go.wa + mo, 64, DMF, s_dz, LD64, s_F, ldF, 1);
+    if (a.otape) {
+      const int nv = min(TT, BN - t0);
+      tape_store(a.otape, trows, 0, s_do, ldD, DM, rb + t0, nv);
+      tape_store(a.otape, trows, DM, s_f, LD64, 64, rb + t0, nv);
+      tape_store(a.otape, trows, DM + 64, s_dz, LD64, 64, rb + t0, nv);
+    } else {
+      wgrad_tiles(a.go.wb + mo, DM, 64, s_do, ldD, s_f, LD64);
+      wgrad_tiles(a.go.wa + mo, 64, DMF, s_dz, LD64, s_F, ldF, 1);
+    }
     for (int c0 = 0; c0 < DM; c0 += 128) colsum_atomic(a.go.bb + mo + c0, min(128, DM - c0), s_do + c0, ldD, 0);
     colsum_atomic(a.go.ba + mo, 64, s_dz, LD64, 128);
     // dF[:, 0:DMF] = dz * Wa  (overwrites: the first writer of block bo's feature gradient)
@@ -775,8 +812,16 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwd a) {
         }
       }
       __syncthreads();
-      wgrad_tiles(a.gp.w2 + mo, 32, 64, s_dg, LD32, s_f, LD64);
-      wgrad_tiles(a.gp.w1 + mo, 64, 32, s_dz, LD64, s_b, LD32, 2);
+      if (a.tape_p) {
+        const int nv = min(TT, BN - t0), c0 = pass ? TF_T_P1 : TF_T_P0;
+        tape_store(a.tape_p, trows, c0, s_dg, LD32, 32, rb + t0, nv);
+        tape_store(a.tape_p, trows, c0 + 32, s_f, LD64, 64, rb + t0, nv);
+        tape_store(a.tape_p, trows, c0 + 96, s_dz, LD64, 64, rb + t0, nv);
+        tape_store(a.tape_p, trows, c0 + 160, s_b, LD32, 32, rb + t0, nv);
+      } else {
+        wgrad_tiles(a.gp.w2 + mo, 32, 64, s_dg, LD32, s_f, LD64);
+        wgrad_tiles(a.gp.w1 + mo, 64, 32, s_dz, LD64, s_b, LD32, 2);
+      }
       colsum_atomic(a.gp.b2 + mo, 32, s_dg, LD32, 0);
       colsum_atomic(a.gp.b1 + mo, 64, s_dz, LD64, 64);
       {  // du = dz * W1 -> s_e
@@ -818,7 +863,10 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwd a) {
       a.dh0acc_out[(rb + t) * 32 + lc + 1] = dres1;
     }
     __syncthreads();
-    wgrad_tiles(a.gp.wout + mo, 32, 32, s_dg, LD32, s_b, LD32);
+    if (a.tape_p)
+      tape_store(a.tape_p, trows, TF_T_DGO, s_dg, LD32, 32, rb + t0, min(TT, BN - t0));
+    else
+      wgrad_tiles(a.gp.wout + mo, 32, 32, s_dg, LD32, s_b, LD32);
     colsum_atomic(a.gp.bout + mo, 32, s_dg, LD32, 0);
     {
       f32x4 acc = zero4();
@@ -862,6 +910,89 @@ int launch_tok_fwd(const TokFwd& a, hipStream_t st) {
   return HDF_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ tf_wgrad
+// Every weight-matrix gradient of the transformer branches as ONE launch over the tapes: gW[o][i] = sum over ALL tokens
+// of a modality of dY[t][o] * X[t][i] (+ a second operand pair for the ff weights, which are used twice per layer).
+// A workgroup owns one 32 x 32 tile of one matrix; its four waves split the token range and contract with
+// v_mfma_f32_32x32x2_f32 straight from global memory (a half-wave reads 128 contiguous bytes of a tape row per step),
+// then reduce through LDS in a fixed order: no atomics, bitwise reproducible.
+__global__ __launch_bounds__(256) void tf_wgrad_kernel(TfWgradArgs a) {
+  __shared__ float red[3][32][33];
+  // grid (tiles of one block and modality, blocks, modalities): no empty workgroups, and consecutive workgroup ids --
+  // which the dispatcher deals round-robin to the 8 XCDs -- are different tiles.  (The first version used
+  // grid.x = 16 tile slots per matrix: slot x always landed on XCD x mod 8, XCD 0 received 7.7x the average work and
+  // the launch took 360 us with the matrix pipes 11 % busy.)
+  const int b = blockIdx.y, m = blockIdx.z;
+  int en = 0, tile = blockIdx.x;
+  for (; en < TF_WG_ENTRIES - 1; en++) {
+    const int nt = (a.e[en].O >> 5) * (a.e[en].I >> 5);
+    if (tile < nt) break;
+    tile -= nt;
+  }
+  const TfWgradEntry& e = a.e[en];
+  const int ti = e.I >> 5;
+  const int to = tile / ti, o0 = to * 32, i0 = (tile - to * ti) * 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int64_t row0 = (int64_t)m * a.BN;
+  const int bb = a.b0 + b;
+  // operand sources: 0 a segment of the layer's tape, 1 the block's feature buffer, 2 the layer's saved ob, 3 a segment of
+  // the block's out tape; (off, ld) = (segment column, segment width) for 0 / 3, (column, row pitch) for 1 / 2
+  auto base = [&](int src, int off) -> const float* {
+    switch (src) {
+      case 0: return a.tape + ((int64_t)(bb * 4 + e.layer) * TF_TAPE_W + off) * a.rows;
+      case 1: return a.F + ((int64_t)bb * a.rows) * a.DMF + off;
+      case 2: return a.save + ((int64_t)(bb * 4 + e.layer) * a.rows) * 232 + a.rows * 128 + off;
+      default: return a.otape + ((int64_t)bb * a.DMF + off) * a.rows;
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; i++) acc[i] = 0.f;
+  const int per = (a.BN + 3) / 4, t_lo = wave * per, t_hi = min(a.BN, t_lo + per);
+#pragma unroll
+  for (int pair = 0; pair < 2; pair++) {
+    if (pair == 1 && e.y1 < 0) break;
+    const int ldy = e.yld, ldx = e.xld;
+    const float* py = base(e.ysrc, pair ? e.y1 : e.y0) + row0 * ldy + o0 + r;
+    const float* px = base(e.xsrc, pair ? e.x1 : e.x0) + row0 * ldx + i0 + r;
+    constexpr int UN = 8;  // 16 loads per lane per batch; the next batch is requested before this batch's MFMAs
+    float ya[UN], xa[UN], yn[UN], xn[UN];
+    auto load = [&](float (&y)[UN], float (&x)[UN], int t) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < UN; u++) {
+        const int tt = min(t + 2 * u + h, a.BN - 1);
+        y[u] = py[(int64_t)tt * ldy];
+        x[u] = px[(int64_t)tt * ldx];
+      }
+    };
+    load(ya, xa, t_lo);
+    for (int t = t_lo; t < t_hi; t += 2 * UN) {
+      load(yn, xn, t + 2 * UN);
+#pragma unroll
+      for (int u = 0; u < UN; u++) {
+        const bool live = t + 2 * u + h < t_hi;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(live ? ya[u] : 0.f, xa[u], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < UN; u++) ya[u] = yn[u], xa[u] = xn[u];
+    }
+  }
+  // fixed-order reduction over the four waves; accumulator i of a lane: row (i & 3) + 8 (i >> 2) + 4 h, column r
+  if (wave > 0) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) red[wave - 1][(i & 3) + 8 * (i >> 2) + 4 * h][r] = acc[i];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float* gW = a.grads + (int64_t)m * a.mstride + a.block0 + (int64_t)b * a.block_stride + e.poff;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+      gW[(int64_t)(o0 + row) * e.I + i0 + r] = ((acc[i] + red[0][row][r]) + red[1][row][r]) + red[2][row][r];
+    }
+  }
+}
+
 template <bool PREB, bool OUTB, bool POSTB, typename T>
 int launch_tok_bwd(const TokBwd& a, hipStream_t st) {
   const TfDims& d = a.d;
@@ -876,11 +1007,21 @@ int launch_tok_bwd(const TokBwd& a, hipStream_t st) {
 
 }  // namespace
 
+int tf_wgrad(const TfWgradArgs& a, int nblocks, int M, hipStream_t st) {
+  int tiles = 0;
+  for (int k = 0; k < TF_WG_ENTRIES; k++) tiles += (a.e[k].O >> 5) * (a.e[k].I >> 5);
+  HDF_CHECK_ARG(tiles > 0 && a.e[TF_WG_ENTRIES - 1].O > 0, "tf_wgrad: empty entry table");
+  hipLaunchKernelGGL(tf_wgrad_kernel, dim3(tiles, nblocks, M), dim3(256), 0, st, a);
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
 int tf_token_bwd(const TfDims& d, const TfTokenBwd& t, int dtype, hipStream_t st) {
   HDF_CHECK_ARG(d.DM % 32 == 0 && d.DM >= 32 && d.DM <= 256, "token kernel: token dim %d unsupported", d.DM);
   TokBwd a{};
   a.d = d;
   a.dF = t.dF;
+  a.tape_q = t.tape_pre, a.tape_p = t.tape_post, a.otape = t.tape_out;
   if (t.pre) {
     a.pq = *t.pre, a.gq = *t.pre_grad, a.bq = t.bq, a.lq = t.lq;
     a.Fq = t.F_pre, a.h0 = t.pre_save.h0, a.dqkv = t.dqkv, a.dh0acc = t.dh0acc;
