@@ -180,7 +180,10 @@ struct hdf_plan {
   // backward scratch
   View gA[4], gY[4], dCat[3], dUp[3], dSkip[3], dP[3], dUa[4], dUy[4], dX4, dAttnall;
   bool dcat_split[3] = {false, false, false};
-  bool materialise_at3 = getenv("HDF_MATERIALISE_AT3") != nullptr;
+  // at3 (the full-resolution transformer feature) is written by upsample_fwd and read by the plain encoder tail; with the
+  // 27-loads-per-8-outputs upsample kernel that is 0.09 ms per step faster than HDF_FUSE_AT3=1 (the tail interpolating it
+  // on the fly from up3's raw output: VALU-bound with register spills), at the price of 268 MB of workspace at batch 2
+  bool materialise_at3 = getenv("HDF_FUSE_AT3") == nullptr;
   bool no_head_fuse = getenv("HDF_NO_HEAD_FUSE") != nullptr;  // A/B knob: separate in_bwd_reduce after the heads
   bool no_bias_fuse = getenv("HDF_NO_BIAS_FUSE") != nullptr;  // A/B knob: separate pass for the ConvTranspose3d bias gradients
   // ---- 2-D model (models/HDenseFormer_2D.py) run as its exact depth-replicated 3-D embedding (see embed2d below)
@@ -461,8 +464,6 @@ void layout(hdf_plan* p, int B) {
   for (int k = 0; k < 3; k++) conv_bufs(p->up[k]);
   p->at[2] = mkview(p, bp, "at1", 2, 4 * nf, B);
   p->at[1] = mkview(p, bp, "at2", 1, 2 * nf, B);
-  // at3 (full resolution): by default never materialised (the encoder tail interpolates it on the fly from up3's raw
-  // output); HDF_MATERIALISE_AT3=1 (A/B knob) writes it with upsample_fwd and runs the plain encoder tail
   p->at[0] = p->materialise_at3 ? mkview(p, bp, "at3", 0, nf, B) : View();
   for (int k = 0; k < 4; k++) {
     conv_bufs(p->enc[k][0]);
