@@ -1823,6 +1823,253 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// conv_wgrad_s2: 16-bit STRIDE-2 weight gradient (ConvTranspose3d: small = its input x, large = dy), double-buffered
+// through LDS-DMA.  conv_wgrad_kernel<.,4,4,4,2> issued ~620 VALU instructions per tile and wave (per-slot div/mod,
+// 64-bit addresses and bounds tests of 13 staging slots) for 28 MFMAs, with one tile of loads in flight and the LDS
+// commit serialised with the MFMAs: 9 % matrix-pipe utilisation.  Here
+//  * a workgroup owns SB = 2 small-channel blocks: a staged dy box and every B fragment feed two MFMAs (half the
+//    L2->LDS bytes and LDS reads per FLOP).  The 2 x 7 x 16 accumulators fill the AGPR file, so nothing is staged through
+//    registers: every 16-byte slot is a global_load_lds_dwordx4 (lane-linear LDS image = consecutive 64-byte rows,
+//    4 lanes per row), slots outside the tensor / beyond the channel count read a zero line instead;
+//  * tile t+1 is in flight while tile t is under the MFMAs (two LDS buffers, one barrier per tile); slot offsets are
+//    per-thread constants (32-bit offsets from a per-tile origin);
+//  * the InstanceNorm/ReLU transform of x is applied in place by the thread that loaded the chunk (its own 16 bytes
+//    are visible to it once vmcnt says so; the small-operand loads are issued first, so they retire first);
+//  * the 9x9x9 dy box is stored with each x-line split into even then odd positions: the 4 voxels a transposed
+//    read addresses (2 apart in x) are then 4 consecutive 64-byte rows = all 64 banks once, without row padding.
+// Tile = 4x4x4 small voxels (whole tiles only: launcher check); wave w owns taps 7w..7w+6 (27 + one dummy).
+__device__ __attribute__((aligned(16))) uint32_t g_zero_line[4] = {0u, 0u, 0u, 0u};
+
+template <typename T, int SB>
+__global__ __launch_bounds__(256) void conv_wgrad_s2_kernel(WgradArgs a) {
+  static_assert(sizeof(T) == 2, "16-bit storage only");
+  constexpr int MT = 64, BX = 9, BOXL = BX * BX * BX;
+  constexpr int LP = 64, CPV = 4, EPC = 8;
+  constexpr int NL_ = (BOXL * CPV + 255) / 256, NSLOT = SB + NL_;
+  constexpr int SBUF = SB * MT * LP, LBUF = NL_ * 256 * 16, BUF = SBUF + LBUF;  // the last slot's tail lanes land in padding
+  constexpr int KS = MT / 16, NT = 7;  // k-steps per tile, taps per wave
+  static_assert(NSLOT <= 32, "slot validity bits");
+  __shared__ __attribute__((aligned(256))) char lds[2 * BUF + SB * 64 * 4];
+  float* const s_xf = reinterpret_cast<float*>(lds + 2 * BUF);  // [SB*32 scale][SB*32 shift] of the small operand
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int scb = blockIdx.y, lcb = blockIdx.z;
+  const int part = tid & (CPV - 1), v0 = tid >> 2;
+  const int ntz = a.Ds / 4, nty = a.Hs / 4, ntx = a.Ws / 4;
+  const bool xfs = a.sm_scale != nullptr;
+  const float relu_lo = (xfs && a.sm_relu) ? 0.f : -INFINITY;
+
+  // ---- transposed-read addresses (lane roles of ds_read_b64_tr_b16: 4 voxels x 16 channels per 16 lanes).  Voxel
+  // lin = 16 ks + 8 hh + 4 tt + q of the tile is (lz, ly, lx) = (ks, 2 hh + tt, q); k-step and tt are immediates,
+  // the buffer parity is folded into the registers (toggled once per tile)
+  const int g4 = lane >> 4, i16 = lane & 15, q = i16 >> 2, p4 = i16 & 3;
+  const int hh = g4 >> 1, cb = (g4 & 1) * 16;
+  const int colb = (cb + 4 * p4) * 2;
+  int sA = (8 * hh + q) * LP + colb;
+  int lB[NT];
+#pragma unroll
+  for (int j = 0; j < NT; j++) {
+    int tap = wave * NT + j;
+    if (tap >= 27) tap = 0;  // dummy slot of the last wave (never stored)
+    const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+    const int pb = kx == 0 ? 0 : (kx == 1 ? 5 : 1);  // line position of box x = kx (even x first: 0,2,4,6,8,1,3,5,7)
+    lB[j] = SBUF + ((kz * BX + 4 * hh + ky) * BX + pb + q) * LP + colb;
+  }
+  const int ntaps_here = min(NT, 27 - wave * NT);
+
+  // ---- staging slots (per-thread constants): slot s < SB -> channel block s of small voxel v0, else box row
+  // v0 + 64 (s - SB).  Only the LOW faces of a box can leave the tensor (whole tiles, Dl = 2 Ds): emz/emy/emx flag
+  // the slots on them; chan_ok the slots whose channels (and box row) exist.
+  const int s_goff = ((((v0 >> 4) * a.Hs) + ((v0 >> 2) & 3)) * a.Ws + (v0 & 3)) * (int)a.sm_pitch;
+  int goffL[NL_];
+  uint32_t emz = 0, emy = 0, emx = 0, chan_ok = 0;
+  const bool lc_ok = lcb * 32 + part * EPC < a.LC;
+#pragma unroll
+  for (int k = 0; k < NL_; k++) {
+    const int row = v0 + 64 * k;  // LDS row
+    const int rc = min(row, BOXL - 1);
+    const int line = rc / BX, pos = rc - line * BX;
+    const int bx = pos < 5 ? 2 * pos : 2 * pos - 9, by = line % BX, bz = line / BX;
+    goffL[k] = ((bz * a.Hl + by) * a.Wl + bx) * (int)a.lg_pitch;
+    emz |= (bz == 0 ? 1u : 0u) << (SB + k);
+    emy |= (by == 0 ? 1u : 0u) << (SB + k);
+    emx |= (bx == 0 ? 1u : 0u) << (SB + k);
+    chan_ok |= ((lc_ok && row < BOXL) ? 1u : 0u) << (SB + k);
+  }
+#pragma unroll
+  for (int b = 0; b < SB; b++) chan_ok |= ((scb * SB + b) * 32 + part * EPC < a.SC ? 1u : 0u) << b;
+  const T* const zero_src = reinterpret_cast<const T*>(g_zero_line);
+  const T* const s_src = reinterpret_cast<const T*>(a.sm) + scb * SB * 32 + part * EPC;
+  const T* const l_src = reinterpret_cast<const T*>(a.lg) + lcb * 32 + part * EPC;
+
+  struct Tl {
+    int n, z0, y0, x0;
+  };
+  auto decode = [&](int t, Tl& c) {
+    c.x0 = (t % ntx) * 4;
+    t /= ntx;
+    c.y0 = (t % nty) * 4;
+    t /= nty;
+    c.z0 = (t % ntz) * 4;
+    c.n = t / ntz;
+  };
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  // all slots of one tile, small operand first (its loads retire first: vmcnt(NL_) = "my x chunks have landed")
+  auto issue_tile = [&](const Tl& c, int buf_off) __attribute__((always_inline)) {
+    const T* const sorg = s_src + ((((int64_t)c.n * a.Ds + c.z0) * a.Hs + c.y0) * a.Ws + c.x0) * a.sm_pitch + s_goff;
+    // box origin; may lie before the tensor (those slots read the zero line)
+    const T* const lorg =
+        l_src + ((((int64_t)c.n * a.Dl + (2 * c.z0 - 1)) * a.Hl + (2 * c.y0 - 1)) * a.Wl + (2 * c.x0 - 1)) * a.lg_pitch;
+    const uint32_t off = (c.z0 == 0 ? emz : 0u) | (c.y0 == 0 ? emy : 0u) | (c.x0 == 0 ? emx : 0u);
+    const uint32_t m = chan_ok & ~off;
+    // wave-uniform LDS byte address of slot 0 (+ lane * 16 by the hardware)
+    const uint32_t wbase = __builtin_amdgcn_readfirstlane(lds_base + buf_off + wave * 1024);
+#pragma unroll
+    for (int s = 0; s < NSLOT; s++) {
+      const bool ok = (m >> s) & 1u;
+      const T* p = (s < SB) ? sorg + s * 32 : lorg + goffL[s < SB ? 0 : s - SB];
+      p = ok ? p : zero_src;
+      // inline asm on purpose: hipcc drains a builtin LDS-DMA (vmcnt(0)) in front of the next LDS read of ANY buffer;
+      // these are counted by hand (s_waitcnt vmcnt below).  M0 = LDS destination, saved and restored per statement.
+      uint32_t keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep)
+                   : "v"(p), "s"(wbase + (uint32_t)(s < SB ? s * MT * LP : SBUF + (s - SB) * 4096))
+                   : "memory");
+    }
+  };
+  int tbl_n = -1;
+  auto refresh_xf = [&](int n) {  // uniform
+    __syncthreads();              // nobody still reads the previous table
+    if (tid < SB * 32) {
+      const int c = scb * SB * 32 + tid;
+      const bool live = c < a.SC;  // channels past the end stay exactly zero under the transform
+      s_xf[tid] = live ? a.sm_scale[(int64_t)n * a.SC + c] : 0.f;
+      s_xf[SB * 32 + tid] = live ? a.sm_shift[(int64_t)n * a.SC + c] : 0.f;
+    }
+    tbl_n = n;
+    __syncthreads();
+  };
+  // x*scale+shift (+relu) on this thread's own chunks of the small tile in buffer buf_off
+  auto transform_own = [&](int buf_off) __attribute__((always_inline)) {
+#pragma unroll
+    for (int b = 0; b < SB; b++) {
+      u32x4* const slot = reinterpret_cast<u32x4*>(lds + buf_off + b * MT * LP + tid * 16);
+      float f[EPC];
+      ST<T>::unpack(*slot, f);
+      const float* tb = s_xf + b * 32 + part * EPC;
+#pragma unroll
+      for (int e = 0; e < EPC; e += 4) {
+        const f32x4 u = *reinterpret_cast<const f32x4*>(tb + e);
+        const f32x4 w = *reinterpret_cast<const f32x4*>(tb + SB * 32 + e);
+#pragma unroll
+        for (int k = 0; k < 4; k++) f[e + k] = fmaxf(f[e + k] * u[k] + w[k], relu_lo);
+      }
+      *slot = ST<T>::pack(f);
+    }
+  };
+
+  f32x16 acc[SB][NT];
+#pragma unroll
+  for (int b = 0; b < SB; b++)
+#pragma unroll
+    for (int j = 0; j < NT; j++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) acc[b][j][i] = 0.f;
+
+  const int t_begin = blockIdx.x * a.tiles_per_group;
+  const int t_end = min(a.num_tiles, t_begin + a.tiles_per_group);
+  if (t_begin < t_end) {
+    using lds_s16x4 = s16x4 __attribute__((address_space(3)));
+    auto tr_read = [&](int off) {
+      s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + off));
+      return __builtin_bit_cast(u32x2, v);
+    };
+    Tl T1;
+    decode(t_begin, T1);
+    if (xfs) refresh_xf(T1.n);
+    issue_tile(T1, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (xfs) transform_own(0);
+    WS_BARRIER();
+    int wr_off = BUF;  // byte offset of the buffer being filled (the other one is read)
+    for (int t = t_begin; t < t_end; t++) {
+      const bool v1 = t + 1 < t_end;
+      if (v1) {  // uniform
+        decode(t + 1, T1);
+        issue_tile(T1, wr_off);
+      }
+      u32x2 A0[2][SB], A1[2][SB], B0[NT], B1[NT];
+      auto read_a = [&](int ks) {
+#pragma unroll
+        for (int b = 0; b < SB; b++) {
+          A0[ks & 1][b] = tr_read(sA + b * MT * LP + ks * 16 * LP);
+          A1[ks & 1][b] = tr_read(sA + b * MT * LP + ks * 16 * LP + 4 * LP);
+        }
+      };
+      auto read_b = [&](int ks, int j) {
+        B0[j] = tr_read(lB[j] + ks * 2 * BX * BX * LP);
+        B1[j] = tr_read(lB[j] + ks * 2 * BX * BX * LP + 2 * BX * LP);
+      };
+      read_a(0);
+#pragma unroll
+      for (int j = 0; j < NT; j++) read_b(0, j);
+#pragma unroll
+      for (int ks = 0; ks < KS; ks++) {
+        if (ks + 1 < KS) read_a(ks + 1);
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+          const u32x4 bf = {B0[j][0], B0[j][1], B1[j][0], B1[j][1]};
+#pragma unroll
+          for (int b = 0; b < SB; b++) {
+            const u32x4 af = {A0[ks & 1][b][0], A0[ks & 1][b][1], A1[ks & 1][b][0], A1[ks & 1][b][1]};
+            Mma<T>::run(af, bf, acc[b][j]);
+          }
+          if (ks + 1 < KS) read_b(ks + 1, j);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (xfs && v1) {
+        if (T1.n != tbl_n) refresh_xf(T1.n);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL_) : "memory");  // this thread's x chunks of tile t+1 have landed
+        transform_own(wr_off);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      WS_BARRIER();  // one buffer fully read, the other fully written
+#pragma unroll
+      for (int b = 0; b < SB; b++)
+#pragma unroll
+        for (int j = 0; j < NT; j++) asm volatile("" : "+a"(acc[b][j]));  // loop-carried accumulators stay in AGPRs
+      // swap the buffers (the read addresses carry the parity)
+      const int d = wr_off ? BUF : -BUF;
+      sA += d;
+#pragma unroll
+      for (int j = 0; j < NT; j++) lB[j] += d;
+      wr_off = BUF - wr_off;
+    }
+  }
+
+  // partial[g][tap][SCp][LCp]
+  const int col = lane & 31, hh2 = lane >> 5;
+#pragma unroll
+  for (int b = 0; b < SB; b++) {
+    if ((scb * SB + b) * 32 >= a.SCp) continue;
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+      if (j < ntaps_here) {
+        const int tap = wave * NT + j;
+        float* base = a.partials + (((int64_t)blockIdx.x * 27 + tap) * a.SCp + (scb * SB + b) * 32) * a.LCp + lcb * 32 + col;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          const int row = (i & 3) + 8 * (i >> 2) + 4 * hh2;
+          base[(int64_t)row * a.LCp] = acc[b][j][i];
+        }
+      }
+    }
+  }
+}
+
 // out[(sc*LC + lc)*27 + tap] (+)= sum_g partial[g][tap][sc][lc].  256 threads = 8 group-lanes x 32 entries; fixed
 // summation order (bitwise reproducible)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw,
@@ -1984,7 +2231,14 @@ int launch_wgrad_t(WgradArgs a, float* dw, int sc_store, int lc_store, int accum
   a.SCp = round_up(a.SC, 32);
   a.LCp = round_up(a.LC, 32);
   a.num_tiles = a.N * ceil_div(a.Ds, TD) * ceil_div(a.Hs, TH) * ceil_div(a.Ws, TW);
-  const int pairs = (a.SCp / 32) * (a.LCp / 32);
+  // 16-bit stride 2 without a transform of the large operand: conv_wgrad_s2_kernel, SB small-channel blocks per workgroup
+  static const bool s2_old = getenv("HDF_WGRAD_S2_OLD") != nullptr;  // A/B knob
+  const bool use_s2 = sizeof(T) == 2 && S == 2 && !a.lg_scale && !s2_old && a.Ds % 4 == 0 && a.Hs % 4 == 0 &&
+                      a.Ws % 4 == 0 && a.Dl == 2 * a.Ds && a.Hl == 2 * a.Hs && a.Wl == 2 * a.Ws;
+  static const int s2_sb = getenv("HDF_WGRAD_S2_SB") ? atoi(getenv("HDF_WGRAD_S2_SB")) : 2;  // tuning knob
+  const int sb = (use_s2 && a.SCp >= 64 && s2_sb == 2) ? 2 : 1;
+  const int sblocks = ceil_div(a.SCp / 32, sb);
+  const int pairs = sblocks * (a.LCp / 32);
   const int64_t per = (int64_t)27 * a.SCp * a.LCp * sizeof(float);
   static const int wg_new = getenv("HDF_WGRAD_WGS") ? atoi(getenv("HDF_WGRAD_WGS")) : 256;  // one workgroup per CU
   // the single-buffered kernel (stride 2, f32) hides its staging only behind other workgroups of the same CU
@@ -2000,7 +2254,15 @@ int launch_wgrad_t(WgradArgs a, float* dw, int sc_store, int lc_store, int accum
   HDF_CHECK_ARG((size_t)(G * per) <= ws_bytes, "wgrad workspace too small: need %lld have %zu", (long long)(G * per),
                 ws_bytes);
   a.partials = reinterpret_cast<float*>(ws);
-  dim3 grid(G, a.SCp / 32, a.LCp / 32);
+  dim3 grid(G, sblocks, a.LCp / 32);
+  if constexpr (sizeof(T) == 2 && S == 2) {
+    if (use_s2) {
+      if (sb == 2)
+        hipLaunchKernelGGL((conv_wgrad_s2_kernel<T, 2>), grid, dim3(256), 0, st, a);
+      else
+        hipLaunchKernelGGL((conv_wgrad_s2_kernel<T, 1>), grid, dim3(256), 0, st, a);
+    }
+  }
   if constexpr (sizeof(T) == 2 && S == 1) {
     if (use_new) {  // HDF_WGRAD_OLD=1 (A/B knob): single-buffered conv_wgrad_kernel everywhere
       if (a.lg_scale)
@@ -2009,7 +2271,7 @@ int launch_wgrad_t(WgradArgs a, float* dw, int sc_store, int lc_store, int accum
         hipLaunchKernelGGL((conv_wgrad2_kernel<T, false>), grid, dim3(256), 0, st, a);
     }
   }
-  if (!use_new) {
+  if (!use_new && !use_s2) {
     hipLaunchKernelGGL((conv_wgrad_kernel<T, TD, TH, TW, S>), grid, dim3(256), 0, st, a);
   }
   HDF_LAUNCH_CHECK();

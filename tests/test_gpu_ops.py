@@ -108,14 +108,14 @@ def test_conv3d_stride2(dtype, cin, cout, size):
     assert rel_err(from_cl(out), ref) < TOL[dtype]
 
 
-def _wgrad(dtype, stride, s_cl, sc, l_cl, lc, dims, sc_store, lc_store):
+def _wgrad(dtype, stride, s_cl, sc, l_cl, lc, dims, sc_store, lc_store, s_scale=None, s_shift=None, s_relu=0):
     n = s_cl.shape[0]
     wsb = lib().hdf_op_wgrad_workspace_bytes(stride, n, *dims, sc, lc)
     ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
     dw = torch.zeros((sc_store, lc_store, 27), dtype=torch.float32, device=DEV)
     check(lib().hdf_op_conv3d_wgrad(dtype, stride, ptr(s_cl), s_cl.shape[-1], sc, ptr(l_cl), l_cl.shape[-1], lc, n,
-                                    *dims, None, None, 0, None, None, 0, ptr(dw), sc_store, lc_store, 0, ptr(ws), wsb,
-                                    st()), "wgrad")
+                                    *dims, ptr(s_scale), ptr(s_shift), s_relu, None, None, 0, ptr(dw), sc_store, lc_store,
+                                    0, ptr(ws), wsb, st()), "wgrad")
     torch.cuda.synchronize()
     return dw.cpu()
 
@@ -153,6 +153,28 @@ def test_conv_transpose3d_wgrad(dtype, cin, cout, size):
     w = torch.zeros(cin, cout, 3, 3, 3, requires_grad=True)
     F.conv_transpose3d(rnd(x, dtype), w, None, stride=2, padding=1, output_padding=1).backward(rnd(dy, dtype))
     got = _wgrad(dtype, 2, to_cl(x, dtype), cin, to_cl(dy, dtype), cout, size, cin, cout).view(cin, cout, 3, 3, 3)
+    assert rel_err(got, w.grad) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [BF16, F16])
+@pytest.mark.parametrize("cin,cout,size,n", [(64, 32, (8, 12, 16), 2), (96, 48, (8, 8, 8), 1), (128, 64, (16, 16, 16), 3),
+                                            (32, 32, (20, 8, 12), 2), (64, 16, (4, 4, 8), 1)])
+@pytest.mark.parametrize("xf", [0, 1])
+def test_conv_transpose3d_wgrad_whole_tiles(dtype, cin, cout, size, n, xf):
+    """Extents that are multiples of 4: the double-buffered stride-2 kernel (one and two input-channel blocks per
+    workgroup, partial channel blocks, several tiles per workgroup and samples), without / with the InstanceNorm+ReLU
+    transform of the transposed conv's input."""
+    osz = tuple(2 * s for s in size)
+    x, dy = _mk((n, cin) + size, 27), _mk((n, cout) + osz, 28)
+    sc = (torch.rand(n, cin, generator=torch.Generator().manual_seed(29)) + 0.5) if xf else None
+    sh = (torch.randn(n, cin, generator=torch.Generator().manual_seed(30)) * 0.3) if xf else None
+    xin = rnd(x, dtype)
+    if xf:
+        xin = rnd(torch.relu(xin * sc[:, :, None, None, None] + sh[:, :, None, None, None]), dtype)
+    w = torch.zeros(cin, cout, 3, 3, 3, requires_grad=True)
+    F.conv_transpose3d(xin, w, None, stride=2, padding=1, output_padding=1).backward(rnd(dy, dtype))
+    got = _wgrad(dtype, 2, to_cl(x, dtype), cin, to_cl(dy, dtype), cout, size, cin, cout,
+                 sc.to(DEV) if xf else None, sh.to(DEV) if xf else None, xf).view(cin, cout, 3, 3, 3)
     assert rel_err(got, w.grad) < TOL[dtype]
 
 
