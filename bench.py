@@ -256,7 +256,8 @@ def main():
         evs[k + 1].record()
     fence()
     dt = time.perf_counter() - t0
-    per_step = sorted(evs[k].elapsed_time(evs[k + 1]) for k in range(a.steps))
+    raw_steps = [evs[k].elapsed_time(evs[k + 1]) for k in range(a.steps)]
+    per_step = sorted(raw_steps)
     median_ms = per_step[len(per_step) // 2]
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -276,7 +277,8 @@ def main():
                        "global_batch": global_batch, "per_gpu_batch": a.batch, "parallelism": f"dp{world}",
                        "dropout": "on (train mode)", "loss": last_loss},
             "step_tflops": FWD_BWD_GFLOP_PER_SAMPLE * sps / 1e3,
-            "hip_event_ms_per_step": {"median": median_ms, "min": per_step[0], "max": per_step[-1]},
+            "hip_event_ms_per_step": {"median": median_ms, "min": per_step[0], "max": per_step[-1],
+                                      "slowest_step": raw_steps.index(per_step[-1])},
         }
         if world == 1:
             rec["roofline"] = roofline_dominant_kernel(dev)

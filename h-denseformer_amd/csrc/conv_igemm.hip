@@ -2070,34 +2070,37 @@ __global__ __launch_bounds__(256) void conv_wgrad_s2_kernel(WgradArgs a) {
   }
 }
 
-// out[(sc*LC + lc)*27 + tap] (+)= sum_g partial[g][tap][sc][lc].  256 threads = 8 group-lanes x 32 entries; fixed
-// summation order (bitwise reproducible)
+// out[(sc*LC + lc)*27 + tap] (+)= sum_g partial[g][tap][sc][lc].  256 threads = 32 group-lanes x 8 lanes of 4 entries
+// (16-byte loads; a workgroup owns 32 consecutive entries = one 128-byte line per slab); fixed summation order
+// (bitwise reproducible)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw,
                                                            int G, int SCp, int LCp, int SC, int LC, int accumulate) {
-  __shared__ float red[8][32];
-  const int el = threadIdx.x & 31, gl = threadIdx.x >> 5;
-  const int64_t idx = (int64_t)blockIdx.x * 32 + el;
-  const int64_t per = (int64_t)27 * SCp * LCp;
-  float s = 0.f;
-  if (idx < per) {
-    int g = gl;
-    for (; g + 24 < G; g += 32) {
-      float a0 = partials[(int64_t)g * per + idx], a1 = partials[(int64_t)(g + 8) * per + idx];
-      float a2 = partials[(int64_t)(g + 16) * per + idx], a3 = partials[(int64_t)(g + 24) * per + idx];
-      s += (a0 + a1) + (a2 + a3);
-    }
-    for (; g < G; g += 8) s += partials[(int64_t)g * per + idx];
+  __shared__ float red[32][36];
+  const int e4 = threadIdx.x & 7, gl = threadIdx.x >> 3;
+  const int64_t per = (int64_t)27 * SCp * LCp;  // a multiple of 32
+  const float* src = partials + (int64_t)blockIdx.x * 32 + e4 * 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  int g = gl;
+  for (; g + 32 < G; g += 64) {
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(src + (int64_t)g * per);
+    const f32x4 a1 = *reinterpret_cast<const f32x4*>(src + (int64_t)(g + 32) * per);
+    s += a0 + a1;
   }
-  red[gl][el] = s;
+  if (g < G) s += *reinterpret_cast<const f32x4*>(src + (int64_t)g * per);
+  *reinterpret_cast<f32x4*>(&red[gl][e4 * 4]) = s;
   __syncthreads();
-  if (gl == 0 && idx < per) {
-    for (int k = 1; k < 8; k++) s += red[k][el];
-    int lc = idx % LCp;
-    int sc = (idx / LCp) % SCp;
-    int tap = idx / ((int64_t)LCp * SCp);
+  if (threadIdx.x < 32) {
+    const int el = threadIdx.x;
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; k++) t += red[k][el];
+    const int64_t idx = (int64_t)blockIdx.x * 32 + el;
+    const int lc = idx % LCp;
+    const int sc = (idx / LCp) % SCp;
+    const int tap = idx / ((int64_t)LCp * SCp);
     if (lc < LC && sc < SC) {
       float* o = dw + ((int64_t)sc * LC + lc) * 27 + tap;
-      *o = accumulate ? (*o + s) : s;
+      *o = accumulate ? (*o + t) : t;
     }
   }
 }
