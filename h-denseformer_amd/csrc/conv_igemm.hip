@@ -2105,6 +2105,33 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// The same reduction for FEW slabs and a LARGE matrix (the low-resolution layers: G <= 8, up to 27 x 512 x 512
+// entries).  There the cost is the transposed store (4-byte writes 108 bytes apart: 7 M sectors for 512 x 512), not
+// the slab reads: a workgroup owns one sc row x 32 lc columns x all 27 taps, sums into LDS and writes the 864 outputs
+// as one contiguous run.
+__global__ __launch_bounds__(256) void wgrad_reduce_rows_kernel(const float* __restrict__ partials,
+                                                                float* __restrict__ dw, int G, int SCp, int LCp, int SC,
+                                                                int LC, int accumulate) {
+  __shared__ float red[27][33];
+  const int sc = blockIdx.y, lc0 = blockIdx.x * 32;
+  const int64_t per = (int64_t)27 * SCp * LCp;
+  for (int i = threadIdx.x; i < 27 * 32; i += 256) {
+    const int tap = i >> 5, l = i & 31;
+    const float* src = partials + ((int64_t)tap * SCp + sc) * LCp + lc0 + l;
+    float s = 0.f;
+    for (int g = 0; g < G; g++) s += src[(int64_t)g * per];
+    red[tap][l] = s;
+  }
+  __syncthreads();
+  if (sc >= SC) return;
+  float* const out = dw + ((int64_t)sc * LC + lc0) * 27;
+  const int n_out = min(32, LC - lc0) * 27;
+  for (int j = threadIdx.x; j < n_out; j += 256) {
+    const int l = j / 27, tap = j - l * 27;
+    out[j] = accumulate ? out[j] + red[tap][l] : red[tap][l];
+  }
+}
+
 // dst[t][o][i] = src[o*so + i*si + (flip ? 26-t : t)]  (zero for o>=O or i>=I); dst is [27][OP][IP]
 template <typename T>
 __global__ void pack_w_kernel(const float* __restrict__ src, T* __restrict__ dst, int O, int I, int OP, int IP,
@@ -2279,8 +2306,12 @@ int launch_wgrad_t(WgradArgs a, float* dw, int sc_store, int lc_store, int accum
   }
   HDF_LAUNCH_CHECK();
   int64_t n = (int64_t)27 * a.SCp * a.LCp;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div64(n, 32)), dim3(256), 0, st, a.partials, dw, G,
-                     a.SCp, a.LCp, sc_store, lc_store, accumulate);
+  if (G <= 8)
+    hipLaunchKernelGGL(wgrad_reduce_rows_kernel, dim3(a.LCp / 32, a.SCp), dim3(256), 0, st, a.partials, dw, G, a.SCp,
+                       a.LCp, sc_store, lc_store, accumulate);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div64(n, 32)), dim3(256), 0, st, a.partials, dw, G,
+                       a.SCp, a.LCp, sc_store, lc_store, accumulate);
   HDF_LAUNCH_CHECK();
   return HDF_OK;
 }

@@ -982,6 +982,96 @@ __global__ __launch_bounds__(256) void patch_embed_fwd_kernel(TfDims d, const fl
   }
 }
 
+// Round-2 form: operands straight from global memory, no barrier in the main loop.  A workgroup owns 32 tokens x 64
+// columns (grid = token tiles x DM/64 x modalities: 256 workgroups at the benchmark size; the LDS-staged kernel above
+// had 128 and re-staged the whole 2 MB weight matrix of a modality in each).  The four waves SPLIT K: wave w contracts
+// the 64-deep chunks c = w (mod 4) for the whole 32 x 64 tile (2 x 4 tiles of v_mfma_f32_16x16x4_f32), so no operand is
+// loaded twice inside a workgroup (giving each wave 16 of the columns instead loaded the token rows four times and
+// kept the vector-memory pipe, not the matrix pipe, busy: 73 us); the four partial tiles meet in LDS once, in a fixed
+// order.  The contraction order is free, so lane group g = lane >> 4 owns k in [16 g, 16 g + 16) of a chunk: its A
+// operands are 64 contiguous bytes of one brick row of its token, its B operands 64 contiguous bytes of one row of the
+// Conv3d weight (float4 loads), prefetched one chunk (128 MFMAs = 4096 cycles) ahead.
+__global__ __launch_bounds__(256) void patch_embed_fwd2_kernel(TfDims d, const float* __restrict__ x, int D, int H,
+                                                               int W, const float* __restrict__ wpe,
+                                                               const float* __restrict__ bpe,
+                                                               const float* __restrict__ pos, float* __restrict__ F) {
+  __shared__ float red[4][32][65];
+  const int m = blockIdx.z, BN = d.B * d.N, DM = d.DM;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i16 = lane & 15, g = lane >> 4;
+  const int gh = H / 16, gw = W / 16;
+  const int col0 = blockIdx.y * 64;  // < DM (DM % 64 == 0)
+  const float* const wrow = wpe + (int64_t)m * d.mstride + (int64_t)(col0 + i16) * 4096 + g * 16;  // + 16 nt rows
+  const float* xt[2];  // first voxel of the 16^3 brick of this lane's token in each row tile (clamped: never stored)
+#pragma unroll
+  for (int mt = 0; mt < 2; mt++) {
+    const int t = min(blockIdx.x * 32 + mt * 16 + i16, BN - 1);
+    const int b = t / d.N, n = t - b * d.N;
+    const int gz = n / (gh * gw), gy = (n / gw) % gh, gx = n % gw;
+    xt[mt] = x + ((((int64_t)b * d.M + m) * D + gz * 16) * H + gy * 16) * W + gx * 16;
+  }
+  constexpr int NCH = 4096 / 64 / 4;  // chunks per wave
+  f32x4 ra[2][2][4], rb[2][4][4];
+  auto load_chunk = [&](int i, int slot) __attribute__((always_inline)) {
+    const int c = i * 4 + wave;
+    const int k16 = c * 4 + g, dz = k16 >> 4, dy = k16 & 15;  // brick row of this lane group's 16 k values
+    const int64_t xo = ((int64_t)dz * H + dy) * W;
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; s4++) ra[slot][mt][s4] = *reinterpret_cast<const f32x4*>(xt[mt] + xo + 4 * s4);
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; s4++)
+        rb[slot][nt][s4] = *reinterpret_cast<const f32x4*>(wrow + (int64_t)nt * 16 * 4096 + c * 64 + 4 * s4);
+  };
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto mma_chunk = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4++)
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+          for (int nt = 0; nt < 4; nt++)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[slot][mt][s4][e], rb[slot][nt][s4][e], acc[mt][nt], 0, 0, 0);
+  };
+  load_chunk(0, 0);
+  for (int i = 0; i < NCH; i += 2) {
+    load_chunk(i + 1, 1);  // NCH is even
+    mma_chunk(0);
+    if (i + 2 < NCH) load_chunk(i + 2, 0);
+    mma_chunk(1);
+  }
+  // C/D layout: row = 4 (lane >> 4) + i, column = lane & 15
+#pragma unroll
+  for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) red[wave][mt * 16 + 4 * g + i][nt * 16 + i16] = acc[mt][nt][i];
+  __syncthreads();
+  const Drop dr = make_drop(d);
+  const uint32_t site = hdf_site_id(m, 63, 7, 7);
+  const int cl = threadIdx.x & 63, col = col0 + cl;
+  const float bias = bpe[(int64_t)m * d.mstride + col];
+  for (int tl = threadIdx.x >> 6; tl < 32; tl += 4) {
+    const int t = blockIdx.x * 32 + tl;
+    if (t < BN) {
+      const int n = t % d.N;
+      float v = ((red[0][tl][cl] + red[1][tl][cl]) + (red[2][tl][cl] + red[3][tl][cl])) + bias +
+                pos[(int64_t)m * d.mstride + (int64_t)n * DM + col];
+      v *= dr.mask(site, (uint32_t)t * DM + col);
+      F[((int64_t)m * BN + t) * d.DMF + col] = v;
+    }
+  }
+}
+
 // masked token gradient + dpos + dbias
 __global__ void patch_embed_bwd_prep_kernel(TfDims d, const float* __restrict__ dF, float* __restrict__ dtok,
                                             float* __restrict__ dbpe, float* __restrict__ dpos) {
@@ -1092,6 +1182,13 @@ int allow_lds(Kern kern, size_t bytes) {
 int tf_patch_embed_fwd(const TfDims& d, const float* x, int D, int H, int W, const float* wpe, const float* bpe,
                        const float* pos, float* F, hipStream_t st) {
   HDF_CHECK_ARG(d.DM <= 256 && d.DM % 32 == 0, "patch_embed: token dim %d unsupported", d.DM);
+  static const bool pe_old = getenv("HDF_PE_OLD") != nullptr;  // A/B knob: the LDS-staged 32-token kernel
+  if (d.DM % 64 == 0 && !pe_old) {
+    hipLaunchKernelGGL(patch_embed_fwd2_kernel, dim3(ceil_div(d.B * d.N, 32), d.DM / 64, d.M), dim3(256), 0, st, d, x, D,
+                       H, W, wpe, bpe, pos, F);
+    HDF_LAUNCH_CHECK();
+    return HDF_OK;
+  }
   size_t shm = (size_t)(32 + d.DM) * 65 * sizeof(float);
   HDF_TRY(allow_lds(patch_embed_fwd_kernel, shm));
   hipLaunchKernelGGL(patch_embed_fwd_kernel, dim3(ceil_div(d.B * d.N, 32), d.M), dim3(256), shm, st, d, x, D, H, W, wpe,
