@@ -107,8 +107,10 @@ def test_backward_fp32_vs_oracle(train):
     loss = crit(outs, onehot.to(DEV))
     loss.backward()
     torch.cuda.synchronize()
-    tr = orc.OracleTrainer(sd)
-    ref_loss, ref_outs = tr.loss_and_grads(x, onehot, seed)
+    # the oracle runs in float64 here: on this fixture its own fp32 gradients are up to 1.2e-2 rel-L2 away from its
+    # float64 ones (attns.0.blocks.0.0.layers.0.1.norm.*), i.e. an fp32 oracle is the less accurate side of the comparison
+    tr = orc.OracleTrainer({k: v.double() for k, v in sd.items()})
+    ref_loss, ref_outs = tr.loss_and_grads(x.double(), onehot.double(), seed)
     print("loss", loss.item(), ref_loss.item())
     for i in range(4):
         assert _rel(outs[i].detach(), ref_outs[i]) < 1e-3, f"out{i}"
@@ -123,9 +125,9 @@ def test_backward_fp32_vs_oracle(train):
     errs.sort(key=lambda kv: -kv[1])
     for k, e in errs[:12]:
         print(f"  grad {k:60s} rel-l2={e:.3e}")
-    # Gradient tolerance: the reference path's OWN fp32-vs-fp64 gradient discrepancy on this fixture is
-    # 1.5e-3 .. 6.4e-3 rel-L2 (ReLU / max-pool decisions flip under 1e-6 perturbations; measured with the
-    # oracle in float64, DESIGN.md "parity"), so two correct fp32 implementations agree to ~1e-2 at best.
+    # Gradient tolerance: ReLU / max-pool decisions flip under 1e-6 perturbations on this fixture (the reference
+    # path's own fp32-vs-fp64 gradient discrepancy is 1.5e-3 .. 1.2e-2 rel-L2, DESIGN.md "parity"), so an fp32
+    # implementation agrees with the float64 oracle to ~1e-2 at best.
     # The last decoder level does not sit behind those decisions and must agree tightly.
     assert errs[0][1] < 1e-2
     d = dict(errs)
