@@ -2070,6 +2070,162 @@ __global__ __launch_bounds__(256) void conv_wgrad_s2_kernel(WgradArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// conv_gather_s2: 16-bit stride-2 gather conv with 64-byte input rows and 64 output channels -- the data gradient of
+// the highest-resolution ConvTranspose3d (dX[v] = sum_tap W[tap]^T dY[2v - 1 + tap], 32 -> 64 channels): persistent
+// workgroups, the same LDS-DMA double-buffered 9x9x9 box as conv_wgrad_s2_kernel, and WEIGHTS-STATIONARY REGISTERS.
+// The generic kernel it replaces (conv_igemm_kernel<.,2,4,8,..,S=2>) ran one 64-voxel tile per workgroup (8192
+// workgroups, each staging its box with per-slot index arithmetic and fetching every weight fragment from L2): 23 VALU
+// instructions per MFMA, 63 % of the LDS cycles in bank conflicts (rows 2 apart), 268 TF.  Here
+//  * wave (mb, nb) owns 32 of the tile's 64 voxels x 32 of the 64 output channels; its 27 x 2 weight fragments
+//    (216 registers) are loaded once per launch;
+//  * per tile a wave issues 54 MFMAs and 54 ds_read_b128 (two accumulator chains, A fragments two steps ahead) and
+//    its share of the next tile's 12 LDS-DMA slots; nothing else;
+//  * box rows keep the even-then-odd x order of conv_wgrad_s2_kernel (stride-2 neighbours = consecutive 64-byte rows),
+//    and the 16-byte chunks of a row are XOR-swizzled by (box y >> 1) & 3 on the SOURCE side of the DMA (the LDS image
+//    of an LDS-DMA is lane-linear), so the 16 lanes a ds_read_b128 services together (4 x positions x 4 different y)
+//    cover all 64 banks.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_gather_s2_kernel(ConvArgs a) {
+  static_assert(sizeof(T) == 2, "16-bit storage only");
+  constexpr int BX = 9, BOXL = BX * BX * BX, LP = 64, EPC = 8;
+  constexpr int NL_ = (BOXL * 4 + 255) / 256, LBUF = NL_ * 256 * 16;  // the last slot's tail lanes land in padding
+  constexpr int NS = 54;                                              // fragment steps per tile: 27 taps x 2
+  __shared__ __attribute__((aligned(256))) char lds[2 * LBUF];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int mb = wave >> 1, nb = wave & 1;
+  const int part = tid & 3, v0 = tid >> 2;
+  const int ntz = a.Do / 4, nty = a.Ho / 4, ntx = a.Wo / 4;  // whole tiles (launcher check)
+  const int num_tiles = a.N * ntz * nty * ntx;
+  const int per = (num_tiles + gridDim.x - 1) / gridDim.x;
+  const int t_begin = blockIdx.x * per, t_end = min(num_tiles, t_begin + per);
+  if (t_begin >= t_end) return;
+
+  // ---- weights -> registers (B operand: lane r = output channel, 8 k values at h)
+  u32x4 wf[NS];
+  {
+    const char* wb = a.wfrag ? reinterpret_cast<const char*>(a.w) + nb * 2 * 1024 + r * 32 + h * 16
+                             : reinterpret_cast<const char*>(a.w) + ((int64_t)(nb * 32 + r) * a.Cin) * 2 + h * 16;
+    const int fstride = a.wfrag ? 1024 : 32;
+    const int64_t wtap_stride = (int64_t)a.CoutP * a.Cin * 2;
+#pragma unroll
+    for (int s_ = 0; s_ < NS; s_++) wf[s_] = *reinterpret_cast<const u32x4*>(wb + (s_ >> 1) * wtap_stride + (s_ & 1) * fstride);
+  }
+
+  // ---- A fragment addresses: M-block row r = (lz & 1) * 16 + ly * 4 + lx, lz = 2 mb + (r >> 4)
+  const int a_ly = (r >> 2) & 3;
+  const int abase = (((2 * (2 * mb + (r >> 4))) * BX + 2 * a_ly) * BX + (r & 3)) * LP;
+  int aoff[2][2];  // [tap y == 2][k-step]: byte offset of this lane's 16-byte chunk inside its row
+#pragma unroll
+  for (int y2 = 0; y2 < 2; y2++)
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) aoff[y2][ks] = abase + (((2 * ks + h) ^ ((a_ly + y2) & 3)) << 4);
+
+  // ---- staging slots (per-thread constants): slot k = box row v0 + 64 k, this lane's chunk = part ^ swizzle(row)
+  int goffL[NL_];
+  uint32_t emz = 0, emy = 0, emx = 0, row_ok = 0;
+#pragma unroll
+  for (int k = 0; k < NL_; k++) {
+    const int row = v0 + 64 * k;
+    const int rc = min(row, BOXL - 1);
+    const int line = rc / BX, pos = rc - line * BX;
+    const int bx = pos < 5 ? 2 * pos : 2 * pos - 9, by = line % BX, bz = line / BX;
+    const int chunk = part ^ ((by >> 1) & 3);
+    goffL[k] = ((bz * a.Hi + by) * a.Wi + bx) * (int)a.in_pitch + chunk * EPC;
+    emz |= (bz == 0 ? 1u : 0u) << k;
+    emy |= (by == 0 ? 1u : 0u) << k;
+    emx |= (bx == 0 ? 1u : 0u) << k;
+    row_ok |= (row < BOXL ? 1u : 0u) << k;
+  }
+  const T* const zero_src = reinterpret_cast<const T*>(g_zero_line);
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  struct Tl {
+    int n, z0, y0, x0;
+  };
+  auto decode = [&](int t, Tl& c) {
+    c.x0 = (t % ntx) * 4;
+    t /= ntx;
+    c.y0 = (t % nty) * 4;
+    t /= nty;
+    c.z0 = (t % ntz) * 4;
+    c.n = t / ntz;
+  };
+  auto issue_tile = [&](const Tl& c, int buf_off) __attribute__((always_inline)) {
+    // box origin; may lie before the tensor (those slots read the zero line)
+    const T* const lorg = reinterpret_cast<const T*>(a.in) +
+                          ((((int64_t)c.n * a.Di + (2 * c.z0 - 1)) * a.Hi + (2 * c.y0 - 1)) * a.Wi + (2 * c.x0 - 1)) * a.in_pitch;
+    const uint32_t off = (c.z0 == 0 ? emz : 0u) | (c.y0 == 0 ? emy : 0u) | (c.x0 == 0 ? emx : 0u);
+    const uint32_t m = row_ok & ~off;
+    const uint32_t wbase = __builtin_amdgcn_readfirstlane(lds_base + buf_off + wave * 1024);
+#pragma unroll
+    for (int k = 0; k < NL_; k++) {
+      const T* p = ((m >> k) & 1u) ? lorg + goffL[k] : zero_src;
+      uint32_t keep;  // inline asm: see conv_wgrad_s2_kernel
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep)
+                   : "v"(p), "s"(wbase + (uint32_t)(k * 4096))
+                   : "memory");
+    }
+  };
+
+  // ---- epilogue constants: accumulator register i = M-block row (i & 3) + 8 (i >> 2) + 4 h
+  const int ch = nb * 32 + r;
+  const bool ch_ok = ch < a.Cout;
+  const float bias = (a.bias && ch_ok) ? a.bias[ch] : 0.f;
+  int eoff[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const int rr = (i & 3) + 8 * (i >> 2) + 4 * h;
+    eoff[i] = (((2 * mb + (rr >> 4)) * a.Ho + ((rr >> 2) & 3)) * a.Wo + (rr & 3)) * (int)a.out_pitch;
+  }
+
+  Tl T1;
+  decode(t_begin, T1);
+  issue_tile(T1, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  WS_BARRIER();
+  int rd_off = 0;
+  for (int t = t_begin; t < t_end; t++) {
+    const Tl T0 = T1;
+    if (t + 1 < t_end) {  // uniform
+      decode(t + 1, T1);
+      issue_tile(T1, LBUF - rd_off);
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) acc[c][i] = 0.f;
+    auto rd = [&](int s_) {
+      const int tap = s_ >> 1, ks = s_ & 1;
+      const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+      const int pb = kx == 0 ? 0 : (kx == 1 ? 5 : 1);
+      return *reinterpret_cast<const u32x4*>(lds + rd_off + aoff[ky == 2][ks] + ((kz * BX + ky) * BX + pb) * LP);
+    };
+    u32x4 af[3];
+    af[0] = rd(0);
+    af[1] = rd(1);
+#pragma unroll
+    for (int s_ = 0; s_ < NS; s_++) {
+      if (s_ + 2 < NS) af[(s_ + 2) % 3] = rd(s_ + 2);
+      Mma<T>::run(af[s_ % 3], wf[s_], acc[s_ & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // epilogue: 2-byte stores, 32 lanes = 64 contiguous bytes of one voxel row
+    T* const obase = reinterpret_cast<T*>(a.out) +
+                     ((((int64_t)T0.n * a.Do + T0.z0) * a.Ho + T0.y0) * a.Wo + T0.x0) * a.out_pitch + ch;
+    if (ch_ok) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) ST<T>::st(obase + eoff[i], acc[0][i] + acc[1][i] + bias);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WS_BARRIER();  // one buffer fully read, the other fully written
+    rd_off = LBUF - rd_off;
+  }
+}
+
 // out[(sc*LC + lc)*27 + tap] (+)= sum_g partial[g][tap][sc][lc].  256 threads = 32 group-lanes x 8 lanes of 4 entries
 // (16-byte loads; a workgroup owns 32 consecutive entries = one 128-byte line per slab); fixed summation order
 // (bitwise reproducible)
@@ -2234,6 +2390,16 @@ int launch_conv_t(int mode, const ConvArgs& a, hipStream_t st) {
     if (a.CoutP <= 32) return launch_cfg<T, 4, 8, 8, 4, 1, 2, 1, false>(a, st);                  // 256 vox x 32 ch
     return launch_cfg<T, 4, 8, 8, 2, 2, 4, 1, false>(a, st);                                     // 256 vox x 64 ch
   } else if (mode == 1) {
+    if constexpr (sizeof(T) == 2) {
+      static const bool g_old = getenv("HDF_GATHER_S2_OLD") != nullptr;  // A/B knob
+      if (!g_old && a.Cin * 2 == 64 && a.CoutP == 64 && !a.in_scale && !a.accumulate && a.Do % 4 == 0 && a.Ho % 4 == 0 &&
+          a.Wo % 4 == 0 && a.Di == 2 * a.Do && a.Hi == 2 * a.Ho && a.Wi == 2 * a.Wo) {
+        const int tiles = a.N * (a.Do / 4) * (a.Ho / 4) * (a.Wo / 4);
+        hipLaunchKernelGGL((conv_gather_s2_kernel<T>), dim3(std::min(tiles, 256)), dim3(256), 0, st, a);
+        HDF_LAUNCH_CHECK();
+        return HDF_OK;
+      }
+    }
     if (a.CoutP <= 64) return launch_cfg<T, 2, 4, 8, 2, 2, 1, 2, false>(a, st);  // 64 vox x 64 ch, stride 2
     return launch_cfg<T, 4, 4, 4, 1, 4, 2, 2, false>(a, st);  // 64 vox x 128 ch, stride 2
   } else {

@@ -108,6 +108,21 @@ def test_conv3d_stride2(dtype, cin, cout, size):
     assert rel_err(from_cl(out), ref) < TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", [BF16, F16])
+@pytest.mark.parametrize("cout,size,n", [(64, (16, 16, 24), 2), (48, (8, 16, 8), 1), (64, (40, 8, 8), 3)])
+def test_conv3d_stride2_whole_tiles(dtype, cout, size, n):
+    """32 -> 64 channels, output extents multiples of 4: the persistent weights-in-registers gather kernel (several
+    tiles per workgroup and samples, low-face zero padding, a partial output-channel block, bias)."""
+    cin = 32
+    x, w = _mk((n, cin) + size, 41), _mk((cout, cin, 3, 3, 3), 42) * (cin * 27) ** -0.5
+    b = _mk((cout,), 43) * 0.1
+    ref = F.conv3d(rnd(x, dtype), rnd(w, dtype), b, stride=2, padding=1)
+    wp = pack_w(w, dtype, cout, cin, rup(cout, 32), cin, cin * 27, 27, 0)
+    out, _ = conv3d(dtype, 1, to_cl(x, dtype), cin, wp, cout, bias=b.to(DEV))
+    torch.cuda.synchronize()
+    assert rel_err(from_cl(out), ref) < TOL[dtype]
+
+
 def _wgrad(dtype, stride, s_cl, sc, l_cl, lc, dims, sc_store, lc_store, s_scale=None, s_shift=None, s_relu=0):
     n = s_cl.shape[0]
     wsb = lib().hdf_op_wgrad_workspace_bytes(stride, n, *dims, sc, lc)
