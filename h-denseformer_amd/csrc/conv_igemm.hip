@@ -2174,11 +2174,13 @@ __global__ __launch_bounds__(256) void conv_gather_s2_kernel(ConvArgs a) {
   const int ch = nb * 32 + r;
   const bool ch_ok = ch < a.Cout;
   const float bias = (a.bias && ch_ok) ? a.bias[ch] : 0.f;
-  int eoff[16];
+  const bool ch_odd = r & 1;
+  int eoff[8];  // accumulator rows 2 j and 2 j + 1 leave as one dword per lane (st_rows2)
 #pragma unroll
-  for (int i = 0; i < 16; i++) {
+  for (int j = 0; j < 8; j++) {
+    const int i = 2 * j + (ch_odd ? 1 : 0);
     const int rr = (i & 3) + 8 * (i >> 2) + 4 * h;
-    eoff[i] = (((2 * mb + (rr >> 4)) * a.Ho + ((rr >> 2) & 3)) * a.Wo + (rr & 3)) * (int)a.out_pitch;
+    eoff[j] = (((2 * mb + (rr >> 4)) * a.Ho + ((rr >> 2) & 3)) * a.Wo + (rr & 3)) * (int)a.out_pitch - (ch_odd ? 1 : 0);
   }
 
   Tl T1;
@@ -2213,17 +2215,304 @@ __global__ __launch_bounds__(256) void conv_gather_s2_kernel(ConvArgs a) {
       Mma<T>::run(af[s_ % 3], wf[s_], acc[s_ & 1]);
       __builtin_amdgcn_sched_barrier(0);
     }
-    // epilogue: 2-byte stores, 32 lanes = 64 contiguous bytes of one voxel row
+    // The next tile's box must have landed before the barrier.  vmcnt counts stores too and retires in order, so the
+    // wait sits BEFORE this tile's stores (behind them it also waited for their write acknowledgements, ~1 us per
+    // tile); the stores then drain under the next tile's MFMAs.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // epilogue: one dword per lane and pair of accumulator rows (16 lanes = 64 contiguous bytes of one voxel row)
     T* const obase = reinterpret_cast<T*>(a.out) +
                      ((((int64_t)T0.n * a.Do + T0.z0) * a.Ho + T0.y0) * a.Wo + T0.x0) * a.out_pitch + ch;
     if (ch_ok) {
 #pragma unroll
-      for (int i = 0; i < 16; i++) ST<T>::st(obase + eoff[i], acc[0][i] + acc[1][i] + bias);
+      for (int j = 0; j < 8; j++)
+        st_rows2<T>(obase + eoff[j], acc[0][2 * j] + acc[1][2 * j] + bias, acc[0][2 * j + 1] + acc[1][2 * j + 1] + bias, ch_odd);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     WS_BARRIER();  // one buffer fully read, the other fully written
     rd_off = LBUF - rd_off;
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// convt_ws: 16-bit ConvTranspose3d(k3,s2,p1,op1) forward for 128-byte input rows and <= 32 output channels (the
+// highest-resolution up-convolution, 64 -> 32): persistent workgroups, LDS-DMA double-buffered input box, weights in
+// registers.  convt_fused_kernel ran one 256-voxel tile per workgroup: generic per-slot staging, every weight
+// fragment fetched from L2 at its point of use by all four waves, 3360 VALU instructions per wave for 216 MFMAs,
+// SQ_WAIT_ANY 64 % of the wave cycles (310 TF).  Here
+//  * the 8 output-parity classes (1,2,2,2,4,4,4,8 taps) are dealt to the waves as {7}, {6,5}, {3,4,0}, {1,2}: a
+//    wave keeps the 16..32 weight fragments of ITS classes in registers for the whole launch and runs them over all
+//    four 32-voxel M-blocks of a 4x4x8 tile (8 : 8 : 7 : 4 taps -- the matrix pipe is not the bound here);
+//  * the (4+1)x(4+1)x(8+1) input box of tile t+1 lands by LDS-DMA while tile t is under the MFMAs; its
+//    InstanceNorm/ReLU transform is applied in place, by the thread that loaded the chunk, between the two halves of
+//    the wave's MFMA work (zero padding = slots that read the zero line and are skipped by the transform);
+//  * 128-byte rows: the 16-byte chunk c of a box row sits in slot c ^ ((x >> 1) & 1 | (y & 3) << 1) (applied on the
+//    source side of the DMA), so the 16 lanes one ds_read_b128 pass services (4 x 4 voxels in x, y) cover the 64 banks.
+template <typename T>
+__global__ __launch_bounds__(256) void convt_ws_kernel(ConvArgs a) {
+  static_assert(sizeof(T) == 2, "16-bit storage only");
+  constexpr int BD = 5, BH = 5, BW = 9, BOX = BD * BH * BW, LP = 128, EPC = 8;
+  constexpr int NJ = (BOX * 8 + 255) / 256, LBUF = NJ * 256 * 16;  // 8 slots per thread; tail lanes land in padding
+  __shared__ __attribute__((aligned(256))) char lds[2 * LBUF + 128 * 4];
+  float* const s_xf = reinterpret_cast<float*>(lds + 2 * LBUF);  // [64 scale][64 shift]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int ntz = a.Di / 4, nty = a.Hi / 4, ntx = a.Wi / 8;  // whole tiles (launcher check)
+  const int num_tiles = a.N * ntz * nty * ntx;
+  const int per = (num_tiles + gridDim.x - 1) / gridDim.x;
+  const int t_begin = blockIdx.x * per, t_end = min(num_tiles, t_begin + per);
+  if (t_begin >= t_end) return;
+  const bool xf = a.in_scale != nullptr;
+  const float relu_lo = (xf && a.in_relu) ? 0.f : -INFINITY;
+
+  // ---- A fragment addresses: M-block mb = tile z, row r = (ly, lx) = (r >> 3, r & 7)
+  const int a_ly = r >> 3, a_lx = r & 7;
+  const int abase = (a_ly * BW + a_lx) * LP;
+  int aoff[2][2][4];  // [tap offset y][tap offset x][k-step]: byte offset of this lane's 16-byte chunk inside its row
+#pragma unroll
+  for (int oy = 0; oy < 2; oy++)
+#pragma unroll
+    for (int ox = 0; ox < 2; ox++) {
+      const int gsw = (((a_lx + ox) >> 1) & 1) | (((a_ly + oy) & 3) << 1);
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) aoff[oy][ox][ks] = abase + (((2 * ks + h) ^ gsw) << 4);
+    }
+
+  // ---- staging slots (per-thread constants): slot k = 16-byte slot tid + 256 k of the lane-linear box image
+  int goff[NJ], tboff[NJ];
+  uint32_t emz = 0, emy = 0, emx = 0, row_ok = 0;
+#pragma unroll
+  for (int k = 0; k < NJ; k++) {
+    const int q = tid + 256 * k, row = q >> 3, sl = q & 7;
+    const int rc = min(row, BOX - 1);
+    const int bz = rc / (BH * BW), by = (rc / BW) % BH, bx = rc % BW;
+    const int chunk = sl ^ (((bx >> 1) & 1) | ((by & 3) << 1));
+    goff[k] = ((bz * a.Hi + by) * a.Wi + bx) * (int)a.in_pitch + chunk * EPC;
+    tboff[k] = chunk * EPC;
+    emz |= (bz == BD - 1 ? 1u : 0u) << k;
+    emy |= (by == BH - 1 ? 1u : 0u) << k;
+    emx |= (bx == BW - 1 ? 1u : 0u) << k;
+    row_ok |= (row < BOX ? 1u : 0u) << k;
+  }
+  const T* const zero_src = reinterpret_cast<const T*>(g_zero_line);
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  struct Tl {
+    int n, z0, y0, x0;
+  };
+  auto decode = [&](int t, Tl& c) {
+    c.x0 = (t % ntx) * 8;
+    t /= ntx;
+    c.y0 = (t % nty) * 4;
+    t /= nty;
+    c.z0 = (t % ntz) * 4;
+    c.n = t / ntz;
+  };
+  // only the HIGH faces of a box can leave the tensor (whole tiles)
+  auto slots_ok = [&](const Tl& c) -> uint32_t {
+    const uint32_t off = (c.z0 + 4 == a.Di ? emz : 0u) | (c.y0 + 4 == a.Hi ? emy : 0u) | (c.x0 + 8 == a.Wi ? emx : 0u);
+    return row_ok & ~off;
+  };
+  auto issue_tile = [&](const Tl& c, uint32_t m, int buf_off) __attribute__((always_inline)) {
+    const T* const org = reinterpret_cast<const T*>(a.in) + ((((int64_t)c.n * a.Di + c.z0) * a.Hi + c.y0) * a.Wi + c.x0) * a.in_pitch;
+    const uint32_t wbase = __builtin_amdgcn_readfirstlane(lds_base + buf_off + wave * 1024);
+#pragma unroll
+    for (int k = 0; k < NJ; k++) {
+      const T* p = ((m >> k) & 1u) ? org + goff[k] : zero_src;
+      uint32_t keep;  // inline asm: see conv_wgrad_s2_kernel
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep)
+                   : "v"(p), "s"(wbase + (uint32_t)(k * 4096))
+                   : "memory");
+    }
+  };
+  int tbl_n = -1;
+  auto refresh_xf = [&](int n) {  // uniform
+    __syncthreads();              // nobody still reads the previous table
+    if (tid < 64) {
+      s_xf[tid] = a.in_scale[(int64_t)n * a.Cin + tid];
+      s_xf[64 + tid] = a.in_shift[(int64_t)n * a.Cin + tid];
+    }
+    tbl_n = n;
+    __syncthreads();
+  };
+  // x*scale+shift (+relu) on this thread's own chunks of the box in buffer buf_off; padding slots stay zero
+  auto transform_own = [&](uint32_t m, int buf_off) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < NJ; k++) {
+      if ((m >> k) & 1u) {
+        u32x4* const slot = reinterpret_cast<u32x4*>(lds + buf_off + (tid + 256 * k) * 16);
+        float f[EPC];
+        ST<T>::unpack(*slot, f);
+        const float* tb = s_xf + tboff[k];
+#pragma unroll
+        for (int e = 0; e < EPC; e += 4) {
+          const f32x4 u = *reinterpret_cast<const f32x4*>(tb + e);
+          const f32x4 w = *reinterpret_cast<const f32x4*>(tb + 64 + e);
+#pragma unroll
+          for (int q = 0; q < 4; q++) f[e + q] = fmaxf(f[e + q] * u[q] + w[q], relu_lo);
+        }
+        *slot = ST<T>::pack(f);
+      }
+    }
+  };
+
+  // ---- epilogue constants: accumulator register i = M-block row (i & 3) + 8 (i >> 2) + 4 h = (ly, lx)
+  const bool ch_ok = r < a.Cout;
+  const float bias = (a.bias && ch_ok) ? a.bias[r] : 0.f;
+  const bool ch_odd = r & 1;
+  int eoff[8];  // accumulator rows 2 j and 2 j + 1 leave as one dword per lane (st_rows2)
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int i = 2 * j + (ch_odd ? 1 : 0);
+    const int rr = (i & 3) + 8 * (i >> 2) + 4 * h;
+    eoff[j] = ((2 * (rr >> 3)) * a.Wo + 2 * (rr & 7)) * (int)a.out_pitch - (ch_odd ? 1 : 0);
+  }
+  const int64_t wtap_stride = (int64_t)a.CoutP * a.Cin * 2;
+  const char* const wrow = reinterpret_cast<const char*>(a.w) + ((int64_t)r * a.Cin) * 2 + h * 16;
+
+  // One parity class = (pz, py, px); tap j of it = (jz, jy, jx) in [0, ntap) per axis: box offset (parity ? 1 - j : 0),
+  // weight index (parity ? 2 j : 1).  The per-wave code below is straight-line: classes, taps and weight slots are
+  // compile-time.
+  u32x4 wf[32];
+  int rd_off = 0;
+  T* obase = nullptr;
+  auto load_class_w = [&](auto cls_tag, auto slot0_tag) __attribute__((always_inline)) {
+    constexpr int cls = decltype(cls_tag)::value, slot0 = decltype(slot0_tag)::value;
+    constexpr int pz = (cls >> 2) & 1, py = (cls >> 1) & 1, px = cls & 1;
+    constexpr int ny = py ? 2 : 1, nx = px ? 2 : 1, ntap = (pz ? 2 : 1) * ny * nx;
+#pragma unroll
+    for (int j = 0; j < ntap; j++) {
+      const int jz = j / (ny * nx), jy = (j / nx) % ny, jx = j % nx;
+      const int wz = pz ? 2 * jz : 1, wy = py ? 2 * jy : 1, wx = px ? 2 * jx : 1;
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++)
+        wf[slot0 + 4 * j + ks] = *reinterpret_cast<const u32x4*>(wrow + ((wz * 3 + wy) * 3 + wx) * wtap_stride + ks * 32);
+    }
+  };
+  // taps [J0, J1) of class cls into acc (zeroed first when J0 == 0)
+  auto run_class = [&](auto cls_tag, auto slot0_tag, auto j0_tag, auto j1_tag, f32x16 (&acc)[4]) __attribute__((always_inline)) {
+    constexpr int cls = decltype(cls_tag)::value, slot0 = decltype(slot0_tag)::value;
+    constexpr int J0 = decltype(j0_tag)::value, J1 = decltype(j1_tag)::value;
+    constexpr int pz = (cls >> 2) & 1, py = (cls >> 1) & 1, px = cls & 1;
+    constexpr int ny = py ? 2 : 1, nx = px ? 2 : 1;
+    if constexpr (J0 == 0) {
+#pragma unroll
+      for (int mb = 0; mb < 4; mb++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[mb][i] = 0.f;
+    }
+    // step s = (tap j, k-step ks); the four A fragments of step s+1 are read under the MFMAs of step s
+    u32x4 af[2][4];
+    auto rd = [&](int s_) {
+      const int j = s_ >> 2, ks = s_ & 3;
+      const int jz = j / (ny * nx), jy = (j / nx) % ny, jx = j % nx;
+      const int oz = pz ? 1 - jz : 0, oy = py ? 1 - jy : 0, ox = px ? 1 - jx : 0;
+#pragma unroll
+      for (int mb = 0; mb < 4; mb++)
+        af[s_ & 1][mb] = *reinterpret_cast<const u32x4*>(lds + rd_off + aoff[oy][ox][ks] + (((mb + oz) * BH + oy) * BW + ox) * LP);
+    };
+    rd(4 * J0);
+#pragma unroll
+    for (int s_ = 4 * J0; s_ < 4 * J1; s_++) {
+      if (s_ + 1 < 4 * J1) rd(s_ + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mb = 0; mb < 4; mb++) Mma<T>::run(af[s_ & 1][mb], wf[slot0 + s_], acc[mb]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // stores of a finished class: one dword per lane and pair of accumulator rows (16 lanes = one 64-byte voxel row)
+  auto store_class = [&](auto cls_tag, const f32x16 (&acc)[4]) __attribute__((always_inline)) {
+    constexpr int cls = decltype(cls_tag)::value;
+    constexpr int pz = (cls >> 2) & 1, py = (cls >> 1) & 1, px = cls & 1;
+    const int coff = ((pz * a.Ho + py) * a.Wo + px) * (int)a.out_pitch;
+    if (ch_ok) {
+#pragma unroll
+      for (int mb = 0; mb < 4; mb++) {
+        T* const ob = obase + coff + (int64_t)(2 * mb) * a.Ho * a.Wo * a.out_pitch;
+#pragma unroll
+        for (int j = 0; j < 8; j++) st_rows2<T>(ob + eoff[j], acc[mb][2 * j] + bias, acc[mb][2 * j + 1] + bias, ch_odd);
+      }
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I4 = std::integral_constant<int, 4>;
+  using I8 = std::integral_constant<int, 8>;
+  using I16 = std::integral_constant<int, 16>;
+  using I24 = std::integral_constant<int, 24>;
+#define CLS(c) std::integral_constant<int, c>{}
+  if (wave == 0) {
+    load_class_w(CLS(7), I0{});
+  } else if (wave == 1) {
+    load_class_w(CLS(6), I0{});
+    load_class_w(CLS(5), I16{});
+  } else if (wave == 2) {
+    load_class_w(CLS(3), I0{});
+    load_class_w(CLS(4), I16{});
+    load_class_w(CLS(0), I24{});
+  } else {
+    load_class_w(CLS(1), I0{});
+    load_class_w(CLS(2), I8{});
+  }
+
+  Tl T1;
+  decode(t_begin, T1);
+  uint32_t m1 = slots_ok(T1);
+  if (xf) refresh_xf(T1.n);
+  issue_tile(T1, m1, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (xf) transform_own(m1, 0);
+  WS_BARRIER();
+  for (int t = t_begin; t < t_end; t++) {
+    const Tl T0 = T1;
+    const bool v1 = t + 1 < t_end;
+    if (v1) {  // uniform
+      decode(t + 1, T1);
+      m1 = slots_ok(T1);
+      issue_tile(T1, m1, LBUF - rd_off);
+      if (xf && T1.n != tbl_n) refresh_xf(T1.n);
+    }
+    obase = reinterpret_cast<T*>(a.out) + ((((int64_t)T0.n * a.Do + 2 * T0.z0) * a.Ho + 2 * T0.y0) * a.Wo + 2 * T0.x0) * a.out_pitch + r;
+    // The next tile's box must have landed (and be transformed) before the barrier.  vmcnt counts stores too and
+    // retires in order, so the wait sits after the first half of the wave's MFMAs and BEFORE the phase's first store:
+    // behind stores it would also wait for their write acknowledgements.  The stores drain under the MFMAs that follow
+    // (this phase's second half, the next phase's first).
+    auto mid = [&]() __attribute__((always_inline)) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (xf && v1) transform_own(m1, LBUF - rd_off);
+    };
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    f32x16 acc[4];
+    if (wave == 0) {
+      run_class(CLS(7), I0{}, I0{}, I4{}, acc);
+      mid();
+      run_class(CLS(7), I0{}, I4{}, I8{}, acc);
+      store_class(CLS(7), acc);
+    } else if (wave == 1) {
+      run_class(CLS(6), I0{}, I0{}, I4{}, acc);
+      mid();
+      store_class(CLS(6), acc);
+      run_class(CLS(5), I16{}, I0{}, I4{}, acc);
+      store_class(CLS(5), acc);
+    } else if (wave == 2) {
+      run_class(CLS(3), I0{}, I0{}, I4{}, acc);
+      mid();
+      store_class(CLS(3), acc);
+      run_class(CLS(4), I16{}, I0{}, I2{}, acc);
+      store_class(CLS(4), acc);
+      run_class(CLS(0), I24{}, I0{}, I1{}, acc);
+      store_class(CLS(0), acc);
+    } else {
+      run_class(CLS(1), I0{}, I0{}, I2{}, acc);
+      mid();
+      store_class(CLS(1), acc);
+      run_class(CLS(2), I8{}, I0{}, I2{}, acc);
+      store_class(CLS(2), acc);
+    }
+    WS_BARRIER();  // one buffer fully read, the other fully written (and transformed)
+    rd_off = LBUF - rd_off;
+  }
+#undef CLS
 }
 
 // out[(sc*LC + lc)*27 + tap] (+)= sum_g partial[g][tap][sc][lc].  256 threads = 32 group-lanes x 8 lanes of 4 entries
@@ -2403,6 +2692,16 @@ int launch_conv_t(int mode, const ConvArgs& a, hipStream_t st) {
     if (a.CoutP <= 64) return launch_cfg<T, 2, 4, 8, 2, 2, 1, 2, false>(a, st);  // 64 vox x 64 ch, stride 2
     return launch_cfg<T, 4, 4, 4, 1, 4, 2, 2, false>(a, st);  // 64 vox x 128 ch, stride 2
   } else {
+    if constexpr (sizeof(T) == 2) {
+      static const bool ct_old = getenv("HDF_CONVT_OLD") != nullptr;  // A/B knob
+      if (!ct_old && a.Cin * 2 == 128 && a.CoutP == 32 && !a.accumulate && a.Di % 4 == 0 && a.Hi % 4 == 0 && a.Wi % 8 == 0 &&
+          a.Do == 2 * a.Di && a.Ho == 2 * a.Hi && a.Wo == 2 * a.Wi) {
+        const int tiles = a.N * (a.Di / 4) * (a.Hi / 4) * (a.Wi / 8);
+        hipLaunchKernelGGL((convt_ws_kernel<T>), dim3(std::min(tiles, 256)), dim3(256), 0, st, a);
+        HDF_LAUNCH_CHECK();
+        return HDF_OK;
+      }
+    }
     if (a.Cin * (int)sizeof(T) <= 128 && !a.accumulate) {  // all 8 parity classes in one workgroup
       dim3 grid(a.N * ceil_div(a.Di, 4) * ceil_div(a.Hi, 8) * ceil_div(a.Wi, 8), a.CoutP / 32);
       const int nfs = a.Cin * (int)sizeof(T) / 32;

@@ -115,6 +115,7 @@ struct ST<bf16_t> {
     for (int i = 0; i < 4; i++) c[i] = pack_bf2(f[2 * i], f[2 * i + 1]);
     return c;
   }
+  __device__ static __forceinline__ uint32_t pack2(float lo, float hi) { return pack_bf2(lo, hi); }
 };
 
 template <>
@@ -138,7 +139,19 @@ struct ST<f16_t> {
     for (int i = 0; i < 4; i++) c[i] = pack_h2(f[2 * i], f[2 * i + 1]);
     return c;
   }
+  __device__ static __forceinline__ uint32_t pack2(float lo, float hi) { return pack_h2(lo, hi); }
 };
+
+// Two MFMA accumulator rows (v0, v1: the same output channel = this lane, two different voxels) stored as ONE dword per
+// lane: even-channel lanes write (channel, channel + 1) of row 0, odd-channel lanes (channel - 1, channel) of row 1, after
+// exchanging one value with lane ^ 1 (DPP quad_perm [1,0,3,2]).  16 lanes x 4 B = one 64-byte voxel row of 32 channels;
+// a wave instruction covers four rows.  `p` = odd ? row1 + channel - 1 : row0 + channel (4-byte aligned), 16-bit T.
+template <typename T>
+__device__ __forceinline__ void st_rows2(T* p, float v0, float v1, bool odd) {
+  const float give = odd ? v0 : v1;
+  const float got = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(give), 0xB1, 0xF, 0xF, false));
+  *reinterpret_cast<uint32_t*>(p) = ST<T>::pack2(odd ? got : v0, odd ? v1 : got);
+}
 
 // one dispatch for every kernel family templated on the storage type
 #define HDF_DISPATCH_T(dtype, ...)                      \

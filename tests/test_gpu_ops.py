@@ -95,6 +95,31 @@ def test_conv_transpose3d(dtype, cin, cout, size):
     assert rel_err(from_cl(out), ref) < TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", [BF16, F16])
+@pytest.mark.parametrize("cout,size,n", [(32, (8, 8, 16), 2), (16, (4, 12, 8), 1), (32, (20, 4, 8), 3)])
+@pytest.mark.parametrize("xf", [0, 1])
+def test_conv_transpose3d_whole_tiles(dtype, cout, size, n, xf):
+    """64 input channels, extents multiples of (4, 4, 8): the persistent weights-in-registers transposed conv (several
+    tiles per workgroup and samples, high-face zero padding, a partial output-channel block, the in-place
+    InstanceNorm+ReLU transform of its input), written into the up-convolution half of a wider row."""
+    cin = 64
+    x, w, b = _mk((n, cin) + size, 51), _mk((cin, cout, 3, 3, 3), 52) * (cin * 27 / 8) ** -0.5, _mk((cout,), 53)
+    sc = (torch.rand(n, cin, generator=torch.Generator().manual_seed(54)) + 0.5) if xf else None
+    sh = (torch.randn(n, cin, generator=torch.Generator().manual_seed(55)) * 0.3) if xf else None
+    xin = rnd(x, dtype)
+    if xf:
+        xin = rnd(torch.relu(xin * sc[:, :, None, None, None] + sh[:, :, None, None, None]), dtype)
+    ref = F.conv_transpose3d(xin, rnd(w, dtype), b, stride=2, padding=1, output_padding=1)
+    wp = pack_w(w, dtype, cout, cin, rup(cout, 32), cin, 27, cout * 27, 0)
+    osz = tuple(2 * v for v in size)
+    wide = torch.full((n,) + osz + (2 * cout,), 7.0, dtype=to_cl(x, dtype).dtype, device=DEV)
+    conv3d(dtype, 2, to_cl(x, dtype), cin, wp, cout, bias=b.to(DEV), scale=sc.to(DEV) if xf else None,
+           shift=sh.to(DEV) if xf else None, relu=xf, out=wide, out_pitch=2 * cout)
+    torch.cuda.synchronize()
+    assert rel_err(from_cl(wide[..., :cout]), ref) < TOL[dtype]
+    assert float((wide[..., cout:].float() - 7).abs().max()) == 0
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16, F16])
 @pytest.mark.parametrize("cin,cout,size", [(16, 32, (8, 8, 8)), (32, 64, (16, 8, 12)), (64, 128, (10, 12, 6))])
 def test_conv3d_stride2(dtype, cin, cout, size):

@@ -19,6 +19,7 @@ ap.add_argument("--size", type=int, default=64)     # low-resolution extent
 ap.add_argument("--n", type=int, default=2)
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--xf", type=int, default=1)
+ap.add_argument("--dense", type=int, default=0)  # convt: write a dense tensor instead of the upconv half of a concat row
 a = ap.parse_args()
 dev = "cuda:0"
 st = torch.cuda.current_stream().cuda_stream
@@ -29,10 +30,11 @@ sc = (torch.rand(n, cl, device=dev) + 0.5) if a.xf else None
 sh = (torch.randn(n, cl, device=dev) * 0.1) if a.xf else None
 if a.op == "convt":
     w = (torch.randn(27 * ((ch + 31) // 32 * 32) * cl, device=dev) * 0.02).to(torch.bfloat16)
-    out = torch.empty(n, 2 * s, 2 * s, 2 * s, 2 * ch, device=dev, dtype=torch.bfloat16)   # the upconv half of a concat row
+    opitch = ch if a.dense else 2 * ch
+    out = torch.empty(n, 2 * s, 2 * s, 2 * s, opitch, device=dev, dtype=torch.bfloat16)   # the upconv half of a concat row
 
     def launch():
-        check(lib().hdf_op_conv3d(BF16, 2, ptr(lo), cl, cl, n, s, s, s, ptr(w), None, ptr(sc), ptr(sh), 1, ptr(out), 2 * ch,
+        check(lib().hdf_op_conv3d(BF16, 2, ptr(lo), cl, cl, n, s, s, s, ptr(w), None, ptr(sc), ptr(sh), 1, ptr(out), opitch,
                                   ch, None, 0, st), "convt")
 elif a.op == "gather":
     w = (torch.randn(27 * ((cl + 31) // 32 * 32) * ch, device=dev) * 0.02).to(torch.bfloat16)
