@@ -1448,6 +1448,32 @@ int hdf_op_conv3d(int dtype, int mode, const void* in, int64_t in_pitch, int Cin
   a.accumulate = accumulate;
   return hdf_launch_conv(dtype, mode, a, (hipStream_t)stream);
 }
+int hdf_op_conv3d_split(int dtype, const void* in, int64_t in_pitch, int Cin, int N, int D, int H, int W,
+                        const void* w_packed, void* out, void* out2, int64_t out_pitch, int Cout, int split,
+                        float* stat_partials, float* colsum, int colsum_C, hdf_stream stream) {
+  HDF_CHECK_ARG(colsum == nullptr || (stat_partials != nullptr && colsum_C > 0 && colsum_C <= Cout),
+                "conv3d_split: column sums need the statistics buffer and 0 < colsum_C <= Cout");
+  ConvArgs a{};
+  a.in = in;
+  a.in_pitch = in_pitch;
+  a.Cin = Cin;
+  a.N = N;
+  a.Di = a.Do = D, a.Hi = a.Ho = H, a.Wi = a.Wo = W;
+  a.w = w_packed;
+  a.out = out;
+  a.out2 = out2;
+  a.split = split;
+  a.out_pitch = out_pitch;
+  a.Cout = Cout;
+  a.CoutP = round_up(Cout, 32);
+  a.stat_partials = stat_partials;
+  HDF_TRY(hdf_launch_conv(dtype, 0, a, (hipStream_t)stream));
+  if (colsum) {
+    const int rows = N * hdf_conv_stat_tiles(0, D, H, W, Cin * hdf_esz(dtype));
+    HDF_TRY(hdf_launch_stat_rows_sum(stat_partials, rows, colsum_C, a.CoutP, colsum, (hipStream_t)stream));
+  }
+  return HDF_OK;
+}
 int hdf_op_conv3d_stat_tiles(int dtype, int Cin, int Do, int Ho, int Wo) {
   return hdf_conv_stat_tiles(0, Do, Ho, Wo, Cin * hdf_esz(dtype));
 }

@@ -149,6 +149,14 @@ int hdf_op_conv3d(int dtype, int mode, const void* in, int64_t in_pitch, int Cin
 /* partial rows per sample of stat_partials ([N*rows][Cout rounded up to 32][2] floats: sum, sum of squares) for this
  * layer shape: one row per output tile, or 512 per-workgroup rows when the weights-stationary kernel takes the layer */
 int hdf_op_conv3d_stat_tiles(int dtype, int Cin, int Do, int Ho, int Wo);
+/* Conv3d(k3,s1,p1) whose output channels [0, split) go to `out` and [split, Cout) to `out2` (two dense buffers of one
+ * pitch; split % 32 == 0), the form the plan uses for the gradient of a decoder concat [upconv | skip]
+ * (models/HDenseFormer.py:245-253 backward).  With stat_partials ([N * hdf_op_conv3d_stat_tiles][round_up(Cout,32)][2])
+ * and colsum ([colsum_C] floats) the per-channel sums over all voxels of channels [0, colsum_C) are written too: the
+ * ConvTranspose3d bias gradient taken from the conv's statistics epilogue. */
+int hdf_op_conv3d_split(int dtype, const void* in, int64_t in_pitch, int Cin, int N, int D, int H, int W,
+                        const void* w_packed, void* out, void* out2, int64_t out_pitch, int Cout, int split,
+                        float* stat_partials, float* colsum, int colsum_C, hdf_stream stream);
 int64_t hdf_op_wgrad_workspace_bytes(int stride, int N, int Ds, int Hs, int Ws, int SC, int LC);
 /* dW[sc][lc][27] = sum S[i][sc] * L[stride*i-1+tap][lc]  (torch weight layout for both Conv3d and ConvTranspose3d) */
 int hdf_op_conv3d_wgrad(int dtype, int stride, const void* sm, int64_t sm_pitch, int SC, const void* lg,

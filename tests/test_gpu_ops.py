@@ -95,6 +95,34 @@ def test_conv_transpose3d(dtype, cin, cout, size):
     assert rel_err(from_cl(out), ref) < TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("cin,cout,split,size", [(32, 64, 32, (48, 48, 48)),   # conv_ws2, two output blocks per workgroup
+                                                  (64, 128, 64, (48, 56, 48)),  # conv_ws2, 128-byte rows
+                                                  (64, 64, 32, (16, 24, 16))])  # conv_igemm
+def test_conv3d_split_output_and_column_sums(dtype, cin, cout, split, size):
+    """The dgrad form of a decoder concat: one conv, output channels [0, split) and [split, cout) in two dense buffers,
+    plus the per-channel sums of the first half from the statistics epilogue (the ConvTranspose3d bias gradient)."""
+    n = 2
+    x, w = _mk((n, cin) + size, 61), _mk((cout, cin, 3, 3, 3), 62) * (cin * 27) ** -0.5
+    ref = F.conv3d(rnd(x, dtype), rnd(w, dtype), None, padding=1)
+    wp = pack_w(w, dtype, cout, cin, rup(cout, 32), cin, cin * 27, 27, 0)
+    x_cl = to_cl(x, dtype)
+    o1 = torch.full((n,) + size + (split,), 7.0, dtype=x_cl.dtype, device=DEV)
+    o2 = torch.full((n,) + size + (cout - split,), 7.0, dtype=x_cl.dtype, device=DEV)
+    assert split == cout - split                      # one pitch for both buffers
+    tiles = lib().hdf_op_conv3d_stat_tiles(dtype, cin, *size)
+    part = torch.zeros((n * tiles, rup(cout, 32), 2), dtype=torch.float32, device=DEV)
+    colsum = torch.zeros(split, dtype=torch.float32, device=DEV)
+    check(lib().hdf_op_conv3d_split(dtype, ptr(x_cl), cin, cin, n, *size, ptr(wp), ptr(o1), ptr(o2), split, cout, split,
+                                    ptr(part), ptr(colsum), split, st()), "conv3d_split")
+    torch.cuda.synchronize()
+    assert rel_err(from_cl(o1), ref[:, :split]) < TOL[dtype]
+    assert rel_err(from_cl(o2), ref[:, split:]) < TOL[dtype]
+    want = ref[:, :split].double().sum(dim=(0, 2, 3, 4))
+    got = colsum.cpu().double()
+    assert float((got - want).abs().max() / (ref[:, :split].double().abs().sum(dim=(0, 2, 3, 4)).max())) < TOL[dtype]
+
+
 @pytest.mark.parametrize("dtype", [BF16, F16])
 @pytest.mark.parametrize("cout,size,n", [(32, (8, 8, 16), 2), (16, (4, 12, 8), 1), (32, (20, 4, 8), 3)])
 @pytest.mark.parametrize("xf", [0, 1])
