@@ -378,6 +378,9 @@ __device__ __forceinline__ int a_swz(int row) {
   return CH == 64 ? ((row >> 2) & 3) : ((row >> 3) & 1);
 }
 
+// 16 zero bytes: the source of LDS-DMA slots that lie outside the tensor (zero padding)
+__device__ __attribute__((aligned(16))) uint32_t g_zero_line[4] = {0u, 0u, 0u, 0u};
+
 struct WsTile {
   int n, z0, y0, x0, tile;
   int k;  // index in the list the tile came from (border pass)
@@ -386,7 +389,12 @@ struct WsTile {
 // NB: 32-channel output blocks per workgroup.  NB = 2 (64-byte rows, Cout % 64 == 0) stages every tile once for both
 // blocks (two workgroups with 32 channels each staged it twice: the 32->64 dgrad at 128^3 was the costliest launch of
 // the step) and shares each A fragment between two MFMAs.
-template <typename T, int CH, int RB, bool XF, int NB>
+// DMA (transform-free layers with 32-byte chunks and more than one pass per tile): an item goes global -> LDS by
+// LDS-DMA (global_load_lds_dwordx4, issued at the start of the pass before the one that reads it) instead of through
+// the pf registers and ds_write commits.  The tile buffer is then the lane-linear image of 32-byte rows (no padding;
+// the two 16-byte halves of a row are swapped for box planes with bit 1 of z set -- applied to the SOURCE address --
+// which keeps the b128 fragment reads conflict-free: the 16 lanes of a pass are 8 x positions in 2 planes 2 apart).
+template <typename T, int CH, int RB, bool XF, int NB, bool DMA = false>
 __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
   constexpr int TD = 4, TH = 8, TW = 8, BD = TD + 2, BH = TH + 2, BW = TW + 2, BOX = BD * BH * BW;
   constexpr int ESZ = sizeof(T), EPC = ST<T>::EPC;
@@ -397,9 +405,10 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
   // tile-buffer row pitch: padded by 16 bytes (conflict-free, see ws_row_to_zx; fragment addresses = one lane
   // base + compile-time offsets) whenever two padded buffers and the weight panel fit in 160 KiB; else unpadded
   // rows with XOR-swizzled 16-byte slots (a 36-entry per-lane address table)
-  constexpr bool SWZ = (2 * BOX * (CH + 16) + 4096 + 512 + 27 * 32 * NB * RB > 160 * 1024);
-  constexpr int AP = SWZ ? CH : CH + 16;
-  constexpr int ABUF = BOX * AP;
+  constexpr bool SWZ = !DMA && (2 * BOX * (CH + 16) + 4096 + 512 + 27 * 32 * NB * RB > 160 * 1024);
+  constexpr int AP = (SWZ || DMA) ? CH : CH + 16;
+  constexpr int ABUF = DMA ? NJ * 4096 : BOX * AP;  // DMA: whole 256-lane slots (the last one's tail lands in padding)
+  static_assert(!DMA || (!XF && CH == 32 && RB / CH > 1 && sizeof(T) == 2), "LDS-DMA staging: transform-free 32-byte chunks");
   constexpr int OFF_RED = 2 * ABUF, OFF_XF = OFF_RED + 2048 * NB, OFF_W = OFF_XF + 512;
   constexpr int NC = 32 * NB;  // output channels of the workgroup
   constexpr int CPR = RB / 16, RP256 = 16 / CPR;
@@ -490,8 +499,18 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
           }
     }
   }
+  int ahalf[3] = {0, 0, 0};  // DMA layout: this lane's 16-byte half of a row of box plane dz + jz
+  if constexpr (DMA) {
+    int dz, x;
+    ws_row_to_zx(r, dz, x);
+    abase = ((dz * BH + 2 * wave) * BW + x) * AP;
+#pragma unroll
+    for (int jz = 0; jz < 3; jz++) ahalf[jz] = (h ^ (((dz + jz) >> 1) & 1)) << 4;
+  }
   auto a_addr = [&](int jz, int yp, int jx, int fs) {
-    if constexpr (SWZ)
+    if constexpr (DMA)
+      return abase + ((jz * BH + yp) * BW + jx) * AP + ahalf[jz];
+    else if constexpr (SWZ)
       return aaddr[jz][yp][jx] ^ (fs * 32);
     else
       return abase + ((jz * BH + yp) * BW + jx) * AP + fs * 32;
@@ -508,6 +527,7 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
     int vox = min(tid + 256 * j, TOTAL - CPV + part) >> CPV_SHIFT;
     int bz = vox / (BH * BW), rem = vox - bz * (BH * BW), by = rem / BW, bx = rem - by * BW;
     boff[j] = ((bz * a.Hi + by) * a.Wi + bx) * (int)a.in_pitch;
+    if constexpr (DMA) boff[j] += ((part ^ ((bz >> 1) & 1)) - part) * EPC;  // source-side swap of the row's halves
     bxyz[j] = (bz << 16) | (by << 8) | bx;
     if constexpr (SWZ) {
       woff_t[j] = vox * CH + ((part ^ a_swz<CH>(vox)) << 4);
@@ -606,6 +626,26 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
       pf[j] = *reinterpret_cast<const u32x4*>(p);
     }
   };
+  // LDS-DMA of one item (tile c, channel chunk) into the tile buffer at byte offset buf_off; slots outside the
+  // tensor read the zero line.  Inline asm, counted by hand (see conv_wgrad_s2_kernel).
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  auto dma_item = [&](auto fast_tag, int chunk, const WsTile& c, bool valid, bool inter, const T* org, int buf_off)
+                      __attribute__((always_inline)) {
+    const uint32_t wbase = __builtin_amdgcn_readfirstlane(lds_base + buf_off + wave * 1024);
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      const T* p = org + boff[j] + chunk * (CH / ESZ);
+      if constexpr (!decltype(fast_tag)::value) {
+        const bool ok = inter | (valid & slot_ok(j, c));
+        p = ok ? p : reinterpret_cast<const T*>(g_zero_line);
+      }
+      uint32_t keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep)
+                   : "v"(p), "s"(wbase + (uint32_t)(j * 4096))
+                   : "memory");
+    }
+  };
   float sc[EPC], sh[EPC];
   auto read_xf = [&](int chunk) {
     const int cb = chunk * (CH / ESZ) + part * EPC;
@@ -678,6 +718,12 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
     org1 = v1 ? tile_org(T1) : src_safe;
     org2 = v2 ? tile_org(T2) : src_safe;
     __syncthreads();  // the previous pass is done with both tile buffers
+    if constexpr (DMA) {  // item 0 -> buffer 0, not overlapped; pass 0 of the first tile phase issues item 1
+      dma_item(std::false_type{}, 0, T0, true, i0, org0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      WS_BARRIER();
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < NJ; j++) load_one(std::false_type{}, j, 0, T0, true, i0, org0);
     if constexpr (XF) {
@@ -886,6 +932,10 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
         read_xf(c_chunk);
       }
       WS2_STAMP(0)
+      if constexpr (DMA) {  // item c+1 -> the other buffer (free since the barrier that ended pass c-1)
+        const T* const c_org = c_next ? org1 : org0;
+        dma_item(fast_tag, c_chunk, CT, c_next ? v1 : true, c_int, c_org, (1 - PAR) * ABUF);
+      }
       u32x4 af[2][4], bf[2][3 * NB];
       auto read_group = [&](int g, u32x4 (&A)[4], u32x4 (&B)[3 * NB]) {
         const int t = g / NFS, fs = g % NFS, jz = t / 3, jx = t % 3;
@@ -918,8 +968,10 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
         for (int j = 0; j < NJ; j++) {
           if ((j * NG) / NJ == g) {
 #ifndef WS2_DBG_NOSTAGE  // energy/cycle attribution experiments: drop the staging or the fragment reads
-            commit_one(fast_tag, j, CT, c_int, a_wr);
-            load_one(fast_tag, j, l_chunk, LT, l_val, l_int, l_org);
+            if constexpr (!DMA) {
+              commit_one(fast_tag, j, CT, c_int, a_wr);
+              load_one(fast_tag, j, l_chunk, LT, l_val, l_int, l_org);
+            }
 #endif
           }
         }
@@ -965,6 +1017,8 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
         __builtin_amdgcn_sched_barrier(0);
       }
       WS2_STAMP(1)
+      // DMA: item c+1 has landed (the epilogue's stores come after this wait: vmcnt counts them too, in order)
+      if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       WS_BARRIER();  // buffer PAR fully read, buffer 1-PAR fully written
       WS2_STAMP(2)
       if (c == 0 && pend_tile >= 0) flush_stats();  // previous tile's partials: every wave's s_red row is visible now
@@ -1839,8 +1893,6 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
 //  * the 9x9x9 dy box is stored with each x-line split into even then odd positions: the 4 voxels a transposed
 //    read addresses (2 apart in x) are then 4 consecutive 64-byte rows = all 64 banks once, without row padding.
 // Tile = 4x4x4 small voxels (whole tiles only: launcher check); wave w owns taps 7w..7w+6 (27 + one dummy).
-__device__ __attribute__((aligned(16))) uint32_t g_zero_line[4] = {0u, 0u, 0u, 0u};
-
 template <typename T, int SB>
 __global__ __launch_bounds__(256) void conv_wgrad_s2_kernel(WgradArgs a) {
   static_assert(sizeof(T) == 2, "16-bit storage only");
@@ -2650,6 +2702,14 @@ int launch_ws2(const ConvArgs& a, hipStream_t st) {
   const int tiles = a.N * ceil_div(a.Do, 4) * ceil_div(a.Ho, 8) * ceil_div(a.Wo, 8);
   const int cout_tiles = a.CoutP / (32 * NB);
   const int gx = std::min(tiles, std::max(1, 256 / cout_tiles));  // one workgroup per CU; the kernel splits the tiles
+  if constexpr (sizeof(T) == 2 && CH == 32 && (RB / CH > 1)) {
+    static const bool dma = getenv("HDF_WS_DMA") != nullptr;  // LDS-DMA staging of the transform-free layers
+    if (dma && !a.in_scale) {
+      hipLaunchKernelGGL((conv_ws2_kernel<T, CH, RB, false, NB, true>), dim3(gx, cout_tiles), dim3(256), 0, st, a);
+      HDF_LAUNCH_CHECK();
+      return HDF_OK;
+    }
+  }
   if (a.in_scale)
     hipLaunchKernelGGL((conv_ws2_kernel<T, CH, RB, true, NB>), dim3(gx, cout_tiles), dim3(256), 0, st, a);
   else
