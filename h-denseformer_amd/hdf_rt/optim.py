@@ -27,7 +27,7 @@ class FlatAdam:
         return flat
 
     def zero_grad(self, set_to_none=True):
-        for p in self.model.parameters():
+        for p in self.model.checked_parameters():
             p.grad = None
 
     @torch.no_grad()

@@ -135,6 +135,8 @@ class HDenseFormer(nn.Module):
         self.conv1x1_d2 = _CONV[nd](4 * nf, n_cls, kernel_size=1)
         self.conv1x1_d3 = _CONV[nd](8 * nf, n_cls, kernel_size=1)
 
+        self._params_checked = None      # parameter list verified by the last forward (see forward)
+        self._any_requires_grad = True
         self.compute_dtype = None        # None: follow autocast; "fp32" / "bf16" / "fp16": force
         self.dropout_seed = 0            # base seed of the counter-hash dropout masks (train mode)
         self._step = 0
@@ -210,7 +212,13 @@ class HDenseFormer(nn.Module):
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
         self._flat = None                 # .cuda()/.to()/.float() replaced param.data: re-flatten lazily
+        self._params_checked = None
         return out
+
+    def checked_parameters(self):
+        """The parameter list the last forward verified (registration order), or a fresh walk: what an optimizer
+        that runs once per step can iterate without paying nn.Module.parameters()'s name building (2.3 ms)."""
+        return self._params_checked if self._params_checked is not None else self._walk_params()
 
     def flat_parameters(self, params=None):
         if not self._aliased(params):
@@ -227,8 +235,8 @@ class HDenseFormer(nn.Module):
         self._forced_seed = int(seed) & 0xFFFFFFFF
 
     def flat_grads(self):
-        self.flat_parameters()
         if self._flat_grad is None:
+            self.flat_parameters()
             self._flat_grad = torch.zeros_like(self._flat)
             tbl = self._plan(_lib.F32).table
             self._grad_views = [self._flat_grad[off: off + numel].view(shape) for (_, off, numel, shape) in tbl]
@@ -263,8 +271,20 @@ class HDenseFormer(nn.Module):
         if x.dim() != 2 + self._ND or x.shape[1] != self.in_channels or tuple(x.shape[2:]) != self.image_size:
             raise _lib.HdfError(f"input shape {tuple(x.shape)} does not match (B,{self.in_channels},"
                                 f"{self.image_size})")
-        params = self._walk_params()
-        flat = self.flat_parameters(params)
+        # Host work before the first launch is exposed whenever the caller synchronises once per step (the reference
+        # trainer does: loss.item(), trainer.py:382-400): the walk over the 1 420 parameters and the check that each is
+        # still the view of the flat buffer cost ~1.5 ms.  So the launch is OPTIMISTIC: with a flat buffer from an
+        # earlier forward the kernels are enqueued first, on the assumption that nothing was replaced and requires_grad
+        # is as it was, and the full check runs while the GPU works; if it fails, the buffer is rebuilt and the forward
+        # is launched again (the first result is dropped before anyone can see it).
+        params = self._params_checked
+        optimistic = self._flat is not None and params is not None
+        if not optimistic:
+            params = self._walk_params()
+            self.flat_parameters(params)
+            self._params_checked = params
+            self._any_requires_grad = any(p.requires_grad for p in params)
+        flat = self._flat
         if flat.device != x.device:
             raise _lib.HdfError(f"parameters on {flat.device}, input on {x.device}")
         dtype = self._pick_dtype(x)
@@ -273,7 +293,7 @@ class HDenseFormer(nn.Module):
             self._runtimes[key] = Runtime(self._plan(dtype), x.device)
         rt = self._runtimes[key]
         xin = x.detach().float().contiguous()
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        need_grad = torch.is_grad_enabled() and self._any_requires_grad
         if self.training:
             self._step += 1
         if self._forced_seed is not None and self.training:
@@ -287,12 +307,29 @@ class HDenseFormer(nn.Module):
             seed = self.step_seed(self._step, rank)
         anchor = torch.zeros(1, device=x.device, requires_grad=need_grad)
         outs = HDFFunction.apply(xin, anchor, self, rt, self.training, seed)
+        if optimistic:  # verify what the launch assumed
+            params = self._walk_params()
+            any_rg = any(p.requires_grad for p in params)
+            stale = not self._aliased(params)
+            if stale or any_rg != self._any_requires_grad:
+                if stale:
+                    self._flatten()
+                self._params_checked, self._any_requires_grad = params, any_rg
+                need_grad = torch.is_grad_enabled() and any_rg
+                anchor = torch.zeros(1, device=x.device, requires_grad=need_grad)
+                outs = HDFFunction.apply(xin, anchor, self, rt, self.training, seed)
+            else:
+                self._params_checked = params
         self._last_rt = rt
         return list(outs)
 
     def _run_backward(self, rt, x, douts):
-        gflat = self.flat_grads()
-        params = self._walk_params()
+        params = self._params_checked        # the tensors the forward of this graph ran on
+        if params is None:
+            params = self._walk_params()
+        if self._flat_grad is None:
+            self.flat_grads()
+        gflat = self._flat_grad
         # torch semantics: .grad accumulates over backward calls until zero_grad().  The C backward
         # OVERWRITES the flat gradient buffer, so carry existing gradients over explicitly.
         prev = None

@@ -685,3 +685,50 @@ def test_bench_two_ranks_on_one_device_exercises_the_multi_gpu_code_path():
     assert rec["config"]["global_batch"] == 4 and rec["config"]["parallelism"] == "dp2"
     assert rec["value"] > 0 and abs(rec["value"] - 4 * 3 / (rec["ms_per_step"] * 3e-3)) < 1e-6 * rec["value"]
     assert "roofline" not in rec and "cpu_baseline" not in rec        # N = 1 only
+
+
+@pytest.mark.gpu
+def test_replaced_parameters_are_noticed_by_the_next_forward():
+    """The forward launches on the flat parameter buffer of the previous call and verifies afterwards that every
+    parameter is still a view of it (models/HDenseFormer.py forward): a tensor replaced between two forwards -- a new
+    module (`net.conv1x1 = nn.Conv3d(..)`), `p.data = ..`, requires_grad toggled -- must still take effect in the very
+    next forward, and the gradients must land on the new tensors."""
+    cfg, batch, tag = CFG_TINY, 2, "g1_tiny_eval"
+    net, sd = _build(cfg)
+    net.eval()
+    x, _ = _data(cfg, batch, tag)
+    xd = x.to(DEV)
+    base = [o.detach().clone() for o in net(xd)]
+    again = [o.detach() for o in net(xd)]                     # the optimistic path (second call), nothing changed
+    for a, b in zip(base, again):
+        assert torch.equal(a, b)
+    # 1. a replaced module: the head becomes a fresh Conv3d with other weights
+    old_head = net.conv1x1
+    new_head = torch.nn.Conv3d(cfg[2], cfg[1], kernel_size=1).to(DEV)
+    with torch.no_grad():
+        new_head.weight.copy_(old_head.weight * 2.0)
+        new_head.bias.copy_(old_head.bias + 1.0)
+    net.conv1x1 = new_head
+    out = net(xd)
+    ref = base[0].float() * 2.0 - old_head.bias.view(1, -1, 1, 1, 1) * 2.0 + (old_head.bias + 1.0).view(1, -1, 1, 1, 1)
+    assert _rel(out[0].detach().float(), ref) < 1e-5
+    for a, b in zip(base[1:], out[1:]):
+        assert torch.equal(a, b.detach())
+    # the gradient reaches the NEW tensors
+    out[0].float().sum().backward()
+    assert net.conv1x1.weight.grad is not None and float(net.conv1x1.weight.grad.abs().sum()) > 0
+    assert net.conv1x1.weight.data_ptr() != new_head.weight.data_ptr() or net.conv1x1.weight is new_head.weight
+    # 2. p.data swapped behind the module's back
+    net.zero_grad(set_to_none=True)
+    net(xd)
+    net.conv1x1_d1.bias.data = net.conv1x1_d1.bias.data.clone() + 3.0
+    out2 = net(xd)
+    assert _rel(out2[1].detach().float(), base[1].float() + 3.0) < 1e-5
+    # 3. requires_grad switched off everywhere: the next forward must not build a graph
+    for p in net.parameters():
+        p.requires_grad_(False)
+    out3 = net(xd)
+    assert not out3[0].requires_grad
+    for p in net.parameters():
+        p.requires_grad_(True)
+    assert net(xd)[0].requires_grad
