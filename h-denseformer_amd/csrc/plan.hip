@@ -178,7 +178,16 @@ struct hdf_plan {
   size_t stat_partials, wgrad_ws, inb_partials, inb_k;
   size_t wgrad_ws_bytes = 0;
   // backward scratch
-  View gA[4], gY[4], dCat[3], dUp[3], dSkip[3], dP[3], dUa[4], dUy[4], dX4, dAttnall;
+  View gA[4], gY[4], gY2[4], dCat[3], dUp[3], dSkip[3], dP[3], dUa[4], dUy[4], dX4, dAttnall;
+  // Side stream of the backward pass (weight gradients; see Exec::wgrad_stream) and a ring of its events.  Created
+  // lazily on first use, destroyed with the plan.
+  hipStream_t side = nullptr;
+  std::vector<hipEvent_t> events;
+  size_t ev_next = 0;
+  ~hdf_plan() {
+    for (hipEvent_t ev : events) (void)hipEventDestroy(ev);
+    if (side) (void)hipStreamDestroy(side);
+  }
   bool dcat_split[3] = {false, false, false};
   // at3 (the full-resolution transformer feature) is written by upsample_fwd and read by the plain encoder tail; with the
   // 27-loads-per-8-outputs upsample kernel that is 0.09 ms per step faster than HDF_FUSE_AT3=1 (the tail interpolating it
@@ -542,6 +551,7 @@ void layout(hdf_plan* p, int B) {
   for (int k = 0; k < 4; k++) {
     p->gA[k] = mkview(p, bp, "", k, ch[k], B);
     p->gY[k] = mkview(p, bp, "", k, ch[k], B);
+    p->gY2[k] = mkview(p, bp, "", k, ch[k], B);  // the level's second conv keeps its own dy (read by a side-stream wgrad)
     if (k < 3) {
       // gradient of cat_k = [upconv | ds]: two dense buffers when the halves are whole 32-channel blocks (every
       // consumer of a half -- InstanceNorm backward, max-pool backward, up-sampling backward, the transposed conv's
@@ -570,6 +580,17 @@ void layout(hdf_plan* p, int B) {
   p->ws_bytes = bp.cur;
 }
 
+// Backward runs its weight gradients on the plan's side stream.  They are off the critical path (nothing in backward
+// reads a weight gradient), MFMA-bound, and leave wave slots and 50 KB of LDS per CU free, while the chain they would
+// otherwise delay is full of HBM-bound passes (InstanceNorm backward, pooling / up-sampling backward, heads): with both in
+// flight the memory-bound kernels run under the matrix kernels (tools/overlap_probe.py: a 64->32 weight gradient plus
+// three elementwise passes over 268 MB tensors take 708 us on two streams against 880 us back to back).  Ordering:
+//  * fork: the side stream waits for an event recorded on the main stream after the producers of the operands;
+//  * a buffer a side-stream kernel still reads (the dy of a conv) is not overwritten: wait_readers() before its next
+//    writer on the main stream (each level keeps two dy buffers so that the wait is normally already satisfied);
+//  * join: the main stream waits for the side stream's last event at the end of every backward call, so at the ABI
+//    boundary all work is ordered on the caller's stream as before.
+// The shared weight-gradient workspace is only touched on the side stream (its kernels run in order).
 struct Exec {
   hdf_plan* p;
   char* ws;
@@ -577,6 +598,49 @@ struct Exec {
   float* grads;
   int B;
   hipStream_t st;
+  bool async = false;                           // weight gradients on the side stream
+  hipEvent_t last_side = nullptr;               // last event recorded on the side stream in this call
+  std::map<size_t, hipEvent_t> readers;         // workspace offset of a buffer -> side-stream event after its last reader
+  hipEvent_t next_event() {
+    if (p->events.size() < 256) {
+      hipEvent_t ev = nullptr;
+      if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+      p->events.push_back(ev);
+      return ev;
+    }
+    return p->events[p->ev_next++ % p->events.size()];
+  }
+  // stream for a weight-gradient launch whose operands are ready on the main stream now
+  hipStream_t wgrad_stream() {
+    if (!async) return st;
+    hipEvent_t f = next_event();
+    if (!f || hipEventRecord(f, st) != hipSuccess || hipStreamWaitEvent(p->side, f, 0) != hipSuccess) {
+      async = false;  // fall back to in-order execution (still correct)
+      return st;
+    }
+    return p->side;
+  }
+  // after the launch: remember that `buf` is read on the side stream until now
+  void wgrad_done(const View& buf) {
+    if (!async) return;
+    hipEvent_t d = next_event();
+    if (d && hipEventRecord(d, p->side) == hipSuccess) {
+      last_side = d;
+      readers[buf.off] = d;
+    }
+  }
+  void wait_readers(const View& buf) {
+    auto it = readers.find(buf.off);
+    if (it != readers.end()) {
+      (void)hipStreamWaitEvent(st, it->second, 0);
+      readers.erase(it);
+    }
+  }
+  void join() {
+    if (last_side) (void)hipStreamWaitEvent(st, last_side, 0);
+    last_side = nullptr;
+    readers.clear();
+  }
   void* at(const View& v) const { return ws + v.off; }
   float* f(size_t off) const { return reinterpret_cast<float*>(ws + off); }
   const float* P(int64_t off) const { return off < 0 ? nullptr : params + off; }
@@ -881,6 +945,7 @@ int in_backward(Exec& e, const Conv3& c, const View& da, const View& dy, int pre
                                      c.Cout, vox, e.st));
   HDF_TRY(hdf_launch_in_bwd_finalize(e.f(p->inb_partials), blocks, e.B, c.Cout, vox, e.P(c.gamma), e.f(c.st.rstd), k1,
                                      ka, kb, e.G(c.gamma), e.G(c.beta), e.st));
+  e.wait_readers(dy);  // a side-stream weight gradient may still read this buffer's previous contents
   HDF_TRY(hdf_launch_in_bwd_apply(p->dtype, e.at(da), da.pitch, e.at(c.y), c.y.pitch, e.f(c.st.scale), e.f(c.st.shift),
                                   e.f(c.st.mean), e.f(c.st.rstd), k1, ka, kb, e.at(dy), dy.pitch, e.B, c.Cout, vox,
                                   e.st));
@@ -909,7 +974,9 @@ int conv_backward(Exec& e, Conv3& c, const View& dy, const View& in, Xf xf, cons
   w.lg_scale = xf.scale;
   w.lg_shift = xf.shift;
   w.lg_relu = xf.relu;
-  HDF_TRY(hdf_launch_wgrad(p->dtype, 1, w, e.G(c.w), c.Cout, c.Cin, 0, e.ws + p->wgrad_ws, p->wgrad_ws_bytes, e.st));
+  HDF_TRY(hdf_launch_wgrad(p->dtype, 1, w, e.G(c.w), c.Cout, c.Cin, 0, e.ws + p->wgrad_ws, p->wgrad_ws_bytes,
+                           e.wgrad_stream()));
+  e.wgrad_done(dy);
   // Conv3 layers with a bias are the UpConvs (HDenseFormer.py:162-175): conv(bias) -> InstanceNorm3d(affine=False).
   // The norm subtracts the per-(sample, channel) mean, so dL/dbias = sum_voxels dy is identically zero (the reference
   // accumulates ~3e-8 of rounding noise there); the gradient buffer was zeroed at the start of backward,
@@ -966,7 +1033,9 @@ int convt_backward(Exec& e, ConvT3& t, const View& dout, const View& in, Xf xf, 
   w.sm_scale = xf.scale;
   w.sm_shift = xf.shift;
   w.sm_relu = xf.relu;
-  HDF_TRY(hdf_launch_wgrad(p->dtype, 2, w, e.G(t.w), t.Cin, t.Cout, 0, e.ws + p->wgrad_ws, p->wgrad_ws_bytes, e.st));
+  HDF_TRY(hdf_launch_wgrad(p->dtype, 2, w, e.G(t.w), t.Cin, t.Cout, 0, e.ws + p->wgrad_ws, p->wgrad_ws_bytes,
+                           e.wgrad_stream()));
+  e.wgrad_done(dout);
   // dX[i][ci] = sum_k sum_co dY[2i-1+k][co] * W[ci][co][k]  -> stride-2 gather conv, packed [tap][CinP][Cout]
   const int OP = round_up(t.Cin, 32);
   ConvArgs a{};
@@ -1242,6 +1311,20 @@ static int backward3d(hdf_plan* p, const float* x, const float* params, void* wo
   HDF_CHECK_ARG(p->batch == batch, "backward: batch %d differs from the forward's %d", batch, p->batch);
   HDF_CHECK_ARG((size_t)workspace_bytes >= p->ws_bytes, "backward: workspace too small");
   Exec e{p, (char*)workspace, params, grads, batch, (hipStream_t)stream};
+  static const bool no_async = getenv("HDF_NO_ASYNC_WGRAD") != nullptr;  // A/B knob: everything on the caller's stream
+  if (!no_async) {
+    if (!p->side) {
+      // lowest priority: when a data-gradient conv (critical path) and a weight gradient are both ready, the data
+      // gradient gets the CUs first and the weight gradient then runs next to the memory-bound passes that follow it
+      int least = 0, greatest = 0;
+      static const bool flat_prio = getenv("HDF_SIDE_STREAM_FLAT_PRIORITY") != nullptr;  // A/B knob
+      if (flat_prio || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
+          hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, least) != hipSuccess) {
+        if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess) p->side = nullptr;
+      }
+    }
+    e.async = p->side != nullptr;
+  }
   const int nf = p->nf;
   const int ch[4] = {nf, 2 * nf, 4 * nf, 8 * nf};
   const void* douts[4] = {dout0, dout1, dout2, dout3};
@@ -1261,13 +1344,13 @@ static int backward3d(hdf_plan* p, const float* x, const float* params, void* wo
     HDF_TRY(head_backward(e, p->head[k], douts[k], c2.y, xf_of(e, c2), p->gA[k], k > 0 ? 1 : 0, &c2, &pre));
     HDF_TRY(in_backward(e, c2, p->gA[k], p->gY[k], pre));
     HDF_TRY(conv_backward(e, c2, p->gY[k], c1.y, xf_of(e, c1), &p->gA[k], 0));
-    HDF_TRY(in_backward(e, c1, p->gA[k], p->gY[k]));
+    HDF_TRY(in_backward(e, c1, p->gA[k], p->gY2[k]));
     // the upconv half of d(cat) is the gradient of upconv_{k+1}'s output: its bias gradient rides on this conv
     float* up_db = p->no_bias_fuse ? nullptr : e.G(p->upc[k].b);
     if (p->dcat_split[k])
-      HDF_TRY(conv_backward(e, c1, p->gY[k], p->cat[k], none, &p->dUp[k], 0, &p->dSkip[k], up_db, ch[k]));
+      HDF_TRY(conv_backward(e, c1, p->gY2[k], p->cat[k], none, &p->dUp[k], 0, &p->dSkip[k], up_db, ch[k]));
     else
-      HDF_TRY(conv_backward(e, c1, p->gY[k], p->cat[k], none, &p->dCat[k], 0, nullptr, up_db, ch[k]));
+      HDF_TRY(conv_backward(e, c1, p->gY2[k], p->cat[k], none, &p->dCat[k], 0, nullptr, up_db, ch[k]));
     // upconv_{k+1}: input is dec[k+1][1] activation (k<2) or the bottleneck x4 (k==2)
     const View& dup = p->dUp[k];
     if (k < 2)
@@ -1289,13 +1372,14 @@ static int backward3d(hdf_plan* p, const float* x, const float* params, void* wo
     }
     HDF_TRY(in_backward(e, c2, dskip, p->gY[k]));
     HDF_TRY(conv_backward(e, c2, p->gY[k], c1.y, xf_of(e, c1), &p->gA[k], 0));
-    HDF_TRY(in_backward(e, c1, p->gA[k], p->gY[k]));
+    HDF_TRY(in_backward(e, c1, p->gA[k], p->gY2[k]));
     if (k > 0)
-      HDF_TRY(conv_backward(e, c1, p->gY[k], p->pooled[k - 1], none, &p->dP[k - 1], 0));
+      HDF_TRY(conv_backward(e, c1, p->gY2[k], p->pooled[k - 1], none, &p->dP[k - 1], 0));
     else
-      HDF_TRY(conv_backward(e, c1, p->gY[k], p->xin, none, nullptr, 0));
+      HDF_TRY(conv_backward(e, c1, p->gY2[k], p->xin, none, nullptr, 0));
   }
 
+  if (!(stages & 6)) e.join();  // staged call (gradient buckets): final when it returns
   }  // stage 1: every gradient of the encoder / decoder / head parameters is final here
   if (stages & 2) {
 
@@ -1322,8 +1406,10 @@ static int backward3d(hdf_plan* p, const float* x, const float* params, void* wo
     HDF_TRY(in_backward(e, c, p->dUa[0], p->dUy[0]));
     HDF_TRY(conv_backward(e, c, p->dUy[0], p->attnall, none, &p->dAttnall, 0));
   }
+  if (!(stages & 4)) e.join();  // staged call: final when it returns; else the transformer branches run under them
   }  // stage 2: deep_conv / up1..3 gradients are final
   if (stages & 4) HDF_TRY(transformer_backward(e, x));
+  e.join();
   return HDF_OK;
 }
 

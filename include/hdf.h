@@ -55,7 +55,9 @@ int hdf_plan_buffer_info(hdf_plan* p, int batch, const char* name, int64_t* byte
 int hdf_forward(hdf_plan* p, const float* x, const float* params, void* workspace, int64_t workspace_bytes, void* out0,
                 void* out1, void* out2, void* out3, int batch, int training, uint64_t seed, hdf_stream stream);
 /* autograd of the above (trainer.py:374-380 loss.backward()).  dout_i: gradients w.r.t. the 4 outputs, same
- * layout/dtype.  grads: flat fp32 buffer, OVERWRITTEN with d loss / d params. */
+ * layout/dtype.  grads: flat fp32 buffer, OVERWRITTEN with d loss / d params.
+ * Streams: the conv weight gradients run on one internal side stream of the plan, forked from `stream` with an event;
+ * `stream` waits for them before the call's work is complete on it (HDF_NO_ASYNC_WGRAD=1 disables). */
 int hdf_backward(hdf_plan* p, const float* x, const float* params, void* workspace, int64_t workspace_bytes,
                  const void* dout0, const void* dout1, const void* dout2, const void* dout3, float* grads, int batch,
                  hdf_stream stream);

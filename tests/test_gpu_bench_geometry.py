@@ -320,3 +320,26 @@ def test_baseline_config_shapes_forward_vs_oracle_and_low_precision_step(name, c
         print(f"  {low} cosine {k:60s} {c:.4f}")
     assert cos[0][1] >= 0.95, cos[:4]
     assert all(bool(torch.isfinite(p.grad).all()) for p in net.parameters())
+
+
+def test_weight_gradients_on_the_side_stream_are_reproducible():
+    """The conv / transposed-conv weight gradients run on the plan's side stream next to the rest of backward
+    (csrc/plan.hip Exec).  They are summed in a fixed order, so the same step run three times must give bitwise equal
+    gradients for every conv weight: a weight gradient that reads a dy buffer the main stream has already overwritten, or
+    a join that comes too early, shows up as a difference.  (Biases, LayerNorm parameters and the heads use float
+    atomics and are compared with a tolerance.)  bf16 storage at 64^3 x 2: every kernel family of the benchmark."""
+    cfg, batch, tag = (4, 4, 32, (64, 64, 64), 8), 2, "g4_mid_train"
+    net, _ = _build(cfg, "bf16")
+    x, onehot = _data(cfg, batch, tag)
+    runs = []
+    for _ in range(3):
+        _step(net, x, onehot, 4321)
+        runs.append({n: p.grad.detach().clone() for n, p in net.named_parameters()})
+    exact = [n for n in runs[0] if n.endswith("conv.weight") or (n.startswith("upconv_") and n.endswith(".weight")) or
+             n.endswith("double_conv.0.weight")]
+    assert len(exact) >= 20
+    for n in exact:
+        assert torch.equal(runs[0][n], runs[1][n]) and torch.equal(runs[0][n], runs[2][n]), n
+    for n in runs[0]:
+        if runs[0][n].norm() > 0:
+            assert _rl2(runs[1][n], runs[0][n]) < 1e-4, n
