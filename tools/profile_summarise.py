@@ -62,9 +62,21 @@ if f:
         k = short(r["Kernel_Name"])
         tot[k][0] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
         tot[k][1] += 1
+    # union of the launch intervals (two streams run concurrently in backward: the per-kernel sums overlap)
+    iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in win)
+    union, cs, ce = 0, iv[0][0], iv[0][1]
+    for a_, b_ in iv[1:]:
+        if a_ > ce:
+            union += ce - cs
+            cs, ce = a_, b_
+        else:
+            ce = max(ce, b_)
+    union += ce - cs
+    queues = sorted({r.get("Queue_Id", "?") for r in win})
     with open(os.path.join(dst, f"{pre}_step_kernel_totals.txt"), "w") as fh:
-        fh.write(f"one adam-to-adam window of the kernel trace: {sum(v[0] for v in tot.values()):.1f} us busy, "
-                 f"{len(win)} launches\n")
+        fh.write(f"one adam-to-adam window of the kernel trace: {union / 1e3:.1f} us with at least one kernel running, "
+                 f"{sum(v[0] for v in tot.values()):.1f} us summed over the kernels ({len(queues)} queues: durations of "
+                 f"kernels that share the GPU are stretched), {len(win)} launches\n")
         for k, (d, n) in sorted(tot.items(), key=lambda kv: -kv[1][0]):
             fh.write(f"{d:9.1f} us {n:4d}  {k}\n")
 for name in ("bench_line_full.json", "roofline_line.json", "clock_probe_64x32.txt", "clock_probe_32x32.txt"):
