@@ -4,8 +4,9 @@
  * replaces the torch call sequence cited next to it (file:line into the reference repository).  All
  * pointers are raw DEVICE pointers unless marked host.  The library never allocates or frees device
  * memory, never synchronises the device and enqueues everything on the caller's stream (hipStream_t
- * passed as void*), so it composes with torch's caching allocator, autograd streams and RCCL side
- * streams.  Errors: every function returns 0 on success, non-zero otherwise; hdf_last_error() gives the
+ * passed as void*; hdf_backward additionally forks work onto one internal stream of the plan and joins
+ * it back before returning, see there), so it composes with torch's caching allocator, autograd
+ * streams and RCCL side streams.  Errors: every function returns 0 on success, non-zero otherwise; hdf_last_error() gives the
  * message (thread-local).  No C++ exception crosses this boundary.
  *
  * dtype enum: 0 = float32 storage (v_mfma_f32_32x32x2_f32, exact fp32 -- the parity path),
