@@ -197,7 +197,11 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # Launched through torch.distributed.run (RANK / MASTER_ADDR in the environment) the process group, GradSync and
+    # the fences are ALWAYS set up, also for one rank: `--nproc-per-node 1` is the pre-flight of the RCCL path that a
+    # single-GPU box allows (RCCL refuses two ranks on one device).  A plain `python bench.py` stays collective-free.
+    dist_on = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
+    if dist_on:
         import torch.distributed as dist
         if one_dev:
             dist.init_process_group("gloo")
@@ -218,7 +222,7 @@ def main():
     crit = DeepSuperloss(criterion=CEPlusDice(weight=None, ignore_index=0))
     opt = FlatAdam(net, lr=1e-3, weight_decay=1e-4)
     sync = None
-    if world > 1:
+    if dist_on:
         from hdf_rt.parallel import GradSync
         sync = GradSync(net)
         net.grad_hook = sync
@@ -239,7 +243,7 @@ def main():
         return loss
 
     def fence():
-        if world > 1:
+        if dist_on:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -259,7 +263,7 @@ def main():
     raw_steps = [evs[k].elapsed_time(evs[k + 1]) for k in range(a.steps)]
     per_step = sorted(raw_steps)
     median_ms = per_step[len(per_step) // 2]
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -275,7 +279,8 @@ def main():
             "config": {"workload": "HDenseFormer_32 3D train step (fwd + DeepSuper CE+Dice + bwd + Adam), "
                                    "in=4 n_cls=4 128^3 transformer_depth=24 (BASELINE configs[1])",
                        "global_batch": global_batch, "per_gpu_batch": a.batch, "parallelism": f"dp{world}",
-                       "dropout": "on (train mode)", "loss": last_loss},
+                       "dropout": "on (train mode)", "loss": last_loss,
+                       "collective": (torch.distributed.get_backend() if dist_on else None)},
             "step_tflops": FWD_BWD_GFLOP_PER_SAMPLE * sps / 1e3,
             "hip_event_ms_per_step": {"median": median_ms, "min": per_step[0], "max": per_step[-1],
                                       "slowest_step": raw_steps.index(per_step[-1])},
@@ -289,7 +294,7 @@ def main():
                 if rec["cpu_baseline"]["value"]:
                     rec["gpu_over_cpu"] = sps / rec["cpu_baseline"]["value"]
         print(json.dumps(rec), flush=True)
-    if world > 1:
+    if dist_on:
         torch.distributed.destroy_process_group()
 
 

@@ -2701,7 +2701,7 @@ template <typename T, int CH, int RB, int NB>
 int launch_ws2(const ConvArgs& a, hipStream_t st) {
   const int tiles = a.N * ceil_div(a.Do, 4) * ceil_div(a.Ho, 8) * ceil_div(a.Wo, 8);
   const int cout_tiles = a.CoutP / (32 * NB);
-  const int gx = std::min(tiles, std::max(1, 256 / cout_tiles));  // one workgroup per CU; the kernel splits the tiles
+  const int gx = std::min(tiles, std::max(1, hdf_cu_budget() / cout_tiles));  // one workgroup per CU; the kernel splits the tiles
   if constexpr (sizeof(T) == 2 && CH == 32 && (RB / CH > 1)) {
     static const bool dma = getenv("HDF_WS_DMA") != nullptr;  // LDS-DMA staging of the transform-free layers
     if (dma && !a.in_scale) {
@@ -2744,7 +2744,7 @@ int launch_conv_t(int mode, const ConvArgs& a, hipStream_t st) {
       if (!g_old && a.Cin * 2 == 64 && a.CoutP == 64 && !a.in_scale && !a.accumulate && a.Do % 4 == 0 && a.Ho % 4 == 0 &&
           a.Wo % 4 == 0 && a.Di == 2 * a.Do && a.Hi == 2 * a.Ho && a.Wi == 2 * a.Wo) {
         const int tiles = a.N * (a.Do / 4) * (a.Ho / 4) * (a.Wo / 4);
-        hipLaunchKernelGGL((conv_gather_s2_kernel<T>), dim3(std::min(tiles, 256)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((conv_gather_s2_kernel<T>), dim3(std::min(tiles, hdf_cu_budget())), dim3(256), 0, st, a);
         HDF_LAUNCH_CHECK();
         return HDF_OK;
       }
@@ -2757,7 +2757,7 @@ int launch_conv_t(int mode, const ConvArgs& a, hipStream_t st) {
       if (!ct_old && a.Cin * 2 == 128 && a.CoutP == 32 && !a.accumulate && a.Di % 4 == 0 && a.Hi % 4 == 0 && a.Wi % 8 == 0 &&
           a.Do == 2 * a.Di && a.Ho == 2 * a.Hi && a.Wo == 2 * a.Wi) {
         const int tiles = a.N * (a.Di / 4) * (a.Hi / 4) * (a.Wi / 8);
-        hipLaunchKernelGGL((convt_ws_kernel<T>), dim3(std::min(tiles, 256)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((convt_ws_kernel<T>), dim3(std::min(tiles, hdf_cu_budget())), dim3(256), 0, st, a);
         HDF_LAUNCH_CHECK();
         return HDF_OK;
       }
@@ -2800,7 +2800,7 @@ int launch_wgrad_t(WgradArgs a, float* dw, int sc_store, int lc_store, int accum
   static const int wg_old = getenv("HDF_WGRAD_OLD_WGS") ? atoi(getenv("HDF_WGRAD_OLD_WGS")) : 256;
   static const bool force_old = getenv("HDF_WGRAD_OLD") != nullptr;
   const bool use_new = sizeof(T) == 2 && S == 1 && !a.sm_scale && !force_old;
-  const int wg_target = use_new ? wg_new : wg_old;
+  const int wg_target = std::min(use_new ? wg_new : wg_old, hdf_cu_budget());
   int G = ceil_div(wg_target, pairs);
   G = (int)std::min<int64_t>(G, std::max<int64_t>(1, (int64_t)ws_bytes / per));
   G = std::min(G, a.num_tiles);

@@ -9,10 +9,11 @@ struct LossScales {
 int hdf_loss_blocks();
 size_t hdf_loss_workspace_floats(int N, int nscale);
 int hdf_launch_loss_fwd(int dtype, const void* const* logits, const float* target, int nscale, int N, int C, int D,
-                        int H, int W, float* ws, float* loss_out, hipStream_t st, float w_ce = 1.f, float w_dice = 1.f);
+                        int H, int W, float* ws, float* loss_out, hipStream_t st, float w_ce = 1.f, float w_dice = 1.f,
+                        const float* class_weight = nullptr, int dice_ignore = 0);
 int hdf_launch_loss_bwd(int dtype, const void* const* logits, const float* target, int nscale, int N, int C, int D,
                         int H, int W, const float* ws, const float* grad_out, void* const* dlogits, hipStream_t st,
-                        float w_ce = 1.f, float w_dice = 1.f);
+                        float w_ce = 1.f, float w_dice = 1.f, const float* class_weight = nullptr, int dice_ignore = 0);
 int hdf_launch_dice_counts(int dtype, const void* logits, const float* target, int N, int C, int64_t V,
                            unsigned long long* counts, hipStream_t st);
 int hdf_launch_confusion(int dtype, const void* logits, const float* target, int N, int C, int64_t V,

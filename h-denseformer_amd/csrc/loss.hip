@@ -10,11 +10,12 @@
 namespace {
 constexpr int MAXC = 8;
 constexpr int LOSS_BLOCKS = 1024;
-constexpr int NSTAT = 3 * MAXC + 1;
+constexpr int NSTAT = 3 * MAXC + 2;  // per class: sum p*t, sum p, sum t; then the (weighted) CE sum and the sum of CE weights
 
 template <typename T>
 __global__ __launch_bounds__(256) void loss_fwd_kernel(const T* __restrict__ logits, const float* __restrict__ target,
                                                        int C, int Ds, int Hs, int Ws, int stride, int D, int H, int W,
+                                                       const float* __restrict__ cw /*[C] class weights or null*/,
                                                        float* __restrict__ partials /*[N][blocks][NSTAT]*/) {
   __shared__ float red[4][NSTAT];
   const int n = blockIdx.y;
@@ -56,7 +57,12 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(const T* __restrict__ log
         acc[c] += p * t[c];
         acc[MAXC + c] += p;
         acc[2 * MAXC + c] += t[c];
-        if (c == tc) acc[3 * MAXC] += lse - lg[c];
+        if (c == tc) {
+          // torch CrossEntropyLoss(weight=w, reduction='mean'): sum_v w[t_v] * nll_v / sum_v w[t_v]
+          const float wv = cw ? cw[c] : 1.f;
+          acc[3 * MAXC] += cw ? wv * (lse - lg[c]) : lse - lg[c];
+          acc[3 * MAXC + 1] += wv;
+        }
       }
   }
 #pragma unroll
@@ -75,8 +81,9 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(const T* __restrict__ log
 // coefficients coef[(i*N+n)*MAXC + c] = (A, B) of the Dice gradient; terms[i*N+n] is summed by loss_total_kernel
 __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ partials, int nscale, int N, int C,
                                                             int blocks, LossScales sc, float smooth, float w_ce,
-                                                            float w_dice, float* __restrict__ terms, float* __restrict__ coefA,
-                                                            float* __restrict__ coefB) {
+                                                            float w_dice, const float* __restrict__ cw, int ignore,
+                                                            float* __restrict__ terms, float* __restrict__ coefA,
+                                                            float* __restrict__ coefB, float* __restrict__ wsum_out) {
   __shared__ double red[4][NSTAT];
   const int i = blockIdx.x / N, n = blockIdx.x % N;
   const float* base = partials + ((int64_t)i * N + n) * blocks * NSTAT;
@@ -86,6 +93,14 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
   for (int b = threadIdx.x; b < blocks; b += 256)
 #pragma unroll
     for (int k = 0; k < NSTAT; k++) s[k] += (double)base[(int64_t)b * NSTAT + k];
+  if (cw) {  // weighted CE: the denominator is the weight sum over ALL samples of the scale (slot NSTAT-1 of every n)
+    double wall = 0.0;
+    for (int m = 0; m < N; m++) {
+      const float* bm = partials + ((int64_t)i * N + m) * blocks * NSTAT;
+      for (int b = threadIdx.x; b < blocks; b += 256) wall += (double)bm[(int64_t)b * NSTAT + 3 * MAXC + 1];
+    }
+    s[3 * MAXC + 1] = wall;
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < NSTAT; k++) {
@@ -99,17 +114,22 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
     double t[NSTAT];
     for (int k = 0; k < NSTAT; k++) t[k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
     double V = (double)sc.V[i];
-    double ce = t[3 * MAXC] / (V * N);
+    double ce = cw ? t[3 * MAXC] / t[3 * MAXC + 1] : t[3 * MAXC] / (V * N);
+    if (n == 0) wsum_out[i] = cw ? (float)t[3 * MAXC + 1] : (float)(V * N);
     double dice = 0.0;
-    for (int c = 1; c < C; c++) {
-      double I = t[c], U = t[MAXC + c] + t[2 * MAXC + c];
-      dice += (1.0 - (2.0 * I + smooth) / (U + smooth)) / (double)N;
-      coefA[((int64_t)i * N + n) * MAXC + c] = (float)(2.0 / (U + smooth));
-      coefB[((int64_t)i * N + n) * MAXC + c] = (float)((2.0 * I + smooth) / ((U + smooth) * (U + smooth)));
+    for (int c = 0; c < C; c++) {
+      float A = 0.f, B = 0.f;
+      if (c != ignore) {  // dice_loss.py:75-84: every class but ignore_index, times its class weight
+        const double wc = cw ? (double)cw[c] : 1.0;
+        double I = t[c], U = t[MAXC + c] + t[2 * MAXC + c];
+        dice += wc * (1.0 - (2.0 * I + smooth) / (U + smooth)) / (double)N;
+        A = (float)(wc * 2.0 / (U + smooth));
+        B = (float)(wc * (2.0 * I + smooth) / ((U + smooth) * (U + smooth)));
+      }
+      coefA[((int64_t)i * N + n) * MAXC + c] = A;
+      coefB[((int64_t)i * N + n) * MAXC + c] = B;
     }
-    coefA[((int64_t)i * N + n) * MAXC] = 0.f;
-    coefB[((int64_t)i * N + n) * MAXC] = 0.f;
-    dice /= (double)(C - 1);
+    dice /= (double)(ignore >= 0 ? C - 1 : C);  // dice_loss.py:84-87
     // CE is already a mean over all N samples' voxels: every (scale, n) block contributes its own share
     terms[blockIdx.x] = (float)(((double)w_ce * ce + (double)w_dice * dice) * (double)sc.weight[i]);
   }
@@ -128,13 +148,17 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const T* __restrict__ log
                                                        int N, int C, int Ds, int Hs, int Ws, int stride, int D, int H,
                                                        int W, const float* __restrict__ coefA,
                                                        const float* __restrict__ coefB, float weight, float w_ce,
-                                                       float w_dice, const float* __restrict__ gup,
+                                                       float w_dice, const float* __restrict__ cw, int ignore,
+                                                       const float* __restrict__ wsum, const float* __restrict__ gup,
                                                        T* __restrict__ dlogits) {
   const int n = blockIdx.y;
   const int64_t V = (int64_t)Ds * Hs * Ws, Vf = (int64_t)D * H * W;
   const float g = (*gup) * weight;
-  const float kce = w_ce * g / ((float)V * (float)N);
-  const float kd = w_dice * g / ((float)(C - 1) * (float)N);
+  const float kce0 = cw ? w_ce * g / (*wsum) : w_ce * g / ((float)V * (float)N);
+  const float kd = w_dice * g / ((float)(ignore >= 0 ? C - 1 : C) * (float)N);
+  float cwr[MAXC];
+#pragma unroll
+  for (int c = 0; c < MAXC; c++) cwr[c] = (cw && c < C) ? cw[c] : 1.f;
   float cA[MAXC], cB[MAXC];
 #pragma unroll
   for (int c = 0; c < MAXC; c++) {
@@ -170,9 +194,15 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const T* __restrict__ log
     for (int c = 0; c < MAXC; c++)
       if (c < C) {
         p[c] *= inv;
-        G[c] = (c >= 1) ? -kd * (cA[c] * t[c] - cB[c]) : 0.f;  // dDice/dp_c
+        G[c] = -kd * (cA[c] * t[c] - cB[c]);  // dDice/dp_c (the coefficients of the ignored class are zero)
         dot += G[c] * p[c];
       }
+    float kce = kce0;
+    if (cw) {
+#pragma unroll
+      for (int c = 0; c < MAXC; c++)
+        if (c == tc) kce = kce0 * cwr[c];
+    }
 #pragma unroll
     for (int c = 0; c < MAXC; c++)
       if (c < C) {
@@ -357,8 +387,10 @@ size_t hdf_loss_workspace_floats(int N, int nscale) {
 }
 
 int hdf_launch_loss_fwd(int dtype, const void* const* logits, const float* target, int nscale, int N, int C, int D,
-                        int H, int W, float* ws, float* loss_out, hipStream_t st, float w_ce, float w_dice) {
+                        int H, int W, float* ws, float* loss_out, hipStream_t st, float w_ce, float w_dice,
+                        const float* class_weight, int dice_ignore) {
   HDF_CHECK_ARG(C <= MAXC && C >= 2, "loss: n_cls=%d unsupported (2..%d)", C, MAXC);
+  HDF_CHECK_ARG(dice_ignore >= -1 && dice_ignore < C, "loss: ignore_index %d outside [-1, %d)", dice_ignore, C);
   HDF_CHECK_ARG(nscale <= 4 && nscale * N <= 256, "loss: nscale=%d N=%d", nscale, N);
   float* partials = ws;
   float* coefA = ws + (size_t)nscale * N * LOSS_BLOCKS * NSTAT;
@@ -373,12 +405,13 @@ int hdf_launch_loss_fwd(int dtype, const void* const* logits, const float* targe
     sc.weight[i] = 1.f / (float)s;
     float* pi = partials + (size_t)i * N * LOSS_BLOCKS * NSTAT;
     HDF_DISPATCH_T(dtype, hipLaunchKernelGGL(loss_fwd_kernel<T>, dim3(LOSS_BLOCKS, N), dim3(256), 0, st,
-                                             (const T*)logits[i], target, C, Ds, Hs, Ws, s, D, H, W, pi));
+                                             (const T*)logits[i], target, C, Ds, Hs, Ws, s, D, H, W, class_weight, pi));
     HDF_LAUNCH_CHECK();
   }
   float* terms = coefB + (size_t)nscale * N * MAXC;
+  float* wsum = terms + (size_t)nscale * N;  // [nscale]: denominator of the cross-entropy mean (the 16 spare floats)
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(nscale * N), dim3(256), 0, st, partials, nscale, N, C, LOSS_BLOCKS, sc,
-                     1e-5f, w_ce, w_dice, terms, coefA, coefB);
+                     1e-5f, w_ce, w_dice, class_weight, dice_ignore, terms, coefA, coefB, wsum);
   HDF_LAUNCH_CHECK();
   hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(64), 0, st, terms, nscale * N, loss_out);
   HDF_LAUNCH_CHECK();
@@ -387,9 +420,10 @@ int hdf_launch_loss_fwd(int dtype, const void* const* logits, const float* targe
 
 int hdf_launch_loss_bwd(int dtype, const void* const* logits, const float* target, int nscale, int N, int C, int D,
                         int H, int W, const float* ws, const float* grad_out, void* const* dlogits, hipStream_t st,
-                        float w_ce, float w_dice) {
+                        float w_ce, float w_dice, const float* class_weight, int dice_ignore) {
   const float* coefA = ws + (size_t)nscale * N * LOSS_BLOCKS * NSTAT;
   const float* coefB = coefA + (size_t)nscale * N * MAXC;
+  const float* wsum = coefB + (size_t)nscale * N * MAXC + (size_t)nscale * N;
   for (int i = 0; i < nscale; i++) {
     int s = 1 << i;
     int Ds = D == 1 ? 1 : D / s, Hs = H / s, Ws = W / s;
@@ -397,8 +431,8 @@ int hdf_launch_loss_bwd(int dtype, const void* const* logits, const float* targe
     unsigned gx = (unsigned)std::min<int64_t>(ceil_div64(V, 256), 2048);
     HDF_DISPATCH_T(dtype, hipLaunchKernelGGL(loss_bwd_kernel<T>, dim3(gx, N), dim3(256), 0, st, (const T*)logits[i],
                                              target, N, C, Ds, Hs, Ws, s, D, H, W, coefA + (size_t)i * N * MAXC,
-                                             coefB + (size_t)i * N * MAXC, 1.f / (float)s, w_ce, w_dice, grad_out,
-                                             (T*)dlogits[i]));
+                                             coefB + (size_t)i * N * MAXC, 1.f / (float)s, w_ce, w_dice, class_weight,
+                                             dice_ignore, wsum + i, grad_out, (T*)dlogits[i]));
     HDF_LAUNCH_CHECK();
   }
   return HDF_OK;

@@ -15,6 +15,10 @@
 #include "unet_ops.h"
 
 static thread_local char g_err[1024] = "";
+static thread_local int g_cu_budget = 256;
+int hdf_cu_budget() { return g_cu_budget; }
+void hdf_set_cu_budget_tl(int cus) { g_cu_budget = (cus >= 8 && cus <= 256) ? cus / 8 * 8 : 256; }
+
 void hdf_set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -1075,6 +1079,11 @@ int head_backward(Exec& e, const Head1& h, const void* dlogits, const View& in, 
 extern "C" {
 
 const char* hdf_version(void) { return "hdf-hip 0.1 (gfx950)"; }
+int hdf_set_cu_budget(int cus) {
+  HDF_CHECK_ARG(cus >= 8 && cus <= 256 && cus % 8 == 0, "cu budget %d: a multiple of 8 in [8, 256]", cus);
+  hdf_set_cu_budget_tl(cus);
+  return HDF_OK;
+}
 const char* hdf_last_error(void) { return g_err; }
 
 static int create_plan(int in_channels, int n_cls, int n_filters, int D, int H, int W, int transformer_depth, int dtype,
@@ -1446,6 +1455,25 @@ int hdf_loss_terms_backward(int dtype, const void* out0, const void* out1, const
   void* douts[4] = {dout0, dout1, dout2, dout3};
   return hdf_launch_loss_bwd(dtype, outs, target_onehot, nscale, batch, n_cls, D, H, W, (const float*)workspace,
                              grad_out, douts, (hipStream_t)stream, ce_weight, dice_weight);
+}
+int hdf_loss_weighted_forward(int dtype, const void* out0, const void* out1, const void* out2, const void* out3,
+                              int nscale, const float* target_onehot, int batch, int n_cls, int D, int H, int W,
+                              float ce_weight, float dice_weight, const float* class_weight, int dice_ignore_index,
+                              void* workspace, float* loss_out, hdf_stream stream) {
+  const void* outs[4] = {out0, out1, out2, out3};
+  return hdf_launch_loss_fwd(dtype, outs, target_onehot, nscale, batch, n_cls, D, H, W, (float*)workspace, loss_out,
+                             (hipStream_t)stream, ce_weight, dice_weight, class_weight, dice_ignore_index);
+}
+int hdf_loss_weighted_backward(int dtype, const void* out0, const void* out1, const void* out2, const void* out3,
+                               int nscale, const float* target_onehot, int batch, int n_cls, int D, int H, int W,
+                               float ce_weight, float dice_weight, const float* class_weight, int dice_ignore_index,
+                               const void* workspace, const float* grad_out, void* dout0, void* dout1, void* dout2,
+                               void* dout3, hdf_stream stream) {
+  const void* outs[4] = {out0, out1, out2, out3};
+  void* douts[4] = {dout0, dout1, dout2, dout3};
+  return hdf_launch_loss_bwd(dtype, outs, target_onehot, nscale, batch, n_cls, D, H, W, (const float*)workspace,
+                             grad_out, douts, (hipStream_t)stream, ce_weight, dice_weight, class_weight,
+                             dice_ignore_index);
 }
 int hdf_dice_counts(int dtype, const void* logits, const float* target_onehot, int batch, int n_cls, int64_t voxels,
                     uint64_t* counts, hdf_stream stream) {

@@ -15,6 +15,7 @@ _vp, _i, _i64, _f, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 _PROTOS = {
     "hdf_version": (C.c_char_p, []),
     "hdf_last_error": (C.c_char_p, []),
+    "hdf_set_cu_budget": (_i, [_i]),
     "hdf_plan_create": (_i, [_i] * 8 + [C.POINTER(_vp)]),
     "hdf_plan_create_2d": (_i, [_i] * 7 + [C.POINTER(_vp)]),
     "hdf_plan_destroy": (None, [_vp]),
@@ -35,6 +36,10 @@ _PROTOS = {
     "hdf_loss_terms_forward": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
     "hdf_loss_terms_backward": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp,
                                      _vp, _vp, _vp]),
+    "hdf_loss_weighted_forward": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _i, _vp, _vp,
+                                       _vp]),
+    "hdf_loss_weighted_backward": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _i, _vp, _vp,
+                                        _vp, _vp, _vp, _vp, _vp]),
     "hdf_dice_counts": (_i, [_i, _vp, _vp, _i, _i, _i64, _vp, _vp]),
     "hdf_confusion_matrix": (_i, [_i, _vp, _vp, _i, _i, _i64, _vp, _i, _vp]),
     "hdf_confusion_matrix_labels": (_i, [_vp, _vp, _i, _i64, _vp, _i, _vp]),

@@ -9,14 +9,19 @@ _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 
 
 class DeepSuperCEDice(torch.autograd.Function):
-    """apply(target, *outs) = DeepSuperloss(CEPlusDice); apply((target, w_ce, w_dice), *outs) weights the two terms
-    (0,1: DiceLoss(ignore_index=0); 1,0: CrossentropyLoss)."""
+    """apply(target, *outs) = DeepSuperloss(CEPlusDice(weight=None, ignore_index=0)); apply((target, w_ce, w_dice), *outs)
+    weights the two terms (0,1: DiceLoss(ignore_index=0); 1,0: CrossentropyLoss); apply((target, w_ce, w_dice,
+    class_weight, ignore_index), *outs) adds the per-class weights and the Dice ignore_index (None: all classes) that
+    trainer.py:743-771 can pass."""
 
     @staticmethod
     def forward(ctx, target, *outs):
-        w_ce, w_dice = 1.0, 1.0
+        w_ce, w_dice, cw, ignore = 1.0, 1.0, None, 0
         if isinstance(target, tuple):
-            target, w_ce, w_dice = target
+            if len(target) == 3:
+                target, w_ce, w_dice = target
+            else:
+                target, w_ce, w_dice, cw, ignore = target
         if not all(o.is_cuda for o in outs) or not target.is_cuda:
             raise _lib.HdfError("fused loss needs GPU tensors (no CPU fallback)")
         dt = outs[0].dtype
@@ -35,14 +40,19 @@ class DeepSuperCEDice(torch.autograd.Function):
                 raise AssertionError(f"predict & target shape do not match at scale {i}: {tuple(o.shape)}")
         outs = [o.contiguous() for o in outs]
         tgt = target.float().contiguous()
+        if cw is not None:
+            cw = torch.as_tensor(cw, dtype=torch.float32).to(tgt.device).contiguous()
+            if cw.dim() != 1 or cw.shape[0] != c:
+                raise AssertionError(f"Expect weight shape [{c}], get[{tuple(cw.shape)}]")     # dice_loss.py:80-81
+        ign = -1 if ignore is None else int(ignore)
         ws = torch.empty(lib().hdf_loss_workspace_bytes(b), dtype=torch.uint8, device=tgt.device)
         loss = torch.empty((), dtype=torch.float32, device=tgt.device)
         po = [ptr(o) for o in outs] + [None] * (4 - n)
-        check(lib().hdf_loss_terms_forward(_DT[dt], po[0], po[1], po[2], po[3], n, ptr(tgt), b, c, d, h, w,
-                                           float(w_ce), float(w_dice), ptr(ws), ptr(loss), stream_ptr()),
-              "hdf_loss_terms_forward")
+        check(lib().hdf_loss_weighted_forward(_DT[dt], po[0], po[1], po[2], po[3], n, ptr(tgt), b, c, d, h, w,
+                                              float(w_ce), float(w_dice), ptr(cw), ign, ptr(ws), ptr(loss),
+                                              stream_ptr()), "hdf_loss_weighted_forward")
         ctx.save_for_backward(tgt, ws, *outs)
-        ctx.n, ctx.w, ctx.dhw = n, (float(w_ce), float(w_dice)), (d, h, w)
+        ctx.n, ctx.w, ctx.dhw, ctx.cw, ctx.ign = n, (float(w_ce), float(w_dice)), (d, h, w), cw, ign
         return loss
 
     @staticmethod
@@ -55,9 +65,9 @@ class DeepSuperCEDice(torch.autograd.Function):
         gg = g.detach().float().reshape(1).contiguous()
         po = [ptr(o) for o in outs] + [None] * (4 - n)
         pd = [ptr(o) for o in douts] + [None] * (4 - n)
-        check(lib().hdf_loss_terms_backward(_DT[outs[0].dtype], po[0], po[1], po[2], po[3], n, ptr(tgt), b, c, d, h, w,
-                                            ctx.w[0], ctx.w[1], ptr(ws), ptr(gg), pd[0], pd[1], pd[2], pd[3],
-                                            stream_ptr()), "hdf_loss_terms_backward")
+        check(lib().hdf_loss_weighted_backward(_DT[outs[0].dtype], po[0], po[1], po[2], po[3], n, ptr(tgt), b, c, d, h,
+                                               w, ctx.w[0], ctx.w[1], ptr(ctx.cw), ctx.ign, ptr(ws), ptr(gg), pd[0],
+                                               pd[1], pd[2], pd[3], stream_ptr()), "hdf_loss_weighted_backward")
         return (None, *douts)
 
 

@@ -1,11 +1,24 @@
 """Drop-in `loss.combine_loss` (reference loss/combine_loss.py:8-35,68-79) backed by the fused HIP loss.
 
-Supported configuration = the one the trainer builds for the H-DenseFormer runs (trainer.py:224-226,
-763-765): DeepSuperloss(criterion=CEPlusDice(weight=None, ignore_index=0)) with BinaryDiceLoss defaults
-(smooth 1e-5, p 1, reduction 'mean').  Anything else raises -- there is no eager fallback."""
+Supported: what trainer.py:743-771 (_get_loss) builds for the H-DenseFormer runs --
+DeepSuperloss(criterion=CEPlusDice(weight=class_weight or None, ignore_index=0)) -- plus ignore_index=None, with the
+BinaryDiceLoss defaults (smooth 1e-5, p 1, reduction 'mean').  Anything else raises: there is no eager fallback."""
 from torch import nn
 
 from hdf_rt.loss_fn import DeepSuperCEDice
+
+_DICE_DEFAULTS = dict(smooth=1e-5, p=1, reduction="mean")
+
+
+def check_dice_kwargs(kwargs):
+    """BinaryDiceLoss keyword arguments (dice_loss.py:20-25): the kernels implement the defaults (trainer.py:761 passes
+    p=1 explicitly); k only matters for reduction='topk'."""
+    for k, v in kwargs.items():
+        if k == "k":
+            continue
+        if k not in _DICE_DEFAULTS or v != _DICE_DEFAULTS[k]:
+            raise NotImplementedError(f"fused Dice loss implements BinaryDiceLoss(smooth=1e-5, p=1, reduction='mean'); "
+                                      f"got {k}={v!r}")
 
 
 class CEPlusDice(nn.Module):
@@ -14,14 +27,15 @@ class CEPlusDice(nn.Module):
         self.weight, self.ignore_index, self.kwargs = weight, ignore_index, kwargs
 
     def _check(self):
-        if self.weight is not None or self.ignore_index != 0 or self.kwargs:
-            raise NotImplementedError("fused CEPlusDice supports weight=None, ignore_index=0, default Dice kwargs "
-                                      "(the configuration trainer.py:763-765 uses)")
+        check_dice_kwargs(self.kwargs)
+
+    def _spec(self, target):
+        return (target, 1.0, 1.0, self.weight, self.ignore_index)
 
     def forward(self, predict, target):
         assert predict.size() == target.size()
         self._check()
-        return DeepSuperCEDice.apply(target, predict)
+        return DeepSuperCEDice.apply(self._spec(target), predict)
 
 
 class DeepSuperloss(nn.Module):
@@ -31,6 +45,6 @@ class DeepSuperloss(nn.Module):
 
     def forward(self, input, target):
         if not isinstance(self.loss, CEPlusDice):
-            raise NotImplementedError("fused DeepSuperloss needs criterion=CEPlusDice(weight=None, ignore_index=0)")
+            raise NotImplementedError("fused DeepSuperloss needs criterion=CEPlusDice(...)")
         self.loss._check()
-        return DeepSuperCEDice.apply(target, *list(input))
+        return DeepSuperCEDice.apply(self.loss._spec(target), *list(input))

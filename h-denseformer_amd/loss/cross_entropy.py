@@ -1,6 +1,6 @@
 """Drop-in `loss.cross_entropy.CrossentropyLoss` (reference loss/cross_entropy.py:8-22): mean cross-entropy of the
-logits against argmax(one-hot target), on the fused HIP loss kernels (the Dice term weighted 0) -- no permuted copy
-of the logits.  weight=None only; there is no eager fallback."""
+logits against argmax(one-hot target), optionally class-weighted like torch.nn.CrossEntropyLoss(weight=..), on the
+fused HIP loss kernels (the Dice term weighted 0) -- no permuted copy of the logits.  There is no eager fallback."""
 from torch import nn
 
 from hdf_rt.loss_fn import DeepSuperCEDice
@@ -9,9 +9,9 @@ from hdf_rt.loss_fn import DeepSuperCEDice
 class CrossentropyLoss(nn.Module):
     def __init__(self, weight=None, **kwargs):
         super().__init__()
+        if kwargs:
+            raise NotImplementedError(f"fused CrossentropyLoss implements weight= only (got {sorted(kwargs)})")
         self.weight = weight
 
     def forward(self, inp, target):
-        if self.weight is not None:
-            raise NotImplementedError("fused CrossentropyLoss supports weight=None")
-        return DeepSuperCEDice.apply((target, 1.0, 0.0), inp)
+        return DeepSuperCEDice.apply((target, 1.0, 0.0, self.weight, 0), inp)

@@ -1,11 +1,13 @@
 """Drop-in `loss.dice_loss.DiceLoss` (reference loss/dice_loss.py:53-87) on the fused HIP loss kernels: softmax over
-classes, per-class soft Dice (BinaryDiceLoss defaults: smooth 1e-5, p 1, batch mean, :5-50) over classes != 0,
-divided by C-1.  One pass over the logits (hdf_loss_terms_forward with the cross-entropy term weighted 0).
-Supported: weight=None, ignore_index=0 and the BinaryDiceLoss defaults -- what trainer.py:763-765 builds; anything
-else raises (there is no eager fallback)."""
+classes, per-class soft Dice (BinaryDiceLoss defaults: smooth 1e-5, p 1, batch mean, :5-50) over the classes other than
+ignore_index, each times its class weight, divided by C-1 (C when ignore_index is None).  One pass over the logits
+(hdf_loss_weighted_forward with the cross-entropy term weighted 0).  Other BinaryDiceLoss settings raise (there is no
+eager fallback)."""
 from torch import nn
 
 from hdf_rt.loss_fn import DeepSuperCEDice
+
+from .combine_loss import check_dice_kwargs
 
 
 class DiceLoss(nn.Module):
@@ -15,6 +17,5 @@ class DiceLoss(nn.Module):
 
     def forward(self, predict, target):
         assert predict.shape == target.shape, "predict & target shape do not match"
-        if self.weight is not None or self.ignore_index != 0 or self.kwargs:
-            raise NotImplementedError("fused DiceLoss supports weight=None, ignore_index=0, default BinaryDiceLoss kwargs")
-        return DeepSuperCEDice.apply((target, 0.0, 1.0), predict)
+        check_dice_kwargs(self.kwargs)
+        return DeepSuperCEDice.apply((target, 0.0, 1.0, self.weight, self.ignore_index), predict)

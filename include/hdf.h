@@ -28,6 +28,11 @@ typedef void* hdf_stream; /* hipStream_t */
 
 const char* hdf_version(void);
 const char* hdf_last_error(void);
+/* Compute units the persistent kernels (conv_ws2 / conv_wgrad2 / the transposed-conv kernels) of the CALLING HOST THREAD
+ * may assume: their grids are one workgroup per CU.  256 = the whole MI355X (default); a multiple of 8 below that for
+ * launches on a stream created with hipExtStreamCreateWithCUMask, so that every workgroup of a launch is resident at
+ * once.  The plan sets it itself around the launches it places on its own masked streams (hdf_forward / hdf_backward). */
+int hdf_set_cu_budget(int cus);
 
 /* ---- model plan: models/HDenseFormer.py:177-227 (HDenseFormer.__init__) ------------------------------- */
 int hdf_plan_create(int in_channels, int n_cls, int n_filters, int D, int H, int W, int transformer_depth, int dtype,
@@ -90,6 +95,20 @@ int hdf_loss_terms_backward(int dtype, const void* out0, const void* out1, const
                             int nscale, const float* target_onehot, int batch, int n_cls, int D, int H, int W,
                             float ce_weight, float dice_weight, const void* workspace, const float* grad_out,
                             void* dout0, void* dout1, void* dout2, void* dout3, hdf_stream stream);
+/* the general forms trainer.py:743-771 (_get_loss) can build: class_weight = device [n_cls] fp32 or NULL
+ * (DiceLoss multiplies class i's Dice term by weight[i], loss/dice_loss.py:79-82; CrossEntropyLoss(weight) is
+ * sum_v w[t_v] nll_v / sum_v w[t_v], loss/cross_entropy.py:8-22 on torch.nn.CrossEntropyLoss); dice_ignore_index =
+ * the class DiceLoss skips (then the class sum is divided by n_cls - 1) or -1 for ignore_index=None (divided by
+ * n_cls), loss/dice_loss.py:75-87.  NULL, 0 reproduce hdf_loss_terms_* bit for bit. */
+int hdf_loss_weighted_forward(int dtype, const void* out0, const void* out1, const void* out2, const void* out3,
+                              int nscale, const float* target_onehot, int batch, int n_cls, int D, int H, int W,
+                              float ce_weight, float dice_weight, const float* class_weight, int dice_ignore_index,
+                              void* workspace, float* loss_out, hdf_stream stream);
+int hdf_loss_weighted_backward(int dtype, const void* out0, const void* out1, const void* out2, const void* out3,
+                               int nscale, const float* target_onehot, int batch, int n_cls, int D, int H, int W,
+                               float ce_weight, float dice_weight, const float* class_weight, int dice_ignore_index,
+                               const void* workspace, const float* grad_out, void* dout0, void* dout1, void* dout2,
+                               void* dout3, hdf_stream stream);
 /* hard-argmax Dice counts of trainer.py:919-945: counts[batch][8][3] = (|P&T|, |P|, |T|) per class, uint64 */
 int hdf_dice_counts(int dtype, const void* logits, const float* target_onehot, int batch, int n_cls, int64_t voxels,
                     uint64_t* counts, hdf_stream stream);

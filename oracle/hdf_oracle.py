@@ -194,29 +194,40 @@ def forward(x, sd, drop_seed=None, want_intermediates=False):
 
 
 # ---------------------------------------------------------------------------------------- loss
-def ce_plus_dice(logits, onehot, smooth=1e-5):
-    """CEPlusDice(weight=None, ignore_index=0): mean CE against argmax(onehot) + soft Dice (p=1) over
-    classes 1..C-1, per sample then batch mean, divided by C-1."""
+def dice_term(logits, onehot, weight=None, ignore_index=0, smooth=1e-5):
+    """DiceLoss (dice_loss.py:53-87): soft Dice (p=1) per class other than ignore_index, per sample then batch mean,
+    times the class weight, summed and divided by C-1 (by C when ignore_index is None)."""
     c = logits.shape[1]
     prob = torch.softmax(logits, dim=1)
     dice = 0.0
-    for k in range(1, c):
+    for k in range(c):
+        if k == ignore_index:
+            continue
         inter = (prob[:, k] * onehot[:, k]).flatten(1).sum(1)
         union = (prob[:, k] + onehot[:, k]).flatten(1).sum(1)
-        dice = dice + (1.0 - (2.0 * inter + smooth) / (union + smooth)).mean()
-    dice = dice / (c - 1)
-    ce = F.cross_entropy(logits, onehot.argmax(1))
-    return ce + dice
+        term = (1.0 - (2.0 * inter + smooth) / (union + smooth)).mean()
+        dice = dice + (term if weight is None else term * weight[k])
+    return dice / (c - 1 if ignore_index is not None else c)
 
 
-def deep_super_loss(outs, onehot):
+def ce_term(logits, onehot, weight=None):
+    """CrossentropyLoss (cross_entropy.py:8-22): [weighted] mean CE against argmax(onehot)."""
+    return F.cross_entropy(logits, onehot.argmax(1), weight=weight)
+
+
+def ce_plus_dice(logits, onehot, smooth=1e-5, weight=None, ignore_index=0):
+    """CEPlusDice(weight, ignore_index) (combine_loss.py:8-35): the two terms above, the class weights in both."""
+    return ce_term(logits, onehot, weight) + dice_term(logits, onehot, weight, ignore_index, smooth)
+
+
+def deep_super_loss(outs, onehot, weight=None, ignore_index=0):
     """sum_i 2^-i * CEPlusDice(out_i, nearest-downsampled one-hot) (combine_loss.py:72-79);
     nearest interpolation onto a 2^i-times smaller grid is the stride-2^i subsample."""
     total = 0.0
     for i, o in enumerate(outs):
         s = onehot.shape[2] // o.shape[2]
         sub = onehot[(slice(None), slice(None)) + (slice(None, None, s),) * (onehot.dim() - 2)]
-        total = total + ce_plus_dice(o, sub) * (1.0 / (2 ** i))
+        total = total + ce_plus_dice(o, sub, weight=weight, ignore_index=ignore_index) * (1.0 / (2 ** i))
     return total
 
 

@@ -9,6 +9,7 @@ What is captured:
   g1_tiny_train   same model, train mode with the hash dropout masks (seed 1234): logits, loss, grads
   g2_odd_eval     HDenseFormer(2,2,16,(48,)*3,td=4)  B=1 (3^3 = 27 tokens, odd grid): logits + loss
   g3_loss         DeepSuperloss(CEPlusDice) values + dL/dlogits on random 4-scale logits (C=3,4; absent class)
+  g3w_loss_weighted  the class-weighted / ignore_index=None forms of CEPlusDice, DiceLoss, CrossentropyLoss (--only g3w)
   g5_full_eval    HDenseFormer_32(4,4,(128,)*3,td=24) B=1 eval: strided logits, stats, Dice, loss  (--full)
   g6_2d           HDenseFormer_2D_32(4,2,(256,256),24) single forward: shapes + strided logits  (config #1)
   g6_2d_train     HDenseFormer_2D(2,3,16,(64,96),td=8) B=2 train step: logits, loss, gradients, Adam-updated samples
@@ -231,6 +232,39 @@ def golden_loss(ref):
     np.savez_compressed(os.path.join(OUT, "g3_loss.npz"), **rec)
 
 
+def golden_loss_weighted(ref):
+    """The class-weighted / ignore_index=None forms trainer.py:743-771 can build, from the reference's own classes."""
+    from loss.cross_entropy import CrossentropyLoss
+    from loss.dice_loss import DiceLoss
+    cw = [0.2, 1.0, 2.5, 0.6]
+    wt = torch.tensor(cw)
+    rec = dict(class_weight=np.array(cw, dtype=np.float32))
+    g = torch.Generator().manual_seed(17)
+    c, s = 4, 16
+    lab = torch.randint(0, c, (2, s, s, s), generator=g)
+    onehot = torch.nn.functional.one_hot(lab, c).permute(0, 4, 1, 2, 3).float()
+    rec["onehot"] = onehot.numpy().astype(np.uint8)
+    base = [(torch.randn(2, c, s >> i, s >> i, s >> i, generator=g) * 2.0) for i in range(4)]
+    for i, o in enumerate(base):
+        rec[f"logits{i}"] = o.numpy()
+    cases = dict(
+        deep_w=(ref["DeepSuperloss"](criterion=ref["CEPlusDice"](weight=wt, ignore_index=0)), 4),
+        cepd_w=(ref["CEPlusDice"](weight=wt, ignore_index=0), 1),
+        dice_w=(DiceLoss(weight=wt, ignore_index=0, p=1), 1),            # trainer.py:761
+        dice_all=(DiceLoss(weight=None, ignore_index=None), 1),
+        dice_w_all=(DiceLoss(weight=wt, ignore_index=None), 1),
+        ce_w=(CrossentropyLoss(weight=wt), 1))
+    for tag, (crit, n) in cases.items():
+        outs = [o.clone().requires_grad_(True) for o in base[:n]]
+        loss = crit(outs, onehot) if n > 1 else crit(outs[0], onehot)
+        loss.backward()
+        rec[tag + "_loss"] = loss.item()
+        for i, o in enumerate(outs):
+            rec[f"{tag}_grad{i}"] = o.grad.numpy()
+        print("g3w", tag, loss.item())
+    np.savez_compressed(os.path.join(OUT, "g3w_loss_weighted.npz"), **rec)
+
+
 def golden_metric(ref):
     tr, me = ref["trainer"], ref["metrics"]
     rec = {}
@@ -271,7 +305,7 @@ def golden_2d(ref):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also the 4x128^3 nf32 td24 fixture (needs ~9 GB, ~1 min)")
-    ap.add_argument("--only", default="", help="comma list of g1,g2,g3,g4,g5,g5t,g6,g6t,g7")
+    ap.add_argument("--only", default="", help="comma list of g1,g2,g3,g3w,g4,g5,g5t,g6,g6t,g7")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -288,6 +322,8 @@ def main():
         golden_model(ref, "g2_odd_eval", (2, 2, 16, (48, 48, 48), 4), 1, None, sample_step=2, inter_step=4)
     if "g3" in todo:
         golden_loss(ref)
+    if "g3w" in todo:
+        golden_loss_weighted(ref)
     if "g6" in todo:
         golden_2d(ref)
     if "g7" in todo:

@@ -108,8 +108,8 @@ def test_product_path_fails_loudly_without_gpu():
     crit = DeepSuperloss(criterion=CEPlusDice(weight=None, ignore_index=0))
     with pytest.raises(_lib.HdfError):
         crit([torch.zeros(1, 3, 8, 8, 8)], torch.zeros(1, 3, 8, 8, 8))
-    with pytest.raises(NotImplementedError):
-        DeepSuperloss(criterion=CEPlusDice(weight=None, ignore_index=None))([torch.zeros(1)], torch.zeros(1))
+    with pytest.raises(NotImplementedError):     # BinaryDiceLoss settings the kernels do not implement
+        DeepSuperloss(criterion=CEPlusDice(weight=None, ignore_index=0, p=2))([torch.zeros(1)], torch.zeros(1))
 
 
 def test_product_never_imports_oracle():

@@ -196,6 +196,33 @@ def test_fused_loss_vs_reference_golden(tag, dt):
         assert _rel(o.grad.float(), torch.from_numpy(g[f"{tag}_grad{i}"])) < tol * 5
 
 
+@pytest.mark.parametrize("tag", ["deep_w", "cepd_w", "dice_w", "dice_all", "dice_w_all", "ce_w"])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_weighted_loss_forms_vs_reference_golden(tag, dt):
+    """What trainer.py:743-771 builds with a class_weight list (and DiceLoss(ignore_index=None)), through the drop-in
+    loss modules, against fixtures from the reference's own classes (oracle/make_goldens.py --only g3w)."""
+    from loss.combine_loss import CEPlusDice, DeepSuperloss
+    from loss.cross_entropy import CrossentropyLoss
+    from loss.dice_loss import DiceLoss
+    g = np.load(os.path.join(GOLDEN, "g3w_loss_weighted.npz"))
+    w = torch.tensor(g["class_weight"].tolist())          # a CPU tensor, as trainer.py:745 makes it
+    onehot = torch.from_numpy(g["onehot"].astype(np.float32)).to(DEV)
+    n = 4 if tag == "deep_w" else 1
+    outs = [torch.from_numpy(g[f"logits{i}"]).to(DEV).to(dt).requires_grad_(True) for i in range(n)]
+    crit = {"deep_w": DeepSuperloss(criterion=CEPlusDice(weight=w, ignore_index=0)),
+            "cepd_w": CEPlusDice(weight=w, ignore_index=0),
+            "dice_w": DiceLoss(weight=w, ignore_index=0, p=1),
+            "dice_all": DiceLoss(weight=None, ignore_index=None),
+            "dice_w_all": DiceLoss(weight=w, ignore_index=None),
+            "ce_w": CrossentropyLoss(weight=w)}[tag]
+    loss = crit(outs, onehot) if n > 1 else crit(outs[0], onehot)
+    loss.backward()
+    tol = 2e-5 if dt == torch.float32 else 2e-2
+    assert abs(loss.item() - float(g[tag + "_loss"])) < tol * 10
+    for i, o in enumerate(outs):
+        assert _rel(o.grad.float(), torch.from_numpy(g[f"{tag}_grad{i}"])) < tol * 5
+
+
 @pytest.mark.parametrize("tag", ["c4", "c4_absent", "c3"])
 def test_dice_metric_vs_reference_golden(tag):
     from hdf_rt.loss_fn import compute_dice
@@ -685,6 +712,58 @@ def test_bench_two_ranks_on_one_device_exercises_the_multi_gpu_code_path():
     assert rec["config"]["global_batch"] == 4 and rec["config"]["parallelism"] == "dp2"
     assert rec["value"] > 0 and abs(rec["value"] - 4 * 3 / (rec["ms_per_step"] * 3e-3)) < 1e-6 * rec["value"]
     assert "roofline" not in rec and "cpu_baseline" not in rec        # N = 1 only
+
+
+def _torchrun_one_rank(script, args=(), env_extra=None, port=29587, timeout=900):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", **(env_extra or {}))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, script), *args]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.gpu
+def test_rccl_one_rank_preflight_gradsync_over_nccl():
+    """The RCCL path itself, as far as one GPU allows (RCCL refuses two ranks on one device): one rank launched by
+    torch.distributed.run, init_process_group("nccl", device_id=..), GradSync's broadcast and its three bucket
+    all-reduces on the comm stream as RCCL kernels, HSA_ENABLE_IPC_MODE_LEGACY=0.  The synced gradient must equal the
+    plain backward's (world 1: sum over one rank / 1) and the optimizer step must run behind sync.wait()."""
+    import json
+    lines = _torchrun_one_rank(os.path.join("tools", "ddp_check.py"), env_extra={"HDF_DDP_BACKEND": "nccl"}, port=29587)
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert rec["backend"] == "nccl" and rec["world"] == 1
+    assert rec["grad_rel_err"] < 1e-5 and rec["param_max_diff"] == 0.0, rec
+
+
+@pytest.mark.gpu
+def test_bench_under_torchrun_with_one_rank_runs_the_rccl_branch():
+    """bench.py exactly as the driver launches the N > 1 runs (torch.distributed.run, backend nccl = RCCL), with
+    --nproc-per-node 1: process group on the device, GradSync in the step, barrier + synchronize fences, the MAX
+    all-reduce of the wall time on the device, one JSON line."""
+    import json
+    lines = _torchrun_one_rank("bench.py", args=("--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"),
+                               port=29588)
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["config"]["collective"] == "nccl" and rec["config"]["parallelism"] == "dp1"
+    assert rec["value"] > 0 and 3.0 < rec["config"]["loss"] < 6.0
+
+
+@pytest.mark.gpu
+def test_staged_backward_with_rccl_matches_the_single_call_backward():
+    """tools/stage_cost.py (64^3 here; the 128^3 figures are in profiles/): the three-stage backward + RCCL bucket
+    all-reduces gives the gradients of the one-call backward, and reports what the staging costs per step."""
+    import json
+    lines = _torchrun_one_rank(os.path.join("tools", "stage_cost.py"), port=29589,
+                               env_extra={"HDF_STAGE_COST_SIZE": "64", "HDF_STAGE_COST_STEPS": "4"})
+    rec = json.loads(lines[-1])
+    assert rec["backend"] == "nccl" and rec["grad_rel_err"] < 1e-4, rec
+    assert rec["ms_three_stages_rccl"] < 2.0 * rec["ms_one_call"] + 1.0, rec
 
 
 @pytest.mark.gpu

@@ -132,6 +132,26 @@ def test_g3_loss(tag):
         assert _rel(o.grad.numpy(), g[f"{tag}_grad{i}"]) < 1e-5
 
 
+@pytest.mark.parametrize("tag", ["deep_w", "cepd_w", "dice_w", "dice_all", "dice_w_all", "ce_w"])
+def test_g3w_weighted_loss_forms(tag):
+    """class-weighted / ignore_index=None forms (trainer.py:743-771) against the reference's own classes"""
+    g = _load("g3w_loss_weighted")
+    w = torch.from_numpy(g["class_weight"])
+    onehot = torch.from_numpy(g["onehot"].astype(np.float32))
+    n = 4 if tag == "deep_w" else 1
+    outs = [torch.from_numpy(g[f"logits{i}"]).requires_grad_(True) for i in range(n)]
+    loss = {"deep_w": lambda: orc.deep_super_loss(outs, onehot, weight=w),
+            "cepd_w": lambda: orc.ce_plus_dice(outs[0], onehot, weight=w),
+            "dice_w": lambda: orc.dice_term(outs[0], onehot, weight=w, ignore_index=0),
+            "dice_all": lambda: orc.dice_term(outs[0], onehot, ignore_index=None),
+            "dice_w_all": lambda: orc.dice_term(outs[0], onehot, weight=w, ignore_index=None),
+            "ce_w": lambda: orc.ce_term(outs[0], onehot, weight=w)}[tag]()
+    loss.backward()
+    assert abs(loss.item() - float(g[tag + "_loss"])) < 1e-5
+    for i, o in enumerate(outs):
+        assert _rel(o.grad.numpy(), g[f"{tag}_grad{i}"]) < 1e-5
+
+
 @pytest.mark.parametrize("tag", ["c4", "c4_absent", "c3"])
 def test_g7_metric(tag):
     g = _load("g7_metric")

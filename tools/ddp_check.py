@@ -1,6 +1,8 @@
-"""Two-rank data-parallel check on ONE GPU (both ranks on cuda:0, gloo transport): exercises GradSync, the staged
-backward and the comm-stream overlap logic on the real HIP path.  Launched by tests/test_gpu_model.py through
-torch.distributed.run.  Prints one JSON line per rank."""
+"""Data-parallel check on ONE GPU: exercises GradSync, the staged backward and the comm-stream overlap logic on the
+real HIP path.  Default: two ranks on cuda:0 over gloo.  HDF_DDP_BACKEND=nccl with --nproc-per-node 1: the same
+checks through RCCL with one rank (RCCL refuses two ranks on one device): init_process_group("nccl", device_id=..),
+the broadcast and the three bucket all-reduces on the comm stream run as RCCL kernels.  Launched by
+tests/test_gpu_model.py through torch.distributed.run.  Prints one JSON line per rank."""
 import json
 import os
 import sys
@@ -16,7 +18,12 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
-    dist.init_process_group("gloo")
+    backend = os.environ.get("HDF_DDP_BACKEND", "gloo")
+    if backend == "nccl":
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group("gloo")
     from hdf_rt.optim import FlatAdam
     from hdf_rt.parallel import GradSync
     from loss.combine_loss import CEPlusDice, DeepSuperloss
@@ -70,11 +77,14 @@ def main():
     sync.wait()
     opt.step()
     torch.cuda.synchronize()
-    flat = net.flat_parameters().detach().cpu()
+    flat = net.flat_parameters().detach()
+    if backend != "nccl":
+        flat = flat.cpu()
     gathered = [torch.zeros_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
-    pdiff = float((gathered[0] - gathered[1]).abs().max())
-    print(json.dumps({"rank": rank, "grad_rel_err": err, "param_max_diff": pdiff, "loss": float(loss.item())}), flush=True)
+    pdiff = float((gathered[0] - gathered[-1]).abs().max())
+    print(json.dumps({"rank": rank, "world": world, "backend": dist.get_backend(), "grad_rel_err": err,
+                      "param_max_diff": pdiff, "loss": float(loss.item())}), flush=True)
     dist.destroy_process_group()
 
 
