@@ -430,14 +430,35 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
   constexpr bool xf = XF;  // input transform x*scale+shift (+relu) on the way into LDS; else a plain copy
   const float relu_lo = (xf && a.in_relu) ? 0.f : -INFINITY;
 
-  // ---- weights -> LDS, once (rows [tap][cout 32][RB bytes], 16-byte slots XOR-swizzled by row)
-  for (int id = tid; id < 27 * NC * CPR; id += 256) {
-    int row = id / CPR, ch = id - row * CPR;
-    int tap = row / NC, rr = row - tap * NC;
-    u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a.w) +
-                                              ((int64_t)(tap * a.CoutP + n0 + rr) * CIN) * ESZ + ch * 16);
-    int sw = ch ^ ((row / RP256) & (CPR - 1));
-    *reinterpret_cast<u32x4*>(w_lds + row * RB + sw * 16) = v;
+  // ---- weights -> LDS, once (rows [tap][cout 32][RB bytes], 16-byte slots XOR-swizzled by row).  ALL of a thread's
+  // loads are issued before its first LDS store: written as load / store pairs in a loop, hipcc waited for every load
+  // in turn (s_waitcnt vmcnt(0) in front of each ds_write), and with all 256 workgroups asking the same L2 lines for
+  // the same rows at the same moment one round trip took ~1.6 us -- 27 of them in a row were 45-55 us of a 480 us
+  // launch (real-time stamps: 575 us per launch against 520 us from the first to the last instruction after this loop).
+  // The batches start at a different 4 KB slice per workgroup so the requests of a round spread over the L2 channels.
+  {
+    constexpr int WTOT = 27 * NC * CPR, WIT = (WTOT + 255) / 256;
+    u32x4 wv[WIT];
+    const int rot = blockIdx.x % WIT;
+#pragma unroll
+    for (int u = 0; u < WIT; u++) {
+      int it = u + rot;
+      it -= (it >= WIT) ? WIT : 0;
+      const int id = min(tid + 256 * it, WTOT - 1);
+      const int row = id / CPR, ch = id - row * CPR;
+      const int tap = row / NC, rr = row - tap * NC;
+      wv[u] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a.w) +
+                                             ((int64_t)(tap * a.CoutP + n0 + rr) * CIN) * ESZ + ch * 16);
+    }
+#pragma unroll
+    for (int u = 0; u < WIT; u++) {
+      int it = u + rot;
+      it -= (it >= WIT) ? WIT : 0;
+      const int id = tid + 256 * it;
+      const int row = id / CPR, ch = id - row * CPR;
+      const int sw = ch ^ ((row / RP256) & (CPR - 1));
+      if (id < WTOT) *reinterpret_cast<u32x4*>(w_lds + row * RB + sw * 16) = wv[u];
+    }
   }
   const int bswz = (r / RP256) & (CPR - 1);
 
@@ -742,38 +763,41 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
     WS_BARRIER();
   };
 
-  const int ch = n0 + r;                 // channel of output block 0 (block nb: + 32 nb)
-  bool ch_ok[NB];
-  float bias[NB];
+  // ---- epilogue geometry.  The MFMAs take the WEIGHT fragment as their A operand and the voxel fragment as B (the two
+  // fragment layouts are the same, so this is only the argument order): the 32 x 32 result then has the output channel on
+  // the register index and the voxel on the lane.  Lane (r, h) holds, for voxel ws_row_to_zx(r) of each of the wave's
+  // two y rows, channels co(i) = 4 h + 8 (i >> 2) + (i & 3): four runs of 4 consecutive channels, i.e. four 8-byte
+  // (16-bit storage) or 16-byte (f32) stores per M-block from ONE lane base with compile-time offsets.  (With the voxel
+  // on the register index a lane owned one channel of 16 voxels: 16 two-byte stores, 16 converts and 16 address
+  // computations per M-block, and per-tile cross-lane sums for the InstanceNorm statistics.)
+  int vdz, vx;
+  ws_row_to_zx(r, vdz, vx);
+  const int voff = ((vdz * a.Ho + 2 * wave) * a.Wo + vx) * (int)a.out_pitch + 4 * h;  // lane's voxel inside a tile
+  bool cfull[NB];  // all 32 channels of the block exist
+  T* outp[NB];     // split output: a 32-channel block lies entirely on one side (split is a multiple of 32)
 #pragma unroll
   for (int nb = 0; nb < NB; nb++) {
-    ch_ok[nb] = ch + 32 * nb < a.Cout;
-    bias[nb] = (a.bias && ch_ok[nb]) ? a.bias[ch + 32 * nb] : 0.f;
+    cfull[nb] = n0 + 32 * nb + 32 <= a.Cout;
+    outp[nb] = ((a.split && n0 + 32 * nb >= a.split) ? reinterpret_cast<T*>(a.out2) - a.split : reinterpret_cast<T*>(a.out)) +
+               n0 + 32 * nb;
   }
-  T* outp[NB];  // split output: a 32-channel block lies entirely on one side (split is a multiple of 32)
-#pragma unroll
-  for (int nb = 0; nb < NB; nb++)
-    outp[nb] = (a.split && n0 + 32 * nb >= a.split) ? reinterpret_cast<T*>(a.out2) - a.split : reinterpret_cast<T*>(a.out);
-  // accumulator register i of this lane: tile voxel (dz, 2w + mb, x) with x = (i & 3) + 4 * ((i >> 2) & 1) and
-  // dz = {0,1,3,2}[i >> 2] (h == 0) or {1,0,2,3}[i >> 2] (h == 1)   (ws_row_to_zx of row (i&3) + 8*(i>>2) + 4h)
-  int edz[4], eplane[4];
-#pragma unroll
-  for (int q4 = 0; q4 < 4; q4++) {
-    int dz, x;
-    ws_row_to_zx(8 * q4 + 4 * h, dz, x);
-    edz[q4] = dz;
-    eplane[q4] = dz * a.Ho * a.Wo * (int)a.out_pitch;
-  }
-  auto eoff = [&](int i) { return eplane[i >> 2] + ((i & 3) + 4 * ((i >> 2) & 1)) * (int)a.out_pitch; };
-  int pend_tile = -1;  // >= 0: a tile's per-wave InstanceNorm partials wait in s_red for the next barrier
-  int pend_n = 0;      // its sample
-  int sr_sel = 0, pend_sel = 0;  // s_red halves alternate per WRITE (a workgroup's consecutive tiles are 32 apart
-                                 // in raster order, so their linear index has one parity)
+  // wide stores need the lane base aligned to the store (launcher: out / out2 16-byte aligned, pitch % 8 == 0)
+  const bool wide_ok = !a.accumulate && (a.out_pitch % 8 == 0) && ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0) &&
+                       (!a.split || (reinterpret_cast<uintptr_t>(a.out2) & 15) == 0);
+  float* const s_bias = s_red + 256 * NB;  // [NC]: the second half of the reduction area
+  const bool has_bias = a.bias != nullptr;
+  if (tid < NC) s_bias[tid] = (has_bias && n0 + tid < a.Cout) ? a.bias[n0 + tid] : 0.f;
   // InstanceNorm partial rows are per WORKGROUP, not per tile: sample n owns WS_STAT_ROWS rows, row
   // pass * 256 + blockIdx.x (+ k gridDim.x for the slots no workgroup has) holds this workgroup's sums over its
-  // tiles of n in that pass.  Threads tid < NC keep the running sums in registers and add them to the row when the
-  // sample changes / the pass ends; the rows are zeroed here first, so in_finalize reads 512 rows instead of one per tile.
-  float racc1 = 0.f, racc2 = 0.f;
+  // tiles of n in that pass.  Every lane keeps running (sum, sum of squares) of ITS 16 channels over its voxels in
+  // registers; they are reduced over lanes and waves and added to the row only when the sample changes / the pass ends
+  // (stats_to_row: a handful of times per launch).  The rows are zeroed here first, so in_finalize reads 512 rows
+  // instead of one per tile.
+  float st1[NB][16], st2[NB][16];
+#pragma unroll
+  for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+    for (int i = 0; i < 16; i++) st1[nb][i] = st2[nb][i] = 0.f;
   int racc_n = -1, cur_pass = 0;
   auto stat_row = [&](int n, int pass, int b) {
     return a.stat_partials + (((int64_t)n * WS_STAT_ROWS + pass * 256 + b) * a.CoutP + n0 + tid) * 2;
@@ -787,34 +811,58 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
           q[1] = 0.f;
         }
   }
-  auto stats_to_row = [&]() {
-    if (a.stat_partials && tid < NC && racc_n >= 0) {
-      float* q = stat_row(racc_n, cur_pass, blockIdx.x);
-      q[0] += racc1;
-      q[1] += racc2;
+  // uniform (every wave takes the same path): lanes -> waves -> the workgroup's row of sample racc_n, fixed order
+  auto stats_to_row = [&]() __attribute__((always_inline)) {
+    if (a.stat_partials && racc_n >= 0) {
+#pragma unroll
+      for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          float u1 = st1[nb][i], u2 = st2[nb][i];
+#pragma unroll
+          for (int o = 1; o < 32; o <<= 1) {
+            u1 += __shfl_xor(u1, o, 64);
+            u2 += __shfl_xor(u2, o, 64);
+          }
+          if (r == 0) {
+            const int c = 32 * nb + 4 * h + 8 * (i >> 2) + (i & 3);
+            s_red[(wave * NC + c) * 2 + 0] = u1;
+            s_red[(wave * NC + c) * 2 + 1] = u2;
+          }
+        }
+      __syncthreads();
+      if (tid < NC) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          t1 += s_red[(k * NC + tid) * 2 + 0];
+          t2 += s_red[(k * NC + tid) * 2 + 1];
+        }
+        float* q = stat_row(racc_n, cur_pass, blockIdx.x);
+        q[0] += t1;
+        q[1] += t2;
+      }
+      __syncthreads();
     }
-    racc1 = racc2 = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) st1[nb][i] = st2[nb][i] = 0.f;
     racc_n = -1;
   };
-  auto flush_stats = [&]() {
-    if (pend_n != racc_n) {
-      stats_to_row();
-      racc_n = pend_n;
+  // the tile about to be summed belongs to sample n (uniform)
+  auto stats_sample = [&](int n) __attribute__((always_inline)) {
+    if (n != racc_n) {
+      if (racc_n >= 0) stats_to_row();
+      racc_n = n;
     }
-    if (a.stat_partials && tid < NC) {
-      const float* sr = s_red + pend_sel * (256 * NB);
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        racc1 += sr[(k * NC + tid) * 2 + 0];
-        racc2 += sr[(k * NC + tid) * 2 + 1];
-      }
-    }
-    pend_tile = -1;
   };
 
 #ifdef WS_DBG_STAMPS
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long treal0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz, the same counter on every CU
   unsigned long long tlast = __builtin_amdgcn_s_memtime();
+  const unsigned long long tcyc0 = tlast;
 #define WS2_STAMP(k)                                       \
   {                                                        \
     __builtin_amdgcn_sched_barrier(0);                     \
@@ -828,66 +876,66 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
 #define WS2_STAMP(k)
 #endif
 
-  // this lane's first output element of a tile: channel n0 + r, rows y0 + 2w (+ mb), voxel (z0, ., x0)
+  // this lane's first output element of a tile: its voxel in y row 2w (M-block mb: + Wo rows), channel 4h of block nb
   auto out_base = [&](const WsTile& t, int nb) -> T* {
-    return outp[nb] + ((((int64_t)t.n * a.Do + t.z0) * a.Ho + t.y0 + 2 * wave) * a.Wo + t.x0) * a.out_pitch + ch + 32 * nb;
+    return outp[nb] + ((((int64_t)t.n * a.Do + t.z0) * a.Ho + t.y0) * a.Wo + t.x0) * a.out_pitch + voff;
+  };
+  // quad q of an M-block: accumulator registers 4q .. 4q+3 = channels 8q + 4h + (0..3) of the lane's voxel
+  auto quad_out = [&](const f32x16& acc, int q, T* orow, float (&s1)[16], float (&s2)[16], const f32x4& bq)
+                      __attribute__((always_inline)) {
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      v[j] = acc[4 * q + j] + bq[j];
+      s1[4 * q + j] += v[j];
+      s2[4 * q + j] = fmaf(v[j], v[j], s2[4 * q + j]);
+    }
+    ST<T>::st4(orow + 8 * q, v[0], v[1], v[2], v[3]);
   };
   auto epilogue = [&](f32x16 (&acc)[2 * NB], const WsTile& ET) __attribute__((always_inline)) {
     const int z0 = ET.z0, y0 = ET.y0, x0 = ET.x0;
     const bool full = z0 + TD <= a.Do && y0 + TH <= a.Ho && x0 + TW <= a.Wo;
-    float* const sr = s_red + sr_sel * (256 * NB);
+    stats_sample(ET.n);
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) {
-      float s1 = 0.f, s2 = 0.f;
       T* const obase = out_base(ET, nb);
-      if (full && ch_ok[nb] && !a.accumulate) {
+      if (full && cfull[nb] && wide_ok) {
+        f32x4 bq[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) bq[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (has_bias) {
+#pragma unroll
+          for (int q = 0; q < 4; q++) bq[q] = *reinterpret_cast<const f32x4*>(s_bias + 32 * nb + 8 * q + 4 * h);
+        }
 #pragma unroll
         for (int mb = 0; mb < 2; mb++) {
           T* const orow = obase + (int64_t)mb * a.Wo * a.out_pitch;
 #pragma unroll
-          for (int i = 0; i < 16; i++) {
-            const float v = acc[nb * 2 + mb][i] + bias[nb];
-            ST<T>::st(orow + eoff(i), v);
-            s1 += v;
-            s2 += v * v;
-          }
+          for (int q = 0; q < 4; q++) quad_out(acc[nb * 2 + mb], q, orow, st1[nb], st2[nb], bq[q]);
         }
-      } else {
+      } else {  // ragged tiles, partial channel blocks, out += result, unaligned views: element by element
+        const int gz = z0 + vdz, gx = x0 + vx;
 #pragma unroll
         for (int mb = 0; mb < 2; mb++) {
           const int gy = y0 + 2 * wave + mb;
+          const bool vok = gz < a.Do && gy < a.Ho && gx < a.Wo;
           T* const orow = obase + (int64_t)mb * a.Wo * a.out_pitch;
 #pragma unroll
           for (int i = 0; i < 16; i++) {
-            const int gz = z0 + edz[i >> 2], gx = x0 + (i & 3) + 4 * ((i >> 2) & 1);
-            const float v = acc[nb * 2 + mb][i] + bias[nb];
-            const bool ok = gz < a.Do && gy < a.Ho && gx < a.Wo;
-            if (ok && ch_ok[nb]) {
+            const int cl = 8 * (i >> 2) + (i & 3);  // channel offset from the lane base (which carries 4h)
+            const bool cok = n0 + 32 * nb + 4 * h + cl < a.Cout;
+            const float v = acc[nb * 2 + mb][i] + s_bias[32 * nb + 4 * h + cl];
+            if (vok && cok) {
               float o = v;
-              if (a.accumulate) o += ST<T>::ld(orow + eoff(i));
-              ST<T>::st(orow + eoff(i), o);
+              if (a.accumulate) o += ST<T>::ld(orow + cl);
+              ST<T>::st(orow + cl, o);
             }
-            const float mk = ok ? 1.f : 0.f;
-            s1 += mk * v;
-            s2 += mk * v * v;
+            const float mk = (vok && cok) ? 1.f : 0.f;
+            st1[nb][i] += mk * v;
+            st2[nb][i] += mk * v * v;
           }
         }
       }
-      if (a.stat_partials) {
-        if (!ch_ok[nb]) s1 = s2 = 0.f;
-        s1 += __shfl_xor(s1, 32, 64);
-        s2 += __shfl_xor(s2, 32, 64);
-        if (h == 0) {
-          sr[(wave * NC + 32 * nb + r) * 2 + 0] = s1;
-          sr[(wave * NC + 32 * nb + r) * 2 + 1] = s2;
-        }
-      }
-    }
-    if (a.stat_partials) {
-      pend_tile = ET.tile;
-      pend_n = ET.n;
-      pend_sel = sr_sel;
-      sr_sel ^= 1;
     }
   };
 
@@ -903,11 +951,10 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
   auto tile_phase = [&](auto par_tag, auto fast_tag, auto din_tag, auto dout_tag) __attribute__((always_inline)) {
     constexpr int PAR0 = decltype(par_tag)::value;
     constexpr bool DIN = decltype(din_tag)::value, DOUT = decltype(dout_tag)::value;
-    constexpr int EPG = (32 + NG - 1) / NG;  // pending elements per MFMA group
     f32x16(&acc)[2 * NB] = accs[PAR0];
     f32x16(&pacc)[2 * NB] = accs[1 - PAR0];
     T* const pbase = out_base(PT, 0);
-    float ds1 = 0.f, ds2 = 0.f;
+    if constexpr (DIN) stats_sample(PT.n);
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
       constexpr int dummy = 0;
@@ -975,28 +1022,13 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
 #endif
           }
         }
-        if constexpr (DIN) {
+        if constexpr (DIN) {  // the pending tile's 8 quads (2 M-blocks x 4), spread over the MFMA groups of this pass
 #pragma unroll
-          for (int u = 0; u < EPG; u++) {
-            const int e = g * EPG + u;
-            if (e < 32) {
-              const int mb = e >> 4, i = e & 15;
-              const float v = pacc[mb][i] + bias[0];
-              ST<T>::st(pbase + (int64_t)mb * a.Wo * a.out_pitch + eoff(i), v);
-              ds1 += v;
-              ds2 += v * v;
+          for (int u = 0; u < 8; u++) {
+            if ((u * NG) / 8 == g) {
+              const int mb = u >> 2, q = u & 3;
+              quad_out(pacc[mb], q, pbase + (int64_t)mb * a.Wo * a.out_pitch, st1[0], st2[0], f32x4{0.f, 0.f, 0.f, 0.f});
             }
-          }
-          if (g == (31 / EPG)) {  // last pending element done: per-wave partials -> s_red (both halves hold the sum)
-            ds1 += __shfl_xor(ds1, 32, 64);
-            ds2 += __shfl_xor(ds2, 32, 64);
-            float* sr = s_red + sr_sel * 256;
-            sr[(wave * 32 + r) * 2 + 0] = ds1;
-            sr[(wave * 32 + r) * 2 + 1] = ds2;
-            pend_tile = PT.tile;
-            pend_n = PT.n;
-            pend_sel = sr_sel;
-            sr_sel ^= 1;
           }
         }
         u32x4(&A)[4] = af[g & 1];
@@ -1011,8 +1043,8 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
         for (int jy = 0; jy < 3; jy++)
 #pragma unroll
           for (int nb = 0; nb < NB; nb++) {
-            Mma<T>::run(A[jy], B[jy * NB + nb], acc[nb * 2 + 0]);      // mb 0: box row y' = jy
-            Mma<T>::run(A[jy + 1], B[jy * NB + nb], acc[nb * 2 + 1]);  // mb 1: box row y' = jy + 1
+            Mma<T>::run(B[jy * NB + nb], A[jy], acc[nb * 2 + 0]);      // mb 0: box row y' = jy   (rows = channels)
+            Mma<T>::run(B[jy * NB + nb], A[jy + 1], acc[nb * 2 + 1]);  // mb 1: box row y' = jy + 1
           }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -1021,7 +1053,6 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
       if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       WS_BARRIER();  // buffer PAR fully read, buffer 1-PAR fully written
       WS2_STAMP(2)
-      if (c == 0 && pend_tile >= 0) flush_stats();  // previous tile's partials: every wave's s_red row is visible now
     }
     if constexpr (DOUT)
       PT = T0;
@@ -1058,7 +1089,7 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
     i2 = v2 && (BORDER ? tile_interior(T2) : true);
     org2 = v2 ? tile_org(T2) : src_safe;
   };
-  const bool can_defer = !a.accumulate && (a.Cout % 32 == 0) && a.stat_partials != nullptr;
+  const bool can_defer = wide_ok && (a.Cout % 32 == 0) && a.stat_partials != nullptr && !has_bias;
 
   // ---- pass A: interior tiles.  Every phase is the unchecked copy; with single-pass tiles and a deferrable
   // epilogue the run alternates between the two hot copies (P1 / P0, pending epilogue in, own epilogue out).
@@ -1101,8 +1132,7 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
   }
   // ---- pass B: border tiles (checked copy, immediate epilogue)
   if (bor_cnt > 0) {
-    begin_pass(Yes{}, bor_begin, bor_cnt);  // (its barrier publishes the last interior tile's s_red row)
-    if (pend_tile >= 0) flush_stats();
+    begin_pass(Yes{}, bor_begin, bor_cnt);
     stats_to_row();
     cur_pass = 1;
     more = true;
@@ -1116,14 +1146,15 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
       step(Yes{});
     }
   }
-  if (pend_tile >= 0) {
-    __syncthreads();
-    flush_stats();
-  }
   stats_to_row();
 #ifdef WS_DBG_STAMPS
-  if (tid == 0 && blockIdx.y == 0)
-    for (int k = 0; k < 8; k++) a.stat_partials[(int64_t)blockIdx.x * 8 + k] = (float)tacc[k];
+  if (tid == 0 && blockIdx.y == 0) {
+    for (int k = 0; k < 5; k++) a.stat_partials[(int64_t)blockIdx.x * 8 + k] = (float)tacc[k];
+    // slots 5, 6: low words of the 100 MHz real-time counter at entry / exit (bit patterns); slot 7: shader cycles
+    a.stat_partials[(int64_t)blockIdx.x * 8 + 5] = __uint_as_float((uint32_t)treal0);
+    a.stat_partials[(int64_t)blockIdx.x * 8 + 6] = __uint_as_float((uint32_t)__builtin_amdgcn_s_memrealtime());
+    a.stat_partials[(int64_t)blockIdx.x * 8 + 7] = (float)(__builtin_amdgcn_s_memtime() - tcyc0);
+  }
 #endif
 }
 

@@ -95,6 +95,10 @@ struct ST<float> {
   static constexpr int DT = HDF_F32;
   __device__ static __forceinline__ float ld(const float* p) { return *p; }
   __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+  // four consecutive elements in one store (p aligned to the store)
+  __device__ static __forceinline__ void st4(float* p, float a, float b, float c, float d) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{a, b, c, d};
+  }
   // unpack a 16-B chunk into EPC floats / pack back
   __device__ static __forceinline__ void unpack(const u32x4& c, float* f) {
 #pragma unroll
@@ -113,6 +117,9 @@ struct ST<bf16_t> {
   static constexpr int DT = HDF_BF16;
   __device__ static __forceinline__ float ld(const bf16_t* p) { return bf2f(p->v); }
   __device__ static __forceinline__ void st(bf16_t* p, float v) { p->v = f2bf(v); }
+  __device__ static __forceinline__ void st4(bf16_t* p, float a, float b, float c, float d) {
+    *reinterpret_cast<u32x2*>(p) = u32x2{pack_bf2(a, b), pack_bf2(c, d)};
+  }
   __device__ static __forceinline__ void unpack(const u32x4& c, float* f) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -135,6 +142,9 @@ struct ST<f16_t> {
   static constexpr int DT = HDF_F16;
   __device__ static __forceinline__ float ld(const f16_t* p) { return h2f(p->v); }
   __device__ static __forceinline__ void st(f16_t* p, float v) { p->v = f2h(v); }
+  __device__ static __forceinline__ void st4(f16_t* p, float a, float b, float c, float d) {
+    *reinterpret_cast<u32x2*>(p) = u32x2{pack_h2(a, b), pack_h2(c, d)};
+  }
   __device__ static __forceinline__ void unpack(const u32x4& c, float* f) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {

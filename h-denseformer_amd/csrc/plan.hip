@@ -178,7 +178,6 @@ struct hdf_plan {
   View xin, attnall, attnout, at[3] /*at[k] lives at level k*/, cat[3], pooled[3], x4;
   size_t pool_idx[3];
   size_t tf_F, tf_save, tf_scratch, tf_dF, tf_tape = 0, tf_otape = 0;
-  bool tf_atomics = getenv("HDF_TF_ATOMICS") != nullptr;  // A/B knob: per-tile weight-gradient products + fp32 atomics
   size_t stat_partials, wgrad_ws, inb_partials, inb_k;
   size_t wgrad_ws_bytes = 0;
   // backward scratch
@@ -193,12 +192,6 @@ struct hdf_plan {
     if (side) (void)hipStreamDestroy(side);
   }
   bool dcat_split[3] = {false, false, false};
-  // at3 (the full-resolution transformer feature) is written by upsample_fwd and read by the plain encoder tail; with the
-  // 27-loads-per-8-outputs upsample kernel that is 0.09 ms per step faster than HDF_FUSE_AT3=1 (the tail interpolating it
-  // on the fly from up3's raw output: VALU-bound with register spills), at the price of 268 MB of workspace at batch 2
-  bool materialise_at3 = getenv("HDF_FUSE_AT3") == nullptr;
-  bool no_head_fuse = getenv("HDF_NO_HEAD_FUSE") != nullptr;  // A/B knob: separate in_bwd_reduce after the heads
-  bool no_bias_fuse = getenv("HDF_NO_BIAS_FUSE") != nullptr;  // A/B knob: separate pass for the ConvTranspose3d bias gradients
   // ---- 2-D model (models/HDenseFormer_2D.py) run as its exact depth-replicated 3-D embedding (see embed2d below)
   bool is2d = false;
   std::vector<ParamInfo> params2d;  // the 2-D reference state_dict: conv kernels [..,3,3], patch kernels [..,16,16]
@@ -477,7 +470,7 @@ void layout(hdf_plan* p, int B) {
   for (int k = 0; k < 3; k++) conv_bufs(p->up[k]);
   p->at[2] = mkview(p, bp, "at1", 2, 4 * nf, B);
   p->at[1] = mkview(p, bp, "at2", 1, 2 * nf, B);
-  p->at[0] = p->materialise_at3 ? mkview(p, bp, "at3", 0, nf, B) : View();
+  p->at[0] = mkview(p, bp, "at3", 0, nf, B);
   for (int k = 0; k < 4; k++) {
     conv_bufs(p->enc[k][0]);
     conv_bufs(p->enc[k][1]);
@@ -781,52 +774,36 @@ int transformer_forward(Exec& e, const float* x) {
   HDF_TRY(tf_patch_embed_fwd(d, x, p->D, p->H, p->W, pm + p->P("attns.0.patch_embeddings.weight"),
                              pm + p->P("attns.0.patch_embeddings.bias"), pm + p->P("attns.0.position_embeddings"), F0,
                              e.st));
-  if (tf_use_fused()) {
-    // token kernel, attention, token kernel, ...: between two attention launches ONE kernel finishes the previous
-    // dense layer (and, at a block boundary, runs the block's out_layer) and starts the next one
-    TfLayerP prev{}, cur{};
-    TfOutP o{};
-    for (int b = 0; b < p->nb; b++) {
-      float* F = F0 + (int64_t)b * rows * p->DMF;
-      for (int l = 0; l < 4; l++) {
-        tf_layer_ptrs(p, pm, b, l, cur);
-        TfTokenFwd t;
-        if (l > 0) {
-          t.post = &prev, t.post_save = tf_save(p, e, b, l - 1), t.bp = b, t.lp = l - 1, t.F_post = F;
-        } else if (b > 0) {
-          float* Fp = F0 + (int64_t)(b - 1) * rows * p->DMF;
-          t.post = &prev, t.post_save = tf_save(p, e, b - 1, 3), t.bp = b - 1, t.lp = 3, t.F_post = Fp;
-          tf_out_ptrs(p, pm, b - 1, o);
-          t.out = &o, t.next_F = F;
-        }
-        t.pre = &cur, t.pre_save = tf_save(p, e, b, l), t.bq = b, t.lq = l, t.F_pre = F;
-        HDF_TRY(tf_token_fwd(d, t, p->dtype, e.st));
-        TfLayerSave s = tf_save(p, e, b, l);
-        HDF_TRY(tf_attention_fwd(d.N, d.M * d.B, s.qkv, s.ob, s.lse, e.st));
-        prev = cur;
-      }
-    }
-    TfTokenFwd t;
-    const int b = p->nb - 1;
-    t.post = &prev, t.post_save = tf_save(p, e, b, 3), t.bp = b, t.lp = 3, t.F_post = F0 + (int64_t)b * rows * p->DMF;
-    tf_out_ptrs(p, pm, b, o);
-    t.out = &o, t.attnall = e.at(p->attnall);
-    return tf_token_fwd(d, t, p->dtype, e.st);
-  }
+  // token kernel, attention, token kernel, ...: between two attention launches ONE kernel finishes the previous
+  // dense layer (and, at a block boundary, runs the block's out_layer) and starts the next one
+  TfLayerP prev{}, cur{};
+  TfOutP o{};
   for (int b = 0; b < p->nb; b++) {
     float* F = F0 + (int64_t)b * rows * p->DMF;
     for (int l = 0; l < 4; l++) {
-      TfLayerP q;
-      tf_layer_ptrs(p, pm, b, l, q);
-      HDF_TRY(tf_layer_fwd(d, b, l, q, F, tf_save(p, e, b, l), e.st));
+      tf_layer_ptrs(p, pm, b, l, cur);
+      TfTokenFwd t;
+      if (l > 0) {
+        t.post = &prev, t.post_save = tf_save(p, e, b, l - 1), t.bp = b, t.lp = l - 1, t.F_post = F;
+      } else if (b > 0) {
+        float* Fp = F0 + (int64_t)(b - 1) * rows * p->DMF;
+        t.post = &prev, t.post_save = tf_save(p, e, b - 1, 3), t.bp = b - 1, t.lp = 3, t.F_post = Fp;
+        tf_out_ptrs(p, pm, b - 1, o);
+        t.out = &o, t.next_F = F;
+      }
+      t.pre = &cur, t.pre_save = tf_save(p, e, b, l), t.bq = b, t.lq = l, t.F_pre = F;
+      HDF_TRY(tf_token_fwd(d, t, p->dtype, e.st));
+      TfLayerSave s = tf_save(p, e, b, l);
+      HDF_TRY(tf_attention_fwd(d.N, d.M * d.B, s.qkv, s.ob, s.lse, e.st));
+      prev = cur;
     }
-    TfOutP o;
-    tf_out_ptrs(p, pm, b, o);
-    bool last = (b == p->nb - 1);
-    HDF_TRY(tf_block_out_fwd(d, b, o, F, last ? nullptr : F + rows * p->DMF, last ? e.at(p->attnall) : nullptr,
-                             p->dtype, e.st));
   }
-  return HDF_OK;
+  TfTokenFwd t;
+  const int b = p->nb - 1;
+  t.post = &prev, t.post_save = tf_save(p, e, b, 3), t.bp = b, t.lp = 3, t.F_post = F0 + (int64_t)b * rows * p->DMF;
+  tf_out_ptrs(p, pm, b, o);
+  t.out = &o, t.attnall = e.at(p->attnall);
+  return tf_token_fwd(d, t, p->dtype, e.st);
 }
 
 int transformer_backward(Exec& e, const float* x) {
@@ -837,95 +814,74 @@ int transformer_backward(Exec& e, const float* x) {
   float* F0 = e.f(p->tf_F);
   float* dF = e.f(p->tf_dF);
   float* scratch = e.f(p->tf_scratch);
-  if (tf_use_fused()) {
-    // token kernel, attention backward, token kernel, ...: one launch runs the Linear0 / LN1 / to_qkv backward of the
-    // layer whose attention backward just finished, (at a block boundary) the previous block's out_layer backward, and
-    // the ff / to_out backward of the next layer down
-    float* dO = scratch;
-    float* dh0acc = scratch + rows * 32;
-    float* dqkv = scratch + rows * 64;
-    TfLayerP up{}, gup{}, cur{}, gcur{};
-    TfOutP o{}, go{};
-    bool have_up = false;
-    int ub = 0, ul = 0;
-    for (int b = p->nb - 1; b >= 0; b--) {
-      float* F = F0 + (int64_t)b * rows * p->DMF;
-      for (int l = 3; l >= 0; l--) {
-        tf_layer_ptrs(p, pm, b, l, cur);
-        tf_layer_ptrs(p, e.grads, b, l, gcur);
-        TfTokenBwd t;
-        t.dF = dF;
-        float* tape = p->tf_atomics ? nullptr : e.f(p->tf_tape);
-        float* otape = p->tf_atomics ? nullptr : e.f(p->tf_otape);
-        if (have_up) {
-          t.pre = &up, t.pre_grad = &gup, t.pre_save = tf_save(p, e, ub, ul), t.bq = ub, t.lq = ul;
-          t.F_pre = F0 + (int64_t)ub * rows * p->DMF, t.dqkv = dqkv, t.dh0acc = dh0acc;
-          if (tape) t.tape_pre = tape + (int64_t)(ub * 4 + ul) * rows * TF_TAPE_W;
-        }
-        if (l == 3) {
-          tf_out_ptrs(p, pm, b, o);
-          tf_out_ptrs(p, e.grads, b, go);
-          t.out = &o, t.out_grad = &go, t.bo = b, t.F_out = F;
-          if (!have_up) t.d_attnall = e.at(p->dAttnall);
-          if (otape) t.tape_out = otape + (int64_t)b * rows * p->DMF;
-        }
-        t.post = &cur, t.post_grad = &gcur, t.post_save = tf_save(p, e, b, l), t.bp = b, t.lp = l;
-        if (tape) t.tape_post = tape + (int64_t)(b * 4 + l) * rows * TF_TAPE_W;
-        t.dO = dO, t.dh0acc_out = dh0acc;
-        HDF_TRY(tf_token_bwd(d, t, p->dtype, e.st));
-        TfLayerSave s = tf_save(p, e, b, l);
-        HDF_TRY(tf_attention_bwd(d.N, d.M * d.B, s.qkv, s.ob, s.lse, dO, dqkv, e.st));
-        up = cur, gup = gcur, ub = b, ul = l, have_up = true;
-      }
-    }
-    TfTokenBwd t;
-    t.dF = dF, t.pre = &up, t.pre_grad = &gup, t.pre_save = tf_save(p, e, 0, 0), t.bq = 0, t.lq = 0, t.F_pre = F0;
-    t.dqkv = dqkv, t.dh0acc = dh0acc;
-    if (!p->tf_atomics) t.tape_pre = e.f(p->tf_tape);
-    HDF_TRY(tf_token_bwd(d, t, p->dtype, e.st));
-    if (!p->tf_atomics) {
-      // every weight-matrix gradient of the branches: one launch over the tapes (fixed-order reductions, no atomics)
-      TfWgradArgs w{};
-      const int64_t blk0 = p->P("attns.0.blocks.0.0.layers.0.0.weight");
-      const int64_t blk_stride = p->nb > 1 ? p->P("attns.0.blocks.1.0.layers.0.0.weight") - blk0 : 0;
-      int k = 0;
-      auto rel = [&](const std::string& n) { return p->P("attns.0.blocks.0.0." + n) - blk0; };
-      for (int l = 0; l < 4; l++) {
-        const std::string pre = "layers." + std::to_string(l);
-        w.e[k++] = TfWgradEntry{rel(pre + ".1.fn.to_qkv.weight"), 96, 32, l, 0, 0, TF_T_DQ, TF_T_T, -1, -1, 96, 32};
-        w.e[k++] = TfWgradEntry{rel(pre + ".0.weight"), 32, p->DM + 32 * l, l, 0, 1, TF_T_DH0, 0, -1, -1, 32, p->DMF};
-        w.e[k++] = TfWgradEntry{rel(pre + ".2.fn.net.3.weight"), 32, 64, l, 0, 0, TF_T_P1, TF_T_P1 + 32, TF_T_P0, TF_T_P0 + 32,
-                                32, 64};
-        w.e[k++] = TfWgradEntry{rel(pre + ".2.fn.net.0.weight"), 64, 32, l, 0, 0, TF_T_P1 + 96, TF_T_P1 + 160, TF_T_P0 + 96,
-                                TF_T_P0 + 160, 64, 32};
-        w.e[k++] = TfWgradEntry{rel(pre + ".1.fn.to_out.0.weight"), 32, 32, l, 0, 2, TF_T_DGO, 0, -1, -1, 32, 32};
-      }
-      w.e[k++] = TfWgradEntry{rel("out_layer.net.3.weight"), p->DM, 64, 0, 3, 3, 0, p->DM, -1, -1, p->DM, 64};
-      w.e[k++] = TfWgradEntry{rel("out_layer.net.0.weight"), 64, p->DMF, 0, 3, 1, p->DM + 64, 0, -1, -1, 64, p->DMF};
-      w.grads = e.grads, w.mstride = p->mstride, w.block0 = blk0, w.block_stride = blk_stride;
-      w.tape = e.f(p->tf_tape), w.otape = e.f(p->tf_otape), w.F = F0, w.save = e.f(p->tf_save);
-      w.rows = rows, w.BN = e.B * p->Ntok, w.DMF = p->DMF, w.b0 = 0;
-      HDF_TRY(tf_wgrad(w, p->nb, p->M, e.st));
-    }
-    HDF_TRY(tf_patch_embed_bwd(d, x, p->D, p->H, p->W, dF, e.grads + p->P("attns.0.patch_embeddings.weight"),
-                               e.grads + p->P("attns.0.patch_embeddings.bias"),
-                               e.grads + p->P("attns.0.position_embeddings"), scratch, e.st));
-    return HDF_OK;
-  }
+  // token kernel, attention backward, token kernel, ...: one launch runs the Linear0 / LN1 / to_qkv backward of the
+  // layer whose attention backward just finished, (at a block boundary) the previous block's out_layer backward, and
+  // the ff / to_out backward of the next layer down
+  float* dO = scratch;
+  float* dh0acc = scratch + rows * 32;
+  float* dqkv = scratch + rows * 64;
+  TfLayerP up{}, gup{}, cur{}, gcur{};
+  TfOutP o{}, go{};
+  bool have_up = false;
+  int ub = 0, ul = 0;
   for (int b = p->nb - 1; b >= 0; b--) {
     float* F = F0 + (int64_t)b * rows * p->DMF;
-    TfOutP o, go;
-    tf_out_ptrs(p, pm, b, o);
-    tf_out_ptrs(p, e.grads, b, go);
-    bool last = (b == p->nb - 1);
-    HDF_TRY(tf_block_out_bwd(d, b, o, go, F, last ? nullptr : dF, last ? e.at(p->dAttnall) : nullptr, p->dtype, dF,
-                             e.st));
     for (int l = 3; l >= 0; l--) {
-      TfLayerP q, gq;
-      tf_layer_ptrs(p, pm, b, l, q);
-      tf_layer_ptrs(p, e.grads, b, l, gq);
-      HDF_TRY(tf_layer_bwd(d, b, l, q, gq, F, dF, tf_save(p, e, b, l), scratch, e.st));
+      tf_layer_ptrs(p, pm, b, l, cur);
+      tf_layer_ptrs(p, e.grads, b, l, gcur);
+      TfTokenBwd t;
+      t.dF = dF;
+      float* tape = e.f(p->tf_tape);
+      float* otape = e.f(p->tf_otape);
+      if (have_up) {
+        t.pre = &up, t.pre_grad = &gup, t.pre_save = tf_save(p, e, ub, ul), t.bq = ub, t.lq = ul;
+        t.F_pre = F0 + (int64_t)ub * rows * p->DMF, t.dqkv = dqkv, t.dh0acc = dh0acc;
+        if (tape) t.tape_pre = tape + (int64_t)(ub * 4 + ul) * rows * TF_TAPE_W;
+      }
+      if (l == 3) {
+        tf_out_ptrs(p, pm, b, o);
+        tf_out_ptrs(p, e.grads, b, go);
+        t.out = &o, t.out_grad = &go, t.bo = b, t.F_out = F;
+        if (!have_up) t.d_attnall = e.at(p->dAttnall);
+        if (otape) t.tape_out = otape + (int64_t)b * rows * p->DMF;
+      }
+      t.post = &cur, t.post_grad = &gcur, t.post_save = tf_save(p, e, b, l), t.bp = b, t.lp = l;
+      if (tape) t.tape_post = tape + (int64_t)(b * 4 + l) * rows * TF_TAPE_W;
+      t.dO = dO, t.dh0acc_out = dh0acc;
+      HDF_TRY(tf_token_bwd(d, t, p->dtype, e.st));
+      TfLayerSave s = tf_save(p, e, b, l);
+      HDF_TRY(tf_attention_bwd(d.N, d.M * d.B, s.qkv, s.ob, s.lse, dO, dqkv, e.st));
+      up = cur, gup = gcur, ub = b, ul = l, have_up = true;
     }
+  }
+  TfTokenBwd t;
+  t.dF = dF, t.pre = &up, t.pre_grad = &gup, t.pre_save = tf_save(p, e, 0, 0), t.bq = 0, t.lq = 0, t.F_pre = F0;
+  t.dqkv = dqkv, t.dh0acc = dh0acc;
+  t.tape_pre = e.f(p->tf_tape);
+  HDF_TRY(tf_token_bwd(d, t, p->dtype, e.st));
+  {
+    // every weight-matrix gradient of the branches: one launch over the tapes (fixed-order reductions, no atomics)
+    TfWgradArgs w{};
+    const int64_t blk0 = p->P("attns.0.blocks.0.0.layers.0.0.weight");
+    const int64_t blk_stride = p->nb > 1 ? p->P("attns.0.blocks.1.0.layers.0.0.weight") - blk0 : 0;
+    int k = 0;
+    auto rel = [&](const std::string& n) { return p->P("attns.0.blocks.0.0." + n) - blk0; };
+    for (int l = 0; l < 4; l++) {
+      const std::string pre = "layers." + std::to_string(l);
+      w.e[k++] = TfWgradEntry{rel(pre + ".1.fn.to_qkv.weight"), 96, 32, l, 0, 0, TF_T_DQ, TF_T_T, -1, -1, 96, 32};
+      w.e[k++] = TfWgradEntry{rel(pre + ".0.weight"), 32, p->DM + 32 * l, l, 0, 1, TF_T_DH0, 0, -1, -1, 32, p->DMF};
+      w.e[k++] = TfWgradEntry{rel(pre + ".2.fn.net.3.weight"), 32, 64, l, 0, 0, TF_T_P1, TF_T_P1 + 32, TF_T_P0, TF_T_P0 + 32,
+                              32, 64};
+      w.e[k++] = TfWgradEntry{rel(pre + ".2.fn.net.0.weight"), 64, 32, l, 0, 0, TF_T_P1 + 96, TF_T_P1 + 160, TF_T_P0 + 96,
+                              TF_T_P0 + 160, 64, 32};
+      w.e[k++] = TfWgradEntry{rel(pre + ".1.fn.to_out.0.weight"), 32, 32, l, 0, 2, TF_T_DGO, 0, -1, -1, 32, 32};
+    }
+    w.e[k++] = TfWgradEntry{rel("out_layer.net.3.weight"), p->DM, 64, 0, 3, 3, 0, p->DM, -1, -1, p->DM, 64};
+    w.e[k++] = TfWgradEntry{rel("out_layer.net.0.weight"), 64, p->DMF, 0, 3, 1, p->DM + 64, 0, -1, -1, 64, p->DMF};
+    w.grads = e.grads, w.mstride = p->mstride, w.block0 = blk0, w.block_stride = blk_stride;
+    w.tape = e.f(p->tf_tape), w.otape = e.f(p->tf_otape), w.F = F0, w.save = e.f(p->tf_save);
+    w.rows = rows, w.BN = e.B * p->Ntok, w.DMF = p->DMF, w.b0 = 0;
+    HDF_TRY(tf_wgrad(w, p->nb, p->M, e.st));
   }
   HDF_TRY(tf_patch_embed_bwd(d, x, p->D, p->H, p->W, dF, e.grads + p->P("attns.0.patch_embeddings.weight"),
                              e.grads + p->P("attns.0.patch_embeddings.bias"),
@@ -1021,9 +977,7 @@ int conv_backward(Exec& e, Conv3& c, const View& dy, const View& in, Xf xf, cons
 int convt_backward(Exec& e, ConvT3& t, const View& dout, const View& in, Xf xf, const View& din) {
   hdf_plan* p = e.p;
   const int* d = e.dm(t.lvl_in);
-  if (p->no_bias_fuse)  // else: taken from the epilogue of the dgrad conv that produced dout (conv_backward)
-    HDF_TRY(hdf_launch_bias_grad(p->dtype, e.at(dout), dout.pitch, e.G(t.b), t.Cout,
-                                 (int64_t)e.B * p->vox(t.lvl_in - 1), e.st));
+  // (the bias gradient comes out of the epilogue of the dgrad conv that produced dout: conv_backward)
   WgradArgs w{};
   w.sm = e.at(in);
   w.sm_pitch = in.pitch;
@@ -1065,7 +1019,7 @@ int head_backward(Exec& e, const Head1& h, const void* dlogits, const View& in, 
                   const Conv3* fuse_in = nullptr, int* pre_blocks = nullptr) {
   hdf_plan* p = e.p;
   const int hb = hdf_head_bwd_blocks(p->vox(h.lvl));
-  const bool fuse = fuse_in && pre_blocks && hb <= 1024 && !p->no_head_fuse;
+  const bool fuse = fuse_in && pre_blocks && hb <= 1024;
   if (pre_blocks) *pre_blocks = fuse ? hb : 0;
   return hdf_launch_head_bwd(p->dtype, dlogits, e.at(in), in.pitch, xf.scale, xf.shift, e.P(h.w), e.at(dx), dx.pitch,
                              acc, e.G(h.w), e.G(h.b), e.B, h.C, p->ncls, p->vox(h.lvl), e.st,
@@ -1234,7 +1188,6 @@ static int forward3d(hdf_plan* p, const float* x, const float* params, void* wor
     for (int k = 0; k < 3; k++) {  // up1 -> at1 (lvl 2), up2 -> at2 (lvl 1), up3 -> at3 (lvl 0)
       Conv3& c = p->up[k];
       HDF_TRY(conv_forward(e, c, *src, none));
-      if (k == 2 && !p->materialise_at3) break;  // at3 is not materialised: the encoder tail interpolates it on the fly
       const View& dst = p->at[2 - k];
       HDF_TRY(hdf_launch_upsample_fwd(p->dtype, e.at(c.y), c.y.pitch, e.f(c.st.scale), e.f(c.st.shift), e.at(dst),
                                       dst.pitch, batch, c.Cout, p->dims[c.lvl][0], p->dims[c.lvl][1],
@@ -1251,15 +1204,11 @@ static int forward3d(hdf_plan* p, const float* x, const float* params, void* wor
     Conv3& c = p->enc[k][1];
     if (k < 3) {
       View ds = subview(p, p->cat[k], ch[k], ch[k]);
-      // ds_k = relu(IN(y)) + at_k ; pooled = MaxPool(ds_k): one fused pass.  Level 0 takes at3 straight from up3's
-      // raw conv output (trilinear x2 of relu(IN(.)) evaluated inside the kernel)
-      Conv3& u3 = p->up[2];
-      const bool ups = (k == 0) && !p->materialise_at3;
-      HDF_TRY(hdf_launch_enc_tail(p->dtype, e.at(c.y), c.y.pitch, e.f(c.st.scale), e.f(c.st.shift),
-                                  ups ? e.at(u3.y) : e.at(p->at[k]), ups ? u3.y.pitch : p->at[k].pitch,
-                                  ups ? e.f(u3.st.scale) : nullptr, ups ? e.f(u3.st.shift) : nullptr, e.at(ds),
-                                  ds.pitch, e.at(p->pooled[k]), p->pooled[k].pitch, (uint8_t*)(e.ws + p->pool_idx[k]),
-                                  batch, ch[k], p->dims[k + 1][0], p->dims[k + 1][1], p->dims[k + 1][2], e.st));
+      // ds_k = relu(IN(y)) + at_k ; pooled = MaxPool(ds_k): one fused pass
+      HDF_TRY(hdf_launch_enc_tail(p->dtype, e.at(c.y), c.y.pitch, e.f(c.st.scale), e.f(c.st.shift), e.at(p->at[k]),
+                                  p->at[k].pitch, e.at(ds), ds.pitch, e.at(p->pooled[k]), p->pooled[k].pitch,
+                                  (uint8_t*)(e.ws + p->pool_idx[k]), batch, ch[k], p->dims[k + 1][0], p->dims[k + 1][1],
+                                  p->dims[k + 1][2], e.st));
       cur = &p->pooled[k];
     } else {
       HDF_TRY(hdf_launch_norm_relu_add(p->dtype, e.at(c.y), c.y.pitch, e.f(c.st.scale), e.f(c.st.shift),
@@ -1355,7 +1304,7 @@ static int backward3d(hdf_plan* p, const float* x, const float* params, void* wo
     HDF_TRY(conv_backward(e, c2, p->gY[k], c1.y, xf_of(e, c1), &p->gA[k], 0));
     HDF_TRY(in_backward(e, c1, p->gA[k], p->gY2[k]));
     // the upconv half of d(cat) is the gradient of upconv_{k+1}'s output: its bias gradient rides on this conv
-    float* up_db = p->no_bias_fuse ? nullptr : e.G(p->upc[k].b);
+    float* up_db = e.G(p->upc[k].b);
     if (p->dcat_split[k])
       HDF_TRY(conv_backward(e, c1, p->gY2[k], p->cat[k], none, &p->dUp[k], 0, &p->dSkip[k], up_db, ch[k]));
     else

@@ -144,4 +144,3 @@ struct TfTokenBwd {
   float* dh0acc_out = nullptr;      // [rows][32] -> PREB of layer (bp, lp)
 };
 int tf_token_bwd(const TfDims& d, const TfTokenBwd& t, int dtype, hipStream_t st);
-bool tf_use_fused();  // false under HDF_TF_OLD=1 (A/B knob: the unfused VALU token kernels)

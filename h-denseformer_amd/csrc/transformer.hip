@@ -5,129 +5,17 @@
 // feature = ff(LN2(h2))  (second evaluation of the same ff, :98).  The feature concat is never
 // materialised: every block owns a dense buffer F[rows][DM+128] whose column ranges ARE the features.
 //
-// Work decomposition: token-parallel kernels give one token to each 32-lane half-wave (the layer
-// width is 32 = growth_rate), 32 tokens per workgroup; attention is a flash-style pass with K,V of
-// one (sample, modality, head) in LDS (N x 4 floats each), 4 lanes per query, no N x N tensor in
-// HBM; backward recomputes the probabilities from the saved log-sum-exp.  Parameter gradients are
-// reduced per workgroup through LDS outer products and then added with fp32 atomics.  The patch
-// embedding (a 4096-deep contraction) and its weight gradient run on v_mfma_f32_32x32x2_f32.
+// This file: the attention core (a flash-style pass with K,V of one (sample, modality, head) in LDS, N x 4 floats
+// each, 4 lanes per query, no N x N tensor in HBM; backward recomputes the probabilities from the saved
+// log-sum-exp), the patch embedding (a 4096-deep contraction) and its weight gradient on the f32 MFMA, and the
+// host-side entry points.  Everything of a dense layer between two attention launches lives in
+// transformer_fused.hip (tok_fwd_kernel / tok_bwd_kernel / tf_wgrad_kernel); the round-1 VALU token kernels
+// (dense_pre/post_*, block_out_*) were removed in round 3.
 #include "transformer.h"
 
 namespace {
 
-constexpr int TJ = 2;        // tokens per 32-lane half-wave group
-constexpr int TB = 8 * TJ;   // tokens per workgroup
-// The two forward token kernels of a dense layer have no per-workgroup weight-gradient work to amortise: one token
-// per half-wave (8 per workgroup, 512 workgroups) is 10-20 % faster there; the backward kernels and the block
-// out-layer (large weight panels, atomics per workgroup) are fastest at TJ = 2 (measured at 1, 2 and 4).
-constexpr int FWD_TJ = 1, FWD_TB = 8 * FWD_TJ;
 constexpr size_t LDS_LIMIT = 160 * 1024;
-
-__device__ __forceinline__ float hsum32(float v) {  // sum over the 32 lanes of a half-wave
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_grad(float x) {
-  return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
-}
-__device__ __forceinline__ float dot_row(const float* __restrict__ w, const float* sv, int K) {
-  float acc = 0.f;
-  for (int k = 0; k < K; k += 4) {
-    float4 a = *reinterpret_cast<const float4*>(w + k);
-    float4 b = *reinterpret_cast<const float4*>(sv + k);
-    acc += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
-  }
-  return acc;
-}
-// sum_o W[o*ld + col] * sv[o]
-__device__ __forceinline__ float dot_col(const float* __restrict__ w, int ld, int col, const float* sv, int O) {
-  float acc = 0.f;
-  for (int o = 0; o < O; o++) acc += w[(int64_t)o * ld + col] * sv[o];
-  return acc;
-}
-// ---- weights through LDS ----------------------------------------------------------------------------------
-// Every lane of a half-wave owns one output row of a Linear; reading that row straight from global memory makes
-// each load touch 32 different cache lines.  Instead the [O][K] matrix is staged once per workgroup with
-// coalesced loads into LDS rows of ODD stride (K+1 floats): "lane = row" reads (forward) and "lane = column"
-// reads (transposed products in backward) are both bank-conflict free on the same image.
-// The loads are float4 (every parameter starts on a 64-byte boundary, K % 4 == 0) and SU of them are in flight per
-// thread before the first LDS store: one memory round trip per 8192 floats instead of one per 256.
-constexpr int SU = 8;
-__device__ __forceinline__ void stage_w(float* sW, const float* __restrict__ gW, int O, int K) {
-  const int ldw = K + 1, total4 = (O * K) >> 2;
-  const float4* g4 = reinterpret_cast<const float4*>(gW);
-  for (int base = threadIdx.x; base < total4; base += 256 * SU) {
-    float4 v[SU];
-#pragma unroll
-    for (int u = 0; u < SU; u++) v[u] = g4[min(base + 256 * u, total4 - 1)];
-#pragma unroll
-    for (int u = 0; u < SU; u++) {
-      const int i = (base + 256 * u) * 4;
-      if (i < 4 * total4) {
-        const int o = i / K, k = i - o * K;
-        float* q = sW + o * ldw + k;
-        q[0] = v[u].x, q[1] = v[u].y, q[2] = v[u].z, q[3] = v[u].w;
-      }
-    }
-  }
-}
-// TB token rows of K floats (row t of the modality's [BN][ld] matrix, rows past BN: clamped or zero) -> sX[TB][K]
-template <bool ZERO, int TBv = TB>
-__device__ __forceinline__ void stage_rows(float* sX, const float* __restrict__ gX, int64_t ld, int K, int t0, int BN) {
-  const int total4 = (TBv * K) >> 2;
-  for (int base = threadIdx.x; base < total4; base += 256 * SU) {
-    float4 v[SU];
-#pragma unroll
-    for (int u = 0; u < SU; u++) {
-      const int i = min(base + 256 * u, total4 - 1) * 4, tl = i / K, k = i - tl * K;
-      v[u] = *reinterpret_cast<const float4*>(gX + (int64_t)min(t0 + tl, BN - 1) * ld + k);
-    }
-#pragma unroll
-    for (int u = 0; u < SU; u++) {
-      const int i = (base + 256 * u) * 4;
-      if (i < 4 * total4) {
-        if (ZERO && t0 + i / K >= BN) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(sX + i) = v[u];
-      }
-    }
-  }
-}
-// sum_k sWrow[k] * sv[k]   (sv 16-byte aligned, K % 4 == 0)
-__device__ __forceinline__ float dot_lds(const float* sWrow, const float* sv, int K) {
-  float acc = 0.f;
-  for (int k = 0; k < K; k += 4) {
-    float4 b = *reinterpret_cast<const float4*>(sv + k);
-    acc += sWrow[k] * b.x + sWrow[k + 1] * b.y + sWrow[k + 2] * b.z + sWrow[k + 3] * b.w;
-  }
-  return acc;
-}
-// NT tokens (rows g, g+8, ... of sX) share every weight read: acc[j] += sum_k sWrow[k] * sX[(g+8j)*ldx + k]
-template <int NT>
-__device__ __forceinline__ void dot_lds_multi(const float* sWrow, const float* sX, int ldx, int g, int K, float* acc) {
-  for (int k = 0; k < K; k += 4) {
-    const float w0 = sWrow[k], w1 = sWrow[k + 1], w2 = sWrow[k + 2], w3 = sWrow[k + 3];
-#pragma unroll
-    for (int j = 0; j < NT; j++) {
-      float4 b = *reinterpret_cast<const float4*>(sX + (g + 8 * j) * ldx + k);
-      acc[j] += w0 * b.x + w1 * b.y + w2 * b.z + w3 * b.w;
-    }
-  }
-}
-// sum_o sW[o*ldw + col] * sv[o]
-__device__ __forceinline__ float dot_col_lds(const float* sW, int ldw, int col, const float* sv, int O) {
-  float acc = 0.f;
-  for (int o = 0; o < O; o += 4) {
-    float4 b = *reinterpret_cast<const float4*>(sv + o);
-    acc += sW[o * ldw + col] * b.x + sW[(o + 1) * ldw + col] * b.y + sW[(o + 2) * ldw + col] * b.z +
-           sW[(o + 3) * ldw + col] * b.w;
-  }
-  return acc;
-}
-
-// select AFTER an unconditional load (the argument is evaluated before the call): never branch around a load
-__device__ __forceinline__ float sel0(bool ok, float v) { return ok ? v : 0.f; }
 
 struct Drop {
   int training;
@@ -140,93 +28,6 @@ struct Drop {
 };
 __device__ __forceinline__ Drop make_drop(const TfDims& d) { return Drop{d.training, d.seed, d.thresh24, d.keep_scale}; }
 
-// gW[o*K + k] += sum_t sA[t*lda + o] * sB[t*ldb + k]   (t < TB; padded tokens hold zeros)
-// One 32x32 block of gW per wave on v_mfma_f32_32x32x2_f32 (exact fp32 fma chains): TB/2 steps of two tokens, each
-// lane feeding one sA and one sB element per step (conflict-free rows), then 16 coalesced atomics per lane.  The
-// per-thread dot-product form of this read 2 * TB LDS words per output.  wrot rotates the block -> wave map so that
-// two small products issued back to back land on different waves.
-__device__ __forceinline__ void outer_acc(float* __restrict__ gW, int O, int K, const float* sA, int lda,
-                                          const float* sB, int ldb, int wrot = 0) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-  const int nbk = (K + 31) >> 5, nblk = ((O + 31) >> 5) * nbk;
-  for (int blk = (wave - wrot) & 3; blk < nblk; blk += 4) {
-    const int bo = blk / nbk, o0 = bo * 32, k0 = (blk - bo * nbk) * 32;
-    const bool aok = o0 + r < O, bok = k0 + r < K;
-    const float* pa = sA + h * lda + min(o0 + r, O - 1);
-    const float* pb = sB + h * ldb + min(k0 + r, K - 1);
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; i++) acc[i] = 0.f;
-#pragma unroll
-    for (int s = 0; s < TB / 2; s++) {
-      const float av = aok ? pa[2 * s * lda] : 0.f;
-      const float bv = bok ? pb[2 * s * ldb] : 0.f;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-    }
-    if (bok) {
-#pragma unroll
-      for (int i = 0; i < 16; i++) {
-        const int o = o0 + (i & 3) + 8 * (i >> 2) + 4 * h;  // accumulator i of this lane: row o, column k0 + r
-        if (o < O) atomicAdd(gW + (int64_t)o * K + k0 + r, acc[i]);
-      }
-    }
-  }
-}
-// gb[o] += sum_t sA[t*lda + o]
-__device__ __forceinline__ void col_acc(float* __restrict__ gb, int O, const float* sA, int lda) {
-  for (int o = threadIdx.x; o < O; o += 256) {
-    float s = 0.f;
-    for (int t = 0; t < TB; t++) s += sA[t * lda + o];
-    atomicAdd(gb + o, s);
-  }
-}
-
-#define TOK_LOOP(j, tl, t, ok, R)                       \
-  _Pragma("unroll") for (int j = 0; j < TJ; j++)        \
-    if (int tl = (threadIdx.x >> 5) + 8 * j; true)      \
-      if (int t = blockIdx.x * TB + tl; true)           \
-        if (bool ok = t < BN; true)                     \
-          if (int64_t R = (int64_t)m * BN + (ok ? t : 0); true)
-
-// ------------------------------------------------------------------------------ K1: Linear0 + LN1 + QKV
-__global__ __launch_bounds__(256) void dense_pre_fwd_kernel(TfDims d, int K, TfLayerP p, const float* __restrict__ F,
-                                                            float* __restrict__ h0, float* __restrict__ qkv) {
-  constexpr int TJ = FWD_TJ, TB = FWD_TB;  // shadow the file-wide token grouping (TOK_LOOP picks these up)
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* s_in = sm;                        // [TB][K]
-  float* s_t = s_in + TB * K;              // [TB][32]
-  float* s_w0 = s_t + TB * 32;             // [32][K+1]
-  float* s_wq = s_w0 + 32 * (K + 1);       // [96][33]
-  const int m = blockIdx.y, BN = d.B * d.N, o = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const int64_t mo = (int64_t)m * d.mstride;
-  stage_rows<false, TB>(s_in, F + (int64_t)m * BN * d.DMF, d.DMF, K, blockIdx.x * TB, BN);
-  stage_w(s_w0, p.w0 + mo, 32, K);
-  stage_w(s_wq, p.wqkv + mo, 96, 32);
-  __syncthreads();
-  {
-    float hacc[4] = {0.f, 0.f, 0.f, 0.f};
-    dot_lds_multi<TJ>(s_w0 + o * (K + 1), s_in, K, grp, K, hacc);
-    TOK_LOOP(j, tl, t, ok, R) {
-      float h = p.b0[mo + o] + hacc[j];
-      float mean = hsum32(h) * (1.f / 32.f);
-      float dd = h - mean;
-      float rstd = rsqrtf(hsum32(dd * dd) * (1.f / 32.f) + 1e-5f);
-      s_t[tl * 32 + o] = dd * rstd * p.ln1g[mo + o] + p.ln1b[mo + o];
-      if (ok) h0[R * 32 + o] = h;
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int c = 0; c < 3; c++) {
-    int jj = o + 32 * c;
-    float qacc[4] = {0.f, 0.f, 0.f, 0.f};
-    dot_lds_multi<TJ>(s_wq + jj * 33, s_t, 32, grp, 32, qacc);
-    TOK_LOOP(j, tl, t, ok, R) {
-      if (ok) qkv[R * 96 + jj] = qacc[j];
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------ K2: attention
 // grid (ceil(N/AQ), 8 heads, M*B).  QL lanes per query, keys interleaved over the QL lanes.  The pair loops are
 // VALU-bound (N^2 pairs x 8 heads x M*B sequences, head dim 4), so they are written on 2-wide fp32 vectors
@@ -238,11 +39,6 @@ constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 lo2(const float4& v) { return f2{v.x, v.y}; }
 __device__ __forceinline__ f2 hi2(const float4& v) { return f2{v.z, v.w}; }
-__device__ __forceinline__ float dot4(f2 a01, f2 a23, f2 b01, f2 b23) {
-  f2 t = a01 * b01;
-  t = __builtin_elementwise_fma(a23, b23, t);
-  return t.x + t.y;
-}
 __host__ __device__ inline int attn_rows(int N) { return (N + ATRIP - 1) / ATRIP * ATRIP; }
 
 // K and V rows of one (sequence, head) -> LDS, padded rows zero; 4 row pairs in flight per thread
@@ -518,472 +314,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(int N, int nseq, const fl
     attn_bwd_dkv_body(N, blockIdx.z - nseq, qkv, ob, lse, dO, dqkv, skv);
 }
 
-// ------------------------------------------------------------------------------ K3: to_out + residual + ff + ff
-__global__ __launch_bounds__(256) void dense_post_fwd_kernel(TfDims d, int block, int layer, TfLayerP p,
-                                                             const float* __restrict__ h0, const float* __restrict__ ob,
-                                                             float* __restrict__ h1s, float* __restrict__ h2s,
-                                                             float* __restrict__ F) {
-  constexpr int TJ = FWD_TJ, TB = FWD_TB;  // shadow the file-wide token grouping (TOK_LOOP picks these up)
-  __shared__ __attribute__((aligned(16))) float s_a[TB][32], s_u[TB][32], s_f[TB][64];
-  __shared__ float s_wo[32 * 33], s_w1[64 * 33], s_w2[32 * 65];
-  const int m = blockIdx.y, BN = d.B * d.N, o = threadIdx.x & 31;
-  const int64_t mo = (int64_t)m * d.mstride;
-  const Drop dr = make_drop(d);
-  const uint32_t site0 = hdf_site_id(m, block, layer, 0);
-  float h1r[4], hcur[4];
-  stage_w(s_wo, p.wout + mo, 32, 32);
-  stage_w(s_w1, p.w1 + mo, 64, 32);
-  stage_w(s_w2, p.w2 + mo, 32, 64);
-  TOK_LOOP(j, tl, t, ok, R) { s_a[tl][o] = sel0(ok, ob[R * 32 + o]); }
-  __syncthreads();
-  TOK_LOOP(j, tl, t, ok, R) {
-    float a = p.bout[mo + o] + dot_lds(s_wo + o * 33, s_a[tl], 32);
-    a *= dr.mask(site0 + 0, (uint32_t)t * 32 + o);
-    float h1 = a + sel0(ok, h0[R * 32 + o]);
-    h1r[j] = h1;
-    hcur[j] = h1;
-    if (ok) h1s[R * 32 + o] = h1;
-  }
-  for (int pass = 0; pass < 2; pass++) {  // pass 0: h2 = ff(LN2(h1)) + h1 ; pass 1: feature = ff(LN2(h2))
-    TOK_LOOP(j, tl, t, ok, R) {
-      float mean = hsum32(hcur[j]) * (1.f / 32.f);
-      float dd = hcur[j] - mean;
-      float rstd = rsqrtf(hsum32(dd * dd) * (1.f / 32.f) + 1e-5f);
-      s_u[tl][o] = dd * rstd * p.ln2g[mo + o] + p.ln2b[mo + o];
-    }
-    __syncthreads();
-    TOK_LOOP(j, tl, t, ok, R) {
-#pragma unroll
-      for (int c = 0; c < 2; c++) {
-        int jj = o + 32 * c;
-        float z = p.b1[mo + jj] + dot_lds(s_w1 + jj * 33, s_u[tl], 32);
-        s_f[tl][jj] = gelu_f(z) * dr.mask(site0 + 1 + 2 * pass, (uint32_t)t * 64 + jj);
-      }
-    }
-    __syncthreads();
-    TOK_LOOP(j, tl, t, ok, R) {
-      float g = p.b2[mo + o] + dot_lds(s_w2 + o * 65, s_f[tl], 64);
-      g *= dr.mask(site0 + 2 + 2 * pass, (uint32_t)t * 32 + o);
-      if (pass == 0) {
-        hcur[j] = g + h1r[j];
-        if (ok) h2s[R * 32 + o] = hcur[j];
-      } else if (ok) {
-        F[R * d.DMF + d.DM + 32 * layer + o] = g;
-      }
-    }
-    __syncthreads();
-  }
-}
-
-// backward of K3.  Inputs: dfeat = dF[:, DM+32l .. +32], saved h1,h2,ob.  Outputs: dO (grad of attention
-// output before to_out), dh0acc (= dh1, the residual path into h0), parameter gradients.
-__global__ __launch_bounds__(256) void dense_post_bwd_kernel(TfDims d, int block, int layer, TfLayerP p, TfLayerP g,
-                                                             const float* __restrict__ h1s,
-                                                             const float* __restrict__ h2s,
-                                                             const float* __restrict__ ob, const float* __restrict__ dF,
-                                                             float* __restrict__ dO, float* __restrict__ dh0acc) {
-  __shared__ __attribute__((aligned(16))) float s_u[TB][32], s_f[TB][64], s_dz[TB][64], s_dg[TB][32];
-  __shared__ float s_red[8][32][2], s_wo[32 * 33], s_w1[64 * 33], s_w2[32 * 65];
-  const int m = blockIdx.y, BN = d.B * d.N, o = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const int64_t mo = (int64_t)m * d.mstride;
-  const Drop dr = make_drop(d);
-  const uint32_t site0 = hdf_site_id(m, block, layer, 0);
-  stage_w(s_wo, p.wout + mo, 32, 32);
-  stage_w(s_w1, p.w1 + mo, 64, 32);
-  stage_w(s_w2, p.w2 + mo, 32, 64);
-  float dcur[4];   // gradient flowing into the current ff's output (post-dropout side)
-  float dres[4];   // gradient of the residual input accumulated so far
-  float gam = 0.f, bet = 0.f;  // LN2 gamma/beta gradient partials of this thread's channel
-  TOK_LOOP(j, tl, t, ok, R) {
-    dcur[j] = sel0(ok, dF[R * d.DMF + d.DM + 32 * layer + o]);
-    dres[j] = 0.f;
-  }
-  for (int pass = 1; pass >= 0; pass--) {  // pass 1: second ff on h2 ; pass 0: first ff on h1
-    const float* hs = pass ? h2s : h1s;
-    float xh[4], rs[4], zz[4][2], mk[4][2];
-    TOK_LOOP(j, tl, t, ok, R) {
-      float h = sel0(ok, hs[R * 32 + o]);
-      float mean = hsum32(h) * (1.f / 32.f);
-      float dd = h - mean;
-      rs[j] = rsqrtf(hsum32(dd * dd) * (1.f / 32.f) + 1e-5f);
-      xh[j] = dd * rs[j];
-      s_u[tl][o] = xh[j] * p.ln2g[mo + o] + p.ln2b[mo + o];
-      s_dg[tl][o] = ok ? dcur[j] * dr.mask(site0 + 2 + 2 * pass, (uint32_t)t * 32 + o) : 0.f;
-    }
-    __syncthreads();
-    TOK_LOOP(j, tl, t, ok, R) {
-#pragma unroll
-      for (int c = 0; c < 2; c++) {
-        int jj = o + 32 * c;
-        float z = p.b1[mo + jj] + dot_lds(s_w1 + jj * 33, s_u[tl], 32);
-        float mkv = dr.mask(site0 + 1 + 2 * pass, (uint32_t)t * 64 + jj);
-        zz[j][c] = z;
-        mk[j][c] = mkv;
-        s_f[tl][jj] = ok ? gelu_f(z) * mkv : 0.f;
-        float df = dot_col_lds(s_w2, 65, jj, s_dg[tl], 32);
-        s_dz[tl][jj] = ok ? df * mkv * gelu_grad(z) : 0.f;
-      }
-    }
-    __syncthreads();
-    outer_acc(g.w2 + mo, 32, 64, &s_dg[0][0], 32, &s_f[0][0], 64);
-    col_acc(g.b2 + mo, 32, &s_dg[0][0], 32);
-    outer_acc(g.w1 + mo, 64, 32, &s_dz[0][0], 64, &s_u[0][0], 32, 2);
-    col_acc(g.b1 + mo, 64, &s_dz[0][0], 64);
-    TOK_LOOP(j, tl, t, ok, R) {
-      float du = dot_col_lds(s_w1, 33, o, s_dz[tl], 64);
-      gam += du * xh[j];
-      bet += du;
-      float dxh = du * p.ln2g[mo + o];
-      float m1 = hsum32(dxh) * (1.f / 32.f), m2 = hsum32(dxh * xh[j]) * (1.f / 32.f);
-      float dh = rs[j] * (dxh - m1 - xh[j] * m2);
-      if (pass == 1) {
-        dcur[j] = ok ? dh : 0.f;   // h2 feeds only the second ff; its gradient flows into ff#1's output
-        dres[j] = dcur[j];         // ... and into the residual h1
-      } else {
-        dres[j] += ok ? dh : 0.f;  // dh1 = dh2 + LN2-bwd path of ff#1
-      }
-    }
-    __syncthreads();
-  }
-  // LN2 gamma/beta: reduce over the 8 token groups, one atomic per channel
-  s_red[grp][o][0] = gam;
-  s_red[grp][o][1] = bet;
-  __syncthreads();
-  if (grp == 0) {
-    float a = 0.f, b = 0.f;
-    for (int k = 0; k < 8; k++) a += s_red[k][o][0], b += s_red[k][o][1];
-    atomicAdd(g.ln2g + mo + o, a);
-    atomicAdd(g.ln2b + mo + o, b);
-  }
-  // to_out: a = (Wout.ob + bout) * mask ; h1 = a + h0
-  TOK_LOOP(j, tl, t, ok, R) {
-    s_dg[tl][o] = ok ? dres[j] * dr.mask(site0 + 0, (uint32_t)t * 32 + o) : 0.f;
-    s_u[tl][o] = sel0(ok, ob[R * 32 + o]);
-    if (ok) dh0acc[R * 32 + o] = dres[j];
-  }
-  __syncthreads();
-  outer_acc(g.wout + mo, 32, 32, &s_dg[0][0], 32, &s_u[0][0], 32);
-  col_acc(g.bout + mo, 32, &s_dg[0][0], 32);
-  TOK_LOOP(j, tl, t, ok, R) {
-    float v = dot_col_lds(s_wo, 33, o, s_dg[tl], 32);
-    if (ok) dO[R * 32 + o] = v;
-  }
-}
-
-// backward of K1.  dF[:, 0:K] += W0^T dh0
-__global__ __launch_bounds__(256) void dense_pre_bwd_kernel(TfDims d, int K, TfLayerP p, TfLayerP g,
-                                                            const float* __restrict__ F, const float* __restrict__ h0,
-                                                            const float* __restrict__ dqkv,
-                                                            const float* __restrict__ dh0acc, float* __restrict__ dF) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* s_in = sm;                 // [TB][K]
-  float* s_t = s_in + TB * K;       // [TB][32]
-  float* s_dq = s_t + TB * 32;      // [TB][96]
-  float* s_dh = s_dq + TB * 96;     // [TB][32]
-  float* s_red = s_dh + TB * 32;    // [8][32][2]
-  float* s_w0 = s_red + 8 * 32 * 2; // [32][K+1]
-  float* s_wq = s_w0 + 32 * (K + 1);  // [96][33]
-  const int m = blockIdx.y, BN = d.B * d.N, o = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const int64_t mo = (int64_t)m * d.mstride;
-  float xh[4], rs[4];
-  stage_w(s_w0, p.w0 + mo, 32, K);
-  stage_w(s_wq, p.wqkv + mo, 96, 32);
-  stage_rows<true>(s_in, F + (int64_t)m * BN * d.DMF, d.DMF, K, blockIdx.x * TB, BN);
-  TOK_LOOP(j, tl, t, ok, R) {
-    float h = sel0(ok, h0[R * 32 + o]);
-    float mean = hsum32(h) * (1.f / 32.f);
-    float dd = h - mean;
-    rs[j] = rsqrtf(hsum32(dd * dd) * (1.f / 32.f) + 1e-5f);
-    xh[j] = dd * rs[j];
-    s_t[tl * 32 + o] = ok ? xh[j] * p.ln1g[mo + o] + p.ln1b[mo + o] : 0.f;
-#pragma unroll
-    for (int c = 0; c < 3; c++) s_dq[tl * 96 + o + 32 * c] = sel0(ok, dqkv[R * 96 + o + 32 * c]);
-  }
-  __syncthreads();
-  outer_acc(g.wqkv + mo, 96, 32, s_dq, 96, s_t, 32);
-  float gam = 0.f, bet = 0.f;
-  TOK_LOOP(j, tl, t, ok, R) {
-    float dt = dot_col_lds(s_wq, 33, o, s_dq + tl * 96, 96);
-    gam += dt * xh[j];
-    bet += dt;
-    float dxh = dt * p.ln1g[mo + o];
-    float m1 = hsum32(dxh) * (1.f / 32.f), m2 = hsum32(dxh * xh[j]) * (1.f / 32.f);
-    float dh = rs[j] * (dxh - m1 - xh[j] * m2) + sel0(ok, dh0acc[R * 32 + o]);
-    s_dh[tl * 32 + o] = ok ? dh : 0.f;
-  }
-  s_red[(grp * 32 + o) * 2 + 0] = gam;
-  s_red[(grp * 32 + o) * 2 + 1] = bet;
-  __syncthreads();
-  if (grp == 0) {
-    float a = 0.f, b = 0.f;
-    for (int k = 0; k < 8; k++) a += s_red[(k * 32 + o) * 2], b += s_red[(k * 32 + o) * 2 + 1];
-    atomicAdd(g.ln1g + mo + o, a);
-    atomicAdd(g.ln1b + mo + o, b);
-  }
-  outer_acc(g.w0 + mo, 32, K, s_dh, 32, s_in, K);
-  col_acc(g.b0 + mo, 32, s_dh, 32);
-  // dF[:, 0:K] += W0^T dh0, SU read-modify-writes in flight per thread (each element has one owner)
-  for (int base = threadIdx.x; base < TB * K; base += 256 * SU) {
-    float cur[SU];
-    float* q[SU];
-    bool okv[SU];
-#pragma unroll
-    for (int u = 0; u < SU; u++) {
-      const int i = min(base + 256 * u, TB * K - 1), tl = i / K, k = i - tl * K, t = blockIdx.x * TB + tl;
-      okv[u] = (base + 256 * u < TB * K) & (t < BN);
-      q[u] = dF + ((int64_t)m * BN + min(t, BN - 1)) * d.DMF + k;
-      cur[u] = *q[u];
-    }
-#pragma unroll
-    for (int u = 0; u < SU; u++) {
-      const int i = min(base + 256 * u, TB * K - 1), tl = i / K, k = i - tl * K;
-      const float v = dot_col_lds(s_w0, K + 1, k, s_dh + tl * 32, 32);
-      if (okv[u]) *q[u] = cur[u] + v;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------ K4: block out_layer
-template <typename T>
-__global__ __launch_bounds__(256) void block_out_fwd_kernel(TfDims d, int block, TfOutP p, const float* __restrict__ F,
-                                                            float* __restrict__ next_F, T* __restrict__ attnall,
-                                                            int stage_wb) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int K = d.DMF;
-  float* s_in = sm;                    // [TB][K]
-  float* s_f = s_in + TB * K;          // [TB][64]
-  float* s_wa = s_f + TB * 64;         // [64][K+1]
-  float* s_wb = s_wa + 64 * (K + 1);   // [DM][65] (only if it fits)
-  const int m = blockIdx.y, BN = d.B * d.N, o = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const int64_t mo = (int64_t)m * d.mstride;
-  const Drop dr = make_drop(d);
-  const uint32_t site0 = hdf_site_id(m, block, 4, 0);
-  stage_rows<false>(s_in, F + (int64_t)m * BN * d.DMF, d.DMF, K, blockIdx.x * TB, BN);
-  stage_w(s_wa, p.wa + mo, 64, K);
-  if (stage_wb) stage_w(s_wb, p.wb + mo, d.DM, 64);
-  __syncthreads();
-#pragma unroll
-  for (int c = 0; c < 2; c++) {
-    int jj = o + 32 * c;
-    float zacc[4] = {0.f, 0.f, 0.f, 0.f};
-    dot_lds_multi<TJ>(s_wa + jj * (K + 1), s_in, K, grp, K, zacc);
-    TOK_LOOP(j, tl, t, ok, R) {
-      float z = p.ba[mo + jj] + zacc[j];
-      s_f[tl * 64 + jj] = gelu_f(z) * dr.mask(site0 + 0, (uint32_t)t * 64 + jj);
-    }
-  }
-  __syncthreads();
-  for (int c = o; c < d.DM; c += 32) {
-    float vacc[4] = {0.f, 0.f, 0.f, 0.f};
-    if (stage_wb) {
-      dot_lds_multi<TJ>(s_wb + c * 65, s_f, 64, grp, 64, vacc);
-    } else {
-      TOK_LOOP(j, tl, t, ok, R) { vacc[j] = dot_row(p.wb + mo + c * 64, s_f + tl * 64, 64); }
-    }
-    TOK_LOOP(j, tl, t, ok, R) {
-      float v = (p.bb[mo + c] + vacc[j]) * dr.mask(site0 + 1, (uint32_t)t * d.DM + c);
-      if (ok) {
-        if (next_F)
-          next_F[R * d.DMF + c] = v;
-        else {
-          int b = t / d.N, n = t - b * d.N;
-          ST<T>::st(attnall + ((int64_t)b * d.N + n) * ((int64_t)d.M * d.DM) + (int64_t)m * d.DM + c, v);
-        }
-      }
-    }
-  }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void block_out_bwd_kernel(TfDims d, int block, TfOutP p, TfOutP g,
-                                                            const float* __restrict__ F,
-                                                            const float* __restrict__ dF_next,
-                                                            const T* __restrict__ d_attnall, float* __restrict__ dF,
-                                                            int stage_wb) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int K = d.DMF, DM = d.DM;
-  float* s_in = sm;                // [TB][K]
-  float* s_f = s_in + TB * K;      // [TB][64]
-  float* s_dz = s_f + TB * 64;     // [TB][64]
-  float* s_do = s_dz + TB * 64;    // [TB][DM]
-  float* s_wa = s_do + TB * DM;    // [64][K+1]
-  float* s_wb = s_wa + 64 * (K + 1);  // [DM][65] (only if it fits)
-  const int m = blockIdx.y, BN = d.B * d.N, o = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const int64_t mo = (int64_t)m * d.mstride;
-  const Drop dr = make_drop(d);
-  const uint32_t site0 = hdf_site_id(m, block, 4, 0);
-  stage_rows<true>(s_in, F + (int64_t)m * BN * d.DMF, d.DMF, K, blockIdx.x * TB, BN);
-  // upstream gradient rows (next block's dF, or the attnall gradient in the conv dtype), SU loads in flight
-  auto stage_do = [&](auto load) __attribute__((always_inline)) {
-    for (int base = threadIdx.x; base < TB * DM; base += 256 * SU) {
-      float v[SU];
-#pragma unroll
-      for (int u = 0; u < SU; u++) {
-        const int i = min(base + 256 * u, TB * DM - 1), tl = i / DM, c = i - tl * DM;
-        v[u] = load(min(blockIdx.x * TB + tl, BN - 1), c);
-      }
-#pragma unroll
-      for (int u = 0; u < SU; u++) {
-        const int i = base + 256 * u;
-        if (i < TB * DM) {
-          const int tl = i / DM, c = i - tl * DM, t = blockIdx.x * TB + tl;
-          s_do[i] = t < BN ? v[u] * dr.mask(site0 + 1, (uint32_t)t * DM + c) : 0.f;
-        }
-      }
-    }
-  };
-  if (dF_next)
-    stage_do([&](int t, int c) { return dF_next[((int64_t)m * BN + t) * d.DMF + c]; });
-  else
-    stage_do([&](int t, int c) {
-      const int b = t / d.N, n = t - b * d.N;
-      return ST<T>::ld(d_attnall + ((int64_t)b * d.N + n) * ((int64_t)d.M * DM) + (int64_t)m * DM + c);
-    });
-  if (stage_wb) stage_w(s_wb, p.wb + mo, DM, 64);
-  stage_w(s_wa, p.wa + mo, 64, K);
-  __syncthreads();
-#pragma unroll
-  for (int c = 0; c < 2; c++) {
-    int jj = o + 32 * c;
-    float zacc[4] = {0.f, 0.f, 0.f, 0.f};
-    dot_lds_multi<TJ>(s_wa + jj * (K + 1), s_in, K, grp, K, zacc);
-    TOK_LOOP(j, tl, t, ok, R) {
-      float z = p.ba[mo + jj] + zacc[j];
-      float mk = dr.mask(site0 + 0, (uint32_t)t * 64 + jj);
-      s_f[tl * 64 + jj] = ok ? gelu_f(z) * mk : 0.f;
-      float df = stage_wb ? dot_col_lds(s_wb, 65, jj, s_do + tl * DM, DM)
-                          : dot_col(p.wb + mo, 64, jj, s_do + tl * DM, DM);  // lanes = consecutive columns: coalesced
-      s_dz[tl * 64 + jj] = ok ? df * mk * gelu_grad(z) : 0.f;
-    }
-  }
-  __syncthreads();
-  outer_acc(g.wb + mo, DM, 64, s_do, DM, s_f, 64);
-  col_acc(g.bb + mo, DM, s_do, DM);
-  outer_acc(g.wa + mo, 64, K, s_dz, 64, s_in, K);
-  col_acc(g.ba + mo, 64, s_dz, 64);
-  for (int i = threadIdx.x; i < TB * K; i += 256) {
-    int tl = i / K, k = i - tl * K, t = blockIdx.x * TB + tl;
-    if (t < BN) dF[((int64_t)m * BN + t) * d.DMF + k] = dot_col_lds(s_wa, K + 1, k, s_dz + tl * 64, 64);
-  }
-}
-
 // ------------------------------------------------------------------------------ patch embedding (MFMA f32)
-// tokens[32] x DM tile per workgroup, K = 4096 in chunks of 64 (4 rows of 16 voxels of the 16^3 brick)
-__global__ __launch_bounds__(256) void patch_embed_fwd_kernel(TfDims d, const float* __restrict__ x, int D, int H,
-                                                              int W, const float* __restrict__ wpe,
-                                                              const float* __restrict__ bpe,
-                                                              const float* __restrict__ pos, float* __restrict__ F) {
-  extern __shared__ float sm[];
-  constexpr int KC = 64, LD = KC + 1;
-  float* sA = sm;             // [32][LD]
-  float* sB = sm + 32 * LD;   // [DM][LD]
-  const int m = blockIdx.y, BN = d.B * d.N, DM = d.DM;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
-  const int gh = H / 16, gw = W / 16;
-  const float* wm = wpe + (int64_t)m * d.mstride;
-  f32x16 acc[2];
-#pragma unroll
-  for (int a = 0; a < 2; a++)
-#pragma unroll
-    for (int i = 0; i < 16; i++) acc[a][i] = 0.f;
-  // Software pipeline over the 64 chunks: the global loads of chunk k+1 are issued right after chunk k's tile is
-  // in LDS and stay in flight under its 32 MFMAs per wave (the single-buffered loop exposed one HBM round trip per
-  // chunk: 170 us for 4 GFLOP).  Tokens beyond BN are clamped to the last token: their outputs are never stored.
-  float4 ra[2], rb[8];
-  const int nbq = DM * KC / 4;  // float4 chunks of the B tile
-  const float* xtok[2];         // this thread's two tokens: first voxel of their 16^3 bricks (loop invariant)
-#pragma unroll
-  for (int u = 0; u < 2; u++) {
-    const int tl = ((threadIdx.x + 256 * u) * 4) >> 6, t = min(blockIdx.x * 32 + tl, BN - 1);
-    const int b = t / d.N, n = t - b * d.N;
-    const int gz = n / (gh * gw), gy = (n / gw) % gh, gx = n % gw;
-    xtok[u] = x + ((((int64_t)b * d.M + m) * D + gz * 16) * H + gy * 16) * W + gx * 16;
-  }
-  auto load_chunk_regs = [&](int kc) __attribute__((always_inline)) {
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
-      const int kk = ((threadIdx.x + 256 * u) * 4) & 63;  // element index in the [32][64] A chunk
-      const int k = kc + kk, dz = k >> 8, dy = (k >> 4) & 15, dx = k & 15;
-      ra[u] = *reinterpret_cast<const float4*>(xtok[u] + ((int64_t)dz * H + dy) * W + dx);
-    }
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      int q = min((int)threadIdx.x + 256 * u, nbq - 1), i = q * 4;
-      int c = i >> 6, kk = i & 63;
-      rb[u] = *reinterpret_cast<const float4*>(wm + (int64_t)c * 4096 + kc + kk);
-    }
-  };
-  load_chunk_regs(0);
-  for (int kc = 0; kc < 4096; kc += KC) {
-    __syncthreads();  // the previous chunk's MFMAs are done with the tile
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
-      int i = (threadIdx.x + 256 * u) * 4, tl = i >> 6, kk = i & 63;
-      float* dst = sA + tl * LD + kk;
-      dst[0] = ra[u].x, dst[1] = ra[u].y, dst[2] = ra[u].z, dst[3] = ra[u].w;
-    }
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      int q = threadIdx.x + 256 * u;
-      if (q < nbq) {
-        int i = q * 4, c = i >> 6, kk = i & 63;
-        float* dst = sB + c * LD + kk;
-        dst[0] = rb[u].x, dst[1] = rb[u].y, dst[2] = rb[u].z, dst[3] = rb[u].w;
-      }
-    }
-    for (int base = 2048; base < nbq; base += 2048) {  // token dims > 128: remaining rows of the weight tile
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        int q = min(base + (int)threadIdx.x + 256 * u, nbq - 1), i = q * 4;
-        rb[u] = *reinterpret_cast<const float4*>(wm + (int64_t)(i >> 6) * 4096 + kc + (i & 63));
-      }
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        int q = base + threadIdx.x + 256 * u;
-        if (q < nbq) {
-          int i = q * 4;
-          float* dst = sB + (i >> 6) * LD + (i & 63);
-          dst[0] = rb[u].x, dst[1] = rb[u].y, dst[2] = rb[u].z, dst[3] = rb[u].w;
-        }
-      }
-    }
-    __syncthreads();
-    if (kc + KC < 4096) load_chunk_regs(kc + KC);
-#pragma unroll
-    for (int a = 0; a < 2; a++) {
-      int nb = wave + 4 * a;
-      if (nb * 32 < DM) {
-        for (int k2 = 0; k2 < KC / 2; k2++) {
-          float av = sA[r * LD + 2 * k2 + h];
-          float bv = sB[(nb * 32 + r) * LD + 2 * k2 + h];
-          acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a], 0, 0, 0);
-        }
-      }
-    }
-  }
-  const Drop dr = make_drop(d);
-  const uint32_t site = hdf_site_id(m, 63, 7, 7);
-#pragma unroll
-  for (int a = 0; a < 2; a++) {
-    int nb = wave + 4 * a;
-    if (nb * 32 < DM) {
-      int c = nb * 32 + r;
-#pragma unroll
-      for (int i = 0; i < 16; i++) {
-        int tl = (i & 3) + 8 * (i >> 2) + 4 * h, t = blockIdx.x * 32 + tl;
-        if (t < BN) {
-          int n = t % d.N;
-          float v = acc[a][i] + bpe[(int64_t)m * d.mstride + c] + pos[(int64_t)m * d.mstride + (int64_t)n * DM + c];
-          v *= dr.mask(site, (uint32_t)t * DM + c);
-          F[((int64_t)m * BN + t) * d.DMF + c] = v;
-        }
-      }
-    }
-  }
-}
-
-// Round-2 form: operands straight from global memory, no barrier in the main loop.  A workgroup owns 32 tokens x 64
-// columns (grid = token tiles x DM/64 x modalities: 256 workgroups at the benchmark size; the LDS-staged kernel above
+// Operands straight from global memory, no barrier in the main loop.  A workgroup owns 32 tokens x 64
+// columns (grid = token tiles x DM/64 x modalities: 256 workgroups at the benchmark size; round 1's LDS-staged kernel
 // had 128 and re-staged the whole 2 MB weight matrix of a modality in each).  The four waves SPLIT K: wave w contracts
 // the 64-deep chunks c = w (mod 4) for the whole 32 x 64 tile (2 x 4 tiles of v_mfma_f32_16x16x4_f32), so no operand is
 // loaded twice inside a workgroup (giving each wave 16 of the columns instead loaded the token rows four times and
@@ -1181,18 +514,10 @@ int allow_lds(Kern kern, size_t bytes) {
 
 int tf_patch_embed_fwd(const TfDims& d, const float* x, int D, int H, int W, const float* wpe, const float* bpe,
                        const float* pos, float* F, hipStream_t st) {
-  HDF_CHECK_ARG(d.DM <= 256 && d.DM % 32 == 0, "patch_embed: token dim %d unsupported", d.DM);
-  static const bool pe_old = getenv("HDF_PE_OLD") != nullptr;  // A/B knob: the LDS-staged 32-token kernel
-  if (d.DM % 64 == 0 && !pe_old) {
-    hipLaunchKernelGGL(patch_embed_fwd2_kernel, dim3(ceil_div(d.B * d.N, 32), d.DM / 64, d.M), dim3(256), 0, st, d, x, D,
-                       H, W, wpe, bpe, pos, F);
-    HDF_LAUNCH_CHECK();
-    return HDF_OK;
-  }
-  size_t shm = (size_t)(32 + d.DM) * 65 * sizeof(float);
-  HDF_TRY(allow_lds(patch_embed_fwd_kernel, shm));
-  hipLaunchKernelGGL(patch_embed_fwd_kernel, dim3(ceil_div(d.B * d.N, 32), d.M), dim3(256), shm, st, d, x, D, H, W, wpe,
-                     bpe, pos, F);
+  // token dim = 4 * n_filters with n_filters % 16 == 0 (plan): a multiple of 64
+  HDF_CHECK_ARG(d.DM <= 256 && d.DM % 64 == 0, "patch_embed: token dim %d unsupported (a multiple of 64, <= 256)", d.DM);
+  hipLaunchKernelGGL(patch_embed_fwd2_kernel, dim3(ceil_div(d.B * d.N, 32), d.DM / 64, d.M), dim3(256), 0, st, d, x, D,
+                     H, W, wpe, bpe, pos, F);
   HDF_LAUNCH_CHECK();
   return HDF_OK;
 }
@@ -1229,103 +554,47 @@ int tf_attention_bwd(int N, int nseq, const float* qkv, const float* ob, const f
   return HDF_OK;
 }
 
-bool tf_use_fused() {
-  static const bool old = getenv("HDF_TF_OLD") != nullptr;  // A/B knob: the round-1 VALU token kernels
-  return !old;
-}
-
 int tf_layer_fwd(const TfDims& d, int block, int layer, const TfLayerP& p, float* F, const TfLayerSave& s,
                  hipStream_t st) {
-  if (tf_use_fused()) {  // one dense layer on its own: PRE, attention, POST as three launches of the fused kernels
-    TfTokenFwd pre;
-    pre.pre = &p, pre.pre_save = s, pre.bq = block, pre.lq = layer, pre.F_pre = F;
-    HDF_TRY(tf_token_fwd(d, pre, HDF_F32, st));
-    HDF_TRY(tf_attention_fwd(d.N, d.M * d.B, s.qkv, s.ob, s.lse, st));
-    TfTokenFwd post;
-    post.post = &p, post.post_save = s, post.bp = block, post.lp = layer, post.F_post = F;
-    return tf_token_fwd(d, post, HDF_F32, st);
-  }
-  const int K = d.DM + 32 * layer, BN = d.B * d.N;
-  dim3 grid(ceil_div(BN, FWD_TB), d.M);
-  size_t shm = (size_t)(FWD_TB * K + FWD_TB * 32 + 32 * (K + 1) + 96 * 33) * sizeof(float);
-  HDF_TRY(allow_lds(dense_pre_fwd_kernel, shm));
-  hipLaunchKernelGGL(dense_pre_fwd_kernel, grid, dim3(256), shm, st, d, K, p, F, s.h0, s.qkv);
-  HDF_LAUNCH_CHECK();
+  // one dense layer on its own (operator-level ABI): PRE, attention, POST as three launches of the fused token kernels
+  TfTokenFwd pre;
+  pre.pre = &p, pre.pre_save = s, pre.bq = block, pre.lq = layer, pre.F_pre = F;
+  HDF_TRY(tf_token_fwd(d, pre, HDF_F32, st));
   HDF_TRY(tf_attention_fwd(d.N, d.M * d.B, s.qkv, s.ob, s.lse, st));
-  hipLaunchKernelGGL(dense_post_fwd_kernel, grid, dim3(256), 0, st, d, block, layer, p, s.h0, s.ob, s.h1, s.h2, F);
-  HDF_LAUNCH_CHECK();
-  return HDF_OK;
+  TfTokenFwd post;
+  post.post = &p, post.post_save = s, post.bp = block, post.lp = layer, post.F_post = F;
+  return tf_token_fwd(d, post, HDF_F32, st);
 }
 
 int tf_layer_bwd(const TfDims& d, int block, int layer, const TfLayerP& p, const TfLayerP& g, const float* F, float* dF,
                  const TfLayerSave& s, float* scratch, hipStream_t st) {
-  const int K = d.DM + 32 * layer, BN = d.B * d.N;
+  const int BN = d.B * d.N;
   const int64_t rows = (int64_t)d.M * BN;
   float* dO = scratch;
   float* dh0acc = scratch + rows * 32;
   float* dqkv = scratch + rows * 64;
-  if (tf_use_fused()) {  // one dense layer on its own: POSTB, attention backward, PREB
-    TfTokenBwd post;
-    post.dF = dF, post.post = &p, post.post_grad = &g, post.post_save = s, post.bp = block, post.lp = layer;
-    post.dO = dO, post.dh0acc_out = dh0acc;
-    HDF_TRY(tf_token_bwd(d, post, HDF_F32, st));
-    HDF_TRY(tf_attention_bwd(d.N, d.M * d.B, s.qkv, s.ob, s.lse, dO, dqkv, st));
-    TfTokenBwd pre;
-    pre.dF = dF, pre.pre = &p, pre.pre_grad = &g, pre.pre_save = s, pre.bq = block, pre.lq = layer, pre.F_pre = F;
-    pre.dqkv = dqkv, pre.dh0acc = dh0acc;
-    return tf_token_bwd(d, pre, HDF_F32, st);
-  }
-  dim3 grid(ceil_div(BN, TB), d.M);
-  hipLaunchKernelGGL(dense_post_bwd_kernel, grid, dim3(256), 0, st, d, block, layer, p, g, s.h1, s.h2, s.ob, dF, dO,
-                     dh0acc);
-  HDF_LAUNCH_CHECK();
+  // one dense layer on its own: POSTB, attention backward, PREB
+  TfTokenBwd post;
+  post.dF = dF, post.post = &p, post.post_grad = &g, post.post_save = s, post.bp = block, post.lp = layer;
+  post.dO = dO, post.dh0acc_out = dh0acc;
+  HDF_TRY(tf_token_bwd(d, post, HDF_F32, st));
   HDF_TRY(tf_attention_bwd(d.N, d.M * d.B, s.qkv, s.ob, s.lse, dO, dqkv, st));
-  size_t shm = (size_t)(TB * K + TB * 32 + TB * 96 + TB * 32 + 8 * 32 * 2 + 32 * (K + 1) + 96 * 33) * sizeof(float);
-  HDF_TRY(allow_lds(dense_pre_bwd_kernel, shm));
-  hipLaunchKernelGGL(dense_pre_bwd_kernel, grid, dim3(256), shm, st, d, K, p, g, F, s.h0, dqkv, dh0acc, dF);
-  HDF_LAUNCH_CHECK();
-  return HDF_OK;
+  TfTokenBwd pre;
+  pre.dF = dF, pre.pre = &p, pre.pre_grad = &g, pre.pre_save = s, pre.bq = block, pre.lq = layer, pre.F_pre = F;
+  pre.dqkv = dqkv, pre.dh0acc = dh0acc;
+  return tf_token_bwd(d, pre, HDF_F32, st);
 }
 
 int tf_block_out_fwd(const TfDims& d, int block, const TfOutP& p, const float* F, float* next_F, void* attnall,
                      int dtype, hipStream_t st) {
-  if (tf_use_fused()) {
-    TfTokenFwd o;
-    o.out = &p, o.bp = block, o.F_post = const_cast<float*>(F), o.next_F = next_F, o.attnall = attnall;
-    return tf_token_fwd(d, o, dtype, st);
-  }
-  dim3 grid(ceil_div(d.B * d.N, TB), d.M);
-  size_t base = (size_t)(TB * d.DMF + TB * 64 + 64 * (d.DMF + 1)) * sizeof(float);
-  size_t with_wb = base + (size_t)d.DM * 65 * sizeof(float);
-  const int stage_wb = with_wb <= LDS_LIMIT ? 1 : 0;
-  size_t shm = stage_wb ? with_wb : base;
-  HDF_CHECK_ARG(shm <= LDS_LIMIT, "block_out: token dim %d needs %zu B of LDS", d.DM, shm);
-  HDF_DISPATCH_T(dtype, {
-    HDF_TRY(allow_lds(block_out_fwd_kernel<T>, shm));
-    hipLaunchKernelGGL(block_out_fwd_kernel<T>, grid, dim3(256), shm, st, d, block, p, F, next_F, (T*)attnall, stage_wb);
-  });
-  HDF_LAUNCH_CHECK();
-  return HDF_OK;
+  TfTokenFwd o;
+  o.out = &p, o.bp = block, o.F_post = const_cast<float*>(F), o.next_F = next_F, o.attnall = attnall;
+  return tf_token_fwd(d, o, dtype, st);
 }
 
 int tf_block_out_bwd(const TfDims& d, int block, const TfOutP& p, const TfOutP& g, const float* F,
                      const float* dF_next, const void* d_attnall, int dtype, float* dF, hipStream_t st) {
-  if (tf_use_fused()) {
-    TfTokenBwd o;
-    o.dF = dF, o.out = &p, o.out_grad = &g, o.bo = block, o.F_out = F, o.dF_next = dF_next, o.d_attnall = d_attnall;
-    return tf_token_bwd(d, o, dtype, st);
-  }
-  dim3 grid(ceil_div(d.B * d.N, TB), d.M);
-  size_t base = (size_t)(TB * d.DMF + TB * 64 * 2 + TB * d.DM + 64 * (d.DMF + 1)) * sizeof(float);
-  size_t with_wb = base + (size_t)d.DM * 65 * sizeof(float);
-  const int stage_wb = with_wb <= LDS_LIMIT ? 1 : 0;
-  size_t shm = stage_wb ? with_wb : base;
-  HDF_CHECK_ARG(shm <= LDS_LIMIT, "block_out_bwd: token dim %d needs %zu B of LDS", d.DM, shm);
-  HDF_DISPATCH_T(dtype, {
-    HDF_TRY(allow_lds(block_out_bwd_kernel<T>, shm));
-    hipLaunchKernelGGL(block_out_bwd_kernel<T>, grid, dim3(256), shm, st, d, block, p, g, F, dF_next,
-                       (const T*)d_attnall, dF, stage_wb);
-  });
-  HDF_LAUNCH_CHECK();
-  return HDF_OK;
+  TfTokenBwd o;
+  o.dF = dF, o.out = &p, o.out_grad = &g, o.bo = block, o.F_out = F, o.dF_next = dF_next, o.d_attnall = d_attnall;
+  return tf_token_bwd(d, o, dtype, st);
 }

@@ -20,9 +20,8 @@ int hdf_launch_norm_relu_add(int dtype, const void* y, int64_t y_pitch, const fl
 // is trilinear_x2(relu(skip_lo*lscale+lshift)) computed on the fly from the low-resolution tensor `skip`
 // (dims Do,Ho,Wo); else `skip` is a materialised full-resolution tensor.
 int hdf_launch_enc_tail(int dtype, const void* y, int64_t y_pitch, const float* scale, const float* shift,
-                        const void* skip, int64_t skip_pitch, const float* lscale, const float* lshift, void* ds,
-                        int64_t ds_pitch, void* pooled, int64_t pooled_pitch, uint8_t* idx, int N, int C, int Do,
-                        int Ho, int Wo, hipStream_t st);
+                        const void* skip, int64_t skip_pitch, void* ds, int64_t ds_pitch, void* pooled,
+                        int64_t pooled_pitch, uint8_t* idx, int N, int C, int Do, int Ho, int Wo, hipStream_t st);
 int hdf_launch_maxpool_fwd(int dtype, const void* in, int64_t in_pitch, void* out, int64_t out_pitch, uint8_t* idx,
                            int N, int C, int Do, int Ho, int Wo, hipStream_t st);
 // din[8 positions] (+)= (pos == idx) ? dout : 0

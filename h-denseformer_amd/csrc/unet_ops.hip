@@ -216,15 +216,14 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dout, int64_t dout_pitc
 // ------------------------------------------------------------------------------ fused encoder tail
 // ds = relu(y*s+t) + skip ;  pooled, idx = MaxPool3d(2)(ds)        (HDenseFormer.py:237-243)
 // One thread owns a 2x2x2 block of ds voxels (one pooled voxel) x one 16-byte channel chunk, so ds is written
-// once and never re-read for pooling.  UPS: the skip is the trilinear x2 up-sampling of relu(ylo*ls+lt)
-// (UpConv, :162-175) evaluated on the fly from the 3x3x3 low-resolution neighbourhood (separable, plane by
-// plane) -- the full-resolution transformer feature at3 is never materialised.
-template <typename T, bool UPS>
+// once and never re-read for pooling.  (Round 1 also evaluated the trilinear x2 of up3's output inside this kernel so
+// that at3 was never materialised; with the 27-loads-per-8-outputs upsample kernel reading the materialised tensor is
+// 0.09 ms per step faster, and that variant -- VALU-bound with register spills -- was removed in round 3.)
+template <typename T>
 __global__ __launch_bounds__(256, 2) void enc_tail_kernel(const T* __restrict__ y, int64_t y_pitch,
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift, const T* __restrict__ skip,
-                                                          int64_t skip_pitch, const float* __restrict__ lscale,
-                                                          const float* __restrict__ lshift, T* __restrict__ ds,
+                                                          int64_t skip_pitch, T* __restrict__ ds,
                                                           int64_t ds_pitch, T* __restrict__ pooled,
                                                           int64_t pooled_pitch, uint8_t* __restrict__ idx, int N, int C,
                                                           int Do, int Ho, int Wo) {
@@ -277,77 +276,13 @@ __global__ __launch_bounds__(256, 2) void enc_tail_kernel(const T* __restrict__ 
         }
       }
     };
-    if constexpr (UPS) {
-      // skip = trilinear x2 of relu(ylo*ls+lt): low-resolution z planes a = 0,1,2 are interpolated in y and x
-      // (P[dy][dx]) one at a time; output plane dz = 0 is .25 P0 + .75 P1 and is finished before P2 is loaded,
-      // dz = 1 is .75 P1 + .25 P2 -- at most two planes and one plane of loads are live (2 waves per SIMD)
-      float ls[EPC], lt[EPC];
 #pragma unroll
-      for (int e = 0; e < EPC; e++) {
-        ls[e] = lscale[(int64_t)n * C + c0 + e];
-        lt[e] = lshift[(int64_t)n * C + c0 + e];
-      }
-      const int xs[3] = {max(ow - 1, 0), ow, min(ow + 1, Wo - 1)};
-      const int ys[3] = {max(oh - 1, 0), oh, min(oh + 1, Ho - 1)};
-      const int zs[3] = {max(od - 1, 0), od, min(od + 1, Do - 1)};
-      // one 64-bit sample base + 32-bit element offsets (a sample fits 2^31 elements: launcher check)
-      const T* const lbase = skip + (int64_t)n * Do * Ho * Wo * skip_pitch + c0;
-      const int lp = (int)skip_pitch;
-      int zo[3], yo[3], xo[3];
-#pragma unroll
-      for (int q = 0; q < 3; q++) {
-        zo[q] = zs[q] * Ho * Wo * lp;
-        yo[q] = ys[q] * Wo * lp;
-        xo[q] = xs[q] * lp;
-      }
-      auto plane_yx = [&](int a, float (&P)[4][EPC]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-#pragma unroll
-          for (int e = 0; e < EPC; e++) P[q][e] = 0.f;
-#pragma unroll
-        for (int b = 0; b < 3; b++) {  // low-resolution y row
-          float L[3][EPC];
-#pragma unroll
-          for (int c = 0; c < 3; c++) {
-            float f[EPC];
-            load_chunk<T>(lbase + (zo[a] + yo[b] + xo[c]), f);
-#pragma unroll
-            for (int e = 0; e < EPC; e++) L[c][e] = fmaxf(f[e] * ls[e] + lt[e], 0.f);
-          }
-          const float wy0 = (b == 0) ? 0.25f : (b == 1 ? 0.75f : 0.f);  // weight of row b for dy = 0
-          const float wy1 = (b == 0) ? 0.f : (b == 1 ? 0.75f : 0.25f);   // ... for dy = 1
-#pragma unroll
-          for (int e = 0; e < EPC; e++) {
-            const float x0 = 0.25f * L[0][e] + 0.75f * L[1][e], x1 = 0.75f * L[1][e] + 0.25f * L[2][e];
-            P[0][e] += wy0 * x0, P[1][e] += wy0 * x1;
-            P[2][e] += wy1 * x0, P[3][e] += wy1 * x1;
-          }
-        }
-      };
-      float P0[4][EPC], P1[4][EPC], sk[4][EPC];
-      plane_yx(0, P0);
-      plane_yx(1, P1);
+    for (int dz = 0; dz < 2; dz++) {
+      float sk[4][EPC];
 #pragma unroll
       for (int q = 0; q < 4; q++)
-#pragma unroll
-        for (int e = 0; e < EPC; e++) sk[q][e] = 0.25f * P0[q][e] + 0.75f * P1[q][e];
-      finish_plane(0, sk);
-      plane_yx(2, P0);
-#pragma unroll
-      for (int q = 0; q < 4; q++)
-#pragma unroll
-        for (int e = 0; e < EPC; e++) sk[q][e] = 0.75f * P1[q][e] + 0.25f * P0[q][e];
-      finish_plane(1, sk);
-    } else {
-#pragma unroll
-      for (int dz = 0; dz < 2; dz++) {
-        float sk[4][EPC];
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-          load_chunk<T>(skip + (row0 + ((int64_t)dz * Hi + (q >> 1)) * Wi + (q & 1)) * skip_pitch + c0, sk[q]);
-        finish_plane(dz, sk);
-      }
+        load_chunk<T>(skip + (row0 + ((int64_t)dz * Hi + (q >> 1)) * Wi + (q & 1)) * skip_pitch + c0, sk[q]);
+      finish_plane(dz, sk);
     }
     store_chunk<T>(pooled + row * pooled_pitch + c0, best);
     if constexpr (EPC == 8) {
@@ -1056,24 +991,13 @@ int hdf_launch_norm_relu_add(int dtype, const void* y, int64_t y_pitch, const fl
 }
 
 int hdf_launch_enc_tail(int dtype, const void* y, int64_t y_pitch, const float* scale, const float* shift,
-                        const void* skip, int64_t skip_pitch, const float* lscale, const float* lshift, void* ds,
-                        int64_t ds_pitch, void* pooled, int64_t pooled_pitch, uint8_t* idx, int N, int C, int Do,
-                        int Ho, int Wo, hipStream_t st) {
+                        const void* skip, int64_t skip_pitch, void* ds, int64_t ds_pitch, void* pooled,
+                        int64_t pooled_pitch, uint8_t* idx, int N, int C, int Do, int Ho, int Wo, hipStream_t st) {
   HDF_CHECK_ARG(C % 16 == 0, "enc_tail: C=%d", C);
-  const bool ups = lscale != nullptr;
-  HDF_CHECK_ARG(!ups || (int64_t)Do * Ho * Wo * skip_pitch < ((int64_t)1 << 31),
-                "enc_tail: a low-resolution sample of %dx%dx%d voxels x pitch %lld exceeds 32-bit element offsets", Do,
-                Ho, Wo, (long long)skip_pitch);
   DISPATCH_T(dtype, {
     unsigned g = grid_for((int64_t)N * Do * Ho * Wo * (C / ST<T>::EPC));
-    if (ups)
-      hipLaunchKernelGGL((enc_tail_kernel<T, true>), dim3(g), dim3(256), 0, st, (const T*)y, y_pitch, scale, shift,
-                         (const T*)skip, skip_pitch, lscale, lshift, (T*)ds, ds_pitch, (T*)pooled, pooled_pitch, idx,
-                         N, C, Do, Ho, Wo);
-    else
-      hipLaunchKernelGGL((enc_tail_kernel<T, false>), dim3(g), dim3(256), 0, st, (const T*)y, y_pitch, scale, shift,
-                         (const T*)skip, skip_pitch, lscale, lshift, (T*)ds, ds_pitch, (T*)pooled, pooled_pitch, idx,
-                         N, C, Do, Ho, Wo);
+    hipLaunchKernelGGL((enc_tail_kernel<T>), dim3(g), dim3(256), 0, st, (const T*)y, y_pitch, scale, shift,
+                       (const T*)skip, skip_pitch, (T*)ds, ds_pitch, (T*)pooled, pooled_pitch, idx, N, C, Do, Ho, Wo);
   });
   HDF_LAUNCH_CHECK();
   return HDF_OK;

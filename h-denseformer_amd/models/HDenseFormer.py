@@ -147,6 +147,16 @@ class HDenseFormer(nn.Module):
         self._plans, self._runtimes = {}, {}
         self.grad_hook = None            # callable(stage:int) used by hdf_rt.parallel for comm/compute overlap
 
+    def _replicate_for_data_parallel(self):
+        """nn.DataParallel(net) with more than one device (trainer.py:228-229) replicates the module per step inside
+        one process; this build is one process per GPU (the flat parameter buffer, the plan's workspace and its
+        streams belong to one device).  With a single device DataParallel never replicates and just calls forward."""
+        raise _lib.HdfError(
+            "nn.DataParallel over several GPUs is not supported by the MI355X build: launch one process per GPU "
+            "(python -m torch.distributed.run --nproc-per-node N ...), init_process_group('nccl') and attach "
+            "hdf_rt.parallel.GradSync(net) as net.grad_hook (INTEGRATION.md section 4); "
+            "DataParallel(net, device_ids=[one device]) works")
+
     # -------------------------------------------------------------- flat parameter management
     def _plan(self, dtype):
         if dtype not in self._plans:

@@ -112,6 +112,21 @@ def test_product_path_fails_loudly_without_gpu():
         DeepSuperloss(criterion=CEPlusDice(weight=None, ignore_index=0, p=2))([torch.zeros(1)], torch.zeros(1))
 
 
+def test_multi_device_dataparallel_is_refused_with_a_pointer_to_the_process_per_gpu_path():
+    """trainer.py:228-229 wraps the net in nn.DataParallel when DEVICE lists several GPUs: replication (what
+    torch.nn.parallel.replicate calls on every module) must fail loudly and say what to do instead; a wrapper around a
+    single device never replicates."""
+    from hdf_rt import _lib
+    from models.HDenseFormer import HDenseFormer_16
+    net = HDenseFormer_16(in_channels=2, n_cls=3, image_size=(32, 32, 32), transformer_depth=8)
+    with pytest.raises(_lib.HdfError, match="one process per GPU"):
+        net._replicate_for_data_parallel()
+    wrapped = torch.nn.DataParallel(net)            # no GPU here: device_ids == [] -> plain module call
+    assert wrapped.module is net
+    with pytest.raises(_lib.HdfError, match="GPU tensor"):
+        wrapped(torch.zeros(1, 2, 32, 32, 32))
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "h-denseformer_amd")
     for dp, _dn, fn in os.walk(pkg):

@@ -75,8 +75,21 @@ if os.environ.get("WS_STAMPS") and a.op == "conv":
     names = ["commit", "barrier1", "prefetch-issue", "mfma-loop", "barriers2+3", "epi:stage+stats", "epi:barrier+stores", "loop-top"]
     if not os.environ.get("HDF_WS_OLD"):
         names = ["xf-read", "mfma-phase", "barrier", "pass/tile-top", "epilogue", "-", "-", "-"]
-    tot = t.sum(1).mean().item()
-    print("  per-WG cycles (mean over WGs):", {n: int(v) for n, v in zip(names, t.mean(0).tolist())}, "total", int(tot))
+    tot = t[:, :5].sum(1).mean().item()
+    print("  per-WG cycles (mean over WGs):", {n: int(v) for n, v in zip(names[:5], t[:, :5].mean(0).tolist())}, "total", int(tot))
+    if not os.environ.get("HDF_WS_OLD"):
+        raw = part[:256 * 8].view(256, 8).view(torch.int32).cpu().long() & 0xFFFFFFFF
+        t0, t1 = raw[:, 5], raw[:, 6]
+        dur = ((t1 - t0) & 0xFFFFFFFF).double() / 100.0          # us (100 MHz counter)
+        start = ((t0 - t0.min()) & 0xFFFFFFFF).double() / 100.0
+        end = start + dur
+        cyc = t[:, 7]
+        q = lambda v: [round(float(x), 1) for x in torch.quantile(v, torch.tensor([0.0, 0.1, 0.5, 0.9, 1.0], dtype=torch.float64))]
+        print("  per-WG us: start", q(start), "duration", q(dur), "end", q(end))
+        print("  in-kernel clock GHz (cycles / real time):", q(cyc / dur / 1e3))
+        for x in range(8):
+            sel = torch.arange(256) % 8 == x
+            print(f"   blockIdx%8={x}: duration median {float(dur[sel].median()):.1f} max {float(dur[sel].max()):.1f} end max {float(end[sel].max()):.1f}")
 if os.environ.get("WS_STAMPS") and a.op == "wgrad":
     per = 27 * ((cout + 31) // 32 * 32) * ((cin + 31) // 32 * 32)
     t = ws.view(torch.float32)[: 256 * per].view(256, per)[:, :8].double().cpu()
