@@ -258,6 +258,7 @@ def main():
     for k in range(a.steps):
         loss = step()
         evs[k + 1].record()
+    t_enqueued = time.perf_counter() - t0          # host side only: all K steps issued (the GPU is still working)
     fence()
     dt = time.perf_counter() - t0
     raw_steps = [evs[k].elapsed_time(evs[k + 1]) for k in range(a.steps)]
@@ -284,6 +285,7 @@ def main():
             "step_tflops": FWD_BWD_GFLOP_PER_SAMPLE * sps / 1e3,
             "hip_event_ms_per_step": {"median": median_ms, "min": per_step[0], "max": per_step[-1],
                                       "slowest_step": raw_steps.index(per_step[-1])},
+            "host_issue_ms_per_step": t_enqueued / a.steps * 1e3,
         }
         if world == 1:
             rec["roofline"] = roofline_dominant_kernel(dev)

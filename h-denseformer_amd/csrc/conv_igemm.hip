@@ -389,12 +389,10 @@ struct WsTile {
 // NB: 32-channel output blocks per workgroup.  NB = 2 (64-byte rows, Cout % 64 == 0) stages every tile once for both
 // blocks (two workgroups with 32 channels each staged it twice: the 32->64 dgrad at 128^3 was the costliest launch of
 // the step) and shares each A fragment between two MFMAs.
-// DMA (transform-free layers with 32-byte chunks and more than one pass per tile): an item goes global -> LDS by
-// LDS-DMA (global_load_lds_dwordx4, issued at the start of the pass before the one that reads it) instead of through
-// the pf registers and ds_write commits.  The tile buffer is then the lane-linear image of 32-byte rows (no padding;
-// the two 16-byte halves of a row are swapped for box planes with bit 1 of z set -- applied to the SOURCE address --
-// which keeps the b128 fragment reads conflict-free: the 16 lanes of a pass are 8 x positions in 2 planes 2 apart).
-template <typename T, int CH, int RB, bool XF, int NB, bool DMA = false>
+// (An LDS-DMA staging variant of the transform-free 32-byte-chunk layers -- global_load_lds_dwordx4 instead of the pf
+// registers and ds_write commits -- was built at the end of round 2, measured neutral (536 vs 539 us) and removed in
+// round 3: DESIGN.md section 6d.)
+template <typename T, int CH, int RB, bool XF, int NB>
 __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
   constexpr int TD = 4, TH = 8, TW = 8, BD = TD + 2, BH = TH + 2, BW = TW + 2, BOX = BD * BH * BW;
   constexpr int ESZ = sizeof(T), EPC = ST<T>::EPC;
@@ -405,10 +403,9 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
   // tile-buffer row pitch: padded by 16 bytes (conflict-free, see ws_row_to_zx; fragment addresses = one lane
   // base + compile-time offsets) whenever two padded buffers and the weight panel fit in 160 KiB; else unpadded
   // rows with XOR-swizzled 16-byte slots (a 36-entry per-lane address table)
-  constexpr bool SWZ = !DMA && (2 * BOX * (CH + 16) + 4096 + 512 + 27 * 32 * NB * RB > 160 * 1024);
-  constexpr int AP = (SWZ || DMA) ? CH : CH + 16;
-  constexpr int ABUF = DMA ? NJ * 4096 : BOX * AP;  // DMA: whole 256-lane slots (the last one's tail lands in padding)
-  static_assert(!DMA || (!XF && CH == 32 && RB / CH > 1 && sizeof(T) == 2), "LDS-DMA staging: transform-free 32-byte chunks");
+  constexpr bool SWZ = (2 * BOX * (CH + 16) + 4096 + 512 + 27 * 32 * NB * RB > 160 * 1024);
+  constexpr int AP = SWZ ? CH : CH + 16;
+  constexpr int ABUF = BOX * AP;
   constexpr int OFF_RED = 2 * ABUF, OFF_XF = OFF_RED + 2048 * NB, OFF_W = OFF_XF + 512;
   constexpr int NC = 32 * NB;  // output channels of the workgroup
   constexpr int CPR = RB / 16, RP256 = 16 / CPR;
@@ -418,6 +415,9 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
   static_assert(OFF_W + 27 * NC * RB <= 160 * 1024, "LDS budget");
   static_assert(NB == 1 || NCH > 1, "the deferred epilogue of single-pass tiles keeps one accumulator block");
   __shared__ __attribute__((aligned(256))) char lds[OFF_W + 27 * NC * RB];
+#ifdef WS_DBG_STAMPS
+  const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();
+#endif
   char* const a_lds = lds;
   float* const s_red = reinterpret_cast<float*>(lds + OFF_RED);  // [2 halves][4 waves][NC][2]
   float* const s_xf = reinterpret_cast<float*>(lds + OFF_XF);
@@ -520,18 +520,8 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
           }
     }
   }
-  int ahalf[3] = {0, 0, 0};  // DMA layout: this lane's 16-byte half of a row of box plane dz + jz
-  if constexpr (DMA) {
-    int dz, x;
-    ws_row_to_zx(r, dz, x);
-    abase = ((dz * BH + 2 * wave) * BW + x) * AP;
-#pragma unroll
-    for (int jz = 0; jz < 3; jz++) ahalf[jz] = (h ^ (((dz + jz) >> 1) & 1)) << 4;
-  }
   auto a_addr = [&](int jz, int yp, int jx, int fs) {
-    if constexpr (DMA)
-      return abase + ((jz * BH + yp) * BW + jx) * AP + ahalf[jz];
-    else if constexpr (SWZ)
+    if constexpr (SWZ)
       return aaddr[jz][yp][jx] ^ (fs * 32);
     else
       return abase + ((jz * BH + yp) * BW + jx) * AP + fs * 32;
@@ -548,7 +538,6 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
     int vox = min(tid + 256 * j, TOTAL - CPV + part) >> CPV_SHIFT;
     int bz = vox / (BH * BW), rem = vox - bz * (BH * BW), by = rem / BW, bx = rem - by * BW;
     boff[j] = ((bz * a.Hi + by) * a.Wi + bx) * (int)a.in_pitch;
-    if constexpr (DMA) boff[j] += ((part ^ ((bz >> 1) & 1)) - part) * EPC;  // source-side swap of the row's halves
     bxyz[j] = (bz << 16) | (by << 8) | bx;
     if constexpr (SWZ) {
       woff_t[j] = vox * CH + ((part ^ a_swz<CH>(vox)) << 4);
@@ -647,26 +636,6 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
       pf[j] = *reinterpret_cast<const u32x4*>(p);
     }
   };
-  // LDS-DMA of one item (tile c, channel chunk) into the tile buffer at byte offset buf_off; slots outside the
-  // tensor read the zero line.  Inline asm, counted by hand (see conv_wgrad_s2_kernel).
-  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
-  auto dma_item = [&](auto fast_tag, int chunk, const WsTile& c, bool valid, bool inter, const T* org, int buf_off)
-                      __attribute__((always_inline)) {
-    const uint32_t wbase = __builtin_amdgcn_readfirstlane(lds_base + buf_off + wave * 1024);
-#pragma unroll
-    for (int j = 0; j < NJ; j++) {
-      const T* p = org + boff[j] + chunk * (CH / ESZ);
-      if constexpr (!decltype(fast_tag)::value) {
-        const bool ok = inter | (valid & slot_ok(j, c));
-        p = ok ? p : reinterpret_cast<const T*>(g_zero_line);
-      }
-      uint32_t keep;
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep)
-                   : "v"(p), "s"(wbase + (uint32_t)(j * 4096))
-                   : "memory");
-    }
-  };
   float sc[EPC], sh[EPC];
   auto read_xf = [&](int chunk) {
     const int cb = chunk * (CH / ESZ) + part * EPC;
@@ -739,12 +708,6 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
     org1 = v1 ? tile_org(T1) : src_safe;
     org2 = v2 ? tile_org(T2) : src_safe;
     __syncthreads();  // the previous pass is done with both tile buffers
-    if constexpr (DMA) {  // item 0 -> buffer 0, not overlapped; pass 0 of the first tile phase issues item 1
-      dma_item(std::false_type{}, 0, T0, true, i0, org0, 0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      WS_BARRIER();
-      return;
-    }
 #pragma unroll
     for (int j = 0; j < NJ; j++) load_one(std::false_type{}, j, 0, T0, true, i0, org0);
     if constexpr (XF) {
@@ -763,41 +726,40 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
     WS_BARRIER();
   };
 
-  // ---- epilogue geometry.  The MFMAs take the WEIGHT fragment as their A operand and the voxel fragment as B (the two
-  // fragment layouts are the same, so this is only the argument order): the 32 x 32 result then has the output channel on
-  // the register index and the voxel on the lane.  Lane (r, h) holds, for voxel ws_row_to_zx(r) of each of the wave's
-  // two y rows, channels co(i) = 4 h + 8 (i >> 2) + (i & 3): four runs of 4 consecutive channels, i.e. four 8-byte
-  // (16-bit storage) or 16-byte (f32) stores per M-block from ONE lane base with compile-time offsets.  (With the voxel
-  // on the register index a lane owned one channel of 16 voxels: 16 two-byte stores, 16 converts and 16 address
-  // computations per M-block, and per-tile cross-lane sums for the InstanceNorm statistics.)
-  int vdz, vx;
-  ws_row_to_zx(r, vdz, vx);
-  const int voff = ((vdz * a.Ho + 2 * wave) * a.Wo + vx) * (int)a.out_pitch + 4 * h;  // lane's voxel inside a tile
-  bool cfull[NB];  // all 32 channels of the block exist
-  T* outp[NB];     // split output: a 32-channel block lies entirely on one side (split is a multiple of 32)
+  const int ch = n0 + r;                 // channel of output block 0 (block nb: + 32 nb)
+  bool ch_ok[NB];
+  float bias[NB];
 #pragma unroll
   for (int nb = 0; nb < NB; nb++) {
-    cfull[nb] = n0 + 32 * nb + 32 <= a.Cout;
-    outp[nb] = ((a.split && n0 + 32 * nb >= a.split) ? reinterpret_cast<T*>(a.out2) - a.split : reinterpret_cast<T*>(a.out)) +
-               n0 + 32 * nb;
+    ch_ok[nb] = ch + 32 * nb < a.Cout;
+    bias[nb] = (a.bias && ch_ok[nb]) ? a.bias[ch + 32 * nb] : 0.f;
   }
-  // wide stores need the lane base aligned to the store (launcher: out / out2 16-byte aligned, pitch % 8 == 0)
-  const bool wide_ok = !a.accumulate && (a.out_pitch % 8 == 0) && ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0) &&
-                       (!a.split || (reinterpret_cast<uintptr_t>(a.out2) & 15) == 0);
-  float* const s_bias = s_red + 256 * NB;  // [NC]: the second half of the reduction area
-  const bool has_bias = a.bias != nullptr;
-  if (tid < NC) s_bias[tid] = (has_bias && n0 + tid < a.Cout) ? a.bias[n0 + tid] : 0.f;
-  // InstanceNorm partial rows are per WORKGROUP, not per tile: sample n owns WS_STAT_ROWS rows, row
-  // pass * 256 + blockIdx.x (+ k gridDim.x for the slots no workgroup has) holds this workgroup's sums over its
-  // tiles of n in that pass.  Every lane keeps running (sum, sum of squares) of ITS 16 channels over its voxels in
-  // registers; they are reduced over lanes and waves and added to the row only when the sample changes / the pass ends
-  // (stats_to_row: a handful of times per launch).  The rows are zeroed here first, so in_finalize reads 512 rows
-  // instead of one per tile.
-  float st1[NB][16], st2[NB][16];
+  T* outp[NB];  // split output: a 32-channel block lies entirely on one side (split is a multiple of 32)
 #pragma unroll
   for (int nb = 0; nb < NB; nb++)
+    outp[nb] = (a.split && n0 + 32 * nb >= a.split) ? reinterpret_cast<T*>(a.out2) - a.split : reinterpret_cast<T*>(a.out);
+  // accumulator register i of this lane: tile voxel (dz, 2w + mb, x) with x = (i & 3) + 4 * ((i >> 2) & 1) and
+  // dz = {0,1,3,2}[i >> 2] (h == 0) or {1,0,2,3}[i >> 2] (h == 1)   (ws_row_to_zx of row (i&3) + 8*(i>>2) + 4h)
+  int edz[4], eplane[4];
 #pragma unroll
-    for (int i = 0; i < 16; i++) st1[nb][i] = st2[nb][i] = 0.f;
+  for (int q4 = 0; q4 < 4; q4++) {
+    int dz, x;
+    ws_row_to_zx(8 * q4 + 4 * h, dz, x);
+    edz[q4] = dz;
+    eplane[q4] = dz * a.Ho * a.Wo * (int)a.out_pitch;
+  }
+  auto eoff = [&](int i) { return eplane[i >> 2] + ((i & 3) + 4 * ((i >> 2) & 1)) * (int)a.out_pitch; };
+  // InstanceNorm partial rows are per WORKGROUP, not per tile: sample n owns WS_STAT_ROWS rows, row
+  // pass * 256 + blockIdx.x (+ k gridDim.x for the slots no workgroup has) holds this workgroup's sums over its
+  // tiles of n in that pass.  Every lane keeps running sums of ITS channel over the voxels it has produced (lr1 / lr2:
+  // two registers per output block, two adds per tile); lanes and waves are combined through s_red only when the sample
+  // changes or the pass ends (stats_to_row, a handful of times per launch).  Round 2 sent every tile's per-wave sums
+  // through LDS and had tid < NC collect them behind the next barrier: a shuffle pair, two LDS writes, eight LDS reads
+  // and two branches per tile inside the hot loop.  The rows are zeroed here first, so in_finalize reads 512 rows
+  // instead of one per tile.
+  float lr1[NB], lr2[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; nb++) lr1[nb] = lr2[nb] = 0.f;
   int racc_n = -1, cur_pass = 0;
   auto stat_row = [&](int n, int pass, int b) {
     return a.stat_partials + (((int64_t)n * WS_STAT_ROWS + pass * 256 + b) * a.CoutP + n0 + tid) * 2;
@@ -811,25 +773,17 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
           q[1] = 0.f;
         }
   }
-  // uniform (every wave takes the same path): lanes -> waves -> the workgroup's row of sample racc_n, fixed order
+  // uniform (every wave takes the same path): lanes -> waves -> this workgroup's row of sample racc_n, fixed order
   auto stats_to_row = [&]() __attribute__((always_inline)) {
     if (a.stat_partials && racc_n >= 0) {
 #pragma unroll
-      for (int nb = 0; nb < NB; nb++)
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-          float u1 = st1[nb][i], u2 = st2[nb][i];
-#pragma unroll
-          for (int o = 1; o < 32; o <<= 1) {
-            u1 += __shfl_xor(u1, o, 64);
-            u2 += __shfl_xor(u2, o, 64);
-          }
-          if (r == 0) {
-            const int c = 32 * nb + 4 * h + 8 * (i >> 2) + (i & 3);
-            s_red[(wave * NC + c) * 2 + 0] = u1;
-            s_red[(wave * NC + c) * 2 + 1] = u2;
-          }
+      for (int nb = 0; nb < NB; nb++) {
+        const float u1 = lr1[nb] + __shfl_xor(lr1[nb], 32, 64), u2 = lr2[nb] + __shfl_xor(lr2[nb], 32, 64);
+        if (h == 0) {
+          s_red[(wave * NC + 32 * nb + r) * 2 + 0] = u1;
+          s_red[(wave * NC + 32 * nb + r) * 2 + 1] = u2;
         }
+      }
       __syncthreads();
       if (tid < NC) {
         float t1 = 0.f, t2 = 0.f;
@@ -845,9 +799,7 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
       __syncthreads();
     }
 #pragma unroll
-    for (int nb = 0; nb < NB; nb++)
-#pragma unroll
-      for (int i = 0; i < 16; i++) st1[nb][i] = st2[nb][i] = 0.f;
+    for (int nb = 0; nb < NB; nb++) lr1[nb] = lr2[nb] = 0.f;
     racc_n = -1;
   };
   // the tile about to be summed belongs to sample n (uniform)
@@ -876,21 +828,9 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
 #define WS2_STAMP(k)
 #endif
 
-  // this lane's first output element of a tile: its voxel in y row 2w (M-block mb: + Wo rows), channel 4h of block nb
+  // this lane's first output element of a tile: channel n0 + r, rows y0 + 2w (+ mb), voxel (z0, ., x0)
   auto out_base = [&](const WsTile& t, int nb) -> T* {
-    return outp[nb] + ((((int64_t)t.n * a.Do + t.z0) * a.Ho + t.y0) * a.Wo + t.x0) * a.out_pitch + voff;
-  };
-  // quad q of an M-block: accumulator registers 4q .. 4q+3 = channels 8q + 4h + (0..3) of the lane's voxel
-  auto quad_out = [&](const f32x16& acc, int q, T* orow, float (&s1)[16], float (&s2)[16], const f32x4& bq)
-                      __attribute__((always_inline)) {
-    float v[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      v[j] = acc[4 * q + j] + bq[j];
-      s1[4 * q + j] += v[j];
-      s2[4 * q + j] = fmaf(v[j], v[j], s2[4 * q + j]);
-    }
-    ST<T>::st4(orow + 8 * q, v[0], v[1], v[2], v[3]);
+    return outp[nb] + ((((int64_t)t.n * a.Do + t.z0) * a.Ho + t.y0 + 2 * wave) * a.Wo + t.x0) * a.out_pitch + ch + 32 * nb;
   };
   auto epilogue = [&](f32x16 (&acc)[2 * NB], const WsTile& ET) __attribute__((always_inline)) {
     const int z0 = ET.z0, y0 = ET.y0, x0 = ET.x0;
@@ -898,43 +838,44 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
     stats_sample(ET.n);
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) {
+      float s1 = 0.f, s2 = 0.f;
       T* const obase = out_base(ET, nb);
-      if (full && cfull[nb] && wide_ok) {
-        f32x4 bq[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) bq[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (has_bias) {
-#pragma unroll
-          for (int q = 0; q < 4; q++) bq[q] = *reinterpret_cast<const f32x4*>(s_bias + 32 * nb + 8 * q + 4 * h);
-        }
+      if (full && ch_ok[nb] && !a.accumulate) {
 #pragma unroll
         for (int mb = 0; mb < 2; mb++) {
-          T* const orow = obase + (int64_t)mb * a.Wo * a.out_pitch;
-#pragma unroll
-          for (int q = 0; q < 4; q++) quad_out(acc[nb * 2 + mb], q, orow, st1[nb], st2[nb], bq[q]);
-        }
-      } else {  // ragged tiles, partial channel blocks, out += result, unaligned views: element by element
-        const int gz = z0 + vdz, gx = x0 + vx;
-#pragma unroll
-        for (int mb = 0; mb < 2; mb++) {
-          const int gy = y0 + 2 * wave + mb;
-          const bool vok = gz < a.Do && gy < a.Ho && gx < a.Wo;
           T* const orow = obase + (int64_t)mb * a.Wo * a.out_pitch;
 #pragma unroll
           for (int i = 0; i < 16; i++) {
-            const int cl = 8 * (i >> 2) + (i & 3);  // channel offset from the lane base (which carries 4h)
-            const bool cok = n0 + 32 * nb + 4 * h + cl < a.Cout;
-            const float v = acc[nb * 2 + mb][i] + s_bias[32 * nb + 4 * h + cl];
-            if (vok && cok) {
-              float o = v;
-              if (a.accumulate) o += ST<T>::ld(orow + cl);
-              ST<T>::st(orow + cl, o);
-            }
-            const float mk = (vok && cok) ? 1.f : 0.f;
-            st1[nb][i] += mk * v;
-            st2[nb][i] += mk * v * v;
+            const float v = acc[nb * 2 + mb][i] + bias[nb];
+            ST<T>::st(orow + eoff(i), v);
+            s1 += v;
+            s2 += v * v;
           }
         }
+      } else {
+#pragma unroll
+        for (int mb = 0; mb < 2; mb++) {
+          const int gy = y0 + 2 * wave + mb;
+          T* const orow = obase + (int64_t)mb * a.Wo * a.out_pitch;
+#pragma unroll
+          for (int i = 0; i < 16; i++) {
+            const int gz = z0 + edz[i >> 2], gx = x0 + (i & 3) + 4 * ((i >> 2) & 1);
+            const float v = acc[nb * 2 + mb][i] + bias[nb];
+            const bool ok = gz < a.Do && gy < a.Ho && gx < a.Wo;
+            if (ok && ch_ok[nb]) {
+              float o = v;
+              if (a.accumulate) o += ST<T>::ld(orow + eoff(i));
+              ST<T>::st(orow + eoff(i), o);
+            }
+            const float mk = ok ? 1.f : 0.f;
+            s1 += mk * v;
+            s2 += mk * v * v;
+          }
+        }
+      }
+      if (ch_ok[nb]) {
+        lr1[nb] += s1;
+        lr2[nb] += s2;
       }
     }
   };
@@ -951,9 +892,11 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
   auto tile_phase = [&](auto par_tag, auto fast_tag, auto din_tag, auto dout_tag) __attribute__((always_inline)) {
     constexpr int PAR0 = decltype(par_tag)::value;
     constexpr bool DIN = decltype(din_tag)::value, DOUT = decltype(dout_tag)::value;
+    constexpr int EPG = (32 + NG - 1) / NG;  // pending elements per MFMA group
     f32x16(&acc)[2 * NB] = accs[PAR0];
     f32x16(&pacc)[2 * NB] = accs[1 - PAR0];
     T* const pbase = out_base(PT, 0);
+    float ds1 = 0.f, ds2 = 0.f;
     if constexpr (DIN) stats_sample(PT.n);
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
@@ -979,10 +922,6 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
         read_xf(c_chunk);
       }
       WS2_STAMP(0)
-      if constexpr (DMA) {  // item c+1 -> the other buffer (free since the barrier that ended pass c-1)
-        const T* const c_org = c_next ? org1 : org0;
-        dma_item(fast_tag, c_chunk, CT, c_next ? v1 : true, c_int, c_org, (1 - PAR) * ABUF);
-      }
       u32x4 af[2][4], bf[2][3 * NB];
       auto read_group = [&](int g, u32x4 (&A)[4], u32x4 (&B)[3 * NB]) {
         const int t = g / NFS, fs = g % NFS, jz = t / 3, jx = t % 3;
@@ -1015,20 +954,26 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
         for (int j = 0; j < NJ; j++) {
           if ((j * NG) / NJ == g) {
 #ifndef WS2_DBG_NOSTAGE  // energy/cycle attribution experiments: drop the staging or the fragment reads
-            if constexpr (!DMA) {
-              commit_one(fast_tag, j, CT, c_int, a_wr);
-              load_one(fast_tag, j, l_chunk, LT, l_val, l_int, l_org);
-            }
+            commit_one(fast_tag, j, CT, c_int, a_wr);
+            load_one(fast_tag, j, l_chunk, LT, l_val, l_int, l_org);
 #endif
           }
         }
-        if constexpr (DIN) {  // the pending tile's 8 quads (2 M-blocks x 4), spread over the MFMA groups of this pass
+        if constexpr (DIN) {
 #pragma unroll
-          for (int u = 0; u < 8; u++) {
-            if ((u * NG) / 8 == g) {
-              const int mb = u >> 2, q = u & 3;
-              quad_out(pacc[mb], q, pbase + (int64_t)mb * a.Wo * a.out_pitch, st1[0], st2[0], f32x4{0.f, 0.f, 0.f, 0.f});
+          for (int u = 0; u < EPG; u++) {
+            const int e = g * EPG + u;
+            if (e < 32) {
+              const int mb = e >> 4, i = e & 15;
+              const float v = pacc[mb][i] + bias[0];
+              ST<T>::st(pbase + (int64_t)mb * a.Wo * a.out_pitch + eoff(i), v);
+              ds1 += v;
+              ds2 += v * v;
             }
+          }
+          if (g == (31 / EPG)) {  // last pending element done
+            lr1[0] += ds1;
+            lr2[0] += ds2;
           }
         }
         u32x4(&A)[4] = af[g & 1];
@@ -1043,14 +988,12 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
         for (int jy = 0; jy < 3; jy++)
 #pragma unroll
           for (int nb = 0; nb < NB; nb++) {
-            Mma<T>::run(B[jy * NB + nb], A[jy], acc[nb * 2 + 0]);      // mb 0: box row y' = jy   (rows = channels)
-            Mma<T>::run(B[jy * NB + nb], A[jy + 1], acc[nb * 2 + 1]);  // mb 1: box row y' = jy + 1
+            Mma<T>::run(A[jy], B[jy * NB + nb], acc[nb * 2 + 0]);      // mb 0: box row y' = jy
+            Mma<T>::run(A[jy + 1], B[jy * NB + nb], acc[nb * 2 + 1]);  // mb 1: box row y' = jy + 1
           }
         __builtin_amdgcn_sched_barrier(0);
       }
       WS2_STAMP(1)
-      // DMA: item c+1 has landed (the epilogue's stores come after this wait: vmcnt counts them too, in order)
-      if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       WS_BARRIER();  // buffer PAR fully read, buffer 1-PAR fully written
       WS2_STAMP(2)
     }
@@ -1089,7 +1032,7 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
     i2 = v2 && (BORDER ? tile_interior(T2) : true);
     org2 = v2 ? tile_org(T2) : src_safe;
   };
-  const bool can_defer = wide_ok && (a.Cout % 32 == 0) && a.stat_partials != nullptr && !has_bias;
+  const bool can_defer = !a.accumulate && (a.Cout % 32 == 0) && a.stat_partials != nullptr;
 
   // ---- pass A: interior tiles.  Every phase is the unchecked copy; with single-pass tiles and a deferrable
   // epilogue the run alternates between the two hot copies (P1 / P0, pending epilogue in, own epilogue out).
@@ -1154,6 +1097,7 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
     a.stat_partials[(int64_t)blockIdx.x * 8 + 5] = __uint_as_float((uint32_t)treal0);
     a.stat_partials[(int64_t)blockIdx.x * 8 + 6] = __uint_as_float((uint32_t)__builtin_amdgcn_s_memrealtime());
     a.stat_partials[(int64_t)blockIdx.x * 8 + 7] = (float)(__builtin_amdgcn_s_memtime() - tcyc0);
+    a.stat_partials[2048 + blockIdx.x] = __uint_as_float((uint32_t)t_entry);  // kernel entry of this workgroup
   }
 #endif
 }
@@ -2712,18 +2656,14 @@ int launch_cfg(const ConvArgs& a, hipStream_t st) {
 
 // tile-shape choice: shared by the launcher and by hdf_conv_stat_tiles (partials geometry)
 inline bool small_tile(int Do, int Ho, int Wo) {
-  static const int64_t mx = getenv("HDF_SMALL_TILE_MAX") ? atoll(getenv("HDF_SMALL_TILE_MAX")) : 32 * 32 * 32 / 2;  // tuning knob
-  return (int64_t)Do * Ho * Wo <= mx;
+  return (int64_t)Do * Ho * Wo <= 32 * 32 * 32 / 2;
 }
 // 8^3-class volumes (the bottleneck UpConv): 64-voxel tiles, or a handful of workgroups would carry the whole layer
 inline bool tiny_tile(int Do, int Ho, int Wo) {
-  static const int64_t mx = getenv("HDF_TINY_TILE_MAX") ? atoll(getenv("HDF_TINY_TILE_MAX")) : 8 * 8 * 16;  // tuning knob
-  return (int64_t)Do * Ho * Wo <= mx;
+  return (int64_t)Do * Ho * Wo <= 8 * 8 * 16;
 }
 // weights-stationary kernel: mode 0, whole Cin row <= 128 B, enough tiles to amortise the weight panel
 inline int ws_cfg(int mode, int Do, int Ho, int Wo, int row_bytes) {
-  static const int ws_max = getenv("HDF_WS_MAX_ROW_BYTES") ? atoi(getenv("HDF_WS_MAX_ROW_BYTES")) : 128;  // tuning knob
-  if (row_bytes > ws_max) return 0;
   if (mode != 0 || row_bytes > 128 || (int64_t)Do * Ho * Wo < 48 * 48 * 48) return 0;
   return (row_bytes == 32 || row_bytes == 64 || row_bytes == 128) ? 1 : 0;
 }
@@ -2733,14 +2673,6 @@ int launch_ws2(const ConvArgs& a, hipStream_t st) {
   const int tiles = a.N * ceil_div(a.Do, 4) * ceil_div(a.Ho, 8) * ceil_div(a.Wo, 8);
   const int cout_tiles = a.CoutP / (32 * NB);
   const int gx = std::min(tiles, std::max(1, hdf_cu_budget() / cout_tiles));  // one workgroup per CU; the kernel splits the tiles
-  if constexpr (sizeof(T) == 2 && CH == 32 && (RB / CH > 1)) {
-    static const bool dma = getenv("HDF_WS_DMA") != nullptr;  // LDS-DMA staging of the transform-free layers
-    if (dma && !a.in_scale) {
-      hipLaunchKernelGGL((conv_ws2_kernel<T, CH, RB, false, NB, true>), dim3(gx, cout_tiles), dim3(256), 0, st, a);
-      HDF_LAUNCH_CHECK();
-      return HDF_OK;
-    }
-  }
   if (a.in_scale)
     hipLaunchKernelGGL((conv_ws2_kernel<T, CH, RB, true, NB>), dim3(gx, cout_tiles), dim3(256), 0, st, a);
   else
@@ -2755,24 +2687,18 @@ int launch_conv_t(int mode, const ConvArgs& a, hipStream_t st) {
     const int rb = a.Cin * (int)sizeof(T);
     const int ws = ws_cfg(mode, a.Do, a.Ho, a.Wo, rb);
     if (ws) {
-      static const bool nb2 = getenv("HDF_WS_NB1") == nullptr;  // A/B knob
       if (rb == 32) return launch_ws2<T, 32, 32, 1>(a, st);
-      if (rb == 64 && a.CoutP % 64 == 0 && nb2) return launch_ws2<T, 32, 64, 2>(a, st);
+      if (rb == 64 && a.CoutP % 64 == 0) return launch_ws2<T, 32, 64, 2>(a, st);
       if (rb == 64) return launch_ws2<T, 64, 64, 1>(a, st);
       if (rb == 128) return launch_ws2<T, 32, 128, 1>(a, st);
     }
     if (tiny_tile(a.Do, a.Ho, a.Wo)) return launch_cfg<T, 2, 4, 8, 2, 2, 1, 1, false>(a, st);   // 64 vox x 64 ch
-    if (small_tile(a.Do, a.Ho, a.Wo)) {
-      static const bool wn1 = getenv("HDF_SMALL_WN1") != nullptr;  // tuning knob: 128 vox x 32 ch, twice the workgroups
-      if (wn1) return launch_cfg<T, 4, 4, 8, 4, 1, 1, 1, false>(a, st);
-      return launch_cfg<T, 4, 4, 8, 2, 2, 2, 1, false>(a, st);  // 128 vox x 64 ch
-    }
+    if (small_tile(a.Do, a.Ho, a.Wo)) return launch_cfg<T, 4, 4, 8, 2, 2, 2, 1, false>(a, st);  // 128 vox x 64 ch
     if (a.CoutP <= 32) return launch_cfg<T, 4, 8, 8, 4, 1, 2, 1, false>(a, st);                  // 256 vox x 32 ch
     return launch_cfg<T, 4, 8, 8, 2, 2, 4, 1, false>(a, st);                                     // 256 vox x 64 ch
   } else if (mode == 1) {
     if constexpr (sizeof(T) == 2) {
-      static const bool g_old = getenv("HDF_GATHER_S2_OLD") != nullptr;  // A/B knob
-      if (!g_old && a.Cin * 2 == 64 && a.CoutP == 64 && !a.in_scale && !a.accumulate && a.Do % 4 == 0 && a.Ho % 4 == 0 &&
+      if (a.Cin * 2 == 64 && a.CoutP == 64 && !a.in_scale && !a.accumulate && a.Do % 4 == 0 && a.Ho % 4 == 0 &&
           a.Wo % 4 == 0 && a.Di == 2 * a.Do && a.Hi == 2 * a.Ho && a.Wi == 2 * a.Wo) {
         const int tiles = a.N * (a.Do / 4) * (a.Ho / 4) * (a.Wo / 4);
         hipLaunchKernelGGL((conv_gather_s2_kernel<T>), dim3(std::min(tiles, hdf_cu_budget())), dim3(256), 0, st, a);
@@ -2784,8 +2710,7 @@ int launch_conv_t(int mode, const ConvArgs& a, hipStream_t st) {
     return launch_cfg<T, 4, 4, 4, 1, 4, 2, 2, false>(a, st);  // 64 vox x 128 ch, stride 2
   } else {
     if constexpr (sizeof(T) == 2) {
-      static const bool ct_old = getenv("HDF_CONVT_OLD") != nullptr;  // A/B knob
-      if (!ct_old && a.Cin * 2 == 128 && a.CoutP == 32 && !a.accumulate && a.Di % 4 == 0 && a.Hi % 4 == 0 && a.Wi % 8 == 0 &&
+      if (a.Cin * 2 == 128 && a.CoutP == 32 && !a.accumulate && a.Di % 4 == 0 && a.Hi % 4 == 0 && a.Wi % 8 == 0 &&
           a.Do == 2 * a.Di && a.Ho == 2 * a.Hi && a.Wo == 2 * a.Wi) {
         const int tiles = a.N * (a.Di / 4) * (a.Hi / 4) * (a.Wi / 8);
         hipLaunchKernelGGL((convt_ws_kernel<T>), dim3(std::min(tiles, hdf_cu_budget())), dim3(256), 0, st, a);
@@ -2818,20 +2743,14 @@ int launch_wgrad_t(WgradArgs a, float* dw, int sc_store, int lc_store, int accum
   a.LCp = round_up(a.LC, 32);
   a.num_tiles = a.N * ceil_div(a.Ds, TD) * ceil_div(a.Hs, TH) * ceil_div(a.Ws, TW);
   // 16-bit stride 2 without a transform of the large operand: conv_wgrad_s2_kernel, SB small-channel blocks per workgroup
-  static const bool s2_old = getenv("HDF_WGRAD_S2_OLD") != nullptr;  // A/B knob
-  const bool use_s2 = sizeof(T) == 2 && S == 2 && !a.lg_scale && !s2_old && a.Ds % 4 == 0 && a.Hs % 4 == 0 &&
+  const bool use_s2 = sizeof(T) == 2 && S == 2 && !a.lg_scale && a.Ds % 4 == 0 && a.Hs % 4 == 0 &&
                       a.Ws % 4 == 0 && a.Dl == 2 * a.Ds && a.Hl == 2 * a.Hs && a.Wl == 2 * a.Ws;
-  static const int s2_sb = getenv("HDF_WGRAD_S2_SB") ? atoi(getenv("HDF_WGRAD_S2_SB")) : 2;  // tuning knob
-  const int sb = (use_s2 && a.SCp >= 64 && s2_sb == 2) ? 2 : 1;
+  const int sb = (use_s2 && a.SCp >= 64) ? 2 : 1;
   const int sblocks = ceil_div(a.SCp / 32, sb);
   const int pairs = sblocks * (a.LCp / 32);
   const int64_t per = (int64_t)27 * a.SCp * a.LCp * sizeof(float);
-  static const int wg_new = getenv("HDF_WGRAD_WGS") ? atoi(getenv("HDF_WGRAD_WGS")) : 256;  // one workgroup per CU
-  // the single-buffered kernel (stride 2, f32) hides its staging only behind other workgroups of the same CU
-  static const int wg_old = getenv("HDF_WGRAD_OLD_WGS") ? atoi(getenv("HDF_WGRAD_OLD_WGS")) : 256;
-  static const bool force_old = getenv("HDF_WGRAD_OLD") != nullptr;
-  const bool use_new = sizeof(T) == 2 && S == 1 && !a.sm_scale && !force_old;
-  const int wg_target = std::min(use_new ? wg_new : wg_old, hdf_cu_budget());
+  const bool use_new = sizeof(T) == 2 && S == 1 && !a.sm_scale;
+  const int wg_target = hdf_cu_budget();  // one workgroup per CU
   int G = ceil_div(wg_target, pairs);
   G = (int)std::min<int64_t>(G, std::max<int64_t>(1, (int64_t)ws_bytes / per));
   G = std::min(G, a.num_tiles);
@@ -2850,7 +2769,7 @@ int launch_wgrad_t(WgradArgs a, float* dw, int sc_store, int lc_store, int accum
     }
   }
   if constexpr (sizeof(T) == 2 && S == 1) {
-    if (use_new) {  // HDF_WGRAD_OLD=1 (A/B knob): single-buffered conv_wgrad_kernel everywhere
+    if (use_new) {
       if (a.lg_scale)
         hipLaunchKernelGGL((conv_wgrad2_kernel<T, true>), grid, dim3(256), 0, st, a);
       else
@@ -2875,9 +2794,8 @@ int launch_wgrad_t(WgradArgs a, float* dw, int sc_store, int lc_store, int accum
 }  // namespace
 
 int hdf_conv_weight_layout(int dtype, int mode, int Cin, int Do, int Ho, int Wo) {
-  static const bool off = getenv("HDF_CONV_ROW_PANELS") != nullptr;  // A/B knob: row-major panels everywhere
   const int rb = Cin * hdf_esz(dtype);
-  if (off || rb % 64 != 0) return 0;                       // the pipelined path needs whole 64-byte chunks
+  if (rb % 64 != 0) return 0;                       // the pipelined path needs whole 64-byte chunks
   if (mode == 0) return ws_cfg(mode, Do, Ho, Wo, rb) ? 0 : 1;  // conv_ws2_kernel stages row-major panels
   if (mode == 1) return 1;                                 // stride-2 gather conv: pipelined path
   return rb > 128 ? 1 : 0;  // transposed conv: convt_fused_kernel (rows <= 128 B) stages row-major panels, wider ones run per class

@@ -179,17 +179,22 @@ struct hdf_plan {
   size_t pool_idx[3];
   size_t tf_F, tf_save, tf_scratch, tf_dF, tf_tape = 0, tf_otape = 0;
   size_t stat_partials, wgrad_ws, inb_partials, inb_k;
+  size_t stat_partials2 = 0, inb_partials2 = 0, inb_k2 = 0;  // the same scratch for the branch stream (see Exec::branch)
   size_t wgrad_ws_bytes = 0;
   // backward scratch
   View gA[4], gY[4], gY2[4], dCat[3], dUp[3], dSkip[3], dP[3], dUa[4], dUy[4], dX4, dAttnall;
   // Side stream of the backward pass (weight gradients; see Exec::wgrad_stream) and a ring of its events.  Created
   // lazily on first use, destroyed with the plan.
   hipStream_t side = nullptr;
+  // Branch stream: the multi-path transformer + UpConv chain (forward), their backward (HDenseFormer.py:230-235), next
+  // to the level-0 encoder convolutions the caller's stream runs meanwhile (forward3d / backward3d).
+  hipStream_t branch = nullptr;
   std::vector<hipEvent_t> events;
   size_t ev_next = 0;
   ~hdf_plan() {
     for (hipEvent_t ev : events) (void)hipEventDestroy(ev);
     if (side) (void)hipStreamDestroy(side);
+    if (branch) (void)hipStreamDestroy(branch);
   }
   bool dcat_split[3] = {false, false, false};
   // ---- 2-D model (models/HDenseFormer_2D.py) run as its exact depth-replicated 3-D embedding (see embed2d below)
@@ -535,6 +540,12 @@ void layout(hdf_plan* p, int B) {
     for (int rb : {32, 1 << 20})  // weights-stationary (per-workgroup rows) and tiled (per-tile rows) geometry
       maxtiles = std::max<size_t>(maxtiles, hdf_conv_stat_tiles(0, p->dims[l][0], p->dims[l][1], p->dims[l][2], rb));
   p->stat_partials = bp.take((size_t)B * maxtiles * round_up(8 * nf, 32) * 2 * sizeof(float));
+  {  // branch stream: deep_conv (level 4) and up1..3 (levels 3, 2, 1) write their InstanceNorm partials here
+    size_t mt = 0;
+    for (int l = 1; l < 5; l++)
+      for (int rb : {32, 1 << 20}) mt = std::max<size_t>(mt, hdf_conv_stat_tiles(0, p->dims[l][0], p->dims[l][1], p->dims[l][2], rb));
+    p->stat_partials2 = bp.take((size_t)B * mt * round_up(8 * nf, 32) * 2 * sizeof(float));
+  }
   // ---- backward scratch
   p->tf_scratch = bp.take((size_t)rows * std::max(160, p->DM) * sizeof(float));
   p->tf_dF = bp.take((size_t)rows * p->DMF * sizeof(float));
@@ -545,6 +556,8 @@ void layout(hdf_plan* p, int B) {
   p->wgrad_ws = bp.take(p->wgrad_ws_bytes);
   p->inb_partials = bp.take((size_t)B * 1024 * 8 * nf * 2 * sizeof(float));  // hdf_in_bwd_blocks <= 1024, C <= 8 nf
   p->inb_k = bp.take((size_t)3 * B * 8 * nf * sizeof(float));
+  p->inb_partials2 = bp.take((size_t)B * 1024 * 8 * nf * 2 * sizeof(float));
+  p->inb_k2 = bp.take((size_t)3 * B * 8 * nf * sizeof(float));
   for (int k = 0; k < 4; k++) {
     p->gA[k] = mkview(p, bp, "", k, ch[k], B);
     p->gY[k] = mkview(p, bp, "", k, ch[k], B);
@@ -596,6 +609,7 @@ struct Exec {
   int B;
   hipStream_t st;
   bool async = false;                           // weight gradients on the side stream
+  bool on_branch = false;                       // this Exec issues onto the plan's branch stream (own scratch)
   hipEvent_t last_side = nullptr;               // last event recorded on the side stream in this call
   std::map<size_t, hipEvent_t> readers;         // workspace offset of a buffer -> side-stream event after its last reader
   hipEvent_t next_event() {
@@ -612,7 +626,10 @@ struct Exec {
     if (!async) return st;
     hipEvent_t f = next_event();
     if (!f || hipEventRecord(f, st) != hipSuccess || hipStreamWaitEvent(p->side, f, 0) != hipSuccess) {
-      async = false;  // fall back to in-order execution (still correct)
+      // fall back to in-order execution: first order this stream behind what the side stream already holds (its
+      // kernels use the shared weight-gradient workspace this stream is about to reuse)
+      join();
+      async = false;
       return st;
     }
     return p->side;
@@ -637,6 +654,35 @@ struct Exec {
     if (last_side) (void)hipStreamWaitEvent(st, last_side, 0);
     last_side = nullptr;
     readers.clear();
+  }
+  // scratch of this Exec's stream (two streams of one call must not share the per-launch partial-sum tables)
+  float* statp() const { return f(on_branch ? p->stat_partials2 : p->stat_partials); }
+  float* inbp() const { return f(on_branch ? p->inb_partials2 : p->inb_partials); }
+  float* inbk() const { return f(on_branch ? p->inb_k2 : p->inb_k); }
+  // fork: a second Exec on the plan's branch stream, ordered behind everything issued on this one so far.  nullptr
+  // stream when the branch stream cannot be used (creation / event failure): the caller then stays in order.
+  hipStream_t fork_branch() {
+    if (!p->branch) {
+      int least = 0, greatest = 0;  // the branch carries the longer dependency chain: highest priority
+      if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
+          hipStreamCreateWithPriority(&p->branch, hipStreamNonBlocking, greatest) != hipSuccess) {
+        if (hipStreamCreateWithFlags(&p->branch, hipStreamNonBlocking) != hipSuccess) p->branch = nullptr;
+      }
+    }
+    if (!p->branch) return nullptr;
+    hipEvent_t f = next_event();
+    if (!f || hipEventRecord(f, st) != hipSuccess || hipStreamWaitEvent(p->branch, f, 0) != hipSuccess) return nullptr;
+    return p->branch;
+  }
+  // join a branch Exec back: this stream waits for everything issued on the branch (incl. its side-stream work)
+  int join_branch(Exec& b) {
+    b.join();
+    hipEvent_t d = next_event();
+    if (!d || hipEventRecord(d, b.st) != hipSuccess || hipStreamWaitEvent(st, d, 0) != hipSuccess) {
+      hdf_set_error("branch stream: join failed");
+      return HDF_ERR_HIP;
+    }
+    return HDF_OK;
   }
   void* at(const View& v) const { return ws + v.off; }
   float* f(size_t off) const { return reinterpret_cast<float*>(ws + off); }
@@ -675,11 +721,11 @@ int conv_forward(Exec& e, Conv3& c, const View& in, Xf xf) {
   a.out_pitch = c.y.pitch;
   a.Cout = c.Cout;
   a.CoutP = CoutP;
-  a.stat_partials = e.f(p->stat_partials);
+  a.stat_partials = e.statp();
   a.accumulate = 0;
   HDF_TRY(hdf_launch_conv(p->dtype, 0, a, e.st));
   int tiles = hdf_conv_stat_tiles(0, d[0], d[1], d[2], c.CinP * p->esz);
-  HDF_TRY(hdf_launch_in_finalize(e.f(p->stat_partials), e.B, tiles, c.Cout, CoutP, p->vox(c.lvl), e.P(c.gamma),
+  HDF_TRY(hdf_launch_in_finalize(e.statp(), e.B, tiles, c.Cout, CoutP, p->vox(c.lvl), e.P(c.gamma),
                                  e.P(c.beta), 1e-5f, e.f(c.st.mean), e.f(c.st.rstd), e.f(c.st.scale),
                                  e.f(c.st.shift), e.st));
   return HDF_OK;
@@ -895,15 +941,15 @@ int in_backward(Exec& e, const Conv3& c, const View& da, const View& dy, int pre
   hdf_plan* p = e.p;
   const int64_t vox = p->vox(c.lvl);
   const int blocks = pre_blocks > 0 ? pre_blocks : hdf_in_bwd_blocks(vox, c.Cout);
-  float* k = e.f(p->inb_k);
+  float* k = e.inbk();
   float* k1 = k;
   float* ka = k + (size_t)e.B * c.Cout;
   float* kb = k + (size_t)2 * e.B * c.Cout;
   if (pre_blocks == 0)
     HDF_TRY(hdf_launch_in_bwd_reduce(p->dtype, e.at(da), da.pitch, e.at(c.y), c.y.pitch, e.f(c.st.scale),
-                                     e.f(c.st.shift), e.f(c.st.mean), e.f(c.st.rstd), e.f(p->inb_partials), blocks, e.B,
+                                     e.f(c.st.shift), e.f(c.st.mean), e.f(c.st.rstd), e.inbp(), blocks, e.B,
                                      c.Cout, vox, e.st));
-  HDF_TRY(hdf_launch_in_bwd_finalize(e.f(p->inb_partials), blocks, e.B, c.Cout, vox, e.P(c.gamma), e.f(c.st.rstd), k1,
+  HDF_TRY(hdf_launch_in_bwd_finalize(e.inbp(), blocks, e.B, c.Cout, vox, e.P(c.gamma), e.f(c.st.rstd), k1,
                                      ka, kb, e.G(c.gamma), e.G(c.beta), e.st));
   e.wait_readers(dy);  // a side-stream weight gradient may still read this buffer's previous contents
   HDF_TRY(hdf_launch_in_bwd_apply(p->dtype, e.at(da), da.pitch, e.at(c.y), c.y.pitch, e.f(c.st.scale), e.f(c.st.shift),
@@ -963,11 +1009,11 @@ int conv_backward(Exec& e, Conv3& c, const View& dy, const View& in, Xf xf, cons
       a.out2 = e.at(*din2);
       a.split = din->C;
     }
-    if (din_colsum) a.stat_partials = e.f(p->stat_partials);  // forward scratch, free during backward
+    if (din_colsum) a.stat_partials = e.statp();  // forward scratch, free during backward
     HDF_TRY(hdf_launch_conv(p->dtype, 0, a, e.st));
     if (din_colsum) {
       const int rows = e.B * hdf_conv_stat_tiles(0, d[0], d[1], d[2], a.Cin * p->esz);
-      HDF_TRY(hdf_launch_stat_rows_sum(e.f(p->stat_partials), rows, colsum_C, OP, din_colsum, e.st));
+      HDF_TRY(hdf_launch_stat_rows_sum(e.statp(), rows, colsum_C, OP, din_colsum, e.st));
     }
   }
   return HDF_OK;
@@ -1024,7 +1070,7 @@ int head_backward(Exec& e, const Head1& h, const void* dlogits, const View& in, 
   return hdf_launch_head_bwd(p->dtype, dlogits, e.at(in), in.pitch, xf.scale, xf.shift, e.P(h.w), e.at(dx), dx.pitch,
                              acc, e.G(h.w), e.G(h.b), e.B, h.C, p->ncls, p->vox(h.lvl), e.st,
                              fuse ? e.f(fuse_in->st.mean) : nullptr, fuse ? e.f(fuse_in->st.rstd) : nullptr,
-                             fuse ? e.f(p->inb_partials) : nullptr);
+                             fuse ? e.inbp() : nullptr);
 }
 
 }  // namespace
@@ -1177,31 +1223,56 @@ static int forward3d(hdf_plan* p, const float* x, const float* params, void* wor
   Xf none;
 
   HDF_TRY(hdf_launch_pack_batch(p->dtype, params, e.ws, p->pack_jobs.data(), (int)p->pack_jobs.size(), e.st));
-  // ---- multi-path transformer (HDenseFormer.py:230) -> attnall, then the UpConv chain (:231-235)
-  HDF_TRY(transformer_forward(e, x));
-  HDF_TRY(conv_forward(e, p->deep, p->attnall, none));
-  HDF_TRY(hdf_launch_upsample_fwd(p->dtype, e.at(p->deep.y), p->deep.y.pitch, e.f(p->deep.st.scale),
-                                  e.f(p->deep.st.shift), e.at(p->attnout), p->attnout.pitch, batch, 8 * nf,
-                                  p->dims[4][0], p->dims[4][1], p->dims[4][2], e.st));
+  // ---- multi-path transformer (HDenseFormer.py:230) -> attnall, then the UpConv chain (:231-235).  Nothing on the
+  // encoder's first level depends on it before ds0 = block_1_2_left(..) + at3 (:238), and it is ~100 launches of
+  // latency-bound token / attention kernels plus low-resolution convs: it runs on the plan's BRANCH stream next to the
+  // two 128^3 encoder convs of the caller's stream (matrix-bound at the package power cap, one wave per SIMD) and is
+  // joined in front of the level-0 encoder tail.  HDF_NO_BRANCH_OVERLAP=1 keeps everything on the caller's stream.
+  static const bool no_branch = getenv("HDF_NO_BRANCH_OVERLAP") != nullptr;  // A/B knob (tests/test_gpu_knobs.py)
+  Exec eb = e;
+  hipStream_t bst = no_branch ? nullptr : e.fork_branch();
+  if (bst) eb.st = bst, eb.on_branch = true;
+  struct Rejoin {  // error returns below must not leave branch-stream work unordered behind the caller's stream
+    Exec &e, &eb;
+    bool armed;
+    ~Rejoin() {
+      if (armed) (void)e.join_branch(eb);
+    }
+  } rejoin{e, eb, bst != nullptr};
+  // the caller's stream first (3 launches), then the ~65 launches of the branch: the host issues launches one after the
+  // other, and whatever is issued second starts that much later when the host is not far ahead of the GPU
+  HDF_TRY(hdf_launch_nchw_to_ndhwc(p->dtype, x, e.at(p->xin), batch, p->M, 16, p->vox(0), e.st));
+  HDF_TRY(conv_forward(e, p->enc[0][0], p->xin, none));
+  HDF_TRY(conv_forward(e, p->enc[0][1], p->enc[0][0].y, xf_of(e, p->enc[0][0])));
+  HDF_TRY(transformer_forward(eb, x));
+  HDF_TRY(conv_forward(eb, p->deep, p->attnall, none));
+  HDF_TRY(hdf_launch_upsample_fwd(p->dtype, eb.at(p->deep.y), p->deep.y.pitch, eb.f(p->deep.st.scale),
+                                  eb.f(p->deep.st.shift), eb.at(p->attnout), p->attnout.pitch, batch, 8 * nf,
+                                  p->dims[4][0], p->dims[4][1], p->dims[4][2], eb.st));
   {
     const View* src = &p->attnout;
     for (int k = 0; k < 3; k++) {  // up1 -> at1 (lvl 2), up2 -> at2 (lvl 1), up3 -> at3 (lvl 0)
       Conv3& c = p->up[k];
-      HDF_TRY(conv_forward(e, c, *src, none));
+      HDF_TRY(conv_forward(eb, c, *src, none));
       const View& dst = p->at[2 - k];
-      HDF_TRY(hdf_launch_upsample_fwd(p->dtype, e.at(c.y), c.y.pitch, e.f(c.st.scale), e.f(c.st.shift), e.at(dst),
+      HDF_TRY(hdf_launch_upsample_fwd(p->dtype, eb.at(c.y), c.y.pitch, eb.f(c.st.scale), eb.f(c.st.shift), eb.at(dst),
                                       dst.pitch, batch, c.Cout, p->dims[c.lvl][0], p->dims[c.lvl][1],
-                                      p->dims[c.lvl][2], e.st));
+                                      p->dims[c.lvl][2], eb.st));
       src = &dst;
     }
   }
   // ---- encoder (:237-244)
-  HDF_TRY(hdf_launch_nchw_to_ndhwc(p->dtype, x, e.at(p->xin), batch, p->M, 16, p->vox(0), e.st));
   const View* cur = &p->xin;
   for (int k = 0; k < 4; k++) {
-    HDF_TRY(conv_forward(e, p->enc[k][0], *cur, none));
-    HDF_TRY(conv_forward(e, p->enc[k][1], p->enc[k][0].y, xf_of(e, p->enc[k][0])));
+    if (k > 0) {  // (level 0: issued above, in front of the branch)
+      HDF_TRY(conv_forward(e, p->enc[k][0], *cur, none));
+      HDF_TRY(conv_forward(e, p->enc[k][1], p->enc[k][0].y, xf_of(e, p->enc[k][0])));
+    }
     Conv3& c = p->enc[k][1];
+    if (k == 0 && bst) {  // at1..3 / attnout are needed from here on
+      HDF_TRY(e.join_branch(eb));
+      rejoin.armed = false;
+    }
     if (k < 3) {
       View ds = subview(p, p->cat[k], ch[k], ch[k]);
       // ds_k = relu(IN(y)) + at_k ; pooled = MaxPool(ds_k): one fused pass
@@ -1263,6 +1334,35 @@ int hdf_backward_stages(hdf_plan* p, const float* x, const float* params, void* 
   return launch_extract2d(p, stages, g3, grads, st);
 }
 
+// ---- UpConv chain backward: at3 <- up3 <- at2 <- up2 <- at1 <- up1 <- attnout <- deep_conv <- attnall
+static int upconv_chain_backward(Exec& e, int batch) {
+  hdf_plan* p = e.p;
+  Xf none;
+  for (int k = 2; k >= 0; k--) {
+    Conv3& c = p->up[k];                                   // up[k] output level c.lvl, upsampled to level c.lvl-1
+    View dat = p->dSkip[c.lvl - 1];  // gradient of at_{..} == of ds
+    const int* d = p->dims[c.lvl];
+    View& da = p->dUa[4 - c.lvl];
+    View& dy = p->dUy[4 - c.lvl];
+    HDF_TRY(hdf_launch_upsample_bwd(p->dtype, e.at(dat), dat.pitch, e.at(da), da.pitch, batch, c.Cout, d[0], d[1], d[2],
+                                    e.st));
+    HDF_TRY(in_backward(e, c, da, dy));
+    // input of up[k]: attnout (k==0) or at_{lvl} ; its gradient buffer already holds the skip-path gradient
+    const View& cin = (k == 0) ? p->attnout : p->at[c.lvl];
+    View din = (k == 0) ? p->dX4 : p->dSkip[c.lvl];
+    HDF_TRY(conv_backward(e, c, dy, cin, none, &din, 1));
+  }
+  {
+    Conv3& c = p->deep;
+    const int* d = p->dims[4];
+    HDF_TRY(hdf_launch_upsample_bwd(p->dtype, e.at(p->dX4), p->dX4.pitch, e.at(p->dUa[0]), p->dUa[0].pitch, batch,
+                                    c.Cout, d[0], d[1], d[2], e.st));
+    HDF_TRY(in_backward(e, c, p->dUa[0], p->dUy[0]));
+    HDF_TRY(conv_backward(e, c, p->dUy[0], p->attnall, none, &p->dAttnall, 0));
+  }
+  return HDF_OK;
+}
+
 static int backward3d(hdf_plan* p, const float* x, const float* params, void* workspace, int64_t workspace_bytes,
                       const void* dout0, const void* dout1, const void* dout2, const void* dout3, float* grads,
                       int batch, int stages, hdf_stream stream) {
@@ -1275,8 +1375,7 @@ static int backward3d(hdf_plan* p, const float* x, const float* params, void* wo
       // lowest priority: when a data-gradient conv (critical path) and a weight gradient are both ready, the data
       // gradient gets the CUs first and the weight gradient then runs next to the memory-bound passes that follow it
       int least = 0, greatest = 0;
-      static const bool flat_prio = getenv("HDF_SIDE_STREAM_FLAT_PRIORITY") != nullptr;  // A/B knob
-      if (flat_prio || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
+      if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
           hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, least) != hipSuccess) {
         if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess) p->side = nullptr;
       }
@@ -1287,6 +1386,24 @@ static int backward3d(hdf_plan* p, const float* x, const float* params, void* wo
   const int ch[4] = {nf, 2 * nf, 4 * nf, 8 * nf};
   const void* douts[4] = {dout0, dout1, dout2, dout3};
   Xf none;
+  // one call for all three stages: stages 2 and 4 fork onto the branch stream inside stage 1 (see the encoder loop).
+  // Both streams send their weight gradients through the side stream (in order: one shared workspace), so the fork
+  // needs it.  Staged calls (gradient buckets of hdf_rt.parallel) keep the three stages in order on the caller's stream.
+  static const bool no_branch = getenv("HDF_NO_BRANCH_OVERLAP") != nullptr;  // A/B knob (tests/test_gpu_knobs.py)
+  const bool fork_ok = stages == 7 && e.async && !no_branch;
+  bool forked = false;
+  Exec eb = e;
+  eb.last_side = nullptr;
+  // every return path (also the HDF_TRY error returns) orders the side and branch streams behind the caller's stream:
+  // the caller may free or reuse the workspace / gradient buffers as soon as its own stream gets there
+  struct Rejoin {
+    Exec &e, &eb;
+    bool& forked;
+    ~Rejoin() {
+      if (forked) (void)e.join_branch(eb);
+      e.join();
+    }
+  } rejoin{e, eb, forked};
   if (stages & 1) {
   hipError_t me = hipMemsetAsync(grads, 0, (size_t)p->total_floats * sizeof(float), e.st);
   if (me != hipSuccess) {
@@ -1328,6 +1445,16 @@ static int backward3d(hdf_plan* p, const float* x, const float* params, void* wo
                                      e.at(dskip), dskip.pitch, batch, ch[k], p->dims[k + 1][0], p->dims[k + 1][1],
                                      p->dims[k + 1][2], 1, e.st));
     }
+    hipStream_t bst = nullptr;
+    if (k == 0 && fork_ok) {
+      // d(ds_0) = d(at3) is final: the UpConv chain and the transformer branches (stages 2 and 4: ~110 launches, mostly
+      // latency-bound) go to the branch stream and run NEXT TO the level-0 encoder backward below (two InstanceNorm
+      // backward passes at 128^3, a 32->32 data-gradient conv and two weight gradients), which is all that is left on
+      // the caller's stream.  The chain only READS d(ds_k) of the levels the encoder has already finished with (it
+      // accumulates into dSkip[1], dSkip[2] and dX4, which the loop above consumed at k = 1, 2, 3).  The fork point is
+      // recorded here; the branch launches are issued AFTER the level-0 launches of the caller's stream (host order).
+      bst = e.fork_branch();
+    }
     HDF_TRY(in_backward(e, c2, dskip, p->gY[k]));
     HDF_TRY(conv_backward(e, c2, p->gY[k], c1.y, xf_of(e, c1), &p->gA[k], 0));
     HDF_TRY(in_backward(e, c1, p->gA[k], p->gY2[k]));
@@ -1335,38 +1462,26 @@ static int backward3d(hdf_plan* p, const float* x, const float* params, void* wo
       HDF_TRY(conv_backward(e, c1, p->gY2[k], p->pooled[k - 1], none, &p->dP[k - 1], 0));
     else
       HDF_TRY(conv_backward(e, c1, p->gY2[k], p->xin, none, nullptr, 0));
+    if (bst) {
+      eb.st = bst, eb.on_branch = true, eb.async = e.async;
+      forked = true;
+      HDF_TRY(upconv_chain_backward(eb, batch));
+      HDF_TRY(transformer_backward(eb, x));
+    }
   }
 
   if (!(stages & 6)) e.join();  // staged call (gradient buckets): final when it returns
   }  // stage 1: every gradient of the encoder / decoder / head parameters is final here
-  if (stages & 2) {
-
-  // ---- UpConv chain: at3 <- up3 <- at2 <- up2 <- at1 <- up1 <- attnout <- deep_conv <- attnall
-  for (int k = 2; k >= 0; k--) {
-    Conv3& c = p->up[k];                                   // up[k] output level c.lvl, upsampled to level c.lvl-1
-    View dat = p->dSkip[c.lvl - 1];  // gradient of at_{..} == of ds
-    const int* d = p->dims[c.lvl];
-    View& da = p->dUa[4 - c.lvl];
-    View& dy = p->dUy[4 - c.lvl];
-    HDF_TRY(hdf_launch_upsample_bwd(p->dtype, e.at(dat), dat.pitch, e.at(da), da.pitch, batch, c.Cout, d[0], d[1], d[2],
-                                    e.st));
-    HDF_TRY(in_backward(e, c, da, dy));
-    // input of up[k]: attnout (k==0) or at_{lvl} ; its gradient buffer already holds the skip-path gradient
-    const View& cin = (k == 0) ? p->attnout : p->at[c.lvl];
-    View din = (k == 0) ? p->dX4 : p->dSkip[c.lvl];
-    HDF_TRY(conv_backward(e, c, dy, cin, none, &din, 1));
+  if (forked) {
+    HDF_TRY(e.join_branch(eb));
+    forked = false;
+  } else {
+    if (stages & 2) {
+      HDF_TRY(upconv_chain_backward(e, batch));
+      if (!(stages & 4)) e.join();  // staged call: final when it returns; else the transformer branches run under them
+    }  // stage 2: deep_conv / up1..3 gradients are final
+    if (stages & 4) HDF_TRY(transformer_backward(e, x));
   }
-  {
-    Conv3& c = p->deep;
-    const int* d = p->dims[4];
-    HDF_TRY(hdf_launch_upsample_bwd(p->dtype, e.at(p->dX4), p->dX4.pitch, e.at(p->dUa[0]), p->dUa[0].pitch, batch,
-                                    c.Cout, d[0], d[1], d[2], e.st));
-    HDF_TRY(in_backward(e, c, p->dUa[0], p->dUy[0]));
-    HDF_TRY(conv_backward(e, c, p->dUy[0], p->attnall, none, &p->dAttnall, 0));
-  }
-  if (!(stages & 4)) e.join();  // staged call: final when it returns; else the transformer branches run under them
-  }  // stage 2: deep_conv / up1..3 gradients are final
-  if (stages & 4) HDF_TRY(transformer_backward(e, x));
   e.join();
   return HDF_OK;
 }

@@ -1,0 +1,57 @@
+"""Every environment knob the library still reads selects another ARRANGEMENT of the same kernels (streams), never
+other arithmetic: a step under each knob must reproduce the default step -- convolution weight gradients bit for bit
+(fixed-order sums), everything else (float atomics in the bias / LayerNorm / head gradients) to 1e-4.  The knobs are read
+once per process, so each configuration runs tools/knob_check.py in its own process.  (Round 2 carried 22 knobs that
+switched to older kernels nothing tested; round 3 deleted those kernels and their knobs.)"""
+import json
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KNOBS = ["HDF_NO_BRANCH_OVERLAP", "HDF_NO_ASYNC_WGRAD"]
+
+
+def _run(env_extra):
+    env = dict(os.environ, **env_extra)
+    for k in KNOBS:
+        if k not in env_extra:
+            env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "knob_check.py")], capture_output=True, text=True,
+                       timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+@pytest.fixture(scope="module")
+def default_run():
+    return _run({})
+
+
+def test_the_knob_list_is_the_set_of_getenv_calls_in_the_sources():
+    found = set()
+    src = os.path.join(ROOT, "h-denseformer_amd", "csrc")
+    for f in os.listdir(src):
+        found |= set(re.findall(r'getenv\("([A-Z0-9_]+)"\)', open(os.path.join(src, f)).read()))
+    assert found == set(KNOBS), found
+
+
+def test_default_step_is_reproducible(default_run):
+    a, b = default_run["step0"], default_run["step1"]
+    assert a["loss"] == b["loss"]
+    assert a["crcs"] == b["crcs"] and len(a["crcs"]) >= 20
+
+
+@pytest.mark.parametrize("knob", KNOBS)
+def test_step_under_knob_matches_the_default_step(default_run, knob):
+    ref = default_run["step1"]
+    got = _run({knob: "1"})["step1"]
+    assert abs(got["loss"] - ref["loss"]) <= 1e-6 * abs(ref["loss"])
+    assert got["crcs"] == ref["crcs"]
+    for n, v in ref["norms"].items():
+        assert abs(got["norms"][n] - v) <= 1e-4 * v + 1e-9, n

@@ -75,8 +75,6 @@ def test_forward_fp32_vs_oracle_and_golden(cfg, batch, tag):
     for k, v in inter.items():
         if k.startswith(("dec", "cat")):   # never materialised on the HIP path (fused into consumers)
             continue
-        if k == "at3" and os.environ.get("HDF_FUSE_AT3"):
-            continue
         errs.append((k, _rel(rt.read_buffer(k), v)))
     for i in range(4):
         errs.append((f"out{i}", _rel(outs[i], ref_outs[i])))

@@ -51,7 +51,8 @@ else:
         check(lib().hdf_op_conv3d_wgrad(dt, 1, ptr(dy), cout, cout, ptr(x), cin, cin, n, s, s, s, None, None, 0, None,
                                         None, 0, ptr(dw), cout, cin, 0, ptr(ws), wsb, st), "wgrad")
     flops = 2.0 * 27 * cin * cout * s ** 3 * n
-launch()
+for _ in range(1 if a.cold else 15):      # clocks ramp over the first launches: time the settled state
+    launch()
 torch.cuda.synchronize()
 if a.cold:
     junk = torch.empty(1 << 30, dtype=torch.uint8, device=dev)   # 1 GiB > L2 + 256 MB memory-side cache
@@ -85,6 +86,11 @@ if os.environ.get("WS_STAMPS") and a.op == "conv":
         end = start + dur
         cyc = t[:, 7]
         q = lambda v: [round(float(x), 1) for x in torch.quantile(v, torch.tensor([0.0, 0.1, 0.5, 0.9, 1.0], dtype=torch.float64))]
+        ent = part[2048:2048 + 256].view(torch.int32).cpu().long() & 0xFFFFFFFF
+        setup = ((t0 - ent) & 0xFFFFFFFF).double() / 100.0
+        print("  per-WG us from kernel entry to the first stamp (weight staging + per-lane setup):", q(setup),
+              "; entry spread", q(((ent - ent.min()) & 0xFFFFFFFF).double() / 100.0),
+              "; entry of the first WG to the end of the last: %.1f" % float((((t1 - ent.min()) & 0xFFFFFFFF).double() / 100.0).max()))
         print("  per-WG us: start", q(start), "duration", q(dur), "end", q(end))
         print("  in-kernel clock GHz (cycles / real time):", q(cyc / dur / 1e3))
         for x in range(8):

@@ -1,4 +1,4 @@
-"""Diagnostic: patch-embedding forward of the HIP kernel against a float64 reference (run with and without HDF_PE_OLD=1)."""
+"""Diagnostic: patch-embedding forward of the HIP kernel against a float64 reference."""
 import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
