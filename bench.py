@@ -67,7 +67,7 @@ def _cpu_baseline_child():
 
     what = "oracle train step (fwd + DeepSuper CE+Dice + bwd + Adam), fp32"
     t64 = time_steps(64, 1, 2)
-    rec = {"value": 1.0 / (8.0 * t64), "unit": "samples/s", "cores": nt, "kind": "port",
+    rec = {"value": 1.0 / (8.0 * t64), "unit": "samples/s", "cores": nt, "host_logical_cpus": os.cpu_count(), "kind": "port",
            "sample": f"{what}, batch 1 of a 4x64^3 crop: {t64:.2f} s/step on {nt} threads, scaled x8 voxels to 4x128^3"}
     print(json.dumps(rec), flush=True)
     if 8.0 * t64 < 12.0:
@@ -98,7 +98,7 @@ def cpu_baseline():
         out = (e.stdout or b"").decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
     lines = [l for l in out.splitlines() if l.startswith("{")]
     if not lines:
-        return {"value": None, "unit": "samples/s", "cores": CPU_THREADS, "kind": "port",
+        return {"value": None, "unit": "samples/s", "cores": CPU_THREADS, "host_logical_cpus": os.cpu_count(), "kind": "port",
                 "sample": f"oracle train step did not finish a 4x64^3 crop within {CPU_BUDGET_S} s"}
     return json.loads(lines[-1])
 

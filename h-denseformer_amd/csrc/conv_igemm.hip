@@ -2698,7 +2698,9 @@ int launch_conv_t(int mode, const ConvArgs& a, hipStream_t st) {
     return launch_cfg<T, 4, 8, 8, 2, 2, 4, 1, false>(a, st);                                     // 256 vox x 64 ch
   } else if (mode == 1) {
     if constexpr (sizeof(T) == 2) {
-      if (a.Cin * 2 == 64 && a.CoutP == 64 && !a.in_scale && !a.accumulate && a.Do % 4 == 0 && a.Ho % 4 == 0 &&
+      // (st_rows2: one dword per lane pair = channels (c, c + 1): even channel count / pitch, 4-byte aligned view)
+      if (a.Cin * 2 == 64 && a.CoutP == 64 && a.Cout % 2 == 0 && a.out_pitch % 2 == 0 &&
+          (reinterpret_cast<uintptr_t>(a.out) & 3) == 0 && !a.in_scale && !a.accumulate && a.Do % 4 == 0 && a.Ho % 4 == 0 &&
           a.Wo % 4 == 0 && a.Di == 2 * a.Do && a.Hi == 2 * a.Ho && a.Wi == 2 * a.Wo) {
         const int tiles = a.N * (a.Do / 4) * (a.Ho / 4) * (a.Wo / 4);
         hipLaunchKernelGGL((conv_gather_s2_kernel<T>), dim3(std::min(tiles, hdf_cu_budget())), dim3(256), 0, st, a);
@@ -2710,7 +2712,8 @@ int launch_conv_t(int mode, const ConvArgs& a, hipStream_t st) {
     return launch_cfg<T, 4, 4, 4, 1, 4, 2, 2, false>(a, st);  // 64 vox x 128 ch, stride 2
   } else {
     if constexpr (sizeof(T) == 2) {
-      if (a.Cin * 2 == 128 && a.CoutP == 32 && !a.accumulate && a.Di % 4 == 0 && a.Hi % 4 == 0 && a.Wi % 8 == 0 &&
+      if (a.Cin * 2 == 128 && a.CoutP == 32 && a.Cout % 2 == 0 && a.out_pitch % 2 == 0 &&
+          (reinterpret_cast<uintptr_t>(a.out) & 3) == 0 && !a.accumulate && a.Di % 4 == 0 && a.Hi % 4 == 0 && a.Wi % 8 == 0 &&
           a.Do == 2 * a.Di && a.Ho == 2 * a.Hi && a.Wo == 2 * a.Wi) {
         const int tiles = a.N * (a.Di / 4) * (a.Hi / 4) * (a.Wi / 8);
         hipLaunchKernelGGL((convt_ws_kernel<T>), dim3(std::min(tiles, hdf_cu_budget())), dim3(256), 0, st, a);

@@ -173,6 +173,7 @@ struct hdf_plan {
   // layout for the current batch
   int batch = -1;
   size_t ws_bytes = 0;
+  size_t ws_fwd_bytes = 0;  // prefix of the workspace a forward-only (inference) call touches
   std::map<std::string, View> bufs;
   // forward buffers
   View xin, attnall, attnout, at[3] /*at[k] lives at level k*/, cat[3], pooled[3], x4;
@@ -546,6 +547,10 @@ void layout(hdf_plan* p, int B) {
       for (int rb : {32, 1 << 20}) mt = std::max<size_t>(mt, hdf_conv_stat_tiles(0, p->dims[l][0], p->dims[l][1], p->dims[l][2], rb));
     p->stat_partials2 = bp.take((size_t)B * mt * round_up(8 * nf, 32) * 2 * sizeof(float));
   }
+  // Everything above is what a forward touches: an inference-only caller (eval / sliding-window prediction) can hand
+  // over just this prefix (hdf_plan_inference_workspace_bytes); the backward scratch below -- transformer tapes, second
+  // dy buffers, the 128 MB weight-gradient workspace, ... -- is more than half of the arena at the benchmark size.
+  p->ws_fwd_bytes = bp.cur;
   // ---- backward scratch
   p->tf_scratch = bp.take((size_t)rows * std::max(160, p->DM) * sizeof(float));
   p->tf_dF = bp.take((size_t)rows * p->DMF * sizeof(float));
@@ -1158,6 +1163,10 @@ int64_t hdf_plan_workspace_bytes(hdf_plan* p, int batch) {
   layout(p, batch);
   return (int64_t)p->ws_bytes;
 }
+int64_t hdf_plan_inference_workspace_bytes(hdf_plan* p, int batch) {
+  layout(p, batch);
+  return (int64_t)p->ws_fwd_bytes;
+}
 
 int hdf_plan_buffer_info(hdf_plan* p, int batch, const char* name, int64_t* byte_offset, int64_t* pitch_elems,
                          int* channels, int* d, int* h, int* w) {
@@ -1188,8 +1197,8 @@ int hdf_forward(hdf_plan* p, const float* x, const float* params, void* workspac
     return forward3d(p, x, params, workspace, workspace_bytes, out0, out1, out2, out3, batch, training, seed, stream);
   // 2-D model: x [B,C,H,W], params = the 2-D flat buffer, outputs [B,n_cls,H/2^i,W/2^i]
   layout(p, batch);
-  HDF_CHECK_ARG((size_t)workspace_bytes >= p->ws_bytes, "forward: workspace %lld < %zu bytes", (long long)workspace_bytes,
-                p->ws_bytes);
+  HDF_CHECK_ARG((size_t)workspace_bytes >= p->ws_fwd_bytes, "forward: workspace %lld < %zu bytes",
+                (long long)workspace_bytes, p->ws_fwd_bytes);
   char* ws = (char*)workspace;
   hipStream_t st = (hipStream_t)stream;
   float* p3 = (float*)(ws + p->e_params3d);
@@ -1212,8 +1221,8 @@ static int forward3d(hdf_plan* p, const float* x, const float* params, void* wor
                      void* out0, void* out1, void* out2, void* out3, int batch, int training, uint64_t seed,
                      hdf_stream stream) {
   layout(p, batch);
-  HDF_CHECK_ARG((size_t)workspace_bytes >= p->ws_bytes, "forward: workspace %lld < %zu bytes", (long long)workspace_bytes,
-                p->ws_bytes);
+  HDF_CHECK_ARG((size_t)workspace_bytes >= p->ws_fwd_bytes, "forward: workspace %lld < %zu bytes",
+                (long long)workspace_bytes, p->ws_fwd_bytes);
   p->training = training ? 1 : 0;
   p->seed = (uint32_t)(seed & 0xffffffffu);
   Exec e{p, (char*)workspace, params, nullptr, batch, (hipStream_t)stream};
@@ -1367,7 +1376,9 @@ static int backward3d(hdf_plan* p, const float* x, const float* params, void* wo
                       const void* dout0, const void* dout1, const void* dout2, const void* dout3, float* grads,
                       int batch, int stages, hdf_stream stream) {
   HDF_CHECK_ARG(p->batch == batch, "backward: batch %d differs from the forward's %d", batch, p->batch);
-  HDF_CHECK_ARG((size_t)workspace_bytes >= p->ws_bytes, "backward: workspace too small");
+  HDF_CHECK_ARG((size_t)workspace_bytes >= p->ws_bytes,
+                "backward: workspace of %lld bytes holds a forward only (hdf_plan_workspace_bytes = %zu)",
+                (long long)workspace_bytes, p->ws_bytes);
   Exec e{p, (char*)workspace, params, grads, batch, (hipStream_t)stream};
   static const bool no_async = getenv("HDF_NO_ASYNC_WGRAD") != nullptr;  // A/B knob: everything on the caller's stream
   if (!no_async) {

@@ -104,10 +104,12 @@ def compute_dice(logits, target_onehot, ignore_index=0):
 class RunningDice:
     """Drop-in for metrics.RunningDice (metrics.py:82-151) with the confusion matrix accumulated on the GPU.
 
-    update_matrix(ground_truth, prediction) takes what the reference takes -- two class maps (numpy arrays or
-    tensors of any integer / float dtype, any shape; trainer.py:393-398 passes the argmax maps) -- and also the
-    pair (one-hot target, logits) straight from the step, in which case no argmax map is ever materialised.  As in
-    the reference, an update whose ground truth consists only of `ignore_label` is dropped (metrics.py:122-124).
+    update_matrix(ground_truth, prediction) takes exactly what the reference takes -- two CLASS MAPS (numpy arrays or
+    tensors of any integer / float dtype and any shape; trainer.py:393-398 passes the argmax maps).  The pair
+    (one-hot target, logits) straight from the step goes through update_from_logits(), which never materialises an
+    argmax map; the two forms are separate methods because a float class map of shape [B, H, W] cannot be told from
+    a score tensor by dtype and shape.  As in the reference, an update whose ground truth consists only of
+    `ignore_label` is dropped (metrics.py:122-124) -- decided on the device, without a host sync.
     compute_dice() does one 512-byte D2H."""
 
     def __init__(self, labels, ignore_label=0):
@@ -115,46 +117,50 @@ class RunningDice:
         self.ignore_label = ignore_label
         self.conf = None
 
-    @staticmethod
-    def _is_scores(a, b):
-        return (torch.is_tensor(a) and torch.is_tensor(b) and a.dim() >= 3 and a.shape == b.shape
-                and a.is_floating_point() and b.is_floating_point())
+    def _accumulate(self, cur, all_ignore):
+        # `if (ground_truth == self.ignore_label).all(): return`: the update is multiplied by 0 instead
+        cur = cur * (~all_ignore).to(cur.dtype)
+        self.conf = cur if self.conf is None else self.conf + cur
+
+    def update_from_logits(self, target_onehot, logits):
+        """target_onehot, logits: [B, C, *spatial] floating tensors on the GPU with C == len(labels)."""
+        c = len(self.labels)
+        if not (torch.is_tensor(target_onehot) and torch.is_tensor(logits) and logits.is_cuda and logits.dim() >= 3
+                and target_onehot.shape == logits.shape and logits.shape[1] == c):
+            raise _lib.HdfError(f"RunningDice.update_from_logits: expected two [B, {c}, ...] GPU tensors of one shape, "
+                                f"got {getattr(target_onehot, 'shape', None)} and {getattr(logits, 'shape', None)}")
+        lg = logits.detach().contiguous()
+        tg = target_onehot.detach().float().contiguous()
+        if lg.dtype not in _DT:
+            raise _lib.HdfError(f"RunningDice: unsupported logits dtype {lg.dtype}")
+        cur = torch.zeros((8, 8), dtype=torch.int64, device=lg.device)
+        check(lib().hdf_confusion_matrix(_DT[lg.dtype], ptr(lg), ptr(tg), lg.shape[0], lg.shape[1],
+                                         lg[0, 0].numel(), ptr(cur), 0, stream_ptr()), "hdf_confusion_matrix")
+        ig = self.ignore_label
+        rows = cur.sum(1)       # every voxel is counted (argmax < C): all-ignore <=> only row `ig` is populated
+        all_ignore = (rows.sum() == rows[ig]) if isinstance(ig, int) and 0 <= ig < c else torch.zeros((), dtype=torch.bool, device=lg.device)
+        self._accumulate(cur, all_ignore)
 
     def update_matrix(self, ground_truth, prediction):
         c = len(self.labels)
-        if self._is_scores(ground_truth, prediction):
-            lg = prediction.detach().contiguous()
-            tg = ground_truth.detach().float().contiguous()
-            if lg.dtype not in _DT:
-                raise _lib.HdfError(f"RunningDice: unsupported logits dtype {lg.dtype}")
-            dev = lg.device
-            cur = torch.zeros((8, 8), dtype=torch.int64, device=dev)
-            check(lib().hdf_confusion_matrix(_DT[lg.dtype], ptr(lg), ptr(tg), lg.shape[0], lg.shape[1],
-                                             lg[0, 0].numel(), ptr(cur), 0, stream_ptr()), "hdf_confusion_matrix")
-        else:
-            dev = self.conf.device if self.conf is not None else (
-                prediction.device if torch.is_tensor(prediction) and prediction.is_cuda else
-                ground_truth.device if torch.is_tensor(ground_truth) and ground_truth.is_cuda else
-                torch.device("cuda", torch.cuda.current_device()))
-            if dev.type != "cuda":
-                raise _lib.HdfError("RunningDice needs a GPU (there is no CPU path)")
-            gt = torch.as_tensor(ground_truth).to(dev).flatten()
-            pr = torch.as_tensor(prediction).to(dev).flatten()
-            if gt.numel() != pr.numel():
-                raise ValueError("ground_truth and prediction differ in size")
-            # labels outside [0, 255) (e.g. a negative ignore value) must not alias a class after the uint8 cast
-            gt = torch.where((gt >= 0) & (gt < 255), gt, torch.full_like(gt, 255)).to(torch.uint8).contiguous()
-            pr = torch.where((pr >= 0) & (pr < 255), pr, torch.full_like(pr, 255)).to(torch.uint8).contiguous()
-            cur = torch.zeros((8, 8), dtype=torch.int64, device=dev)
-            check(lib().hdf_confusion_matrix_labels(ptr(gt), ptr(pr), c, gt.numel(), ptr(cur), 0, stream_ptr()),
-                  "hdf_confusion_matrix_labels")
-        # `if (ground_truth == self.ignore_label).all(): return` without a host sync: the update is multiplied by 0
-        # when every counted ground-truth voxel sits in the ignore_label row
-        ig = self.ignore_label
-        if isinstance(ig, int) and 0 <= ig < 8:
-            rows = cur.sum(1)
-            cur = cur * (rows.sum() != rows[ig]).to(cur.dtype)
-        self.conf = cur if self.conf is None else self.conf + cur
+        dev = self.conf.device if self.conf is not None else (
+            prediction.device if torch.is_tensor(prediction) and prediction.is_cuda else
+            ground_truth.device if torch.is_tensor(ground_truth) and ground_truth.is_cuda else
+            torch.device("cuda", torch.cuda.current_device()))
+        if dev.type != "cuda":
+            raise _lib.HdfError("RunningDice needs a GPU (there is no CPU path)")
+        gt0 = torch.as_tensor(ground_truth).to(dev).flatten()
+        pr = torch.as_tensor(prediction).to(dev).flatten()
+        if gt0.numel() != pr.numel():
+            raise ValueError("ground_truth and prediction differ in size")
+        all_ignore = (gt0 == self.ignore_label).all()        # over EVERY voxel, like the reference (labels >= n_cls too)
+        # labels outside [0, 255) (e.g. a negative ignore value) must not alias a class after the uint8 cast
+        gt = torch.where((gt0 >= 0) & (gt0 < 255), gt0, torch.full_like(gt0, 255)).to(torch.uint8).contiguous()
+        pr = torch.where((pr >= 0) & (pr < 255), pr, torch.full_like(pr, 255)).to(torch.uint8).contiguous()
+        cur = torch.zeros((8, 8), dtype=torch.int64, device=dev)
+        check(lib().hdf_confusion_matrix_labels(ptr(gt), ptr(pr), c, gt.numel(), ptr(cur), 0, stream_ptr()),
+              "hdf_confusion_matrix_labels")
+        self._accumulate(cur, all_ignore)
 
     def compute_dice(self, smooth=1e-5):
         import numpy as np

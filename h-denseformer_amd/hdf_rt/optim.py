@@ -18,12 +18,15 @@ class FlatAdam:
         self._state_for = None
 
     def _state(self):
-        flat = self.model.flat_parameters()
+        # the list the last forward verified: no second walk over the 1 420 parameters per step (1.5 ms of host time)
+        flat = self.model.flat_parameters(self.model.checked_parameters())
         if self._state_for is None or self._state_for.data_ptr() != flat.data_ptr():
+            # a new flat buffer (module moved / re-flattened): the moments restart, and so does the bias correction
             self.exp_avg = torch.zeros_like(flat)
             self.exp_avg_sq = torch.zeros_like(flat)
             self.mask = self.model.weight_decay_mask()
             self._state_for = flat
+            self.step_count = 0
         return flat
 
     def zero_grad(self, set_to_none=True):

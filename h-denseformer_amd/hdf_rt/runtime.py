@@ -47,8 +47,11 @@ class Plan:
         except Exception:
             pass
 
-    def workspace_bytes(self, batch):
-        return lib().hdf_plan_workspace_bytes(self.h, batch)
+    def workspace_bytes(self, batch, backward=True):
+        """bytes of the arena for a training step, or (backward=False) of the prefix a forward alone touches"""
+        if backward:
+            return lib().hdf_plan_workspace_bytes(self.h, batch)
+        return lib().hdf_plan_inference_workspace_bytes(self.h, batch)
 
     def buffer_info(self, batch, name):
         off, pitch = C.c_int64(), C.c_int64()
@@ -67,19 +70,21 @@ class Runtime:
         self.device = device
         self.ws = None
         self.ws_batch = -1
+        self.ws_backward = False    # the arena includes the backward scratch
         self.gen = 0            # forward generation; backward must match (single forward in flight)
         self.out_shapes = None
 
-    def _ensure_ws(self, batch):
-        if self.ws is None or self.ws_batch != batch:
+    def _ensure_ws(self, batch, backward):
+        """Inference (no autograd graph) gets the forward prefix only: less than half of the training arena."""
+        if self.ws is None or self.ws_batch != batch or (backward and not self.ws_backward):
             self.ws = None
-            self.ws = torch.empty(self.plan.workspace_bytes(batch), dtype=torch.uint8, device=self.device)
-            self.ws_batch = batch
+            self.ws = torch.empty(self.plan.workspace_bytes(batch, backward), dtype=torch.uint8, device=self.device)
+            self.ws_batch, self.ws_backward = batch, backward
 
-    def forward(self, x, flat_params, training, seed):
+    def forward(self, x, flat_params, training, seed, need_backward=True):
         cfg = self.plan.cfg
         b = x.shape[0]
-        self._ensure_ws(b)
+        self._ensure_ws(b, need_backward)
         tdt = _TORCH_DTYPE[self.plan.dtype]
         outs = [torch.empty((b, cfg[1]) + tuple(s >> i for s in cfg[3]), dtype=tdt, device=self.device)
                 for i in range(4)]
@@ -115,7 +120,7 @@ class HDFFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, anchor, module, rt, training, seed):
-        outs = rt.forward(x, module._flat, training, seed)
+        outs = rt.forward(x, module._flat, training, seed, need_backward=bool(anchor.requires_grad))
         ctx.module, ctx.rt, ctx.gen = module, rt, rt.gen
         ctx.save_for_backward(x)
         return tuple(outs)

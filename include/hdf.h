@@ -51,6 +51,9 @@ int64_t hdf_plan_param_floats(const hdf_plan* p);
 int hdf_plan_param_info(const hdf_plan* p, int64_t idx, char* name, int name_cap, int64_t* offset, int64_t* numel,
                         int* ndim, int64_t* shape5);
 int64_t hdf_plan_workspace_bytes(hdf_plan* p, int batch);
+/* the prefix of that arena a forward touches: enough for hdf_forward when no hdf_backward follows (eval, sliding-window
+ * prediction); hdf_backward* refuse a workspace smaller than hdf_plan_workspace_bytes */
+int64_t hdf_plan_inference_workspace_bytes(hdf_plan* p, int batch);
 /* named activation buffers inside the workspace (debug / parity tests): channels-last views */
 int hdf_plan_buffer_info(hdf_plan* p, int batch, const char* name, int64_t* byte_offset, int64_t* pitch_elems,
                          int* channels, int* d, int* h, int* w);

@@ -316,11 +316,11 @@ def test_running_dice_confusion_matrix_vs_reference_golden(tag):
     onehot = torch.from_numpy(g[tag + "_onehot"].astype(np.float32)).to(DEV)
     c = logits.shape[1]
     rd = RunningDice(labels=range(c), ignore_label=-1)
-    rd.update_matrix(onehot, logits)
+    rd.update_from_logits(onehot, logits)
     mean, per = rd.compute_dice()
     assert abs(mean - float(g[tag + "_run_dice"])) < 1e-6
     assert np.allclose(per, g[tag + "_run_list"], atol=1e-4)
-    rd.update_matrix(onehot, logits)                       # running accumulation: doubling every count keeps the ratios
+    rd.update_from_logits(onehot, logits)                  # running accumulation: doubling every count keeps the ratios
     mean2, _ = rd.compute_dice()
     assert abs(mean2 - mean) < 1e-5
     # the reference's own call signature (metrics.py:104; trainer.py:393-398 passes numpy argmax maps)
@@ -331,15 +331,30 @@ def test_running_dice_confusion_matrix_vs_reference_golden(tag):
     assert hasattr(mean3, "item")
     # metrics.py:122-124: an update whose ground truth is all `ignore_label` is dropped (default ignore_label = 0)
     rd3 = RunningDice(labels=range(c), ignore_label=0)
-    rd3.update_matrix(onehot, logits)
+    rd3.update_from_logits(onehot, logits)
     before = rd3.conf.clone()
     bg = torch.zeros_like(onehot)
     bg[:, 0] = 1.0
-    rd3.update_matrix(bg, logits)
+    rd3.update_from_logits(bg, logits)
     rd3.update_matrix(np.zeros((2, 8, 8, 8), dtype=np.int64), logits.argmax(1).cpu().numpy())
     assert torch.equal(rd3.conf, before)
-    rd3.update_matrix(onehot, logits)
+    rd3.update_from_logits(onehot, logits)
     assert torch.equal(rd3.conf, 2 * before)
+    # a FLOAT class map of shape [B, H, W] is a class map (the reference accepts any dtype), never a score tensor ...
+    rd4 = RunningDice(labels=range(c), ignore_label=-1)
+    rd4.update_matrix(onehot.argmax(1).float()[:, 0], logits.argmax(1).float()[:, 0])
+    rd5 = RunningDice(labels=range(c), ignore_label=-1)
+    rd5.update_matrix(onehot.argmax(1)[:, 0].cpu().numpy(), logits.argmax(1)[:, 0].cpu().numpy())
+    assert torch.equal(rd4.conf, rd5.conf)
+    # ... and ground truth that is all `ignore_label` except for labels >= n_cls is NOT all-ignore (metrics.py:122)
+    rd6 = RunningDice(labels=range(c), ignore_label=0)
+    gt = np.zeros((2, 8, 8, 8), dtype=np.int64)
+    gt[0, 0, 0, 0] = c + 3
+    gt[1, 1, 1, 1] = 1
+    rd6.update_matrix(gt, logits.argmax(1).cpu().numpy())
+    assert int(rd6.conf.sum()) == gt.size - 1 and int(rd6.conf[1].sum()) == 1
+    with pytest.raises(Exception):
+        rd6.update_from_logits(onehot.argmax(1).float(), logits.argmax(1).float())
 
 
 @pytest.mark.gpu
@@ -762,6 +777,36 @@ def test_staged_backward_with_rccl_matches_the_single_call_backward():
     rec = json.loads(lines[-1])
     assert rec["backend"] == "nccl" and rec["grad_rel_err"] < 1e-4, rec
     assert rec["ms_three_stages_rccl"] < 2.0 * rec["ms_one_call"] + 1.0, rec
+
+
+@pytest.mark.gpu
+def test_inference_forward_uses_the_forward_prefix_of_the_workspace():
+    """Without an autograd graph (eval / sliding-window prediction) the runtime hands hdf_forward only the prefix of the
+    arena a forward touches (hdf_plan_inference_workspace_bytes: no transformer tapes, second dy buffers or 128 MB
+    weight-gradient workspace); a later training step re-allocates the full arena, gives the same logits, and a
+    backward on the small arena is refused by the library."""
+    from hdf_rt._lib import HdfError, check, lib, ptr, stream_ptr
+    cfg, batch, tag = (2, 3, 16, (32, 32, 32), 8), 2, "g1_tiny_eval"
+    net, _ = _build(cfg)
+    net.eval()
+    x, onehot = _data(cfg, batch, tag)
+    with torch.no_grad():
+        outs = [o.float().clone() for o in net(x.to(DEV))]
+    rt = net._last_rt
+    small = rt.ws.numel()
+    assert not rt.ws_backward and small == rt.plan.workspace_bytes(batch, backward=False)
+    assert small < 0.6 * rt.plan.workspace_bytes(batch)
+    g = torch.zeros(net.flat_parameters().numel(), device=DEV)
+    d = [torch.zeros_like(o) for o in outs]
+    rc = lib().hdf_backward_stages(rt.plan.h, ptr(x.to(DEV)), ptr(net.flat_parameters()), ptr(rt.ws), rt.ws.numel(),
+                                   ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), ptr(g), batch, 7, stream_ptr())
+    assert rc != 0 and b"holds a forward only" in lib().hdf_last_error()
+    outs2 = net(x.to(DEV))                       # grad mode: the full arena
+    assert rt.ws_backward and rt.ws.numel() == rt.plan.workspace_bytes(batch)
+    for a, b in zip(outs, outs2):
+        assert torch.equal(a, b.detach().float())
+    sum(o.float().sum() for o in outs2).backward()
+    torch.cuda.synchronize()
 
 
 @pytest.mark.gpu

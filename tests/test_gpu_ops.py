@@ -148,6 +148,32 @@ def test_conv_transpose3d_whole_tiles(dtype, cout, size, n, xf):
     assert float((wide[..., cout:].float() - 7).abs().max()) == 0
 
 
+@pytest.mark.parametrize("dtype", [BF16, F16])
+def test_transposed_conv_kernels_with_an_odd_channel_count_take_the_generic_path(dtype):
+    """The two persistent top-level transposed-conv kernels store channel PAIRS as one dword (st_rows2): an odd channel
+    count or pitch, legal at the operator ABI, must fall through to the element-store kernels, not write channel Cout
+    (= channel 0 of the next voxel).  Forward (64 -> 31 channels, pitch 31) and its data gradient (31 -> 63, pitch 63)."""
+    n, size = 1, (4, 4, 8)
+    for mode, cin, cout in ((2, 64, 31), (1, 32, 63)):
+        if mode == 2:
+            x, w = _mk((n, cin) + size, 61), _mk((cin, cout, 3, 3, 3), 62) * (cin * 27 / 8) ** -0.5
+            ref = F.conv_transpose3d(rnd(x, dtype), rnd(w, dtype), None, stride=2, padding=1, output_padding=1)
+            wp = pack_w(w, dtype, cout, cin, rup(cout, 32), cin, 27, cout * 27, 0)
+            osz = tuple(2 * v for v in size)
+        else:
+            big = tuple(2 * v for v in size)
+            x, w = _mk((n, cin) + big, 63), _mk((cout, cin, 3, 3, 3), 64) * (cin * 27) ** -0.5
+            ref = F.conv3d(rnd(x, dtype), rnd(w, dtype), None, stride=2, padding=1)
+            wp = pack_w(w, dtype, cout, cin, rup(cout, 32), cin, cin * 27, 27, 0)
+            osz = size
+        out = torch.full((n,) + osz + (cout,), 7.0, dtype=to_cl(x, dtype).dtype, device=DEV)
+        guard = torch.full((64,), 7.0, dtype=out.dtype, device=DEV)          # allocated right behind it
+        conv3d(dtype, mode, to_cl(x, dtype), cin, wp, cout, out=out, out_pitch=cout)
+        torch.cuda.synchronize()
+        assert rel_err(from_cl(out), ref) < TOL[dtype], (mode, cin, cout)
+        assert float((guard.float() - 7).abs().max()) == 0
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16, F16])
 @pytest.mark.parametrize("cin,cout,size", [(16, 32, (8, 8, 8)), (32, 64, (16, 8, 12)), (64, 128, (10, 12, 6))])
 def test_conv3d_stride2(dtype, cin, cout, size):

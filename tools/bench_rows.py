@@ -73,7 +73,7 @@ emit(row="8f-1 compute_dice", config=f"{B}x{C}x{S}^3 bf16 logits + fp32 one-hot"
      achieved_GBps=by / ms / 1e6, hbm_peak_GBps=8000, cpu_baseline={"kind": "port", "what": "torch CPU softmax+argmax+overlap, one sample",
                                                                      "s_per_sample": cpu_s(ref_dice), "threads": torch.get_num_threads()})
 rd = RunningDice(list(range(C)), ignore_label=-1)
-ms = gpu_ms(lambda: rd.update_matrix(onehot, logits))
+ms = gpu_ms(lambda: rd.update_from_logits(onehot, logits))
 gt_np, pr_np = lab[:1].numpy().ravel(), lg_c.argmax(1).numpy().ravel().astype(np.uint8)
 emit(row="8f-1 RunningDice.update_matrix", config=f"{B}x{C}x{S}^3 (one-hot, logits) -> {C}x{C} counts", gpu_ms=ms,
      algorithmic_bytes=by, achieved_GBps=by / ms / 1e6, hbm_peak_GBps=8000,

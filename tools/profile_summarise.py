@@ -47,10 +47,71 @@ def pmc_per_kernel(path):
 
 
 # 1. kernel stats + one-step totals
-for leg in ("bench", "roofline"):
+for leg in ("bench", "bench1s", "roofline"):
     f = one(f"{leg}/**/*_kernel_stats.csv")
     if f:
         shutil.copy(f, os.path.join(dst, f"{pre}_{leg}_kernel_stats.csv"))
+
+
+def step_window(path):
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    adam = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
+    return rows[adam[-2] + 1: adam[-1] + 1]
+
+
+def per_kernel_us(win):
+    tot = defaultdict(lambda: [0.0, 0])
+    for r in win:
+        k = short(r["Kernel_Name"])
+        tot[k][0] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        tot[k][1] += 1
+    return tot
+
+
+# 1b. the per-kernel table of a step: clean (one-stream) time, time inside the shipped three-stream step, HBM bytes
+#     and matrix-pipe cycles from the PMC passes, and what that is against the two roofs
+f1, f3 = one("bench1s/**/*_kernel_trace.csv"), one("bench/**/*_kernel_trace.csv")
+if f1 and f3:
+    clean, over = per_kernel_us(step_window(f1)), per_kernel_us(step_window(f3))
+    pm = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE", "MFMA"):
+        g = one(f"pmc_step_{c}/**/*counter_collection.csv")
+        pm[c] = pmc_per_kernel(g) if g else {}
+    steps_in_pmc = 2.0      # bench.py --steps 1 --warmup 1 (the roofline launches are taken out below)
+    F32_KERNELS = ("tok_", "attn_", "tf_wgrad", "patch_embed")
+    with open(os.path.join(dst, f"{pre}_step_kernel_table.txt"), "w") as fh:
+        fh.write("Per-kernel table of one training step (4x128^3, batch 2, bf16).  us_1s: duration with both stream knobs set "
+                 "(one stream, nothing shares the GPU);\nus_3s: inside the shipped step (caller's stream + weight-gradient side "
+                 "stream + branch stream: durations of kernels that share the GPU are stretched).\nHBM MB per step = "
+                 "(2 x FETCH_SIZE + WRITE_SIZE) from separate --pmc passes (gfx950 correction: FETCH_SIZE counts half of "
+                 "wide reads); GB/s = MB / us_1s, vs the 8 TB/s HBM roof.\nMFMA TF = SQ_VALU_MFMA_BUSY_CYCLES x (1024 FLOP per "
+                 "busy cycle for the bf16 32x32x16 kernels, 64 for the f32 MFMAs of the token / attention / patch kernels) / us_1s, "
+                 "vs 2500 (bf16) or 157 (f32) TF: executed matrix FLOPs, padding included.\n\n")
+        fh.write(f"{'kernel':60s} {'n':>4s} {'us_1s':>9s} {'us_3s':>9s} {'HBM MB':>9s} {'GB/s':>7s} {'of 8T':>6s} {'MFMA TF':>8s} {'of roof':>7s}\n")
+        t1 = t3 = 0.0
+        for k, (d, n) in sorted(clean.items(), key=lambda kv: -kv[1][0]):
+            def ctr(c, name):
+                e = pm[c].get(k, {}).get(name)
+                return None if not e else e[1]
+            fe, wr, mf = ctr("FETCH_SIZE", "FETCH_SIZE"), ctr("WRITE_SIZE", "WRITE_SIZE"), ctr("MFMA", "SQ_VALU_MFMA_BUSY_CYCLES")
+            calls = pm["FETCH_SIZE"].get(k, {}).get("FETCH_SIZE", [0, 0])[0]
+            scale = (n / calls) if calls else 0.0        # counters cover 2 steps (+ 120 roofline launches of one kernel)
+            mb = (2 * fe + wr) * 1024 / 1e6 * scale if fe is not None and wr is not None else None
+            mcalls = pm["MFMA"].get(k, {}).get("SQ_VALU_MFMA_BUSY_CYCLES", [0, 0])[0]
+            rate = 64.0 if any(t in k for t in F32_KERNELS) else 1024.0
+            tf = (mf * (n / mcalls) * rate / (d * 1e-6) / 1e12) if mf and mcalls and d > 0 else None
+            roof = 157.0 if rate == 64.0 else 2500.0
+            gbs = mb / d * 1e3 / 1e3 if mb is not None and d > 0 else None      # MB / us = TB/s * 1e-... -> GB/s below
+            gbs = mb * 1e6 / (d * 1e-6) / 1e9 if mb is not None and d > 0 else None
+            o = over.get(k, [0.0, 0])[0]
+            t1 += d
+            t3 += o
+            fh.write(f"{k:60s} {n:4d} {d:9.1f} {o:9.1f} " + (f"{mb:9.1f} {gbs:7.0f} {gbs / 8000:6.2f} " if mb is not None else f"{'-':>9s} {'-':>7s} {'-':>6s} ") +
+                     (f"{tf:8.1f} {tf / roof:7.3f}" if tf is not None and tf > 0.05 else f"{'-':>8s} {'-':>7s}") + "\n")
+        fh.write(f"\nsum of kernel durations: {t1:.1f} us on one stream, {t3:.1f} us summed over the three streams\n")
+    print("wrote", f"{pre}_step_kernel_table.txt")
+
 f = one("bench/**/*_kernel_trace.csv")
 if f:
     rows = list(csv.DictReader(open(f)))
