@@ -169,6 +169,8 @@ def main():
     ap.add_argument("--batch", type=int, default=2, help="per-GPU batch")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true",
+                    help="skip the 120 launches of the roofline leg (per-kernel counter passes of tools/profile_round.sh)")
     ap.add_argument("--roofline-only", action="store_true",
                     help="only the roofline leg (the dominant kernel's timed launches): the command profiled for "
                          "profiles/*_roofline_kernel_stats.csv, whose per-kernel average must match avg_launch_ms")
@@ -287,8 +289,9 @@ def main():
                                       "slowest_step": raw_steps.index(per_step[-1])},
             "host_issue_ms_per_step": t_enqueued / a.steps * 1e3,
         }
-        if world == 1:
+        if world == 1 and not a.no_roofline:
             rec["roofline"] = roofline_dominant_kernel(dev)
+        if world == 1:
             if not a.no_cpu_baseline:
                 del net, opt
                 torch.cuda.empty_cache()

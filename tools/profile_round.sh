@@ -30,9 +30,9 @@ done
 # 4. per-kernel HBM traffic and matrix-pipe cycles of one whole step (one stream, so that a counter belongs to one kernel)
 export HDF_NO_ASYNC_WGRAD=1 HDF_NO_BRANCH_OVERLAP=1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_step_$c -- $PY $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_step_$c -- $PY $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
 done
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_step_MFMA -- $PY $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_step_MFMA -- $PY $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
 unset HDF_NO_ASYNC_WGRAD HDF_NO_BRANCH_OVERLAP
 # 5. clock / power under the sustained roofline kernel
 $PY $REPO/tools/clock_probe.py 64 32 > $OUT/clock_probe_64x32.txt 2>&1
