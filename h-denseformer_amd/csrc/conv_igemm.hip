@@ -2689,7 +2689,10 @@ int launch_conv_t(int mode, const ConvArgs& a, hipStream_t st) {
     if (ws) {
       if (rb == 32) return launch_ws2<T, 32, 32, 1>(a, st);
       if (rb == 64 && a.CoutP % 64 == 0) return launch_ws2<T, 32, 64, 2>(a, st);
-      if (rb == 64) return launch_ws2<T, 64, 64, 1>(a, st);
+      // 64-byte rows, one output block: two 32-byte passes per tile.  (Rounds 1-2 ran these layers as ONE 64-byte pass
+      // with the deferred epilogue: 512 registers, 500 B of scratch per lane in the border copies, 1.2x the output in
+      // HBM writes; the two-pass form needs 303 registers and is 7 % faster without / 1 % with an input transform.)
+      if (rb == 64) return launch_ws2<T, 32, 64, 1>(a, st);
       if (rb == 128) return launch_ws2<T, 32, 128, 1>(a, st);
     }
     if (tiny_tile(a.Do, a.Ho, a.Wo)) return launch_cfg<T, 2, 4, 8, 2, 2, 1, 1, false>(a, st);   // 64 vox x 64 ch
