@@ -369,8 +369,7 @@ __device__ __forceinline__ void ws_row_to_zx(int r, int& dz, int& x) {
 //    instruction outside the MFMA shadow costs ~5 cycles with one wave per SIMD), scale/shift sit in an LDS table
 //  * epilogue: accumulators (+bias) -> storage type -> element stores (32 lanes = one voxel row of 32 channels), no
 //    LDS staging and no barrier; the cross-wave reduction of the InstanceNorm partials rides on the next pass's
-//    barrier.  In the interior run of single-pass tiles the epilogue of tile t is deferred into the MFMA gaps of
-//    tile t+1 (two accumulator register sets)
+//    barrier
 //  * schedule: an interior pass (unchecked copy of the phase) then a border pass (checked copy) per workgroup, both
 //    split XCD-aware (see the kernel body)
 template <int CH>
@@ -413,7 +412,6 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
   static_assert(NCH == 1 || NCH % 2 == 0, "buffer parity at tile start must be compile-time");
   static_assert(2 * CIN * 4 <= 512, "scale/shift table");
   static_assert(OFF_W + 27 * NC * RB <= 160 * 1024, "LDS budget");
-  static_assert(NB == 1 || NCH > 1, "the deferred epilogue of single-pass tiles keeps one accumulator block");
   __shared__ __attribute__((aligned(256))) char lds[OFF_W + 27 * NC * RB];
 #ifdef WS_DBG_STAMPS
   const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();
@@ -463,7 +461,7 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
   const int bswz = (r / RP256) & (CPR - 1);
 
   // Tile schedule: every workgroup first runs a contiguous share of the INTERIOR tiles (halo box inside the volume:
-  // no bounds logic, deferred epilogue, one long run inside the two hot copies of the phase), then a share of the
+  // no bounds logic, one long run inside the hot copy of the phase), then a share of the
   // BORDER tiles with the checked copy.  Walking all tiles in raster order switched between the copies at every
   // x-row (two border tiles per 16), and each switch re-fetched cold code and drained the staging pipeline.
   const int ntz = (a.Do + TD - 1) / TD, nty = (a.Ho + TH - 1) / TH, ntx = (a.Wo + TW - 1) / TW;
@@ -882,22 +880,12 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
 
   // One tile: NCH passes.  Pass c runs the MFMAs of chunk c out of buffer (PAR0 + c) & 1 and, in their shadow,
   // commits item c+1 (chunk (c+1) % NCH of T0 or T1) into the other buffer and loads item c+2 into the freed pf.
-  //
-  // Deferred epilogue (single-pass tiles, runs of interior tiles): the accumulators alternate between two register
-  // sets with the buffer parity.  DOUT: the phase leaves its tile "pending" (coordinates in PT) instead of running
-  // the epilogue; DIN: the phase converts / stores / sums the pending tile out of the OTHER set, a few elements per
-  // MFMA group, and hands the per-wave InstanceNorm partials to the flush behind its barrier.
-  f32x16 accs[2][2 * NB];  // [register set][nb * 2 + mb]
-  WsTile PT = T0;
-  auto tile_phase = [&](auto par_tag, auto fast_tag, auto din_tag, auto dout_tag) __attribute__((always_inline)) {
+  // (Rounds 1-2 deferred the epilogue of single-pass tiles into the MFMA gaps of the next tile, with two accumulator
+  // register sets; once the 64-byte-row layers became two-pass that served only the 16->32 first layer, where it was
+  // worth 3 % of the launch and nothing in the step, at 30 more registers: removed in round 3.)
+  f32x16 acc[2 * NB];  // [nb * 2 + mb]
+  auto tile_phase = [&](auto par_tag, auto fast_tag) __attribute__((always_inline)) {
     constexpr int PAR0 = decltype(par_tag)::value;
-    constexpr bool DIN = decltype(din_tag)::value, DOUT = decltype(dout_tag)::value;
-    constexpr int EPG = (32 + NG - 1) / NG;  // pending elements per MFMA group
-    f32x16(&acc)[2 * NB] = accs[PAR0];
-    f32x16(&pacc)[2 * NB] = accs[1 - PAR0];
-    T* const pbase = out_base(PT, 0);
-    float ds1 = 0.f, ds2 = 0.f;
-    if constexpr (DIN) stats_sample(PT.n);
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
       constexpr int dummy = 0;
@@ -959,23 +947,6 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
 #endif
           }
         }
-        if constexpr (DIN) {
-#pragma unroll
-          for (int u = 0; u < EPG; u++) {
-            const int e = g * EPG + u;
-            if (e < 32) {
-              const int mb = e >> 4, i = e & 15;
-              const float v = pacc[mb][i] + bias[0];
-              ST<T>::st(pbase + (int64_t)mb * a.Wo * a.out_pitch + eoff(i), v);
-              ds1 += v;
-              ds2 += v * v;
-            }
-          }
-          if (g == (31 / EPG)) {  // last pending element done
-            lr1[0] += ds1;
-            lr2[0] += ds2;
-          }
-        }
         u32x4(&A)[4] = af[g & 1];
         u32x4(&B)[3 * NB] = bf[g & 1];
         if (c == 0 && g == 0) {  // first MFMAs of the tile take a zero C operand: no accumulator clearing
@@ -997,13 +968,7 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
       WS_BARRIER();  // buffer PAR fully read, buffer 1-PAR fully written
       WS2_STAMP(2)
     }
-    if constexpr (DOUT)
-      PT = T0;
-    else
-      epilogue(acc, T0);
-    // pin the loop-carried accumulators to AGPRs (else they travel through VGPR copies between phases)
-    if constexpr (NB == 1 && NCH == 1)
-      asm volatile("" : "+a"(accs[0][0]), "+a"(accs[0][1]), "+a"(accs[1][0]), "+a"(accs[1][1]));
+    epilogue(acc, T0);
     WS2_STAMP(4)
   };
 
@@ -1032,48 +997,22 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
     i2 = v2 && (BORDER ? tile_interior(T2) : true);
     org2 = v2 ? tile_org(T2) : src_safe;
   };
-  const bool can_defer = !a.accumulate && (a.Cout % 32 == 0) && a.stat_partials != nullptr;
 
-  // ---- pass A: interior tiles.  Every phase is the unchecked copy; with single-pass tiles and a deferrable
-  // epilogue the run alternates between the two hot copies (P1 / P0, pending epilogue in, own epilogue out).
+  // ---- pass A: interior tiles: the unchecked copy of the phase (single-pass tiles alternate the buffer parity)
   if (int_cnt > 0) {
     begin_pass(No{}, int_begin, int_cnt);
     more = true;
-    if (NCH > 1) {
-      while (more) {
-        tile_phase(P0{}, Yes{}, No{}, No{});
-        step(No{});
-      }
-    } else if (can_defer) {
-      tile_phase(P0{}, Yes{}, No{}, Yes{});
-      step(No{});
-      int last = 0;  // register set of the pending tile
-      while (more) {
-        tile_phase(P1{}, Yes{}, Yes{}, Yes{});
-        step(No{});
-        last = 1;
-        if (!more) break;
-        tile_phase(P0{}, Yes{}, Yes{}, Yes{});
-        step(No{});
-        last = 0;
-      }
-      if (last == 0)
-        epilogue(accs[0], PT);
+    int par = 0;
+    while (more) {
+      if (NCH > 1 || par == 0)
+        tile_phase(P0{}, Yes{});
       else
-        epilogue(accs[1], PT);
-    } else {
-      int par = 0;
-      while (more) {
-        if (par == 0)
-          tile_phase(P0{}, Yes{}, No{}, No{});
-        else
-          tile_phase(P1{}, Yes{}, No{}, No{});
-        par ^= 1;
-        step(No{});
-      }
+        tile_phase(P1{}, Yes{});
+      if (NCH == 1) par ^= 1;
+      step(No{});
     }
   }
-  // ---- pass B: border tiles (checked copy, immediate epilogue)
+  // ---- pass B: border tiles (checked copy)
   if (bor_cnt > 0) {
     begin_pass(Yes{}, bor_begin, bor_cnt);
     stats_to_row();
@@ -1082,9 +1021,9 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
     int par = 0;
     while (more) {
       if (NCH > 1 || par == 0)
-        tile_phase(P0{}, No{}, No{}, No{});
+        tile_phase(P0{}, No{});
       else
-        tile_phase(P1{}, No{}, No{}, No{});
+        tile_phase(P1{}, No{});
       if (NCH == 1) par ^= 1;
       step(Yes{});
     }
