@@ -1456,15 +1456,28 @@ static int backward3d(hdf_plan* p, const float* x, const float* params, void* wo
                                      e.at(dskip), dskip.pitch, batch, ch[k], p->dims[k + 1][0], p->dims[k + 1][1],
                                      p->dims[k + 1][2], 1, e.st));
     }
-    hipStream_t bst = nullptr;
     if (k == 0 && fork_ok) {
-      // d(ds_0) = d(at3) is final: the UpConv chain and the transformer branches (stages 2 and 4: ~110 launches, mostly
-      // latency-bound) go to the branch stream and run NEXT TO the level-0 encoder backward below (two InstanceNorm
-      // backward passes at 128^3, a 32->32 data-gradient conv and two weight gradients), which is all that is left on
-      // the caller's stream.  The chain only READS d(ds_k) of the levels the encoder has already finished with (it
-      // accumulates into dSkip[1], dSkip[2] and dX4, which the loop above consumed at k = 1, 2, 3).  The fork point is
-      // recorded here; the branch launches are issued AFTER the level-0 launches of the caller's stream (host order).
-      bst = e.fork_branch();
+      // d(ds_0) = d(at3) is final.  What is left: (1) the UpConv chain backward, (2) the transformer branches' backward,
+      // (3) the level-0 encoder backward (two InstanceNorm backward passes at 128^3, a 32->32 data-gradient conv, two
+      // weight gradients).  (1) -> (2) is the critical path (~2.1 ms, of which (2) is ~100 latency-bound launches that
+      // leave most of the chip idle); (3) is 1.4 ms of heavy kernels nothing waits for.  So (1) + (2) go to the BRANCH
+      // stream, and the caller's stream runs (3) NEXT TO (2): it waits for the end of (1) first -- issued together, the
+      // persistent convs of (3) held every CU while the chain's small kernels queued behind them (a 5 us
+      // in_bwd_finalize waited 208 us for a slot; 3.5 ms from here to the end of the step instead of 2.4).
+      // The chain only READS d(ds_k) of the levels the encoder has already finished with (it accumulates into
+      // dSkip[1], dSkip[2] and dX4, which the loop above consumed at k = 1, 2, 3).
+      hipStream_t bst = e.fork_branch();
+      if (bst) {
+        eb.st = bst, eb.on_branch = true, eb.async = e.async;
+        forked = true;
+        HDF_TRY(upconv_chain_backward(eb, batch));
+        hipEvent_t chain_done = e.next_event();
+        if (!chain_done || hipEventRecord(chain_done, bst) != hipSuccess ||
+            hipStreamWaitEvent(e.st, chain_done, 0) != hipSuccess) {
+          hdf_set_error("branch stream: event failed");
+          return HDF_ERR_HIP;
+        }
+      }
     }
     HDF_TRY(in_backward(e, c2, dskip, p->gY[k]));
     HDF_TRY(conv_backward(e, c2, p->gY[k], c1.y, xf_of(e, c1), &p->gA[k], 0));
@@ -1473,12 +1486,8 @@ static int backward3d(hdf_plan* p, const float* x, const float* params, void* wo
       HDF_TRY(conv_backward(e, c1, p->gY2[k], p->pooled[k - 1], none, &p->dP[k - 1], 0));
     else
       HDF_TRY(conv_backward(e, c1, p->gY2[k], p->xin, none, nullptr, 0));
-    if (bst) {
-      eb.st = bst, eb.on_branch = true, eb.async = e.async;
-      forked = true;
-      HDF_TRY(upconv_chain_backward(eb, batch));
-      HDF_TRY(transformer_backward(eb, x));
-    }
+    // (host order: the ten level-0 launches of the caller's stream first, then the ~100 of the transformer backward)
+    if (k == 0 && forked) HDF_TRY(transformer_backward(eb, x));
   }
 
   if (!(stages & 6)) e.join();  // staged call (gradient buckets): final when it returns
