@@ -56,7 +56,7 @@ __device__ __forceinline__ void stage_box(char* lds, const T* __restrict__ src, 
                                           const float* __restrict__ scale, const float* __restrict__ shift, int relu) {
   constexpr int EPC = ST<T>::EPC;
   const int cpv = row_bytes >> 4;  // 16-B chunks per voxel row (power of two)
-  const int cpv_shift = (cpv == 8) ? 3 : (cpv == 4) ? 2 : (cpv == 2) ? 1 : 0;
+  const int cpv_shift = (cpv == 16) ? 4 : (cpv == 8) ? 3 : (cpv == 4) ? 2 : (cpv == 2) ? 1 : 0;
   const int total = (BD * BH * BW) << cpv_shift;
   const int part = threadIdx.x & (cpv - 1);  // constant per thread (256 % cpv == 0)
   const int cbase = c0 + part * EPC;
@@ -1054,7 +1054,9 @@ __global__ __launch_bounds__(256) void convt_fused_kernel(ConvArgs a) {
   static_assert(4 * MB * 32 == TD * TH * TW, "tile/wave decomposition");
   constexpr int BD = TD + 1, BH = TH + 1, BW = TW + 1, BOX = BD * BH * BW;
   constexpr int ESZ = sizeof(T), EPC = ST<T>::EPC;
-  constexpr int LP = 128 + 16;               // box row pitch (full Cin, up to 128 B)
+  constexpr int ROWB = NFS > 4 ? 256 : 128;  // row payload the box is laid out for (full Cin: up to 128 / 256 B)
+  constexpr int LP = ROWB + 16;              // box row pitch
+  static_assert(BOX * LP <= 160 * 1024, "LDS budget");
   __shared__ __attribute__((aligned(16))) char lds[BOX * LP];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1069,9 +1071,9 @@ __global__ __launch_bounds__(256) void convt_fused_kernel(ConvArgs a) {
   const int n = t / ntz;
   const int z0 = tz * TD, y0 = ty * TH, x0 = tx * TW;
   const int n0 = blockIdx.y * 32;
-  const int RB = a.Cin * ESZ;                // 32, 64 or 128 bytes of channels per voxel (= 32 * NFS)
+  const int RB = a.Cin * ESZ;                // 32, 64, 128 or 256 bytes of channels per voxel (= 32 * NFS)
 
-  stage_box<T, BD, BH, BW, 128, LP>(lds, reinterpret_cast<const T*>(a.in), a.in_pitch, a.Cin, n, a.Di, a.Hi, a.Wi, z0,
+  stage_box<T, BD, BH, BW, ROWB, LP>(lds, reinterpret_cast<const T*>(a.in), a.in_pitch, a.Cin, n, a.Di, a.Hi, a.Wi, z0,
                                     y0, x0, 0, RB, a.in_scale, a.in_shift, a.in_relu);
   __syncthreads();
 
@@ -2663,11 +2665,14 @@ int launch_conv_t(int mode, const ConvArgs& a, hipStream_t st) {
         return HDF_OK;
       }
     }
-    if (a.Cin * (int)sizeof(T) <= 128 && !a.accumulate) {  // all 8 parity classes in one workgroup
+    if (a.Cin * (int)sizeof(T) <= 256 && !a.accumulate) {  // all 8 parity classes in one workgroup
       dim3 grid(a.N * ceil_div(a.Di, 4) * ceil_div(a.Hi, 8) * ceil_div(a.Wi, 8), a.CoutP / 32);
       const int nfs = a.Cin * (int)sizeof(T) / 32;
-      HDF_CHECK_ARG(nfs == 1 || nfs == 2 || nfs == 4, "convT: Cin=%d rows are not 32, 64 or 128 bytes", a.Cin);
-      if (nfs == 4)
+      HDF_CHECK_ARG(nfs == 1 || nfs == 2 || nfs == 4 || nfs == 8, "convT: Cin=%d rows are not 32, 64, 128 or 256 bytes",
+                    a.Cin);
+      if (nfs == 8)
+        hipLaunchKernelGGL((convt_fused_kernel<T, 4, 8, 8, 2, 8>), grid, dim3(256), 0, st, a);
+      else if (nfs == 4)
         hipLaunchKernelGGL((convt_fused_kernel<T, 4, 8, 8, 2, 4>), grid, dim3(256), 0, st, a);
       else if (nfs == 2)
         hipLaunchKernelGGL((convt_fused_kernel<T, 4, 8, 8, 2, 2>), grid, dim3(256), 0, st, a);
@@ -2743,7 +2748,7 @@ int hdf_conv_weight_layout(int dtype, int mode, int Cin, int Do, int Ho, int Wo)
   if (rb % 64 != 0) return 0;                       // the pipelined path needs whole 64-byte chunks
   if (mode == 0) return ws_cfg(mode, Do, Ho, Wo, rb) ? 0 : 1;  // conv_ws2_kernel stages row-major panels
   if (mode == 1) return 1;                                 // stride-2 gather conv: pipelined path
-  return rb > 128 ? 1 : 0;  // transposed conv: convt_fused_kernel (rows <= 128 B) stages row-major panels, wider ones run per class
+  return rb > 256 ? 1 : 0;  // transposed conv: convt_fused_kernel (rows <= 256 B) reads row-major panels, wider ones run per class
 }
 
 int hdf_conv_stat_tiles(int mode, int Do, int Ho, int Wo, int row_bytes) {

@@ -153,3 +153,31 @@ def step2():
 ms = gpu_ms(step2, reps=5, warm=2)
 emit(row="8f-4 HDenseFormer_2D_32 train step", config="batch 2 of 4x256^2, fwd + DeepSuper CE+Dice + bwd + Adam, bf16", gpu_ms=ms,
      samples_per_s=2 / ms * 1e3)
+
+# ---- 8f-4 at the reference's own 2-D workload: PI-CAI 384^2, batch 24 (config.py:69-77), the model of test.py:4-13
+del net2, opt
+torch.cuda.empty_cache()
+try:
+    net3 = HDenseFormer_2D_32(2, 2, (384, 384), 16).to(DEV)
+    net3.compute_dtype = "bf16"
+    x3 = torch.rand(24, 2, 384, 384, generator=g).to(DEV)
+    net3.eval()
+    with torch.no_grad():
+        ms = gpu_ms(lambda: net3(x3), reps=3, warm=1)
+    emit(row="8f-4 HDenseFormer_2D_32 eval forward, PI-CAI shape", config="batch 24 of 2x384^2, n_cls 2, td 16, bf16 (depth-16 embedding)",
+         gpu_ms=ms, samples_per_s=24 / ms * 1e3)
+    net3.train()
+    opt3 = FlatAdam(net3, lr=1e-3, weight_decay=1e-4)
+    t3 = torch.nn.functional.one_hot(torch.randint(0, 2, (24, 384, 384), generator=g), 2).permute(0, 3, 1, 2).float().contiguous().to(DEV)
+
+    def step3():
+        opt3.zero_grad()
+        loss = crit(net3(x3), t3)
+        loss.backward()
+        opt3.step()
+
+    ms = gpu_ms(step3, reps=3, warm=1)
+    emit(row="8f-4 HDenseFormer_2D_32 train step, PI-CAI shape", config="batch 24 of 2x384^2, fwd + DeepSuper CE+Dice + bwd + Adam, bf16",
+         gpu_ms=ms, samples_per_s=24 / ms * 1e3)
+except Exception as exc:  # report, do not hide: the row then says why it is missing
+    emit(row="8f-4 PI-CAI shape", error=repr(exc)[:300])
