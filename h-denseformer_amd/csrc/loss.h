@@ -4,6 +4,7 @@
 struct LossScales {
   float V[4];
   float weight[4];
+  int blocks[4];  // partial rows written per (scale, sample)
 };
 
 int hdf_loss_blocks();

@@ -5,6 +5,8 @@
 // One pass per scale reads the logits once (NCDHW, coalesced along voxels) and the fp32 one-hot target
 // at the 2^i-strided positions (nearest down-sampling), producing per-(sample,class) sums
 // sum(p*t), sum(p), sum(t) and the CE sum; backward recomputes the softmax from the logits.
+#include <type_traits>
+
 #include "loss.h"
 
 namespace {
@@ -12,81 +14,163 @@ constexpr int MAXC = 8;
 constexpr int LOSS_BLOCKS = 1024;
 constexpr int NSTAT = 3 * MAXC + 2;  // per class: sum p*t, sum p, sum t; then the (weighted) CE sum and the sum of CE weights
 
+// All scales of the deep supervision in ONE launch: grid (sum of the scales' block counts, N); a block finds its scale from
+// the block ranges in LossLevels.  A thread owns VEC = 4 consecutive voxels of a row of the scale's grid (one 8-byte load
+// of 16-bit logits and -- at scale 0 -- one 16-byte load of the one-hot target per class: the scalar form had 2 + 4 bytes
+// per lane and class in flight and ran at 1.1 TB/s); rows whose width is not a multiple of 4, or unaligned views, take
+// VEC = 1.  The sums of a thread are taken in voxel order, of a block in a fixed order: bitwise reproducible.
+struct LossLevel {
+  const void* logits;
+  void* dlogits;
+  int Ds, Hs, Ws, stride;
+  int blk0, nblk, vec;
+};
+struct LossLevels {
+  LossLevel L[4];
+  int nscale;
+};
+
 template <typename T>
-__global__ __launch_bounds__(256) void loss_fwd_kernel(const T* __restrict__ logits, const float* __restrict__ target,
-                                                       int C, int Ds, int Hs, int Ws, int stride, int D, int H, int W,
+__device__ __forceinline__ void ld_vox(const T* p, float* f, std::integral_constant<int, 1>) {
+  f[0] = ST<T>::ld(p);
+}
+__device__ __forceinline__ void ld_vox(const float* p, float* f, std::integral_constant<int, 4>) {
+  const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+  f[0] = v[0], f[1] = v[1], f[2] = v[2], f[3] = v[3];
+}
+__device__ __forceinline__ void ld_vox(const bf16_t* p, float* f, std::integral_constant<int, 4>) {
+  const u32x2 v = *reinterpret_cast<const u32x2*>(p);
+  f[0] = __uint_as_float(v[0] << 16), f[1] = __uint_as_float(v[0] & 0xffff0000u);
+  f[2] = __uint_as_float(v[1] << 16), f[3] = __uint_as_float(v[1] & 0xffff0000u);
+}
+__device__ __forceinline__ void ld_vox(const f16_t* p, float* f, std::integral_constant<int, 4>) {
+  const u32x2 v = *reinterpret_cast<const u32x2*>(p);
+  const uint32_t w0 = v[0], w1 = v[1];
+  f[0] = h2f((uint16_t)(w0 & 0xffffu)), f[1] = h2f((uint16_t)(w0 >> 16));
+  f[2] = h2f((uint16_t)(w1 & 0xffffu)), f[3] = h2f((uint16_t)(w1 >> 16));
+}
+template <typename T>
+__device__ __forceinline__ void st_vox(T* p, const float* f, std::integral_constant<int, 1>) {
+  ST<T>::st(p, f[0]);
+}
+template <typename T>
+__device__ __forceinline__ void st_vox(T* p, const float* f, std::integral_constant<int, 4>) {
+  ST<T>::st4(p, f[0], f[1], f[2], f[3]);
+}
+// one-hot target of VEC voxels that are `stride` apart in the full-resolution row
+template <int VEC>
+__device__ __forceinline__ void ld_tgt(const float* p, int stride, float* t) {
+  if (VEC == 4 && stride == 1) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+    t[0] = v[0], t[1] = v[1], t[2] = v[2], t[3] = v[3];
+  } else {
+#pragma unroll
+    for (int j = 0; j < VEC; j++) t[j] = p[(int64_t)j * stride];
+  }
+}
+
+template <typename T, int VEC, int MC>
+__device__ __forceinline__ void loss_fwd_body(const LossLevel& L, int bx, const float* __restrict__ target, int C, int D,
+                                              int H, int W, const float* __restrict__ cw, float* acc) {
+  const T* logits = reinterpret_cast<const T*>(L.logits);
+  const int n = blockIdx.y, Ws = L.Ws, Hs = L.Hs, stride = L.stride;
+  const int64_t V = (int64_t)L.Ds * Hs * Ws, Vf = (int64_t)D * H * W;
+  const std::integral_constant<int, VEC> vt{};
+  // (32-bit voxel indices inside a sample: the launcher checks D*H*W < 2^31; at scale 0 the two grids coincide)
+  for (int v = (bx * 256 + (int)threadIdx.x) * VEC; v < (int)V; v += L.nblk * 256 * VEC) {
+    int64_t vf = v;
+    if (stride > 1) {
+      const int x = v % Ws, y = (v / Ws) % Hs, z = v / (Ws * Hs);
+      vf = ((int64_t)z * stride * H + (int64_t)y * stride) * W + (int64_t)x * stride;
+    }
+    float lg[MC][VEC], t[MC][VEC];
+#pragma unroll
+    for (int c = 0; c < MC; c++)
+      if (c < C) {
+        ld_vox(logits + ((int64_t)n * C + c) * V + v, lg[c], vt);
+        ld_tgt<VEC>(target + ((int64_t)n * C + c) * Vf + vf, stride, t[c]);
+      }
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      float mx = -INFINITY, tbest = -INFINITY;
+      int tc = 0;
+#pragma unroll
+      for (int c = 0; c < MC; c++)
+        if (c < C) {
+          mx = fmaxf(mx, lg[c][j]);
+          if (t[c][j] > tbest) {
+            tbest = t[c][j];
+            tc = c;
+          }
+        }
+      float se = 0.f, e[MC];
+#pragma unroll
+      for (int c = 0; c < MC; c++)
+        if (c < C) {
+          e[c] = __expf(lg[c][j] - mx);
+          se += e[c];
+        }
+      const float inv = 1.f / se;
+      const float lse = mx + __logf(se);
+#pragma unroll
+      for (int c = 0; c < MC; c++)
+        if (c < C) {
+          const float p = e[c] * inv;
+          acc[c] += p * t[c][j];
+          acc[MAXC + c] += p;
+          acc[2 * MAXC + c] += t[c][j];
+          if (c == tc) {
+            // torch CrossEntropyLoss(weight=w, reduction='mean'): sum_v w[t_v] * nll_v / sum_v w[t_v]
+            const float wv = cw ? cw[c] : 1.f;
+            acc[3 * MAXC] += cw ? wv * (lse - lg[c][j]) : lse - lg[c][j];
+            acc[3 * MAXC + 1] += wv;
+          }
+        }
+    }
+  }
+}
+
+template <typename T, int MC>  // MC: class slots held in registers (4 or 8)
+__global__ __launch_bounds__(256) void loss_fwd_kernel(LossLevels lv, const float* __restrict__ target, int C, int D,
+                                                       int H, int W,
                                                        const float* __restrict__ cw /*[C] class weights or null*/,
-                                                       float* __restrict__ partials /*[N][blocks][NSTAT]*/) {
+                                                       float* __restrict__ partials /*[scale][N][LOSS_BLOCKS][NSTAT]*/) {
   __shared__ float red[4][NSTAT];
-  const int n = blockIdx.y;
-  const int64_t V = (int64_t)Ds * Hs * Ws, Vf = (int64_t)D * H * W;
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < 4; k++)
+    if (k < lv.nscale && (int)blockIdx.x >= lv.L[k].blk0) i = k;
+  const LossLevel& L = lv.L[i];
+  const int bx = blockIdx.x - L.blk0;
   float acc[NSTAT];
 #pragma unroll
-  for (int i = 0; i < NSTAT; i++) acc[i] = 0.f;
-  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < V; v += (int64_t)gridDim.x * 256) {
-    int x = v % Ws, y = (v / Ws) % Hs, z = v / ((int64_t)Ws * Hs);
-    int64_t vf = ((int64_t)z * stride * H + (int64_t)y * stride) * W + (int64_t)x * stride;
-    float lg[MAXC], t[MAXC];
-    float mx = -INFINITY, tbest = -INFINITY;
-    int tc = 0;
+  for (int k = 0; k < NSTAT; k++) acc[k] = 0.f;
+  if (L.vec == 4)
+    loss_fwd_body<T, 4, MC>(L, bx, target, C, D, H, W, cw, acc);
+  else
+    loss_fwd_body<T, 1, MC>(L, bx, target, C, D, H, W, cw, acc);
 #pragma unroll
-    for (int c = 0; c < MAXC; c++) {
-      if (c < C) {
-        lg[c] = ST<T>::ld(logits + ((int64_t)n * C + c) * V + v);
-        t[c] = target[((int64_t)n * C + c) * Vf + vf];
-        mx = fmaxf(mx, lg[c]);
-        if (t[c] > tbest) {
-          tbest = t[c];
-          tc = c;
-        }
-      }
-    }
-    float se = 0.f, e[MAXC];
-#pragma unroll
-    for (int c = 0; c < MAXC; c++)
-      if (c < C) {
-        e[c] = __expf(lg[c] - mx);
-        se += e[c];
-      }
-    float inv = 1.f / se;
-    float lse = mx + __logf(se);
-#pragma unroll
-    for (int c = 0; c < MAXC; c++)
-      if (c < C) {
-        float p = e[c] * inv;
-        acc[c] += p * t[c];
-        acc[MAXC + c] += p;
-        acc[2 * MAXC + c] += t[c];
-        if (c == tc) {
-          // torch CrossEntropyLoss(weight=w, reduction='mean'): sum_v w[t_v] * nll_v / sum_v w[t_v]
-          const float wv = cw ? cw[c] : 1.f;
-          acc[3 * MAXC] += cw ? wv * (lse - lg[c]) : lse - lg[c];
-          acc[3 * MAXC + 1] += wv;
-        }
-      }
-  }
-#pragma unroll
-  for (int i = 0; i < NSTAT; i++) acc[i] = wave_sum(acc[i]);
+  for (int k = 0; k < NSTAT; k++) acc[k] = wave_sum(acc[k]);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0)
 #pragma unroll
-    for (int i = 0; i < NSTAT; i++) red[wave][i] = acc[i];
+    for (int k = 0; k < NSTAT; k++) red[wave][k] = acc[k];
   __syncthreads();
   if (threadIdx.x < NSTAT)
-    partials[((int64_t)n * gridDim.x + blockIdx.x) * NSTAT + threadIdx.x] =
+    partials[(((int64_t)i * gridDim.y + blockIdx.y) * LOSS_BLOCKS + bx) * NSTAT + threadIdx.x] =
         red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
 // grid = nscale*N blocks of 256 threads (one per partial slot): per-(scale, sample) loss term + the backward
 // coefficients coef[(i*N+n)*MAXC + c] = (A, B) of the Dice gradient; terms[i*N+n] is summed by loss_total_kernel
 __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ partials, int nscale, int N, int C,
-                                                            int blocks, LossScales sc, float smooth, float w_ce,
+                                                            LossScales sc, float smooth, float w_ce,
                                                             float w_dice, const float* __restrict__ cw, int ignore,
                                                             float* __restrict__ terms, float* __restrict__ coefA,
                                                             float* __restrict__ coefB, float* __restrict__ wsum_out) {
   __shared__ double red[4][NSTAT];
-  const int i = blockIdx.x / N, n = blockIdx.x % N;
-  const float* base = partials + ((int64_t)i * N + n) * blocks * NSTAT;
+  const int i = blockIdx.x / N, n = blockIdx.x % N, blocks = sc.blocks[i];
+  const float* base = partials + ((int64_t)i * N + n) * LOSS_BLOCKS * NSTAT;
   double s[NSTAT];
 #pragma unroll
   for (int k = 0; k < NSTAT; k++) s[k] = 0.0;
@@ -96,7 +180,7 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
   if (cw) {  // weighted CE: the denominator is the weight sum over ALL samples of the scale (slot NSTAT-1 of every n)
     double wall = 0.0;
     for (int m = 0; m < N; m++) {
-      const float* bm = partials + ((int64_t)i * N + m) * blocks * NSTAT;
+      const float* bm = partials + ((int64_t)i * N + m) * LOSS_BLOCKS * NSTAT;
       for (int b = threadIdx.x; b < blocks; b += 256) wall += (double)bm[(int64_t)b * NSTAT + 3 * MAXC + 1];
     }
     s[3 * MAXC + 1] = wall;
@@ -143,73 +227,104 @@ __global__ void loss_total_kernel(const float* __restrict__ terms, int count, fl
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void loss_bwd_kernel(const T* __restrict__ logits, const float* __restrict__ target,
-                                                       int N, int C, int Ds, int Hs, int Ws, int stride, int D, int H,
-                                                       int W, const float* __restrict__ coefA,
-                                                       const float* __restrict__ coefB, float weight, float w_ce,
-                                                       float w_dice, const float* __restrict__ cw, int ignore,
-                                                       const float* __restrict__ wsum, const float* __restrict__ gup,
-                                                       T* __restrict__ dlogits) {
-  const int n = blockIdx.y;
-  const int64_t V = (int64_t)Ds * Hs * Ws, Vf = (int64_t)D * H * W;
-  const float g = (*gup) * weight;
-  const float kce0 = cw ? w_ce * g / (*wsum) : w_ce * g / ((float)V * (float)N);
-  const float kd = w_dice * g / ((float)(ignore >= 0 ? C - 1 : C) * (float)N);
-  float cwr[MAXC];
+struct LossBwdP {
+  const float *coefA, *coefB;  // [scale][N][MAXC]
+  const float* wsum;           // [scale]
+  const float* gup;
+  const float* cw;
+  float w_ce, w_dice;
+  int ignore;
+};
+
+template <typename T, int VEC, int MC>
+__device__ __forceinline__ void loss_bwd_body(const LossLevel& L, int i, int bx, const float* __restrict__ target, int N,
+                                              int C, int D, int H, int W, const LossBwdP& q) {
+  const T* logits = reinterpret_cast<const T*>(L.logits);
+  T* dlogits = reinterpret_cast<T*>(L.dlogits);
+  const int n = blockIdx.y, Ws = L.Ws, Hs = L.Hs, stride = L.stride;
+  const int64_t V = (int64_t)L.Ds * Hs * Ws, Vf = (int64_t)D * H * W;
+  const float g = (*q.gup) / (float)stride;   // scale weight 1 / 2^i (combine_loss.py:68-79)
+  const float kce0 = q.cw ? q.w_ce * g / q.wsum[i] : q.w_ce * g / ((float)V * (float)N);
+  const float kd = q.w_dice * g / ((float)(q.ignore >= 0 ? C - 1 : C) * (float)N);
+  float cwr[MC], cA[MC], cB[MC];
 #pragma unroll
-  for (int c = 0; c < MAXC; c++) cwr[c] = (cw && c < C) ? cw[c] : 1.f;
-  float cA[MAXC], cB[MAXC];
-#pragma unroll
-  for (int c = 0; c < MAXC; c++) {
-    cA[c] = c < C ? coefA[(int64_t)n * MAXC + c] : 0.f;
-    cB[c] = c < C ? coefB[(int64_t)n * MAXC + c] : 0.f;
+  for (int c = 0; c < MC; c++) {
+    cwr[c] = (q.cw && c < C) ? q.cw[c] : 1.f;
+    cA[c] = c < C ? q.coefA[((int64_t)i * N + n) * MAXC + c] : 0.f;
+    cB[c] = c < C ? q.coefB[((int64_t)i * N + n) * MAXC + c] : 0.f;
   }
-  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < V; v += (int64_t)gridDim.x * 256) {
-    int x = v % Ws, y = (v / Ws) % Hs, z = v / ((int64_t)Ws * Hs);
-    int64_t vf = ((int64_t)z * stride * H + (int64_t)y * stride) * W + (int64_t)x * stride;
-    float lg[MAXC], t[MAXC];
-    float mx = -INFINITY, tbest = -INFINITY;
-    int tc = 0;
+  const std::integral_constant<int, VEC> vt{};
+  // (32-bit voxel indices inside a sample: the launcher checks D*H*W < 2^31; at scale 0 the two grids coincide)
+  for (int v = (bx * 256 + (int)threadIdx.x) * VEC; v < (int)V; v += L.nblk * 256 * VEC) {
+    int64_t vf = v;
+    if (stride > 1) {
+      const int x = v % Ws, y = (v / Ws) % Hs, z = v / (Ws * Hs);
+      vf = ((int64_t)z * stride * H + (int64_t)y * stride) * W + (int64_t)x * stride;
+    }
+    float lg[MC][VEC], t[MC][VEC];
 #pragma unroll
-    for (int c = 0; c < MAXC; c++)
+    for (int c = 0; c < MC; c++)
       if (c < C) {
-        lg[c] = ST<T>::ld(logits + ((int64_t)n * C + c) * V + v);
-        t[c] = target[((int64_t)n * C + c) * Vf + vf];
-        mx = fmaxf(mx, lg[c]);
-        if (t[c] > tbest) {
-          tbest = t[c];
-          tc = c;
+        ld_vox(logits + ((int64_t)n * C + c) * V + v, lg[c], vt);
+        ld_tgt<VEC>(target + ((int64_t)n * C + c) * Vf + vf, stride, t[c]);
+      }
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      float mx = -INFINITY, tbest = -INFINITY;
+      int tc = 0;
+#pragma unroll
+      for (int c = 0; c < MC; c++)
+        if (c < C) {
+          mx = fmaxf(mx, lg[c][j]);
+          if (t[c][j] > tbest) {
+            tbest = t[c][j];
+            tc = c;
+          }
         }
-      }
-    float se = 0.f, p[MAXC];
+      float se = 0.f, p[MC];
 #pragma unroll
-    for (int c = 0; c < MAXC; c++)
-      if (c < C) {
-        p[c] = __expf(lg[c] - mx);
-        se += p[c];
-      }
-    float inv = 1.f / se, dot = 0.f, G[MAXC];
+      for (int c = 0; c < MC; c++)
+        if (c < C) {
+          p[c] = __expf(lg[c][j] - mx);
+          se += p[c];
+        }
+      float inv = 1.f / se, dot = 0.f, G[MC];
 #pragma unroll
-    for (int c = 0; c < MAXC; c++)
-      if (c < C) {
-        p[c] *= inv;
-        G[c] = -kd * (cA[c] * t[c] - cB[c]);  // dDice/dp_c (the coefficients of the ignored class are zero)
-        dot += G[c] * p[c];
-      }
-    float kce = kce0;
-    if (cw) {
+      for (int c = 0; c < MC; c++)
+        if (c < C) {
+          p[c] *= inv;
+          G[c] = -kd * (cA[c] * t[c][j] - cB[c]);  // dDice/dp_c (the coefficients of the ignored class are zero)
+          dot += G[c] * p[c];
+        }
+      float kce = kce0;
+      if (q.cw) {
 #pragma unroll
-      for (int c = 0; c < MAXC; c++)
-        if (c == tc) kce = kce0 * cwr[c];
+        for (int c = 0; c < MC; c++)
+          if (c == tc) kce = kce0 * cwr[c];
+      }
+#pragma unroll
+      for (int c = 0; c < MC; c++)
+        if (c < C) lg[c][j] = kce * (p[c] - (c == tc ? 1.f : 0.f)) + p[c] * (G[c] - dot);
     }
 #pragma unroll
-    for (int c = 0; c < MAXC; c++)
-      if (c < C) {
-        float d = kce * (p[c] - (c == tc ? 1.f : 0.f)) + p[c] * (G[c] - dot);
-        ST<T>::st(dlogits + ((int64_t)n * C + c) * V + v, d);
-      }
+    for (int c = 0; c < MC; c++)
+      if (c < C) st_vox(dlogits + ((int64_t)n * C + c) * V + v, lg[c], vt);
   }
+}
+
+template <typename T, int MC>
+__global__ __launch_bounds__(256) void loss_bwd_kernel(LossLevels lv, const float* __restrict__ target, int N, int C,
+                                                       int D, int H, int W, LossBwdP q) {
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < 4; k++)
+    if (k < lv.nscale && (int)blockIdx.x >= lv.L[k].blk0) i = k;
+  const LossLevel& L = lv.L[i];
+  const int bx = blockIdx.x - L.blk0;
+  if (L.vec == 4)
+    loss_bwd_body<T, 4, MC>(L, i, bx, target, N, C, D, H, W, q);
+  else
+    loss_bwd_body<T, 1, MC>(L, i, bx, target, N, C, D, H, W, q);
 }
 
 // ---------------------------------------------------------------------------------- Dice metric
@@ -386,32 +501,62 @@ size_t hdf_loss_workspace_floats(int N, int nscale) {
   return (size_t)nscale * N * LOSS_BLOCKS * NSTAT + 2 * (size_t)nscale * N * MAXC + (size_t)nscale * N + 16;
 }
 
+// geometry of the scales: nearest down-sampling by 2^i (combine_loss.py:68-79); D == 1: 2-D logits [N][C][H][W]
+// (models/HDenseFormer_2D.py), the down-sampling then strides H and W only
+static int loss_levels(const void* const* logits, void* const* dlogits, const float* target, int nscale, int D, int H,
+                       int W, LossLevels& lv, LossScales& sc, int& blocks) {
+  lv.nscale = nscale;
+  int blk = 0;
+  for (int i = 0; i < nscale; i++) {
+    const int s = 1 << i;
+    HDF_CHECK_ARG((D == 1 || D % s == 0) && H % s == 0 && W % s == 0, "loss: size not divisible by %d", s);
+    HDF_CHECK_ARG((int64_t)D * H * W < ((int64_t)1 << 31) - 4096 * 256, "loss: %dx%dx%d voxels per sample", D, H, W);
+    LossLevel& L = lv.L[i];
+    L.logits = logits[i];
+    L.dlogits = dlogits ? dlogits[i] : nullptr;
+    L.Ds = D == 1 ? 1 : D / s, L.Hs = H / s, L.Ws = W / s, L.stride = s;
+    const int64_t V = (int64_t)L.Ds * L.Hs * L.Ws;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(L.logits) | reinterpret_cast<uintptr_t>(L.dlogits) |
+                         reinterpret_cast<uintptr_t>(target);
+    L.vec = (L.Ws % 4 == 0 && (al & 15) == 0) ? 4 : 1;
+    L.blk0 = blk;
+    L.nblk = (int)std::min<int64_t>(std::max<int64_t>(ceil_div64(V, 256 * L.vec), 1), LOSS_BLOCKS);
+    blk += L.nblk;
+    sc.V[i] = (float)V;
+    sc.weight[i] = 1.f / (float)s;
+    sc.blocks[i] = L.nblk;
+  }
+  for (int i = nscale; i < 4; i++) lv.L[i] = lv.L[0], sc.V[i] = 0.f, sc.weight[i] = 0.f, sc.blocks[i] = 0;
+  blocks = blk;
+  return HDF_OK;
+}
+
 int hdf_launch_loss_fwd(int dtype, const void* const* logits, const float* target, int nscale, int N, int C, int D,
                         int H, int W, float* ws, float* loss_out, hipStream_t st, float w_ce, float w_dice,
                         const float* class_weight, int dice_ignore) {
   HDF_CHECK_ARG(C <= MAXC && C >= 2, "loss: n_cls=%d unsupported (2..%d)", C, MAXC);
   HDF_CHECK_ARG(dice_ignore >= -1 && dice_ignore < C, "loss: ignore_index %d outside [-1, %d)", dice_ignore, C);
-  HDF_CHECK_ARG(nscale <= 4 && nscale * N <= 256, "loss: nscale=%d N=%d", nscale, N);
+  HDF_CHECK_ARG(nscale >= 1 && nscale <= 4 && nscale * N <= 256, "loss: nscale=%d N=%d", nscale, N);
   float* partials = ws;
   float* coefA = ws + (size_t)nscale * N * LOSS_BLOCKS * NSTAT;
   float* coefB = coefA + (size_t)nscale * N * MAXC;
+  LossLevels lv;
   LossScales sc;
-  for (int i = 0; i < nscale; i++) {
-    int s = 1 << i;
-    // D == 1: 2-D logits [N][C][H][W] (models/HDenseFormer_2D.py); the nearest down-sampling then strides H and W only
-    HDF_CHECK_ARG((D == 1 || D % s == 0) && H % s == 0 && W % s == 0, "loss: size not divisible by %d", s);
-    int Ds = D == 1 ? 1 : D / s, Hs = H / s, Ws = W / s;
-    sc.V[i] = (float)((int64_t)Ds * Hs * Ws);
-    sc.weight[i] = 1.f / (float)s;
-    float* pi = partials + (size_t)i * N * LOSS_BLOCKS * NSTAT;
-    HDF_DISPATCH_T(dtype, hipLaunchKernelGGL(loss_fwd_kernel<T>, dim3(LOSS_BLOCKS, N), dim3(256), 0, st,
-                                             (const T*)logits[i], target, C, Ds, Hs, Ws, s, D, H, W, class_weight, pi));
-    HDF_LAUNCH_CHECK();
-  }
+  int blocks = 0;
+  HDF_TRY(loss_levels(logits, nullptr, target, nscale, D, H, W, lv, sc, blocks));
+  HDF_DISPATCH_T(dtype, {
+    if (C <= 4)
+      hipLaunchKernelGGL((loss_fwd_kernel<T, 4>), dim3(blocks, N), dim3(256), 0, st, lv, target, C, D, H, W, class_weight,
+                         partials);
+    else
+      hipLaunchKernelGGL((loss_fwd_kernel<T, MAXC>), dim3(blocks, N), dim3(256), 0, st, lv, target, C, D, H, W,
+                         class_weight, partials);
+  });
+  HDF_LAUNCH_CHECK();
   float* terms = coefB + (size_t)nscale * N * MAXC;
   float* wsum = terms + (size_t)nscale * N;  // [nscale]: denominator of the cross-entropy mean (the 16 spare floats)
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(nscale * N), dim3(256), 0, st, partials, nscale, N, C, LOSS_BLOCKS, sc,
-                     1e-5f, w_ce, w_dice, class_weight, dice_ignore, terms, coefA, coefB, wsum);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(nscale * N), dim3(256), 0, st, partials, nscale, N, C, sc, 1e-5f, w_ce,
+                     w_dice, class_weight, dice_ignore, terms, coefA, coefB, wsum);
   HDF_LAUNCH_CHECK();
   hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(64), 0, st, terms, nscale * N, loss_out);
   HDF_LAUNCH_CHECK();
@@ -421,20 +566,23 @@ int hdf_launch_loss_fwd(int dtype, const void* const* logits, const float* targe
 int hdf_launch_loss_bwd(int dtype, const void* const* logits, const float* target, int nscale, int N, int C, int D,
                         int H, int W, const float* ws, const float* grad_out, void* const* dlogits, hipStream_t st,
                         float w_ce, float w_dice, const float* class_weight, int dice_ignore) {
-  const float* coefA = ws + (size_t)nscale * N * LOSS_BLOCKS * NSTAT;
-  const float* coefB = coefA + (size_t)nscale * N * MAXC;
-  const float* wsum = coefB + (size_t)nscale * N * MAXC + (size_t)nscale * N;
-  for (int i = 0; i < nscale; i++) {
-    int s = 1 << i;
-    int Ds = D == 1 ? 1 : D / s, Hs = H / s, Ws = W / s;
-    int64_t V = (int64_t)Ds * Hs * Ws;
-    unsigned gx = (unsigned)std::min<int64_t>(ceil_div64(V, 256), 2048);
-    HDF_DISPATCH_T(dtype, hipLaunchKernelGGL(loss_bwd_kernel<T>, dim3(gx, N), dim3(256), 0, st, (const T*)logits[i],
-                                             target, N, C, Ds, Hs, Ws, s, D, H, W, coefA + (size_t)i * N * MAXC,
-                                             coefB + (size_t)i * N * MAXC, 1.f / (float)s, w_ce, w_dice, class_weight,
-                                             dice_ignore, wsum + i, grad_out, (T*)dlogits[i]));
-    HDF_LAUNCH_CHECK();
-  }
+  HDF_CHECK_ARG(nscale >= 1 && nscale <= 4, "loss: nscale=%d", nscale);
+  LossBwdP q;
+  q.coefA = ws + (size_t)nscale * N * LOSS_BLOCKS * NSTAT;
+  q.coefB = q.coefA + (size_t)nscale * N * MAXC;
+  q.wsum = q.coefB + (size_t)nscale * N * MAXC + (size_t)nscale * N;
+  q.gup = grad_out, q.cw = class_weight, q.w_ce = w_ce, q.w_dice = w_dice, q.ignore = dice_ignore;
+  LossLevels lv;
+  LossScales sc;
+  int blocks = 0;
+  HDF_TRY(loss_levels(logits, dlogits, target, nscale, D, H, W, lv, sc, blocks));
+  HDF_DISPATCH_T(dtype, {
+    if (C <= 4)
+      hipLaunchKernelGGL((loss_bwd_kernel<T, 4>), dim3(blocks, N), dim3(256), 0, st, lv, target, N, C, D, H, W, q);
+    else
+      hipLaunchKernelGGL((loss_bwd_kernel<T, MAXC>), dim3(blocks, N), dim3(256), 0, st, lv, target, N, C, D, H, W, q);
+  });
+  HDF_LAUNCH_CHECK();
   return HDF_OK;
 }
 

@@ -1231,7 +1231,6 @@ static int forward3d(hdf_plan* p, const float* x, const float* params, void* wor
   void* outs[4] = {out0, out1, out2, out3};
   Xf none;
 
-  HDF_TRY(hdf_launch_pack_batch(p->dtype, params, e.ws, p->pack_jobs.data(), (int)p->pack_jobs.size(), e.st));
   // ---- multi-path transformer (HDenseFormer.py:230) -> attnall, then the UpConv chain (:231-235).  Nothing on the
   // encoder's first level depends on it before ds0 = block_1_2_left(..) + at3 (:238), and it is ~100 launches of
   // latency-bound token / attention kernels plus low-resolution convs: it runs on the plan's BRANCH stream next to the
@@ -1248,12 +1247,27 @@ static int forward3d(hdf_plan* p, const float* x, const float* params, void* wor
       if (armed) (void)e.join_branch(eb);
     }
   } rejoin{e, eb, bst != nullptr};
-  // the caller's stream first (3 launches), then the ~65 launches of the branch: the host issues launches one after the
+  // the fork sits in front of the weight pack: the token kernels read the fp32 parameters themselves, only the branch's
+  // convs (deep_conv, up1..3) wait for the packed panels
+  HDF_TRY(hdf_launch_pack_batch(p->dtype, params, e.ws, p->pack_jobs.data(), (int)p->pack_jobs.size(), e.st));
+  hipEvent_t packed = nullptr;
+  if (bst) {
+    packed = e.next_event();
+    if (!packed || hipEventRecord(packed, e.st) != hipSuccess) {
+      hdf_set_error("branch stream: event failed");
+      return HDF_ERR_HIP;
+    }
+  }
+  // the caller's stream first (4 launches), then the ~65 launches of the branch: the host issues launches one after the
   // other, and whatever is issued second starts that much later when the host is not far ahead of the GPU
   HDF_TRY(hdf_launch_nchw_to_ndhwc(p->dtype, x, e.at(p->xin), batch, p->M, 16, p->vox(0), e.st));
   HDF_TRY(conv_forward(e, p->enc[0][0], p->xin, none));
   HDF_TRY(conv_forward(e, p->enc[0][1], p->enc[0][0].y, xf_of(e, p->enc[0][0])));
   HDF_TRY(transformer_forward(eb, x));
+  if (packed && hipStreamWaitEvent(bst, packed, 0) != hipSuccess) {
+    hdf_set_error("branch stream: wait failed");
+    return HDF_ERR_HIP;
+  }
   HDF_TRY(conv_forward(eb, p->deep, p->attnall, none));
   HDF_TRY(hdf_launch_upsample_fwd(p->dtype, eb.at(p->deep.y), p->deep.y.pitch, eb.f(p->deep.st.scale),
                                   eb.f(p->deep.st.shift), eb.at(p->attnout), p->attnout.pitch, batch, 8 * nf,

@@ -554,13 +554,17 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ in,
 // across the block ONCE at the end (the first version rebuilt a 256-voxel LDS tile and ran a 256-deep serial LDS
 // reduction per tile: 3x the HBM time).  grid (blocks, N); C <= 256 (cols = C/8 <= 32).
 constexpr int HEAD_VOX_MAX = 2048;  // voxels per workgroup (fewer at the low-resolution levels: see head_vox)
-// voxels per workgroup: a multiple of 64, at least 128 workgroups per sample when the level has that many voxels
-inline int head_vox(int64_t vox) { return (int)std::max<int64_t>(64, std::min<int64_t>(HEAD_VOX_MAX, (vox / 128) & ~63)); }
-template <typename T, int MC>       // MC: class slots held in registers (4 or 8)
+// voxels per workgroup: a multiple of 64; at least 128 (backward: every workgroup ends with a block reduction and 132
+// atomics; 512 per sample was slower, 39.8 -> 49.4 us at 64^3) / 1024 (forward: with 128 per sample the 64^3 level ran
+// one workgroup per CU at 1.7 TB/s) workgroups per sample when the level has that many 64-voxel groups
+inline int head_vox(int64_t vox, int wgs = 128) {
+  return (int)std::max<int64_t>(64, std::min<int64_t>(HEAD_VOX_MAX, (vox / wgs) & ~63));
+}
+template <typename T, int MC, bool ACC>  // MC: class slots held in registers (4 or 8); ACC: dx += (else dx =)
 __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ dlogits, const T* __restrict__ in,
                                                        int64_t in_pitch, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const float* __restrict__ w,
-                                                       T* __restrict__ dx, int64_t dx_pitch, int accumulate_dx,
+                                                       T* __restrict__ dx, int64_t dx_pitch,
                                                        float* __restrict__ dw, float* __restrict__ db, int N, int C,
                                                        int ncls, int64_t vox, int per,
                                                        const float* __restrict__ in_mean,
@@ -610,14 +614,14 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ dlo
   if (vl < vlanes) {
     constexpr int U = 4;
     for (int64_t v0 = vb + vl; v0 < ve; v0 += (int64_t)U * vlanes) {
-      float f[U][EPC], g[U][EPC], dl[U][MC];
+      float f[U][EPC], g[ACC ? U : 1][EPC], dl[U][MC];
       int64_t row[U];
 #pragma unroll
       for (int u = 0; u < U; u++) {  // clamped: never branch around a load; the tail is masked below
         const int64_t v = min(v0 + (int64_t)u * vlanes, ve - 1);
         row[u] = (int64_t)n * vox + v;
         load_chunk<T>(in + row[u] * in_pitch + c0, f[u]);
-        if (accumulate_dx) load_chunk<T>(dx + row[u] * dx_pitch + c0, g[u]);
+        if (ACC) load_chunk<T>(dx + row[u] * dx_pitch + c0, g[ACC ? u : 0]);
 #pragma unroll
         for (int o = 0; o < MC; o++) dl[u][o] = red[(int)(v - vb) * MC + o];
       }
@@ -631,7 +635,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ dlo
         for (int e = 0; e < EPC; e++) {
           float x = f[u][e];
           if (scale) x = fmaxf(x * sc[e] + sh[e], 0.f);
-          float t = accumulate_dx ? g[u][e] : 0.f;
+          float t = ACC ? g[ACC ? u : 0][e] : 0.f;
 #pragma unroll
           for (int o = 0; o < MC; o++) {
             t += dl[u][o] * wv[o][e];
@@ -675,10 +679,14 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ dlo
     if (o >= ncls) continue;
     float t = 0.f;
     for (int k = 0; k < vlanes; k++) t += red[k * ld + i];
+#ifdef HEAD_DBG_NOATOMIC  // attribution build
+    if (t == 12345.678f) dw[0] = t;
+#else
     if (c < C)
       atomicAdd(dw + o * C + c, t);
     else
       atomicAdd(db + o, t);
+#endif
   }
   if (inb_partials) {  // same fixed-order reduction over the voxel lanes as in_bwd_reduce_kernel
     __syncthreads();
@@ -1051,7 +1059,7 @@ int hdf_launch_head_fwd(int dtype, const void* in, int64_t in_pitch, const float
                         hipStream_t st) {
   HDF_CHECK_ARG(ncls <= HEAD_MAXCLS, "head: n_cls=%d > %d", ncls, HEAD_MAXCLS);
   HDF_CHECK_ARG(C % 16 == 0 && C <= 1024, "head_fwd: C=%d", C);
-  const int per = head_vox(vox);
+  const int per = head_vox(vox, 1024);
   const unsigned gx = (unsigned)ceil_div64(vox, per);
   DISPATCH_T(dtype, {
     if (ncls <= 4)
@@ -1082,17 +1090,16 @@ int hdf_launch_head_bwd(int dtype, const void* dlogits, const void* in, int64_t 
     const int mc = ncls <= 4 ? 4 : 8;
     const size_t shm =
         std::max(std::max((size_t)vlanes * (C + 1) * mc, (size_t)per * mc), (size_t)vlanes * C * 2) * sizeof(float);
-    if (mc == 4) {
-      HDF_TRY(allow_big_lds((const void*)head_bwd_kernel<T, 4>, shm));
-      hipLaunchKernelGGL((head_bwd_kernel<T, 4>), dim3(gx, N), dim3(256), shm, st, (const T*)dlogits, (const T*)in,
-                         in_pitch, scale, shift, w, (T*)dx, dx_pitch, accumulate_dx, dw, db, N, C, ncls, vox, per, in_mean,
-                         in_rstd, inb_partials);
-    } else {
-      HDF_TRY(allow_big_lds((const void*)head_bwd_kernel<T, 8>, shm));
-      hipLaunchKernelGGL((head_bwd_kernel<T, 8>), dim3(gx, N), dim3(256), shm, st, (const T*)dlogits, (const T*)in,
-                         in_pitch, scale, shift, w, (T*)dx, dx_pitch, accumulate_dx, dw, db, N, C, ncls, vox, per, in_mean,
-                         in_rstd, inb_partials);
-    }
+    auto go = [&](auto kern) -> int {
+      HDF_TRY(allow_big_lds((const void*)kern, shm));
+      hipLaunchKernelGGL(kern, dim3(gx, N), dim3(256), shm, st, (const T*)dlogits, (const T*)in, in_pitch, scale, shift, w,
+                         (T*)dx, dx_pitch, dw, db, N, C, ncls, vox, per, in_mean, in_rstd, inb_partials);
+      return HDF_OK;
+    };
+    if (mc == 4)
+      HDF_TRY(accumulate_dx ? go(head_bwd_kernel<T, 4, true>) : go(head_bwd_kernel<T, 4, false>));
+    else
+      HDF_TRY(accumulate_dx ? go(head_bwd_kernel<T, 8, true>) : go(head_bwd_kernel<T, 8, false>));
   });
   HDF_LAUNCH_CHECK();
   return HDF_OK;

@@ -221,6 +221,31 @@ def test_weighted_loss_forms_vs_reference_golden(tag, dt):
         assert _rel(o.grad.float(), torch.from_numpy(g[f"{tag}_grad{i}"])) < tol * 5
 
 
+@pytest.mark.parametrize("shape", [(8, 16, 24), (16, 8, 40), (24, 40)])
+@pytest.mark.parametrize("weighted", [False, True])
+@pytest.mark.parametrize("c", [4, 6])
+def test_fused_loss_on_rows_that_are_not_multiples_of_four_vs_oracle(shape, weighted, c):
+    """The one-launch loss kernels take 4 voxels of a row per thread where the row width of a scale allows it and one
+    otherwise (widths 24/12/6/3, 40/20/10/5; 2-D logits too), with 4 or 8 class slots in registers: loss and logit
+    gradients against the oracle in fp32."""
+    from loss.combine_loss import CEPlusDice, DeepSuperloss
+    gen = torch.Generator().manual_seed(11)
+    n = 2
+    lab = torch.randint(0, c, (n,) + shape, generator=gen)
+    onehot = torch.nn.functional.one_hot(lab, c).movedim(-1, 1).float().contiguous()
+    outs = [torch.randn((n, c) + tuple(d >> i for d in shape), generator=gen) for i in range(4)]
+    w = torch.tensor([0.2, 1.0, 2.0, 0.5, 1.5, 0.7][:c]) if weighted else None
+    ref_in = [o.double().requires_grad_(True) for o in outs]
+    ref = orc.deep_super_loss(ref_in, onehot.double(), weight=None if w is None else w.double(), ignore_index=0)
+    ref.backward()
+    mine_in = [o.to(DEV).requires_grad_(True) for o in outs]
+    loss = DeepSuperloss(criterion=CEPlusDice(weight=w, ignore_index=0))(mine_in, onehot.to(DEV))
+    loss.backward()
+    assert abs(loss.item() - ref.item()) < 2e-5 * abs(ref.item())
+    for a, b in zip(mine_in, ref_in):
+        assert _rel(a.grad, b.grad) < 1e-4
+
+
 @pytest.mark.parametrize("tag", ["c4", "c4_absent", "c3"])
 def test_dice_metric_vs_reference_golden(tag):
     from hdf_rt.loss_fn import compute_dice

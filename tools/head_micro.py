@@ -1,0 +1,67 @@
+"""Micro-driver: the 1x1x1 head kernels (forward / backward) and the fused loss at the four levels of the benchmark
+geometry, HIP-event medians, with the bytes each launch must move."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "h-denseformer_amd")):
+    sys.path.insert(0, p)
+import torch
+
+from hdf_rt._lib import BF16, check, lib, ptr
+
+dev = "cuda:0"
+st = torch.cuda.current_stream().cuda_stream
+N, ncls = 2, 4
+
+
+def med(fn, reps=30, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    return sorted(ts)[len(ts) // 2]
+
+
+for size, C in ((128, 32), (64, 64), (32, 128), (16, 256)):
+    vox = size ** 3
+    x = torch.randn(N, vox, C, device=dev).to(torch.bfloat16)
+    sc, sh = torch.rand(N, C, device=dev) + 0.5, torch.randn(N, C, device=dev) * 0.1
+    w, b = torch.randn(ncls, C, device=dev) * 0.1, torch.zeros(ncls, device=dev)
+    logits = torch.empty(N, ncls, vox, device=dev, dtype=torch.bfloat16)
+    dl = torch.randn(N, ncls, vox, device=dev).to(torch.bfloat16)
+    dx = torch.zeros(N, vox, C, device=dev, dtype=torch.bfloat16)
+    dw, db = torch.zeros(ncls, C, device=dev), torch.zeros(ncls, device=dev)
+    t = med(lambda: check(lib().hdf_op_head_fwd(BF16, ptr(x), C, ptr(sc), ptr(sh), ptr(w), ptr(b), ptr(logits), N, C, ncls,
+                                                vox, st), "head_fwd"))
+    by = x.numel() * 2 + logits.numel() * 2
+    print(f"head_fwd {C}ch @{size}^3: {t:7.1f} us  {by / t / 1e6:6.2f} TB/s")
+    for acc in (0, 1):
+        t = med(lambda: check(lib().hdf_op_head_bwd(BF16, ptr(dl), ptr(x), C, ptr(sc), ptr(sh), ptr(w), ptr(dx), C, acc,
+                                                    ptr(dw), ptr(db), N, C, ncls, vox, st), "head_bwd"))
+        by = x.numel() * 2 * (2 + acc) + dl.numel() * 2
+        print(f"head_bwd {C}ch @{size}^3 accumulate={acc}: {t:7.1f} us  {by / t / 1e6:6.2f} TB/s")
+
+# fused deep-supervision loss, forward and backward
+outs = [torch.randn(N, ncls, 128 >> i, 128 >> i, 128 >> i, device=dev).to(torch.bfloat16) for i in range(4)]
+douts = [torch.empty_like(o) for o in outs]
+lab = torch.randint(0, ncls, (N, 128, 128, 128), device=dev)
+onehot = torch.nn.functional.one_hot(lab, ncls).movedim(-1, 1).float().contiguous()
+ws = torch.empty(lib().hdf_loss_workspace_bytes(N), dtype=torch.uint8, device=dev)
+loss = torch.zeros(1, device=dev)
+gup = torch.ones(1, device=dev)
+t = med(lambda: check(lib().hdf_loss_forward(BF16, *[ptr(o) for o in outs], 4, ptr(onehot), N, ncls, 128, 128, 128, ptr(ws),
+                                            ptr(loss), st), "loss_fwd"))
+by = sum(o.numel() for o in outs) * 2 + onehot.numel() * 4
+print(f"loss forward (4 scales + finalize + total): {t:7.1f} us  {by / t / 1e6:6.2f} TB/s")
+t = med(lambda: check(lib().hdf_loss_backward(BF16, *[ptr(o) for o in outs], 4, ptr(onehot), N, ncls, 128, 128, 128, ptr(ws),
+                                             ptr(gup), *[ptr(o) for o in douts], st), "loss_bwd"))
+by = sum(o.numel() for o in outs) * 4 + onehot.numel() * 4
+print(f"loss backward (4 scales): {t:7.1f} us  {by / t / 1e6:6.2f} TB/s")
