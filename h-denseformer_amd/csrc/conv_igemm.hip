@@ -2609,6 +2609,9 @@ inline int ws_cfg(int mode, int Do, int Ho, int Wo, int row_bytes) {
   return (row_bytes == 32 || row_bytes == 64 || row_bytes == 128) ? 1 : 0;
 }
 
+// transposed conv: row widths convt_fused_kernel is instantiated for
+inline bool convt_fused_rows(int rb) { return rb == 32 || rb == 64 || rb == 128 || rb == 256; }
+
 template <typename T, int CH, int RB, int NB>
 int launch_ws2(const ConvArgs& a, hipStream_t st) {
   const int tiles = a.N * ceil_div(a.Do, 4) * ceil_div(a.Ho, 8) * ceil_div(a.Wo, 8);
@@ -2665,11 +2668,10 @@ int launch_conv_t(int mode, const ConvArgs& a, hipStream_t st) {
         return HDF_OK;
       }
     }
-    if (a.Cin * (int)sizeof(T) <= 256 && !a.accumulate) {  // all 8 parity classes in one workgroup
+    // all 8 parity classes in one workgroup: rows of 32, 64, 128 or 256 bytes (n_filters = 48: 192-byte rows run per class)
+    if (convt_fused_rows(a.Cin * (int)sizeof(T)) && !a.accumulate) {
       dim3 grid(a.N * ceil_div(a.Di, 4) * ceil_div(a.Hi, 8) * ceil_div(a.Wi, 8), a.CoutP / 32);
       const int nfs = a.Cin * (int)sizeof(T) / 32;
-      HDF_CHECK_ARG(nfs == 1 || nfs == 2 || nfs == 4 || nfs == 8, "convT: Cin=%d rows are not 32, 64, 128 or 256 bytes",
-                    a.Cin);
       if (nfs == 8)
         hipLaunchKernelGGL((convt_fused_kernel<T, 4, 8, 8, 2, 8>), grid, dim3(256), 0, st, a);
       else if (nfs == 4)
@@ -2748,7 +2750,7 @@ int hdf_conv_weight_layout(int dtype, int mode, int Cin, int Do, int Ho, int Wo)
   if (rb % 64 != 0) return 0;                       // the pipelined path needs whole 64-byte chunks
   if (mode == 0) return ws_cfg(mode, Do, Ho, Wo, rb) ? 0 : 1;  // conv_ws2_kernel stages row-major panels
   if (mode == 1) return 1;                                 // stride-2 gather conv: pipelined path
-  return rb > 256 ? 1 : 0;  // transposed conv: convt_fused_kernel (rows <= 256 B) reads row-major panels, wider ones run per class
+  return convt_fused_rows(rb) ? 0 : 1;  // transposed conv: convt_fused_kernel reads row-major panels, other widths run per class
 }
 
 int hdf_conv_stat_tiles(int mode, int Do, int Ho, int Wo, int row_bytes) {

@@ -38,17 +38,20 @@ __global__ void nchw_to_ndhwc_kernel(const float* __restrict__ x, T* __restrict_
 }
 
 // ------------------------------------------------------------------------------ IN statistics
-// one workgroup per (n, 32-channel group): 32 tile lanes x 32 channels, 4 independent loads in flight per
-// thread, double accumulation in a fixed order (bitwise reproducible)
-constexpr int FIN_LANES = 32;
-__global__ __launch_bounds__(1024) void in_finalize_kernel(const float* __restrict__ partials, int tiles, int C, int CP,
+// one workgroup per (n, 8-channel group): 32 tile lanes x 8 channels, 4 independent loads in flight per
+// thread, double accumulation in a fixed order (bitwise reproducible).  256 threads and few registers ON PURPOSE: the
+// 1024-thread form (32 x 32, 128 registers) needed a compute unit with every SIMD empty, and next to a persistent conv /
+// weight-gradient kernel of another stream (one wave per SIMD, 300-430 registers) this 5 us kernel waited 60-95 us for
+// that kernel to END (r03c timeline: five such waits on the caller's stream in one backward).
+constexpr int FIN_LANES = 32, FIN_CG = 8;
+__global__ __launch_bounds__(256, 4) void in_finalize_kernel(const float* __restrict__ partials, int tiles, int C, int CP,
                                                            int64_t vox, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps,
                                                            float* __restrict__ mean, float* __restrict__ rstd,
                                                            float* __restrict__ scale, float* __restrict__ shift) {
-  __shared__ double red[FIN_LANES][32][2];
+  __shared__ double red[FIN_LANES][FIN_CG][2];
   const int n = blockIdx.y, cg = blockIdx.x;
-  const int cl = threadIdx.x & 31, c = cg * 32 + cl, tl = threadIdx.x >> 5;
+  const int cl = threadIdx.x & (FIN_CG - 1), c = cg * FIN_CG + cl, tl = threadIdx.x / FIN_CG;
   double s1 = 0.0, s2 = 0.0;
   if (c < CP) {
     const float* p = partials + ((int64_t)n * tiles * CP + c) * 2;
@@ -736,16 +739,17 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const T* __restrict_
   if (vl < vlanes) {
     int64_t per = (vox + blocks - 1) / blocks;
     int64_t vb = (int64_t)blockIdx.x * per, ve = min(vox, vb + per);
-    for (int64_t v0 = vb + vl; v0 < ve; v0 += 4 * vlanes) {
-      float g[4][EPC], f[4][EPC];
+    constexpr int U = 4;
+    for (int64_t v0 = vb + vl; v0 < ve; v0 += U * vlanes) {
+      float g[U][EPC], f[U][EPC];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {  // clamped (never branch around a load); the tail is masked below
+      for (int u = 0; u < U; u++) {  // clamped (never branch around a load); the tail is masked below
         int64_t row = (int64_t)n * vox + min(v0 + (int64_t)u * vlanes, ve - 1);
         load_chunk<T>(da + row * da_pitch + c0, g[u]);
         load_chunk<T>(y + row * y_pitch + c0, f[u]);
       }
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < U; u++) {
         const bool live = v0 + (int64_t)u * vlanes < ve;
 #pragma unroll
         for (int e = 0; e < EPC; e++) {
@@ -769,16 +773,16 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const T* __restrict_
   }
 }
 
-// grid (ceil(C/32), N), 1024 threads = 32 block-lanes x 32 channels (with 8 lanes the 1024-row partial table of a
-// 128^3 level cost 49 us of serial fp64 adds on two workgroups); fixed summation order
-__global__ __launch_bounds__(1024) void in_bwd_finalize_kernel(const float* __restrict__ partials, int blocks, int N,
+// grid (ceil(C/8), N), 256 threads = 32 block-lanes x 8 channels (with 8 lanes the 1024-row partial table of a
+// 128^3 level cost 49 us of serial fp64 adds on two workgroups); fixed summation order; light on purpose (in_finalize)
+__global__ __launch_bounds__(256, 4) void in_bwd_finalize_kernel(const float* __restrict__ partials, int blocks, int N,
                                                                int C, int64_t vox, const float* __restrict__ gamma,
                                                                const float* __restrict__ rstd, float* __restrict__ k1,
                                                                float* __restrict__ ka, float* __restrict__ kb,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta) {
   constexpr int BL = 32;
-  __shared__ double red[BL][32][2];
-  const int n = blockIdx.y, cl = threadIdx.x & 31, c = blockIdx.x * 32 + cl, bl = threadIdx.x >> 5;
+  __shared__ double red[BL][FIN_CG][2];
+  const int n = blockIdx.y, cl = threadIdx.x & (FIN_CG - 1), c = blockIdx.x * FIN_CG + cl, bl = threadIdx.x / FIN_CG;
   double s1 = 0.0, s2 = 0.0;
   if (c < C) {
     const float* p = partials + ((int64_t)n * blocks * C + c) * 2;
@@ -949,11 +953,11 @@ int hdf_launch_nchw_to_ndhwc(int dtype, const float* x, void* out, int N, int C,
 }
 
 // out[c] += sum over `rows` partial rows of partials[row][c][0] (the per-channel SUM column of the conv kernels'
-// InstanceNorm partial table), c < C.  grid ceil(C/32), 1024 threads = 32 row lanes x 32 channels, fixed order.
-__global__ __launch_bounds__(1024) void stat_rows_sum_kernel(const float* __restrict__ partials, int rows, int C, int CP,
+// InstanceNorm partial table), c < C.  grid ceil(C/8), 256 threads = 32 row lanes x 8 channels, fixed order.
+__global__ __launch_bounds__(256, 6) void stat_rows_sum_kernel(const float* __restrict__ partials, int rows, int C, int CP,
                                                              float* __restrict__ out) {
-  __shared__ double red[32][32];
-  const int cl = threadIdx.x & 31, c = blockIdx.x * 32 + cl, rl = threadIdx.x >> 5;
+  __shared__ double red[32][FIN_CG];
+  const int cl = threadIdx.x & (FIN_CG - 1), c = blockIdx.x * FIN_CG + cl, rl = threadIdx.x / FIN_CG;
   double s = 0.0;
   if (c < C) {
     const float* p = partials + (int64_t)c * 2;
@@ -973,7 +977,7 @@ __global__ __launch_bounds__(1024) void stat_rows_sum_kernel(const float* __rest
 }
 
 int hdf_launch_stat_rows_sum(const float* partials, int rows, int C, int CP, float* out, hipStream_t st) {
-  hipLaunchKernelGGL(stat_rows_sum_kernel, dim3(ceil_div(C, 32)), dim3(1024), 0, st, partials, rows, C, CP, out);
+  hipLaunchKernelGGL(stat_rows_sum_kernel, dim3(ceil_div(C, FIN_CG)), dim3(256), 0, st, partials, rows, C, CP, out);
   HDF_LAUNCH_CHECK();
   return HDF_OK;
 }
@@ -981,7 +985,7 @@ int hdf_launch_stat_rows_sum(const float* partials, int rows, int C, int CP, flo
 int hdf_launch_in_finalize(const float* partials, int N, int tiles, int C, int CP, int64_t vox, const float* gamma,
                            const float* beta, float eps, float* mean, float* rstd, float* scale, float* shift,
                            hipStream_t st) {
-  hipLaunchKernelGGL(in_finalize_kernel, dim3(ceil_div(CP, 32), N), dim3(1024), 0, st, partials, tiles, C, CP, vox, gamma,
+  hipLaunchKernelGGL(in_finalize_kernel, dim3(ceil_div(CP, FIN_CG), N), dim3(256), 0, st, partials, tiles, C, CP, vox, gamma,
                      beta, eps, mean, rstd, scale, shift);
   HDF_LAUNCH_CHECK();
   return HDF_OK;
@@ -1130,7 +1134,7 @@ int hdf_launch_in_bwd_reduce(int dtype, const void* da, int64_t da_pitch, const 
 int hdf_launch_in_bwd_finalize(const float* partials, int blocks, int N, int C, int64_t vox, const float* gamma,
                                const float* rstd, float* k1, float* ka, float* kb, float* dgamma, float* dbeta,
                                hipStream_t st) {
-  hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3(ceil_div(C, 32), N), dim3(1024), 0, st, partials, blocks, N, C, vox, gamma,
+  hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3(ceil_div(C, FIN_CG), N), dim3(256), 0, st, partials, blocks, N, C, vox, gamma,
                      rstd, k1, ka, kb, dgamma, dbeta);
   HDF_LAUNCH_CHECK();
   return HDF_OK;
