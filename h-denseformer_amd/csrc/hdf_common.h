@@ -95,9 +95,13 @@ struct ST<float> {
   static constexpr int DT = HDF_F32;
   __device__ static __forceinline__ float ld(const float* p) { return *p; }
   __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
-  // four consecutive elements in one store (p aligned to the store)
+  // four consecutive elements in one store / load (p aligned to the access)
   __device__ static __forceinline__ void st4(float* p, float a, float b, float c, float d) {
     *reinterpret_cast<f32x4*>(p) = f32x4{a, b, c, d};
+  }
+  __device__ static __forceinline__ void ld4(const float* p, float* f) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+    f[0] = v[0], f[1] = v[1], f[2] = v[2], f[3] = v[3];
   }
   // unpack a 16-B chunk into EPC floats / pack back
   __device__ static __forceinline__ void unpack(const u32x4& c, float* f) {
@@ -119,6 +123,11 @@ struct ST<bf16_t> {
   __device__ static __forceinline__ void st(bf16_t* p, float v) { p->v = f2bf(v); }
   __device__ static __forceinline__ void st4(bf16_t* p, float a, float b, float c, float d) {
     *reinterpret_cast<u32x2*>(p) = u32x2{pack_bf2(a, b), pack_bf2(c, d)};
+  }
+  __device__ static __forceinline__ void ld4(const bf16_t* p, float* f) {
+    const u32x2 v = *reinterpret_cast<const u32x2*>(p);
+    f[0] = __uint_as_float(v[0] << 16), f[1] = __uint_as_float(v[0] & 0xffff0000u);
+    f[2] = __uint_as_float(v[1] << 16), f[3] = __uint_as_float(v[1] & 0xffff0000u);
   }
   __device__ static __forceinline__ void unpack(const u32x4& c, float* f) {
 #pragma unroll
@@ -144,6 +153,12 @@ struct ST<f16_t> {
   __device__ static __forceinline__ void st(f16_t* p, float v) { p->v = f2h(v); }
   __device__ static __forceinline__ void st4(f16_t* p, float a, float b, float c, float d) {
     *reinterpret_cast<u32x2*>(p) = u32x2{pack_h2(a, b), pack_h2(c, d)};
+  }
+  __device__ static __forceinline__ void ld4(const f16_t* p, float* f) {
+    const u32x2 v = *reinterpret_cast<const u32x2*>(p);
+    const uint32_t w0 = v[0], w1 = v[1];  // (through scalars: see unpack)
+    f[0] = h2f((uint16_t)(w0 & 0xffffu)), f[1] = h2f((uint16_t)(w0 >> 16));
+    f[2] = h2f((uint16_t)(w1 & 0xffffu)), f[3] = h2f((uint16_t)(w1 >> 16));
   }
   __device__ static __forceinline__ void unpack(const u32x4& c, float* f) {
 #pragma unroll

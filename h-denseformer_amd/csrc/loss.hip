@@ -34,20 +34,9 @@ template <typename T>
 __device__ __forceinline__ void ld_vox(const T* p, float* f, std::integral_constant<int, 1>) {
   f[0] = ST<T>::ld(p);
 }
-__device__ __forceinline__ void ld_vox(const float* p, float* f, std::integral_constant<int, 4>) {
-  const f32x4 v = *reinterpret_cast<const f32x4*>(p);
-  f[0] = v[0], f[1] = v[1], f[2] = v[2], f[3] = v[3];
-}
-__device__ __forceinline__ void ld_vox(const bf16_t* p, float* f, std::integral_constant<int, 4>) {
-  const u32x2 v = *reinterpret_cast<const u32x2*>(p);
-  f[0] = __uint_as_float(v[0] << 16), f[1] = __uint_as_float(v[0] & 0xffff0000u);
-  f[2] = __uint_as_float(v[1] << 16), f[3] = __uint_as_float(v[1] & 0xffff0000u);
-}
-__device__ __forceinline__ void ld_vox(const f16_t* p, float* f, std::integral_constant<int, 4>) {
-  const u32x2 v = *reinterpret_cast<const u32x2*>(p);
-  const uint32_t w0 = v[0], w1 = v[1];
-  f[0] = h2f((uint16_t)(w0 & 0xffffu)), f[1] = h2f((uint16_t)(w0 >> 16));
-  f[2] = h2f((uint16_t)(w1 & 0xffffu)), f[3] = h2f((uint16_t)(w1 >> 16));
+template <typename T>
+__device__ __forceinline__ void ld_vox(const T* p, float* f, std::integral_constant<int, 4>) {
+  ST<T>::ld4(p, f);
 }
 template <typename T>
 __device__ __forceinline__ void st_vox(T* p, const float* f, std::integral_constant<int, 1>) {

@@ -773,6 +773,123 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const T* __restrict_
   }
 }
 
+// Register-light forms of the two streaming passes for 16-bit storage: FOUR channels per thread (8-byte loads; the forms
+// above take 8 with 16-byte loads and need 160 / 114 registers).  Backward runs these passes on the caller's stream NEXT
+// TO a persistent weight-gradient kernel of the side stream that holds one wave per SIMD with 301-376 of its 512
+// registers: the heavy forms then got one wave per SIMD or none at all (a reduce pass of 60 us took 237 us, and the
+// weight gradient it was supposed to hide cost as much as it saved); these fit two to three waves into what is left.
+template <typename T>
+__global__ __launch_bounds__(256, 6) void in_bwd_reduce4_kernel(const T* __restrict__ da, int64_t da_pitch,
+                                                                const T* __restrict__ y, int64_t y_pitch,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ shift,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd,
+                                                                float* __restrict__ partials, int blocks, int C,
+                                                                int64_t vox) {
+  extern __shared__ float red[];  // [vlanes][C][2]
+  const int n = blockIdx.y;
+  const int cols = C >> 2, vlanes = 256 / cols;
+  const int col = threadIdx.x % cols, vl = threadIdx.x / cols, c0 = col * 4;
+  float s1[4], s2[4], sc[4], sh[4], mu[4], rs[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const int64_t o = (int64_t)n * C + c0 + e;
+    s1[e] = s2[e] = 0.f;
+    sc[e] = scale[o], sh[e] = shift[o], mu[e] = mean[o], rs[e] = rstd[o];
+  }
+  if (vl < vlanes) {
+    const int64_t per = (vox + blocks - 1) / blocks;
+    const int64_t vb = (int64_t)blockIdx.x * per, ve = min(vox, vb + per);
+    constexpr int U = 4;
+    const T* dap = da + (int64_t)n * vox * da_pitch + c0;
+    const T* yp = y + (int64_t)n * vox * y_pitch + c0;
+    for (int64_t v0 = vb + vl; v0 < ve; v0 += U * vlanes) {
+      float g[U][4], f[U][4];
+#pragma unroll
+      for (int u = 0; u < U; u++) {  // clamped (never branch around a load); the tail is masked below
+        const int64_t v = min(v0 + (int64_t)u * vlanes, ve - 1);
+        ST<T>::ld4(dap + v * da_pitch, g[u]);
+        ST<T>::ld4(yp + v * y_pitch, f[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const bool live = v0 + (int64_t)u * vlanes < ve;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const float gg = (live && f[u][e] * sc[e] + sh[e] > 0.f) ? g[u][e] : 0.f;
+          s1[e] += gg;
+          s2[e] += gg * ((f[u][e] - mu[e]) * rs[e]);
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      red[(vl * C + c0 + e) * 2 + 0] = s1[e];
+      red[(vl * C + c0 + e) * 2 + 1] = s2[e];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C * 2; i += 256) {
+    float s = 0.f;
+    for (int k = 0; k < vlanes; k++) s += red[k * C * 2 + i];
+    partials[((int64_t)n * blocks + blockIdx.x) * C * 2 + i] = s;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 8) void in_bwd_apply4_kernel(const T* __restrict__ da, int64_t da_pitch,
+                                                               const T* __restrict__ y, int64_t y_pitch,
+                                                               const float* __restrict__ scale,
+                                                               const float* __restrict__ shift,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd,
+                                                               const float* __restrict__ k1,
+                                                               const float* __restrict__ ka,
+                                                               const float* __restrict__ kb, T* __restrict__ dy,
+                                                               int64_t dy_pitch, int C, int64_t vox) {
+  constexpr int U = 4;
+  const int n = blockIdx.y;
+  const int cols = C >> 2, vlanes = 256 / cols;
+  const int col = threadIdx.x % cols, vl = threadIdx.x / cols, c0 = col * 4;
+  if (vl >= vlanes) return;
+  float sc[4], sh[4], mu[4], rs[4], c1[4], ca[4], cb[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const int64_t o = (int64_t)n * C + c0 + e;
+    sc[e] = scale[o], sh[e] = shift[o], mu[e] = mean[o], rs[e] = rstd[o];
+    c1[e] = k1[o], ca[e] = ka[o], cb[e] = kb[o];
+  }
+  const int64_t per = (vox + gridDim.x - 1) / gridDim.x;
+  const int64_t vb = (int64_t)blockIdx.x * per, ve = min(vox, vb + per);
+  const T* dap = da + (int64_t)n * vox * da_pitch + c0;
+  const T* yp = y + (int64_t)n * vox * y_pitch + c0;
+  T* dyp = dy + (int64_t)n * vox * dy_pitch + c0;
+  for (int64_t v0 = vb + vl; v0 < ve; v0 += (int64_t)U * vlanes) {
+    float g[U][4], f[U][4];
+#pragma unroll
+    for (int u = 0; u < U; u++) {  // clamped: never branch around a load
+      const int64_t v = min(v0 + (int64_t)u * vlanes, ve - 1);
+      ST<T>::ld4(dap + v * da_pitch, g[u]);
+      ST<T>::ld4(yp + v * y_pitch, f[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t v = v0 + (int64_t)u * vlanes;
+      if (v < ve) {
+        float d[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const float gg = (f[u][e] * sc[e] + sh[e] > 0.f) ? g[u][e] : 0.f;
+          const float xh = (f[u][e] - mu[e]) * rs[e];
+          d[e] = c1[e] * (gg - ca[e] - xh * cb[e]);
+        }
+        ST<T>::st4(dyp + v * dy_pitch, d[0], d[1], d[2], d[3]);
+      }
+    }
+  }
+}
+
 // grid (ceil(C/8), N), 256 threads = 32 block-lanes x 8 channels (with 8 lanes the 1024-row partial table of a
 // 128^3 level cost 49 us of serial fp64 adds on two workgroups); fixed summation order; light on purpose (in_finalize)
 __global__ __launch_bounds__(256, 4) void in_bwd_finalize_kernel(const float* __restrict__ partials, int blocks, int N,
@@ -1120,12 +1237,21 @@ int hdf_launch_in_bwd_reduce(int dtype, const void* da, int64_t da_pitch, const 
                              float* partials, int blocks, int N, int C, int64_t vox, hipStream_t st) {
   HDF_CHECK_ARG(C % 16 == 0 && C <= 1024, "in_bwd: C=%d", C);
   DISPATCH_T(dtype, {
-    int cols = C / ST<T>::EPC;
-    HDF_CHECK_ARG(cols <= 256, "in_bwd: C=%d too wide", C);
-    int vlanes = 256 / cols;
-    size_t shm = (size_t)vlanes * C * 2 * sizeof(float);
-    hipLaunchKernelGGL(in_bwd_reduce_kernel<T>, dim3(blocks, N), dim3(256), shm, st, (const T*)da, da_pitch,
-                       (const T*)y, y_pitch, scale, shift, mean, rstd, partials, blocks, C, vox);
+#ifndef INB_HEAVY
+    if constexpr (sizeof(T) == 2) {  // register-light form: co-runs with the side stream's weight gradients
+      const int vlanes = 256 / (C / 4);
+      hipLaunchKernelGGL(in_bwd_reduce4_kernel<T>, dim3(blocks, N), dim3(256), (size_t)vlanes * C * 2 * sizeof(float), st,
+                         (const T*)da, da_pitch, (const T*)y, y_pitch, scale, shift, mean, rstd, partials, blocks, C, vox);
+    } else
+#endif
+    {
+      int cols = C / ST<T>::EPC;
+      HDF_CHECK_ARG(cols <= 256, "in_bwd: C=%d too wide", C);
+      int vlanes = 256 / cols;
+      size_t shm = (size_t)vlanes * C * 2 * sizeof(float);
+      hipLaunchKernelGGL(in_bwd_reduce_kernel<T>, dim3(blocks, N), dim3(256), shm, st, (const T*)da, da_pitch,
+                         (const T*)y, y_pitch, scale, shift, mean, rstd, partials, blocks, C, vox);
+    }
   });
   HDF_LAUNCH_CHECK();
   return HDF_OK;
@@ -1147,9 +1273,16 @@ int hdf_launch_in_bwd_apply(int dtype, const void* da, int64_t da_pitch, const v
   HDF_CHECK_ARG(C % 16 == 0 && C <= 1024, "in_bwd_apply: C=%d", C);
   // ~1K chunks per workgroup, at most 2048 workgroups per sample
   const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, vox * (C / 8) / 1024));
-  DISPATCH_T(dtype, hipLaunchKernelGGL(in_bwd_apply_kernel<T>, dim3(blocks, N), dim3(256), 0, st, (const T*)da,
-                                       da_pitch, (const T*)y, y_pitch, scale, shift, mean, rstd, k1, ka, kb, (T*)dy,
-                                       dy_pitch, C, vox));
+  DISPATCH_T(dtype, {
+#ifndef INB_HEAVY
+    if constexpr (sizeof(T) == 2)
+      hipLaunchKernelGGL(in_bwd_apply4_kernel<T>, dim3(blocks, N), dim3(256), 0, st, (const T*)da, da_pitch, (const T*)y,
+                         y_pitch, scale, shift, mean, rstd, k1, ka, kb, (T*)dy, dy_pitch, C, vox);
+    else
+#endif
+      hipLaunchKernelGGL(in_bwd_apply_kernel<T>, dim3(blocks, N), dim3(256), 0, st, (const T*)da, da_pitch, (const T*)y,
+                         y_pitch, scale, shift, mean, rstd, k1, ka, kb, (T*)dy, dy_pitch, C, vox);
+  });
   HDF_LAUNCH_CHECK();
   return HDF_OK;
 }
