@@ -563,8 +563,20 @@ constexpr int HEAD_VOX_MAX = 2048;  // voxels per workgroup (fewer at the low-re
 inline int head_vox(int64_t vox, int wgs = 128) {
   return (int)std::max<int64_t>(64, std::min<int64_t>(HEAD_VOX_MAX, (vox / wgs) & ~63));
 }
-template <typename T, int MC, bool ACC>  // MC: class slots held in registers (4 or 8); ACC: dx += (else dx =)
-__global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ dlogits, const T* __restrict__ in,
+// storage rounding of one value (what a later pass would read back)
+template <typename T>
+__device__ __forceinline__ float storage_round(float v) {
+  T t;
+  ST<T>::st(&t, v);
+  return ST<T>::ld(&t);
+}
+// MC: class slots held in registers (4 or 8); ACC: dx += (else dx =).  FOUR channels per thread for every storage type
+// (16-bit: 8-byte loads, two voxel rows in flight, <= 128 registers).  The 8-channel form for 16-bit storage needed 238
+// registers: below the top level the head gradient runs next to a persistent weight-gradient kernel of the side stream
+// (one wave per SIMD, 301-376 registers) and WAITED for that kernel to end (179 us instead of 58 at 64^3 in the r03c
+// timeline); alone the light form is as fast at 128^3 (151 vs 159 us), slower at 64^3 (52 vs 38 us).
+template <typename T, int MC, bool ACC>
+__global__ __launch_bounds__(256, (MC == 4 && sizeof(T) == 2) ? 4 : 1) void head_bwd_kernel(const T* __restrict__ dlogits, const T* __restrict__ in,
                                                        int64_t in_pitch, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const float* __restrict__ w,
                                                        T* __restrict__ dx, int64_t dx_pitch,
@@ -573,7 +585,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ dlo
                                                        const float* __restrict__ in_mean,
                                                        const float* __restrict__ in_rstd,
                                                        float* __restrict__ inb_partials) {
-  constexpr int EPC = ST<T>::EPC;
+  constexpr int EPC = 4;
   // inb_partials (optional): this kernel produces the complete gradient dx of the activation relu(IN(in)), so it
   // also writes the first pass of that InstanceNorm's backward -- per workgroup and channel (sum g, sum g*xhat) with
   // g = dx where the activation is positive, row layout of in_bwd_reduce_kernel with gridDim.x rows per sample -- and
@@ -615,7 +627,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ dlo
   }
   __syncthreads();
   if (vl < vlanes) {
-    constexpr int U = 4;
+    constexpr int U = sizeof(T) == 2 ? 2 : 4;  // 16-bit storage: 128 registers
     for (int64_t v0 = vb + vl; v0 < ve; v0 += (int64_t)U * vlanes) {
       float f[U][EPC], g[ACC ? U : 1][EPC], dl[U][MC];
       int64_t row[U];
@@ -623,8 +635,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ dlo
       for (int u = 0; u < U; u++) {  // clamped: never branch around a load; the tail is masked below
         const int64_t v = min(v0 + (int64_t)u * vlanes, ve - 1);
         row[u] = (int64_t)n * vox + v;
-        load_chunk<T>(in + row[u] * in_pitch + c0, f[u]);
-        if (ACC) load_chunk<T>(dx + row[u] * dx_pitch + c0, g[ACC ? u : 0]);
+        ST<T>::ld4(in + row[u] * in_pitch + c0, f[u]);
+        if (ACC) ST<T>::ld4(dx + row[u] * dx_pitch + c0, g[ACC ? u : 0]);
 #pragma unroll
         for (int o = 0; o < MC; o++) dl[u][o] = red[(int)(v - vb) * MC + o];
       }
@@ -647,13 +659,11 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ dlo
           // relu of the producing norm is handled by the IN backward of that layer (dx is d/d activation)
           d[e] = t;
         }
-        if (live) store_chunk<T>(dx + row[u] * dx_pitch + c0, d);
+        if (live) ST<T>::st4(dx + row[u] * dx_pitch + c0, d[0], d[1], d[2], d[3]);
         if (inb_partials) {
-          float dr[EPC];
-          ST<T>::unpack(ST<T>::pack(d), dr);
 #pragma unroll
           for (int e = 0; e < EPC; e++) {
-            const float gg = (live && f[u][e] * sc[e] + sh[e] > 0.f) ? dr[e] : 0.f;
+            const float gg = (live && f[u][e] * sc[e] + sh[e] > 0.f) ? storage_round<T>(d[e]) : 0.f;
             s1[e] += gg;
             s2[e] += gg * ((f[u][e] - mu[e]) * rs[e]);
           }
@@ -1202,12 +1212,12 @@ int hdf_launch_head_bwd(int dtype, const void* dlogits, const void* in, int64_t 
                         float* db, int N, int C, int ncls, int64_t vox, hipStream_t st, const float* in_mean,
                         const float* in_rstd, float* inb_partials) {
   HDF_CHECK_ARG(ncls <= HEAD_MAXCLS, "head: n_cls=%d > %d", ncls, HEAD_MAXCLS);
-  HDF_CHECK_ARG(C % 16 == 0 && C <= 1024, "head_bwd: C=%d", C);
+  HDF_CHECK_ARG(C % 16 == 0 && C <= 1024, "head_bwd: C=%d", C);  // (C / 4 <= 256 chunk lanes)
   HDF_CHECK_ARG(inb_partials == nullptr || (scale && in_mean && in_rstd), "head_bwd: IN partials need the layer's statistics");
   const int per = head_vox(vox);
   const unsigned gx = (unsigned)hdf_head_bwd_blocks(vox);
   DISPATCH_T(dtype, {
-    const int cols = C / ST<T>::EPC, vlanes = 256 / cols;
+    const int cols = C / 4, vlanes = 256 / cols;
     const int mc = ncls <= 4 ? 4 : 8;
     const size_t shm =
         std::max(std::max((size_t)vlanes * (C + 1) * mc, (size_t)per * mc), (size_t)vlanes * C * 2) * sizeof(float);
