@@ -984,7 +984,7 @@ __global__ __launch_bounds__(256) void tf_wgrad_kernel(TfWgradArgs a) {
   }
   __syncthreads();
   if (wave == 0) {
-    float* gW = a.grads + (int64_t)m * a.mstride + a.block0 + (int64_t)b * a.block_stride + e.poff;
+    float* gW = a.grads + (int64_t)m * a.mstride + a.block0 + (int64_t)bb * a.block_stride + e.poff;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
