@@ -561,8 +561,8 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwd a) {
   const TfDims& d = a.d;
   const int DM = d.DM, DMF = d.DMF, ldF = DMF + 4, ldD = DM + 4;
   float* s_F = sm;                      // [16][ldF]  feature rows (PREB: block bq; OUTB: block bo)
-  float* s_do = s_F + TT * ldF;         // [16][ldD]  OUTB: masked gradient of the out_layer output
-  float* s_dq = s_do + TT * ldD;        // [16][100]  PREB: dqkv tile
+  float* s_do = s_F + TT * ldF;         // [16][ldD]  OUTB: masked gradient of the out_layer output (no room otherwise:
+  float* s_dq = s_do + (OUTB ? TT * ldD : 0);  // [16][100]  PREB: dqkv tile      see launch_tok_bwd)
   float* s_a = s_dq + TT * 100;         // [16][36] x 6 small tiles
   float* s_b = s_a + TT * LD32;
   float* s_c = s_b + TT * LD32;
@@ -997,8 +997,12 @@ template <bool PREB, bool OUTB, bool POSTB, typename T>
 int launch_tok_bwd(const TokBwd& a, hipStream_t st) {
   const TfDims& d = a.d;
   dim3 grid(ceil_div(d.B * d.N, TT), d.M);
-  const size_t shm = (size_t)(TT * (d.DMF + 4) + TT * (d.DM + 4) + TT * 100 + 7 * TT * LD32 + 2 * TT * LD64 + 2 * 16 * 16) *
-                     sizeof(float);
+  // The inner-layer form (no out_layer stage) leaves out that stage's [16][DM + 4] tile: 49.9 KB instead of 58.4 KB at
+  // DM = 128, and with that it fits beside a level-0 weight-gradient workgroup of the side stream (110 KB of LDS, 304 of
+  // the 512 registers per lane against this kernel's 208): the transformer backward then advances next to it instead
+  // of queueing behind it.
+  const size_t shm = (size_t)(TT * (d.DMF + 4) + (OUTB ? TT * (d.DM + 4) : 0) + TT * 100 + 7 * TT * LD32 + 2 * TT * LD64 +
+                              2 * 16 * 16) * sizeof(float);
   HDF_TRY(allow_lds_f(tok_bwd_kernel<PREB, OUTB, POSTB, T>, shm));
   hipLaunchKernelGGL((tok_bwd_kernel<PREB, OUTB, POSTB, T>), grid, dim3(256), shm, st, a);
   HDF_LAUNCH_CHECK();
