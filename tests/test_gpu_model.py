@@ -246,6 +246,35 @@ def test_fused_loss_on_rows_that_are_not_multiples_of_four_vs_oracle(shape, weig
         assert _rel(a.grad, b.grad) < 1e-4
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_fused_loss_on_views_that_are_not_16_byte_aligned(dt):
+    """The 4-voxel loads of the loss kernels need aligned rows; logits handed over as a view one element into its
+    storage (contiguous, but 2 or 4 bytes off) take the one-voxel form: same loss, same gradients."""
+    from loss.combine_loss import CEPlusDice, DeepSuperloss
+    g = np.load(os.path.join(GOLDEN, "g3_loss.npz"))
+    onehot = torch.from_numpy(g["c4_onehot"].astype(np.float32)).to(DEV)
+    crit = DeepSuperloss(criterion=CEPlusDice(weight=None, ignore_index=0))
+
+    def run(shift):
+        outs = []
+        for i in range(4):
+            ref = torch.from_numpy(g[f"c4_logits{i}"]).to(DEV).to(dt)
+            buf = torch.zeros(ref.numel() + 8, device=DEV, dtype=dt)
+            v = buf[shift:shift + ref.numel()].view(ref.shape)
+            v.copy_(ref)
+            assert v.is_contiguous() and (v.data_ptr() % 16 != 0) == (shift % (16 // v.element_size()) != 0)
+            outs.append(v.requires_grad_(True))
+        loss = crit(outs, onehot)
+        loss.backward()
+        return loss.item(), [o.grad.float() for o in outs]
+
+    l0, g0 = run(0)
+    l1, g1 = run(1)
+    assert abs(l0 - l1) < 1e-5 * abs(l0)
+    for a, b in zip(g0, g1):
+        assert _rel(b, a) < (1e-5 if dt == torch.float32 else 1e-2)
+
+
 @pytest.mark.parametrize("tag", ["c4", "c4_absent", "c3"])
 def test_dice_metric_vs_reference_golden(tag):
     from hdf_rt.loss_fn import compute_dice
