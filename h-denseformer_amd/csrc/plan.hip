@@ -1744,6 +1744,13 @@ int hdf_op_maxpool_fwd(int dtype, const void* in, int64_t in_pitch, void* out, i
                        int C, int Do, int Ho, int Wo, hdf_stream stream) {
   return hdf_launch_maxpool_fwd(dtype, in, in_pitch, out, out_pitch, idx, N, C, Do, Ho, Wo, (hipStream_t)stream);
 }
+int hdf_op_enc_tail(int dtype, const void* y, int64_t y_pitch, const float* scale, const float* shift, const void* skip,
+                    int64_t skip_pitch, void* ds, int64_t ds_pitch, void* pooled, int64_t pooled_pitch, uint8_t* idx,
+                    int N, int C, int Do, int Ho, int Wo, hdf_stream stream) {
+  HDF_CHECK_ARG(y && scale && shift && skip && ds && pooled && idx, "enc_tail: null argument");
+  return hdf_launch_enc_tail(dtype, y, y_pitch, scale, shift, skip, skip_pitch, ds, ds_pitch, pooled, pooled_pitch, idx, N,
+                             C, Do, Ho, Wo, (hipStream_t)stream);
+}
 int hdf_op_maxpool_bwd(int dtype, const void* dout, int64_t dout_pitch, const uint8_t* idx, void* din,
                        int64_t din_pitch, int N, int C, int Do, int Ho, int Wo, int accumulate, hdf_stream stream) {
   return hdf_launch_maxpool_bwd(dtype, dout, dout_pitch, idx, din, din_pitch, N, C, Do, Ho, Wo, accumulate,

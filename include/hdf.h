@@ -204,6 +204,13 @@ int hdf_op_norm_relu_add(int dtype, const void* y, int64_t y_pitch, const float*
                          int64_t voxels, hdf_stream stream);
 int hdf_op_maxpool_fwd(int dtype, const void* in, int64_t in_pitch, void* out, int64_t out_pitch, uint8_t* idx, int N,
                        int C, int Do, int Ho, int Wo, hdf_stream stream);
+/* The encoder tail of a level in one pass (models/HDenseFormer.py:238-243): ds = relu(y * scale + shift) + skip (the
+ * InstanceNorm + ReLU of the level's second conv plus the transformer feature at_k), stored, and MaxPool3d(2) of the stored
+ * values with the arg-max byte per channel (0..7 = dz*4 + dy*2 + dx, first maximum in scan order as torch).
+ * (Do, Ho, Wo) = the pooled size. */
+int hdf_op_enc_tail(int dtype, const void* y, int64_t y_pitch, const float* scale, const float* shift, const void* skip,
+                    int64_t skip_pitch, void* ds, int64_t ds_pitch, void* pooled, int64_t pooled_pitch, uint8_t* idx,
+                    int N, int C, int Do, int Ho, int Wo, hdf_stream stream);
 int hdf_op_maxpool_bwd(int dtype, const void* dout, int64_t dout_pitch, const uint8_t* idx, void* din,
                        int64_t din_pitch, int N, int C, int Do, int Ho, int Wo, int accumulate, hdf_stream stream);
 int hdf_op_upsample_fwd(int dtype, const void* y, int64_t y_pitch, const float* scale, const float* shift, void* out,

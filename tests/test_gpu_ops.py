@@ -310,6 +310,44 @@ def test_pool_upsample(dtype):
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16, F16])
+@pytest.mark.parametrize("c", [16, 32, 48, 128])
+def test_encoder_tail_vs_torch(dtype, c):
+    """hdf_op_enc_tail: ds = relu(y * scale + shift) + skip and MaxPool3d(2) of the stored ds with torch's tie rule, in one
+    pass (HDenseFormer.py:238-243), incl. a channel count that is not a power of two, exact ties (a block of zeros after the
+    ReLU: the FIRST maximum in scan order must win) and a negative gamma."""
+    n, size = 2, (8, 12, 16)
+    y = _mk((n, c) + size, 31)
+    skip = _mk((n, c) + size, 32)
+    skip[:, :, :2] = 0.0
+    y[:, :, :2] = -1.0                                  # relu -> exact zeros: ties, the FIRST maximum must win
+    scale, shift = _mk((n, c), 33) * 0.5 + 1.0, _mk((n, c), 34) * 0.3
+    scale[:, 0] = -scale[:, 0]                          # a negative gamma
+    shift[:, 1] = -abs(shift[:, 1])                     # channel 1 of the zeroed planes: relu(-1 * s + t) == 0 exactly
+    scale[:, 1] = abs(scale[:, 1])
+    act = torch.relu(rnd(y, dtype) * scale[:, :, None, None, None] + shift[:, :, None, None, None]) + rnd(skip, dtype)
+    ds_ref = rnd(act, dtype)
+    y_cl, sk_cl = to_cl(y, dtype), to_cl(skip, dtype)
+    ds = torch.empty_like(y_cl)
+    po = torch.empty((n,) + tuple(v // 2 for v in size) + (c,), dtype=y_cl.dtype, device=DEV)
+    idx = torch.empty(po.shape, dtype=torch.uint8, device=DEV)
+    sc, sh = scale.to(DEV).contiguous(), shift.to(DEV).contiguous()
+    check(lib().hdf_op_enc_tail(dtype, ptr(y_cl), c, ptr(sc), ptr(sh), ptr(sk_cl), c, ptr(ds), c, ptr(po), c, ptr(idx), n, c,
+                                *po.shape[1:4], st()), "enc_tail")
+    torch.cuda.synchronize()
+    got_ds, got_po = from_cl(ds), from_cl(po)
+    assert rel_err(got_ds, ds_ref) < TOL[dtype]
+    # pooling is exact on the stored values: compare against a pool of OUR stored ds
+    po2, idx2 = F.max_pool3d(got_ds, 2, return_indices=True)
+    assert bool((got_po == po2).all())
+    # arg-max byte -> flat index of the full-resolution volume, as torch reports it
+    k = idx.permute(0, 4, 1, 2, 3).cpu().long()
+    od, oh, ow = torch.meshgrid(*[torch.arange(v // 2) for v in size], indexing="ij")
+    flat = ((2 * od + (k >> 2)) * size[1] + 2 * oh + ((k >> 1) & 1)) * size[2] + 2 * ow + (k & 1)
+    assert bool((flat == idx2).all())
+    assert int((got_ds[:, 1, :2] == 0).sum()) == got_ds[:, 1, :2].numel()      # the tie case is really in the data
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16, F16])
 @pytest.mark.parametrize("n,c,size", [(2, 32, (8, 12, 16)), (1, 64, (20, 16, 24)), (2, 16, (32, 32, 36))])
 def test_instance_norm_relu_backward(dtype, n, c, size):
     """hdf_op_in_bwd (reduce + finalize + apply) vs autograd of relu(InstanceNorm3d(affine)(y)) (HDenseFormer.py:152-158)."""

@@ -65,3 +65,18 @@ t = med(lambda: check(lib().hdf_loss_backward(BF16, *[ptr(o) for o in outs], 4, 
                                              ptr(gup), *[ptr(o) for o in douts], st), "loss_bwd"))
 by = sum(o.numel() for o in outs) * 4 + onehot.numel() * 4
 print(f"loss backward (4 scales): {t:7.1f} us  {by / t / 1e6:6.2f} TB/s")
+
+# encoder tail (relu(IN) + skip, stored, max-pooled) at the three encoder levels
+for size, C in ((128, 32), (64, 64), (32, 128)):
+    vox = size ** 3
+    y = torch.randn(N, vox, C, device=dev).to(torch.bfloat16)
+    sk = torch.randn(N, vox, C, device=dev).to(torch.bfloat16)
+    sc, sh = torch.rand(N, C, device=dev) + 0.5, torch.randn(N, C, device=dev) * 0.1
+    ds = torch.empty_like(y)
+    po = torch.empty(N, vox // 8, C, device=dev, dtype=torch.bfloat16)
+    ix = torch.empty(N, vox // 8, C, device=dev, dtype=torch.uint8)
+    h = size // 2
+    t = med(lambda: check(lib().hdf_op_enc_tail(BF16, ptr(y), C, ptr(sc), ptr(sh), ptr(sk), C, ptr(ds), C, ptr(po), C, ptr(ix),
+                                                N, C, h, h, h, st), "enc_tail"))
+    by = y.numel() * 2 * 3 + po.numel() * 3
+    print(f"enc_tail {C}ch @{size}^3: {t:7.1f} us  {by / t / 1e6:6.2f} TB/s")
