@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ in,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        const float* __restrict__ w, const float* __restrict__ b,
                                                        T* __restrict__ logits, int N, int C, int ncls, int64_t vox,
-                                                       int per) {
+                                                       int per, int vec4) {
   constexpr int EPC = ST<T>::EPC;
   extern __shared__ float outs[];  // [MC][per], then [256][MC] partials when cols is not a power of two
   float* part = outs + MC * per;
@@ -547,8 +547,15 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ in,
   __syncthreads();
   for (int o = 0; o < ncls; o++) {
     const float bo = b[o];
-    for (int lv = threadIdx.x; lv < per; lv += 256)
-      if (vb + lv < vox) ST<T>::st(logits + ((int64_t)n * ncls + o) * vox + vb + lv, outs[o * per + lv] + bo);
+    if (vec4) {  // four voxels of the class plane per store
+      for (int lv = threadIdx.x * 4; lv < per; lv += 1024)
+        if (vb + lv < vox)
+          ST<T>::st4(logits + ((int64_t)n * ncls + o) * vox + vb + lv, outs[o * per + lv] + bo, outs[o * per + lv + 1] + bo,
+                     outs[o * per + lv + 2] + bo, outs[o * per + lv + 3] + bo);
+    } else {
+      for (int lv = threadIdx.x; lv < per; lv += 256)
+        if (vb + lv < vox) ST<T>::st(logits + ((int64_t)n * ncls + o) * vox + vb + lv, outs[o * per + lv] + bo);
+    }
   }
 }
 
@@ -584,7 +591,7 @@ __global__ __launch_bounds__(256, (MC == 4 && sizeof(T) == 2) ? 4 : 1) void head
                                                        int ncls, int64_t vox, int per,
                                                        const float* __restrict__ in_mean,
                                                        const float* __restrict__ in_rstd,
-                                                       float* __restrict__ inb_partials) {
+                                                       float* __restrict__ inb_partials, int vec4) {
   constexpr int EPC = 4;
   // inb_partials (optional): this kernel produces the complete gradient dx of the activation relu(IN(in)), so it
   // also writes the first pass of that InstanceNorm's backward -- per workgroup and channel (sum g, sum g*xhat) with
@@ -618,11 +625,21 @@ __global__ __launch_bounds__(256, (MC == 4 && sizeof(T) == 2) ? 4 : 1) void head
     }
   }
   const int64_t vb = (int64_t)blockIdx.x * per, ve = min(vox, vb + per);
-  for (int o = 0; o < MC; o++) {
-    const T* src = dlogits + ((int64_t)n * ncls + min(o, ncls - 1)) * vox;
-    for (int lv = threadIdx.x; lv < per; lv += 256) {
-      const float v = ST<T>::ld(src + min(vb + lv, vox - 1));
-      red[lv * MC + o] = (o < ncls && vb + lv < vox) ? v : 0.f;
+  if (vec4) {  // four voxels of a class plane per load (the plane rows are aligned and whole: see the launcher)
+    for (int i = threadIdx.x; i < MC * (per >> 2); i += 256) {
+      const int o = i / (per >> 2), lv = (i - o * (per >> 2)) * 4;
+      float v[4];
+      ST<T>::ld4(dlogits + ((int64_t)n * ncls + min(o, ncls - 1)) * vox + min(vb + lv, vox - 4), v);
+#pragma unroll
+      for (int j = 0; j < 4; j++) red[(lv + j) * MC + o] = (o < ncls && vb + lv < vox) ? v[j] : 0.f;
+    }
+  } else {
+    for (int o = 0; o < MC; o++) {
+      const T* src = dlogits + ((int64_t)n * ncls + min(o, ncls - 1)) * vox;
+      for (int lv = threadIdx.x; lv < per; lv += 256) {
+        const float v = ST<T>::ld(src + min(vb + lv, vox - 1));
+        red[lv * MC + o] = (o < ncls && vb + lv < vox) ? v : 0.f;
+      }
     }
   }
   __syncthreads();
@@ -1193,15 +1210,18 @@ int hdf_launch_head_fwd(int dtype, const void* in, int64_t in_pitch, const float
                         hipStream_t st) {
   HDF_CHECK_ARG(ncls <= HEAD_MAXCLS, "head: n_cls=%d > %d", ncls, HEAD_MAXCLS);
   HDF_CHECK_ARG(C % 16 == 0 && C <= 1024, "head_fwd: C=%d", C);
-  const int per = head_vox(vox, 1024);
+  // >= 1024 workgroups per sample where that still leaves 256 voxels each (64^3: 42 -> 32 us), else the backward's rule
+  // (64-voxel workgroups at 32^3 were slower: 28 vs 18.5 us)
+  const int per = head_vox(vox, 1024) >= 256 ? head_vox(vox, 1024) : head_vox(vox);
   const unsigned gx = (unsigned)ceil_div64(vox, per);
+  const int vec4 = (vox % 4 == 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0) ? 1 : 0;
   DISPATCH_T(dtype, {
     if (ncls <= 4)
       hipLaunchKernelGGL((head_fwd_kernel<T, 4>), dim3(gx, N), dim3(256), (size_t)4 * (per + 256) * sizeof(float), st,
-                         (const T*)in, in_pitch, scale, shift, w, b, (T*)logits, N, C, ncls, vox, per);
+                         (const T*)in, in_pitch, scale, shift, w, b, (T*)logits, N, C, ncls, vox, per, vec4);
     else
       hipLaunchKernelGGL((head_fwd_kernel<T, 8>), dim3(gx, N), dim3(256), (size_t)8 * (per + 256) * sizeof(float), st,
-                         (const T*)in, in_pitch, scale, shift, w, b, (T*)logits, N, C, ncls, vox, per);
+                         (const T*)in, in_pitch, scale, shift, w, b, (T*)logits, N, C, ncls, vox, per, vec4);
   });
   HDF_LAUNCH_CHECK();
   return HDF_OK;
@@ -1219,6 +1239,8 @@ int hdf_launch_head_bwd(int dtype, const void* dlogits, const void* in, int64_t 
   HDF_CHECK_ARG(inb_partials == nullptr || (scale && in_mean && in_rstd), "head_bwd: IN partials need the layer's statistics");
   const int per = head_vox(vox);
   const unsigned gx = (unsigned)hdf_head_bwd_blocks(vox);
+  // logit-gradient planes by 4-voxel loads: whole aligned groups (per is a multiple of 64)
+  const int vec4 = (vox % 4 == 0 && (reinterpret_cast<uintptr_t>(dlogits) & 15) == 0) ? 1 : 0;
   DISPATCH_T(dtype, {
     const int cols = C / 4, vlanes = 256 / cols;
     const int mc = ncls <= 4 ? 4 : 8;
@@ -1227,7 +1249,7 @@ int hdf_launch_head_bwd(int dtype, const void* dlogits, const void* in, int64_t 
     auto go = [&](auto kern) -> int {
       HDF_TRY(allow_big_lds((const void*)kern, shm));
       hipLaunchKernelGGL(kern, dim3(gx, N), dim3(256), shm, st, (const T*)dlogits, (const T*)in, in_pitch, scale, shift, w,
-                         (T*)dx, dx_pitch, dw, db, N, C, ncls, vox, per, in_mean, in_rstd, inb_partials);
+                         (T*)dx, dx_pitch, dw, db, N, C, ncls, vox, per, in_mean, in_rstd, inb_partials, vec4);
       return HDF_OK;
     };
     if (mc == 4)
