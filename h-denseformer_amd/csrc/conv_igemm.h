@@ -25,7 +25,14 @@ struct ConvArgs {
   void* out2;            // split output (mode 0): channels >= split go to out2[...][ch - split], same pitch as out
   int split;             // multiple of 32, 0 = single output
   int wfrag;             // weight layout: 0 = [27][CoutP][Cin] rows, 1 = fragment-major (hdf_conv_weight_layout)
+  // split-K scratch (optional, mode 0): the launcher may split the input-channel chunks of a low-resolution layer over up
+  // to 4 workgroups per tile (fp32 partial tiles here, summed in a fixed order by conv_ksplit_reduce_kernel)
+  float* kpart;
+  size_t kpart_bytes;
+  int ksplit;            // set by the launcher
 };
+// split-K scratch a plan keeps per stream
+constexpr size_t HDF_KSPLIT_BYTES = (size_t)16 << 20;
 
 struct WgradArgs {
   // D[tap][sc][lc] = sum_{n,i} S[n,i][sc] * L[n, STRIDE*i - 1 + tap][lc]

@@ -188,7 +188,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #define V1_RING_SMALL 9
 #endif
       constexpr int RING = (MB >= 4) ? V1_RING_BIG : V1_RING_SMALL;  // divides 54: the ring position is the same in every chunk
-      const int nchunk = a.Cin * ESZ / 64;
+      const int nchunk_all = a.Cin * ESZ / 64;
+      // split-K (a.ksplit > 1: low-resolution layers with fewer tiles than CUs): this workgroup contracts chunks
+      // [c_lo, c_hi) and leaves an fp32 partial tile to conv_ksplit_reduce_kernel
+      const int kz = a.ksplit > 1 ? (int)blockIdx.z : 0;
+      const int c_lo = a.ksplit > 1 ? kz * (nchunk_all / a.ksplit) : 0;
+      const int nchunk = a.ksplit > 1 ? c_lo + nchunk_all / a.ksplit : nchunk_all;
       u32x4 bq[RING];
       // fragment-major panels (a.wfrag, see hdf_conv_weight_layout): the 32 rows x 32 B of one fragment step are one
       // contiguous 1 KB block, steps of a row follow each other, then the next 32-channel block; a tap plane has
@@ -204,11 +209,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         return ((tap / 9 * BH + (tap / 3) % 3) * BW + tap % 3) * PITCH + h * 16 + fs * 32;
       };
 #pragma unroll
-      for (int k = 0; k < RING; k++) bq[k] = b_load(0, k);
-      for (int chunk = 0; chunk < nchunk; chunk++) {
-        if (chunk > 0) __syncthreads();
+      for (int k = 0; k < RING; k++) bq[k] = b_load(c_lo, k);
+      for (int chunk = c_lo; chunk < nchunk; chunk++) {
+        if (chunk > c_lo) __syncthreads();
 #ifdef V1_DBG_NOSTAGE  // attribution build: only the first chunk is staged
-        if (chunk == 0)
+        if (chunk == c_lo)
 #endif
         stage_box<T, BD, BH, BW, 64, PITCH>(lds, reinterpret_cast<const T*>(a.in), a.in_pitch, a.Cin, n, a.Di, a.Hi,
                                             a.Wi, oz, oy, ox, chunk * chunk_elems_max, 64, a.in_scale, a.in_shift,
@@ -279,6 +284,27 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 
   // ------------------------------------------------------------------------------- epilogue
   const int ch = n_base + r;
+  if constexpr (!CONVT) {
+    if (a.ksplit > 1) {  // fp32 partial tile [split][voxel][CoutP]: bias, storage rounding and statistics in the reduce pass
+      if (n_active) {
+        const int64_t mtot = (int64_t)a.N * a.Do * a.Ho * a.Wo;
+#pragma unroll
+        for (int mb = 0; mb < MB; mb++) {
+#pragma unroll
+          for (int i = 0; i < 16; i++) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+            const int lin = (wm * MB + mb) * 32 + row;
+            const int lz = lin / (TH * TW), ly = (lin / TW) % TH, lx = lin % TW;
+            const int gz = z0 + lz, gy = y0 + ly, gx = x0 + lx;
+            if (gz < Td && gy < Th && gx < Tw)
+              a.kpart[((int64_t)blockIdx.z * mtot + (((int64_t)n * a.Do + gz) * a.Ho + gy) * a.Wo + gx) * a.CoutP + ch] =
+                  acc[mb][i];
+          }
+        }
+      }
+      return;
+    }
+  }
   const bool ch_ok = n_active && ch < a.Cout;
   const float bias = (a.bias && ch_ok) ? a.bias[ch] : 0.f;
   float s1 = 0.f, s2 = 0.f;
@@ -2586,12 +2612,101 @@ __global__ void pack_batch_kernel(PackBatch b, const float* __restrict__ params,
   }
 }
 
+// Second pass of a split-K conv launch: one workgroup per (TILE of the conv's tiling, 64-channel block) -- so that the
+// InstanceNorm partial rows keep their geometry -- thread = (voxel lane, 4 consecutive channels): the partial tiles are
+// summed in split order, + bias (+ the old output when accumulating), stored in the storage type, and the per-channel
+// (sum, sum of squares) of the tile reduced over the 16 voxel lanes in a fixed order.
+template <typename T, int TD, int TH, int TW>
+__global__ __launch_bounds__(256) void conv_ksplit_reduce_kernel(ConvArgs a) {
+  __shared__ float red[16][64][2];
+  const int ntz = (a.Do + TD - 1) / TD, nty = (a.Ho + TH - 1) / TH, ntx = (a.Wo + TW - 1) / TW;
+  int t = blockIdx.x;
+  const int tx = t % ntx;
+  t /= ntx;
+  const int ty = t % nty;
+  t /= nty;
+  const int tz = t % ntz, n = t / ntz;
+  const int cl = ((int)threadIdx.x & 15) * 4, c0 = blockIdx.y * 64 + cl, vl = (int)threadIdx.x >> 4;
+  const bool c_on = c0 < a.CoutP;
+  const int64_t mtot = (int64_t)a.N * a.Do * a.Ho * a.Wo;
+  float bias[4], s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 4; e++) bias[e] = (a.bias && c0 + e < a.Cout) ? a.bias[c0 + e] : 0.f;
+  constexpr int TV = TD * TH * TW, IT = (TV + 15) / 16;
+  static_assert(TV % 16 == 0, "tile voxels per voxel lane");
+  if (c_on) {
+#pragma unroll 2
+    for (int it = 0; it < IT; it++) {
+      const int lin = vl + 16 * it;
+      const int gz = tz * TD + lin / (TH * TW), gy = ty * TH + (lin / TW) % TH, gx = tx * TW + lin % TW;
+      const bool ok = gz < a.Do && gy < a.Ho && gx < a.Wo;
+      const int64_t vox = ok ? (((int64_t)n * a.Do + gz) * a.Ho + gy) * a.Wo + gx : 0;
+      f32x4 pv[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++)   // (ksplit <= 4; clamped: never branch around a load)
+        pv[k] = *reinterpret_cast<const f32x4*>(a.kpart + ((int64_t)min(k, a.ksplit - 1) * mtot + vox) * a.CoutP + c0);
+      f32x4 v = pv[0];
+      for (int k = 1; k < a.ksplit; k++) v += pv[k];
+      if (ok) {
+        T* p = reinterpret_cast<T*>(a.out) + vox * a.out_pitch + c0;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          if (c0 + e < a.Cout) {
+            float o = v[e] + bias[e];
+            if (a.accumulate) o += ST<T>::ld(p + e);
+            ST<T>::st(p + e, o);
+            s1[e] += o;
+            s2[e] += o * o;
+          }
+        }
+      }
+    }
+  }
+  if (a.stat_partials) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) red[vl][cl + e][0] = s1[e], red[vl][cl + e][1] = s2[e];
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      const int c = threadIdx.x >> 1, j = threadIdx.x & 1;
+      if (blockIdx.y * 64 + c < a.CoutP) {
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) sum += red[k][c][j];
+        a.stat_partials[((int64_t)blockIdx.x * a.CoutP + blockIdx.y * 64 + c) * 2 + j] = sum;
+      }
+    }
+  }
+}
+
 template <typename T, int TD, int TH, int TW, int WM, int WN, int MB, int S, bool CONVT>
-int launch_cfg(const ConvArgs& a, hipStream_t st) {
+int launch_cfg(const ConvArgs& a0, hipStream_t st) {
+  ConvArgs a = a0;
   const int Td = CONVT ? a.Di : a.Do, Th = CONVT ? a.Hi : a.Ho, Tw = CONVT ? a.Wi : a.Wo;
-  dim3 grid(a.N * ceil_div(Td, TD) * ceil_div(Th, TH) * ceil_div(Tw, TW), ceil_div(a.CoutP, WN * 32), CONVT ? 8 : 1);
+  const int tiles = a.N * ceil_div(Td, TD) * ceil_div(Th, TH) * ceil_div(Tw, TW), nblk = ceil_div(a.CoutP, WN * 32);
+  a.ksplit = 1;
+  if constexpr (!CONVT && S == 1) {
+    // split-K: a low-resolution layer whose tiles x output blocks leave CUs idle, whole 64-byte chunks (the pipelined
+    // path), one plain output; 4 or 2 ways while every workgroup keeps >= 2 chunks and the partial tiles fit the scratch
+    const int nchunk = (a.Cin * (int)sizeof(T)) % 64 == 0 ? a.Cin * (int)sizeof(T) / 64 : 0;
+    if (a.kpart && !a.split && a.CoutP <= 1024 && a.CoutP % 4 == 0 && a.out_pitch % 4 == 0) {
+      for (int ks = 4; ks >= 2; ks >>= 1) {
+        const size_t need = (size_t)ks * a.N * a.Do * a.Ho * a.Wo * a.CoutP * sizeof(float);
+        if (tiles * nblk * ks <= hdf_cu_budget() && nchunk % ks == 0 && nchunk / ks >= 2 && need <= a.kpart_bytes) {
+          a.ksplit = ks;
+          break;
+        }
+      }
+    }
+  }
+  dim3 grid(tiles, nblk, CONVT ? 8 : a.ksplit);
   hipLaunchKernelGGL((conv_igemm_kernel<T, TD, TH, TW, WM, WN, MB, S, CONVT>), grid, dim3(256), 0, st, a);
   HDF_LAUNCH_CHECK();
+  if constexpr (!CONVT && S == 1) {
+    if (a.ksplit > 1) {
+      hipLaunchKernelGGL((conv_ksplit_reduce_kernel<T, TD, TH, TW>), dim3(tiles, ceil_div(a.CoutP, 64)), dim3(256), 0, st, a);
+      HDF_LAUNCH_CHECK();
+    }
+  }
   return HDF_OK;
 }
 

@@ -181,6 +181,7 @@ struct hdf_plan {
   size_t tf_F, tf_save, tf_scratch, tf_dF, tf_tape = 0, tf_otape = 0;
   size_t stat_partials, wgrad_ws, inb_partials, inb_k;
   size_t stat_partials2 = 0, inb_partials2 = 0, inb_k2 = 0;  // the same scratch for the branch stream (see Exec::branch)
+  size_t ksplit_ws = 0, ksplit_ws2 = 0;                      // split-K partial tiles of the low-resolution convs, per stream
   size_t wgrad_ws_bytes = 0;
   // backward scratch
   View gA[4], gY[4], gY2[4], dCat[3], dUp[3], dSkip[3], dP[3], dUa[4], dUy[4], dX4, dAttnall;
@@ -547,6 +548,8 @@ void layout(hdf_plan* p, int B) {
       for (int rb : {32, 1 << 20}) mt = std::max<size_t>(mt, hdf_conv_stat_tiles(0, p->dims[l][0], p->dims[l][1], p->dims[l][2], rb));
     p->stat_partials2 = bp.take((size_t)B * mt * round_up(8 * nf, 32) * 2 * sizeof(float));
   }
+  p->ksplit_ws = bp.take(HDF_KSPLIT_BYTES);
+  p->ksplit_ws2 = bp.take(HDF_KSPLIT_BYTES);
   // Everything above is what a forward touches: an inference-only caller (eval / sliding-window prediction) can hand
   // over just this prefix (hdf_plan_inference_workspace_bytes); the backward scratch below -- transformer tapes, second
   // dy buffers, the 128 MB weight-gradient workspace, ... -- is more than half of the arena at the benchmark size.
@@ -662,6 +665,7 @@ struct Exec {
   }
   // scratch of this Exec's stream (two streams of one call must not share the per-launch partial-sum tables)
   float* statp() const { return f(on_branch ? p->stat_partials2 : p->stat_partials); }
+  float* kspl() const { return f(on_branch ? p->ksplit_ws2 : p->ksplit_ws); }
   float* inbp() const { return f(on_branch ? p->inb_partials2 : p->inb_partials); }
   float* inbk() const { return f(on_branch ? p->inb_k2 : p->inb_k); }
   // fork: a second Exec on the plan's branch stream, ordered behind everything issued on this one so far.  nullptr
@@ -728,6 +732,7 @@ int conv_forward(Exec& e, Conv3& c, const View& in, Xf xf) {
   a.CoutP = CoutP;
   a.stat_partials = e.statp();
   a.accumulate = 0;
+  a.kpart = e.kspl(), a.kpart_bytes = HDF_KSPLIT_BYTES;
   HDF_TRY(hdf_launch_conv(p->dtype, 0, a, e.st));
   int tiles = hdf_conv_stat_tiles(0, d[0], d[1], d[2], c.CinP * p->esz);
   HDF_TRY(hdf_launch_in_finalize(e.statp(), e.B, tiles, c.Cout, CoutP, p->vox(c.lvl), e.P(c.gamma),
@@ -1015,6 +1020,7 @@ int conv_backward(Exec& e, Conv3& c, const View& dy, const View& in, Xf xf, cons
       a.split = din->C;
     }
     if (din_colsum) a.stat_partials = e.statp();  // forward scratch, free during backward
+    a.kpart = e.kspl(), a.kpart_bytes = HDF_KSPLIT_BYTES;
     HDF_TRY(hdf_launch_conv(p->dtype, 0, a, e.st));
     if (din_colsum) {
       const int rows = e.B * hdf_conv_stat_tiles(0, d[0], d[1], d[2], a.Cin * p->esz);
