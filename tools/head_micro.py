@@ -80,3 +80,14 @@ for size, C in ((128, 32), (64, 64), (32, 128)):
                                                 N, C, h, h, h, st), "enc_tail"))
     by = y.numel() * 2 * 3 + po.numel() * 3
     print(f"enc_tail {C}ch @{size}^3: {t:7.1f} us  {by / t / 1e6:6.2f} TB/s")
+
+# trilinear x2 of relu(x * scale + shift): the at_k features of the UpConv chain (at3: 64^3 -> 128^3, 32 channels)
+for size, C in ((64, 32), (32, 64), (16, 128)):
+    vox = size ** 3
+    x = torch.randn(N, vox, C, device=dev).to(torch.bfloat16)
+    sc, sh = torch.rand(N, C, device=dev) + 0.5, torch.randn(N, C, device=dev) * 0.1
+    up = torch.empty(N, vox * 8, C, device=dev, dtype=torch.bfloat16)
+    t = med(lambda: check(lib().hdf_op_upsample_fwd(BF16, ptr(x), C, ptr(sc), ptr(sh), ptr(up), C, N, C, size, size, size, st),
+                          "upsample_fwd"))
+    by = x.numel() * 2 + up.numel() * 2
+    print(f"upsample_fwd {C}ch {size}^3 -> {2 * size}^3: {t:7.1f} us  {by / t / 1e6:6.2f} TB/s")
