@@ -1470,11 +1470,15 @@ static int backward3d(hdf_plan* p, const float* x, const float* params, void* wo
   for (int k = 3; k >= 0; k--) {
     Conv3 &c1 = p->enc[k][0], &c2 = p->enc[k][1];
     View dskip = (k == 3) ? p->dX4 : p->dSkip[k];
+    int pre = 0;
     if (k < 3) {
-      // ds_k also feeds pool_{k+1}
-      HDF_TRY(hdf_launch_maxpool_bwd(p->dtype, e.at(p->dP[k]), p->dP[k].pitch, (const uint8_t*)(e.ws + p->pool_idx[k]),
-                                     e.at(dskip), dskip.pitch, batch, ch[k], p->dims[k + 1][0], p->dims[k + 1][1],
-                                     p->dims[k + 1][2], 1, e.st));
+      // ds_k also feeds pool_{k+1}: with that gradient added d(ds_k) is complete, and the pass that adds it takes the first
+      // pass of c2's InstanceNorm backward along (pre rows per sample in the partials table)
+      pre = hdf_maxpool_bwd_in_blocks((int64_t)p->dims[k + 1][0] * p->dims[k + 1][1] * p->dims[k + 1][2], ch[k]);
+      HDF_TRY(hdf_launch_maxpool_bwd_in(p->dtype, e.at(p->dP[k]), p->dP[k].pitch, (const uint8_t*)(e.ws + p->pool_idx[k]),
+                                        e.at(dskip), dskip.pitch, e.at(c2.y), c2.y.pitch, e.f(c2.st.scale),
+                                        e.f(c2.st.shift), e.f(c2.st.mean), e.f(c2.st.rstd), e.inbp(), batch, ch[k],
+                                        p->dims[k + 1][0], p->dims[k + 1][1], p->dims[k + 1][2], e.st));
     }
     if (k == 0 && fork_ok) {
       // d(ds_0) = d(at3) is final.  What is left: (1) the UpConv chain backward, (2) the transformer branches' backward,
@@ -1499,7 +1503,7 @@ static int backward3d(hdf_plan* p, const float* x, const float* params, void* wo
         }
       }
     }
-    HDF_TRY(in_backward(e, c2, dskip, p->gY[k]));
+    HDF_TRY(in_backward(e, c2, dskip, p->gY[k], pre));
     HDF_TRY(conv_backward(e, c2, p->gY[k], c1.y, xf_of(e, c1), &p->gA[k], 0));
     HDF_TRY(in_backward(e, c1, p->gA[k], p->gY2[k]));
     if (k > 0)
@@ -1761,6 +1765,17 @@ int hdf_op_maxpool_bwd(int dtype, const void* dout, int64_t dout_pitch, const ui
                        int64_t din_pitch, int N, int C, int Do, int Ho, int Wo, int accumulate, hdf_stream stream) {
   return hdf_launch_maxpool_bwd(dtype, dout, dout_pitch, idx, din, din_pitch, N, C, Do, Ho, Wo, accumulate,
                                 (hipStream_t)stream);
+}
+int hdf_op_maxpool_bwd_in_rows(int C, int Do, int Ho, int Wo) {
+  return hdf_maxpool_bwd_in_blocks((int64_t)Do * Ho * Wo, C);
+}
+int hdf_op_maxpool_bwd_in(int dtype, const void* dout, int64_t dout_pitch, const uint8_t* idx, void* din,
+                          int64_t din_pitch, const void* y, int64_t y_pitch, const float* scale, const float* shift,
+                          const float* mean, const float* rstd, float* partials, int N, int C, int Do, int Ho, int Wo,
+                          hdf_stream stream) {
+  HDF_CHECK_ARG(dout && idx && din && y && scale && shift && mean && rstd && partials, "maxpool_bwd_in: null argument");
+  return hdf_launch_maxpool_bwd_in(dtype, dout, dout_pitch, idx, din, din_pitch, y, y_pitch, scale, shift, mean, rstd,
+                                   partials, N, C, Do, Ho, Wo, (hipStream_t)stream);
 }
 int hdf_op_upsample_fwd(int dtype, const void* y, int64_t y_pitch, const float* scale, const float* shift, void* out,
                         int64_t out_pitch, int N, int C, int Di, int Hi, int Wi, hdf_stream stream) {

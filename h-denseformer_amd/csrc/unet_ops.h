@@ -41,6 +41,13 @@ int hdf_launch_head_fwd(int dtype, const void* in, int64_t in_pitch, const float
                         hipStream_t st);
 // dX (+)= W^T dlogits ; dW += dlogits . act(in)^T ; db += sum dlogits   (dW, db accumulated with float atomics)
 int hdf_head_bwd_blocks(int64_t vox);
+// MaxPool3d(2) backward accumulating into din + the first pass of the InstanceNorm(+ReLU) backward of the layer whose
+// activation gradient din then is (hdf_maxpool_bwd_in_blocks rows per sample in `partials`)
+int hdf_maxpool_bwd_in_blocks(int64_t pooled_vox, int C);
+int hdf_launch_maxpool_bwd_in(int dtype, const void* dout, int64_t dout_pitch, const uint8_t* idx, void* din,
+                              int64_t din_pitch, const void* y, int64_t y_pitch, const float* scale, const float* shift,
+                              const float* mean, const float* rstd, float* partials, int N, int C, int Do, int Ho, int Wo,
+                              hipStream_t st);
 int hdf_launch_head_bwd(int dtype, const void* dlogits, const void* in, int64_t in_pitch, const float* scale,
                         const float* shift, const float* w, void* dx, int64_t dx_pitch, int accumulate_dx, float* dw,
                         float* db, int N, int C, int ncls, int64_t vox, hipStream_t st, const float* in_mean = nullptr,

@@ -1172,6 +1172,104 @@ int hdf_launch_maxpool_fwd(int dtype, const void* in, int64_t in_pitch, void* ou
   return HDF_OK;
 }
 
+// MaxPool3d(2) backward, accumulating into din, for the encoder levels: din (= the gradient of ds_k = relu(IN(y)) + at_k)
+// is COMPLETE once the pooled branch's gradient has been added, so the pass that adds it also takes the first pass of that
+// layer's InstanceNorm(+ReLU) backward -- per workgroup and channel (sum g, sum g * xhat) with g = the STORED din where
+// relu(IN(y)) is positive, rows of in_bwd_reduce_kernel's layout with gridDim.x rows per sample -- and saves that pass its
+// read of din (one of its two tensors; y is read here instead).  grid (blocks, N); thread = (pooled-voxel lane, 4 channels).
+template <typename T>
+__global__ __launch_bounds__(256, 4) void maxpool_bwd_inb_kernel(const T* __restrict__ dout, int64_t dout_pitch,
+                                                                 const uint8_t* __restrict__ idx, T* __restrict__ din,
+                                                                 int64_t din_pitch, const T* __restrict__ y,
+                                                                 int64_t y_pitch, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift,
+                                                                 const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd,
+                                                                 float* __restrict__ partials, int C, int Do, int Ho,
+                                                                 int Wo) {
+  extern __shared__ float red[];  // [vlanes][C][2]
+  const int n = blockIdx.y, blocks = gridDim.x;
+  const int cols = C >> 2, vlanes = 256 / cols;
+  const int col = threadIdx.x % cols, vl = threadIdx.x / cols, c0 = col * 4;
+  const int Hi = 2 * Ho, Wi = 2 * Wo;
+  const int pvox = Do * Ho * Wo;
+  float sc[4], sh[4], mu[4], rs[4], s1[4], s2[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const int64_t o = (int64_t)n * C + c0 + e;
+    sc[e] = scale[o], sh[e] = shift[o], mu[e] = mean[o], rs[e] = rstd[o];
+    s1[e] = s2[e] = 0.f;
+  }
+  if (vl < vlanes) {
+    const int per = (pvox + blocks - 1) / blocks;
+    const int vb = blockIdx.x * per, ve = min(pvox, vb + per);
+    for (int v = vb + vl; v < ve; v += vlanes) {
+      const int ow = v % Wo, oh = (v / Wo) % Ho, od = v / (Wo * Ho);
+      const int64_t prow = (int64_t)n * pvox + v;
+      float g[4];
+      ST<T>::ld4(dout + prow * dout_pitch + c0, g);
+      const uint32_t pk = *reinterpret_cast<const uint32_t*>(idx + prow * C + c0);
+      const int64_t row0 = (((int64_t)n * 2 * Do + 2 * od) * Hi + 2 * oh) * Wi + 2 * ow;
+#pragma unroll 1
+      for (int half = 0; half < 2; half++) {   // one z plane of the 2x2x2 block at a time: 8 loads in flight
+        float f[4][4], yv[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int64_t irow = row0 + ((int64_t)half * Hi + (q >> 1)) * Wi + (q & 1);
+          ST<T>::ld4(din + irow * din_pitch + c0, f[q]);
+          ST<T>::ld4(y + irow * y_pitch + c0, yv[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int k = half * 4 + q;
+          const int64_t irow = row0 + ((int64_t)half * Hi + (q >> 1)) * Wi + (q & 1);
+#pragma unroll
+          for (int e = 0; e < 4; e++)
+            if ((int)((pk >> (8 * e)) & 255u) == k) f[q][e] += g[e];
+          ST<T>::st4(din + irow * din_pitch + c0, f[q][0], f[q][1], f[q][2], f[q][3]);
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const float gg = (yv[q][e] * sc[e] + sh[e] > 0.f) ? storage_round<T>(f[q][e]) : 0.f;
+            s1[e] += gg;
+            s2[e] += gg * ((yv[q][e] - mu[e]) * rs[e]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      red[(vl * C + c0 + e) * 2 + 0] = s1[e];
+      red[(vl * C + c0 + e) * 2 + 1] = s2[e];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C * 2; i += 256) {
+    float s = 0.f;
+    for (int k = 0; k < vlanes; k++) s += red[k * C * 2 + i];
+    partials[((int64_t)n * blocks + blockIdx.x) * C * 2 + i] = s;
+  }
+}
+
+// rows per sample of the partials maxpool_bwd_inb_kernel writes: ~256 pooled voxels x chunk lanes per workgroup, <= 1024
+int hdf_maxpool_bwd_in_blocks(int64_t pooled_vox, int C) {
+  return (int)std::max<int64_t>(1, std::min<int64_t>(1024, pooled_vox * (C / 4) / 2048));
+}
+
+int hdf_launch_maxpool_bwd_in(int dtype, const void* dout, int64_t dout_pitch, const uint8_t* idx, void* din,
+                              int64_t din_pitch, const void* y, int64_t y_pitch, const float* scale, const float* shift,
+                              const float* mean, const float* rstd, float* partials, int N, int C, int Do, int Ho, int Wo,
+                              hipStream_t st) {
+  HDF_CHECK_ARG(C % 16 == 0 && C <= 1024, "maxpool_bwd_in: C=%d", C);
+  HDF_CHECK_ARG((int64_t)Do * Ho * Wo < ((int64_t)1 << 28), "maxpool_bwd_in: %dx%dx%d pooled voxels per sample", Do, Ho, Wo);
+  const int blocks = hdf_maxpool_bwd_in_blocks((int64_t)Do * Ho * Wo, C);
+  const int vlanes = 256 / (C / 4);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool_bwd_inb_kernel<T>, dim3(blocks, N), dim3(256),
+                                       (size_t)vlanes * C * 2 * sizeof(float), st, (const T*)dout, dout_pitch, idx, (T*)din,
+                                       din_pitch, (const T*)y, y_pitch, scale, shift, mean, rstd, partials, C, Do, Ho, Wo));
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
 int hdf_launch_maxpool_bwd(int dtype, const void* dout, int64_t dout_pitch, const uint8_t* idx, void* din,
                            int64_t din_pitch, int N, int C, int Do, int Ho, int Wo, int accumulate, hipStream_t st) {
   DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<T>,

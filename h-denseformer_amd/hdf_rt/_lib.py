@@ -66,6 +66,8 @@ _PROTOS = {
     "hdf_op_in_finalize": (_i, [_vp, _i, _i, _i, _i, _i64, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
     "hdf_op_norm_relu_add": (_i, [_i, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _i64, _vp]),
     "hdf_op_maxpool_fwd": (_i, [_i, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _i, _i, _vp]),
+    "hdf_op_maxpool_bwd_in_rows": (_i, [_i, _i, _i, _i]),
+    "hdf_op_maxpool_bwd_in": (_i, [_i, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "hdf_op_enc_tail": (_i, [_i, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _i, _i, _vp]),
     "hdf_op_maxpool_bwd": (_i, [_i, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp]),
     "hdf_op_upsample_fwd": (_i, [_i, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp]),

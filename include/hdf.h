@@ -213,6 +213,15 @@ int hdf_op_enc_tail(int dtype, const void* y, int64_t y_pitch, const float* scal
                     int N, int C, int Do, int Ho, int Wo, hdf_stream stream);
 int hdf_op_maxpool_bwd(int dtype, const void* dout, int64_t dout_pitch, const uint8_t* idx, void* din,
                        int64_t din_pitch, int N, int C, int Do, int Ho, int Wo, int accumulate, hdf_stream stream);
+/* hdf_op_maxpool_bwd with accumulate = 1 for the encoder levels: din becomes the complete gradient of
+ * ds = relu(y * scale + shift) + skip, and the same pass writes the first pass of that InstanceNorm(+ReLU)'s backward:
+ * partials[n][row][c][2] = per-workgroup (sum g, sum g * (y - mean) * rstd) with g = the stored din where the activation
+ * is positive, hdf_op_maxpool_bwd_in_rows(C, Do, Ho, Wo) rows per sample (what hdf_op_in_bwd's reduce pass would write). */
+int hdf_op_maxpool_bwd_in_rows(int C, int Do, int Ho, int Wo);
+int hdf_op_maxpool_bwd_in(int dtype, const void* dout, int64_t dout_pitch, const uint8_t* idx, void* din,
+                          int64_t din_pitch, const void* y, int64_t y_pitch, const float* scale, const float* shift,
+                          const float* mean, const float* rstd, float* partials, int N, int C, int Do, int Ho, int Wo,
+                          hdf_stream stream);
 int hdf_op_upsample_fwd(int dtype, const void* y, int64_t y_pitch, const float* scale, const float* shift, void* out,
                         int64_t out_pitch, int N, int C, int Di, int Hi, int Wi, hdf_stream stream);
 int hdf_op_upsample_bwd(int dtype, const void* dout, int64_t dout_pitch, void* din, int64_t din_pitch, int N, int C,

@@ -310,6 +310,45 @@ def test_pool_upsample(dtype):
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16, F16])
+@pytest.mark.parametrize("c", [16, 32, 48])
+def test_maxpool_backward_with_instance_norm_first_pass(dtype, c):
+    """hdf_op_maxpool_bwd_in: din += scatter(dout) exactly as hdf_op_maxpool_bwd(accumulate=1), and the partial rows sum
+    to (sum g, sum g * xhat) over the voxels where relu(y * scale + shift) is positive, g = the stored din."""
+    n, size = 2, (8, 12, 16)
+    ps = tuple(v // 2 for v in size)
+    x = _mk((n, c) + size, 41)
+    x_cl = to_cl(x, dtype)
+    po = torch.empty((n,) + ps + (c,), dtype=x_cl.dtype, device=DEV)
+    idx = torch.empty(po.shape, dtype=torch.uint8, device=DEV)
+    check(lib().hdf_op_maxpool_fwd(dtype, ptr(x_cl), c, ptr(po), c, ptr(idx), n, c, *ps, st()), "pool")
+    gcl = to_cl(_mk((n, c) + ps, 42), dtype)
+    d0 = to_cl(_mk((n, c) + size, 43), dtype)
+    y = _mk((n, c) + size, 44)
+    y_cl = to_cl(y, dtype)
+    yr = from_cl(y_cl)
+    mean, rstd = yr.mean((2, 3, 4)), (yr.var((2, 3, 4), unbiased=False) + 1e-5).rsqrt()
+    gamma, beta = _mk((c,), 45) * 0.3 + 1.0, _mk((c,), 46) * 0.2
+    gamma[0] = -gamma[0]
+    scale, shift = (gamma[None] * rstd).contiguous(), (beta[None] - mean * gamma[None] * rstd).contiguous()
+    dev = [t.to(DEV).contiguous() for t in (scale, shift, mean, rstd)]
+    ref = d0.clone()
+    check(lib().hdf_op_maxpool_bwd(dtype, ptr(gcl), c, ptr(idx), ptr(ref), c, n, c, *ps, 1, st()), "poolb")
+    got = d0.clone()
+    rows = lib().hdf_op_maxpool_bwd_in_rows(c, *ps)
+    part = torch.full((n, rows, c, 2), float("nan"), device=DEV)
+    check(lib().hdf_op_maxpool_bwd_in(dtype, ptr(gcl), c, ptr(idx), ptr(got), c, ptr(y_cl), c, *[ptr(t) for t in dev],
+                                      ptr(part), n, c, *ps, st()), "poolb_in")
+    torch.cuda.synchronize()
+    assert bool((got == ref).all())
+    g = from_cl(got).double()
+    act = yr.double() * scale.double()[:, :, None, None, None] + shift.double()[:, :, None, None, None]
+    gm = torch.where(act > 0, g, torch.zeros_like(g))
+    xh = (yr.double() - mean.double()[:, :, None, None, None]) * rstd.double()[:, :, None, None, None]
+    s = part.double().sum(1).cpu()
+    assert rel_err(s[..., 0], gm.sum((2, 3, 4))) < 1e-4 and rel_err(s[..., 1], (gm * xh).sum((2, 3, 4))) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16, F16])
 @pytest.mark.parametrize("c", [16, 32, 48, 128])
 def test_encoder_tail_vs_torch(dtype, c):
     """hdf_op_enc_tail: ds = relu(y * scale + shift) + skip and MaxPool3d(2) of the stored ds with torch's tie rule, in one
