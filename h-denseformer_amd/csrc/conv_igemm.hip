@@ -937,13 +937,19 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
       }
       WS2_STAMP(0)
       u32x4 af[2][4], bf[2][3 * NB];
+      // RB == 32: the 27 weight fragments of the single pass are the same LDS words for every tile, and hipcc hoists
+      // their reads out of the tile loop into 108 AGPRs (384 registers in all: nothing of another stream fits beside
+      // the workgroup -- the branch stream's first token kernels waited 150 us for the first encoder conv).  The
+      // laundered pointer keeps the reads in the loop, as in the wider variants.
+      const char* w_rd = w_lds;
+      if constexpr (RB == 32) asm volatile("" : "+v"(w_rd));
       auto read_group = [&](int g, u32x4 (&A)[4], u32x4 (&B)[3 * NB]) {
         const int t = g / NFS, fs = g % NFS, jz = t / 3, jx = t % 3;
         auto rdA = [&](int yp) { A[yp] = *reinterpret_cast<const u32x4*>(a_rd + a_addr(jz, yp, jx, fs)); };
         auto rdB = [&](int jy) {
 #pragma unroll
           for (int nb = 0; nb < NB; nb++)
-            B[jy * NB + nb] = *reinterpret_cast<const u32x4*>(w_lds + ((jz * 9 + jy * 3 + jx) * NC + 32 * nb) * RB +
+            B[jy * NB + nb] = *reinterpret_cast<const u32x4*>(w_rd + ((jz * 9 + jy * 3 + jx) * NC + 32 * nb) * RB +
                                                               (bvar[c] ^ (fs * 32)));
         };
         // in order of first use (LDS returns in order, the waits are counted)
