@@ -289,7 +289,8 @@ def test_patch_embed_fwd_bwd(DM, size, B, M, train):
 @pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("C_,ncls,size,n,xf", [(32, 4, (16, 16, 16), 2, True), (64, 3, (8, 12, 10), 1, False),
                                               (48, 2, (9, 7, 5), 2, True), (256, 4, (4, 4, 4), 2, False),
-                                              (384, 3, (2, 3, 4), 1, True), (512, 3, (4, 4, 4), 1, False)])
+                                              (384, 3, (2, 3, 4), 1, True), (512, 3, (4, 4, 4), 1, False),
+                                              (32, 6, (8, 8, 12), 2, True), (64, 8, (6, 5, 7), 1, False)])
 def test_head_fwd_bwd(dtype, C_, ncls, size, n, xf):
     g = _g(C_ + ncls)
     tdt = torch.bfloat16 if dtype == BF16 else torch.float32
