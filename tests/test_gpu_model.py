@@ -90,9 +90,12 @@ def test_forward_fp32_vs_oracle_and_golden(cfg, batch, tag):
     assert abs(compute_dice(outs[0], onehot.to(DEV)) - float(g["dice_rounded"])) <= 1e-4
 
 
-@pytest.mark.parametrize("train", [False, True])
-def test_backward_fp32_vs_oracle(train):
-    cfg, batch, tag = CFG_TINY, 2, "g1_tiny_eval"
+CFG_SIX = (3, 6, 16, (32, 32, 32), 4)     # six classes: the 8-class-slot forms of the head and loss kernels
+
+
+@pytest.mark.parametrize("train,cfg", [(False, CFG_TINY), (True, CFG_TINY), (True, CFG_SIX)])
+def test_backward_fp32_vs_oracle(train, cfg):
+    batch, tag = 2, "g1_tiny_eval"
     from loss.combine_loss import CEPlusDice, DeepSuperloss
     net, sd = _build(cfg)
     net.train(train)
