@@ -15,16 +15,10 @@ static inline int hdf_esz(int dtype) { return dtype == HDF_F32 ? 4 : 2; }  // by
 
 void hdf_set_error(const char* fmt, ...);
 
-// Persistent kernels size their grid to the compute units they may use: 256 = the whole chip (default), fewer for
-// launches on a CU-masked stream (hipExtStreamCreateWithCUMask) so that every workgroup is resident at once.  The value
-// is per host thread: the plan sets it around the launches it places on its masked streams.
+// Persistent kernels size their grid to the compute units they may use: 256 = the whole chip (default).  A
+// process-wide diagnostic knob (hdf_set_cu_budget; tools/cu_budget_sweep.py, tools/cumask_probe.py): the plan itself
+// never changes it and creates no CU-masked streams (measured: no gain).
 int hdf_cu_budget();
-void hdf_set_cu_budget_tl(int cus);
-struct HdfCuBudget {  // scope guard
-  int prev;
-  explicit HdfCuBudget(int cus) : prev(hdf_cu_budget()) { hdf_set_cu_budget_tl(cus); }
-  ~HdfCuBudget() { hdf_set_cu_budget_tl(prev); }
-};
 
 #define HDF_CHECK_ARG(cond, ...)              \
   do {                                        \

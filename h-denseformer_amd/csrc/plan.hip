@@ -1,6 +1,7 @@
 // Model plan / executor: owns the parameter table (= the reference state_dict, HDenseFormer.py:178-227),
 // the workspace layout and the forward/backward launch sequences of HDenseFormer.forward
 // (HDenseFormer.py:229-255) and its autograd.  Host-side C++; every device buffer is caller-owned.
+#include <atomic>
 #include <algorithm>
 #include <cstdarg>
 #include <cstring>
@@ -15,9 +16,10 @@
 #include "unet_ops.h"
 
 static thread_local char g_err[1024] = "";
-static thread_local int g_cu_budget = 256;
-int hdf_cu_budget() { return g_cu_budget; }
-void hdf_set_cu_budget_tl(int cus) { g_cu_budget = (cus >= 8 && cus <= 256) ? cus / 8 * 8 : 256; }
+// process-wide (relaxed atomic): forward runs on the caller's thread and backward on autograd's worker thread, and both
+// must size their grids -- and take their split-K decisions -- from the same value
+static std::atomic<int> g_cu_budget{256};
+int hdf_cu_budget() { return g_cu_budget.load(std::memory_order_relaxed); }
 
 void hdf_set_error(const char* fmt, ...) {
   va_list ap;
@@ -634,22 +636,33 @@ struct Exec {
     if (!async) return st;
     hipEvent_t f = next_event();
     if (!f || hipEventRecord(f, st) != hipSuccess || hipStreamWaitEvent(p->side, f, 0) != hipSuccess) {
-      // fall back to in-order execution: first order this stream behind what the side stream already holds (its
-      // kernels use the shared weight-gradient workspace this stream is about to reuse)
-      join();
+      // fall back to in-order execution: first order this stream behind EVERYTHING the side stream holds -- the main and
+      // the branch Exec both feed it and share the one weight-gradient workspace this stream is about to reuse, so this
+      // Exec's own last_side is not enough.  A fresh event on the side stream, or, if events are what fails, a host wait.
+      hipEvent_t all = next_event();
+      if (!all || hipEventRecord(all, p->side) != hipSuccess || hipStreamWaitEvent(st, all, 0) != hipSuccess)
+        (void)hipStreamSynchronize(p->side);
+      last_side = nullptr;
+      readers.clear();
       async = false;
       return st;
     }
     return p->side;
   }
   // after the launch: remember that `buf` is read on the side stream until now
-  void wgrad_done(const View& buf) {
-    if (!async) return;
+  // (an event that cannot be recorded would leave the launch outside every later join: a hard error, not a silent
+  // loss of ordering)
+  int wgrad_done(const View& buf) {
+    if (!async) return HDF_OK;
     hipEvent_t d = next_event();
-    if (d && hipEventRecord(d, p->side) == hipSuccess) {
-      last_side = d;
-      readers[buf.off] = d;
+    if (!d || hipEventRecord(d, p->side) != hipSuccess) {
+      (void)hipStreamSynchronize(p->side);
+      hdf_set_error("backward: could not record the side stream's completion event");
+      return HDF_ERR_HIP;
     }
+    last_side = d;
+    readers[buf.off] = d;
+    return HDF_OK;
   }
   void wait_readers(const View& buf) {
     auto it = readers.find(buf.off);
@@ -992,7 +1005,7 @@ int conv_backward(Exec& e, Conv3& c, const View& dy, const View& in, Xf xf, cons
   w.lg_relu = xf.relu;
   HDF_TRY(hdf_launch_wgrad(p->dtype, 1, w, e.G(c.w), c.Cout, c.Cin, 0, e.ws + p->wgrad_ws, p->wgrad_ws_bytes,
                            e.wgrad_stream()));
-  e.wgrad_done(dy);
+  HDF_TRY(e.wgrad_done(dy));
   // Conv3 layers with a bias are the UpConvs (HDenseFormer.py:162-175): conv(bias) -> InstanceNorm3d(affine=False).
   // The norm subtracts the per-(sample, channel) mean, so dL/dbias = sum_voxels dy is identically zero (the reference
   // accumulates ~3e-8 of rounding noise there); the gradient buffer was zeroed at the start of backward,
@@ -1050,7 +1063,7 @@ int convt_backward(Exec& e, ConvT3& t, const View& dout, const View& in, Xf xf, 
   w.sm_relu = xf.relu;
   HDF_TRY(hdf_launch_wgrad(p->dtype, 2, w, e.G(t.w), t.Cin, t.Cout, 0, e.ws + p->wgrad_ws, p->wgrad_ws_bytes,
                            e.wgrad_stream()));
-  e.wgrad_done(dout);
+  HDF_TRY(e.wgrad_done(dout));
   // dX[i][ci] = sum_k sum_co dY[2i-1+k][co] * W[ci][co][k]  -> stride-2 gather conv, packed [tap][CinP][Cout]
   const int OP = round_up(t.Cin, 32);
   ConvArgs a{};
@@ -1092,7 +1105,7 @@ extern "C" {
 const char* hdf_version(void) { return "hdf-hip 0.1 (gfx950)"; }
 int hdf_set_cu_budget(int cus) {
   HDF_CHECK_ARG(cus >= 8 && cus <= 256 && cus % 8 == 0, "cu budget %d: a multiple of 8 in [8, 256]", cus);
-  hdf_set_cu_budget_tl(cus);
+  g_cu_budget.store(cus, std::memory_order_relaxed);
   return HDF_OK;
 }
 const char* hdf_last_error(void) { return g_err; }

@@ -1314,12 +1314,18 @@ int hdf_launch_head_fwd(int dtype, const void* in, int64_t in_pitch, const float
   const unsigned gx = (unsigned)ceil_div64(vox, per);
   const int vec4 = (vox % 4 == 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0) ? 1 : 0;
   DISPATCH_T(dtype, {
+    // 8 class slots at per = 2048 (the 128^3 level) need 72 KiB of dynamic LDS: above 64 KiB it is allowed per kernel
+    auto go = [&](auto kern, int mc) -> int {
+      const size_t shm = (size_t)mc * (per + 256) * sizeof(float);
+      HDF_TRY(allow_big_lds((const void*)kern, shm));
+      hipLaunchKernelGGL(kern, dim3(gx, N), dim3(256), shm, st, (const T*)in, in_pitch, scale, shift, w, b, (T*)logits, N,
+                         C, ncls, vox, per, vec4);
+      return HDF_OK;
+    };
     if (ncls <= 4)
-      hipLaunchKernelGGL((head_fwd_kernel<T, 4>), dim3(gx, N), dim3(256), (size_t)4 * (per + 256) * sizeof(float), st,
-                         (const T*)in, in_pitch, scale, shift, w, b, (T*)logits, N, C, ncls, vox, per, vec4);
+      HDF_TRY(go(head_fwd_kernel<T, 4>, 4));
     else
-      hipLaunchKernelGGL((head_fwd_kernel<T, 8>), dim3(gx, N), dim3(256), (size_t)8 * (per + 256) * sizeof(float), st,
-                         (const T*)in, in_pitch, scale, shift, w, b, (T*)logits, N, C, ncls, vox, per, vec4);
+      HDF_TRY(go(head_fwd_kernel<T, 8>, 8));
   });
   HDF_LAUNCH_CHECK();
   return HDF_OK;

@@ -7,6 +7,24 @@ from ._lib import BF16, F16, F32, check, lib, ptr, stream_ptr
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 
+# class weights as the trainer builds them (trainer.py:743-771: a CPU tensor / list) -> one device copy per (device,
+# values): a pageable host-to-device copy on every loss call would block the host once per step
+_CW_CACHE = {}
+
+
+def _device_class_weight(cw, device):
+    if torch.is_tensor(cw) and cw.is_cuda:
+        return cw.detach().to(device=device, dtype=torch.float32).contiguous()
+    vals = tuple(float(v) for v in (cw.detach().flatten().tolist() if torch.is_tensor(cw) else list(cw)))
+    shape = tuple(cw.shape) if torch.is_tensor(cw) else (len(vals),)
+    key = (str(device), shape, vals)
+    t = _CW_CACHE.get(key)
+    if t is None:
+        if len(_CW_CACHE) > 64:
+            _CW_CACHE.clear()
+        t = _CW_CACHE[key] = torch.tensor(vals, dtype=torch.float32).reshape(shape).to(device)
+    return t
+
 
 class DeepSuperCEDice(torch.autograd.Function):
     """apply(target, *outs) = DeepSuperloss(CEPlusDice(weight=None, ignore_index=0)); apply((target, w_ce, w_dice), *outs)
@@ -41,7 +59,7 @@ class DeepSuperCEDice(torch.autograd.Function):
         outs = [o.contiguous() for o in outs]
         tgt = target.float().contiguous()
         if cw is not None:
-            cw = torch.as_tensor(cw, dtype=torch.float32).to(tgt.device).contiguous()
+            cw = _device_class_weight(cw, tgt.device)
             if cw.dim() != 1 or cw.shape[0] != c:
                 raise AssertionError(f"Expect weight shape [{c}], get[{tuple(cw.shape)}]")     # dice_loss.py:80-81
         ign = -1 if ignore is None else int(ignore)

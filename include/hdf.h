@@ -28,10 +28,11 @@ typedef void* hdf_stream; /* hipStream_t */
 
 const char* hdf_version(void);
 const char* hdf_last_error(void);
-/* Compute units the persistent kernels (conv_ws2 / conv_wgrad2 / the transposed-conv kernels) of the CALLING HOST THREAD
- * may assume: their grids are one workgroup per CU.  256 = the whole MI355X (default); a multiple of 8 below that for
- * launches on a stream created with hipExtStreamCreateWithCUMask, so that every workgroup of a launch is resident at
- * once.  The plan sets it itself around the launches it places on its own masked streams (hdf_forward / hdf_backward). */
+/* Compute units the persistent kernels (conv_ws2 / conv_wgrad2 / the transposed-conv kernels) may assume: their grids
+ * are one workgroup per CU.  256 = the whole MI355X (default); a multiple of 8 below that for launches on a stream the
+ * CALLER created with hipExtStreamCreateWithCUMask, so that every workgroup of a launch is resident at once.  Process-wide
+ * (forward and autograd's backward thread see the same value: it also enters the split-K decision of the low-resolution
+ * convs, i.e. their summation order); a diagnostic knob -- the plan never changes it and owns no masked streams. */
 int hdf_set_cu_budget(int cus);
 
 /* ---- model plan: models/HDenseFormer.py:177-227 (HDenseFormer.__init__) ------------------------------- */

@@ -290,7 +290,10 @@ def test_patch_embed_fwd_bwd(DM, size, B, M, train):
 @pytest.mark.parametrize("C_,ncls,size,n,xf", [(32, 4, (16, 16, 16), 2, True), (64, 3, (8, 12, 10), 1, False),
                                               (48, 2, (9, 7, 5), 2, True), (256, 4, (4, 4, 4), 2, False),
                                               (384, 3, (2, 3, 4), 1, True), (512, 3, (4, 4, 4), 1, False),
-                                              (32, 6, (8, 8, 12), 2, True), (64, 8, (6, 5, 7), 1, False)])
+                                              (32, 6, (8, 8, 12), 2, True), (64, 8, (6, 5, 7), 1, False),
+                                              # vox = 2^21 (the 128^3 level): 2048 voxels per workgroup; with 8 class slots the
+                                              # forward needs 72 KiB of dynamic LDS (allowed per kernel)
+                                              (16, 6, (128, 128, 128), 1, True)])
 def test_head_fwd_bwd(dtype, C_, ncls, size, n, xf):
     g = _g(C_ + ncls)
     tdt = torch.bfloat16 if dtype == BF16 else torch.float32
