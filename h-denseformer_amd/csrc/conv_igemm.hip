@@ -17,35 +17,12 @@
 // bias, stores the raw conv output once and emits per-tile (sum, sum^2) partials for the following
 // InstanceNorm, reduced deterministically by in_finalize (no float atomics).
 #include "conv_igemm.h"
+#include "conv_tile.h"
 #include <type_traits>
 
 namespace {
 
 constexpr int PITCH = 80;  // LDS bytes per voxel row: 64 payload + 16 pad
-
-template <typename T>
-struct Mma;
-template <>
-struct Mma<bf16_t> {
-  static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-  }
-};
-template <>
-struct Mma<f16_t> {
-  static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-  }
-};
-template <>
-struct Mma<float> {
-  // lane (r, h) holds channels 4h..4h+3 of an 8-channel group: step s contracts channels {s, 4+s}
-  static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
-#pragma unroll
-    for (int s = 0; s < 4; s++)
-      c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[s]), __uint_as_float(b[s]), c, 0, 0, 0);
-  }
-};
 
 // Stage a box of voxels (channels [c0, c0 + chunk_elems)) of a pitched NDHWC tensor into LDS with the
 // optional per-(n,channel) affine(+relu) transform.  Voxels outside the tensor and channels >= C
@@ -357,26 +334,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// MFMA row (0..31) -> (dz in 0..3, x in 0..7).  ds_read_b128 services lanes {0-3,12-15,20-27} and {4-11,16-19,
-// 28-31} (and the same +32) as groups; group 1 gets z in {0,2}, group 2 z in {1,3}: box row = 100*z + 10*y + x
-// (BH = BW = 10) is then distinct mod 16 inside each group.
-constexpr int WS_STAT_ROWS = 512;  // conv_ws2_kernel: InstanceNorm partial rows per sample (2 passes x 256 workgroup slots)
-__device__ __forceinline__ void ws_row_to_zx(int r, int& dz, int& x) {
-  const int g2 = ((r >= 4 && r < 12) || (r >= 16 && r < 20) || r >= 28) ? 1 : 0;
-  const int rank = g2 ? (r < 12 ? r - 4 : (r < 20 ? r - 8 : r - 16)) : (r < 4 ? r : (r < 16 ? r - 8 : r - 12));
-  dz = 2 * (rank >> 3) + g2;
-  x = rank & 7;
-}
-
-// workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain the vector-memory
-// counter, so prefetch loads and epilogue stores stay in flight across it
-#define WS_BARRIER()                                     \
-  do {                                                   \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
-    __builtin_amdgcn_s_barrier();                        \
-    asm volatile("" ::: "memory");                       \
-  } while (0)
-
 // ------------------------------------------------------------------------------------------------
 // conv_ws2: weights-stationary persistent kernel with a DOUBLE-BUFFERED activation tile.
 //
@@ -405,11 +362,6 @@ __device__ __forceinline__ int a_swz(int row) {
 
 // 16 zero bytes: the source of LDS-DMA slots that lie outside the tensor (zero padding)
 __device__ __attribute__((aligned(16))) uint32_t g_zero_line[4] = {0u, 0u, 0u, 0u};
-
-struct WsTile {
-  int n, z0, y0, x0, tile;
-  int k;  // index in the list the tile came from (border pass)
-};
 
 // NB: 32-channel output blocks per workgroup.  NB = 2 (64-byte rows, Cout % 64 == 0) stages every tile once for both
 // blocks (two workgroups with 32 channels each staged it twice: the 32->64 dgrad at 128^3 was the costliest launch of
@@ -2891,6 +2843,9 @@ int hdf_launch_conv(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
                 "conv: fragment-major weights given to a launch that reads row-major panels (mode %d Cin %d)", mode, a.Cin);
   HDF_CHECK_ARG(a.split == 0 || (mode == 0 && a.split % 32 == 0 && a.split < a.Cout && a.out2 != nullptr),
                 "conv: split output needs mode 0, split %% 32 == 0 and a second buffer (split=%d)", a.split);
+#ifndef HDF_NO_CONV_WR  // (A/B builds: the weights-stationary kernels for every launch)
+  if (mode == 0 && hdf_conv_wr_takes(dtype, a)) return hdf_launch_conv_wr(dtype, a, st);
+#endif
   HDF_DISPATCH_T(dtype, return launch_conv_t<T>(mode, a, st));
   return HDF_ERR_UNSUPPORTED;
 }

@@ -42,6 +42,33 @@ def test_conv3d_s1(dtype, cin, cout, size, n):
     assert rel_err(s[..., 1], (ref * ref).sum((2, 3, 4))) < 5e-3 + TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", [BF16, F16])
+@pytest.mark.parametrize("cin,cout,size,n", [(32, 32, (56, 52, 50), 2),      # 8x8x8 tiles, ragged in y and x, two samples
+                                            (32, 32, (64, 64, 64), 1),      # whole tiles only
+                                            (64, 32, (64, 56, 48), 2),      # K split over the waves + LDS exchange
+                                            (64, 64, (48, 52, 56), 1),      # two output blocks through blockIdx.y
+                                            (64, 48, (50, 49, 51), 1),      # channel count below the padded block
+                                            (32, 64, (50, 49, 51), 2),      # two output blocks per wave (NB = 2)
+                                            (32, 96, (48, 48, 48), 1)])
+def test_conv3d_weights_in_registers(dtype, cin, cout, size, n):
+    """conv_wr_kernel (csrc/conv_wr.hip): 16-bit storage, 64- / 128-byte rows at >= 48^3 -- every instantiation, ragged
+    extents (the checked border phase), several samples (the tile list and the statistics rows cross samples), bias,
+    InstanceNorm partial sums.  Reference: torch fp32 conv3d on the storage-rounded operands."""
+    x, w, b = _mk((n, cin) + size, 21), _mk((cout, cin, 3, 3, 3), 22) * (cin * 27) ** -0.5, _mk((cout,), 23)
+    ref = F.conv3d(rnd(x, dtype), rnd(w, dtype), b, padding=1)
+    wp = pack_w(w, dtype, cout, cin, rup(cout, 32), cin, cin * 27, 27, 0)
+    out, part = conv3d(dtype, 0, to_cl(x, dtype), cin, wp, cout, bias=b.to(DEV), stats=True)
+    torch.cuda.synchronize()
+    got = from_cl(out)
+    assert rel_err(got, ref) < TOL[dtype]
+    # element-wise too: a misplaced tile or M-block would hide in a norm of 10^6 values
+    assert float((got - ref).abs().max()) < 0.05 * float(ref.abs().max())
+    tiles = part.shape[0] // n
+    s = part.view(n, tiles, -1, 2).sum(1).cpu()[:, :cout]
+    assert rel_err(s[..., 0], ref.sum((2, 3, 4))) < 5e-3 + TOL[dtype]
+    assert rel_err(s[..., 1], (ref * ref).sum((2, 3, 4))) < 5e-3 + TOL[dtype]
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16, F16])
 @pytest.mark.parametrize("cin,cout,size,n", [(32, 32, (8, 8, 16), 2), (32, 64, (48, 48, 52), 3), (64, 32, (52, 48, 48), 1),
                                             (16, 48, (48, 50, 48), 1)])

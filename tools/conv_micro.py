@@ -71,6 +71,15 @@ else:
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.reps
+if os.environ.get("WR_STAMPS") and a.op == "conv":
+    # conv_wr.hip -DWR_DBG_STAMPS: [workgroup][wave 0/1][16]: cycles per section, total cycles, real time in 10 ns
+    t = part[:256 * 2 * 16].view(256, 2, 16).double().cpu()
+    names = ["mfma-phase", "barrier1", "xch-write", "barrier2", "xch-read", "barrier3", "epilogue", "step/top"]
+    for w in range(2):
+        m = t[:, w, :8].mean(0).tolist()
+        tot = t[:, w, 8].mean().item()
+        print(f"  wave {w}: total {int(tot)} cycles, clock {tot / (t[:, w, 9].mean().item() * 10):.2f} GHz; " +
+              ", ".join(f"{n} {v / tot * 100:.1f}%" for n, v in zip(names, m)))
 if os.environ.get("WS_STAMPS") and a.op == "conv":
     t = part[:256 * 8].view(256, 8).double().cpu()
     names = ["commit", "barrier1", "prefetch-issue", "mfma-loop", "barriers2+3", "epi:stage+stats", "epi:barrier+stores", "loop-top"]

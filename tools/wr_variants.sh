@@ -1,0 +1,16 @@
+#!/bin/bash
+# Attribution builds of conv_wr.hip (each deletes one ingredient of the phase; results are wrong, timings are the point):
+# libhdf_hip_wr_<tag>.so = the product objects with conv_wr.o rebuilt under -DWR_DBG_<tag>.  Then tools/wr_attrib.sh on the GPU box.
+cd "$(dirname "$0")/../h-denseformer_amd"
+python build.py > /dev/null
+VARS=${VARS:-"NOLOAD NOSTAGE NOSTORE NOMFMA"}
+for v in $VARS; do
+  mkdir -p build/wr_$v
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-mfma-vgpr-form -DWR_DBG_$v -c csrc/conv_wr.hip -o build/wr_$v/conv_wr.o &
+done
+wait
+for v in $VARS; do
+  objs="build/conv_igemm.o build/unet_ops.o build/transformer.o build/transformer_fused.o build/loss.o build/plan.o"
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o lib/libhdf_hip_wr_$v.so $objs build/wr_$v/conv_wr.o
+done
+ls -la lib/
