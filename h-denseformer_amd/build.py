@@ -13,8 +13,10 @@ OBJ = os.path.join(HERE, "build")
 SOURCES = ["conv_igemm.hip", "conv_wr.hip", "unet_ops.hip", "transformer.hip", "transformer_fused.hip", "loss.hip", "plan.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # per-file additions.  conv_wr.hip: MFMA results in architectural VGPRs -- its AGPR half holds the 216 weight registers
-# of a wave (left to its heuristic hipcc puts the accumulators there and spills weights to scratch)
-EXTRA = {"conv_wr.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+# of a wave (left to its heuristic hipcc puts the accumulators there and spills weights to scratch); its tile phase is one
+# fully unrolled block of 216 MFMAs + staging, above the default size limit of `#pragma unroll` with an input transform
+# (and no SLP vectorisation there: packed f32 adds beside MFMAs cost more than the scalar pair they replace)
+EXTRA = {"conv_wr.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form", "-mllvm", "-pragma-unroll-threshold=1000000"]}
 
 
 def _digest():

@@ -55,7 +55,8 @@ struct WgradArgs {
 };
 
 // conv_wr.hip: weights-in-registers form of the mode-0 launches with 64- / 128-byte rows at >= 48^3 (16-bit storage)
-bool hdf_conv_wr_takes(int dtype, const ConvArgs& a);
+bool hdf_conv_wr_can(int dtype, const ConvArgs& a);    // the kernel handles this launch
+bool hdf_conv_wr_takes(int dtype, const ConvArgs& a);  // ... and the plan routes it there
 int hdf_launch_conv_wr(int dtype, const ConvArgs& a, hipStream_t st);
 int hdf_launch_conv(int dtype, int mode /*0 conv s1, 1 conv s2, 2 convT*/, const ConvArgs& a, hipStream_t st);
 // tiles per sample of the stat partials; row_bytes = Cin*sizeof(storage) selects the kernel variant (pass a

@@ -33,6 +33,32 @@
 
 namespace {
 
+// 16 zero bytes: the source of DMA slots that lie outside the tensor (zero padding)
+__device__ __attribute__((aligned(16))) uint32_t g_wr_zero_line[4] = {0u, 0u, 0u, 0u};
+
+// s_waitcnt vmcnt(n) for a value that is a constant only after unrolling (the builtin wants a literal): the switch folds
+#define WR_VMCNT_CASE(n) \
+  case n:                \
+    __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14)); \
+    break;
+__device__ __forceinline__ void wr_wait_vmcnt(int n) {
+  switch (n) {
+    WR_VMCNT_CASE(0) WR_VMCNT_CASE(1) WR_VMCNT_CASE(2) WR_VMCNT_CASE(3) WR_VMCNT_CASE(4) WR_VMCNT_CASE(5)
+    WR_VMCNT_CASE(6) WR_VMCNT_CASE(7) WR_VMCNT_CASE(8) WR_VMCNT_CASE(9) WR_VMCNT_CASE(10) WR_VMCNT_CASE(11)
+    WR_VMCNT_CASE(12) WR_VMCNT_CASE(13) WR_VMCNT_CASE(14) WR_VMCNT_CASE(15) WR_VMCNT_CASE(16) WR_VMCNT_CASE(17)
+    WR_VMCNT_CASE(18) WR_VMCNT_CASE(19) WR_VMCNT_CASE(20) WR_VMCNT_CASE(21) WR_VMCNT_CASE(22) WR_VMCNT_CASE(23)
+    WR_VMCNT_CASE(24) WR_VMCNT_CASE(25) WR_VMCNT_CASE(26) WR_VMCNT_CASE(27) WR_VMCNT_CASE(28) WR_VMCNT_CASE(29)
+    WR_VMCNT_CASE(30) WR_VMCNT_CASE(31) WR_VMCNT_CASE(32) WR_VMCNT_CASE(33) WR_VMCNT_CASE(34) WR_VMCNT_CASE(35)
+    WR_VMCNT_CASE(36) WR_VMCNT_CASE(37) WR_VMCNT_CASE(38) WR_VMCNT_CASE(39) WR_VMCNT_CASE(40) WR_VMCNT_CASE(41)
+    WR_VMCNT_CASE(42) WR_VMCNT_CASE(43) WR_VMCNT_CASE(44) WR_VMCNT_CASE(45) WR_VMCNT_CASE(46) WR_VMCNT_CASE(47)
+    WR_VMCNT_CASE(48) WR_VMCNT_CASE(49) WR_VMCNT_CASE(50) WR_VMCNT_CASE(51) WR_VMCNT_CASE(52) WR_VMCNT_CASE(53)
+    WR_VMCNT_CASE(54) WR_VMCNT_CASE(55) WR_VMCNT_CASE(56) WR_VMCNT_CASE(57) WR_VMCNT_CASE(58) WR_VMCNT_CASE(59)
+    WR_VMCNT_CASE(60)
+    default:
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): always sufficient
+  }
+}
+
 template <int RB>
 __device__ __forceinline__ int wr_key(int bz, int bx) {
   return RB == 128 ? (((bx >> 1) & 3) | (((bz >> 1) & 1) << 2)) : (((bx >> 2) & 1) | (((bz >> 1) & 1) << 1));
@@ -51,8 +77,7 @@ __global__ __launch_bounds__(256) void conv_wr_kernel(ConvArgs a) {
   constexpr int NG = 9 * KSW;         // (jz, jx, k-step) groups per tile
   constexpr int CPV = RB / 16, VPS = 256 / CPV;  // 16-byte chunks per voxel row; voxels per staging round
   constexpr int NJ = (BOX + VPS - 1) / VPS;      // staging slots per thread and tile
-  constexpr int R = (NJ + 1) / 2;                // slots in flight (registers): half a tile
-  constexpr int ABUF = BOX * RB;
+  constexpr int ABUF = NJ * VPS * RB;            // tile buffer = whole staging rounds of 4 KB (the LDS-DMA image is lane-linear)
   constexpr int NC = 32 * NB;
   constexpr int OFF_RED = 2 * ABUF;              // [4 waves][NC][2] floats
   constexpr int XCH_BYTES = (KSPLIT == 2) ? 4 * KEEP * NB * 16 * 64 * 4 : 0;  // 4 waves x outgoing accumulators
@@ -179,8 +204,6 @@ __global__ __launch_bounds__(256) void conv_wr_kernel(ConvArgs a) {
     cpk[j / 2] |= (bx | (by << 4) | (bz << 8) | (sw << 12)) << (16 * (j % 2));
   }
   const uint32_t XS = (uint32_t)a.in_pitch * ESZ, YS = XS * a.Wi, ZS = YS * a.Hi;  // < 2^24 (launcher)
-  const uint32_t part16 = part * 16;
-  const int lbase = tv * RB;
   // the field of slot j, opaque to the optimiser: everything derived from it is recomputed where it is used (left
   // visible, all 3 NJ coordinates and NJ offsets are hoisted out of the tile loop into registers again)
   auto slot_field = [&](int j) __attribute__((always_inline)) {
@@ -188,19 +211,12 @@ __global__ __launch_bounds__(256) void conv_wr_kernel(ConvArgs a) {
     asm volatile("" : "+v"(c));
     return (j % 2) ? (c >> 16) : (c & 0xffffu);
   };
+  // global byte offset of the chunk that belongs into THIS lane's 16 bytes of the (lane-linear) LDS image: the XOR
+  // swizzle is applied on the source side of the DMA (chunk part ^ key of the voxel; an involution, so the same field is
+  // also the LDS position of the thread's own chunk `part`, used by the in-place transform)
   auto slot_goff = [&](uint32_t f) __attribute__((always_inline)) {
-    return __umul24(f & 15u, XS) + __umul24((f >> 4) & 15u, YS) + __umul24((f >> 8) & 15u, ZS) + part16;
+    return __umul24(f & 15u, XS) + __umul24((f >> 4) & 15u, YS) + __umul24((f >> 8) & 15u, ZS) + ((f >> 12) << 4);
   };
-  // byte offset of slot j from `wbase` (= buffer offset + lbase); the last slot's voxel may be the clamped one
-  auto loff = [&](int j, uint32_t f, int wbase) __attribute__((always_inline)) {
-    const int sw16 = (int)(f >> 12) << 4;
-    if (j == NJ - 1 && NJ * VPS != BOX) {
-      const int vox = (int)(((f >> 8) & 15u) * (BH * BW) + ((f >> 4) & 15u) * BW + (f & 15u));
-      return wbase - lbase + vox * RB + sw16;
-    }
-    return wbase + sw16 + j * VPS * RB;
-  };
-
   auto tile_lin = [&](const WsTile& c) __attribute__((always_inline)) { return ((c.n * ntz + c.z0 / TD) * nty + c.y0 / TH) * ntx + c.x0 / TW; };
   auto int_init = [&](WsTile& c, int k) __attribute__((always_inline)) {
     int t = k;
@@ -286,33 +302,43 @@ __global__ __launch_bounds__(256) void conv_wr_kernel(ConvArgs a) {
     const int xlo = max(0, 1 - c.x0), xn = min(BW, a.Wi + 1 - c.x0) - xlo;
     return (uint32_t)(zlo | (zn << 4) | (ylo << 8) | (yn << 12) | (xlo << 16) | (xn << 20));
   };
-  u32x4 pf[R];
   auto slot_ok = [&](uint32_t f, uint32_t rng) __attribute__((always_inline)) {
     const unsigned bx = f & 15u, by = (f >> 4) & 15u, bz = (f >> 8) & 15u;
     const bool in = ((bz - (rng & 15u)) < ((rng >> 4) & 15u)) & ((by - ((rng >> 8) & 15u)) < ((rng >> 12) & 15u)) &
                     ((bx - ((rng >> 16) & 15u)) < ((rng >> 20) & 15u));
     return in | ((int32_t)rng < 0);  // bitwise: no short-circuit branches
   };
-  // load slot j of the tile (base, toff, rng) into pf[j % R]; returns the slot's mask bit (border path).
-  // FAST: a valid interior tile.  (A UNIFORM base + a 32-bit per-lane offset computed right here: global_load ... saddr.)
-  auto load_one = [&](auto fast_tag, int j, const char* base, int toff, uint32_t rng) __attribute__((always_inline)) {
+  // Staging is LDS-DMA: global_load_lds_dwordx4 moves 16 bytes per lane from global memory straight into the tile buffer
+  // (lane-linear: a wave writes 1 KB, a staging round of the workgroup 4 KB).  No staging registers -- the register-staged
+  // first version of this kernel needed 10 x 4 of them beside the 216 weight registers and hipcc spilled weights --, no
+  // commit instructions, and all NJ rounds of the next tile are in flight from the first groups of a phase on (76 KB per
+  // CU instead of 40).  The instruction is inline asm and counted by hand (s_waitcnt vmcnt): issued through the builtin,
+  // hipcc waits for vmcnt(0) in front of the next LDS read of ANY buffer.  M0 = LDS destination of the wave.
+  const char* const zero_src = reinterpret_cast<const char*>(g_wr_zero_line);
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  // issue round j of the tile (base, toff, rng) into the buffer at byte offset bufoff; returns the round's mask bit
+  auto dma_one = [&](auto fast_tag, int j, const char* base, int toff, uint32_t rng, int bufoff) __attribute__((always_inline)) {
     const uint32_t f = slot_field(j);
+    const char* p;
+    uint32_t bit = 0u;
     if constexpr (decltype(fast_tag)::value) {
-#ifdef WR_DBG_L2HIT  // attribution build: every interior tile stages the SAME box (cache hits: issue cost without HBM latency)
-      base = in_b;
-#endif
-      pf[j % R] = *reinterpret_cast<const u32x4*>(base + slot_goff(f));
-      return 0u;
+      p = base + slot_goff(f);
     } else {
       const bool ok = slot_ok(f, rng);
-      const uint32_t off = ok ? (uint32_t)toff + slot_goff(f) : 0u;
-      pf[j % R] = *reinterpret_cast<const u32x4*>(base + off);
-      return ok ? (1u << j) : 0u;
+      p = ok ? base + (int64_t)toff + slot_goff(f) : zero_src;   // zero padding: a 16-byte line of zeros
+      bit = ok ? (1u << j) : 0u;
     }
+    const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)bufoff + (uint32_t)(j * 4096) + (uint32_t)(wave * 1024));
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(p), "s"(m0v)
+                 : "memory");
+    return bit;
   };
   float sc[EPC], sh[EPC];
   int xf_n = -1;
-  auto load_xf = [&](int n) __attribute__((always_inline)) {  // uniform; this thread's 8 channels are the same for every slot
+  auto load_xf = [&](int n) __attribute__((always_inline)) {  // uniform; this thread's 8 channels (chunk `part`) for every slot
     if constexpr (XF) {
       if (n != xf_n) {
         const f32x4* ps = reinterpret_cast<const f32x4*>(a.in_scale + (int64_t)n * CIN + part * EPC);
@@ -327,82 +353,73 @@ __global__ __launch_bounds__(256) void conv_wr_kernel(ConvArgs a) {
       }
     }
   };
-  auto commit_one = [&](auto fast_tag, int j, uint32_t mask, int dstoff /* buffer offset + lbase */) __attribute__((always_inline)) {
-    // The staging registers live in the AGPRs the weights leave free (global_load writes them, ds_write reads them
-    // directly; with a transform the commit copies them out, 4 v_accvgpr_read per slot): the 256 architectural registers
-    // then hold accumulators, A fragments and tables without spilling.  The pin sits HERE, at the use: placed behind the
-    // load it is a use of the loaded value, and hipcc waits for every load right after issuing it (s_waitcnt vmcnt(0):
-    // one memory round trip per slot, 12 us per tile).
-    if constexpr (XF && 216 + 4 * R <= 248) asm volatile("" : "+a"(pf[j % R]));
-    u32x4 v = pf[j % R];
+  // XF: the producer's InstanceNorm + ReLU, applied IN PLACE to round j once it has landed: thread (voxel, chunk `part`)
+  // rewrites the 16 bytes at the chunk's swizzled position of its voxel's row -- written by a lane of its own wave (the
+  // 8 or 4 lanes of a voxel row share a wave), so the wave's own vmcnt wait is all the ordering needed.  `landed` =
+  // DMA rounds of this tile issued after j (they retire in order).  Rounds of zero padding stay zero (mask).
+  auto xf_one = [&](auto fast_tag, int j, uint32_t mask, int bufoff, int younger) __attribute__((always_inline)) {
     if constexpr (XF) {
-      float f[EPC];
-      ST<T>::unpack(v, f);
+      const uint32_t f = slot_field(j);
+      const int vox = (int)(((f >> 8) & 15u) * (BH * BW) + ((f >> 4) & 15u) * BW + (f & 15u));
+      char* const q = lds + bufoff + vox * RB + ((int)(f >> 12) << 4);
+      wr_wait_vmcnt(younger);
+      asm volatile("" ::: "memory");
+      u32x4 v = *reinterpret_cast<const u32x4*>(q);
+      float fl[EPC];
+      ST<T>::unpack(v, fl);
 #pragma unroll
-      for (int e = 0; e < EPC; e++) f[e] = fmaxf(f[e] * sc[e] + sh[e], relu_lo);
-      v = ST<T>::pack(f);
-    }
-    if constexpr (!decltype(fast_tag)::value) {
-      const uint32_t keep = (uint32_t)(((int32_t)(mask << (31 - j))) >> 31);  // all ones where the voxel exists
+      for (int e = 0; e < EPC; e++) fl[e] = fmaxf(fl[e] * sc[e] + sh[e], relu_lo);
+      u32x4 w = ST<T>::pack(fl);
+      if constexpr (!decltype(fast_tag)::value) {
+        const uint32_t keepm = (uint32_t)(((int32_t)(mask << (31 - j))) >> 31);  // all ones where the voxel exists
 #pragma unroll
-      for (int k = 0; k < 4; k++) v[k] &= keep;
+        for (int k = 0; k < 4; k++) w[k] &= keepm;
+      }
+      // threads past the end of the box (last round) must not touch it: their field is the box's last voxel, and a
+      // second read-modify-write of the same 16 bytes would transform them twice
+      if (j < NJ - 1 || NJ * VPS == BOX || VPS * j + tv < BOX) *reinterpret_cast<u32x4*>(q) = w;
     }
-    *reinterpret_cast<u32x4*>(lds + loff(j, slot_field(j), dstoff)) = v;
   };
 
-  // T0: tile under the MFMAs; T1: the tile being staged into the other buffer; T2: the tile whose first half is loaded
-  WsTile T0, T1, T2;
+  // T0: tile under the MFMAs; T1: the tile landing in the other buffer
+  WsTile T0, T1, T2;  // T2: the tile after T1, decoded under the MFMAs of T0 (scalar work off the loop's serial tail)
   const char *base1 = in_b, *base2 = in_b;
   int toff1 = 0, toff2 = 0;
-  uint32_t rng1 = 0, rng2 = 0;
-  uint32_t m1 = 0, m2 = 0;  // zero-padding masks of T1's / T2's slots (border pass)
+  uint32_t rng1 = 0, rng2 = 0, m1 = 0;
   bool v1 = false, v2 = false;
   int left = 0, par = 0;
   using Yes = std::true_type;
   using No = std::false_type;
   auto begin_pass = [&](auto border_tag, int k, int count) __attribute__((always_inline)) {
     constexpr bool BORDER = decltype(border_tag)::value;
-    auto next = [&](WsTile& c) __attribute__((always_inline)) {
-      if constexpr (BORDER)
-        bor_next(c);
-      else
-        int_next(c);
-    };
     if constexpr (BORDER)
       bor_init(T0, k);
     else
       int_init(T0, k);
     left = count - 1;
     T1 = T0;
-    next(T1);
-    T2 = T1;
-    next(T2);
-    v1 = left >= 1, v2 = left >= 2;
-    const bool i0 = BORDER ? tile_interior(T0) : true, i1 = v1 && (BORDER ? tile_interior(T1) : true),
-               i2 = v2 && (BORDER ? tile_interior(T2) : true);
+    if constexpr (BORDER)
+      bor_next(T1);
+    else
+      int_next(T1);
+    v1 = left >= 1;
+    const bool i0 = BORDER ? tile_interior(T0) : true, i1 = v1 && (BORDER ? tile_interior(T1) : true);
     const char* const base0 = src_base(T0, true, i0);
     const int toff0 = src_toff(T0, true, i0);
     const uint32_t rng0 = src_rng(T0, true, i0);
     base1 = src_base(T1, v1, i1), toff1 = src_toff(T1, v1, i1), rng1 = src_rng(T1, v1, i1);
-    base2 = src_base(T2, v2, i2), toff2 = src_toff(T2, v2, i2), rng2 = src_rng(T2, v2, i2);
+    T2 = T1;
     __syncthreads();  // the previous pass is done with both tile buffers
     par = 0;
     load_xf(T0.n);
-    // T0 -> buffer 0, not overlapped: two half batches through the R staging registers
+    // T0 -> buffer 0, not overlapped
     uint32_t m0 = 0;
 #pragma unroll
-    for (int half = 0; half < 2; half++) {
+    for (int j = 0; j < NJ; j++) m0 |= dma_one(No{}, j, base0, toff0, rng0, 0);
 #pragma unroll
-      for (int j = half * R; j < min(NJ, (half + 1) * R); j++) m0 |= load_one(No{}, j, base0, toff0, rng0);
-#pragma unroll
-      for (int j = half * R; j < min(NJ, (half + 1) * R); j++) commit_one(No{}, j, m0, lbase);
-    }
-    m1 = 0, m2 = 0;
-#pragma unroll
-    for (int j = 0; j < R; j++) m1 |= load_one(No{}, j, base1, toff1, rng1);
-    // drained once per pass, so that the tile loop is entered with nothing in flight: entered with these R loads
-    // pending and no store behind them, the merged state at the loop head is the conservative one described at `epilogue`
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    for (int j = 0; j < NJ; j++) xf_one(No{}, j, m0, 0, NJ - 1 - j);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    m1 = 0;
     WS_BARRIER();
   };
 
@@ -428,7 +445,9 @@ __global__ __launch_bounds__(256) void conv_wr_kernel(ConvArgs a) {
     edz[q4] = dz;
     eplane[q4] = dz * a.Ho * a.Wo * (int)a.out_pitch;
   }
-  auto eoff = [&](int i) __attribute__((always_inline)) { return eplane[i >> 2] + ((i & 3) + 4 * ((i >> 2) & 1)) * (int)a.out_pitch; };
+  // element offset of accumulator register i inside its M-block: plane part per lane (edz depends on h), x part uniform
+  int opitch_l = (int)a.out_pitch;
+  auto eoff = [&](int i) __attribute__((always_inline)) { return eplane[i >> 2] + ((i & 3) + 4 * ((i >> 2) & 1)) * opitch_l; };
   const int ykeep = ybase + (KSPLIT == 2 ? KEEP * kq : 0);  // first y row this wave stores
   const bool ch_odd = r & 1;
 
@@ -478,9 +497,11 @@ __global__ __launch_bounds__(256) void conv_wr_kernel(ConvArgs a) {
   // load) from the path with the FEWEST younger operations -- with a conditional store path it assumes none, emits
   // vmcnt(R - 2) and thereby waits for every prefetch load, the one issued a moment ago included, and for the write
   // acknowledgements of this tile's stores: a full memory round trip at the top of every tile.
-  auto epilogue = [&](f32x16 (&fin)[MBW][NB], const WsTile& ET, auto plain_tag) __attribute__((always_inline)) {
+  auto epilogue = [&](auto& fin, const WsTile& ET, auto plain_tag) __attribute__((always_inline)) {
     constexpr bool PLAIN = decltype(plain_tag)::value;
     const int z0 = ET.z0 + 4 * zb, y0 = ET.y0 + ykeep, x0 = ET.x0;
+    opitch_l = (int)a.out_pitch;
+    asm volatile("" : "+s"(opitch_l));
     const bool full = PLAIN || (ET.z0 + TD <= a.Do && ET.y0 + TH <= a.Ho && ET.x0 + TW <= a.Wo);
     stats_sample(ET.n);
 #pragma unroll
@@ -550,6 +571,58 @@ __global__ __launch_bounds__(256) void conv_wr_kernel(ConvArgs a) {
     }
   };
 
+  // DEFERRED EPILOGUE (plain phases).  With one wave per SIMD the stores, the 64-bit address arithmetic and the
+  // InstanceNorm sums of a tile -- 15 % of a workgroup's cycles behind the MFMA phase of the 8x8x8 tile, and as much
+  // again in the tail that hipcc sinks the sums into -- run with the matrix pipe idle.  Instead the kept accumulators
+  // are copied to `pend` when a tile's phase ends and leave during the NEXT tile's phase, NPAIR paired-row stores spread
+  // over its NG groups.  A pass starts with pend = 0 on its own first tile: the zeros it stores there are overwritten by
+  // that tile's real values one phase later (same wave, same addresses, program order) and add nothing to the sums -- so
+  // the phase never branches on "is there a pending tile".  The pass ends with an immediate epilogue of the last tile.
+  constexpr int NPAIR = KEEP * NB * 8;
+  f32x16 pend[KEEP][NB];
+  WsTile PT;
+  T* pbase[NB];
+  auto pend_clear = [&](const WsTile& c) __attribute__((always_inline)) {
+#pragma unroll
+    for (int mb = 0; mb < KEEP; mb++)
+#pragma unroll
+      for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) pend[mb][nb][i] = 0.f;
+    PT = c;
+  };
+  auto pend_begin = [&]() __attribute__((always_inline)) {
+    stats_sample(PT.n);
+    opitch_l = (int)a.out_pitch;
+    asm volatile("" : "+s"(opitch_l));
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++)
+      pbase[nb] = outp[nb] + ((((int64_t)PT.n * a.Do + PT.z0 + 4 * zb) * a.Ho + PT.y0 + ykeep) * a.Wo + PT.x0) * a.out_pitch +
+                  ch + 32 * nb - (ch_odd ? 1 : 0);
+  };
+  auto epi_piece = [&](int k) __attribute__((always_inline)) {
+    const int mb = k / (NB * 8), nb = (k / 8) % NB, i = 2 * (k % 8);
+    const float v0 = pend[mb][nb][i], v1 = pend[mb][nb][i + 1];
+    st_rows2<T>(pbase[nb] + (int64_t)mb * a.Wo * opitch_l + eoff(ch_odd ? i + 1 : i), v0, v1, ch_odd);
+    lr1[nb] += v0 + v1;
+    lr2[nb] += v0 * v0 + v1 * v1;
+  };
+  auto pend_flush = [&]() __attribute__((always_inline)) {
+    pend_begin();
+#pragma unroll
+    for (int k = 0; k < NPAIR; k++) epi_piece(k);
+  };
+  // VM operations a phase issues behind its last DMA round: the stores of the pieces scheduled in or after that group
+  // (within a group: DMA rounds, transforms, then pieces).  vmcnt retires in order, so waiting until at most that many are
+  // outstanding means every round of T1 has landed.
+  constexpr int G_LAST_DMA = ((NJ - 1) * (NG / 2)) / NJ;
+  constexpr int N_AFTER_DMA = [] {
+    int n = 0;
+    for (int k = 0; k < KEEP * NB * 8; k++)
+      if ((k * NG) / (KEEP * NB * 8) >= G_LAST_DMA) n++;
+    return n;
+  }();
+
   // One tile.  Group g = (jz, jx, k-step): its six A fragments were read during group g - 1; in the gaps of its 12 NB
   // MFMAs the stream commits the slots of T1 scheduled for g (registers -> transform -> LDS, other buffer) and reloads
   // each freed register: first half of the phase with the second half of T1's slots, second half with T2's first half
@@ -585,14 +658,32 @@ __global__ __launch_bounds__(256) void conv_wr_kernel(ConvArgs a) {
       for (int ks = 0; ks < KSW; ks++)
 #pragma unroll
         for (int nb = 0; nb < NB; nb++) asm volatile("" : "+a"(wreg[tap][ks][nb]));
+    constexpr bool PLAINP = decltype(plain_tag)::value;
+    constexpr bool BORDERP = !decltype(fast_tag)::value;
     char* const a_rd = lds + par * ABUF;
-    const int a_wr = (1 - par) * ABUF + lbase;
+    const int a_wr = (1 - par) * ABUF;
     WR_STAMP(7)
     if (v1) load_xf(T1.n);
+    if constexpr (PLAINP) pend_begin();
+    // the tile after T1, for the next phase (uniform scalar work, here under the MFMAs instead of between two phases)
+    T2 = T1;
+    if constexpr (BORDERP)
+      bor_next(T2);
+    else
+      int_next(T2);
+    v2 = left >= 2;
+    {
+      const bool i2 = v2 && (BORDERP ? tile_interior(T2) : true);
+      base2 = src_base(T2, v2, i2), toff2 = src_toff(T2, v2, i2), rng2 = src_rng(T2, v2, i2);
+    }
     u32x4 af[2][6];
     auto read_group = [&](int g, u32x4 (&A)[6]) __attribute__((always_inline)) {
       const int t = g / KSW, ks = g % KSW, jz = t / 3, jx = t % 3;
-      const char* p = a_rd + (ga[jz][jx] ^ (ks * 32));
+      // (laundered: left visible, hipcc hoists the 9 KSW xor-ed addresses out of the tile loop into registers of their
+      // own and spills some -- and a scratch reload inside the phase is an s_waitcnt vmcnt(0), a drain of the DMA queue)
+      int g0 = ga[jz][jx];
+      asm volatile("" : "+v"(g0));
+      const char* p = a_rd + (g0 ^ (ks * 32));
 #pragma unroll
       for (int yp = 0; yp < 6; yp++) A[yp] = *reinterpret_cast<const u32x4*>(p + yp * BW * RB);
     };
@@ -601,23 +692,26 @@ __global__ __launch_bounds__(256) void conv_wr_kernel(ConvArgs a) {
     for (int g = 0; g < NG; g++) {
       if (g + 1 < NG) read_group(g + 1, af[(g + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);  // look-ahead reads stay ABOVE this group's MFMAs
+#ifndef WR_DBG_NOSTAGE  // attribution build (wrong results): no staging at all
+      // first half of the phase: the DMA rounds of T1 (other buffer), NJ of them spread over NG / 2 groups; second half
+      // (XF only): the in-place transform of each round once it has landed
 #pragma unroll
       for (int j = 0; j < NJ; j++) {
-        if ((j * NG) / (2 * R) == g) {
-#ifndef WR_DBG_NOSTAGE  // attribution builds (wrong results): -DWR_DBG_NOSTAGE no staging at all, -DWR_DBG_NOLOAD commits only
-          commit_one(fast_tag, j, m1, a_wr);
-#endif
-#if !defined(WR_DBG_NOSTAGE) && !defined(WR_DBG_NOLOAD)
-          if (j < R) {
-            if (j + R < NJ)
-              m1 |= load_one(fast_tag, j + R, base1, toff1, rng1);
-            else
-              m2 |= load_one(fast_tag, j, base2, toff2, rng2);
-          } else {
-            m2 |= load_one(fast_tag, j - R, base2, toff2, rng2);
-          }
-#endif
+        if ((j * (NG / 2)) / NJ == g) m1 |= dma_one(fast_tag, j, base1, toff1, rng1, a_wr);
+        if (XF && NG / 2 + (j * (NG - NG / 2)) / NJ == g) {
+          // younger than round j: the rounds after it and the stores of the pieces between its group and this one
+          int younger = NJ - 1 - j;
+          if (PLAINP)
+            for (int k = 0; k < NPAIR; k++)
+              if ((k * NG) / NPAIR >= (j * (NG / 2)) / NJ && (k * NG) / NPAIR < g) younger++;
+          xf_one(fast_tag, j, m1, a_wr, younger);
         }
+      }
+#endif
+      if constexpr (PLAINP) {
+#pragma unroll
+        for (int k = 0; k < NPAIR; k++)
+          if ((k * NG) / NPAIR == g) epi_piece(k);
       }
       const int t = g / KSW, ks = g % KSW, jz = t / 3, jx = t % 3;
       u32x4(&A)[6] = af[g & 1];
@@ -644,10 +738,14 @@ __global__ __launch_bounds__(256) void conv_wr_kernel(ConvArgs a) {
 #pragma unroll
       for (int k = 0; k < 12 * NB; k++) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // one MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002 | 0x220, 2, 0);  // two of: VALU, VMEM read, DS write
+        __builtin_amdgcn_sched_group_barrier(0x002 | 0x260, PLAINP ? 3 : 2, 0);  // of: VALU, VMEM, DS write
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    // T1 has landed (and, with a transform, been rewritten).  vmcnt counts stores too and retires in order: the previous
+    // tile's stores were issued before this phase's DMA rounds and are a whole phase old.
+    wr_wait_vmcnt(PLAINP ? N_AFTER_DMA : 0);
+    asm volatile("" ::: "memory");
     WR_STAMP(0)
     WS_BARRIER();  // buffer `par` fully read, the other one fully written
     WR_STAMP(1)
@@ -685,44 +783,43 @@ __global__ __launch_bounds__(256) void conv_wr_kernel(ConvArgs a) {
       WR_STAMP(5)
     }
 #endif
-#ifdef WR_DBG_NOEPI  // attribution build: one value per tile leaves (keeps the accumulators live)
-    if (acc[0][0][0] == 12345.678f) epilogue(acc, T0, plain_tag);
-#else
-    epilogue(acc, T0, plain_tag);
-#endif
+    if constexpr (PLAINP) {
+#pragma unroll
+      for (int mb = 0; mb < KEEP; mb++)
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+          for (int i = 0; i < 16; i++) pend[mb][nb][i] = acc[mb][nb][i] + bias[nb];  // (bias here: the zeros of a pass's start stay zeros)
+      PT = T0;
+    } else {
+      epilogue(acc, T0, plain_tag);
+    }
     WR_STAMP(6)
     par ^= 1;
   };
 
   bool more = true;
-  auto step = [&](auto border_tag) __attribute__((always_inline)) {
-    constexpr bool BORDER = decltype(border_tag)::value;
+  auto step = [&]() __attribute__((always_inline)) {
     more = v1;
     if (!more) return;
     left--;
     T0 = T1;
     T1 = T2;
-    base1 = base2, toff1 = toff2, rng1 = rng2;
-    m1 = m2;
-    m2 = 0;
     v1 = v2;
-    if constexpr (BORDER)
-      bor_next(T2);
-    else
-      int_next(T2);
-    v2 = left >= 2;
-    const bool i2 = v2 && (BORDER ? tile_interior(T2) : true);
-    base2 = src_base(T2, v2, i2), toff2 = src_toff(T2, v2, i2), rng2 = src_rng(T2, v2, i2);
+    base1 = base2, toff1 = toff2, rng1 = rng2;
+    m1 = 0;
   };
 
   auto run = [&](auto kq_tag) __attribute__((always_inline)) {
     if (int_cnt > 0) {
       begin_pass(No{}, int_begin, int_cnt);  // (interior tiles exist only in plain launches, and they are whole)
+      pend_clear(T0);
       more = true;
       while (more) {
         tile_phase(Yes{}, Yes{}, kq_tag);
-        step(No{});
+        step();
       }
+      pend_flush();  // the pass's last tile
     }
     if (bor_cnt > 0) {
       begin_pass(Yes{}, bor_begin, bor_cnt);
@@ -730,14 +827,16 @@ __global__ __launch_bounds__(256) void conv_wr_kernel(ConvArgs a) {
       cur_pass = 1;
       more = true;
       if (all_full) {
+        pend_clear(T0);
         while (more) {
           tile_phase(No{}, Yes{}, kq_tag);
-          step(Yes{});
+          step();
         }
+        pend_flush();
       } else {
         while (more) {
           tile_phase(No{}, No{}, kq_tag);
-          step(Yes{});
+          step();
         }
       }
     }
@@ -767,9 +866,10 @@ int launch_wr(const ConvArgs& a, hipStream_t st) {
   const int tiles = a.N * ceil_div(a.Do, TD) * ceil_div(a.Ho, 8) * ceil_div(a.Wo, 8);
   const int cout_tiles = a.CoutP / (32 * NB);
   const int gx = std::min(tiles, std::max(1, hdf_cu_budget() / cout_tiles));
-  // (launches with an input transform stay on conv_ws2_kernel this round: with the transform's registers -- eight scales,
-  // eight shifts, the unpacked chunk -- hipcc spills weight fragments whatever is pinned where; hdf_conv_wr_takes)
-  hipLaunchKernelGGL((conv_wr_kernel<T, RB, NB, KSPLIT, TD, false>), dim3(gx, cout_tiles), dim3(256), 0, st, a);
+  if (a.in_scale)
+    hipLaunchKernelGGL((conv_wr_kernel<T, RB, NB, KSPLIT, TD, true>), dim3(gx, cout_tiles), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((conv_wr_kernel<T, RB, NB, KSPLIT, TD, false>), dim3(gx, cout_tiles), dim3(256), 0, st, a);
   HDF_LAUNCH_CHECK();
   return HDF_OK;
 }
@@ -778,14 +878,20 @@ int launch_wr(const ConvArgs& a, hipStream_t st) {
 
 // Does the weights-in-registers kernel take this mode-0 launch?  (16-bit storage, 64- or 128-byte rows, a volume the old
 // weights-stationary kernel would take, a sample below 2 GiB so that 32-bit byte offsets address it.)
+// Measured against conv_ws2_kernel on one box (tools/conv_ab.sh, round 4): 64 -> 32 @128^3 without an input transform
+// 482 vs 502 us; with a transform, at 64^3 and for the 64-byte-row instantiations it is level or behind (DESIGN.md
+// section 6e), so only that class is routed here.  hdf_op_conv3d_wr runs any eligible shape through it (tests, tools).
 bool hdf_conv_wr_takes(int dtype, const ConvArgs& a) {
-  return false;  // work in progress: register-staged version, not yet ahead of conv_ws2_kernel
+  return hdf_conv_wr_can(dtype, a) && a.Cin * 2 == 128 && !a.in_scale && (int64_t)a.Do * a.Ho * a.Wo >= 96 * 96 * 96;
+}
+
+bool hdf_conv_wr_can(int dtype, const ConvArgs& a) {
   if (dtype == HDF_F32 || a.wfrag) return false;
-  if (a.in_scale) return false;  // see launch_wr
   const int rb = a.Cin * 2;
   if (rb != 64 && rb != 128) return false;
   if ((int64_t)a.Do * a.Ho * a.Wo < 48 * 48 * 48) return false;
   if ((int64_t)a.Di * a.Hi * a.Wi * a.in_pitch * 2 >= ((int64_t)1 << 31)) return false;
+  if ((int64_t)a.Hi * a.Wi * a.in_pitch * 2 >= (1 << 24)) return false;  // 24-bit multiplies by the z stride
   if (a.Di != a.Do || a.Hi != a.Ho || a.Wi != a.Wo) return false;
   return true;
 }

@@ -1709,6 +1709,22 @@ int hdf_op_conv3d_split(int dtype, const void* in, int64_t in_pitch, int Cin, in
   }
   return HDF_OK;
 }
+int hdf_op_conv3d_wr(int dtype, const void* in, int64_t in_pitch, int Cin, int N, int D, int H, int W,
+                     const void* w_packed, const float* bias, const float* in_scale, const float* in_shift, int in_relu,
+                     void* out, int64_t out_pitch, int Cout, float* stat_partials, int accumulate, hdf_stream stream) {
+  ConvArgs a{};
+  a.in = in, a.in_pitch = in_pitch, a.Cin = Cin, a.N = N;
+  a.Di = a.Do = D, a.Hi = a.Ho = H, a.Wi = a.Wo = W;
+  a.w = w_packed, a.bias = bias, a.in_scale = in_scale, a.in_shift = in_shift, a.in_relu = in_relu;
+  a.out = out, a.out_pitch = out_pitch, a.Cout = Cout, a.CoutP = round_up(Cout, 32);
+  a.stat_partials = stat_partials, a.accumulate = accumulate;
+  HDF_CHECK_ARG(a.in_pitch % 8 == 0 && (((uintptr_t)a.in) & 15) == 0, "conv_wr: input view must be 16-byte aligned");
+  if (!hdf_conv_wr_can(dtype, a)) {
+    hdf_set_error("conv3d_wr: shape not handled by the weights-in-registers kernel (dtype %d Cin %d %dx%dx%d)", dtype, Cin, D, H, W);
+    return HDF_ERR_UNSUPPORTED;
+  }
+  return hdf_launch_conv_wr(dtype, a, (hipStream_t)stream);
+}
 int hdf_op_conv3d_stat_tiles(int dtype, int Cin, int Do, int Ho, int Wo) {
   return hdf_conv_stat_tiles(0, Do, Ho, Wo, Cin * hdf_esz(dtype));
 }

@@ -55,6 +55,7 @@ _PROTOS = {
     "hdf_op_pack_weights": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i, _vp]),
     "hdf_op_conv3d": (_i, [_i, _i, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i64, _i, _vp, _i,
                            _vp]),
+    "hdf_op_conv3d_wr": (_i, [_i, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i64, _i, _vp, _i, _vp]),
     "hdf_op_conv3d_stat_tiles": (_i, [_i, _i, _i, _i, _i]),
     "hdf_op_conv3d_split": (_i, [_i, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _i, _vp]),
     "hdf_op_in_bwd_workspace_floats": (_i64, [_i, _i, _i64]),

@@ -172,6 +172,11 @@ int hdf_op_pack_weights(int dtype, const float* src, void* dst, int O, int I, in
 int hdf_op_conv3d(int dtype, int mode, const void* in, int64_t in_pitch, int Cin, int N, int Di, int Hi, int Wi,
                   const void* w_packed, const float* bias, const float* in_scale, const float* in_shift, int in_relu,
                   void* out, int64_t out_pitch, int Cout, float* stat_partials, int accumulate, hdf_stream stream);
+/* The same Conv3d(k3,s1,p1) forced through the weights-in-registers kernel (csrc/conv_wr.hip: 16-bit storage, Cin of 32
+ * or 64, >= 48^3) whatever the plan's routing rule says; HDF_ERR_UNSUPPORTED for other shapes.  Tests and tools. */
+int hdf_op_conv3d_wr(int dtype, const void* in, int64_t in_pitch, int Cin, int N, int D, int H, int W,
+                     const void* w_packed, const float* bias, const float* in_scale, const float* in_shift, int in_relu,
+                     void* out, int64_t out_pitch, int Cout, float* stat_partials, int accumulate, hdf_stream stream);
 /* partial rows per sample of stat_partials ([N*rows][Cout rounded up to 32][2] floats: sum, sum of squares) for this
  * layer shape: one row per output tile, or 512 per-workgroup rows when the weights-stationary kernel takes the layer */
 int hdf_op_conv3d_stat_tiles(int dtype, int Cin, int Do, int Ho, int Wo);

@@ -42,7 +42,22 @@ def test_conv3d_s1(dtype, cin, cout, size, n):
     assert rel_err(s[..., 1], (ref * ref).sum((2, 3, 4))) < 5e-3 + TOL[dtype]
 
 
+def _conv3d_wr(dtype, x_cl, cin, w_packed, cout, bias=None, scale=None, shift=None, relu=0, out=None, out_pitch=None,
+               accumulate=0):
+    """hdf_op_conv3d_wr: the weights-in-registers kernel whatever the plan's routing rule says."""
+    n, d, h, w = x_cl.shape[:4]
+    if out is None:
+        out = torch.zeros((n, d, h, w, cout), dtype=x_cl.dtype, device=DEV)
+        out_pitch = cout
+    tiles = lib().hdf_op_conv3d_stat_tiles(dtype, cin, d, h, w)
+    part = torch.zeros((n * tiles, rup(cout, 32), 2), dtype=torch.float32, device=DEV)
+    check(lib().hdf_op_conv3d_wr(dtype, ptr(x_cl), x_cl.shape[4], cin, n, d, h, w, ptr(w_packed), ptr(bias), ptr(scale),
+                                 ptr(shift), relu, ptr(out), out_pitch, cout, ptr(part), accumulate, st()), "conv3d_wr")
+    return out, part
+
+
 @pytest.mark.parametrize("dtype", [BF16, F16])
+@pytest.mark.parametrize("xf", [False, True])
 @pytest.mark.parametrize("cin,cout,size,n", [(32, 32, (56, 52, 50), 2),      # 8x8x8 tiles, ragged in y and x, two samples
                                             (32, 32, (64, 64, 64), 1),      # whole tiles only
                                             (64, 32, (64, 56, 48), 2),      # K split over the waves + LDS exchange
@@ -50,14 +65,20 @@ def test_conv3d_s1(dtype, cin, cout, size, n):
                                             (64, 48, (50, 49, 51), 1),      # channel count below the padded block
                                             (32, 64, (50, 49, 51), 2),      # two output blocks per wave (NB = 2)
                                             (32, 96, (48, 48, 48), 1)])
-def test_conv3d_weights_in_registers(dtype, cin, cout, size, n):
-    """conv_wr_kernel (csrc/conv_wr.hip): 16-bit storage, 64- / 128-byte rows at >= 48^3 -- every instantiation, ragged
-    extents (the checked border phase), several samples (the tile list and the statistics rows cross samples), bias,
-    InstanceNorm partial sums.  Reference: torch fp32 conv3d on the storage-rounded operands."""
+def test_conv3d_weights_in_registers(dtype, xf, cin, cout, size, n):
+    """conv_wr_kernel (csrc/conv_wr.hip) through hdf_op_conv3d_wr: 16-bit storage, 64- / 128-byte rows at >= 48^3 -- every
+    instantiation, with and without the producer's InstanceNorm + ReLU on load (the in-place LDS transform), ragged extents
+    (the checked border phase), several samples (the tile list, the deferred epilogue and the statistics rows cross
+    samples), bias, InstanceNorm partial sums.  Reference: torch fp32 conv3d on the storage-rounded operands."""
     x, w, b = _mk((n, cin) + size, 21), _mk((cout, cin, 3, 3, 3), 22) * (cin * 27) ** -0.5, _mk((cout,), 23)
-    ref = F.conv3d(rnd(x, dtype), rnd(w, dtype), b, padding=1)
+    scale, shift = _mk((n, cin), 24) * 0.5 + 1.0, _mk((n, cin), 25) * 0.3
+    xa = rnd(x, dtype)
+    if xf:
+        xa = rnd(torch.relu(xa * scale[:, :, None, None, None] + shift[:, :, None, None, None]), dtype)
+    ref = F.conv3d(xa, rnd(w, dtype), b, padding=1)
     wp = pack_w(w, dtype, cout, cin, rup(cout, 32), cin, cin * 27, 27, 0)
-    out, part = conv3d(dtype, 0, to_cl(x, dtype), cin, wp, cout, bias=b.to(DEV), stats=True)
+    sc, sh = (scale.to(DEV), shift.to(DEV)) if xf else (None, None)
+    out, part = _conv3d_wr(dtype, to_cl(x, dtype), cin, wp, cout, bias=b.to(DEV), scale=sc, shift=sh, relu=1)
     torch.cuda.synchronize()
     got = from_cl(out)
     assert rel_err(got, ref) < TOL[dtype]
@@ -67,6 +88,29 @@ def test_conv3d_weights_in_registers(dtype, cin, cout, size, n):
     s = part.view(n, tiles, -1, 2).sum(1).cpu()[:, :cout]
     assert rel_err(s[..., 0], ref.sum((2, 3, 4))) < 5e-3 + TOL[dtype]
     assert rel_err(s[..., 1], (ref * ref).sum((2, 3, 4))) < 5e-3 + TOL[dtype]
+
+
+@pytest.mark.parametrize("cin,cout,size,n", [(64, 32, (48, 48, 56), 2), (32, 32, (56, 48, 48), 1)])
+def test_conv3d_weights_in_registers_accumulate_and_pitch(cin, cout, size, n):
+    """out += conv(x) into a channel slice of a wider buffer, input a slice too: the launch is not `plain`, every tile runs
+    the checked phase with the immediate epilogue."""
+    dtype = BF16
+    x, w = _mk((n, cin) + size, 31), _mk((cout, cin, 3, 3, 3), 32) * (cin * 27) ** -0.5
+    base = _mk((n, cout) + size, 33)
+    ref = rnd(base, dtype) + F.conv3d(rnd(x, dtype), rnd(w, dtype), None, padding=1)
+    wp = pack_w(w, dtype, cout, cin, rup(cout, 32), cin, cin * 27, 27, 0)
+    xcl = to_cl(x, dtype)
+    wide_in = torch.zeros((n,) + size + (2 * cin,), dtype=xcl.dtype, device=DEV)
+    wide_in[..., cin:] = xcl
+    wide_out = torch.full((n,) + size + (3 * cout,), 7.0, dtype=xcl.dtype, device=DEV)
+    wide_out[..., cout:2 * cout] = to_cl(base, dtype)
+    vin, vout = wide_in.view(-1)[cin:], wide_out.view(-1)[cout:]
+    check(lib().hdf_op_conv3d_wr(dtype, ptr(vin), 2 * cin, cin, n, *size, ptr(wp), None, None, None, 0, ptr(vout),
+                                 3 * cout, cout, None, 1, st()), "conv3d_wr")
+    torch.cuda.synchronize()
+    assert rel_err(from_cl(wide_out[..., cout:2 * cout]), ref) < TOL[dtype] * 1.5
+    assert float((wide_out[..., :cout].float() - 7.0).abs().max()) == 0.0      # the neighbouring slices are untouched
+    assert float((wide_out[..., 2 * cout:].float() - 7.0).abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16, F16])

@@ -9,7 +9,7 @@ for shape in "64 32 128" "32 32 128" "32 64 128" "64 64 64" "32 64 64" "64 32 64
   set -- $shape
   for xf in $XFS; do
     for round in 1 2; do
-      echo -n "new: "; python tools/conv_micro.py --cin $1 --cout $2 --size $3 --reps $REPS --xf $xf 2>/dev/null | tail -1
+      echo -n "new: "; python tools/conv_micro.py --wr 1 --cin $1 --cout $2 --size $3 --reps $REPS --xf $xf 2>/dev/null | tail -1
       echo -n "old: "; HDF_LIB_PATH=$VAR python tools/conv_micro.py --cin $1 --cout $2 --size $3 --reps $REPS --xf $xf 2>/dev/null | tail -1
     done
   done

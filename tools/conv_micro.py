@@ -19,6 +19,7 @@ ap.add_argument("--n", type=int, default=2)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--xf", type=int, default=0)
 ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--wr", type=int, default=0, help="1: force conv_wr_kernel (hdf_op_conv3d_wr)")
 ap.add_argument("--cold", type=int, default=0, help="1: evict L2 / memory-side cache before every timed launch")
 a = ap.parse_args()
 dt = BF16 if a.dtype == "bf16" else F32
@@ -38,6 +39,10 @@ if a.op == "conv":
     sh = torch.randn(n, cin, device=dev) * 0.1 if a.xf else None
 
     def launch():
+        if a.wr:
+            check(lib().hdf_op_conv3d_wr(dt, ptr(x), cin, cin, n, s, s, s, ptr(w), None, ptr(sc), ptr(sh), 1, ptr(out),
+                                         cout, cout, ptr(part), 0, st), "conv_wr")
+            return
         check(lib().hdf_op_conv3d(dt, 0, ptr(x), cin, cin, n, s, s, s, ptr(w), None, ptr(sc), ptr(sh), 1, ptr(out), cout,
                                   cout, ptr(part), 0, st), "conv")
     flops = 2.0 * 27 * cin * cout * s ** 3 * n

@@ -6,7 +6,7 @@ python build.py > /dev/null
 VARS=${VARS:-"NOLOAD NOSTAGE NOSTORE NOMFMA"}
 for v in $VARS; do
   mkdir -p build/wr_$v
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-mfma-vgpr-form -DWR_DBG_$v -c csrc/conv_wr.hip -o build/wr_$v/conv_wr.o &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form -mllvm -pragma-unroll-threshold=1000000 -DWR_DBG_$v -c csrc/conv_wr.hip -o build/wr_$v/conv_wr.o &
 done
 wait
 for v in $VARS; do
