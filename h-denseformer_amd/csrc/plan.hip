@@ -195,7 +195,11 @@ struct hdf_plan {
   hipStream_t branch = nullptr;
   std::vector<hipEvent_t> events;
   size_t ev_next = 0;
+  // "gradient bucket k is final" (hdf_backward_events): recorded on whichever stream of the call finishes the bucket
+  hipEvent_t bucket_ev[3] = {nullptr, nullptr, nullptr};
   ~hdf_plan() {
+    for (hipEvent_t ev : bucket_ev)
+      if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : events) (void)hipEventDestroy(ev);
     if (side) (void)hipStreamDestroy(side);
     if (branch) (void)hipStreamDestroy(branch);
@@ -1207,7 +1211,7 @@ static int forward3d(hdf_plan* p, const float* x, const float* params, void* wor
                      hdf_stream stream);
 static int backward3d(hdf_plan* p, const float* x, const float* params, void* workspace, int64_t workspace_bytes,
                       const void* dout0, const void* dout1, const void* dout2, const void* dout3, float* grads,
-                      int batch, int stages, hdf_stream stream);
+                      int batch, int stages, hdf_stream stream, hipEvent_t* bev = nullptr);
 
 int hdf_forward(hdf_plan* p, const float* x, const float* params, void* workspace, int64_t workspace_bytes, void* out0,
                 void* out1, void* out2, void* out3, int batch, int training, uint64_t seed, hdf_stream stream) {
@@ -1352,12 +1356,49 @@ int hdf_backward(hdf_plan* p, const float* x, const float* params, void* workspa
                              stream);
 }
 
+static int backward_any(hdf_plan* p, const float* x, const float* params, void* workspace, int64_t workspace_bytes,
+                        const void* dout0, const void* dout1, const void* dout2, const void* dout3, float* grads,
+                        int batch, int stages, hdf_stream stream, hipEvent_t* bev);
+
 int hdf_backward_stages(hdf_plan* p, const float* x, const float* params, void* workspace, int64_t workspace_bytes,
                         const void* dout0, const void* dout1, const void* dout2, const void* dout3, float* grads,
                         int batch, int stages, hdf_stream stream) {
+  return backward_any(p, x, params, workspace, workspace_bytes, dout0, dout1, dout2, dout3, grads, batch, stages, stream,
+                      nullptr);
+}
+
+int hdf_backward_events(hdf_plan* p, const float* x, const float* params, void* workspace, int64_t workspace_bytes,
+                        const void* dout0, const void* dout1, const void* dout2, const void* dout3, float* grads,
+                        int batch, hdf_stream stream, void** bucket_events) {
+  HDF_CHECK_ARG(p && bucket_events, "backward_events: null argument");
+  for (int k = 0; k < 3; k++) {
+    if (!p->bucket_ev[k] && hipEventCreateWithFlags(&p->bucket_ev[k], hipEventDisableTiming) != hipSuccess) {
+      p->bucket_ev[k] = nullptr;
+      hdf_set_error("backward_events: could not create an event");
+      return HDF_ERR_HIP;
+    }
+    bucket_events[k] = (void*)p->bucket_ev[k];
+  }
+  return backward_any(p, x, params, workspace, workspace_bytes, dout0, dout1, dout2, dout3, grads, batch, 7, stream,
+                      p->bucket_ev);
+}
+
+int hdf_stream_wait_event(hdf_stream stream, void* event) {
+  HDF_CHECK_ARG(event != nullptr, "stream_wait_event: null event");
+  if (hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0) != hipSuccess) {
+    hdf_set_error("hipStreamWaitEvent failed");
+    return HDF_ERR_HIP;
+  }
+  return HDF_OK;
+}
+
+static int backward_any(hdf_plan* p, const float* x, const float* params, void* workspace, int64_t workspace_bytes,
+                        const void* dout0, const void* dout1, const void* dout2, const void* dout3, float* grads,
+                        int batch, int stages, hdf_stream stream, hipEvent_t* bev) {
   HDF_CHECK_ARG(p && x && params && workspace && grads, "backward: null argument");
   if (!p->is2d)
-    return backward3d(p, x, params, workspace, workspace_bytes, dout0, dout1, dout2, dout3, grads, batch, stages, stream);
+    return backward3d(p, x, params, workspace, workspace_bytes, dout0, dout1, dout2, dout3, grads, batch, stages, stream,
+                      bev);
   // 2-D model: the forward left the replicated input and the embedded parameters in the workspace
   HDF_CHECK_ARG(p->batch == batch && (size_t)workspace_bytes >= p->ws_bytes, "backward: batch / workspace mismatch");
   char* ws = (char*)workspace;
@@ -1373,7 +1414,15 @@ int hdf_backward_stages(hdf_plan* p, const float* x, const float* params, void* 
   float* g3 = (float*)(ws + p->e_grads3d);
   HDF_TRY(backward3d(p, (const float*)(ws + p->e_x3d), (const float*)(ws + p->e_params3d), workspace, workspace_bytes,
                      d3[0], d3[1], d3[2], d3[3], g3, batch, stages, stream));
-  return launch_extract2d(p, stages, g3, grads, st);
+  HDF_TRY(launch_extract2d(p, stages, g3, grads, st));
+  if (bev) {  // the 2-D gradients exist only after the extraction: all three buckets are final here
+    for (int k = 0; k < 3; k++)
+      if (hipEventRecord(bev[k], st) != hipSuccess) {
+        hdf_set_error("backward: could not record a bucket event");
+        return HDF_ERR_HIP;
+      }
+  }
+  return HDF_OK;
 }
 
 // ---- UpConv chain backward: at3 <- up3 <- at2 <- up2 <- at1 <- up1 <- attnout <- deep_conv <- attnall
@@ -1405,10 +1454,21 @@ static int upconv_chain_backward(Exec& e, int batch) {
   return HDF_OK;
 }
 
+// bev (optional, stages == 7): three events, recorded where the parameter gradients of bucket 1 (encoder / decoder /
+// heads), 2 (UpConv chain) and 3 (transformer branches) are final -- on the caller's stream, the side stream or the
+// branch stream, whichever finishes them -- so that a communication stream can start a bucket's all-reduce while the
+// rest of this one call is still running (no staged calls, the branch-stream fork stays).
 static int backward3d(hdf_plan* p, const float* x, const float* params, void* workspace, int64_t workspace_bytes,
                       const void* dout0, const void* dout1, const void* dout2, const void* dout3, float* grads,
-                      int batch, int stages, hdf_stream stream) {
+                      int batch, int stages, hdf_stream stream, hipEvent_t* bev) {
   HDF_CHECK_ARG(p->batch == batch, "backward: batch %d differs from the forward's %d", batch, p->batch);
+  auto record = [&](int k, hipStream_t s) -> int {
+    if (bev && hipEventRecord(bev[k], s) != hipSuccess) {
+      hdf_set_error("backward: could not record the event of gradient bucket %d", k + 1);
+      return HDF_ERR_HIP;
+    }
+    return HDF_OK;
+  };
   HDF_CHECK_ARG((size_t)workspace_bytes >= p->ws_bytes,
                 "backward: workspace of %lld bytes holds a forward only (hdf_plan_workspace_bytes = %zu)",
                 (long long)workspace_bytes, p->ws_bytes);
@@ -1514,6 +1574,16 @@ static int backward3d(hdf_plan* p, const float* x, const float* params, void* wo
           hdf_set_error("branch stream: event failed");
           return HDF_ERR_HIP;
         }
+        if (bev) {
+          // bucket 2 = the chain's conv weight gradients: launched on the side stream (every one of them is enqueued by
+          // now), the rest of the chain on the branch stream.  The side stream's later launches belong to the level-0
+          // encoder work, which the caller's stream starts behind chain_done anyway.
+          if (hipStreamWaitEvent(p->side, chain_done, 0) != hipSuccess) {
+            hdf_set_error("side stream: event failed");
+            return HDF_ERR_HIP;
+          }
+          HDF_TRY(record(1, p->side));
+        }
       }
     }
     HDF_TRY(in_backward(e, c2, dskip, p->gY[k], pre));
@@ -1524,10 +1594,17 @@ static int backward3d(hdf_plan* p, const float* x, const float* params, void* wo
     else
       HDF_TRY(conv_backward(e, c1, p->gY2[k], p->xin, none, nullptr, 0));
     // (host order: the ten level-0 launches of the caller's stream first, then the ~100 of the transformer backward)
-    if (k == 0 && forked) HDF_TRY(transformer_backward(eb, x));
+    if (k == 0 && forked) {
+      HDF_TRY(transformer_backward(eb, x));
+      if (bev) {
+        eb.join();  // (the branch's own side-stream launches, if any)
+        HDF_TRY(record(2, eb.st));
+      }
+    }
   }
 
-  if (!(stages & 6)) e.join();  // staged call (gradient buckets): final when it returns
+  if (!(stages & 6) || bev) e.join();  // staged call (gradient buckets) / bucket event: final here
+  HDF_TRY(record(0, e.st));
   }  // stage 1: every gradient of the encoder / decoder / head parameters is final here
   if (forked) {
     HDF_TRY(e.join_branch(eb));
@@ -1535,9 +1612,16 @@ static int backward3d(hdf_plan* p, const float* x, const float* params, void* wo
   } else {
     if (stages & 2) {
       HDF_TRY(upconv_chain_backward(e, batch));
-      if (!(stages & 4)) e.join();  // staged call: final when it returns; else the transformer branches run under them
+      if (!(stages & 4) || bev) e.join();  // staged call: final when it returns; else the transformer branches run under them
+      HDF_TRY(record(1, e.st));
     }  // stage 2: deep_conv / up1..3 gradients are final
-    if (stages & 4) HDF_TRY(transformer_backward(e, x));
+    if (stages & 4) {
+      HDF_TRY(transformer_backward(e, x));
+      if (bev) {
+        e.join();
+        HDF_TRY(record(2, e.st));
+      }
+    }
   }
   e.join();
   return HDF_OK;

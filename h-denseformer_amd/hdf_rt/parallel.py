@@ -28,10 +28,20 @@ def bucket_bounds(table, chain_name="deep_conv.double_conv.0.weight", unet_name=
 
 
 class GradSync:
-    """Attach to an HDenseFormer: model.grad_hook = GradSync(model).  Call .wait() before optimizer.step()."""
+    """Attach to an HDenseFormer: model.grad_hook = GradSync(model).  Call .wait() before optimizer.step().
 
-    def __init__(self, model, group=None):
+    Default protocol (GPU): the module runs its backward as ONE call (hdf_backward_events) and hands this hook three
+    events, "bucket k is final", recorded inside the call on whichever of its streams finishes the bucket; the hook's
+    communication stream waits for each event and all-reduces that bucket -- in the order the buckets become final (UpConv
+    chain, encoder/decoder/heads, transformer branches) -- while the rest of the backward is still running.
+    staged=True (and every CPU run) keeps the three staged backward calls with one hook call after each."""
+
+    # buckets in the order hdf_backward_events finishes them (index into self.buckets)
+    EVENT_ORDER = (1, 0, 2)
+
+    def __init__(self, model, group=None, staged=False):
         self.model, self.group = model, group
+        self.staged = staged or not torch.cuda.is_available()
         self.world = dist.get_world_size(group)
         self.comm = torch.cuda.Stream() if torch.cuda.is_available() else None
         self._pending = []
@@ -52,7 +62,22 @@ class GradSync:
         ready.record()
         with torch.cuda.stream(self.comm):
             self.comm.wait_event(ready)
-            flat_allreduce_mean(chunk, self.world, self.group)
+            self._reduce(chunk)
+            done = torch.cuda.Event()
+            done.record()
+        self._pending.append(done)
+
+    def _reduce(self, chunk):
+        flat_allreduce_mean(chunk, self.world, self.group)
+
+    def on_bucket_events(self, events):
+        from . import _lib
+        g = self.model.flat_grads()
+        with torch.cuda.stream(self.comm):
+            for k in self.EVENT_ORDER:
+                lo, hi = self.buckets[k]
+                _lib.check(_lib.lib().hdf_stream_wait_event(self.comm.cuda_stream, events[k]), "hdf_stream_wait_event")
+                self._reduce(g[lo:min(hi, g.numel())])
             done = torch.cuda.Event()
             done.record()
         self._pending.append(done)

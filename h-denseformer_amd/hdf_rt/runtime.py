@@ -100,6 +100,17 @@ class Runtime:
                                         ptr(douts[0]), ptr(douts[1]), ptr(douts[2]), ptr(douts[3]), ptr(flat_grads),
                                         b, stages, stream_ptr()), "hdf_backward")
 
+    def backward_events(self, x, flat_params, douts, flat_grads):
+        """The one-call backward; returns three opaque event handles: gradient bucket k (the stage-(k+1) bucket of
+        hdf_rt.parallel.bucket_bounds) is final once handle k has fired (include/hdf.h: hdf_backward_events)."""
+        import ctypes
+        b = x.shape[0]
+        evs = (ctypes.c_void_p * 3)()
+        check(lib().hdf_backward_events(self.plan.h, ptr(x), ptr(flat_params), ptr(self.ws), self.ws.numel(),
+                                        ptr(douts[0]), ptr(douts[1]), ptr(douts[2]), ptr(douts[3]), ptr(flat_grads),
+                                        b, stream_ptr(), evs), "hdf_backward_events")
+        return [evs[0], evs[1], evs[2]]
+
     def read_buffer(self, name):
         """Debug / parity helper: copy a named channels-last activation out of the workspace as NCDHW fp32
         (2-D plans: the buffers of the depth-replicated 3-D embedding)."""

@@ -358,6 +358,11 @@ class HDenseFormer(nn.Module):
             if self.grad_hook is not None:           # accumulated gradients: reduce after the add, no overlap
                 for stage in (1, 2, 3):
                     self.grad_hook(stage)
+        elif hasattr(self.grad_hook, "on_bucket_events") and not getattr(self.grad_hook, "staged", False):
+            # ONE backward call (the branch-stream fork stays, no host round trip between the stages); the library
+            # hands back one event per gradient bucket, recorded where that bucket becomes final, and the hook makes
+            # its communication stream wait for them
+            self.grad_hook.on_bucket_events(rt.backward_events(x, self._flat, douts, gflat))
         else:
             # each stage's parameter gradients are final when it returns: their all-reduce overlaps the next stage
             rt.backward(x, self._flat, douts, gflat, stages=1)      # decoder / encoder / heads

@@ -81,6 +81,20 @@ int hdf_backward_stages(hdf_plan* p, const float* x, const float* params, void* 
                         const void* dout0, const void* dout1, const void* dout2, const void* dout3, float* grads,
                         int batch, int stages, hdf_stream stream);
 
+/* hdf_backward (ONE call, with its internal side / branch streams) that also tells the caller when each of the three
+ * gradient buckets of hdf_backward_stages is final: bucket_events[k] (k = 0: encoder / decoder / heads, 1: UpConv chain,
+ * 2: transformer branches) receives an event owned by the plan -- valid until the next hdf_backward_events call on it or
+ * hdf_plan_destroy --, already recorded, on whichever internal stream finishes that bucket, when the call returns.  A
+ * communication stream that waits for event k (hdf_stream_wait_event, or hipStreamWaitEvent on the handle) may all-reduce
+ * bucket k while the rest of the backward is still running: no host round trip between the stages, the branch-stream
+ * fork of the one-call backward stays.  Order of finality in the default arrangement: bucket 1 (chain), 0, 2.
+ * Replaces nn.DataParallel's reduce (trainer.py:228-229). */
+int hdf_backward_events(hdf_plan* p, const float* x, const float* params, void* workspace, int64_t workspace_bytes,
+                        const void* dout0, const void* dout1, const void* dout2, const void* dout3, float* grads,
+                        int batch, hdf_stream stream, void** bucket_events /* [3] hipEvent_t out */);
+/* hipStreamWaitEvent(stream, event) for callers that hold streams and events as opaque handles */
+int hdf_stream_wait_event(hdf_stream stream, void* event);
+
 /* ---- loss: loss/combine_loss.py:68-79 DeepSuperloss(CEPlusDice(weight=None, ignore_index=0)) --------- */
 int64_t hdf_loss_workspace_bytes(int batch);
 int hdf_loss_forward(int dtype, const void* out0, const void* out1, const void* out2, const void* out3, int nscale,

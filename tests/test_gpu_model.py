@@ -678,6 +678,80 @@ def test_fp16_storage_flat_adam_with_gradscaler():
 
 
 @pytest.mark.gpu
+def test_gradsync_bucket_events_keep_the_one_call_backward():
+    """under GradSync the backward stays ONE call (hdf_backward_events: branch-stream fork, no host round
+    trip between the stages); the library hands back one event per gradient bucket and the communication stream waits
+    for them.  Stand-in collective as in the staged test below.  Asserted with HIP events: the three reduces run in the
+    order the buckets become final (UpConv chain, encoder/decoder/heads, transformer), the first one STARTS before the
+    backward has finished on the caller's stream (it overlaps), wait() orders the optimizer behind all of them, and the
+    gradient equals the one-shot backward's."""
+    import torch.distributed as dist
+    from hdf_rt import parallel
+    from loss.combine_loss import CEPlusDice, DeepSuperloss
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29585")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        cfg, batch = (4, 4, 32, (64, 64, 64), 8), 2
+        net, sd = _build(cfg, "bf16")
+        net.train()
+        x, onehot = _data(cfg, batch, "overlap")
+        crit = DeepSuperloss(criterion=CEPlusDice(weight=None, ignore_index=0))
+        net.set_dropout_seed(5)
+        crit(net(x.to(DEV)), onehot.to(DEV)).backward()
+        torch.cuda.synchronize()
+        g_ref = net.flat_grads().clone()
+
+        marks, sizes = [], []
+        spin = int(100e3 * 2.0)
+
+        def fake_allreduce(flat, world, group=None):
+            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s0.record()
+            torch.cuda._sleep(spin)
+            flat.mul_(1.0)
+            s1.record()
+            marks.append((s0, s1))
+            sizes.append(flat.numel())
+        orig = parallel.flat_allreduce_mean
+        parallel.flat_allreduce_mean = fake_allreduce
+        try:
+            sync = parallel.GradSync(net)
+            assert not sync.staged
+            net.grad_hook = sync
+            for p in net.parameters():
+                p.grad = None
+            net.set_dropout_seed(5)
+            t_begin = torch.cuda.Event(enable_timing=True)
+            t_begin.record()
+            loss = crit(net(x.to(DEV)), onehot.to(DEV))
+            loss.backward()
+            t_bwd_end = torch.cuda.Event(enable_timing=True)
+            t_bwd_end.record()               # caller's stream: everything of the one-call backward is behind this
+            sync.wait()
+            t_after_wait = torch.cuda.Event(enable_timing=True)
+            t_after_wait.record()
+            torch.cuda.synchronize()
+        finally:
+            parallel.flat_allreduce_mean = orig
+            net.grad_hook = None
+        ms = lambda a, b: a.elapsed_time(b)      # noqa: E731
+        assert len(marks) == 3
+        want = [sync.buckets[k][1] - sync.buckets[k][0] for k in sync.EVENT_ORDER]
+        assert [abs(a - b) < 32 for a, b in zip(sizes, want)] == [True] * 3, (sizes, want)
+        print("  backward end %.3f ms; reduce spans:" % ms(t_begin, t_bwd_end),
+              [(round(ms(t_begin, a), 3), round(ms(t_begin, b), 3)) for a, b in marks])
+        assert ms(marks[0][0], t_bwd_end) > 0.0          # the chain bucket's reduce starts while the backward still runs
+        assert ms(marks[1][0], t_bwd_end) > 0.0          # ... and so does the encoder / decoder bucket's
+        for k in range(3):
+            assert ms(marks[k][1], t_after_wait) >= 0.0
+        assert _rl2(net.flat_grads(), g_ref) < 1e-5
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
 def test_gradsync_overlaps_bucket_reduce_with_next_backward_stage():
     """bucket k's all-reduce runs on a side stream while stage k+1 back-propagates.  gloo is host
     synchronous (it cannot overlap) and RCCL needs one GPU per rank, so the collective is replaced by an asynchronous

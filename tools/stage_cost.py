@@ -41,7 +41,8 @@ def main():
     x = torch.rand(2, 4, size, size, size, generator=g).to(dev)
     lab = torch.randint(0, 4, (2, size, size, size), generator=g)
     t = torch.nn.functional.one_hot(lab, 4).permute(0, 4, 1, 2, 3).float().contiguous().to(dev)
-    sync = GradSync(net)
+    sync = GradSync(net)                      # one-call backward + bucket events (default protocol)
+    sync_staged = GradSync(net, staged=True)  # round-3 protocol: three staged backward calls
 
     def step(seed=None):
         if seed is not None:
@@ -49,8 +50,8 @@ def main():
         opt.zero_grad()
         loss = crit(net(x), t)
         loss.backward()
-        if net.grad_hook is sync:
-            sync.wait()
+        if net.grad_hook is sync or net.grad_hook is sync_staged:
+            net.grad_hook.wait()
         return loss
 
     def timed(hook):
@@ -79,7 +80,7 @@ def main():
     err = float((g_sync - g_plain).abs().max() / (g_plain.abs().max() + 1e-30))
 
     rec = {"world": dist.get_world_size(), "backend": dist.get_backend(), "size": size, "grad_rel_err": err,
-           "ms_one_call": timed(None), "ms_three_stages_noop_hook": timed(lambda stage: None), "ms_three_stages_rccl": timed(sync)}
+           "ms_one_call": timed(None), "ms_three_stages_noop_hook": timed(lambda stage: None), "ms_three_stages_rccl": timed(sync_staged), "ms_one_call_events_rccl": timed(sync)}
     print(json.dumps(rec), flush=True)
     dist.destroy_process_group()
 
