@@ -107,15 +107,16 @@ def conv_source_digest():
     """sha256 over the sources the dominant conv kernel is compiled from (what a PMC traffic profile is valid for)"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("conv_igemm.hip", "conv_igemm.h", "hdf_common.h"):
+    for f in ("conv_igemm.hip", "conv_wr.hip", "conv_tile.h", "conv_igemm.h", "hdf_common.h"):
         with open(os.path.join(ROOT, "h-denseformer_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
 
 
 def roofline_dominant_kernel(dev):
-    """Live HIP-event timing of the dominant kernel class of the step: the bf16 implicit-GEMM conv
-    (conv_ws2_kernel) on its largest layer, block_1_1_right: 64->32 channels at 128^3, batch 2.
+    """Live HIP-event timing of the dominant kernel class of the step: the bf16 implicit-GEMM conv on its largest layer,
+    block_1_1_right: 64->32 channels at 128^3, batch 2 (round 4: conv_wr_kernel, csrc/conv_wr.hip -- the launch goes
+    through hdf_op_conv3d, i.e. through the plan's own routing rule).
     Algorithmic FLOPs per launch = 2*27*Cin*Cout*voxels*batch."""
     from hdf_rt._lib import BF16, check, lib, ptr
     n, cin, cout, s = 2, 64, 32, 128
@@ -157,7 +158,7 @@ def roofline_dominant_kernel(dev):
             f"(digest {digest[:12]}); reporting null")
     return {"bound": "mfma", "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": "conv_ws2_kernel<bf16_t,32,128,false,1> (block_1_1_right fwd, 64->32 @128^3, batch 2)",
+            "kernel": "conv_wr_kernel<bf16_t,128,1,2,4,false> (block_1_1_right fwd, 64->32 @128^3, batch 2)",
             "avg_launch_ms": ms, "flops_per_launch": flops, "algorithmic_bytes_per_launch": 2.0 * n * s ** 3 * (cin + cout)}
 
 

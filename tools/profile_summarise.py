@@ -31,7 +31,7 @@ def short(n):
 
 def conv_source_digest():
     h = hashlib.sha256()
-    for f in ("conv_igemm.hip", "conv_igemm.h", "hdf_common.h"):
+    for f in ("conv_igemm.hip", "conv_wr.hip", "conv_tile.h", "conv_igemm.h", "hdf_common.h"):
         with open(os.path.join(ROOT, "h-denseformer_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
@@ -150,12 +150,12 @@ fe, wr = one("pmc_conv_FETCH_SIZE/**/*counter_collection.csv"), one("pmc_conv_WR
 if fe and wr:
     def per_launch(path, ctr):
         v = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
-             if r["Counter_Name"] == ctr and "conv_ws2_kernel" in r["Kernel_Name"]]
+             if r["Counter_Name"] == ctr and ("conv_wr_kernel" in r["Kernel_Name"] or "conv_ws2_kernel" in r["Kernel_Name"])]
         return sum(v) / len(v), len(v)
     fk, nf = per_launch(fe, "FETCH_SIZE")
     wk, nw = per_launch(wr, "WRITE_SIZE")
     rec = {
-        "kernel": "conv_ws2_kernel<bf16_t, 32, 128, false, 1> (block_1_1_right forward: 64->32 channels @128^3, batch 2)",
+        "kernel": "conv_wr_kernel<bf16_t, 128, 1, 2, 4, false> (block_1_1_right forward: 64->32 channels @128^3, batch 2)",
         "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, in a separate pass, --pmc WRITE_SIZE) --output-format "
                    "csv -- python3 tools/conv_micro.py --cin 64 --cout 32 --xf 0 --reps 2",
         "launches_averaged": [nf, nw], "FETCH_SIZE_KB_raw": fk, "WRITE_SIZE_KB": wk,
