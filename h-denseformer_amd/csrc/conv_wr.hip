@@ -578,6 +578,11 @@ __global__ __launch_bounds__(256) void conv_wr_kernel(ConvArgs a) {
   // over its NG groups.  A pass starts with pend = 0 on its own first tile: the zeros it stores there are overwritten by
   // that tile's real values one phase later (same wave, same addresses, program order) and add nothing to the sums -- so
   // the phase never branches on "is there a pending tile".  The pass ends with an immediate epilogue of the last tile.
+#ifdef WR_PLAIN_STORES
+#define WR_STORES_PER_PIECE 2
+#else
+#define WR_STORES_PER_PIECE 1
+#endif
   constexpr int NPAIR = KEEP * NB * 8;
   f32x16 pend[KEEP][NB];
   WsTile PT;
@@ -603,7 +608,13 @@ __global__ __launch_bounds__(256) void conv_wr_kernel(ConvArgs a) {
   auto epi_piece = [&](int k) __attribute__((always_inline)) {
     const int mb = k / (NB * 8), nb = (k / 8) % NB, i = 2 * (k % 8);
     const float v0 = pend[mb][nb][i], v1 = pend[mb][nb][i + 1];
+#ifdef WR_PLAIN_STORES  // A/B build: two 2-byte stores per piece instead of the paired dword store
+    T* const q0 = pbase[nb] + (ch_odd ? 1 : 0) + (int64_t)mb * a.Wo * opitch_l;
+    ST<T>::st(q0 + eoff(i), v0);
+    ST<T>::st(q0 + eoff(i + 1), v1);
+#else
     st_rows2<T>(pbase[nb] + (int64_t)mb * a.Wo * opitch_l + eoff(ch_odd ? i + 1 : i), v0, v1, ch_odd);
+#endif
     lr1[nb] += v0 + v1;
     lr2[nb] += v0 * v0 + v1 * v1;
   };
@@ -620,6 +631,9 @@ __global__ __launch_bounds__(256) void conv_wr_kernel(ConvArgs a) {
     int n = 0;
     for (int k = 0; k < KEEP * NB * 8; k++)
       if ((k * NG) / (KEEP * NB * 8) >= G_LAST_DMA) n++;
+#ifdef WR_PLAIN_STORES
+    n *= 2;
+#endif
     return n;
   }();
 
@@ -703,7 +717,7 @@ __global__ __launch_bounds__(256) void conv_wr_kernel(ConvArgs a) {
           int younger = NJ - 1 - j;
           if (PLAINP)
             for (int k = 0; k < NPAIR; k++)
-              if ((k * NG) / NPAIR >= (j * (NG / 2)) / NJ && (k * NG) / NPAIR < g) younger++;
+              if ((k * NG) / NPAIR >= (j * (NG / 2)) / NJ && (k * NG) / NPAIR < g) younger += WR_STORES_PER_PIECE;
           xf_one(fast_tag, j, m1, a_wr, younger);
         }
       }
