@@ -4,7 +4,7 @@
 # Outputs under gpurun_out/prof_<round>/ ; tools/profile_summarise.py turns them into the files kept in profiles/.
 # Counter passes are separate runs with --kernel-trace only (never combined with other trace domains).
 set -u
-ROUND=${1:-r03}
+ROUND=${1:-r04}
 TAG=${2:-}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_${ROUND}${TAG}
@@ -33,6 +33,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_step_$c -- $PY $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
 done
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_step_MFMA -- $PY $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
+# 4b. LDS traffic per matrix instruction (VERDICT r03 #1a): LDS instructions, LDS-array cycles and bank-conflict cycles per kernel
+rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_step_LDS -- $PY $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
 unset HDF_NO_ASYNC_WGRAD HDF_NO_BRANCH_OVERLAP
 # 5. clock / power under the sustained roofline kernel
 $PY $REPO/tools/clock_probe.py 64 32 > $OUT/clock_probe_64x32.txt 2>&1

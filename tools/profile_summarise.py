@@ -75,7 +75,7 @@ f1, f3 = one("bench1s/**/*_kernel_trace.csv"), one("bench/**/*_kernel_trace.csv"
 if f1 and f3:
     clean, over = per_kernel_us(step_window(f1)), per_kernel_us(step_window(f3))
     pm = {}
-    for c in ("FETCH_SIZE", "WRITE_SIZE", "MFMA"):
+    for c in ("FETCH_SIZE", "WRITE_SIZE", "MFMA", "LDS"):
         g = one(f"pmc_step_{c}/**/*counter_collection.csv")
         pm[c] = pmc_per_kernel(g) if g else {}
     steps_in_pmc = 2.0      # bench.py --steps 1 --warmup 1 (the roofline launches are taken out below)
@@ -87,8 +87,10 @@ if f1 and f3:
                  "(2 x FETCH_SIZE + WRITE_SIZE) from separate --pmc passes (gfx950 correction: FETCH_SIZE counts half of "
                  "wide reads); GB/s = MB / us_1s, vs the 8 TB/s HBM roof.\nMFMA TF = SQ_VALU_MFMA_BUSY_CYCLES x (1024 FLOP per "
                  "busy cycle for the bf16 32x32x16 kernels, 64 for the f32 MFMAs of the token / attention / patch kernels) / us_1s, "
-                 "vs 2500 (bf16) or 157 (f32) TF: executed matrix FLOPs, padding included.\n\n")
-        fh.write(f"{'kernel':60s} {'n':>4s} {'us_1s':>9s} {'us_3s':>9s} {'HBM MB':>9s} {'GB/s':>7s} {'of 8T':>6s} {'MFMA TF':>8s} {'of roof':>7s}\n")
+                 "vs 2500 (bf16) or 157 (f32) TF: executed matrix FLOPs, padding included.\nLDS/MFMA = SQ_INSTS_LDS per matrix instruction "
+                 "(SQ_VALU_MFMA_BUSY_CYCLES / 32 for the bf16 32x32x16 kernels, / 64 and / 32 for the f32 32x32x2 and 16x16x4 forms are "
+                 "not told apart: shown for the bf16 kernels only); conf = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE.\n\n")
+        fh.write(f"{'kernel':60s} {'n':>4s} {'us_1s':>9s} {'us_3s':>9s} {'HBM MB':>9s} {'GB/s':>7s} {'of 8T':>6s} {'MFMA TF':>8s} {'of roof':>7s} {'LDS/MFMA':>8s} {'conf':>5s}\n")
         t1 = t3 = 0.0
         for k, (d, n) in sorted(clean.items(), key=lambda kv: -kv[1][0]):
             def ctr(c, name):
@@ -107,8 +109,15 @@ if f1 and f3:
             o = over.get(k, [0.0, 0])[0]
             t1 += d
             t3 += o
+            li, la, lc = ctr("LDS", "SQ_INSTS_LDS"), ctr("LDS", "SQ_LDS_IDX_ACTIVE"), ctr("LDS", "SQ_LDS_BANK_CONFLICT")
+            lcalls = pm["LDS"].get(k, {}).get("SQ_INSTS_LDS", [0, 0])[0]
+            lds_per = None
+            if li and mf and lcalls and mcalls and rate == 1024.0:
+                lds_per = (li / lcalls) / ((mf / mcalls) / 32.0)
+            conf = (lc / la) if la else None
             fh.write(f"{k:60s} {n:4d} {d:9.1f} {o:9.1f} " + (f"{mb:9.1f} {gbs:7.0f} {gbs / 8000:6.2f} " if mb is not None else f"{'-':>9s} {'-':>7s} {'-':>6s} ") +
-                     (f"{tf:8.1f} {tf / roof:7.3f}" if tf is not None and tf > 0.05 else f"{'-':>8s} {'-':>7s}") + "\n")
+                     (f"{tf:8.1f} {tf / roof:7.3f} " if tf is not None and tf > 0.05 else f"{'-':>8s} {'-':>7s} ") +
+                     (f"{lds_per:8.2f} " if lds_per is not None else f"{'-':>8s} ") + (f"{conf:5.2f}" if conf is not None else f"{'-':>5s}") + "\n")
         fh.write(f"\nsum of kernel durations: {t1:.1f} us on one stream, {t3:.1f} us summed over the three streams\n")
     print("wrote", f"{pre}_step_kernel_table.txt")
 
