@@ -25,8 +25,13 @@
 // differ in their immediate offsets -- chosen so that each 16-lane group of a ds_read_b128 (ws_row_to_zx: z in {b, b+2}
 // x eight consecutive x) covers all 64 banks: 128-byte rows alternate bank halves with bx & 1, key = (bx>>1)&3 | (bz>>1)&1
 // << 2; 64-byte rows select a bank quarter with (2 by + bx) & 3, key = (bx>>2)&1 | (bz>>1)&1 << 1.
-// Everything else follows conv_ws2_kernel: persistent workgroups, interior tiles through an unchecked copy of the phase
-// then border tiles through a checked one, XCD-aware tile split, InstanceNorm partial sums per lane, raw bf16 / f16 stores.
+// Staging is LDS-DMA (global_load_lds_dwordx4, swizzle on the source side, the producer's InstanceNorm + ReLU applied in
+// place afterwards): no staging registers beside the 216 weight registers, all rounds of the next tile in flight from the
+// first groups of a phase on.  The epilogue of a whole tile is deferred into the next tile's phase (paired-row stores, one
+// piece per group).  Everything else follows conv_ws2_kernel: persistent workgroups, interior tiles through an unchecked
+// copy of the phase then border tiles through a checked one, XCD-aware tile split, InstanceNorm partial sums per lane.
+// Measurements, the attribution that led here and why the plan routes only one layer class to this kernel: DESIGN.md 6e.
+// Build flags (build.py EXTRA): -mllvm -amdgpu-mfma-vgpr-form, -mllvm -pragma-unroll-threshold=1000000, -fno-slp-vectorize.
 #include "conv_igemm.h"
 #include "conv_tile.h"
 #include <type_traits>
@@ -763,7 +768,6 @@ __global__ __launch_bounds__(256) void conv_wr_kernel(ConvArgs a) {
     WR_STAMP(0)
     WS_BARRIER();  // buffer `par` fully read, the other one fully written
     WR_STAMP(1)
-#ifndef WR_DBG_NOXCH  // attribution build: no exchange of the K halves
     if constexpr (KSPLIT == 2) {
       // sum the two K halves: a wave keeps acc[0 .. KEEP) and sends acc[KEEP .. 4) -- the M-blocks its partner (wave ^ 1)
       // keeps, in the partner's order -- through LDS, 1 KB per ds_write_b128 / ds_read_b128, lane-linear
@@ -796,7 +800,6 @@ __global__ __launch_bounds__(256) void conv_wr_kernel(ConvArgs a) {
       if constexpr (XCH_ALIAS) WS_BARRIER();  // the scratch is the next phase's staging target
       WR_STAMP(5)
     }
-#endif
     if constexpr (PLAINP) {
 #pragma unroll
       for (int mb = 0; mb < KEEP; mb++)

@@ -1,7 +1,7 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
 REPS=${1:-20}
-VARS=${VARS:-"_wr_NOLOAD _wr_NOSTAGE _wr_NOSTORE _wr_NOMFMA _nowr"}
+VARS=${VARS:-"_wr_NOSTAGE _wr_NOSTORE _wr_NOMFMA _nowr"}
 for shape in "64 32 128" "32 32 128"; do
   set -- $shape
   for round in 1 2; do

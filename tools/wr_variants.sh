@@ -3,7 +3,7 @@
 # libhdf_hip_wr_<tag>.so = the product objects with conv_wr.o rebuilt under -DWR_DBG_<tag>.  Then tools/wr_attrib.sh on the GPU box.
 cd "$(dirname "$0")/../h-denseformer_amd"
 python build.py > /dev/null
-VARS=${VARS:-"NOLOAD NOSTAGE NOSTORE NOMFMA"}
+VARS=${VARS:-"NOSTAGE NOSTORE NOMFMA STAMPS"}
 for v in $VARS; do
   mkdir -p build/wr_$v
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form -mllvm -pragma-unroll-threshold=1000000 -DWR_DBG_$v -c csrc/conv_wr.hip -o build/wr_$v/conv_wr.o &
