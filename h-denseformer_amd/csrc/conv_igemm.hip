@@ -699,9 +699,14 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
       else
         load_one(std::false_type{}, j, 0, T1, v1, i1, org1);
     }
+    // (round 4) drained once per pass: hipcc derives the N of every `s_waitcnt vmcnt(N)` in the tile loop from the
+    // predecessor with the FEWEST younger operations -- entered with these loads pending and no store behind them, the
+    // first commit of every tile waits for the acknowledgements of the previous tile's stores (see `epilogue`)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     WS_BARRIER();
   };
 
+  const bool plain = !a.accumulate && n0 + NC <= a.Cout;  // uniform: see `epilogue`
   const int ch = n0 + r;                 // channel of output block 0 (block nb: + 32 nb)
   bool ch_ok[NB];
   float bias[NB];
@@ -808,15 +813,21 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
   auto out_base = [&](const WsTile& t, int nb) -> T* {
     return outp[nb] + ((((int64_t)t.n * a.Do + t.z0) * a.Ho + t.y0 + 2 * wave) * a.Wo + t.x0) * a.out_pitch + ch + 32 * nb;
   };
-  auto epilogue = [&](f32x16 (&acc)[2 * NB], const WsTile& ET) __attribute__((always_inline)) {
+  // PLAIN (compile-time, round 4): the launch stores whole 32-channel blocks without accumulating (`plain`, uniform) and
+  // the tile is whole (every interior tile is): the epilogue is then branch-free, a FIXED number of stores.  vmcnt counts
+  // stores too and retires in order; with a conditional store path in the loop hipcc assumes that no store is younger than
+  // the loads the next tile's first commit waits for, emits vmcnt(4) and thereby waits for the write acknowledgements of
+  // this tile's 32 NB stores at every tile top (the "tile top" share of the round-3 stamps).
+  auto epilogue = [&](f32x16 (&acc)[2 * NB], const WsTile& ET, auto plain_tag) __attribute__((always_inline)) {
+    constexpr bool PLAIN = decltype(plain_tag)::value;
     const int z0 = ET.z0, y0 = ET.y0, x0 = ET.x0;
-    const bool full = z0 + TD <= a.Do && y0 + TH <= a.Ho && x0 + TW <= a.Wo;
+    const bool full = PLAIN || (z0 + TD <= a.Do && y0 + TH <= a.Ho && x0 + TW <= a.Wo);
     stats_sample(ET.n);
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) {
       float s1 = 0.f, s2 = 0.f;
       T* const obase = out_base(ET, nb);
-      if (full && ch_ok[nb] && !a.accumulate) {
+      if (PLAIN || (full && ch_ok[nb] && !a.accumulate)) {
 #pragma unroll
         for (int mb = 0; mb < 2; mb++) {
           T* const orow = obase + (int64_t)mb * a.Wo * a.out_pitch;
@@ -849,7 +860,7 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
           }
         }
       }
-      if (ch_ok[nb]) {
+      if (PLAIN || ch_ok[nb]) {
         lr1[nb] += s1;
         lr2[nb] += s2;
       }
@@ -862,7 +873,7 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
   // register sets; once the 64-byte-row layers became two-pass that served only the 16->32 first layer, where it was
   // worth 3 % of the launch and nothing in the step, at 30 more registers: removed in round 3.)
   f32x16 acc[2 * NB];  // [nb * 2 + mb]
-  auto tile_phase = [&](auto par_tag, auto fast_tag) __attribute__((always_inline)) {
+  auto tile_phase = [&](auto par_tag, auto fast_tag, auto plain_tag) __attribute__((always_inline)) {
     constexpr int PAR0 = decltype(par_tag)::value;
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
@@ -952,7 +963,7 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
       WS_BARRIER();  // buffer PAR fully read, buffer 1-PAR fully written
       WS2_STAMP(2)
     }
-    epilogue(acc, T0);
+    epilogue(acc, T0, plain_tag);
     WS2_STAMP(4)
   };
 
@@ -987,13 +998,25 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
     begin_pass(No{}, int_begin, int_cnt);
     more = true;
     int par = 0;
-    while (more) {
-      if (NCH > 1 || par == 0)
-        tile_phase(P0{}, Yes{});
-      else
-        tile_phase(P1{}, Yes{});
-      if (NCH == 1) par ^= 1;
-      step(No{});
+    // (two loops, not one loop with a branch: the two epilogues must not meet at one loop head, see `epilogue`)
+    if (plain) {
+      while (more) {
+        if (NCH > 1 || par == 0)
+          tile_phase(P0{}, Yes{}, Yes{});
+        else
+          tile_phase(P1{}, Yes{}, Yes{});
+        if (NCH == 1) par ^= 1;
+        step(No{});
+      }
+    } else {
+      while (more) {
+        if (NCH > 1 || par == 0)
+          tile_phase(P0{}, Yes{}, No{});
+        else
+          tile_phase(P1{}, Yes{}, No{});
+        if (NCH == 1) par ^= 1;
+        step(No{});
+      }
     }
   }
   // ---- pass B: border tiles (checked copy)
@@ -1005,9 +1028,9 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
     int par = 0;
     while (more) {
       if (NCH > 1 || par == 0)
-        tile_phase(P0{}, No{});
+        tile_phase(P0{}, No{}, No{});
       else
-        tile_phase(P1{}, No{});
+        tile_phase(P1{}, No{}, No{});
       if (NCH == 1) par ^= 1;
       step(Yes{});
     }
