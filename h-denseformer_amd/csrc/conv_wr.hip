@@ -588,6 +588,7 @@ __global__ __launch_bounds__(256) void conv_wr_kernel(ConvArgs a) {
 #else
 #define WR_STORES_PER_PIECE 1
 #endif
+  constexpr bool DEFER = KSPLIT == 2 && NB == 1;
   constexpr int NPAIR = KEEP * NB * 8;
   f32x16 pend[KEEP][NB];
   WsTile PT;
@@ -678,12 +679,15 @@ __global__ __launch_bounds__(256) void conv_wr_kernel(ConvArgs a) {
 #pragma unroll
         for (int nb = 0; nb < NB; nb++) asm volatile("" : "+a"(wreg[tap][ks][nb]));
     constexpr bool PLAINP = decltype(plain_tag)::value;
+    // the epilogue is deferred into the next tile's phase only where its 16 KEEP NB pending registers fit beside the phase's
+    // own (instantiation A); the 8x8x8 tile (64 accumulator + 64 pending registers) spilled and runs it immediately
+    constexpr bool DEFERP = PLAINP && DEFER;
     constexpr bool BORDERP = !decltype(fast_tag)::value;
     char* const a_rd = lds + par * ABUF;
     const int a_wr = (1 - par) * ABUF;
     WR_STAMP(7)
     if (v1) load_xf(T1.n);
-    if constexpr (PLAINP) pend_begin();
+    if constexpr (DEFERP) pend_begin();
     // the tile after T1, for the next phase (uniform scalar work, here under the MFMAs instead of between two phases)
     T2 = T1;
     if constexpr (BORDERP)
@@ -720,14 +724,14 @@ __global__ __launch_bounds__(256) void conv_wr_kernel(ConvArgs a) {
         if (XF && NG / 2 + (j * (NG - NG / 2)) / NJ == g) {
           // younger than round j: the rounds after it and the stores of the pieces between its group and this one
           int younger = NJ - 1 - j;
-          if (PLAINP)
+          if (DEFERP)
             for (int k = 0; k < NPAIR; k++)
               if ((k * NG) / NPAIR >= (j * (NG / 2)) / NJ && (k * NG) / NPAIR < g) younger += WR_STORES_PER_PIECE;
           xf_one(fast_tag, j, m1, a_wr, younger);
         }
       }
 #endif
-      if constexpr (PLAINP) {
+      if constexpr (DEFERP) {
 #pragma unroll
         for (int k = 0; k < NPAIR; k++)
           if ((k * NG) / NPAIR == g) epi_piece(k);
@@ -757,13 +761,13 @@ __global__ __launch_bounds__(256) void conv_wr_kernel(ConvArgs a) {
 #pragma unroll
       for (int k = 0; k < 12 * NB; k++) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // one MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002 | 0x260, PLAINP ? 3 : 2, 0);  // of: VALU, VMEM, DS write
+        __builtin_amdgcn_sched_group_barrier(0x002 | 0x260, DEFERP ? 3 : 2, 0);  // of: VALU, VMEM, DS write
       }
       __builtin_amdgcn_sched_barrier(0);
     }
     // T1 has landed (and, with a transform, been rewritten).  vmcnt counts stores too and retires in order: the previous
     // tile's stores were issued before this phase's DMA rounds and are a whole phase old.
-    wr_wait_vmcnt(PLAINP ? N_AFTER_DMA : 0);
+    wr_wait_vmcnt(DEFERP ? N_AFTER_DMA : 0);
     asm volatile("" ::: "memory");
     WR_STAMP(0)
     WS_BARRIER();  // buffer `par` fully read, the other one fully written
@@ -800,7 +804,7 @@ __global__ __launch_bounds__(256) void conv_wr_kernel(ConvArgs a) {
       if constexpr (XCH_ALIAS) WS_BARRIER();  // the scratch is the next phase's staging target
       WR_STAMP(5)
     }
-    if constexpr (PLAINP) {
+    if constexpr (DEFERP) {
 #pragma unroll
       for (int mb = 0; mb < KEEP; mb++)
 #pragma unroll
@@ -830,13 +834,13 @@ __global__ __launch_bounds__(256) void conv_wr_kernel(ConvArgs a) {
   auto run = [&](auto kq_tag) __attribute__((always_inline)) {
     if (int_cnt > 0) {
       begin_pass(No{}, int_begin, int_cnt);  // (interior tiles exist only in plain launches, and they are whole)
-      pend_clear(T0);
+      if constexpr (DEFER) pend_clear(T0);
       more = true;
       while (more) {
         tile_phase(Yes{}, Yes{}, kq_tag);
         step();
       }
-      pend_flush();  // the pass's last tile
+      if constexpr (DEFER) pend_flush();  // the pass's last tile
     }
     if (bor_cnt > 0) {
       begin_pass(Yes{}, bor_begin, bor_cnt);
@@ -844,12 +848,12 @@ __global__ __launch_bounds__(256) void conv_wr_kernel(ConvArgs a) {
       cur_pass = 1;
       more = true;
       if (all_full) {
-        pend_clear(T0);
+        if constexpr (DEFER) pend_clear(T0);
         while (more) {
           tile_phase(No{}, Yes{}, kq_tag);
           step();
         }
-        pend_flush();
+        if constexpr (DEFER) pend_flush();
       } else {
         while (more) {
           tile_phase(No{}, No{}, kq_tag);
@@ -899,7 +903,11 @@ int launch_wr(const ConvArgs& a, hipStream_t st) {
 // 482 vs 502 us; with a transform, at 64^3 and for the 64-byte-row instantiations it is level or behind (DESIGN.md
 // section 6e), so only that class is routed here.  hdf_op_conv3d_wr runs any eligible shape through it (tests, tools).
 bool hdf_conv_wr_takes(int dtype, const ConvArgs& a) {
-  return hdf_conv_wr_can(dtype, a) && a.Cin * 2 == 128 && !a.in_scale && (int64_t)a.Do * a.Ho * a.Wo >= 96 * 96 * 96;
+  if (!hdf_conv_wr_can(dtype, a) || (int64_t)a.Do * a.Ho * a.Wo < 96 * 96 * 96) return false;
+#ifdef HDF_WR_ROUTE_B  // A/B builds: the 32 -> 32 layers too (with and without a transform)
+  if (a.Cin * 2 == 64 && a.CoutP == 32) return true;
+#endif
+  return a.Cin * 2 == 128 && !a.in_scale;
 }
 
 bool hdf_conv_wr_can(int dtype, const ConvArgs& a) {

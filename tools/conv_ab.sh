@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 REPS=${1:-20}
 XFS=${2:-0}
 VAR=${VAR:-h-denseformer_amd/lib/libhdf_hip_nowr.so}
-for shape in "64 32 128" "32 32 128" "32 64 128" "64 64 64" "32 64 64" "64 32 64"; do
+for shape in ${SHAPES:-"64 32 128" "32 32 128" "32 64 128" "64 64 64" "32 64 64" "64 32 64"}; do
   set -- $shape
   for xf in $XFS; do
     for round in 1 2; do
