@@ -16,7 +16,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # of a wave (left to its heuristic hipcc puts the accumulators there and spills weights to scratch); its tile phase is one
 # fully unrolled block of 216 MFMAs + staging, above the default size limit of `#pragma unroll` with an input transform
 # (and no SLP vectorisation there: packed f32 adds beside MFMAs cost more than the scalar pair they replace)
-EXTRA = {"conv_wr.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form", "-mllvm", "-pragma-unroll-threshold=1000000"]}
+EXTRA = {"conv_wr.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form", "-mllvm", "-pragma-unroll-threshold=1000000"],
+         # attention: the score MFMA results feed v_exp_f32 directly (VALU sources cannot be AGPRs)
+         "transformer.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _digest():

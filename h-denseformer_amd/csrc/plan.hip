@@ -668,6 +668,18 @@ struct Exec {
     readers[buf.off] = d;
     return HDF_OK;
   }
+  // the same for a side-stream launch whose operands are never overwritten inside this call: only join() waits for it
+  int side_done() {
+    if (!async) return HDF_OK;
+    hipEvent_t d = next_event();
+    if (!d || hipEventRecord(d, p->side) != hipSuccess) {
+      (void)hipStreamSynchronize(p->side);
+      hdf_set_error("backward: could not record the side stream's completion event");
+      return HDF_ERR_HIP;
+    }
+    last_side = d;
+    return HDF_OK;
+  }
   void wait_readers(const View& buf) {
     auto it = readers.find(buf.off);
     if (it != readers.end()) {
@@ -893,6 +905,38 @@ int transformer_backward(Exec& e, const float* x) {
   float* dO = scratch;
   float* dh0acc = scratch + rows * 32;
   float* dqkv = scratch + rows * 64;
+  // Every weight-matrix gradient of the branches comes from the tapes the token kernels leave behind (fixed-order
+  // reductions, no atomics): one launch per block, issued on the side stream as soon as that block's last tape segment
+  // is written (the token kernel that also starts the next block down), so that only block 0's -- next to the patch
+  // embedding's -- is left at the end of the chain.  (One launch for all blocks after the chain: 114 us with nothing
+  // else left to run beside it.)
+  TfWgradArgs w{};
+  {
+    const int64_t blk0 = p->P("attns.0.blocks.0.0.layers.0.0.weight");
+    const int64_t blk_stride = p->nb > 1 ? p->P("attns.0.blocks.1.0.layers.0.0.weight") - blk0 : 0;
+    int k = 0;
+    auto rel = [&](const std::string& n) { return p->P("attns.0.blocks.0.0." + n) - blk0; };
+    for (int l = 0; l < 4; l++) {
+      const std::string pre = "layers." + std::to_string(l);
+      w.e[k++] = TfWgradEntry{rel(pre + ".1.fn.to_qkv.weight"), 96, 32, l, 0, 0, TF_T_DQ, TF_T_T, -1, -1, 96, 32};
+      w.e[k++] = TfWgradEntry{rel(pre + ".0.weight"), 32, p->DM + 32 * l, l, 0, 1, TF_T_DH0, 0, -1, -1, 32, p->DMF};
+      w.e[k++] = TfWgradEntry{rel(pre + ".2.fn.net.3.weight"), 32, 64, l, 0, 0, TF_T_P1, TF_T_P1 + 32, TF_T_P0, TF_T_P0 + 32,
+                              32, 64};
+      w.e[k++] = TfWgradEntry{rel(pre + ".2.fn.net.0.weight"), 64, 32, l, 0, 0, TF_T_P1 + 96, TF_T_P1 + 160, TF_T_P0 + 96,
+                              TF_T_P0 + 160, 64, 32};
+      w.e[k++] = TfWgradEntry{rel(pre + ".1.fn.to_out.0.weight"), 32, 32, l, 0, 2, TF_T_DGO, 0, -1, -1, 32, 32};
+    }
+    w.e[k++] = TfWgradEntry{rel("out_layer.net.3.weight"), p->DM, 64, 0, 3, 3, 0, p->DM, -1, -1, p->DM, 64};
+    w.e[k++] = TfWgradEntry{rel("out_layer.net.0.weight"), 64, p->DMF, 0, 3, 1, p->DM + 64, 0, -1, -1, 64, p->DMF};
+    w.grads = e.grads, w.mstride = p->mstride, w.block0 = blk0, w.block_stride = blk_stride;
+    w.tape = e.f(p->tf_tape), w.otape = e.f(p->tf_otape), w.F = F0, w.save = e.f(p->tf_save);
+    w.rows = rows, w.BN = e.B * p->Ntok, w.DMF = p->DMF, w.b0 = 0;
+  }
+  auto wgrad_block = [&](int b) -> int {
+    w.b0 = b;
+    HDF_TRY(tf_wgrad(w, 1, p->M, e.wgrad_stream()));
+    return e.side_done();
+  };
   TfLayerP up{}, gup{}, cur{}, gcur{};
   TfOutP o{}, go{};
   bool have_up = false;
@@ -922,8 +966,13 @@ int transformer_backward(Exec& e, const float* x) {
       if (tape) t.tape_post = tape + (int64_t)(b * 4 + l) * rows * TF_TAPE_W;
       t.dO = dO, t.dh0acc_out = dh0acc;
       HDF_TRY(tf_token_bwd(d, t, p->dtype, e.st));
+      if (have_up && l == 3) HDF_TRY(wgrad_block(ub));  // block b + 1 is complete
       TfLayerSave s = tf_save(p, e, b, l);
-      HDF_TRY(tf_attention_bwd(d.N, d.M * d.B, s.qkv, s.ob, s.lse, dO, dqkv, e.st));
+#ifdef HDF_ATTN_FP32  // A/B builds: the exact-fp32 attention backward in every storage mode
+      HDF_TRY(tf_attention_bwd(d.N, d.M * d.B, s.qkv, s.ob, s.lse, dO, dqkv, e.st, 0));
+#else
+      HDF_TRY(tf_attention_bwd(d.N, d.M * d.B, s.qkv, s.ob, s.lse, dO, dqkv, e.st, p->dtype));
+#endif
       up = cur, gup = gcur, ub = b, ul = l, have_up = true;
     }
   }
@@ -932,30 +981,7 @@ int transformer_backward(Exec& e, const float* x) {
   t.dqkv = dqkv, t.dh0acc = dh0acc;
   t.tape_pre = e.f(p->tf_tape);
   HDF_TRY(tf_token_bwd(d, t, p->dtype, e.st));
-  {
-    // every weight-matrix gradient of the branches: one launch over the tapes (fixed-order reductions, no atomics)
-    TfWgradArgs w{};
-    const int64_t blk0 = p->P("attns.0.blocks.0.0.layers.0.0.weight");
-    const int64_t blk_stride = p->nb > 1 ? p->P("attns.0.blocks.1.0.layers.0.0.weight") - blk0 : 0;
-    int k = 0;
-    auto rel = [&](const std::string& n) { return p->P("attns.0.blocks.0.0." + n) - blk0; };
-    for (int l = 0; l < 4; l++) {
-      const std::string pre = "layers." + std::to_string(l);
-      w.e[k++] = TfWgradEntry{rel(pre + ".1.fn.to_qkv.weight"), 96, 32, l, 0, 0, TF_T_DQ, TF_T_T, -1, -1, 96, 32};
-      w.e[k++] = TfWgradEntry{rel(pre + ".0.weight"), 32, p->DM + 32 * l, l, 0, 1, TF_T_DH0, 0, -1, -1, 32, p->DMF};
-      w.e[k++] = TfWgradEntry{rel(pre + ".2.fn.net.3.weight"), 32, 64, l, 0, 0, TF_T_P1, TF_T_P1 + 32, TF_T_P0, TF_T_P0 + 32,
-                              32, 64};
-      w.e[k++] = TfWgradEntry{rel(pre + ".2.fn.net.0.weight"), 64, 32, l, 0, 0, TF_T_P1 + 96, TF_T_P1 + 160, TF_T_P0 + 96,
-                              TF_T_P0 + 160, 64, 32};
-      w.e[k++] = TfWgradEntry{rel(pre + ".1.fn.to_out.0.weight"), 32, 32, l, 0, 2, TF_T_DGO, 0, -1, -1, 32, 32};
-    }
-    w.e[k++] = TfWgradEntry{rel("out_layer.net.3.weight"), p->DM, 64, 0, 3, 3, 0, p->DM, -1, -1, p->DM, 64};
-    w.e[k++] = TfWgradEntry{rel("out_layer.net.0.weight"), 64, p->DMF, 0, 3, 1, p->DM + 64, 0, -1, -1, 64, p->DMF};
-    w.grads = e.grads, w.mstride = p->mstride, w.block0 = blk0, w.block_stride = blk_stride;
-    w.tape = e.f(p->tf_tape), w.otape = e.f(p->tf_otape), w.F = F0, w.save = e.f(p->tf_save);
-    w.rows = rows, w.BN = e.B * p->Ntok, w.DMF = p->DMF, w.b0 = 0;
-    HDF_TRY(tf_wgrad(w, p->nb, p->M, e.st));
-  }
+  HDF_TRY(wgrad_block(0));
   HDF_TRY(tf_patch_embed_bwd(d, x, p->D, p->H, p->W, dF, e.grads + p->P("attns.0.patch_embeddings.weight"),
                              e.grads + p->P("attns.0.patch_embeddings.bias"),
                              e.grads + p->P("attns.0.position_embeddings"), scratch, e.st));
@@ -1937,6 +1963,12 @@ int hdf_op_attention_bwd(const float* qkv, const float* ob, const float* lse, co
                          int N, hdf_stream stream) {
   HDF_CHECK_ARG(qkv && ob && lse && d_ob && dqkv && nseq >= 1, "attention_bwd: null argument");
   return tf_attention_bwd(N, nseq, qkv, ob, lse, d_ob, dqkv, (hipStream_t)stream);
+}
+int hdf_op_attention_amp_bwd(int dtype, const float* qkv, const float* ob, const float* lse, const float* d_ob,
+                             float* dqkv, int nseq, int N, hdf_stream stream) {
+  HDF_CHECK_ARG(qkv && ob && lse && d_ob && dqkv && nseq >= 1, "attention_amp_bwd: null argument");
+  HDF_CHECK_ARG(dtype == HDF_F32 || dtype == HDF_BF16 || dtype == HDF_F16, "attention_amp_bwd: dtype %d", dtype);
+  return tf_attention_bwd(N, nseq, qkv, ob, lse, d_ob, dqkv, (hipStream_t)stream, dtype);
 }
 int hdf_op_patch_embed_fwd(const float* x, int M, int B, int D, int H, int W, int DM, const float* weight,
                            const float* bias, const float* pos, int64_t mstride, float* F, int training, uint64_t seed,

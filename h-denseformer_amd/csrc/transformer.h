@@ -46,8 +46,10 @@ int tf_patch_embed_bwd(const TfDims& d, const float* x, int D, int H, int W, con
 // merged, before to_out), lse [nseq*N][8] (natural-log row log-sum-exp of the 0.5-scaled scores)
 int tf_attention_fwd(int N, int nseq, const float* qkv, float* ob, float* lse, hipStream_t st);
 // dO [nseq*N][32] -> dqkv [nseq*N][96]
+// lp: 0 = everything fp32 (fp32 storage); HDF_BF16 / HDF_F16 = the accumulations dS.k, dS^T.q, attn^T.dO with 16-bit operands
+// on the matrix core (the plan's 16-bit storage modes: what torch autocast does to the matmuls of Dense_Attention)
 int tf_attention_bwd(int N, int nseq, const float* qkv, const float* ob, const float* lse, const float* dO, float* dqkv,
-                     hipStream_t st);
+                     hipStream_t st, int lp = 0);
 
 int tf_layer_fwd(const TfDims& d, int block, int layer, const TfLayerP& p, float* F, const TfLayerSave& s,
                  hipStream_t st);

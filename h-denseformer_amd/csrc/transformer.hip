@@ -75,9 +75,15 @@ __device__ __forceinline__ f32x4 attn_scores(const float* sKf, int j0, float bq)
   f32x4 z = {0.f, 0.f, 0.f, 0.f};
   return __builtin_amdgcn_mfma_f32_16x16x4f32(sKf[(j0 + (lane & 15)) * 4 + (lane >> 4)], bq, z, 0, 0, 0);
 }
+// the same with a C operand: row r of the lane's column starts at c[r] (a subtraction folded into the matrix op)
+__device__ __forceinline__ f32x4 attn_scores(const float* sKf, int j0, float bq, const f32x4& c) {
+  const int lane = threadIdx.x & 63;
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(sKf[(j0 + (lane & 15)) * 4 + (lane >> 4)], bq, c, 0, 0, 0);
+}
 
 __global__ __launch_bounds__(256) void attn_fwd_kernel(int N, const float* __restrict__ qkv, float* __restrict__ ob,
                                                        float* __restrict__ lse) {
+  HDF_CHAIN_PRIO();
   extern __shared__ float4 skv[];
   const int NP = attn_rows(N);
   float4* sK = skv;
@@ -85,13 +91,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(int N, const float* __res
   const float* sKf = reinterpret_cast<const float*>(sK);
   const int head = blockIdx.y;
   const int64_t rowbase = (int64_t)blockIdx.z * N;
-  attn_stage_kv(N, NP, qkv, rowbase, head, sK, sV);
-  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
   const int qi = blockIdx.x * AQ + 16 * wave + (lane & 15);
   const bool ok = qi < N;
   // B operand of every score MFMA: this lane's query, component g, pre-scaled (dim_head^-0.5 = 0.5; log2 units)
+  // (requested before the staging loads: one global round trip less on this launch's critical path)
   const float bq = qkv[(rowbase + (ok ? qi : 0)) * 96 + head * 4 + g] * (0.5f * LOG2E);
+  attn_stage_kv(N, NP, qkv, rowbase, head, sK, sV);
+  __syncthreads();
   float mx = -INFINITY, l = 0.f;
   f2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
   auto trip = [&](int j0, const f32x4& sc4, auto masked) __attribute__((always_inline)) {
@@ -157,6 +164,36 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(int N, const float* __res
   }
 }
 
+// ---- 16-bit storage modes: the three accumulations of the BACKWARD (dS.K, dS^T.Q, P^T.dO) on the matrix core.
+// Under torch autocast the reference runs the matmuls of Dense_Attention with 16-bit operands and fp32 accumulation
+// (trainer.py:369, HDenseFormer.py:70-73); the scores and the softmax stay on the exact-fp32 path here.  The dS / P values a
+// lane holds after the exponentials -- 4 consecutive keys (queries) of the block for its query (key) -- are exactly the A
+// operand of v_mfma_f32_16x16x16 (row = lane & 15, k = 4 (lane >> 4) + e), so they are packed to bf16 / f16 in place and
+// ONE matrix instruction per 16 x 16 block replaces the lane's eight packed FMAs; the B operand comes from a TRANSPOSED
+// 16-bit copy in LDS ([component][row]: 8 contiguous bytes per lane; lanes whose column is >= 4 read a row of zeros).
+// The forward keeps the exact kernel in every mode: the same construction for P.V needs the row maximum before the first
+// accumulation (the result tile has the query on the register index, which a running maximum cannot rescale), i.e. a
+// second pass over the keys, and measured no faster (11.9 us against 11.5: the launch is bound by its prologue, not its
+// 32-trip loop) -- so the forward output is exact and only the gradient sees the 16-bit operands.
+template <int LP>
+struct LpPack;
+template <>
+struct LpPack<1> {  // bf16
+  static __device__ __forceinline__ uint16_t one(float v) { return f2bf(v); }
+  static __device__ __forceinline__ u32x2 four(float a, float b, float c, float d) { return u32x2{pack_bf2(a, b), pack_bf2(c, d)}; }
+  static __device__ __forceinline__ f32x4 mma(const u32x2& a, const u32x2& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+  }
+};
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+template <>
+struct LpPack<2> {  // f16
+  static __device__ __forceinline__ uint16_t one(float v) { return f2h(v); }
+  static __device__ __forceinline__ u32x2 four(float a, float b, float c, float d) { return u32x2{pack_h2(a, b), pack_h2(c, d)}; }
+  static __device__ __forceinline__ f32x4 mma(const u32x2& a, const u32x2& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a), __builtin_bit_cast(f16x4, b), c, 0, 0, 0);
+  }
+};
 // dQ: same decomposition as forward; the two 16 x 16 x 4 products per block (scores K.Q and T = V.dO) on the matrix core
 __device__ __forceinline__ void attn_bwd_dq_body(int N, int seq, const float* __restrict__ qkv,
                                                  const float* __restrict__ ob, const float* __restrict__ lse,
@@ -168,18 +205,18 @@ __device__ __forceinline__ void attn_bwd_dq_body(int N, int seq, const float* __
   const float* sVf = reinterpret_cast<const float*>(sV);
   const int head = blockIdx.y;
   const int64_t rowbase = (int64_t)seq * N;
-  attn_stage_kv(N, NP, qkv, rowbase, head, sK, sV);
-  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
   const int qi = blockIdx.x * AQ + 16 * wave + (lane & 15);
   const bool ok = qi < N;
   const int64_t R = rowbase + (ok ? qi : 0);
   const float4 go = *reinterpret_cast<const float4*>(dO + R * 32 + head * 4);
   const float4 oo = *reinterpret_cast<const float4*>(ob + R * 32 + head * 4);
-  const float delta = go.x * oo.x + go.y * oo.y + go.z * oo.z + go.w * oo.w;
   const float ls = lse[R * 8 + head] * LOG2E;
   const float bq = qkv[R * 96 + head * 4 + g] * (0.5f * LOG2E);   // B operands: query / dO component g of this lane's row
   const float bg = dO[R * 32 + head * 4 + g];
+  attn_stage_kv(N, NP, qkv, rowbase, head, sK, sV);
+  __syncthreads();
+  const float delta = go.x * oo.x + go.y * oo.y + go.z * oo.z + go.w * oo.w;
   f2 d01 = {0.f, 0.f}, d23 = {0.f, 0.f};
   auto trip = [&](int j0, const f32x4& s4, const f32x4& t4, auto masked) __attribute__((always_inline)) {
     float4 k[AU];
@@ -307,11 +344,200 @@ __device__ __forceinline__ void attn_bwd_dkv_body(int N, int seq, const float* _
 __global__ __launch_bounds__(256) void attn_bwd_kernel(int N, int nseq, const float* __restrict__ qkv,
                                                        const float* __restrict__ ob, const float* __restrict__ lse,
                                                        const float* __restrict__ dO, float* __restrict__ dqkv) {
+  HDF_CHAIN_PRIO();
   extern __shared__ float4 skv[];
   if ((int)blockIdx.z < nseq)
     attn_bwd_dq_body(N, blockIdx.z, qkv, ob, lse, dO, dqkv, skv);
   else
     attn_bwd_dkv_body(N, blockIdx.z - nseq, qkv, ob, lse, dO, dqkv, skv);
+}
+
+// ---- backward, 16-bit storage modes: the three accumulations on v_mfma_f32_16x16x16 (see attn_fwd_lp_kernel).
+// dQ: A = dS of (query lane & 15, keys 4g + e), B = K^T 16-bit -> lane (c, g) holds dQ[query 4g + r][c].
+// dK / dV: the lane's dS / P values are (key lane & 15, queries 4g + e), i.e. the A operand of dS^T.Q and P^T.dO as they
+// stand; B = Q^T / dO^T 16-bit.  The exact version read 160 B of LDS per lane and trip in the dK/dV half (fp32 q, dO rows
+// for the packed FMAs); this one reads 48.
+__host__ __device__ inline size_t attn_bwd_lp_lds(int N) { return (size_t)attn_rows(N) * (16 + 16 + 8 + 10 + 10); }
+
+template <int LP>
+__device__ __forceinline__ void attn_bwd_dq_lp_body(int N, int seq, const float* __restrict__ qkv,
+                                                    const float* __restrict__ ob, const float* __restrict__ lse,
+                                                    const float* __restrict__ dO, float* __restrict__ dqkv, float4* skv) {
+  const int NP = attn_rows(N);
+  float4* sK = skv;
+  float4* sV = skv + NP;
+  uint16_t* sKt = reinterpret_cast<uint16_t*>(skv + 2 * NP);  // [5][NP]
+  const float* sKf = reinterpret_cast<const float*>(sK);
+  const float* sVf = reinterpret_cast<const float*>(sV);
+  const int head = blockIdx.y;
+  const int64_t rowbase = (int64_t)seq * N;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+  const int qi = blockIdx.x * AQ + 16 * wave + c;
+  const bool ok = qi < N;
+  const int64_t R = rowbase + (ok ? qi : 0);
+  const float4 go = *reinterpret_cast<const float4*>(dO + R * 32 + head * 4);
+  const float4 oo = *reinterpret_cast<const float4*>(ob + R * 32 + head * 4);
+  const float ls = lse[R * 8 + head] * LOG2E;
+  const float bq = qkv[R * 96 + head * 4 + g] * (0.5f * LOG2E);
+  const float bg = dO[R * 32 + head * 4 + g];
+  for (int base = threadIdx.x; base < NP; base += 256 * 4) {
+    float4 k[4], v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const float* r = qkv + (rowbase + min(base + 256 * u, N - 1)) * 96 + head * 4;
+      k[u] = *reinterpret_cast<const float4*>(r + 32);
+      v[u] = *reinterpret_cast<const float4*>(r + 64);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = base + 256 * u;
+      if (i < NP) {
+        const float z = i < N ? 1.f : 0.f;
+        const float4 kk = make_float4(k[u].x * z, k[u].y * z, k[u].z * z, k[u].w * z);
+        sK[i] = kk;
+        sV[i] = make_float4(v[u].x * z, v[u].y * z, v[u].z * z, v[u].w * z);
+        sKt[0 * NP + i] = LpPack<LP>::one(kk.x), sKt[1 * NP + i] = LpPack<LP>::one(kk.y);
+        sKt[2 * NP + i] = LpPack<LP>::one(kk.z), sKt[3 * NP + i] = LpPack<LP>::one(kk.w);
+        sKt[4 * NP + i] = 0;
+      }
+    }
+  }
+  __syncthreads();
+  const float delta = go.x * oo.x + go.y * oo.y + go.z * oo.z + go.w * oo.w;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const uint16_t* krow = sKt + (size_t)min(c, 4) * NP + 4 * g;
+  const int nfull = N / ATRIP * ATRIP;
+  // C operands: the scores come out as (score - lse), T as (dO.v - delta)
+  const f32x4 nl = {-ls, -ls, -ls, -ls}, nd = {-delta, -delta, -delta, -delta};
+  f32x4 cs = attn_scores(sKf, 0, bq, nl), ct = attn_scores(sVf, 0, bg, nd);
+  int j0 = 0;
+#pragma unroll 2
+  for (; j0 < nfull; j0 += ATRIP) {
+    const int jn = min(j0 + ATRIP, NP - ATRIP);
+    const f32x4 ns = attn_scores(sKf, jn, bq, nl), nt = attn_scores(sVf, jn, bg, nd);
+    const u32x2 kb = *reinterpret_cast<const u32x2*>(krow + j0);
+    __builtin_amdgcn_sched_barrier(0);
+    float ds[AU];
+#pragma unroll
+    for (int u = 0; u < AU; u++) ds[u] = __builtin_amdgcn_exp2f(cs[u]) * ct[u];
+    acc = LpPack<LP>::mma(LpPack<LP>::four(ds[0], ds[1], ds[2], ds[3]), kb, acc);
+    cs = ns, ct = nt;
+  }
+  if (j0 < NP) {
+    const u32x2 kb = *reinterpret_cast<const u32x2*>(krow + j0);
+    float ds[AU];
+#pragma unroll
+    for (int u = 0; u < AU; u++) ds[u] = (j0 + 4 * g + u < N) ? __builtin_amdgcn_exp2f(cs[u]) * ct[u] : 0.f;
+    acc = LpPack<LP>::mma(LpPack<LP>::four(ds[0], ds[1], ds[2], ds[3]), kb, acc);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int q2 = blockIdx.x * AQ + 16 * wave + 4 * g + r;
+    if (c < 4 && q2 < N) dqkv[(rowbase + q2) * 96 + head * 4 + c] = 0.5f * acc[r];
+  }
+}
+
+struct LsePair {
+  f32x4 first, second;
+};
+template <int LP>
+__device__ __forceinline__ void attn_bwd_dkv_lp_body(int N, int seq, const float* __restrict__ qkv,
+                                                     const float* __restrict__ ob, const float* __restrict__ lse,
+                                                     const float* __restrict__ dO, float* __restrict__ dqkv,
+                                                     float4* skv) {
+  const int NP = attn_rows(N);
+  float4* sQ = skv;        // pre-scaled by 0.5 log2(e): score operand
+  float4* sG = skv + NP;   // dO: operand of T = dO.V
+  float* sLse = reinterpret_cast<float*>(skv + 2 * NP);  // -lse log2(e); padded rows: -inf
+  float* sDel = sLse + NP;                                // -delta
+  uint16_t* sQt = reinterpret_cast<uint16_t*>(sDel + NP);  // [5][NP], unscaled q
+  uint16_t* sGt = sQt + 5 * NP;                           // [5][NP]
+  const float* sQf = reinterpret_cast<const float*>(sQ);
+  const float* sGf = reinterpret_cast<const float*>(sG);
+  const int head = blockIdx.y;
+  const int64_t rowbase = (int64_t)seq * N;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+  const int kj = blockIdx.x * AQ + 16 * wave + c;
+  const bool ok = kj < N;
+  const int64_t R = rowbase + (ok ? kj : 0);
+  const float bk = qkv[R * 96 + 32 + head * 4 + g], bv = qkv[R * 96 + 64 + head * 4 + g];
+  for (int base = threadIdx.x; base < NP; base += 256 * 4) {
+    float4 q[4], go[4], oo[4];
+    float lv[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int64_t r = rowbase + min(base + 256 * u, N - 1);
+      q[u] = *reinterpret_cast<const float4*>(qkv + r * 96 + head * 4);
+      go[u] = *reinterpret_cast<const float4*>(dO + r * 32 + head * 4);
+      oo[u] = *reinterpret_cast<const float4*>(ob + r * 32 + head * 4);
+      lv[u] = lse[r * 8 + head];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = base + 256 * u;
+      if (i < NP) {
+        const bool real = i < N;
+        const float sc = real ? 0.5f * LOG2E : 0.f;
+        const float z = real ? 1.f : 0.f;
+        sQ[i] = make_float4(q[u].x * sc, q[u].y * sc, q[u].z * sc, q[u].w * sc);
+        sG[i] = make_float4(go[u].x * z, go[u].y * z, go[u].z * z, go[u].w * z);
+        sLse[i] = real ? -lv[u] * LOG2E : -INFINITY;
+        sDel[i] = -z * (go[u].x * oo[u].x + go[u].y * oo[u].y + go[u].z * oo[u].z + go[u].w * oo[u].w);
+        sQt[0 * NP + i] = LpPack<LP>::one(q[u].x * z), sQt[1 * NP + i] = LpPack<LP>::one(q[u].y * z);
+        sQt[2 * NP + i] = LpPack<LP>::one(q[u].z * z), sQt[3 * NP + i] = LpPack<LP>::one(q[u].w * z);
+        sQt[4 * NP + i] = 0;
+        sGt[0 * NP + i] = LpPack<LP>::one(go[u].x * z), sGt[1 * NP + i] = LpPack<LP>::one(go[u].y * z);
+        sGt[2 * NP + i] = LpPack<LP>::one(go[u].z * z), sGt[3 * NP + i] = LpPack<LP>::one(go[u].w * z);
+        sGt[4 * NP + i] = 0;
+      }
+    }
+  }
+  __syncthreads();
+  f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+  const uint16_t* qrow = sQt + (size_t)min(c, 4) * NP + 4 * g;
+  const uint16_t* grow = sGt + (size_t)min(c, 4) * NP + 4 * g;
+  // the (-lse, -delta) of the block's queries are the C operands of the two score products (row r = query 4g + r):
+  // scores arrive as (score - lse), T as (dO.v - delta); both are fetched one block ahead of the MFMA that takes them
+  auto lrow = [&](int i0) __attribute__((always_inline)) {
+    return LsePair{*reinterpret_cast<const f32x4*>(sLse + i0 + 4 * g), *reinterpret_cast<const f32x4*>(sDel + i0 + 4 * g)};
+  };
+  LsePair l0 = lrow(0);
+  f32x4 cs = attn_scores(sQf, 0, bk, l0.first), ct = attn_scores(sGf, 0, bv, l0.second);
+  LsePair ln = lrow(min(ATRIP, NP - ATRIP));
+#pragma unroll 2
+  for (int i0 = 0; i0 < NP; i0 += ATRIP) {
+    const int in = min(i0 + ATRIP, NP - ATRIP);
+    const f32x4 ns = attn_scores(sQf, in, bk, ln.first), nt = attn_scores(sGf, in, bv, ln.second);
+    ln = lrow(min(i0 + 2 * ATRIP, NP - ATRIP));
+    const u32x2 qb = *reinterpret_cast<const u32x2*>(qrow + i0);
+    const u32x2 gb = *reinterpret_cast<const u32x2*>(grow + i0);
+    __builtin_amdgcn_sched_barrier(0);
+    const float p0 = __builtin_amdgcn_exp2f(cs[0]), p1 = __builtin_amdgcn_exp2f(cs[1]);
+    const float p2 = __builtin_amdgcn_exp2f(cs[2]), p3 = __builtin_amdgcn_exp2f(cs[3]);
+    dv = LpPack<LP>::mma(LpPack<LP>::four(p0, p1, p2, p3), gb, dv);
+    dk = LpPack<LP>::mma(LpPack<LP>::four(p0 * ct[0], p1 * ct[1], p2 * ct[2], p3 * ct[3]), qb, dk);
+    cs = ns, ct = nt;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int k2 = blockIdx.x * AQ + 16 * wave + 4 * g + r;
+    if (c < 4 && k2 < N) {
+      dqkv[(rowbase + k2) * 96 + 32 + head * 4 + c] = 0.5f * dk[r];
+      dqkv[(rowbase + k2) * 96 + 64 + head * 4 + c] = dv[r];
+    }
+  }
+}
+
+template <int LP>
+__global__ __launch_bounds__(256) void attn_bwd_lp_kernel(int N, int nseq, const float* __restrict__ qkv,
+                                                          const float* __restrict__ ob, const float* __restrict__ lse,
+                                                          const float* __restrict__ dO, float* __restrict__ dqkv) {
+  HDF_CHAIN_PRIO();
+  extern __shared__ float4 skv[];
+  if ((int)blockIdx.z < nseq)
+    attn_bwd_dq_lp_body<LP>(N, blockIdx.z, qkv, ob, lse, dO, dqkv, skv);
+  else
+    attn_bwd_dkv_lp_body<LP>(N, blockIdx.z - nseq, qkv, ob, lse, dO, dqkv, skv);
 }
 
 // ------------------------------------------------------------------------------ patch embedding (MFMA f32)
@@ -544,7 +770,21 @@ int tf_attention_fwd(int N, int nseq, const float* qkv, float* ob, float* lse, h
 }
 
 int tf_attention_bwd(int N, int nseq, const float* qkv, const float* ob, const float* lse, const float* dO, float* dqkv,
-                     hipStream_t st) {
+                     hipStream_t st, int lp) {
+  if (lp == HDF_BF16 || lp == HDF_F16) {
+    const size_t shm = attn_bwd_lp_lds(N);
+    HDF_CHECK_ARG(N >= 1 && shm <= LDS_LIMIT, "attention backward: %d tokens need %zu B of LDS", N, shm);
+    const dim3 grid(ceil_div(N, AQ), 8, 2 * nseq);
+    if (lp == HDF_BF16) {
+      HDF_TRY(allow_lds(attn_bwd_lp_kernel<1>, shm));
+      hipLaunchKernelGGL(attn_bwd_lp_kernel<1>, grid, dim3(256), shm, st, N, nseq, qkv, ob, lse, dO, dqkv);
+    } else {
+      HDF_TRY(allow_lds(attn_bwd_lp_kernel<2>, shm));
+      hipLaunchKernelGGL(attn_bwd_lp_kernel<2>, grid, dim3(256), shm, st, N, nseq, qkv, ob, lse, dO, dqkv);
+    }
+    HDF_LAUNCH_CHECK();
+    return HDF_OK;
+  }
   const size_t shm = (size_t)attn_rows(N) * 40;
   HDF_CHECK_ARG(N >= 1 && shm <= LDS_LIMIT, "attention backward: %d tokens need %zu B of LDS", N, shm);
   HDF_TRY(allow_lds(attn_bwd_kernel, shm));

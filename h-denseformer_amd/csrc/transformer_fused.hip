@@ -150,6 +150,7 @@ struct TokFwd {
 
 template <bool POST, bool OUT, bool PRE, typename T>
 __global__ __launch_bounds__(256) void tok_fwd_kernel(TokFwd a) {
+  HDF_CHAIN_PRIO();
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const TfDims& d = a.d;
   const int DM = d.DM, DMF = d.DMF, ldF = DMF + 4;
@@ -557,6 +558,7 @@ struct TokBwd {
 
 template <bool PREB, bool OUTB, bool POSTB, typename T>
 __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwd a) {
+  HDF_CHAIN_PRIO();
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const TfDims& d = a.d;
   const int DM = d.DM, DMF = d.DMF, ldF = DMF + 4, ldD = DM + 4;

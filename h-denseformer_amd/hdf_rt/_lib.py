@@ -77,6 +77,7 @@ _PROTOS = {
     "hdf_op_upsample_bwd": (_i, [_i, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _vp]),
     "hdf_op_attention_fwd": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "hdf_op_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "hdf_op_attention_amp_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "hdf_op_patch_embed_fwd": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _i, _u64, _vp]),
     "hdf_op_patch_embed_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _i, _u64, _vp]),
     "hdf_op_dense_layer_fwd": (_i, [_i, _i, _i, _i, _i, _i, _vp, _i64, _vp, _vp, _i, _u64, _vp]),

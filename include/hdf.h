@@ -260,6 +260,13 @@ int hdf_op_upsample_bwd(int dtype, const void* dout, int64_t dout_pitch, void* d
 int hdf_op_attention_fwd(const float* qkv, int nseq, int N, float* ob, float* lse, hdf_stream stream);
 int hdf_op_attention_bwd(const float* qkv, const float* ob, const float* lse, const float* d_ob, float* dqkv, int nseq,
                          int N, hdf_stream stream);
+/* The backward as the plan runs it in storage mode `dtype` (HDF_F32: identical to hdf_op_attention_bwd).  In the 16-bit
+ * modes the scores and the softmax stay fp32 and the accumulations dS.k, dS^T.q and attn^T.d_ob take bf16 / f16 operands
+ * with fp32 accumulation on the matrix core: what torch.cuda.amp.autocast does to the torch.matmul calls of
+ * Dense_Attention (HDenseFormer.py:70-73 under trainer.py:369).  The forward is the exact one in every mode.
+ * Same buffers as above, all fp32. */
+int hdf_op_attention_amp_bwd(int dtype, const float* qkv, const float* ob, const float* lse, const float* d_ob,
+                             float* dqkv, int nseq, int N, hdf_stream stream);
 /* Dense_TransformerBlock front (:115-119,133-138): Conv3d(1 -> DM, k16, s16) + flatten + position embedding + dropout.
  * x: [B][M][D][H][W]; writes F[:, 0:DM].  backward: dF -> dweight, dpos (+=), dbias (+=); scratch rows*DM floats */
 int hdf_op_patch_embed_fwd(const float* x, int M, int B, int D, int H, int W, int DM, const float* weight,

@@ -66,6 +66,39 @@ def test_attention_fwd_bwd(N, nseq):
     assert rel_err(dq.cpu(), q.grad) < TOL
 
 
+# the backward with what autocast does to the matmuls of Dense_Attention (16-bit operands, fp32 accumulate): tolerance =
+# the operand rounding (2^-9 for bf16, 2^-12 for f16) against max|ref|; lse comes from the fp32 scores and stays at the fp32 tolerance
+AMP_TOL = {1: 1.5e-2, 2: 2e-3}
+
+
+@pytest.mark.parametrize("N", [8, 27, 64, 512, 729, 1000])
+@pytest.mark.parametrize("nseq", [1, 3])
+@pytest.mark.parametrize("dtype", [0, 1, 2])
+def test_attention_amp_bwd(N, nseq, dtype):
+    qkv = torch.randn(nseq * N, 96, generator=_g(N + 7)) * 1.5
+    d_ob = torch.randn(nseq * N, 32, generator=_g(N + 8))
+    q = qkv.clone().requires_grad_(True)
+    qq, kk, vv = [t.reshape(nseq, N, 8, 4).permute(0, 2, 1, 3) for t in q.split(32, dim=-1)]
+    dots = torch.matmul(qq, kk.transpose(-1, -2)) * 0.5
+    ref = torch.matmul(torch.softmax(dots, dim=-1), vv).permute(0, 2, 1, 3).reshape(nseq * N, 32)
+    ref.backward(d_ob)
+    ref_lse = torch.logsumexp(dots, dim=-1).permute(0, 2, 1).reshape(nseq * N, 8)
+
+    gq, gd = qkv.to(DEV), d_ob.to(DEV)
+    ob = torch.full((nseq * N, 32), float("nan"), device=DEV)
+    lse = torch.full((nseq * N, 8), float("nan"), device=DEV)
+    dq = torch.full((nseq * N, 96), float("nan"), device=DEV)
+    check(lib().hdf_op_attention_fwd(ptr(gq), nseq, N, ptr(ob), ptr(lse), st()), "attention_fwd")
+    check(lib().hdf_op_attention_amp_bwd(dtype, ptr(gq), ptr(ob), ptr(lse), ptr(gd), ptr(dq), nseq, N, st()),
+          "attention_amp_bwd")
+    torch.cuda.synchronize()
+    tol = AMP_TOL.get(dtype, TOL)
+    assert rel_err(lse.cpu(), ref_lse.detach()) < TOL
+    assert rel_err(ob.cpu(), ref.detach()) < TOL
+    for i, name in enumerate("qkv"):      # per third: dq, dk, dv have different magnitudes
+        assert rel_err(dq.cpu()[:, 32 * i:32 * i + 32], q.grad[:, 32 * i:32 * i + 32]) < tol, name
+
+
 # ------------------------------------------------------------------------------------------------ dense layer
 def _layer_params(DM, layer, M, seed):
     g = _g(seed)
