@@ -483,7 +483,9 @@ void layout(hdf_plan* p, int B) {
   for (int k = 0; k < 3; k++) conv_bufs(p->up[k]);
   p->at[2] = mkview(p, bp, "at1", 2, 4 * nf, B);
   p->at[1] = mkview(p, bp, "at2", 1, 2 * nf, B);
+#ifdef HDF_NO_FUSED_AT3  // (A/B builds; the product evaluates at3 inside the level-0 encoder tail: forward3d)
   p->at[0] = mkview(p, bp, "at3", 0, nf, B);
+#endif
   for (int k = 0; k < 4; k++) {
     conv_bufs(p->enc[k][0]);
     conv_bufs(p->enc[k][1]);
@@ -1309,6 +1311,11 @@ static int forward3d(hdf_plan* p, const float* x, const float* params, void* wor
   }
   // the caller's stream first (4 launches), then the ~65 launches of the branch: the host issues launches one after the
   // other, and whatever is issued second starts that much later when the host is not far ahead of the GPU
+#ifdef HDF_NO_FUSED_AT3  // A/B builds
+  const bool fused_at3 = false;
+#else
+  const bool fused_at3 = true;
+#endif
   HDF_TRY(hdf_launch_nchw_to_ndhwc(p->dtype, x, e.at(p->xin), batch, p->M, 16, p->vox(0), e.st));
   HDF_TRY(conv_forward(e, p->enc[0][0], p->xin, none));
   HDF_TRY(conv_forward(e, p->enc[0][1], p->enc[0][0].y, xf_of(e, p->enc[0][0])));
@@ -1327,6 +1334,8 @@ static int forward3d(hdf_plan* p, const float* x, const float* params, void* wor
       Conv3& c = p->up[k];
       HDF_TRY(conv_forward(eb, c, *src, none));
       const View& dst = p->at[2 - k];
+      // at3 (k == 2) is not materialised: the level-0 encoder tail interpolates it from up3's output (enc_tail_up_kernel)
+      if (k == 2 && fused_at3) break;
       HDF_TRY(hdf_launch_upsample_fwd(p->dtype, eb.at(c.y), c.y.pitch, eb.f(c.st.scale), eb.f(c.st.shift), eb.at(dst),
                                       dst.pitch, batch, c.Cout, p->dims[c.lvl][0], p->dims[c.lvl][1],
                                       p->dims[c.lvl][2], eb.st));
@@ -1348,6 +1357,13 @@ static int forward3d(hdf_plan* p, const float* x, const float* params, void* wor
     if (k < 3) {
       View ds = subview(p, p->cat[k], ch[k], ch[k]);
       // ds_k = relu(IN(y)) + at_k ; pooled = MaxPool(ds_k): one fused pass
+      if (k == 0 && fused_at3) {
+        Conv3& u = p->up[2];  // at3 = Upsample(relu(IN(up3 conv))), evaluated inside the pass
+        HDF_TRY(hdf_launch_enc_tail_up(p->dtype, e.at(c.y), c.y.pitch, e.f(c.st.scale), e.f(c.st.shift), e.at(u.y), u.y.pitch,
+                                       e.f(u.st.scale), e.f(u.st.shift), e.at(ds), ds.pitch, e.at(p->pooled[k]),
+                                       p->pooled[k].pitch, (uint8_t*)(e.ws + p->pool_idx[k]), batch, ch[k],
+                                       p->dims[k + 1][0], p->dims[k + 1][1], p->dims[k + 1][2], e.st));
+      } else
       HDF_TRY(hdf_launch_enc_tail(p->dtype, e.at(c.y), c.y.pitch, e.f(c.st.scale), e.f(c.st.shift), e.at(p->at[k]),
                                   p->at[k].pitch, e.at(ds), ds.pitch, e.at(p->pooled[k]), p->pooled[k].pitch,
                                   (uint8_t*)(e.ws + p->pool_idx[k]), batch, ch[k], p->dims[k + 1][0], p->dims[k + 1][1],
@@ -1899,6 +1915,14 @@ int hdf_op_enc_tail(int dtype, const void* y, int64_t y_pitch, const float* scal
   HDF_CHECK_ARG(y && scale && shift && skip && ds && pooled && idx, "enc_tail: null argument");
   return hdf_launch_enc_tail(dtype, y, y_pitch, scale, shift, skip, skip_pitch, ds, ds_pitch, pooled, pooled_pitch, idx, N,
                              C, Do, Ho, Wo, (hipStream_t)stream);
+}
+int hdf_op_enc_tail_up(int dtype, const void* y, int64_t y_pitch, const float* scale, const float* shift, const void* low,
+                       int64_t low_pitch, const float* lscale, const float* lshift, void* ds, int64_t ds_pitch,
+                       void* pooled, int64_t pooled_pitch, uint8_t* idx, int N, int C, int Do, int Ho, int Wo,
+                       hdf_stream stream) {
+  HDF_CHECK_ARG(y && scale && shift && low && lscale && lshift && ds && pooled && idx, "enc_tail_up: null argument");
+  return hdf_launch_enc_tail_up(dtype, y, y_pitch, scale, shift, low, low_pitch, lscale, lshift, ds, ds_pitch, pooled,
+                                pooled_pitch, idx, N, C, Do, Ho, Wo, (hipStream_t)stream);
 }
 int hdf_op_maxpool_bwd(int dtype, const void* dout, int64_t dout_pitch, const uint8_t* idx, void* din,
                        int64_t din_pitch, int N, int C, int Do, int Ho, int Wo, int accumulate, hdf_stream stream) {

@@ -22,6 +22,11 @@ int hdf_launch_norm_relu_add(int dtype, const void* y, int64_t y_pitch, const fl
 int hdf_launch_enc_tail(int dtype, const void* y, int64_t y_pitch, const float* scale, const float* shift,
                         const void* skip, int64_t skip_pitch, void* ds, int64_t ds_pitch, void* pooled,
                         int64_t pooled_pitch, uint8_t* idx, int N, int C, int Do, int Ho, int Wo, hipStream_t st);
+// the same with skip = trilinear x2 of relu(low * lscale + lshift), low at (Do, Ho, Wo): the skip tensor is never materialised
+int hdf_launch_enc_tail_up(int dtype, const void* y, int64_t y_pitch, const float* scale, const float* shift,
+                           const void* low, int64_t low_pitch, const float* lscale, const float* lshift, void* ds,
+                           int64_t ds_pitch, void* pooled, int64_t pooled_pitch, uint8_t* idx, int N, int C, int Do, int Ho,
+                           int Wo, hipStream_t st);
 int hdf_launch_maxpool_fwd(int dtype, const void* in, int64_t in_pitch, void* out, int64_t out_pitch, uint8_t* idx,
                            int N, int C, int Do, int Ho, int Wo, hipStream_t st);
 // din[8 positions] (+)= (pos == idx) ? dout : 0

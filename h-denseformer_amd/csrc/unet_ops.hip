@@ -394,6 +394,125 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const T* __restrict__
   }
 }
 
+// ------------------------------------------------------------------------------ encoder tail with the up-sampling inside
+// ds = relu(y*s+t) + trilinear_x2(relu(low*ls+lt)) ;  pooled, idx = MaxPool3d(2)(ds)     (HDenseFormer.py:168-175,237-243)
+// enc_tail_kernel and upsample_fwd_kernel share their decomposition -- a thread owns one LOW-resolution voxel chunk, i.e.
+// one 2 x 2 x 2 block of ds -- so the level-0 feature at3 = up3(...) need not exist in memory: this kernel interpolates
+// the block from the 3 x 3 x 3 low-resolution neighbourhood (the same separable x, y, z arithmetic as
+// upsample_fwd_kernel, plane by plane) and adds it in registers.  What it is for: at3's up-sampling (268 MB written at
+// 128^3, batch 2: 103 us) was the LAST launch of the transformer / UpConv chain the caller's stream waits for in the
+// forward (plan.hip: forward3d); with it here the wait ends at up3's InstanceNorm statistics, and this pass reads the
+// 33 MB low-resolution tensor (L2-resident neighbours) instead of 268 MB.  The interpolated value is added in fp32
+// (the materialised at3 was rounded to the storage type first).
+// Registers: two interpolated planes (64 floats at 8 channels) + four norm vectors + the running maxima: one workgroup
+// of 256 per SIMD set, no spills (the round-1 attempt at this fusion kept all eight interpolated chunks live and spilled).
+template <typename T>
+__global__ __launch_bounds__(256, 2) void enc_tail_up_kernel(const T* __restrict__ y, int64_t y_pitch,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, const T* __restrict__ low,
+                                                             int64_t low_pitch, const float* __restrict__ lscale,
+                                                             const float* __restrict__ lshift, T* __restrict__ ds,
+                                                             int64_t ds_pitch, T* __restrict__ pooled,
+                                                             int64_t pooled_pitch, uint8_t* __restrict__ idx, int N, int C,
+                                                             int Do, int Ho, int Wo) {
+  constexpr int EPC = 4;  // four channels per thread (8-byte accesses in the 16-bit modes): two workgroups per SIMD set
+  // grid (x tiles, oh, n * Do + od): the plane and row coordinates are uniform per workgroup, so every base address is
+  // scalar arithmetic and a thread adds 32-bit offsets inside one row (the first version, a flat index with 64-bit
+  // divisions and one 64-bit multiply per neighbour, spent a third of its vector cycles on addresses)
+  const int cols = C / EPC;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= Wo * cols) return;
+  const int ow = t / cols, c0 = (t - ow * cols) * EPC;
+  const int oh = blockIdx.y;
+  const int nz = blockIdx.z, n = nz / Do, od = nz - n * Do;
+  const int Hi = 2 * Ho, Wi = 2 * Wo;
+  const int yp = (int)y_pitch, dp = (int)ds_pitch, lp = (int)low_pitch;
+  float sc[EPC], sh[EPC], lsc[EPC], lsh[EPC], best[EPC];
+  int bi[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; e++) {
+    sc[e] = scale[(int64_t)n * C + c0 + e];
+    sh[e] = shift[(int64_t)n * C + c0 + e];
+    lsc[e] = lscale[(int64_t)n * C + c0 + e];
+    lsh[e] = lshift[(int64_t)n * C + c0 + e];
+    best[e] = -INFINITY;
+    bi[e] = 0;
+  }
+  // ---- the low-resolution neighbourhood (upsample_fwd_kernel's plane_yx, same order of operations)
+  const int zs[3] = {max(od - 1, 0), od, min(od + 1, Do - 1)};
+  const int ys[3] = {max(oh - 1, 0), oh, min(oh + 1, Ho - 1)};
+  const int xo[3] = {max(ow - 1, 0) * lp + c0, ow * lp + c0, min(ow + 1, Wo - 1) * lp + c0};
+  auto plane_yx = [&](int a, float (&P)[4][EPC]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+      for (int e = 0; e < EPC; e++) P[q][e] = 0.f;
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+      const T* const lrow = low + (((int64_t)n * Do + zs[a]) * Ho + ys[b]) * Wo * low_pitch;  // uniform
+      float L[3][EPC];
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        float f[EPC];
+        ST<T>::ld4(lrow + xo[c], f);
+#pragma unroll
+        for (int e = 0; e < EPC; e++) L[c][e] = fmaxf(f[e] * lsc[e] + lsh[e], 0.f);
+      }
+      const float wy0 = (b == 0) ? 0.25f : (b == 1 ? 0.75f : 0.f);
+      const float wy1 = (b == 0) ? 0.f : (b == 1 ? 0.75f : 0.25f);
+#pragma unroll
+      for (int e = 0; e < EPC; e++) {
+        const float x0 = 0.25f * L[0][e] + 0.75f * L[1][e], x1 = 0.75f * L[1][e] + 0.25f * L[2][e];
+        P[0][e] += wy0 * x0, P[1][e] += wy0 * x1;
+        P[2][e] += wy1 * x0, P[3][e] += wy1 * x1;
+      }
+    }
+  };
+  // first voxel row of the workgroup's 2 x 2 x (2 Wo) slab (uniform) + this thread's x offset
+  const int64_t slab = (((int64_t)nz * 2) * Hi + 2 * oh) * Wi;
+  const T* const ybase = y + slab * y_pitch + 2 * ow * yp + c0;
+  T* const dbase = ds + slab * ds_pitch + 2 * ow * dp + c0;
+  // one output z plane of the block: ds = relu(y*s+t) + (wa A + wb B), stored, folded into the running maximum in scan
+  // order d,h,w (strict > keeps the FIRST maximum: torch's tie rule; over the STORED values, as enc_tail_kernel)
+  auto finish_plane = [&](int dz, const float (&A)[4][EPC], float wa, const float (&B)[4][EPC], float wb)
+      __attribute__((always_inline)) {
+    float yv[4][EPC];
+#pragma unroll
+    for (int q = 0; q < 4; q++) ST<T>::ld4(ybase + ((int64_t)(dz * Hi + (q >> 1)) * Wi) * y_pitch + (q & 1) * yp, yv[q]);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int k = dz * 4 + q;
+      float f[EPC];
+#pragma unroll
+      for (int e = 0; e < EPC; e++) f[e] = fmaxf(yv[q][e] * sc[e] + sh[e], 0.f) + (wa * A[q][e] + wb * B[q][e]);
+      ST<T>::st4(dbase + ((int64_t)(dz * Hi + (q >> 1)) * Wi) * ds_pitch + (q & 1) * dp, f[0], f[1], f[2], f[3]);
+      float g[EPC];
+#pragma unroll
+      for (int e = 0; e < EPC; e++) {
+        T tmp;
+        ST<T>::st(&tmp, f[e]);
+        g[e] = ST<T>::ld(&tmp);
+      }
+#pragma unroll
+      for (int e = 0; e < EPC; e++) {
+        if (g[e] > best[e] || g[e] != g[e]) {
+          best[e] = g[e];
+          bi[e] = k;
+        }
+      }
+    }
+  };
+  float P0[4][EPC], P1[4][EPC];
+  plane_yx(0, P0);
+  plane_yx(1, P1);
+  finish_plane(0, P0, 0.25f, P1, 0.75f);
+  plane_yx(2, P0);
+  finish_plane(1, P1, 0.75f, P0, 0.25f);
+  const int64_t prow = ((int64_t)nz * Ho + oh) * Wo + ow;
+  ST<T>::st4(pooled + prow * pooled_pitch + c0, best[0], best[1], best[2], best[3]);
+  *reinterpret_cast<uint32_t*>(idx + prow * C + c0) = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+}
+
 // input i receives from outputs 2i-1 (.25, i>=1), 2i (.75 [+.25 at i==0]), 2i+1 (.75 [+.25 at i==n-1]), 2i+2 (.25, i<=n-2)
 __device__ __forceinline__ void up_bwd_taps(int i, int n, int* o, float* w) {
   o[0] = 2 * i - 1;
@@ -408,61 +527,67 @@ __device__ __forceinline__ void up_bwd_taps(int i, int n, int* o, float* w) {
   if (i > n - 2) o[3] = 2 * n - 1;
 }
 
+// XCD-aware workgroup order.  The dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs, each with its own
+// L2: with tiles in raster order, a tile's neighbours in y and z -- which share its halo -- run on OTHER XCDs and every
+// halo row is fetched from the fabric once per XCD that touches it.  logical tile = xcd * (W / 8) + id / 8 gives every
+// XCD one contiguous range of the raster instead (W a multiple of 8; else the identity).
+__device__ __forceinline__ int xcd_slab_id(int L, int W) { return (W & 7) ? L : (L & 7) * (W >> 3) + (L >> 3); }
+
+// One thread per low-resolution voxel chunk: 4 x 4 x 4 output taps.  Grid = x tiles * Hi * (N * Di) workgroups, one
+// low-resolution row segment each: plane and row are uniform per workgroup (scalar address arithmetic; the flat-index
+// version decoded its coordinates with 64-bit divisions), and the XCD slab order above keeps the 16 output rows a
+// workgroup reads in the L2 that read them for the previous row (the raster order fetched 1.1 GB per step for 0.35 GB of
+// operands: three XCDs per output row).
 template <typename T>
-__global__ void upsample_bwd_kernel(const T* __restrict__ dout, int64_t dout_pitch, T* __restrict__ din,
-                                    int64_t din_pitch, int N, int C, int Di, int Hi, int Wi) {
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__ dout, int64_t dout_pitch,
+                                                           T* __restrict__ din, int64_t din_pitch, int N, int C, int Di,
+                                                           int Hi, int Wi, int gx) {
   constexpr int EPC = ST<T>::EPC;
   const int cols = C / EPC;
-  const int Do = 2 * Di, Ho = 2 * Hi, Wo = 2 * Wi;
-  int64_t total = (int64_t)N * Di * Hi * Wi * cols;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t row = i / cols;
-    int c0 = (int)(i - row * cols) * EPC;
-    int64_t t = row;
-    int iw = t % Wi;
-    t /= Wi;
-    int ih = t % Hi;
-    t /= Hi;
-    int id = t % Di;
-    int n = (int)(t / Di);
-    int oz[4], oy[4], ox[4];
-    float wz[4], wy[4], wx[4];
-    up_bwd_taps(id, Di, oz, wz);
-    up_bwd_taps(ih, Hi, oy, wy);
-    up_bwd_taps(iw, Wi, ox, wx);
-    float acc[EPC];
+  const int Ho = 2 * Hi, Wo = 2 * Wi;
+  const int vb = xcd_slab_id(blockIdx.x, gridDim.x);
+  const int xt = vb % gx, r = vb / gx;
+  const int ih = r % Hi, nz = r / Hi;
+  const int id = nz % Di, n = nz / Di;
+  const int t = xt * 256 + threadIdx.x;
+  if (t >= Wi * cols) return;
+  const int iw = t / cols, c0 = (t - iw * cols) * EPC;
+  int oz[4], oy[4], ox[4];
+  float wz[4], wy[4], wx[4];
+  up_bwd_taps(id, Di, oz, wz);
+  up_bwd_taps(ih, Hi, oy, wy);
+  up_bwd_taps(iw, Wi, ox, wx);
+  float acc[EPC];
 #pragma unroll
-    for (int e = 0; e < EPC; e++) acc[e] = 0.f;
-    // all 64 taps unconditionally (indices are clamped into range, out-of-range taps carry weight 0): no
-    // branch around any load, so the loads of a thread are all in flight together
-    // addresses: one 64-bit sample base, then 32-bit element offsets z + y + x (the launcher checks that a sample
-    // fits 2^31 elements) -- 64 full 64-bit row products per thread cost more VALU time than the 64 loads
-    const T* const sbase = dout + (int64_t)n * Do * Ho * Wo * dout_pitch + c0;
-    const int pit = (int)dout_pitch;
-    int zo[4], yo[4], xo[4];
+  for (int e = 0; e < EPC; e++) acc[e] = 0.f;
+  // all 64 taps unconditionally (indices are clamped into range, out-of-range taps carry weight 0): no branch around
+  // any load, so the loads of a thread are all in flight together.  Addresses: one 64-bit sample base, 32-bit element
+  // offsets z + y (uniform) + x (the launcher checks that a sample fits 2^31 elements)
+  const T* const sbase = dout + (int64_t)n * (2 * Di) * Ho * Wo * dout_pitch + c0;
+  const int pit = (int)dout_pitch;
+  int zo[4], yo[4], xo[4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      zo[q] = oz[q] * Ho * Wo * pit;
-      yo[q] = oy[q] * Wo * pit;
-      xo[q] = ox[q] * pit;
-    }
-#pragma unroll
-    for (int a = 0; a < 4; a++) {
-#pragma unroll
-      for (int b = 0; b < 4; b++) {
-        const float wzy = wz[a] * wy[b];
-        const int zy = zo[a] + yo[b];
-        float f[4][EPC];
-#pragma unroll
-        for (int c = 0; c < 4; c++) load_chunk<T>(sbase + (zy + xo[c]), f[c]);
-#pragma unroll
-        for (int c = 0; c < 4; c++)
-#pragma unroll
-          for (int e = 0; e < EPC; e++) acc[e] += (wzy * wx[c]) * f[c][e];
-      }
-    }
-    store_chunk<T>(din + row * din_pitch + c0, acc);
+  for (int q = 0; q < 4; q++) {
+    zo[q] = oz[q] * Ho * Wo * pit;
+    yo[q] = oy[q] * Wo * pit;
+    xo[q] = ox[q] * pit;
   }
+#pragma unroll
+  for (int a = 0; a < 4; a++) {
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const float wzy = wz[a] * wy[b];
+      const int zy = zo[a] + yo[b];
+      float f[4][EPC];
+#pragma unroll
+      for (int c = 0; c < 4; c++) load_chunk<T>(sbase + (zy + xo[c]), f[c]);
+#pragma unroll
+      for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int e = 0; e < EPC; e++) acc[e] += (wzy * wx[c]) * f[c][e];
+    }
+  }
+  store_chunk<T>(din + (((int64_t)nz * Hi + ih) * Wi + iw) * din_pitch + c0, acc);
 }
 
 // ------------------------------------------------------------------------------ 1x1x1 heads
@@ -1162,6 +1287,21 @@ int hdf_launch_enc_tail(int dtype, const void* y, int64_t y_pitch, const float* 
   return HDF_OK;
 }
 
+int hdf_launch_enc_tail_up(int dtype, const void* y, int64_t y_pitch, const float* scale, const float* shift,
+                           const void* low, int64_t low_pitch, const float* lscale, const float* lshift, void* ds,
+                           int64_t ds_pitch, void* pooled, int64_t pooled_pitch, uint8_t* idx, int N, int C, int Do, int Ho,
+                           int Wo, hipStream_t st) {
+  HDF_CHECK_ARG(C % 16 == 0, "enc_tail_up: C=%d", C);
+  DISPATCH_T(dtype, {
+    HDF_CHECK_ARG(Ho <= 65535 && (int64_t)N * Do <= 65535, "enc_tail_up: extent %d x %d x %d", Do, Ho, Wo);
+    hipLaunchKernelGGL((enc_tail_up_kernel<T>), dim3(ceil_div(Wo * (C / 4), 256), Ho, N * Do), dim3(256), 0, st, (const T*)y, y_pitch, scale, shift,
+                       (const T*)low, low_pitch, lscale, lshift, (T*)ds, ds_pitch, (T*)pooled, pooled_pitch, idx, N, C, Do,
+                       Ho, Wo);
+  });
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
 int hdf_launch_maxpool_fwd(int dtype, const void* in, int64_t in_pitch, void* out, int64_t out_pitch, uint8_t* idx,
                            int N, int C, int Do, int Ho, int Wo, hipStream_t st) {
   HDF_CHECK_ARG(C % 16 == 0, "maxpool: C=%d", C);
@@ -1296,9 +1436,13 @@ int hdf_launch_upsample_bwd(int dtype, const void* dout, int64_t dout_pitch, voi
   HDF_CHECK_ARG((int64_t)8 * Di * Hi * Wi * dout_pitch < ((int64_t)1 << 31),
                 "upsample_bwd: a sample of %dx%dx%d voxels x pitch %lld exceeds 32-bit element offsets", 2 * Di, 2 * Hi,
                 2 * Wi, (long long)dout_pitch);
-  DISPATCH_T(dtype,
-             hipLaunchKernelGGL(upsample_bwd_kernel<T>, dim3(grid_for((int64_t)N * Di * Hi * Wi * (C / ST<T>::EPC))),
-                                dim3(256), 0, st, (const T*)dout, dout_pitch, (T*)din, din_pitch, N, C, Di, Hi, Wi));
+  DISPATCH_T(dtype, {
+    const int gx = ceil_div(Wi * (C / ST<T>::EPC), 256);
+    const int64_t wgs = (int64_t)gx * Hi * N * Di;
+    HDF_CHECK_ARG(wgs < ((int64_t)1 << 31), "upsample_bwd: %lld workgroups", (long long)wgs);
+    hipLaunchKernelGGL(upsample_bwd_kernel<T>, dim3((unsigned)wgs), dim3(256), 0, st, (const T*)dout, dout_pitch, (T*)din,
+                       din_pitch, N, C, Di, Hi, Wi, gx);
+  });
   HDF_LAUNCH_CHECK();
   return HDF_OK;
 }

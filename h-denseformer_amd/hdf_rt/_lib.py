@@ -72,6 +72,8 @@ _PROTOS = {
     "hdf_op_maxpool_bwd_in_rows": (_i, [_i, _i, _i, _i]),
     "hdf_op_maxpool_bwd_in": (_i, [_i, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "hdf_op_enc_tail": (_i, [_i, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _i, _i, _vp]),
+    "hdf_op_enc_tail_up": (_i, [_i, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _i, _i,
+                                _vp]),
     "hdf_op_maxpool_bwd": (_i, [_i, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp]),
     "hdf_op_upsample_fwd": (_i, [_i, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp]),
     "hdf_op_upsample_bwd": (_i, [_i, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _vp]),

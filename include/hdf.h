@@ -231,6 +231,13 @@ int hdf_op_maxpool_fwd(int dtype, const void* in, int64_t in_pitch, void* out, i
 int hdf_op_enc_tail(int dtype, const void* y, int64_t y_pitch, const float* scale, const float* shift, const void* skip,
                     int64_t skip_pitch, void* ds, int64_t ds_pitch, void* pooled, int64_t pooled_pitch, uint8_t* idx,
                     int N, int C, int Do, int Ho, int Wo, hdf_stream stream);
+/* hdf_op_enc_tail with skip = Upsample(x2, trilinear)(relu(low * lscale + lshift)) evaluated inside the pass (low at the
+ * pooled extent Do x Ho x Wo): level 0 of the encoder, where the skip is the UpConv chain's last feature
+ * (HDenseFormer.py:168-175, 237; the up-sampled tensor is not written). */
+int hdf_op_enc_tail_up(int dtype, const void* y, int64_t y_pitch, const float* scale, const float* shift, const void* low,
+                       int64_t low_pitch, const float* lscale, const float* lshift, void* ds, int64_t ds_pitch,
+                       void* pooled, int64_t pooled_pitch, uint8_t* idx, int N, int C, int Do, int Ho, int Wo,
+                       hdf_stream stream);
 int hdf_op_maxpool_bwd(int dtype, const void* dout, int64_t dout_pitch, const uint8_t* idx, void* din,
                        int64_t din_pitch, int N, int C, int Do, int Ho, int Wo, int accumulate, hdf_stream stream);
 /* hdf_op_maxpool_bwd with accumulate = 1 for the encoder levels: din becomes the complete gradient of

@@ -73,7 +73,7 @@ def test_forward_fp32_vs_oracle_and_golden(cfg, batch, tag):
     rt = net._last_rt
     errs = []
     for k, v in inter.items():
-        if k.startswith(("dec", "cat")):   # never materialised on the HIP path (fused into consumers)
+        if k.startswith(("dec", "cat")) or k == "at3":   # never materialised on the HIP path (fused into consumers)
             continue
         errs.append((k, _rel(rt.read_buffer(k), v)))
     for i in range(4):

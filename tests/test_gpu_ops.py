@@ -458,6 +458,42 @@ def test_encoder_tail_vs_torch(dtype, c):
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16, F16])
+@pytest.mark.parametrize("c,size", [(16, (8, 12, 16)), (32, (4, 6, 10)), (48, (2, 2, 2)), (32, (16, 20, 12))])
+def test_encoder_tail_with_upsampling_inside_vs_torch(dtype, c, size):
+    """hdf_op_enc_tail_up: ds = relu(y * s + t) + Upsample(x2, trilinear)(relu(low * ls + lt)), MaxPool3d(2) of the stored
+    ds (HDenseFormer.py:168-175,237-243): the level-0 encoder tail with at3 evaluated inside.  Edge voxels use torch's
+    align_corners=False rule (sizes down to a single low-resolution voxel per axis); ties and the arg-max bytes as in
+    test_encoder_tail_vs_torch."""
+    n = 2
+    lo = tuple(v // 2 for v in size)
+    y, low = _mk((n, c) + size, 41), _mk((n, c) + lo, 42)
+    y[:, :, :1] = -1.0
+    scale, shift = _mk((n, c), 43) * 0.5 + 1.0, _mk((n, c), 44) * 0.3
+    lscale, lshift = _mk((n, c), 45) * 0.5 + 1.0, _mk((n, c), 46) * 0.3
+    scale[:, 0] = -scale[:, 0]
+    bc = lambda v: v[:, :, None, None, None]
+    up = F.interpolate(torch.relu(rnd(low, dtype) * bc(lscale) + bc(lshift)), scale_factor=2, mode="trilinear",
+                       align_corners=False)
+    ds_ref = rnd(torch.relu(rnd(y, dtype) * bc(scale) + bc(shift)) + up, dtype)
+    y_cl, low_cl = to_cl(y, dtype), to_cl(low, dtype)
+    ds = torch.empty_like(y_cl)
+    po = torch.empty((n,) + lo + (c,), dtype=y_cl.dtype, device=DEV)
+    idx = torch.empty(po.shape, dtype=torch.uint8, device=DEV)
+    dev = [t.to(DEV).contiguous() for t in (scale, shift, lscale, lshift)]
+    check(lib().hdf_op_enc_tail_up(dtype, ptr(y_cl), c, ptr(dev[0]), ptr(dev[1]), ptr(low_cl), c, ptr(dev[2]), ptr(dev[3]),
+                                   ptr(ds), c, ptr(po), c, ptr(idx), n, c, *lo, st()), "enc_tail_up")
+    torch.cuda.synchronize()
+    got_ds, got_po = from_cl(ds), from_cl(po)
+    assert rel_err(got_ds, ds_ref) < TOL[dtype]
+    po2, idx2 = F.max_pool3d(got_ds, 2, return_indices=True)
+    assert bool((got_po == po2).all())
+    k = idx.permute(0, 4, 1, 2, 3).cpu().long()
+    od, oh, ow = torch.meshgrid(*[torch.arange(v) for v in lo], indexing="ij")
+    flat = ((2 * od + (k >> 2)) * size[1] + 2 * oh + ((k >> 1) & 1)) * size[2] + 2 * ow + (k & 1)
+    assert bool((flat == idx2).all())
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16, F16])
 @pytest.mark.parametrize("n,c,size", [(2, 32, (8, 12, 16)), (1, 64, (20, 16, 24)), (2, 16, (32, 32, 36))])
 def test_instance_norm_relu_backward(dtype, n, c, size):
     """hdf_op_in_bwd (reduce + finalize + apply) vs autograd of relu(InstanceNorm3d(affine)(y)) (HDenseFormer.py:152-158)."""

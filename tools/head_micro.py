@@ -91,3 +91,28 @@ for size, C in ((64, 32), (32, 64), (16, 128)):
                           "upsample_fwd"))
     by = x.numel() * 2 + up.numel() * 2
     print(f"upsample_fwd {C}ch {size}^3 -> {2 * size}^3: {t:7.1f} us  {by / t / 1e6:6.2f} TB/s")
+
+# its adjoint (the first launch of the UpConv chain's backward: d(at3) 128^3 -> 64^3)
+for size, C in ((64, 32), (32, 64), (16, 128)):
+    vox = size ** 3
+    g = torch.randn(N, vox * 8, C, device=dev).to(torch.bfloat16)
+    dx = torch.empty(N, vox, C, device=dev, dtype=torch.bfloat16)
+    t = med(lambda: check(lib().hdf_op_upsample_bwd(BF16, ptr(g), C, ptr(dx), C, N, C, size, size, size, st), "upsample_bwd"))
+    by = g.numel() * 2 + dx.numel() * 2
+    print(f"upsample_bwd {C}ch {2 * size}^3 -> {size}^3: {t:7.1f} us  {by / t / 1e6:6.2f} TB/s")
+
+# level-0 encoder tail with the up-sampling inside (at3 never written)
+for size, C in ((128, 32),):
+    vox = size ** 3
+    y = torch.randn(N, vox, C, device=dev).to(torch.bfloat16)
+    low = torch.randn(N, vox // 8, C, device=dev).to(torch.bfloat16)
+    sc, sh = torch.rand(N, C, device=dev) + 0.5, torch.randn(N, C, device=dev) * 0.1
+    ds = torch.empty_like(y)
+    po = torch.empty(N, vox // 8, C, device=dev, dtype=torch.bfloat16)
+    ix = torch.empty(N, vox // 8, C, device=dev, dtype=torch.uint8)
+    h = size // 2
+    t = med(lambda: check(lib().hdf_op_enc_tail_up(BF16, ptr(y), C, ptr(sc), ptr(sh), ptr(low), C, ptr(sc), ptr(sh), ptr(ds), C,
+                                                   ptr(po), C, ptr(ix), N, C, h, h, h, st), "enc_tail_up"))
+    by = y.numel() * 2 * 2 + low.numel() * 2 + po.numel() * 3
+    print(f"enc_tail_up {C}ch @{size}^3: {t:7.1f} us  {by / t / 1e6:6.2f} TB/s")
+
