@@ -1,0 +1,4 @@
+cd /tmp; export TMPDIR=/tmp; export HDF_NO_ASYNC_WGRAD=1 HDF_NO_BRANCH_OVERLAP=1
+rocprofv3 --kernel-trace --output-format csv -d /root/repo/gpurun_out/one_new -- python3 /root/repo/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline > /dev/null 2>&1
+export HDF_LIB_PATH=/root/repo/h-denseformer_amd/lib/libhdf_hip_prev.so
+rocprofv3 --kernel-trace --output-format csv -d /root/repo/gpurun_out/one_prev -- python3 /root/repo/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline > /dev/null 2>&1
