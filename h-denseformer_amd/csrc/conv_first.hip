@@ -1,0 +1,308 @@
+// First layer of the encoder (block_1_1_left: Conv3d(in_channels <= 4 -> n_filters, k3, p1), HDenseFormer.py:152-158,190):
+// tap-packed K.  The generic stride-1 kernels contract one tap at a time over the input's channel
+// row, which the first layer pads from 4 to 16 channels: 27 k-steps of 16 of which three quarters multiply zeros
+// (conv_ws2<32,32>: 276 us, matrix pipe 0.17 busy).  Here K = (tap, channel) = 27 x 4 = 108 -> 128, eight k-steps:
+//   * the tile's 6 x 10 x 10 input box (the 4 real channels = 8 bytes of each 32-byte voxel row) goes to LDS once, 600
+//     8-byte loads per tile (the first version had every thread fetch its 27 neighbours from global memory: 6,912
+//     32-byte-strided requests per tile kept the texture path, not HBM, busy -- 238 us);
+//   * every thread owns one voxel of the 4 x 8 x 8 tile and builds that voxel's im2col row from the box: 27 ds_read_b64
+//     (consecutive lanes = consecutive x: conflict-free) written at byte 8 * tap of a 272-byte row (256 + 16: the 32 rows
+//     of an A fragment then spread over all banks);
+//   * the weights [K = 128][Cout] sit in registers for the whole launch as B fragments (32 registers per output block,
+//     read once from the fp32 parameters and rounded to the storage type like the packed panels are);
+//   * a wave owns two 32-voxel M-blocks: 8 ds_read_b128 + 8 MFMAs each per tile.
+// The next tile's box loads (3 per thread) are in flight under the current tile's MFMAs and stores.  Bound: the 268 MB of
+// output at 128^3, batch 2 (HBM).  InstanceNorm partial sums leave as in conv_ws2_kernel: one row per workgroup and
+// sample (WS_STAT_ROWS rows per sample, the unused ones zeroed here).
+#include "conv_igemm.h"
+#include "conv_tile.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int CF_PITCH = 272;  // bytes per im2col row
+constexpr int CF_TD = 4, CF_TH = 8, CF_TW = 8, CF_VOX = CF_TD * CF_TH * CF_TW;
+
+struct ConvFirstArgs {
+  const void* in;       // channels-last, >= 4 channels per voxel (the first 4 are read), in_pitch elements apart
+  int64_t in_pitch;
+  int Cin;              // real input channels, 1..4
+  int N, D, H, W;
+  const float* w32;     // torch layout [Cout][Cin][3][3][3], fp32
+  const float* bias;    // [Cout] or null
+  void* out;
+  int64_t out_pitch;
+  int Cout, CoutP;
+  float* stat_partials;  // [N][WS_STAT_ROWS][CoutP][2] or null
+};
+
+template <typename T, int NB>
+__global__ __launch_bounds__(256) void conv_first_kernel(ConvFirstArgs a) {
+  __shared__ __attribute__((aligned(16))) char s_col[CF_VOX * CF_PITCH];
+  __shared__ u32x2 s_box[(CF_TD + 2) * (CF_TH + 2) * (CF_TW + 2)];
+  __shared__ float s_red[4 * 32 * NB * 2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int n = blockIdx.y;
+  const int ntz = (a.D + CF_TD - 1) / CF_TD, nty = (a.H + CF_TH - 1) / CF_TH, ntx = (a.W + CF_TW - 1) / CF_TW;
+  const int ntile = ntz * nty * ntx;
+
+  // ---- B fragments: lane (co = r, kg = h) holds k = 16 ks + 8 kg + j, j = 0..7; k = 4 tap + ci
+  u32x4 wf[NB][8];
+#pragma unroll
+  for (int nb = 0; nb < NB; nb++) {
+    const int co = 32 * nb + r;
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) {
+      float f[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int k = 16 * ks + 8 * h + j, tap = k >> 2, ci = k & 3;
+        const bool ok = co < a.Cout && tap < 27 && ci < a.Cin;
+        f[j] = ok ? a.w32[((int64_t)co * a.Cin + ci) * 27 + tap] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) wf[nb][ks][j] = ST<T>::pack2(f[2 * j], f[2 * j + 1]);
+    }
+  }
+  float bias[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; nb++) bias[nb] = (a.bias && 32 * nb + r < a.Cout) ? a.bias[32 * nb + r] : 0.f;
+
+  // ---- this thread's voxel of a tile and the zero columns [108, 128) of its row (never overwritten)
+  const int lx = tid & 7, ly = (tid >> 3) & 7, lz = tid >> 6;
+  char* const my_row = s_col + tid * CF_PITCH;
+#pragma unroll
+  for (int b = 216; b < 256; b += 8) *reinterpret_cast<u32x2*>(my_row + b) = u32x2{0u, 0u};  // k = 108..127
+  const T* const xin = reinterpret_cast<const T*>(a.in) + (int64_t)n * a.D * a.H * a.W * a.in_pitch;
+  T* const outp = reinterpret_cast<T*>(a.out) + (int64_t)n * a.D * a.H * a.W * a.out_pitch;
+  const int ip = (int)a.in_pitch, op = (int)a.out_pitch;
+
+  constexpr int BD = CF_TD + 2, BH = CF_TH + 2, BW = CF_TW + 2, BOX = BD * BH * BW, NSL = (BOX + 255) / 256;
+  u32x2 pf[NSL];
+  unsigned pf_ok = 0;   // bit j: slot j of the prefetched box lies inside the volume
+  auto tile_origin = [&](int t, int& z0, int& y0, int& x0) {
+    const int tx = t % ntx, ty = (t / ntx) % nty, tz = t / (ntx * nty);
+    z0 = tz * CF_TD, y0 = ty * CF_TH, x0 = tx * CF_TW;
+  };
+  // box slots of this thread: s = tid + 256 j -> (bz, by, bx)
+  int sbz[NSL], sby[NSL], sbx[NSL];
+#pragma unroll
+  for (int j = 0; j < NSL; j++) {
+    const int sl = min(tid + 256 * j, BOX - 1);
+    sbz[j] = sl / (BH * BW), sby[j] = (sl / BW) % BH, sbx[j] = sl % BW;
+  }
+  // the box of tile t -> registers (clamped addresses; voxels outside the volume are zeros: the conv's padding)
+  auto prefetch = [&](int t) __attribute__((always_inline)) {
+    int z0, y0, x0;
+    tile_origin(t, z0, y0, x0);
+#pragma unroll
+    for (int j = 0; j < NSL; j++) {
+      const int z = z0 - 1 + sbz[j], y = y0 - 1 + sby[j], x = x0 - 1 + sbx[j];
+      const bool ok = (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+      const int off = ((min(max(z, 0), a.D - 1) * a.H + min(max(y, 0), a.H - 1)) * a.W + min(max(x, 0), a.W - 1)) * ip;
+      pf[j] = *reinterpret_cast<const u32x2*>(xin + off);   // (no use of the value here: a select on it would make the
+      pf_ok = ok ? (pf_ok | (1u << j)) : (pf_ok & ~(1u << j));  //  wave wait for the load it has just issued)
+    }
+  };
+  auto commit_box = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < NSL; j++) {
+      const bool ok = (pf_ok >> j) & 1u;
+      if (tid + 256 * j < BOX) s_box[tid + 256 * j] = u32x2{ok ? pf[j][0] : 0u, ok ? pf[j][1] : 0u};
+    }
+  };
+  // this thread's im2col row from the box (rows of the previous tile must not be in use any more)
+  const u32x2* const my_box = s_box + (lz * BH + ly) * BW + lx;
+  auto build_rows = [&]() __attribute__((always_inline)) {
+    u32x2 v[27];
+#pragma unroll
+    for (int tap = 0; tap < 27; tap++) v[tap] = my_box[((tap / 9) * BH + (tap / 3) % 3) * BW + tap % 3];
+#pragma unroll
+    for (int tap = 0; tap < 27; tap++) *reinterpret_cast<u32x2*>(my_row + 8 * tap) = v[tap];
+  };
+
+  float lr1[NB], lr2[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; nb++) lr1[nb] = lr2[nb] = 0.f;
+
+  // two barriers per tile: rows(t) built from box(t) | barrier | box(t+1) written from registers loaded a tile ago, the
+  // loads of box(t+2) issued, MFMAs + stores of tile t | barrier
+  int t = blockIdx.x;
+  if (t < ntile) {
+    prefetch(t);
+    commit_box();
+    prefetch(min(t + (int)gridDim.x, ntile - 1));
+  }
+  // drain here: entered with loads pending, the loop's wait for the prefetched box would have to hold for the entry path
+  // too (no store younger than the loads) and would wait for every store of the previous tile on every trip
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  // (barriers that order LDS traffic only: __syncthreads() would wait for the tile's stores to be acknowledged, 4.9 us
+  // per tile; and two copies of the loop, because a conditional store path makes hipcc wait for every outstanding
+  // store wherever it waits for the prefetched box -- DESIGN 6e, the vmcnt finding)
+  auto run = [&](auto full_tag) __attribute__((always_inline)) {
+  for (; t < ntile; t += gridDim.x) {
+    build_rows();
+    WS_BARRIER();   // rows complete, nobody reads the box any more
+    if (t + (int)gridDim.x < ntile) commit_box();
+    prefetch(min(t + 2 * (int)gridDim.x, ntile - 1));   // unconditional (a skipped prefetch is a second path to the
+                                                        // next commit, and hipcc then waits for the stores as well)
+    int z0, y0, x0;
+    tile_origin(t, z0, y0, x0);
+    // ---- 2 M-blocks per wave: voxels 64 wave + 32 mb + m, row m of the block = (ly & 3) * 8 + lx
+    f32x16 acc[2][NB];
+#pragma unroll
+    for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+      for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[mb][nb][i] = 0.f;
+#pragma unroll
+    for (int mb = 0; mb < 2; mb++) {
+      const char* const arow = s_col + (64 * wave + 32 * mb + r) * CF_PITCH + 16 * h;
+      u32x4 af[8];
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++) af[ks] = *reinterpret_cast<const u32x4*>(arow + 32 * ks);
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++)
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) Mma<T>::run(af[ks], wf[nb][ks], acc[mb][nb]);
+    }
+    // ---- epilogue: lane (co = r, h): accumulator i = voxel row (i & 3) + 8 (i >> 2) + 4 h of the M-block, i.e.
+    // y = 4 (mb-th half) + (i >> 2), x = (i & 3) + 4 h; the wave's M-blocks are (lz = wave, y half mb)
+    const int gz = z0 + wave;
+    if constexpr (decltype(full_tag)::value) {
+      // whole tile, whole channel blocks (uniform): branch-free, one per-lane base + uniform 32-bit offsets
+      // A lane holds ONE channel of 16 voxels: stored as they are that is 16 two-byte stores per lane and block, and the
+      // launch is bound by the number of store instructions (2.1 M wave stores for 268 MB).  The 4 x 4 blocks (4 lanes of
+      // a quad = 4 channels) x (4 voxels) are transposed inside the quad (two DPP butterfly rounds), after which a lane
+      // holds 4 channels of ONE voxel per group: 4 eight-byte stores per lane and block.
+      T* const obase = outp + (((int64_t)gz * a.H + y0) * a.W + x0 + 4 * h + (r & 3)) * op + (r & ~3);
+      const bool l1 = r & 1, l2 = r & 2;
+#pragma unroll
+      for (int mb = 0; mb < 2; mb++) {
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) {
+#pragma unroll
+          for (int g = 0; g < 4; g++) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              v[j] = acc[mb][nb][4 * g + j] + bias[nb];
+              lr1[nb] += v[j];
+              lr2[nb] += v[j] * v[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {   // round 1: partner = lane ^ 1
+              const float snd = l1 ? v[j] : v[j + 1];
+              const float rcv = __builtin_bit_cast(
+                  float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, snd), 0xB1, 0xF, 0xF, false));
+              if (l1) v[j] = rcv; else v[j + 1] = rcv;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++) {      // round 2: partner = lane ^ 2
+              const float snd = l2 ? v[j] : v[j + 2];
+              const float rcv = __builtin_bit_cast(
+                  float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, snd), 0x4E, 0xF, 0xF, false));
+              if (l2) v[j] = rcv; else v[j + 2] = rcv;
+            }
+            // v[c] = channel (r & ~3) + c of voxel row (r & 3) + 8 g + 4 h: y = 4 mb + g, x = (r & 3) + 4 h
+            ST<T>::st4(obase + ((4 * mb + g) * a.W) * op + 32 * nb, v[0], v[1], v[2], v[3]);
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int mb = 0; mb < 2; mb++) {
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) {
+          const int co = 32 * nb + r;
+#pragma unroll
+          for (int i = 0; i < 16; i++) {
+            const int gy = y0 + 4 * mb + (i >> 2), gx = x0 + (i & 3) + 4 * h;
+            const float v = acc[mb][nb][i] + bias[nb];
+            const bool ok = gz < a.D && gy < a.H && gx < a.W && co < a.Cout;
+            if (ok) ST<T>::st(outp + (((int64_t)gz * a.H + gy) * a.W + gx) * op + co, v);
+            const float mk = ok ? 1.f : 0.f;
+            lr1[nb] += mk * v;
+            lr2[nb] += mk * v * v;
+          }
+        }
+      }
+    }
+    WS_BARRIER();  // every wave is done with the im2col rows; the next box is complete
+  }
+  };
+  if (a.D % CF_TD == 0 && a.H % CF_TH == 0 && a.W % CF_TW == 0 && 32 * NB <= a.Cout)
+    run(std::true_type{});
+  else
+    run(std::false_type{});
+  // ---- InstanceNorm partial sums: row blockIdx.x of sample n; the rows no workgroup owns are zeroed
+  if (a.stat_partials) {
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) {
+      const float u1 = lr1[nb] + __shfl_xor(lr1[nb], 32, 64), u2 = lr2[nb] + __shfl_xor(lr2[nb], 32, 64);
+      if (h == 0) {
+        s_red[((wave * NB + nb) * 32 + r) * 2 + 0] = u1;
+        s_red[((wave * NB + nb) * 32 + r) * 2 + 1] = u2;
+      }
+    }
+    __syncthreads();
+    if (tid < 32 * NB) {
+      const int nb = tid >> 5, c = tid & 31;
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        t1 += s_red[((k * NB + nb) * 32 + c) * 2 + 0];
+        t2 += s_red[((k * NB + nb) * 32 + c) * 2 + 1];
+      }
+      for (int row = blockIdx.x; row < WS_STAT_ROWS; row += gridDim.x) {
+        float* q = a.stat_partials + (((int64_t)n * WS_STAT_ROWS + row) * a.CoutP + tid) * 2;
+        q[0] = row == (int)blockIdx.x ? t1 : 0.f;
+        q[1] = row == (int)blockIdx.x ? t2 : 0.f;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+bool hdf_conv_first_can(int dtype, int Cin, int Cout, int D, int H, int W, int64_t in_pitch) {
+  return dtype != HDF_F32 && Cin >= 1 && Cin <= 4 && Cout >= 1 && Cout <= 64 && in_pitch % 4 == 0 && D >= 1 && H >= 1 &&
+         W >= 1 && (int64_t)D * H * W * in_pitch < ((int64_t)1 << 31);
+}
+
+// the plan's routing rule: where the generic launcher would use conv_ws2_kernel (same InstanceNorm partials geometry)
+bool hdf_conv_first_takes(int dtype, int Cin, int Cout, int D, int H, int W, int64_t in_pitch) {
+  return hdf_conv_first_can(dtype, Cin, Cout, D, H, W, in_pitch) && (int64_t)D * H * W >= 48 * 48 * 48 &&
+         hdf_conv_stat_tiles(0, D, H, W, 32) == WS_STAT_ROWS;
+}
+
+int hdf_launch_conv_first(int dtype, const void* in, int64_t in_pitch, int Cin, int N, int D, int H, int W,
+                          const float* w32, const float* bias, void* out, int64_t out_pitch, int Cout,
+                          float* stat_partials, hipStream_t st) {
+  HDF_CHECK_ARG(hdf_conv_first_can(dtype, Cin, Cout, D, H, W, in_pitch), "conv_first: dtype %d Cin %d Cout %d %dx%dx%d",
+                dtype, Cin, Cout, D, H, W);
+  HDF_CHECK_ARG((reinterpret_cast<uintptr_t>(in) & 7) == 0, "conv_first: input must be 8-byte aligned");
+  ConvFirstArgs a{};
+  a.in = in, a.in_pitch = in_pitch, a.Cin = Cin, a.N = N, a.D = D, a.H = H, a.W = W;
+  a.w32 = w32, a.bias = bias, a.out = out, a.out_pitch = out_pitch, a.Cout = Cout, a.CoutP = (Cout + 31) / 32 * 32;
+  a.stat_partials = stat_partials;
+  const int tiles = ((D + CF_TD - 1) / CF_TD) * ((H + CF_TH - 1) / CF_TH) * ((W + CF_TW - 1) / CF_TW);
+  // two workgroups per CU (70 KB of LDS each): one's barriers and stores hide under the other's tile
+  const int gx = std::max(1, std::min(tiles, std::min(WS_STAT_ROWS, 2 * hdf_cu_budget() / std::max(1, N))));
+  const dim3 grid(gx, N);
+  if (a.CoutP == 32) {
+    if (dtype == HDF_BF16)
+      hipLaunchKernelGGL((conv_first_kernel<bf16_t, 1>), grid, dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((conv_first_kernel<f16_t, 1>), grid, dim3(256), 0, st, a);
+  } else {
+    if (dtype == HDF_BF16)
+      hipLaunchKernelGGL((conv_first_kernel<bf16_t, 2>), grid, dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((conv_first_kernel<f16_t, 2>), grid, dim3(256), 0, st, a);
+  }
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}

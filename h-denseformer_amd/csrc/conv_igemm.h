@@ -55,6 +55,13 @@ struct WgradArgs {
 };
 
 // conv_wr.hip: weights-in-registers form of the mode-0 launches with 64- / 128-byte rows at >= 48^3 (16-bit storage)
+// csrc/conv_first.hip: the encoder's first layer (1..4 real input channels, 16-bit storage) with tap-packed K.  Reads the
+// fp32 torch-layout weights itself; stat_partials as hdf_launch_conv with WS_STAT_ROWS rows per sample.
+bool hdf_conv_first_can(int dtype, int Cin, int Cout, int D, int H, int W, int64_t in_pitch);
+bool hdf_conv_first_takes(int dtype, int Cin, int Cout, int D, int H, int W, int64_t in_pitch);
+int hdf_launch_conv_first(int dtype, const void* in, int64_t in_pitch, int Cin, int N, int D, int H, int W,
+                          const float* w32, const float* bias, void* out, int64_t out_pitch, int Cout,
+                          float* stat_partials, hipStream_t st);
 bool hdf_conv_wr_can(int dtype, const ConvArgs& a);    // the kernel handles this launch
 bool hdf_conv_wr_takes(int dtype, const ConvArgs& a);  // ... and the plan routes it there
 int hdf_launch_conv_wr(int dtype, const ConvArgs& a, hipStream_t st);

@@ -764,6 +764,13 @@ int conv_forward(Exec& e, Conv3& c, const View& in, Xf xf) {
   a.stat_partials = e.statp();
   a.accumulate = 0;
   a.kpart = e.kspl(), a.kpart_bytes = HDF_KSPLIT_BYTES;
+#ifndef HDF_NO_CONV_FIRST  // (A/B builds)
+  // the encoder's first layer (<= 4 real channels in a 16-channel row): K = (tap, channel), csrc/conv_first.hip
+  if (c.Cin <= 4 && !xf.scale && hdf_conv_first_takes(p->dtype, c.Cin, c.Cout, d[0], d[1], d[2], in.pitch)) {
+    HDF_TRY(hdf_launch_conv_first(p->dtype, e.at(in), in.pitch, c.Cin, e.B, d[0], d[1], d[2], e.P(c.w), e.P(c.b),
+                                  e.at(c.y), c.y.pitch, c.Cout, e.statp(), e.st));
+  } else
+#endif
   HDF_TRY(hdf_launch_conv(p->dtype, 0, a, e.st));
   int tiles = hdf_conv_stat_tiles(0, d[0], d[1], d[2], c.CinP * p->esz);
   HDF_TRY(hdf_launch_in_finalize(e.statp(), e.B, tiles, c.Cout, CoutP, p->vox(c.lvl), e.P(c.gamma),
@@ -1834,6 +1841,13 @@ int hdf_op_conv3d_split(int dtype, const void* in, int64_t in_pitch, int Cin, in
     HDF_TRY(hdf_launch_stat_rows_sum(stat_partials, rows, colsum_C, a.CoutP, colsum, (hipStream_t)stream));
   }
   return HDF_OK;
+}
+int hdf_op_conv3d_first(int dtype, const void* in, int64_t in_pitch, int Cin, int N, int D, int H, int W, const float* weight,
+                        const float* bias, void* out, int64_t out_pitch, int Cout, float* stat_partials,
+                        hdf_stream stream) {
+  HDF_CHECK_ARG(in && weight && out, "conv3d_first: null argument");
+  return hdf_launch_conv_first(dtype, in, in_pitch, Cin, N, D, H, W, weight, bias, out, out_pitch, Cout, stat_partials,
+                               (hipStream_t)stream);
 }
 int hdf_op_conv3d_wr(int dtype, const void* in, int64_t in_pitch, int Cin, int N, int D, int H, int W,
                      const void* w_packed, const float* bias, const float* in_scale, const float* in_shift, int in_relu,

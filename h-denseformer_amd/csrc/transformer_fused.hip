@@ -561,7 +561,8 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(TokBwd a) {
   HDF_CHAIN_PRIO();
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const TfDims& d = a.d;
-  const int DM = d.DM, DMF = d.DMF, ldF = DMF + 4, ldD = DM + 4;
+  // (the inner-layer form stages only the Kq <= DMF - 32 feature columns Linear0 of layers 0..3 reads: 2 KB less LDS)
+  const int DM = d.DM, DMF = d.DMF, ldF = (OUTB ? DMF : DMF - 32) + 4, ldD = DM + 4;
   float* s_F = sm;                      // [16][ldF]  feature rows (PREB: block bq; OUTB: block bo)
   float* s_do = s_F + TT * ldF;         // [16][ldD]  OUTB: masked gradient of the out_layer output (no room otherwise:
   float* s_dq = s_do + (OUTB ? TT * ldD : 0);  // [16][100]  PREB: dqkv tile      see launch_tok_bwd)
@@ -1003,8 +1004,10 @@ int launch_tok_bwd(const TokBwd& a, hipStream_t st) {
   // DM = 128, and with that it fits beside a level-0 weight-gradient workgroup of the side stream (110 KB of LDS, 304 of
   // the 512 registers per lane against this kernel's 208): the transformer backward then advances next to it instead
   // of queueing behind it.
-  const size_t shm = (size_t)(TT * (d.DMF + 4) + (OUTB ? TT * (d.DM + 4) : 0) + TT * 100 + 7 * TT * LD32 + 2 * TT * LD64 +
-                              2 * 16 * 16) * sizeof(float);
+  // ... and (round 4) only the DMF - 32 feature columns it can read: 47.9 KB, which also fits beside the 113 KB workgroups
+  // of the level-0 data-gradient conv (conv_ws2<32,64>), i.e. on every CU during the level-0 encoder backward.
+  const size_t shm = (size_t)(TT * ((OUTB ? d.DMF : d.DMF - 32) + 4) + (OUTB ? TT * (d.DM + 4) : 0) + TT * 100 +
+                              7 * TT * LD32 + 2 * TT * LD64 + 2 * 16 * 16) * sizeof(float);
   HDF_TRY(allow_lds_f(tok_bwd_kernel<PREB, OUTB, POSTB, T>, shm));
   hipLaunchKernelGGL((tok_bwd_kernel<PREB, OUTB, POSTB, T>), grid, dim3(256), shm, st, a);
   HDF_LAUNCH_CHECK();

@@ -186,6 +186,14 @@ int hdf_op_pack_weights(int dtype, const float* src, void* dst, int O, int I, in
 int hdf_op_conv3d(int dtype, int mode, const void* in, int64_t in_pitch, int Cin, int N, int Di, int Hi, int Wi,
                   const void* w_packed, const float* bias, const float* in_scale, const float* in_shift, int in_relu,
                   void* out, int64_t out_pitch, int Cout, float* stat_partials, int accumulate, hdf_stream stream);
+/* The encoder's first layer as the plan runs it in a 16-bit storage mode (nn.Conv3d(in_channels <= 4, n_filters, 3, padding=1),
+ * HDenseFormer.py:152-158,190; csrc/conv_first.hip: K = (tap, channel) instead of 27 quarter-empty channel rows).  in:
+ * channels-last, the first Cin of in_pitch channels per voxel are read (in_pitch % 4 == 0); weight: the torch fp32 tensor
+ * [Cout][Cin][3][3][3] itself (rounded to the storage type inside); stat_partials (optional): [N][512][round_up(Cout,32)][2]
+ * InstanceNorm partial sums (sum, sum of squares of the fp32 results), every row written. */
+int hdf_op_conv3d_first(int dtype, const void* in, int64_t in_pitch, int Cin, int N, int D, int H, int W, const float* weight,
+                        const float* bias, void* out, int64_t out_pitch, int Cout, float* stat_partials,
+                        hdf_stream stream);
 /* The same Conv3d(k3,s1,p1) forced through the weights-in-registers kernel (csrc/conv_wr.hip: 16-bit storage, Cin of 32
  * or 64, >= 48^3) whatever the plan's routing rule says; HDF_ERR_UNSUPPORTED for other shapes.  Tests and tools. */
 int hdf_op_conv3d_wr(int dtype, const void* in, int64_t in_pitch, int Cin, int N, int D, int H, int W,

@@ -419,6 +419,42 @@ def test_maxpool_backward_with_instance_norm_first_pass(dtype, c):
     assert rel_err(s[..., 0], gm.sum((2, 3, 4))) < 1e-4 and rel_err(s[..., 1], (gm * xh).sum((2, 3, 4))) < 1e-4
 
 
+@pytest.mark.parametrize("dtype", [BF16, F16])
+@pytest.mark.parametrize("cin,cout,size,n", [(4, 32, (8, 16, 24), 2), (4, 32, (5, 9, 11), 1), (1, 16, (4, 8, 8), 2),
+                                             (3, 48, (6, 10, 12), 1), (2, 64, (8, 8, 16), 1), (4, 32, (32, 32, 32), 1)])
+@pytest.mark.parametrize("with_bias", [False, True])
+def test_conv3d_first_layer_tap_packed(dtype, cin, cout, size, n, with_bias):
+    """hdf_op_conv3d_first (csrc/conv_first.hip): the encoder's first Conv3d(in_channels <= 4, n_filters, 3, padding=1)
+    (HDenseFormer.py:152-158,190) with K = (tap, channel), against torch on the storage-rounded operands; the input is the
+    plan's 16-channel row of which the first `cin` channels are real (the rest poisoned here: they must not be read into
+    the result), ragged extents, 1..4 channels, 16..64 filters, and the InstanceNorm partial sums of the fp32 results."""
+    x = _mk((n, cin) + size, 51)
+    w = _mk((cout, cin, 3, 3, 3), 52) * 0.2
+    b = _mk((cout,), 53) * 0.1 if with_bias else None
+    ref = F.conv3d(rnd(x, dtype), rnd(w, dtype), b, padding=1)
+    pitch = 16
+    xin = torch.full((n,) + size + (pitch,), 7.0, dtype=TDT[dtype], device=DEV)
+    xin[..., :cin] = x.to(DEV).permute(0, 2, 3, 4, 1).to(TDT[dtype])
+    if cin < 4:
+        xin[..., cin:4] = 0       # the plan's padded channels are zeros (the kernel reads 4 channels and masks by Cin)
+    coutp = (cout + 31) // 32 * 32
+    out = torch.full((n,) + size + (coutp,), float("nan"), dtype=TDT[dtype], device=DEV)
+    part = torch.full((n, 512, coutp, 2), float("nan"), device=DEV)
+    wd = w.to(DEV).contiguous()
+    bd = b.to(DEV).contiguous() if with_bias else None
+    check(lib().hdf_op_conv3d_first(dtype, ptr(xin), pitch, cin, n, *size, ptr(wd), ptr(bd), ptr(out), coutp, cout, ptr(part),
+                                    st()), "conv3d_first")
+    torch.cuda.synchronize()
+    got = out[..., :cout].permute(0, 4, 1, 2, 3).float().cpu()
+    assert rel_err(got, ref) < TOL[dtype]
+    s = part.double().sum(1).cpu()
+    assert rel_err(s[:, :cout, 0], ref.double().sum((2, 3, 4))) < 1e-3
+    assert rel_err(s[:, :cout, 1], (ref.double() ** 2).sum((2, 3, 4))) < 1e-3
+    assert bool((s[:, cout:] == 0).all())
+    if coutp > cout:
+        assert bool(torch.isnan(out[..., cout:].float()).all())     # channels beyond Cout are not written
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16, F16])
 @pytest.mark.parametrize("c", [16, 32, 48, 128])
 def test_encoder_tail_vs_torch(dtype, c):

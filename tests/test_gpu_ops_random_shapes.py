@@ -126,6 +126,39 @@ def test_maxpool_and_upsample_random(dtype, size, n, c16, seed):
 
 
 @settings(**CFG)
+@given(dtype=dtypes, size=dims, n=hs.integers(1, 3), c16=hs.integers(1, 6), extra=hs.integers(0, 2),
+       seed=hs.integers(0, 10 ** 6))
+def test_encoder_tail_with_upsampling_inside_random(dtype, size, n, c16, extra, seed):
+    """hdf_op_enc_tail_up with every operand a channel slice of a wider buffer (the plan's ds is a slice of cat)"""
+    c = 16 * c16
+    pitch, lead = c + 16 * extra, 16 * (extra // 2)
+    lo = tuple(v // 2 for v in size)
+    y, low = _mk((n, c) + size, seed), _mk((n, c) + lo, seed + 1)
+    scale, shift = _mk((n, c), seed + 2) * 0.5 + 1.0, _mk((n, c), seed + 3) * 0.3
+    lscale, lshift = _mk((n, c), seed + 4) * 0.5 + 1.0, _mk((n, c), seed + 5) * 0.3
+    bc = lambda v: v[:, :, None, None, None]
+    up = F.interpolate(torch.relu(rnd(low, dtype) * bc(lscale) + bc(lshift)), scale_factor=2, mode="trilinear",
+                       align_corners=False)
+    ds_ref = rnd(torch.relu(rnd(y, dtype) * bc(scale) + bc(shift)) + up, dtype)
+    ybuf, yv = _wide(y, dtype, pitch, lead)
+    lbuf, lv = _wide(low, dtype, pitch, lead)
+    dbuf, dv = _wide(torch.zeros_like(y), dtype, pitch, lead)
+    po = torch.empty((n,) + lo + (c,), dtype=TDT[dtype], device=DEV)
+    idx = torch.empty(po.shape, dtype=torch.uint8, device=DEV)
+    dev = [t.to(DEV).contiguous() for t in (scale, shift, lscale, lshift)]
+    check(lib().hdf_op_enc_tail_up(dtype, ptr(yv), pitch, ptr(dev[0]), ptr(dev[1]), ptr(lv), pitch, ptr(dev[2]), ptr(dev[3]),
+                                   ptr(dv), pitch, ptr(po), c, ptr(idx), n, c, *lo, st()), "enc_tail_up")
+    torch.cuda.synchronize()
+    got = dbuf[..., lead:lead + c].permute(0, 4, 1, 2, 3).float().cpu()
+    assert rel_err(got, ds_ref) < TOL[dtype]
+    po2, _ = F.max_pool3d(got, 2, return_indices=True)
+    assert bool((from_cl(po) == po2).all())
+    if pitch > c:   # the channels outside the slice are untouched
+        rest = torch.cat([dbuf[..., :lead], dbuf[..., lead + c:]], -1)
+        assert bool((rest == 3.0).all())
+
+
+@settings(**CFG)
 @given(dtype=hs.sampled_from([F32, BF16]), size=ragged, n=hs.integers(1, 2), c16=hs.integers(1, 8), ncls=hs.integers(2, 8),
        xf=hs.booleans(), seed=hs.integers(0, 10 ** 6))
 def test_head_random(dtype, size, n, c16, ncls, xf, seed):
