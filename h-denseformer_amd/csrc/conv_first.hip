@@ -265,6 +265,189 @@ __global__ __launch_bounds__(256) void conv_first_kernel(ConvFirstArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ weight gradient
+// dW[co][ci][tap] = sum over (sample, voxel) of dy[voxel][co] * x[voxel + tap][ci], the same tap-packed K seen from the
+// other side: a 32 x 32 x 16 MFMA contracts 16 VOXELS, M = co, N = (tap, ci) = 108 -> 128: four N-blocks, one per wave, for
+// 1/6.75 of the matrix instructions of the generic kernel (27 taps x a 32-channel block of which 4 channels are real).
+// Per 2 x 8 x 8 tile: the input box and the dy rows go to LDS (registers loaded a tile ahead), every (voxel, tap) pair is
+// copied from the box into the voxel's im2col row (320-byte pitch: the four voxel rows x 16 dwords a half-wave's
+// ds_read_b64_tr_b16 touches then tile the 64 banks), and both MFMA operands come out of LDS through transposed reads
+// (lane roles as in conv_wgrad2_kernel).  60 KB of LDS, ~120 registers: two workgroups per CU, and room for the
+// transformer branch's kernels beside it (the generic kernel: 110 KB, one per CU).  Each workgroup leaves one fp32
+// partial [Cout][128]; wgrad_first_reduce_kernel sums them in a fixed order into the torch layout.
+constexpr int WF_TD = 2, WF_VOX = WF_TD * CF_TH * CF_TW, WF_PITCH = 320;
+constexpr int WF_BD = WF_TD + 2, WF_BH = CF_TH + 2, WF_BW = CF_TW + 2, WF_BOX = WF_BD * WF_BH * WF_BW;
+
+struct WgradFirstArgs {
+  const void* dy;      // [N][D][H][W] rows of dy_pitch elements, SC = Cout channels used
+  int64_t dy_pitch;
+  int SC;
+  const void* x;       // the layer's input, x_pitch elements per voxel, the first 4 read
+  int64_t x_pitch;
+  int Cin, N, D, H, W;
+  float* partials;     // [gridDim.y * gridDim.x][SCp][128]
+  int SCp;
+};
+
+template <typename T, int MB>
+__global__ __launch_bounds__(256) void wgrad_first_kernel(WgradFirstArgs a) {
+  __shared__ __attribute__((aligned(16))) char s_col[WF_VOX * WF_PITCH];
+  __shared__ __attribute__((aligned(16))) char s_dy[2][WF_VOX * 64 * MB];
+  __shared__ u32x2 s_box[WF_BOX];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = blockIdx.y;
+  const int ntz = (a.D + WF_TD - 1) / WF_TD, nty = (a.H + CF_TH - 1) / CF_TH, ntx = (a.W + CF_TW - 1) / CF_TW;
+  const int ntile = ntz * nty * ntx, G = gridDim.x;
+  const T* const xin = reinterpret_cast<const T*>(a.x) + (int64_t)n * a.D * a.H * a.W * a.x_pitch;
+  const T* const dyin = reinterpret_cast<const T*>(a.dy) + (int64_t)n * a.D * a.H * a.W * a.dy_pitch;
+  const int xp = (int)a.x_pitch, yp = (int)a.dy_pitch;
+  constexpr int ROWB = 64 * MB;             // bytes of a dy row in LDS
+  constexpr int NBX = (WF_BOX + 255) / 256;  // box slots per thread (2)
+  constexpr int NDY = WF_VOX * (ROWB / 16) / 256;  // 16-byte dy chunks per thread (2 MB)
+  auto tile_origin = [&](int t, int& z0, int& y0, int& x0) {
+    const int tx = t % ntx, ty = (t / ntx) % nty, tz = t / (ntx * nty);
+    z0 = tz * WF_TD, y0 = ty * CF_TH, x0 = tx * CF_TW;
+  };
+  // ---- per-thread staging slots
+  int sbz[NBX], sby[NBX], sbx[NBX];
+#pragma unroll
+  for (int j = 0; j < NBX; j++) {
+    const int sl = min(tid + 256 * j, WF_BOX - 1);
+    sbz[j] = sl / (WF_BH * WF_BW), sby[j] = (sl / WF_BW) % WF_BH, sbx[j] = sl % WF_BW;
+  }
+  u32x2 pfb[NBX];
+  u32x4 pfd[NDY];
+  unsigned pf_ok = 0;  // bits 0..NBX-1: box slot inside the volume; bits 8..: dy chunk valid
+  auto prefetch = [&](int t) __attribute__((always_inline)) {
+    int z0, y0, x0;
+    tile_origin(t, z0, y0, x0);
+#pragma unroll
+    for (int j = 0; j < NBX; j++) {
+      const int z = z0 - 1 + sbz[j], y = y0 - 1 + sby[j], x = x0 - 1 + sbx[j];
+      const bool ok = (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+      const int off = ((min(max(z, 0), a.D - 1) * a.H + min(max(y, 0), a.H - 1)) * a.W + min(max(x, 0), a.W - 1)) * xp;
+      pfb[j] = *reinterpret_cast<const u32x2*>(xin + off);
+      pf_ok = ok ? (pf_ok | (1u << j)) : (pf_ok & ~(1u << j));
+    }
+#pragma unroll
+    for (int j = 0; j < NDY; j++) {
+      const int c = tid + 256 * j, v = c / (ROWB / 16), ch = (c - v * (ROWB / 16)) * 8;
+      const int z = z0 + (v >> 6), y = y0 + ((v >> 3) & 7), x = x0 + (v & 7);
+      const bool ok = z < a.D && y < a.H && x < a.W && ch < a.SC;
+      const int off = ((min(z, a.D - 1) * a.H + min(y, a.H - 1)) * a.W + min(x, a.W - 1)) * yp + min(ch, a.SC - 8);
+      pfd[j] = *reinterpret_cast<const u32x4*>(dyin + off);
+      pf_ok = ok ? (pf_ok | (256u << j)) : (pf_ok & ~(256u << j));
+    }
+  };
+  auto commit = [&](int par) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < NBX; j++) {
+      const bool ok = (pf_ok >> j) & 1u;
+      if (tid + 256 * j < WF_BOX) s_box[tid + 256 * j] = u32x2{ok ? pfb[j][0] : 0u, ok ? pfb[j][1] : 0u};
+    }
+#pragma unroll
+    for (int j = 0; j < NDY; j++) {
+      const bool ok = (pf_ok >> (8 + j)) & 1u;
+      u32x4 v = pfd[j];
+#pragma unroll
+      for (int k = 0; k < 4; k++) v[k] = ok ? v[k] : 0u;
+      *reinterpret_cast<u32x4*>(s_dy[par] + (tid + 256 * j) * 16) = v;
+    }
+  };
+  // ---- im2col rows: thread (voxel v, half): taps [14 half, 14 half + 14) of voxel v
+  const int v = tid & (WF_VOX - 1), half = tid >> 7;
+  const int lx = v & 7, ly = (v >> 3) & 7, lz = v >> 6;
+  char* const my_row = s_col + v * WF_PITCH;
+  if (half == 0) {
+#pragma unroll
+    for (int b = 216; b < 256; b += 8) *reinterpret_cast<u32x2*>(my_row + b) = u32x2{0u, 0u};  // k = 108..127
+  }
+  const u32x2* const my_box = s_box + (lz * WF_BH + ly) * WF_BW + lx;
+  auto build_rows = [&]() __attribute__((always_inline)) {
+    u32x2 t[14];
+#pragma unroll
+    for (int k = 0; k < 14; k++) {
+      const int tap = min(14 * half + k, 26);
+      t[k] = my_box[((tap / 9) * WF_BH + (tap / 3) % 3) * WF_BW + tap % 3];
+    }
+#pragma unroll
+    for (int k = 0; k < 14; k++) {
+      const int tap = min(14 * half + k, 26);
+      *reinterpret_cast<u32x2*>(my_row + 8 * tap) = t[k];   // (half 1 writes tap 26 twice)
+    }
+  };
+  // ---- transposed-read lane roles (conv_wgrad2_kernel): 16 lanes cover 4 voxel rows x 16 channels, lane i16 receives
+  // channel cb + i16 of the 4 voxels
+  const int g4 = lane >> 4, i16 = lane & 15, q = i16 >> 2, p4 = i16 & 3, hh = g4 >> 1, cb = (g4 & 1) * 16;
+  const int colb = (cb + 4 * p4) * 2;
+  using lds_s16x4 = s16x4 __attribute__((address_space(3)));
+  auto tr_read = [&](const char* p) {
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p));
+  };
+  f32x16 acc[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[mb][i] = 0.f;
+
+  int t = blockIdx.x, par = 0;
+  if (t < ntile) {
+    prefetch(t);
+    commit(0);
+    prefetch(min(t + G, ntile - 1));
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  for (; t < ntile; t += G) {
+    build_rows();
+    WS_BARRIER();   // rows complete; the box is free
+    if (t + G < ntile) commit(par ^ 1);
+    prefetch(min(t + 2 * G, ntile - 1));
+    const char* const dyb = s_dy[par];
+#pragma unroll
+    for (int ks = 0; ks < WF_VOX / 16; ks++) {
+      const int row0 = 16 * ks + 8 * hh + q;
+      const u32x2 b0 = tr_read(s_col + row0 * WF_PITCH + 64 * wave + colb);
+      const u32x2 b1 = tr_read(s_col + (row0 + 4) * WF_PITCH + 64 * wave + colb);
+      const u32x4 bf = {b0[0], b0[1], b1[0], b1[1]};
+#pragma unroll
+      for (int mb = 0; mb < MB; mb++) {
+        const u32x2 a0 = tr_read(dyb + row0 * ROWB + 64 * mb + colb);
+        const u32x2 a1 = tr_read(dyb + (row0 + 4) * ROWB + 64 * mb + colb);
+        Mma<T>::run(u32x4{a0[0], a0[1], a1[0], a1[1]}, bf, acc[mb]);
+      }
+    }
+    par ^= 1;
+    WS_BARRIER();   // every wave is done with the rows and this dy buffer; the next box / dy are complete
+  }
+  // ---- this workgroup's partial: rows co = 32 mb + (i & 3) + 8 (i >> 2) + 4 h, columns 32 wave + (lane & 31)
+  float* const part = a.partials + ((int64_t)blockIdx.y * G + blockIdx.x) * a.SCp * 128;
+  const int h = lane >> 5, col = 32 * wave + (lane & 31);
+#pragma unroll
+  for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+    for (int i = 0; i < 16; i++) part[(32 * mb + (i & 3) + 8 * (i >> 2) + 4 * h) * 128 + col] = acc[mb][i];
+}
+
+// dw[(co * Cin + ci) * 27 + tap] (+)= sum_g partial[g][co][4 tap + ci]   (fixed order: bitwise reproducible)
+__global__ __launch_bounds__(256) void wgrad_first_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw,
+                                                                 int G, int SCp, int SC, int Cin, int accumulate) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= SCp * 128) return;
+  float s0 = 0.f, s1 = 0.f;
+  int g = 0;
+  for (; g + 1 < G; g += 2) {
+    s0 += partials[(int64_t)g * SCp * 128 + idx];
+    s1 += partials[(int64_t)(g + 1) * SCp * 128 + idx];
+  }
+  if (g < G) s0 += partials[(int64_t)g * SCp * 128 + idx];
+  const int co = idx >> 7, k = idx & 127, tap = k >> 2, ci = k & 3;
+  if (co < SC && tap < 27 && ci < Cin) {
+    float* o = dw + ((int64_t)co * Cin + ci) * 27 + tap;
+    *o = accumulate ? *o + (s0 + s1) : (s0 + s1);
+  }
+}
+
 }  // namespace
 
 bool hdf_conv_first_can(int dtype, int Cin, int Cout, int D, int H, int W, int64_t in_pitch) {
@@ -303,6 +486,47 @@ int hdf_launch_conv_first(int dtype, const void* in, int64_t in_pitch, int Cin, 
     else
       hipLaunchKernelGGL((conv_first_kernel<f16_t, 2>), grid, dim3(256), 0, st, a);
   }
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
+bool hdf_wgrad_first_takes(int dtype, int Cin, int Cout, int D, int H, int W, int64_t x_pitch, int64_t dy_pitch) {
+  return hdf_conv_first_can(dtype, Cin, Cout, D, H, W, x_pitch) && Cout % 8 == 0 && dy_pitch % 8 == 0 &&
+         (int64_t)D * H * W * dy_pitch < ((int64_t)1 << 31) && (int64_t)D * H * W >= 48 * 48 * 48;
+}
+
+int hdf_launch_wgrad_first(int dtype, const void* dy, int64_t dy_pitch, int Cout, const void* x, int64_t x_pitch, int Cin,
+                           int N, int D, int H, int W, float* dw, int accumulate, void* workspace, size_t workspace_bytes,
+                           hipStream_t st) {
+  HDF_CHECK_ARG(hdf_conv_first_can(dtype, Cin, Cout, D, H, W, x_pitch) && Cout % 8 == 0 && dy_pitch % 8 == 0 &&
+                    (int64_t)D * H * W * dy_pitch < ((int64_t)1 << 31),
+                "wgrad_first: dtype %d Cin %d Cout %d %dx%dx%d", dtype, Cin, Cout, D, H, W);
+  HDF_CHECK_ARG(((reinterpret_cast<uintptr_t>(dy) & 15) | (reinterpret_cast<uintptr_t>(x) & 7)) == 0,
+                "wgrad_first: operands must be 16- / 8-byte aligned");
+  WgradFirstArgs a{};
+  a.dy = dy, a.dy_pitch = dy_pitch, a.SC = Cout, a.x = x, a.x_pitch = x_pitch, a.Cin = Cin;
+  a.N = N, a.D = D, a.H = H, a.W = W, a.SCp = (Cout + 31) / 32 * 32;
+  const int tiles = ((D + WF_TD - 1) / WF_TD) * ((H + CF_TH - 1) / CF_TH) * ((W + CF_TW - 1) / CF_TW);
+  const int64_t per = (int64_t)a.SCp * 128 * sizeof(float);
+  int gx = std::max(1, std::min(tiles, 2 * hdf_cu_budget() / std::max(1, N)));  // 60 KB of LDS: two per CU
+  gx = (int)std::min<int64_t>(gx, (int64_t)workspace_bytes / (per * N));
+  HDF_CHECK_ARG(gx >= 1, "wgrad_first: workspace of %zu bytes too small", workspace_bytes);
+  a.partials = reinterpret_cast<float*>(workspace);
+  const dim3 grid(gx, N);
+  if (a.SCp == 32) {
+    if (dtype == HDF_BF16)
+      hipLaunchKernelGGL((wgrad_first_kernel<bf16_t, 1>), grid, dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((wgrad_first_kernel<f16_t, 1>), grid, dim3(256), 0, st, a);
+  } else {
+    if (dtype == HDF_BF16)
+      hipLaunchKernelGGL((wgrad_first_kernel<bf16_t, 2>), grid, dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((wgrad_first_kernel<f16_t, 2>), grid, dim3(256), 0, st, a);
+  }
+  HDF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(wgrad_first_reduce_kernel, dim3((a.SCp * 128 + 255) / 256), dim3(256), 0, st, a.partials, dw, gx * N,
+                     a.SCp, Cout, Cin, accumulate);
   HDF_LAUNCH_CHECK();
   return HDF_OK;
 }

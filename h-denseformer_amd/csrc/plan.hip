@@ -1042,6 +1042,13 @@ int conv_backward(Exec& e, Conv3& c, const View& dy, const View& in, Xf xf, cons
   w.lg_scale = xf.scale;
   w.lg_shift = xf.shift;
   w.lg_relu = xf.relu;
+#if !defined(HDF_NO_CONV_FIRST) && !defined(HDF_NO_WGRAD_FIRST)  // (A/B builds)
+  // the encoder's first layer: K = (tap, channel) from the other side, csrc/conv_first.hip
+  if (c.Cin <= 4 && !xf.scale && hdf_wgrad_first_takes(p->dtype, c.Cin, c.Cout, d[0], d[1], d[2], in.pitch, dy.pitch)) {
+    HDF_TRY(hdf_launch_wgrad_first(p->dtype, e.at(dy), dy.pitch, c.Cout, e.at(in), in.pitch, c.Cin, e.B, d[0], d[1], d[2],
+                                   e.G(c.w), 0, e.ws + p->wgrad_ws, p->wgrad_ws_bytes, e.wgrad_stream()));
+  } else
+#endif
   HDF_TRY(hdf_launch_wgrad(p->dtype, 1, w, e.G(c.w), c.Cout, c.Cin, 0, e.ws + p->wgrad_ws, p->wgrad_ws_bytes,
                            e.wgrad_stream()));
   HDF_TRY(e.wgrad_done(dy));
@@ -1848,6 +1855,13 @@ int hdf_op_conv3d_first(int dtype, const void* in, int64_t in_pitch, int Cin, in
   HDF_CHECK_ARG(in && weight && out, "conv3d_first: null argument");
   return hdf_launch_conv_first(dtype, in, in_pitch, Cin, N, D, H, W, weight, bias, out, out_pitch, Cout, stat_partials,
                                (hipStream_t)stream);
+}
+int hdf_op_conv3d_first_wgrad(int dtype, const void* dy, int64_t dy_pitch, int Cout, const void* x, int64_t x_pitch,
+                              int Cin, int N, int D, int H, int W, float* dweight, int accumulate, void* workspace,
+                              int64_t workspace_bytes, hdf_stream stream) {
+  HDF_CHECK_ARG(dy && x && dweight && workspace, "conv3d_first_wgrad: null argument");
+  return hdf_launch_wgrad_first(dtype, dy, dy_pitch, Cout, x, x_pitch, Cin, N, D, H, W, dweight, accumulate, workspace,
+                                (size_t)workspace_bytes, (hipStream_t)stream);
 }
 int hdf_op_conv3d_wr(int dtype, const void* in, int64_t in_pitch, int Cin, int N, int D, int H, int W,
                      const void* w_packed, const float* bias, const float* in_scale, const float* in_shift, int in_relu,

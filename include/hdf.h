@@ -194,6 +194,12 @@ int hdf_op_conv3d(int dtype, int mode, const void* in, int64_t in_pitch, int Cin
 int hdf_op_conv3d_first(int dtype, const void* in, int64_t in_pitch, int Cin, int N, int D, int H, int W, const float* weight,
                         const float* bias, void* out, int64_t out_pitch, int Cout, float* stat_partials,
                         hdf_stream stream);
+/* ... and its weight gradient: dweight [Cout][Cin][3][3][3] fp32 (+)= sum over samples and voxels of dy (x) shifted x.
+ * dy: channels-last, Cout (a multiple of 8) of dy_pitch channels; x as above; workspace: >= 2 * 256 * round_up(Cout,32) *
+ * 512 bytes of scratch (fp32 partial sums per workgroup, reduced in a fixed order). */
+int hdf_op_conv3d_first_wgrad(int dtype, const void* dy, int64_t dy_pitch, int Cout, const void* x, int64_t x_pitch,
+                              int Cin, int N, int D, int H, int W, float* dweight, int accumulate, void* workspace,
+                              int64_t workspace_bytes, hdf_stream stream);
 /* The same Conv3d(k3,s1,p1) forced through the weights-in-registers kernel (csrc/conv_wr.hip: 16-bit storage, Cin of 32
  * or 64, >= 48^3) whatever the plan's routing rule says; HDF_ERR_UNSUPPORTED for other shapes.  Tests and tools. */
 int hdf_op_conv3d_wr(int dtype, const void* in, int64_t in_pitch, int Cin, int N, int D, int H, int W,

@@ -455,6 +455,35 @@ def test_conv3d_first_layer_tap_packed(dtype, cin, cout, size, n, with_bias):
         assert bool(torch.isnan(out[..., cout:].float()).all())     # channels beyond Cout are not written
 
 
+@pytest.mark.parametrize("dtype", [BF16, F16])
+@pytest.mark.parametrize("cin,cout,size,n", [(4, 32, (8, 16, 24), 2), (4, 32, (5, 9, 11), 1), (1, 16, (4, 8, 8), 2),
+                                             (3, 48, (6, 10, 12), 1), (2, 64, (8, 8, 16), 1), (4, 32, (32, 32, 32), 2)])
+@pytest.mark.parametrize("accumulate", [0, 1])
+def test_conv3d_first_layer_weight_gradient(dtype, cin, cout, size, n, accumulate):
+    """hdf_op_conv3d_first_wgrad (csrc/conv_first.hip): the weight gradient of the encoder's first Conv3d against autograd
+    on the storage-rounded operands (HDenseFormer.py:152-158,190), dy a channel slice of a wider buffer, ragged extents,
+    1..4 input channels, 16..64 filters, overwrite and accumulate."""
+    x = rnd(_mk((n, cin) + size, 61), dtype)
+    dy = rnd(_mk((n, cout) + size, 62), dtype)
+    w = torch.zeros(cout, cin, 3, 3, 3, requires_grad=True)
+    F.conv3d(x, w, None, padding=1).backward(dy)
+    xin = torch.full((n,) + size + (16,), 7.0, dtype=TDT[dtype], device=DEV)
+    xin[..., :4] = 0
+    xin[..., :cin] = x.to(DEV).permute(0, 2, 3, 4, 1).to(TDT[dtype])
+    pitch = cout + 16
+    dyb = torch.full((n,) + size + (pitch,), 5.0, dtype=TDT[dtype], device=DEV)
+    dyb[..., 8:8 + cout] = dy.to(DEV).permute(0, 2, 3, 4, 1).to(TDT[dtype])
+    dyv = dyb.view(-1)[8:]
+    prev = _mk((cout, cin, 3, 3, 3), 63)
+    dw = prev.to(DEV).contiguous() if accumulate else torch.full((cout, cin, 3, 3, 3), float("nan"), device=DEV)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    check(lib().hdf_op_conv3d_first_wgrad(dtype, ptr(dyv), pitch, cout, ptr(xin), 16, cin, n, *size, ptr(dw), accumulate,
+                                          ptr(ws), ws.numel(), st()), "conv3d_first_wgrad")
+    torch.cuda.synchronize()
+    ref = w.grad + (prev if accumulate else 0)
+    assert rel_err(dw.cpu(), ref) < 1e-4
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16, F16])
 @pytest.mark.parametrize("c", [16, 32, 48, 128])
 def test_encoder_tail_vs_torch(dtype, c):
