@@ -37,7 +37,7 @@ struct ConvFirstArgs {
 };
 
 template <typename T, int NB>
-__global__ __launch_bounds__(256) void conv_first_kernel(ConvFirstArgs a) {
+__global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void conv_first_kernel(ConvFirstArgs a) {
   __shared__ __attribute__((aligned(16))) char s_col[CF_VOX * CF_PITCH];
   __shared__ u32x2 s_box[(CF_TD + 2) * (CF_TH + 2) * (CF_TW + 2)];
   __shared__ float s_red[4 * 32 * NB * 2];
@@ -111,14 +111,25 @@ __global__ __launch_bounds__(256) void conv_first_kernel(ConvFirstArgs a) {
       if (tid + 256 * j < BOX) s_box[tid + 256 * j] = u32x2{ok ? pf[j][0] : 0u, ok ? pf[j][1] : 0u};
     }
   };
-  // this thread's im2col row from the box (rows of the previous tile must not be in use any more)
-  const u32x2* const my_box = s_box + (lz * BH + ly) * BW + lx;
+  // the tile's 256 x 27 (voxel, tap) items, tap fastest, dealt to the threads in order: a wave then writes 64 CONSECUTIVE
+  // 8-byte slots of the rows (conflict-free; one voxel per lane put 16 lanes on each bank: rows are 68 dwords apart)
+  unsigned item[27];  // box slot (10 bits) | row byte offset << 10 (one register per item: 54 cost an occupancy step)
+#pragma unroll
+  for (int j = 0; j < 27; j++) {
+    const int i = tid + 256 * j, v = i / 27, tap = i - 27 * v;
+    const int vz = v >> 6, vy = (v >> 3) & 7, vx = v & 7;
+    item[j] = (unsigned)(((vz + tap / 9) * BH + vy + (tap / 3) % 3) * BW + vx + tap % 3) |
+              ((unsigned)(v * CF_PITCH + 8 * tap) << 10);
+  }
   auto build_rows = [&]() __attribute__((always_inline)) {
-    u32x2 v[27];
 #pragma unroll
-    for (int tap = 0; tap < 27; tap++) v[tap] = my_box[((tap / 9) * BH + (tap / 3) % 3) * BW + tap % 3];
+    for (int j0 = 0; j0 < 27; j0 += 9) {   // three rounds of nine: 18 transient registers
+      u32x2 v[9];
 #pragma unroll
-    for (int tap = 0; tap < 27; tap++) *reinterpret_cast<u32x2*>(my_row + 8 * tap) = v[tap];
+      for (int j = 0; j < 9; j++) v[j] = s_box[item[j0 + j] & 1023u];
+#pragma unroll
+      for (int j = 0; j < 9; j++) *reinterpret_cast<u32x2*>(s_col + (item[j0 + j] >> 10)) = v[j];
+    }
   };
 
   float lr1[NB], lr2[NB];
@@ -354,27 +365,29 @@ __global__ __launch_bounds__(256) void wgrad_first_kernel(WgradFirstArgs a) {
       *reinterpret_cast<u32x4*>(s_dy[par] + (tid + 256 * j) * 16) = v;
     }
   };
-  // ---- im2col rows: thread (voxel v, half): taps [14 half, 14 half + 14) of voxel v
   const int v = tid & (WF_VOX - 1), half = tid >> 7;
-  const int lx = v & 7, ly = (v >> 3) & 7, lz = v >> 6;
   char* const my_row = s_col + v * WF_PITCH;
   if (half == 0) {
 #pragma unroll
     for (int b = 216; b < 256; b += 8) *reinterpret_cast<u32x2*>(my_row + b) = u32x2{0u, 0u};  // k = 108..127
   }
-  const u32x2* const my_box = s_box + (lz * WF_BH + ly) * WF_BW + lx;
+  // the 128 x 27 (voxel, tap) items, tap fastest, dealt to the threads in order: consecutive lanes write consecutive
+  // 8-byte slots (one voxel per lane put 16 lanes on each bank: rows are 80 dwords apart)
+  constexpr int NIT = (WF_VOX * 27 + 255) / 256;  // 14 (the last round is half empty)
+  int it_src[NIT], it_dst[NIT];
+#pragma unroll
+  for (int j = 0; j < NIT; j++) {
+    const int i = min(tid + 256 * j, WF_VOX * 27 - 1), vv = i / 27, tap = i - 27 * vv;
+    const int vz = vv >> 6, vy = (vv >> 3) & 7, vx = vv & 7;
+    it_src[j] = ((vz + tap / 9) * WF_BH + vy + (tap / 3) % 3) * WF_BW + vx + tap % 3;
+    it_dst[j] = vv * WF_PITCH + 8 * tap;
+  }
   auto build_rows = [&]() __attribute__((always_inline)) {
-    u32x2 t[14];
+    u32x2 t[NIT];
 #pragma unroll
-    for (int k = 0; k < 14; k++) {
-      const int tap = min(14 * half + k, 26);
-      t[k] = my_box[((tap / 9) * WF_BH + (tap / 3) % 3) * WF_BW + tap % 3];
-    }
+    for (int j = 0; j < NIT; j++) t[j] = s_box[it_src[j]];
 #pragma unroll
-    for (int k = 0; k < 14; k++) {
-      const int tap = min(14 * half + k, 26);
-      *reinterpret_cast<u32x2*>(my_row + 8 * tap) = t[k];   // (half 1 writes tap 26 twice)
-    }
+    for (int j = 0; j < NIT; j++) *reinterpret_cast<u32x2*>(s_col + it_dst[j]) = t[j];   // (the clamped tail rewrites the last item)
   };
   // ---- transposed-read lane roles (conv_wgrad2_kernel): 16 lanes cover 4 voxel rows x 16 channels, lane i16 receives
   // channel cb + i16 of the 4 voxels
@@ -429,22 +442,33 @@ __global__ __launch_bounds__(256) void wgrad_first_kernel(WgradFirstArgs a) {
     for (int i = 0; i < 16; i++) part[(32 * mb + (i & 3) + 8 * (i >> 2) + 4 * h) * 128 + col] = acc[mb][i];
 }
 
-// dw[(co * Cin + ci) * 27 + tap] (+)= sum_g partial[g][co][4 tap + ci]   (fixed order: bitwise reproducible)
+// dw[(co * Cin + ci) * 27 + tap] (+)= sum_g partial[g][co][4 tap + ci]: a workgroup owns 32 consecutive entries, its 8
+// lane groups take every 8th partial (4 loads in flight each), summed through LDS in a fixed order: bitwise reproducible
+// (one thread per entry walking all 512 partials: 103 us of dependent loads)
 __global__ __launch_bounds__(256) void wgrad_first_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw,
                                                                  int G, int SCp, int SC, int Cin, int accumulate) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= SCp * 128) return;
-  float s0 = 0.f, s1 = 0.f;
-  int g = 0;
-  for (; g + 1 < G; g += 2) {
-    s0 += partials[(int64_t)g * SCp * 128 + idx];
-    s1 += partials[(int64_t)(g + 1) * SCp * 128 + idx];
+  __shared__ float red[8][33];
+  const int el = threadIdx.x & 31, gl = threadIdx.x >> 5;
+  const int idx = blockIdx.x * 32 + el;
+  const int64_t per = (int64_t)SCp * 128;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  int g = gl;
+  for (; g + 24 < G; g += 32) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) s[k] += partials[(int64_t)(g + 8 * k) * per + idx];
   }
-  if (g < G) s0 += partials[(int64_t)g * SCp * 128 + idx];
-  const int co = idx >> 7, k = idx & 127, tap = k >> 2, ci = k & 3;
-  if (co < SC && tap < 27 && ci < Cin) {
-    float* o = dw + ((int64_t)co * Cin + ci) * 27 + tap;
-    *o = accumulate ? *o + (s0 + s1) : (s0 + s1);
+  for (; g < G; g += 8) s[0] += partials[(int64_t)g * per + idx];
+  red[gl][el] = (s[0] + s[1]) + (s[2] + s[3]);
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) t += red[k][el];
+    const int co = idx >> 7, k = idx & 127, tap = k >> 2, ci = k & 3;
+    if (co < SC && tap < 27 && ci < Cin) {
+      float* o = dw + ((int64_t)co * Cin + ci) * 27 + tap;
+      *o = accumulate ? *o + t : t;
+    }
   }
 }
 
@@ -525,7 +549,7 @@ int hdf_launch_wgrad_first(int dtype, const void* dy, int64_t dy_pitch, int Cout
       hipLaunchKernelGGL((wgrad_first_kernel<f16_t, 2>), grid, dim3(256), 0, st, a);
   }
   HDF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(wgrad_first_reduce_kernel, dim3((a.SCp * 128 + 255) / 256), dim3(256), 0, st, a.partials, dw, gx * N,
+  hipLaunchKernelGGL(wgrad_first_reduce_kernel, dim3(a.SCp * 128 / 32), dim3(256), 0, st, a.partials, dw, gx * N,
                      a.SCp, Cout, Cin, accumulate);
   HDF_LAUNCH_CHECK();
   return HDF_OK;
