@@ -116,3 +116,21 @@ for size, C in ((128, 32),):
     by = y.numel() * 2 * 2 + low.numel() * 2 + po.numel() * 3
     print(f"enc_tail_up {C}ch @{size}^3: {t:7.1f} us  {by / t / 1e6:6.2f} TB/s")
 
+# max-pool backward into the complete ds gradient + first pass of the InstanceNorm backward (the launch in front of the
+# backward's fork at level 0)
+for size, C in ((128, 32), (64, 64)):
+    vox = size ** 3
+    h = size // 2
+    g = torch.randn(N, vox // 8, C, device=dev).to(torch.bfloat16)
+    ix = torch.randint(0, 8, (N, vox // 8, C), device=dev, dtype=torch.uint8)
+    din = torch.randn(N, vox, C, device=dev).to(torch.bfloat16)
+    y = torch.randn(N, vox, C, device=dev).to(torch.bfloat16)
+    sc, sh = torch.rand(N, C, device=dev) + 0.5, torch.randn(N, C, device=dev) * 0.1
+    mu, rs = torch.randn(N, C, device=dev) * 0.1, torch.rand(N, C, device=dev) + 0.5
+    rows = lib().hdf_op_maxpool_bwd_in_rows(C, h, h, h)
+    part = torch.empty(N, rows, C, 2, device=dev)
+    t = med(lambda: check(lib().hdf_op_maxpool_bwd_in(BF16, ptr(g), C, ptr(ix), ptr(din), C, ptr(y), C, ptr(sc), ptr(sh), ptr(mu),
+                                                      ptr(rs), ptr(part), N, C, h, h, h, st), "maxpool_bwd_in"))
+    by = din.numel() * 2 * 2 + y.numel() * 2 + g.numel() * 3
+    print(f"maxpool_bwd_in {C}ch @{size}^3: {t:7.1f} us  {by / t / 1e6:6.2f} TB/s")
+
