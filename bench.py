@@ -256,14 +256,31 @@ def main():
     # wall clock around EXACTLY K steps between two barrier + synchronize fences (the contract's `value`), plus a HIP
     # event after every step on the stream the kernels run on: their median is the per-step device time
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+    # the dominant conv launch INSIDE the timed steps: the library records one event pair per step around it
+    # (hdf_plan_set_probe); read back after the closing fence
+    probes, plan_h = [], None
+    if world == 1 and not a.no_roofline:
+        from hdf_rt._lib import check as _check, lib as _lib
+        plan_h = net._last_rt.plan.h
+        for _ in range(a.steps):
+            pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            pair[0].record(), pair[1].record()          # torch creates the HIP event at the first record
+            probes.append(pair)
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     evs[0].record()
     for k in range(a.steps):
+        if probes:
+            _check(_lib().hdf_plan_set_probe(plan_h, probes[k][0].cuda_event, probes[k][1].cuda_event), "set_probe")
         loss = step()
         evs[k + 1].record()
     t_enqueued = time.perf_counter() - t0          # host side only: all K steps issued (the GPU is still working)
     fence()
     dt = time.perf_counter() - t0
+    in_step_ms = None
+    if probes:
+        _check(_lib().hdf_plan_set_probe(plan_h, None, None), "set_probe")
+        in_step_ms = sorted(p0.elapsed_time(p1) for p0, p1 in probes)
     raw_steps = [evs[k].elapsed_time(evs[k + 1]) for k in range(a.steps)]
     per_step = sorted(raw_steps)
     median_ms = per_step[len(per_step) // 2]
@@ -292,6 +309,16 @@ def main():
         }
         if world == 1 and not a.no_roofline:
             rec["roofline"] = roofline_dominant_kernel(dev)
+            if in_step_ms:
+                # the same launch as it runs inside the timed steps (HIP events recorded by the library around it, one
+                # pair per step): `frac` above stays the back-to-back figure of the earlier rounds, this is what the
+                # kernel does in the workload (the chip is not at its power cap between two launches of a step)
+                ms_in = sum(in_step_ms) / len(in_step_ms)
+                fl = rec["roofline"]["flops_per_launch"]
+                rec["roofline"]["in_step"] = {
+                    "avg_launch_ms": ms_in, "median_ms": in_step_ms[len(in_step_ms) // 2], "min_ms": in_step_ms[0],
+                    "max_ms": in_step_ms[-1], "launches": len(in_step_ms),
+                    "achieved": fl / (ms_in * 1e-3) / 1e12, "frac": fl / (ms_in * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS}
         if world == 1:
             if not a.no_cpu_baseline:
                 del net, opt

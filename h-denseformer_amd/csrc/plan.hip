@@ -197,6 +197,8 @@ struct hdf_plan {
   size_t ev_next = 0;
   // "gradient bucket k is final" (hdf_backward_events): recorded on whichever stream of the call finishes the bucket
   hipEvent_t bucket_ev[3] = {nullptr, nullptr, nullptr};
+  // hdf_plan_set_probe: caller-owned events recorded around the dominant conv launch of the forward (measurement only)
+  hipEvent_t probe_start = nullptr, probe_stop = nullptr;
   ~hdf_plan() {
     for (hipEvent_t ev : bucket_ev)
       if (ev) (void)hipEventDestroy(ev);
@@ -1396,7 +1398,16 @@ static int forward3d(hdf_plan* p, const float* x, const float* params, void* wor
   for (int k = 2; k >= 0; k--) {
     View up_out = subview(p, p->cat[k], 0, ch[k]);
     HDF_TRY(convt_forward(e, p->upc[k], *dec_in, dec_xf, up_out));
+    const bool probe = k == 0 && p->probe_start && p->probe_stop;   // block_1_1_right: bench.py's roofline kernel
+    if (probe && hipEventRecord(p->probe_start, e.st) != hipSuccess) {
+      hdf_set_error("probe: hipEventRecord failed");
+      return HDF_ERR_HIP;
+    }
     HDF_TRY(conv_forward(e, p->dec[k][0], p->cat[k], none));
+    if (probe && hipEventRecord(p->probe_stop, e.st) != hipSuccess) {
+      hdf_set_error("probe: hipEventRecord failed");
+      return HDF_ERR_HIP;
+    }
     HDF_TRY(conv_forward(e, p->dec[k][1], p->dec[k][0].y, xf_of(e, p->dec[k][0])));
     dec_in = &p->dec[k][1].y;
     dec_xf = xf_of(e, p->dec[k][1]);
@@ -1437,6 +1448,12 @@ int hdf_backward_events(hdf_plan* p, const float* x, const float* params, void* 
   }
   return backward_any(p, x, params, workspace, workspace_bytes, dout0, dout1, dout2, dout3, grads, batch, 7, stream,
                       p->bucket_ev);
+}
+
+int hdf_plan_set_probe(hdf_plan* p, void* ev_start, void* ev_stop) {
+  HDF_CHECK_ARG(p && ((ev_start == nullptr) == (ev_stop == nullptr)), "plan_set_probe: both events or none");
+  p->probe_start = (hipEvent_t)ev_start, p->probe_stop = (hipEvent_t)ev_stop;
+  return HDF_OK;
 }
 
 int hdf_stream_wait_event(hdf_stream stream, void* event) {

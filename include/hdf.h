@@ -92,6 +92,11 @@ int hdf_backward_stages(hdf_plan* p, const float* x, const float* params, void* 
 int hdf_backward_events(hdf_plan* p, const float* x, const float* params, void* workspace, int64_t workspace_bytes,
                         const void* dout0, const void* dout1, const void* dout2, const void* dout3, float* grads,
                         int batch, hdf_stream stream, void** bucket_events /* [3] hipEvent_t out */);
+/* Measurement hook: every following hdf_forward on this plan records ev_start immediately before and ev_stop immediately
+ * after the launch of the forward's dominant convolution (block_1_1_right, 64 -> 32 channels at full resolution: the
+ * kernel bench.py's `roofline` object reports) on the caller's stream.  Two caller-owned HIP events created with timing
+ * enabled; NULL, NULL switches it off.  The launch itself is unchanged. */
+int hdf_plan_set_probe(hdf_plan* p, void* ev_start, void* ev_stop);
 /* hipStreamWaitEvent(stream, event) for callers that hold streams and events as opaque handles */
 int hdf_stream_wait_event(hdf_stream stream, void* event);
 

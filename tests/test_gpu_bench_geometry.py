@@ -387,3 +387,34 @@ def test_weight_gradients_on_the_side_stream_are_reproducible():
     for n in runs[0]:
         if runs[0][n].norm() > 0:
             assert _rl2(runs[1][n], runs[0][n]) < 1e-4, n
+
+
+def test_probe_events_bracket_the_dominant_conv_launch_and_change_nothing():
+    """hdf_plan_set_probe (include/hdf.h): two caller-owned events recorded around the launch of block_1_1_right's conv in
+    every following forward -- what bench.py's roofline.in_step is measured with.  The logits must be bit-identical with
+    and without the probe, the bracketed time positive and a small part of the forward, and NULL, NULL switches it off."""
+    from hdf_rt._lib import check, lib
+    cfg, batch, tag = (4, 4, 32, (64, 64, 64), 8), 2, "g4_mid_train"
+    net, _ = _build(cfg, "bf16")
+    net.eval()
+    x, _ = _data(cfg, batch, tag)
+    with torch.no_grad():
+        ref = [o.clone() for o in net(x.to(DEV))]
+        rt = net._last_rt
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(), e1.record()
+        torch.cuda.synchronize()
+        check(lib().hdf_plan_set_probe(rt.plan.h, e0.cuda_event, e1.cuda_event), "set_probe")
+        f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        f0.record()
+        got = net(x.to(DEV))
+        f1.record()
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(ref, got))
+        t_conv, t_fwd = e0.elapsed_time(e1), f0.elapsed_time(f1)
+        assert 0.0 < t_conv < 0.5 * t_fwd, (t_conv, t_fwd)
+        check(lib().hdf_plan_set_probe(rt.plan.h, None, None), "set_probe")
+        assert lib().hdf_plan_set_probe(rt.plan.h, e0.cuda_event, None) != 0      # one event without the other: refused
+        got2 = net(x.to(DEV))
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(ref, got2))
