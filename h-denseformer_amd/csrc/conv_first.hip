@@ -298,9 +298,15 @@ struct WgradFirstArgs {
   int Cin, N, D, H, W;
   float* partials;     // [gridDim.y * gridDim.x][SCp][128]
   int SCp;
+  // XF: `dy` holds the gradient w.r.t. the layer's ACTIVATION relu(IN(y)) and the kernel applies the second pass of the
+  // InstanceNorm(+ReLU) backward while it stages a row (in_bwd_apply4_kernel's arithmetic, rounded to the storage type like
+  // the tensor that pass would have written): dy = k1 * ((y*scale+shift > 0 ? da : 0) - ka - (y - mean) * rstd * kb)
+  const void* y;
+  int64_t y_pitch;
+  const float *scale, *shift, *mean, *rstd, *k1, *ka, *kb;  // [N][SC]
 };
 
-template <typename T, int MB>
+template <typename T, int MB, bool XF>
 __global__ __launch_bounds__(256) void wgrad_first_kernel(WgradFirstArgs a) {
   __shared__ __attribute__((aligned(16))) char s_col[WF_VOX * WF_PITCH];
   __shared__ __attribute__((aligned(16))) char s_dy[2][WF_VOX * 64 * MB];
@@ -327,8 +333,21 @@ __global__ __launch_bounds__(256) void wgrad_first_kernel(WgradFirstArgs a) {
     sbz[j] = sl / (WF_BH * WF_BW), sby[j] = (sl / WF_BW) % WF_BH, sbx[j] = sl % WF_BW;
   }
   u32x2 pfb[NBX];
-  u32x4 pfd[NDY];
+  u32x4 pfd[NDY], pfy[XF ? NDY : 1];
   unsigned pf_ok = 0;  // bits 0..NBX-1: box slot inside the volume; bits 8..: dy chunk valid
+  // XF: the thread's dy chunks all cover the same 8 channels (256 is a multiple of the chunks per row)
+  float xsc[XF ? 8 : 1], xsh[XF ? 8 : 1], xmu[XF ? 8 : 1], xrs[XF ? 8 : 1], xk1[XF ? 8 : 1], xka[XF ? 8 : 1], xkb[XF ? 8 : 1];
+  const T* const yin = XF ? reinterpret_cast<const T*>(a.y) + (int64_t)n * a.D * a.H * a.W * a.y_pitch : nullptr;
+  const int ypit = (int)a.y_pitch;
+  if constexpr (XF) {
+    const int ch = min((tid % (ROWB / 16)) * 8, a.SC - 8);
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const int64_t o = (int64_t)n * a.SC + ch + e;
+      xsc[e] = a.scale[o], xsh[e] = a.shift[o], xmu[e] = a.mean[o], xrs[e] = a.rstd[o];
+      xk1[e] = a.k1[o], xka[e] = a.ka[o], xkb[e] = a.kb[o];
+    }
+  }
   auto prefetch = [&](int t) __attribute__((always_inline)) {
     int z0, y0, x0;
     tile_origin(t, z0, y0, x0);
@@ -347,6 +366,10 @@ __global__ __launch_bounds__(256) void wgrad_first_kernel(WgradFirstArgs a) {
       const bool ok = z < a.D && y < a.H && x < a.W && ch < a.SC;
       const int off = ((min(z, a.D - 1) * a.H + min(y, a.H - 1)) * a.W + min(x, a.W - 1)) * yp + min(ch, a.SC - 8);
       pfd[j] = *reinterpret_cast<const u32x4*>(dyin + off);
+      if constexpr (XF) {
+        const int offy = ((min(z, a.D - 1) * a.H + min(y, a.H - 1)) * a.W + min(x, a.W - 1)) * ypit + min(ch, a.SC - 8);
+        pfy[j] = *reinterpret_cast<const u32x4*>(yin + offy);
+      }
       pf_ok = ok ? (pf_ok | (256u << j)) : (pf_ok & ~(256u << j));
     }
   };
@@ -360,6 +383,18 @@ __global__ __launch_bounds__(256) void wgrad_first_kernel(WgradFirstArgs a) {
     for (int j = 0; j < NDY; j++) {
       const bool ok = (pf_ok >> (8 + j)) & 1u;
       u32x4 v = pfd[j];
+      if constexpr (XF) {
+        float g[8], f[8];
+        ST<T>::unpack(v, g);
+        ST<T>::unpack(pfy[j], f);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const float gg = (f[e] * xsc[e] + xsh[e] > 0.f) ? g[e] : 0.f;
+          const float xh = (f[e] - xmu[e]) * xrs[e];
+          g[e] = xk1[e] * (gg - xka[e] - xh * xkb[e]);
+        }
+        v = ST<T>::pack(g);
+      }
 #pragma unroll
       for (int k = 0; k < 4; k++) v[k] = ok ? v[k] : 0u;
       *reinterpret_cast<u32x4*>(s_dy[par] + (tid + 256 * j) * 16) = v;
@@ -521,7 +556,7 @@ bool hdf_wgrad_first_takes(int dtype, int Cin, int Cout, int D, int H, int W, in
 
 int hdf_launch_wgrad_first(int dtype, const void* dy, int64_t dy_pitch, int Cout, const void* x, int64_t x_pitch, int Cin,
                            int N, int D, int H, int W, float* dw, int accumulate, void* workspace, size_t workspace_bytes,
-                           hipStream_t st) {
+                           hipStream_t st, const WgradFirstIn* in_bwd) {
   HDF_CHECK_ARG(hdf_conv_first_can(dtype, Cin, Cout, D, H, W, x_pitch) && Cout % 8 == 0 && dy_pitch % 8 == 0 &&
                     (int64_t)D * H * W * dy_pitch < ((int64_t)1 << 31),
                 "wgrad_first: dtype %d Cin %d Cout %d %dx%dx%d", dtype, Cin, Cout, D, H, W);
@@ -536,17 +571,33 @@ int hdf_launch_wgrad_first(int dtype, const void* dy, int64_t dy_pitch, int Cout
   gx = (int)std::min<int64_t>(gx, (int64_t)workspace_bytes / (per * N));
   HDF_CHECK_ARG(gx >= 1, "wgrad_first: workspace of %zu bytes too small", workspace_bytes);
   a.partials = reinterpret_cast<float*>(workspace);
+  if (in_bwd) {
+    HDF_CHECK_ARG(in_bwd->y && in_bwd->scale && in_bwd->shift && in_bwd->mean && in_bwd->rstd && in_bwd->k1 && in_bwd->ka &&
+                      in_bwd->kb && in_bwd->y_pitch % 8 == 0 && (reinterpret_cast<uintptr_t>(in_bwd->y) & 15) == 0 &&
+                      (int64_t)D * H * W * in_bwd->y_pitch < ((int64_t)1 << 31),
+                  "wgrad_first: bad InstanceNorm-backward operands");
+    a.y = in_bwd->y, a.y_pitch = in_bwd->y_pitch, a.scale = in_bwd->scale, a.shift = in_bwd->shift, a.mean = in_bwd->mean;
+    a.rstd = in_bwd->rstd, a.k1 = in_bwd->k1, a.ka = in_bwd->ka, a.kb = in_bwd->kb;
+  }
   const dim3 grid(gx, N);
+  auto go = [&](auto t_tag, auto mb_tag) {
+    using T = decltype(t_tag);
+    constexpr int MB = decltype(mb_tag)::value;
+    if (in_bwd)
+      hipLaunchKernelGGL((wgrad_first_kernel<T, MB, true>), grid, dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((wgrad_first_kernel<T, MB, false>), grid, dim3(256), 0, st, a);
+  };
   if (a.SCp == 32) {
     if (dtype == HDF_BF16)
-      hipLaunchKernelGGL((wgrad_first_kernel<bf16_t, 1>), grid, dim3(256), 0, st, a);
+      go(bf16_t{}, std::integral_constant<int, 1>{});
     else
-      hipLaunchKernelGGL((wgrad_first_kernel<f16_t, 1>), grid, dim3(256), 0, st, a);
+      go(f16_t{}, std::integral_constant<int, 1>{});
   } else {
     if (dtype == HDF_BF16)
-      hipLaunchKernelGGL((wgrad_first_kernel<bf16_t, 2>), grid, dim3(256), 0, st, a);
+      go(bf16_t{}, std::integral_constant<int, 2>{});
     else
-      hipLaunchKernelGGL((wgrad_first_kernel<f16_t, 2>), grid, dim3(256), 0, st, a);
+      go(f16_t{}, std::integral_constant<int, 2>{});
   }
   HDF_LAUNCH_CHECK();
   hipLaunchKernelGGL(wgrad_first_reduce_kernel, dim3(a.SCp * 128 / 32), dim3(256), 0, st, a.partials, dw, gx * N,

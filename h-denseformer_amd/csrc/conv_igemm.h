@@ -64,9 +64,17 @@ int hdf_launch_conv_first(int dtype, const void* in, int64_t in_pitch, int Cin, 
                           float* stat_partials, hipStream_t st);
 // the same layer's weight gradient (csrc/conv_first.hip): dw in the torch layout [Cout][Cin][27], fp32
 bool hdf_wgrad_first_takes(int dtype, int Cin, int Cout, int D, int H, int W, int64_t x_pitch, int64_t dy_pitch);
+// in_bwd (optional): `dy` is the gradient w.r.t. the layer's activation relu(IN(y)); the kernel applies the second pass of that
+// InstanceNorm(+ReLU)'s backward (hdf_launch_in_bwd_apply's arithmetic and storage rounding) while it stages the rows, so
+// that pass and the tensor it writes are not needed.  All vectors [N][Cout].
+struct WgradFirstIn {
+  const void* y;
+  int64_t y_pitch;
+  const float *scale, *shift, *mean, *rstd, *k1, *ka, *kb;
+};
 int hdf_launch_wgrad_first(int dtype, const void* dy, int64_t dy_pitch, int Cout, const void* x, int64_t x_pitch, int Cin,
                            int N, int D, int H, int W, float* dw, int accumulate, void* workspace, size_t workspace_bytes,
-                           hipStream_t st);
+                           hipStream_t st, const WgradFirstIn* in_bwd = nullptr);
 bool hdf_conv_wr_can(int dtype, const ConvArgs& a);    // the kernel handles this launch
 bool hdf_conv_wr_takes(int dtype, const ConvArgs& a);  // ... and the plan routes it there
 int hdf_launch_conv_wr(int dtype, const ConvArgs& a, hipStream_t st);

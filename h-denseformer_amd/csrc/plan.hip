@@ -1001,7 +1001,8 @@ int transformer_backward(Exec& e, const float* x) {
 
 // InstanceNorm(+ReLU) backward of conv layer c: da (grad w.r.t. the activation) -> dy (grad w.r.t. raw conv out)
 // pre_blocks > 0: the producer of da (head_backward) already wrote that many partial rows per sample
-int in_backward(Exec& e, const Conv3& c, const View& da, const View& dy, int pre_blocks = 0) {
+// apply = false: only the statistics passes (k1 / ka / kb in e.inbk()); the consumer applies them itself
+int in_backward(Exec& e, const Conv3& c, const View& da, const View& dy, int pre_blocks = 0, bool apply = true) {
   hdf_plan* p = e.p;
   const int64_t vox = p->vox(c.lvl);
   const int blocks = pre_blocks > 0 ? pre_blocks : hdf_in_bwd_blocks(vox, c.Cout);
@@ -1015,6 +1016,7 @@ int in_backward(Exec& e, const Conv3& c, const View& da, const View& dy, int pre
                                      c.Cout, vox, e.st));
   HDF_TRY(hdf_launch_in_bwd_finalize(e.inbp(), blocks, e.B, c.Cout, vox, e.P(c.gamma), e.f(c.st.rstd), k1,
                                      ka, kb, e.G(c.gamma), e.G(c.beta), e.st));
+  if (!apply) return HDF_OK;
   e.wait_readers(dy);  // a side-stream weight gradient may still read this buffer's previous contents
   HDF_TRY(hdf_launch_in_bwd_apply(p->dtype, e.at(da), da.pitch, e.at(c.y), c.y.pitch, e.f(c.st.scale), e.f(c.st.shift),
                                   e.f(c.st.mean), e.f(c.st.rstd), k1, ka, kb, e.at(dy), dy.pitch, e.B, c.Cout, vox,
@@ -1661,11 +1663,31 @@ static int backward3d(hdf_plan* p, const float* x, const float* params, void* wo
     }
     HDF_TRY(in_backward(e, c2, dskip, p->gY[k], pre));
     HDF_TRY(conv_backward(e, c2, p->gY[k], c1.y, xf_of(e, c1), &p->gA[k], 0));
-    HDF_TRY(in_backward(e, c1, p->gA[k], p->gY2[k]));
-    if (k > 0)
-      HDF_TRY(conv_backward(e, c1, p->gY2[k], p->pooled[k - 1], none, &p->dP[k - 1], 0));
-    else
-      HDF_TRY(conv_backward(e, c1, p->gY2[k], p->xin, none, nullptr, 0));
+    bool first_fused = false;
+#if !defined(HDF_NO_CONV_FIRST) && !defined(HDF_NO_WGRAD_FIRST) && !defined(HDF_NO_WGRAD_FIRST_IN)
+    // The first layer has no input gradient: the second pass of its InstanceNorm backward would write dy (268 MB at the
+    // benchmark size) only for the weight gradient to read it back.  wgrad_first_kernel applies that pass to the rows it
+    // stages (from d(activation) and y) instead: one pass over two tensors less on the caller's stream.
+    if (k == 0 && hdf_wgrad_first_takes(p->dtype, c1.Cin, c1.Cout, p->dims[0][0], p->dims[0][1], p->dims[0][2],
+                                        p->xin.pitch, p->gA[k].pitch)) {
+      HDF_TRY(in_backward(e, c1, p->gA[k], p->gY2[k], 0, false));
+      float* kk = e.inbk();
+      const WgradFirstIn fi{e.at(c1.y), c1.y.pitch, e.f(c1.st.scale), e.f(c1.st.shift), e.f(c1.st.mean), e.f(c1.st.rstd),
+                            kk, kk + (size_t)e.B * c1.Cout, kk + (size_t)2 * e.B * c1.Cout};
+      HDF_TRY(hdf_launch_wgrad_first(p->dtype, e.at(p->gA[k]), p->gA[k].pitch, c1.Cout, e.at(p->xin), p->xin.pitch, c1.Cin,
+                                     e.B, p->dims[0][0], p->dims[0][1], p->dims[0][2], e.G(c1.w), 0, e.ws + p->wgrad_ws,
+                                     p->wgrad_ws_bytes, e.wgrad_stream(), &fi));
+      HDF_TRY(e.wgrad_done(p->gA[k]));
+      first_fused = true;
+    }
+#endif
+    if (!first_fused) {
+      HDF_TRY(in_backward(e, c1, p->gA[k], p->gY2[k]));
+      if (k > 0)
+        HDF_TRY(conv_backward(e, c1, p->gY2[k], p->pooled[k - 1], none, &p->dP[k - 1], 0));
+      else
+        HDF_TRY(conv_backward(e, c1, p->gY2[k], p->xin, none, nullptr, 0));
+    }
     // (host order: the ten level-0 launches of the caller's stream first, then the ~100 of the transformer backward)
     if (k == 0 && forked) {
       HDF_TRY(transformer_backward(eb, x));
@@ -1879,6 +1901,16 @@ int hdf_op_conv3d_first_wgrad(int dtype, const void* dy, int64_t dy_pitch, int C
   HDF_CHECK_ARG(dy && x && dweight && workspace, "conv3d_first_wgrad: null argument");
   return hdf_launch_wgrad_first(dtype, dy, dy_pitch, Cout, x, x_pitch, Cin, N, D, H, W, dweight, accumulate, workspace,
                                 (size_t)workspace_bytes, (hipStream_t)stream);
+}
+int hdf_op_conv3d_first_wgrad_in(int dtype, const void* da, int64_t da_pitch, int Cout, const void* y, int64_t y_pitch,
+                                 const float* scale, const float* shift, const float* mean, const float* rstd,
+                                 const float* k1, const float* ka, const float* kb, const void* x, int64_t x_pitch, int Cin,
+                                 int N, int D, int H, int W, float* dweight, int accumulate, void* workspace,
+                                 int64_t workspace_bytes, hdf_stream stream) {
+  HDF_CHECK_ARG(da && x && dweight && workspace, "conv3d_first_wgrad_in: null argument");
+  const WgradFirstIn fi{y, y_pitch, scale, shift, mean, rstd, k1, ka, kb};
+  return hdf_launch_wgrad_first(dtype, da, da_pitch, Cout, x, x_pitch, Cin, N, D, H, W, dweight, accumulate, workspace,
+                                (size_t)workspace_bytes, (hipStream_t)stream, &fi);
 }
 int hdf_op_conv3d_wr(int dtype, const void* in, int64_t in_pitch, int Cin, int N, int D, int H, int W,
                      const void* w_packed, const float* bias, const float* in_scale, const float* in_shift, int in_relu,

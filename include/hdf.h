@@ -205,6 +205,15 @@ int hdf_op_conv3d_first(int dtype, const void* in, int64_t in_pitch, int Cin, in
 int hdf_op_conv3d_first_wgrad(int dtype, const void* dy, int64_t dy_pitch, int Cout, const void* x, int64_t x_pitch,
                               int Cin, int N, int D, int H, int W, float* dweight, int accumulate, void* workspace,
                               int64_t workspace_bytes, hdf_stream stream);
+/* The same with the second pass of the layer's InstanceNorm(+ReLU) backward applied to the rows as they are staged: da is
+ * the gradient w.r.t. the activation relu(IN(y)), and dy = k1 * ((y*scale+shift > 0 ? da : 0) - ka - (y-mean)*rstd*kb)
+ * (rounded to the storage type: what hdf_op_in_bwd's apply pass would have written) is what enters the weight gradient.
+ * The first layer has no input gradient, so dy itself is never needed.  Vectors [N][Cout]. */
+int hdf_op_conv3d_first_wgrad_in(int dtype, const void* da, int64_t da_pitch, int Cout, const void* y, int64_t y_pitch,
+                                 const float* scale, const float* shift, const float* mean, const float* rstd,
+                                 const float* k1, const float* ka, const float* kb, const void* x, int64_t x_pitch, int Cin,
+                                 int N, int D, int H, int W, float* dweight, int accumulate, void* workspace,
+                                 int64_t workspace_bytes, hdf_stream stream);
 /* The same Conv3d(k3,s1,p1) forced through the weights-in-registers kernel (csrc/conv_wr.hip: 16-bit storage, Cin of 32
  * or 64, >= 48^3) whatever the plan's routing rule says; HDF_ERR_UNSUPPORTED for other shapes.  Tests and tools. */
 int hdf_op_conv3d_wr(int dtype, const void* in, int64_t in_pitch, int Cin, int N, int D, int H, int W,

@@ -484,6 +484,37 @@ def test_conv3d_first_layer_weight_gradient(dtype, cin, cout, size, n, accumulat
     assert rel_err(dw.cpu(), ref) < 1e-4
 
 
+@pytest.mark.parametrize("dtype", [BF16, F16])
+@pytest.mark.parametrize("cin,cout,size,n", [(4, 32, (8, 16, 24), 2), (4, 32, (5, 9, 11), 1), (3, 48, (6, 10, 12), 1),
+                                             (2, 64, (8, 8, 16), 2)])
+def test_conv3d_first_layer_weight_gradient_with_the_norm_backward_inside(dtype, cin, cout, size, n):
+    """hdf_op_conv3d_first_wgrad_in: the first layer's weight gradient from d(activation) and y, with the apply pass of the
+    InstanceNorm(+ReLU) backward (unet_ops.hip in_bwd_apply4_kernel) evaluated on the staged rows -- against the two-step
+    path: dy by that formula in torch (rounded to the storage type), then hdf_op_conv3d_first_wgrad on it."""
+    x = rnd(_mk((n, cin) + size, 71), dtype)
+    da, y = rnd(_mk((n, cout) + size, 72), dtype), rnd(_mk((n, cout) + size, 73), dtype)
+    vec = [(_mk((n, cout), 74 + i) * 0.3 + (1.0 if i in (0, 3, 4) else 0.0)).contiguous() for i in range(7)]
+    sc, sh, mu, rs, k1, ka, kb = vec
+    bc = lambda v: v[:, :, None, None, None]
+    gg = torch.where(y * bc(sc) + bc(sh) > 0, da, torch.zeros_like(da))
+    dy = rnd(bc(k1) * (gg - bc(ka) - (y - bc(mu)) * bc(rs) * bc(kb)), dtype)
+    xin = torch.zeros((n,) + size + (16,), dtype=TDT[dtype], device=DEV)
+    xin[..., :cin] = x.to(DEV).permute(0, 2, 3, 4, 1).to(TDT[dtype])
+    cl = lambda t: t.to(DEV).permute(0, 2, 3, 4, 1).to(TDT[dtype]).contiguous()
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    ref = torch.full((cout, cin, 3, 3, 3), float("nan"), device=DEV)
+    dy_cl = cl(dy)
+    check(lib().hdf_op_conv3d_first_wgrad(dtype, ptr(dy_cl), cout, cout, ptr(xin), 16, cin, n, *size, ptr(ref), 0, ptr(ws),
+                                          ws.numel(), st()), "first_wgrad")
+    got = torch.full((cout, cin, 3, 3, 3), float("nan"), device=DEV)
+    da_cl, y_cl = cl(da), cl(y)
+    dev = [v.to(DEV) for v in vec]
+    check(lib().hdf_op_conv3d_first_wgrad_in(dtype, ptr(da_cl), cout, cout, ptr(y_cl), cout, *[ptr(v) for v in dev], ptr(xin),
+                                             16, cin, n, *size, ptr(got), 0, ptr(ws), ws.numel(), st()), "first_wgrad_in")
+    torch.cuda.synchronize()
+    assert rel_err(got.cpu(), ref.cpu()) < 2e-3     # (a value at a rounding tie of the storage type may fall the other way)
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16, F16])
 @pytest.mark.parametrize("c", [16, 32, 48, 128])
 def test_encoder_tail_vs_torch(dtype, c):
