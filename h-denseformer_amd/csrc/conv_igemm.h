@@ -30,6 +30,14 @@ struct ConvArgs {
   float* kpart;
   size_t kpart_bytes;
   int ksplit;            // set by the launcher
+  // Backward statistics (optional, mode 0, 16-bit storage, whole 4x8x8 tiles, CoutP == Cout, no accumulate / split): the
+  // launch computes the gradient w.r.t. the ACTIVATION relu(IN(bs_y)) of the layer below, and stat_partials receives the
+  // first pass of that InstanceNorm(+ReLU)'s backward instead of (sum, sum of squares): per channel (sum g, sum g * xhat),
+  // g = the STORED output where bs_y * bs_scale + bs_shift > 0, xhat = (bs_y - bs_mean) * bs_rstd -- the rows
+  // hdf_launch_in_bwd_reduce would write (WS_STAT_ROWS per sample), without its pass over the two tensors.
+  const void* bs_y;
+  int64_t bs_y_pitch;
+  const float *bs_scale, *bs_shift, *bs_mean, *bs_rstd;   // [N][Cout]
 };
 // split-K scratch a plan keeps per stream
 constexpr size_t HDF_KSPLIT_BYTES = (size_t)16 << 20;
@@ -82,6 +90,8 @@ int hdf_launch_conv(int dtype, int mode /*0 conv s1, 1 conv s2, 2 convT*/, const
 // tiles per sample of the stat partials; row_bytes = Cin*sizeof(storage) selects the kernel variant (pass a
 // large value for the upper bound used to size buffers)
 int hdf_conv_stat_tiles(int mode, int Do, int Ho, int Wo, int row_bytes);
+// can this mode-0 launch take the bs_* fields (else the caller runs hdf_launch_in_bwd_reduce)?
+bool hdf_conv_bwd_stats_ok(int dtype, const ConvArgs& a);
 int hdf_launch_wgrad(int dtype, int stride, WgradArgs a, float* dw, int sc_store, int lc_store, int accumulate,
                      void* workspace, size_t workspace_bytes, hipStream_t st);
 size_t hdf_wgrad_workspace_bytes(int stride, int N, int Ds, int Hs, int Ws, int SC, int LC);

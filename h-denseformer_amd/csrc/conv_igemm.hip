@@ -387,7 +387,7 @@ __device__ __attribute__((aligned(16))) uint32_t g_zero_line[4] = {0u, 0u, 0u, 0
 // (An LDS-DMA staging variant of the transform-free 32-byte-chunk layers -- global_load_lds_dwordx4 instead of the pf
 // registers and ds_write commits -- was built at the end of round 2, measured neutral (536 vs 539 us) and removed in
 // round 3: DESIGN.md section 6d.)
-template <typename T, int CH, int RB, bool XF, int NB>
+template <typename T, int CH, int RB, bool XF, int NB, bool BS = false>
 __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
   constexpr int TD = 4, TH = 8, TW = 8, BD = TD + 2, BH = TH + 2, BW = TW + 2, BOX = BD * BH * BW;
   constexpr int ESZ = sizeof(T), EPC = ST<T>::EPC;
@@ -802,10 +802,16 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
     racc_n = -1;
   };
   // the tile about to be summed belongs to sample n (uniform)
+  // BS (backward statistics, ConvArgs::bs_*): this lane's channel constants of the sample being summed
+  float bsc = 0.f, bsh = 0.f, bmu = 0.f, brs = 0.f;
   auto stats_sample = [&](int n) __attribute__((always_inline)) {
     if (n != racc_n) {
       if (racc_n >= 0) stats_to_row();
       racc_n = n;
+      if constexpr (BS) {
+        const int64_t o = (int64_t)n * a.Cout + min(n0 + r, a.Cout - 1);
+        bsc = a.bs_scale[o], bsh = a.bs_shift[o], bmu = a.bs_mean[o], brs = a.bs_rstd[o];
+      }
     }
   };
 
@@ -846,6 +852,33 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
       float s1 = 0.f, s2 = 0.f;
       T* const obase = out_base(ET, nb);
       if (PLAIN || (full && ch_ok[nb] && !a.accumulate)) {
+        if constexpr (BS) {
+          // the y values of the tile's 32 voxels are requested first, the outputs stored under their latency; the sums
+          // use the STORED (storage-rounded) gradient, as in_bwd_reduce would read it back
+          const T* const ybase = reinterpret_cast<const T*>(a.bs_y) +
+                                 ((((int64_t)ET.n * a.Do + z0) * a.Ho + y0 + 2 * wave) * a.Wo + x0) * a.bs_y_pitch + ch;
+          float yv[2][16];
+#pragma unroll
+          for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+              yv[mb][i] = ST<T>::ld(ybase + ((int64_t)(edz[i >> 2] * a.Ho + mb) * a.Wo + (i & 3) + 4 * ((i >> 2) & 1)) *
+                                                a.bs_y_pitch);
+#pragma unroll
+          for (int mb = 0; mb < 2; mb++) {
+            T* const orow = obase + (int64_t)mb * a.Wo * a.out_pitch;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+              const float v = acc[nb * 2 + mb][i] + bias[nb];
+              ST<T>::st(orow + eoff(i), v);
+              T tmp;
+              ST<T>::st(&tmp, v);
+              const float g = (yv[mb][i] * bsc + bsh > 0.f) ? ST<T>::ld(&tmp) : 0.f;
+              s1 += g;
+              s2 += g * ((yv[mb][i] - bmu) * brs);
+            }
+          }
+        } else {
 #pragma unroll
         for (int mb = 0; mb < 2; mb++) {
           T* const orow = obase + (int64_t)mb * a.Wo * a.out_pitch;
@@ -856,6 +889,7 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
             s1 += v;
             s2 += v * v;
           }
+        }
         }
       } else if (full && ch_ok[nb]) {
         // accumulating launch (the UpConv chain's data gradients add into the skip gradient), whole tile: the 16 old
@@ -2750,6 +2784,14 @@ int launch_ws2(const ConvArgs& a, hipStream_t st) {
   const int tiles = a.N * ceil_div(a.Do, 4) * ceil_div(a.Ho, 8) * ceil_div(a.Wo, 8);
   const int cout_tiles = a.CoutP / (32 * NB);
   const int gx = std::min(tiles, std::max(1, hdf_cu_budget() / cout_tiles));  // one workgroup per CU; the kernel splits the tiles
+  if constexpr (sizeof(T) == 2 && NB == 1 && RB == 64) {   // the level-0 32 -> 32 data gradient (hdf_conv_bwd_stats_ok)
+    if (a.bs_y && !a.in_scale) {
+      hipLaunchKernelGGL((conv_ws2_kernel<T, CH, RB, false, NB, true>), dim3(gx, cout_tiles), dim3(256), 0, st, a);
+      HDF_LAUNCH_CHECK();
+      return HDF_OK;
+    }
+  }
+  HDF_CHECK_ARG(a.bs_y == nullptr, "conv: backward statistics are not available for this launch (hdf_conv_bwd_stats_ok)");
   if (a.in_scale)
     hipLaunchKernelGGL((conv_ws2_kernel<T, CH, RB, true, NB>), dim3(gx, cout_tiles), dim3(256), 0, st, a);
   else
@@ -2884,6 +2926,16 @@ int hdf_conv_weight_layout(int dtype, int mode, int Cin, int Do, int Ho, int Wo)
   if (mode == 0) return ws_cfg(mode, Do, Ho, Wo, rb) ? 0 : 1;  // conv_ws2_kernel stages row-major panels
   if (mode == 1) return 1;                                 // stride-2 gather conv: pipelined path
   return convt_fused_rows(rb) ? 0 : 1;  // transposed conv: convt_fused_kernel reads row-major panels, other widths run per class
+}
+
+bool hdf_conv_bwd_stats_ok(int dtype, const ConvArgs& a) {
+  const int rb = a.Cin * hdf_esz(dtype);
+  return dtype != HDF_F32 && rb == 64 && a.Cout == 32 && a.CoutP == 32 && !a.in_scale && !a.accumulate && !a.split &&
+         a.Do % 4 == 0 && a.Ho % 8 == 0 && a.Wo % 8 == 0 && ws_cfg(0, a.Do, a.Ho, a.Wo, rb) && a.stat_partials &&
+#ifndef HDF_NO_CONV_WR
+         !hdf_conv_wr_takes(dtype, a) &&
+#endif
+         a.Di == a.Do && a.Hi == a.Ho && a.Wi == a.Wo;
 }
 
 int hdf_conv_stat_tiles(int mode, int Do, int Ho, int Wo, int row_bytes) {

@@ -183,6 +183,8 @@ struct hdf_plan {
   size_t tf_F, tf_save, tf_scratch, tf_dF, tf_tape = 0, tf_otape = 0;
   size_t stat_partials, wgrad_ws, inb_partials, inb_k;
   size_t stat_partials2 = 0, inb_partials2 = 0, inb_k2 = 0;  // the same scratch for the branch stream (see Exec::branch)
+  size_t inb_k3 = 0;  // k1 / ka / kb of the first layer's InstanceNorm backward: read by its weight gradient on the SIDE stream,
+                      // i.e. possibly after the caller's stream has run the next in_backward (which reuses inb_k)
   size_t ksplit_ws = 0, ksplit_ws2 = 0;                      // split-K partial tiles of the low-resolution convs, per stream
   size_t wgrad_ws_bytes = 0;
   // backward scratch
@@ -576,6 +578,7 @@ void layout(hdf_plan* p, int B) {
   p->inb_k = bp.take((size_t)3 * B * 8 * nf * sizeof(float));
   p->inb_partials2 = bp.take((size_t)B * 1024 * 8 * nf * 2 * sizeof(float));
   p->inb_k2 = bp.take((size_t)3 * B * 8 * nf * sizeof(float));
+  p->inb_k3 = bp.take((size_t)3 * B * 8 * nf * sizeof(float));
   for (int k = 0; k < 4; k++) {
     p->gA[k] = mkview(p, bp, "", k, ch[k], B);
     p->gY[k] = mkview(p, bp, "", k, ch[k], B);
@@ -1002,11 +1005,13 @@ int transformer_backward(Exec& e, const float* x) {
 // InstanceNorm(+ReLU) backward of conv layer c: da (grad w.r.t. the activation) -> dy (grad w.r.t. raw conv out)
 // pre_blocks > 0: the producer of da (head_backward) already wrote that many partial rows per sample
 // apply = false: only the statistics passes (k1 / ka / kb in e.inbk()); the consumer applies them itself
-int in_backward(Exec& e, const Conv3& c, const View& da, const View& dy, int pre_blocks = 0, bool apply = true) {
+// kbuf: where k1 | ka | kb go (default: the Exec's scratch, overwritten by its next in_backward)
+int in_backward(Exec& e, const Conv3& c, const View& da, const View& dy, int pre_blocks = 0, bool apply = true,
+                float* kbuf = nullptr) {
   hdf_plan* p = e.p;
   const int64_t vox = p->vox(c.lvl);
   const int blocks = pre_blocks > 0 ? pre_blocks : hdf_in_bwd_blocks(vox, c.Cout);
-  float* k = e.inbk();
+  float* k = kbuf ? kbuf : e.inbk();
   float* k1 = k;
   float* ka = k + (size_t)e.B * c.Cout;
   float* kb = k + (size_t)2 * e.B * c.Cout;
@@ -1028,8 +1033,12 @@ int in_backward(Exec& e, const Conv3& c, const View& da, const View& dy, int pre
 // din_colsum (optional, [colsum_C] floats): += the per-channel sums over (sample, voxel) of the first colsum_C channels of
 // the input gradient, taken from the dgrad conv's own InstanceNorm-partials epilogue (fp32 accumulators): the
 // ConvTranspose3d bias gradient of the layer that produced those channels, without a pass over the tensor
+// bs_next / bs_rows (optional): the conv whose InstanceNorm(+ReLU) backward consumes *din next.  Where the data-gradient
+// launch can (hdf_conv_bwd_stats_ok) its epilogue writes the first pass of that backward into e.inbp() and *bs_rows is
+// set to the rows per sample (pass it to in_backward as pre_blocks); else *bs_rows = 0.
 int conv_backward(Exec& e, Conv3& c, const View& dy, const View& in, Xf xf, const View* din, int accumulate,
-                  const View* din2 = nullptr, float* din_colsum = nullptr, int colsum_C = 0) {
+                  const View* din2 = nullptr, float* din_colsum = nullptr, int colsum_C = 0,
+                  const Conv3* bs_next = nullptr, int* bs_rows = nullptr) {
   hdf_plan* p = e.p;
   const int* d = e.dm(c.lvl);
   WgradArgs w{};
@@ -1084,6 +1093,20 @@ int conv_backward(Exec& e, Conv3& c, const View& dy, const View& in, Xf xf, cons
     }
     if (din_colsum) a.stat_partials = e.statp();  // forward scratch, free during backward
     a.kpart = e.kspl(), a.kpart_bytes = HDF_KSPLIT_BYTES;
+    if (bs_rows) *bs_rows = 0;
+#ifndef HDF_NO_CONV_BWD_STATS  // (A/B builds)
+    if (bs_next && bs_rows && !din_colsum && !din2) {
+      ConvArgs b = a;
+      b.stat_partials = e.inbp();
+      b.bs_y = e.at(bs_next->y), b.bs_y_pitch = bs_next->y.pitch;
+      b.bs_scale = e.f(bs_next->st.scale), b.bs_shift = e.f(bs_next->st.shift);
+      b.bs_mean = e.f(bs_next->st.mean), b.bs_rstd = e.f(bs_next->st.rstd);
+      if (bs_next->Cout == a.Cout && hdf_conv_bwd_stats_ok(p->dtype, b)) {
+        a = b;
+        *bs_rows = hdf_conv_stat_tiles(0, d[0], d[1], d[2], a.Cin * p->esz);
+      }
+    }
+#endif
     HDF_TRY(hdf_launch_conv(p->dtype, 0, a, e.st));
     if (din_colsum) {
       const int rows = e.B * hdf_conv_stat_tiles(0, d[0], d[1], d[2], a.Cin * p->esz);
@@ -1597,8 +1620,9 @@ static int backward3d(hdf_plan* p, const float* x, const float* params, void* wo
     int pre = 0;
     HDF_TRY(head_backward(e, p->head[k], douts[k], c2.y, xf_of(e, c2), p->gA[k], k > 0 ? 1 : 0, &c2, &pre));
     HDF_TRY(in_backward(e, c2, p->gA[k], p->gY[k], pre));
-    HDF_TRY(conv_backward(e, c2, p->gY[k], c1.y, xf_of(e, c1), &p->gA[k], 0));
-    HDF_TRY(in_backward(e, c1, p->gA[k], p->gY2[k]));
+    int bsr = 0;  // the data-gradient conv may leave the first pass of c1's InstanceNorm backward behind (level 0)
+    HDF_TRY(conv_backward(e, c2, p->gY[k], c1.y, xf_of(e, c1), &p->gA[k], 0, nullptr, nullptr, 0, &c1, &bsr));
+    HDF_TRY(in_backward(e, c1, p->gA[k], p->gY2[k], bsr));
     // the upconv half of d(cat) is the gradient of upconv_{k+1}'s output: its bias gradient rides on this conv
     float* up_db = e.G(p->upc[k].b);
     if (p->dcat_split[k])
@@ -1662,7 +1686,8 @@ static int backward3d(hdf_plan* p, const float* x, const float* params, void* wo
       }
     }
     HDF_TRY(in_backward(e, c2, dskip, p->gY[k], pre));
-    HDF_TRY(conv_backward(e, c2, p->gY[k], c1.y, xf_of(e, c1), &p->gA[k], 0));
+    int bsr = 0;
+    HDF_TRY(conv_backward(e, c2, p->gY[k], c1.y, xf_of(e, c1), &p->gA[k], 0, nullptr, nullptr, 0, &c1, &bsr));
     bool first_fused = false;
 #if !defined(HDF_NO_CONV_FIRST) && !defined(HDF_NO_WGRAD_FIRST) && !defined(HDF_NO_WGRAD_FIRST_IN)
     // The first layer has no input gradient: the second pass of its InstanceNorm backward would write dy (268 MB at the
@@ -1670,8 +1695,8 @@ static int backward3d(hdf_plan* p, const float* x, const float* params, void* wo
     // stages (from d(activation) and y) instead: one pass over two tensors less on the caller's stream.
     if (k == 0 && hdf_wgrad_first_takes(p->dtype, c1.Cin, c1.Cout, p->dims[0][0], p->dims[0][1], p->dims[0][2],
                                         p->xin.pitch, p->gA[k].pitch)) {
-      HDF_TRY(in_backward(e, c1, p->gA[k], p->gY2[k], 0, false));
-      float* kk = e.inbk();
+      float* kk = e.f(p->inb_k3);
+      HDF_TRY(in_backward(e, c1, p->gA[k], p->gY2[k], bsr, false, kk));
       const WgradFirstIn fi{e.at(c1.y), c1.y.pitch, e.f(c1.st.scale), e.f(c1.st.shift), e.f(c1.st.mean), e.f(c1.st.rstd),
                             kk, kk + (size_t)e.B * c1.Cout, kk + (size_t)2 * e.B * c1.Cout};
       HDF_TRY(hdf_launch_wgrad_first(p->dtype, e.at(p->gA[k]), p->gA[k].pitch, c1.Cout, e.at(p->xin), p->xin.pitch, c1.Cin,
@@ -1682,7 +1707,7 @@ static int backward3d(hdf_plan* p, const float* x, const float* params, void* wo
     }
 #endif
     if (!first_fused) {
-      HDF_TRY(in_backward(e, c1, p->gA[k], p->gY2[k]));
+      HDF_TRY(in_backward(e, c1, p->gA[k], p->gY2[k], bsr));
       if (k > 0)
         HDF_TRY(conv_backward(e, c1, p->gY2[k], p->pooled[k - 1], none, &p->dP[k - 1], 0));
       else
@@ -1861,6 +1886,21 @@ int hdf_op_conv3d(int dtype, int mode, const void* in, int64_t in_pitch, int Cin
   a.stat_partials = stat_partials;
   a.accumulate = accumulate;
   return hdf_launch_conv(dtype, mode, a, (hipStream_t)stream);
+}
+int hdf_op_conv3d_bwd_stats(int dtype, const void* in, int64_t in_pitch, int Cin, int N, int D, int H, int W,
+                            const void* w_packed, void* out, int64_t out_pitch, int Cout, const void* y, int64_t y_pitch,
+                            const float* scale, const float* shift, const float* mean, const float* rstd,
+                            float* partials, hdf_stream stream) {
+  HDF_CHECK_ARG(in && w_packed && out && y && scale && shift && mean && rstd && partials, "conv3d_bwd_stats: null argument");
+  ConvArgs a{};
+  a.in = in, a.in_pitch = in_pitch, a.Cin = Cin, a.N = N;
+  a.Di = a.Do = D, a.Hi = a.Ho = H, a.Wi = a.Wo = W;
+  a.w = w_packed, a.out = out, a.out_pitch = out_pitch, a.Cout = Cout, a.CoutP = round_up(Cout, 32);
+  a.stat_partials = partials;
+  a.bs_y = y, a.bs_y_pitch = y_pitch, a.bs_scale = scale, a.bs_shift = shift, a.bs_mean = mean, a.bs_rstd = rstd;
+  HDF_CHECK_ARG(hdf_conv_bwd_stats_ok(dtype, a), "conv3d_bwd_stats: this launch cannot take the statistics epilogue "
+                "(16-bit storage, 32 -> 32 channels, whole 4x8x8 tiles, >= 48^3)");
+  return hdf_launch_conv(dtype, 0, a, (hipStream_t)stream);
 }
 int hdf_op_conv3d_split(int dtype, const void* in, int64_t in_pitch, int Cin, int N, int D, int H, int W,
                         const void* w_packed, void* out, void* out2, int64_t out_pitch, int Cout, int split,

@@ -62,6 +62,8 @@ _PROTOS = {
     "hdf_op_conv3d_first_wgrad": (_i, [_i, _vp, _i64, _i, _vp, _i64, _i, _i, _i, _i, _i, _vp, _i, _vp, _i64, _vp]),
     "hdf_op_conv3d_first_wgrad_in": (_i, [_i, _vp, _i64, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i,
                                           _i, _i, _i, _i, _vp, _i, _vp, _i64, _vp]),
+    "hdf_op_conv3d_bwd_stats": (_i, [_i, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _i64, _i, _vp, _i64, _vp, _vp, _vp, _vp,
+                                     _vp, _vp]),
     "hdf_op_conv3d_wr": (_i, [_i, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i64, _i, _vp, _i, _vp]),
     "hdf_op_conv3d_stat_tiles": (_i, [_i, _i, _i, _i, _i]),
     "hdf_op_conv3d_split": (_i, [_i, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _i, _vp]),

@@ -222,6 +222,15 @@ int hdf_op_conv3d_wr(int dtype, const void* in, int64_t in_pitch, int Cin, int N
 /* partial rows per sample of stat_partials ([N*rows][Cout rounded up to 32][2] floats: sum, sum of squares) for this
  * layer shape: one row per output tile, or 512 per-workgroup rows when the weights-stationary kernel takes the layer */
 int hdf_op_conv3d_stat_tiles(int dtype, int Cin, int Do, int Ho, int Wo);
+/* hdf_op_conv3d (mode 0) as a data gradient whose epilogue also takes the first pass of the NEXT InstanceNorm(+ReLU)
+ * backward: out is the gradient w.r.t. the activation relu(IN(y)) of the layer below, and partials [N][512][Cout][2] receive
+ * per channel (sum g, sum g * xhat), g = the stored out where y*scale+shift > 0, xhat = (y-mean)*rstd -- the rows
+ * hdf_op_in_bwd's reduce pass would produce from (out, y), without that pass.  16-bit storage, Cin = Cout = 32, extents
+ * multiples of (4, 8, 8) and >= 48^3 (the level-0 data gradients of the plan); other launches are refused. */
+int hdf_op_conv3d_bwd_stats(int dtype, const void* in, int64_t in_pitch, int Cin, int N, int D, int H, int W,
+                            const void* w_packed, void* out, int64_t out_pitch, int Cout, const void* y, int64_t y_pitch,
+                            const float* scale, const float* shift, const float* mean, const float* rstd,
+                            float* partials, hdf_stream stream);
 /* Conv3d(k3,s1,p1) whose output channels [0, split) go to `out` and [split, Cout) to `out2` (two dense buffers of one
  * pitch; split % 32 == 0), the form the plan uses for the gradient of a decoder concat [upconv | skip]
  * (models/HDenseFormer.py:245-253 backward).  With stat_partials ([N * hdf_op_conv3d_stat_tiles][round_up(Cout,32)][2])

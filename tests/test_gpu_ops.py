@@ -515,6 +515,37 @@ def test_conv3d_first_layer_weight_gradient_with_the_norm_backward_inside(dtype,
     assert rel_err(got.cpu(), ref.cpu()) < 2e-3     # (a value at a rounding tie of the storage type may fall the other way)
 
 
+@pytest.mark.parametrize("dtype", [BF16, F16])
+@pytest.mark.parametrize("size,n", [((48, 48, 48), 2), ((52, 48, 56), 1)])
+def test_conv3d_data_gradient_with_the_next_norm_backward_statistics(dtype, size, n):
+    """hdf_op_conv3d_bwd_stats: the 32 -> 32 stride-1 conv as a data gradient whose epilogue writes the first pass of the next
+    InstanceNorm(+ReLU) backward (csrc/conv_igemm.hip conv_ws2_kernel<..., BS>): the output must equal the plain conv's bit for
+    bit, and the partial rows summed over the workgroups must be (sum g, sum g * xhat) of the STORED output."""
+    cin = cout = 32
+    x = _mk((n, cin) + size, 81)
+    w = _mk((cout, cin, 3, 3, 3), 82) * 0.1
+    y = rnd(_mk((n, cout) + size, 83), dtype)
+    sc, sh = _mk((n, cout), 84) * 0.5 + 1.0, _mk((n, cout), 85) * 0.3
+    mu, rs = _mk((n, cout), 86) * 0.2, _mk((n, cout), 87).abs() + 0.5
+    wp = pack_w(w, dtype, cout, cin, 32, cin, cin * 27, 27, 0)
+    x_cl, y_cl = to_cl(x, dtype), to_cl(y, dtype)
+    ref_out, _ = conv3d(dtype, 0, x_cl, cin, wp, cout, stats=True)
+    out = torch.full_like(ref_out, float("nan"))
+    part = torch.full((n, 512, cout, 2), float("nan"), device=DEV)
+    dev = [v.to(DEV).contiguous() for v in (sc, sh, mu, rs)]
+    check(lib().hdf_op_conv3d_bwd_stats(dtype, ptr(x_cl), cin, cin, n, *size, ptr(wp), ptr(out), cout, cout, ptr(y_cl), cout,
+                                        *[ptr(v) for v in dev], ptr(part), st()), "conv3d_bwd_stats")
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref_out)
+    g = from_cl(out).double()
+    bc = lambda v: v.double()[:, :, None, None, None]
+    yd = y.double()
+    gm = torch.where(yd * bc(sc) + bc(sh) > 0, g, torch.zeros_like(g))
+    s = part.double().sum(1).cpu()
+    assert rel_err(s[..., 0], gm.sum((2, 3, 4))) < 1e-4
+    assert rel_err(s[..., 1], (gm * (yd - bc(mu)) * bc(rs)).sum((2, 3, 4))) < 1e-4
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16, F16])
 @pytest.mark.parametrize("c", [16, 32, 48, 128])
 def test_encoder_tail_vs_torch(dtype, c):
