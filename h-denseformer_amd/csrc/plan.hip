@@ -870,9 +870,14 @@ int transformer_forward(Exec& e, const float* x) {
   float* pm = const_cast<float*>(e.params);
   const int64_t rows = (int64_t)p->M * e.B * p->Ntok;
   float* F0 = e.f(p->tf_F);
+#ifdef HDF_PE_FP32  // (A/B builds: the exact fp32 patch embedding in every storage mode)
+  const int PE_LP = 0;
+#else
+  const int PE_LP = p->dtype;
+#endif
   HDF_TRY(tf_patch_embed_fwd(d, x, p->D, p->H, p->W, pm + p->P("attns.0.patch_embeddings.weight"),
                              pm + p->P("attns.0.patch_embeddings.bias"), pm + p->P("attns.0.position_embeddings"), F0,
-                             e.st));
+                             e.st, PE_LP));
   // token kernel, attention, token kernel, ...: between two attention launches ONE kernel finishes the previous
   // dense layer (and, at a block boundary, runs the block's out_layer) and starts the next one
   TfLayerP prev{}, cur{};

@@ -38,7 +38,7 @@ struct TfLayerSave {
 };
 
 int tf_patch_embed_fwd(const TfDims& d, const float* x /*[B][M][D][H][W]*/, int D, int H, int W, const float* wpe,
-                       const float* bpe, const float* pos, float* F /*[rows][DMF]*/, hipStream_t st);
+                       const float* bpe, const float* pos, float* F /*[rows][DMF]*/, hipStream_t st, int lp = 0);
 int tf_patch_embed_bwd(const TfDims& d, const float* x, int D, int H, int W, const float* dF /*[rows][DMF]*/,
                        float* dwpe, float* dbpe, float* dpos, float* scratch /*[rows][DM]*/, hipStream_t st);
 

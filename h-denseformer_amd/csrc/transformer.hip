@@ -550,6 +550,12 @@ __global__ __launch_bounds__(256) void attn_bwd_lp_kernel(int N, int nseq, const
 // order.  The contraction order is free, so lane group g = lane >> 4 owns k in [16 g, 16 g + 16) of a chunk: its A
 // operands are 64 contiguous bytes of one brick row of its token, its B operands 64 contiguous bytes of one row of the
 // Conv3d weight (float4 loads), prefetched one chunk (128 MFMAs = 4096 cycles) ahead.
+// LP = 1 / 2 (the plan's bf16 / f16 storage modes): the operands are rounded to that type and contracted with
+// v_mfma_f32_16x16x16 -- what autocast does to the patch Conv3d (HDenseFormer.py:115-119 under trainer.py:369).  A lane's
+// four consecutive fp32 values of a 16-byte load are exactly the four k of one 16x16x16 step (k = 4 g + e), for A and B
+// alike: one matrix instruction per load pair instead of four, 32 per 64-deep chunk instead of 128 (this launch is the
+// first of the forward's critical chain, and with fp32 steps it is bound by the matrix pipe: 2,048 steps of 32 cycles).
+template <int LP>
 __global__ __launch_bounds__(256) void patch_embed_fwd2_kernel(TfDims d, const float* __restrict__ x, int D, int H,
                                                                int W, const float* __restrict__ wpe,
                                                                const float* __restrict__ bpe,
@@ -590,15 +596,38 @@ __global__ __launch_bounds__(256) void patch_embed_fwd2_kernel(TfDims d, const f
 #pragma unroll
     for (int nt = 0; nt < 4; nt++) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto mma_chunk = [&](int slot) __attribute__((always_inline)) {
+    if constexpr (LP == 0) {
 #pragma unroll
-    for (int s4 = 0; s4 < 4; s4++)
+      for (int s4 = 0; s4 < 4; s4++)
 #pragma unroll
-      for (int e = 0; e < 4; e++)
+        for (int e = 0; e < 4; e++)
+#pragma unroll
+          for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++)
+              acc[mt][nt] =
+                  __builtin_amdgcn_mfma_f32_16x16x4f32(ra[slot][mt][s4][e], rb[slot][nt][s4][e], acc[mt][nt], 0, 0, 0);
+    } else {
+      constexpr int L = LP == 0 ? 1 : LP;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; s4++) {
+        u32x2 pa[2], pb[4];
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++) {
+          const f32x4& v = ra[slot][mt][s4];
+          pa[mt] = LpPack<L>::four(v[0], v[1], v[2], v[3]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) {
+          const f32x4& v = rb[slot][nt][s4];
+          pb[nt] = LpPack<L>::four(v[0], v[1], v[2], v[3]);
+        }
 #pragma unroll
         for (int mt = 0; mt < 2; mt++)
 #pragma unroll
-          for (int nt = 0; nt < 4; nt++)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[slot][mt][s4][e], rb[slot][nt][s4][e], acc[mt][nt], 0, 0, 0);
+          for (int nt = 0; nt < 4; nt++) acc[mt][nt] = LpPack<L>::mma(pa[mt], pb[nt], acc[mt][nt]);
+      }
+    }
   };
   load_chunk(0, 0);
   for (int i = 0; i < NCH; i += 2) {
@@ -739,11 +768,16 @@ int allow_lds(Kern kern, size_t bytes) {
 }  // namespace
 
 int tf_patch_embed_fwd(const TfDims& d, const float* x, int D, int H, int W, const float* wpe, const float* bpe,
-                       const float* pos, float* F, hipStream_t st) {
+                       const float* pos, float* F, hipStream_t st, int lp) {
   // token dim = 4 * n_filters with n_filters % 16 == 0 (plan): a multiple of 64
   HDF_CHECK_ARG(d.DM <= 256 && d.DM % 64 == 0, "patch_embed: token dim %d unsupported (a multiple of 64, <= 256)", d.DM);
-  hipLaunchKernelGGL(patch_embed_fwd2_kernel, dim3(ceil_div(d.B * d.N, 32), d.DM / 64, d.M), dim3(256), 0, st, d, x, D,
-                     H, W, wpe, bpe, pos, F);
+  const dim3 grid(ceil_div(d.B * d.N, 32), d.DM / 64, d.M);
+  if (lp == HDF_BF16)
+    hipLaunchKernelGGL(patch_embed_fwd2_kernel<1>, grid, dim3(256), 0, st, d, x, D, H, W, wpe, bpe, pos, F);
+  else if (lp == HDF_F16)
+    hipLaunchKernelGGL(patch_embed_fwd2_kernel<2>, grid, dim3(256), 0, st, d, x, D, H, W, wpe, bpe, pos, F);
+  else
+    hipLaunchKernelGGL(patch_embed_fwd2_kernel<0>, grid, dim3(256), 0, st, d, x, D, H, W, wpe, bpe, pos, F);
   HDF_LAUNCH_CHECK();
   return HDF_OK;
 }
