@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib")
 OBJ = os.path.join(HERE, "build")
-SOURCES = ["conv_igemm.hip", "conv_wr.hip", "conv_first.hip", "unet_ops.hip", "transformer.hip", "transformer_fused.hip", "loss.hip", "plan.hip"]
+SOURCES = ["conv_igemm.hip", "conv_wr.hip", "conv_first.hip", "unet_ops.hip", "transformer.hip", "transformer_fused.hip", "transformer_chain.hip", "loss.hip", "plan.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # per-file additions.  conv_wr.hip: MFMA results in architectural VGPRs -- its AGPR half holds the 216 weight registers
 # of a wave (left to its heuristic hipcc puts the accumulators there and spills weights to scratch); its tile phase is one

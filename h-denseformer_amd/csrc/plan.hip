@@ -181,6 +181,7 @@ struct hdf_plan {
   View xin, attnall, attnout, at[3] /*at[k] lives at level k*/, cat[3], pooled[3], x4;
   size_t pool_idx[3];
   size_t tf_F, tf_save, tf_scratch, tf_dF, tf_tape = 0, tf_otape = 0;
+  size_t tf_sync = 0;   // arrival counters of the persistent transformer kernels (transformer_chain.hip)
   size_t stat_partials, wgrad_ws, inb_partials, inb_k;
   size_t stat_partials2 = 0, inb_partials2 = 0, inb_k2 = 0;  // the same scratch for the branch stream (see Exec::branch)
   size_t inb_k3 = 0;  // k1 / ka / kb of the first layer's InstanceNorm backward: read by its weight gradient on the SIDE stream,
@@ -481,6 +482,7 @@ void layout(hdf_plan* p, int B) {
   const int64_t rows = (int64_t)p->M * B * p->Ntok;
   p->tf_F = bp.take((size_t)p->nb * rows * p->DMF * sizeof(float));
   p->tf_save = bp.take((size_t)p->nb * 4 * rows * 232 * sizeof(float));
+  p->tf_sync = bp.take(2 * ((size_t)(p->M * B + 1) * 128 + 128));  // forward | backward counters
   p->attnall = mkview(p, bp, "attnall", 4, p->M * p->DM, B);
   conv_bufs(p->deep);
   p->attnout = mkview(p, bp, "attnout", 3, 8 * nf, B);
@@ -864,6 +866,33 @@ TfLayerSave tf_save(const hdf_plan* p, const Exec& e, int b, int l) {
   return s;
 }
 
+// Parameter addressing of the persistent transformer kernels (TfChainP, transformer.h): block-relative offsets of the 13
+// tensors of each of a block's four dense layers and of its out_layer, the same for every block and modality.
+TfChainP tf_chain_params(const hdf_plan* p) {
+  TfChainP c{};
+  c.blk0 = p->P("attns.0.blocks.0.0.layers.0.0.weight");
+  c.blk_stride = p->nb > 1 ? p->P("attns.0.blocks.1.0.layers.0.0.weight") - c.blk0 : 0;
+  TfLayerP q;
+  TfOutP o;
+  float* base = nullptr;
+  for (int l = 0; l < 4; l++) {
+    tf_layer_ptrs(p, base, 0, l, q);
+    float* const f[13] = {q.w0, q.b0, q.ln1g, q.ln1b, q.wqkv, q.wout, q.bout, q.ln2g, q.ln2b, q.w1, q.b1, q.w2, q.b2};
+    for (int k = 0; k < 13; k++) c.loff[l][k] = (int32_t)((f[k] - base) - c.blk0);
+  }
+  tf_out_ptrs(p, base, 0, o);
+  float* const g[4] = {o.wa, o.ba, o.wb, o.bb};
+  for (int k = 0; k < 4; k++) c.ooff[k] = (int32_t)((g[k] - base) - c.blk0);
+  return c;
+}
+// The persistent kernels take the plan's transformer when every 16-token tile of every sequence gets a compute unit of
+// its own (resident together: their per-sequence barriers need that).  HDF_NO_TF_CHAIN=1: the launch chain
+// (tok_fwd / attention / tok_bwd ...) instead -- the third arrangement knob of tests/test_gpu_knobs.py.
+bool tf_use_chain(const hdf_plan* p, int B) {
+  const bool off = getenv("HDF_NO_TF_CHAIN") != nullptr;   // read per call: tests switch it inside one process
+  return !off && tf_chain_supported(tf_dims(p, B));
+}
+
 int transformer_forward(Exec& e, const float* x) {
   hdf_plan* p = e.p;
   TfDims d = tf_dims(p, e.B);
@@ -878,6 +907,9 @@ int transformer_forward(Exec& e, const float* x) {
   HDF_TRY(tf_patch_embed_fwd(d, x, p->D, p->H, p->W, pm + p->P("attns.0.patch_embeddings.weight"),
                              pm + p->P("attns.0.patch_embeddings.bias"), pm + p->P("attns.0.position_embeddings"), F0,
                              e.st, PE_LP));
+  if (tf_use_chain(p, e.B))   // all layers of all blocks in one persistent launch (transformer_chain.hip)
+    return tf_chain_forward(d, tf_chain_params(p), p->nb, pm, F0, e.f(p->tf_save), e.at(p->attnall),
+                            reinterpret_cast<unsigned*>(e.ws + p->tf_sync), p->dtype, e.st);
   // token kernel, attention, token kernel, ...: between two attention launches ONE kernel finishes the previous
   // dense layer (and, at a block boundary, runs the block's out_layer) and starts the next one
   TfLayerP prev{}, cur{};
@@ -1277,6 +1309,24 @@ int hdf_plan_buffer_info(hdf_plan* p, int batch, const char* name, int64_t* byte
   *d = p->dims[v.lvl][0];
   *h = p->dims[v.lvl][1];
   *w = p->dims[v.lvl][2];
+  return HDF_OK;
+}
+
+int hdf_plan_region_info(hdf_plan* p, int batch, const char* name, int64_t* byte_offset, int64_t* bytes) {
+  HDF_CHECK_ARG(p && name && byte_offset && bytes, "region_info: null argument");
+  layout(p, batch);
+  const int64_t rows = (int64_t)p->M * batch * p->Ntok;
+  const std::string n = name;
+  if (n == "tf_F") *byte_offset = (int64_t)p->tf_F, *bytes = (int64_t)p->nb * rows * p->DMF * 4;
+  else if (n == "tf_save") *byte_offset = (int64_t)p->tf_save, *bytes = (int64_t)p->nb * 4 * rows * 232 * 4;
+  else if (n == "tf_sync") *byte_offset = (int64_t)p->tf_sync, *bytes = 2 * ((int64_t)(p->M * batch + 1) * 128 + 128);
+  else if (n == "tf_dF") *byte_offset = (int64_t)p->tf_dF, *bytes = rows * p->DMF * 4;
+  else if (n == "tf_tape") *byte_offset = (int64_t)p->tf_tape, *bytes = (int64_t)p->nb * 4 * rows * TF_TAPE_W * 4;
+  else if (n == "tf_otape") *byte_offset = (int64_t)p->tf_otape, *bytes = (int64_t)p->nb * rows * p->DMF * 4;
+  else {
+    hdf_set_error("region_info: no region named '%s'", name);
+    return HDF_ERR_ARG;
+  }
   return HDF_OK;
 }
 

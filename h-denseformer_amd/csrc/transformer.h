@@ -146,3 +146,21 @@ struct TfTokenBwd {
   float* dh0acc_out = nullptr;      // [rows][32] -> PREB of layer (bp, lp)
 };
 int tf_token_bwd(const TfDims& d, const TfTokenBwd& t, int dtype, hipStream_t st);
+
+// ---- persistent chain kernels (transformer_chain.hip): every dense layer of every block in ONE launch per direction.
+// Parameter addressing of a branch: tensor k of layer l of block b sits at blk0 + b * blk_stride + loff[l][k] floats from the
+// flat parameter (or gradient) buffer's base, + m * mstride for modality m.  loff order = the members of TfLayerP;
+// ooff = the block's out_layer (wa, ba, wb, bb).
+struct TfChainP {
+  int32_t loff[4][13];
+  int32_t ooff[4];
+  int64_t blk0, blk_stride;
+};
+// the launch takes the shape (one workgroup per 16 tokens of a sequence, all resident at once)
+bool tf_chain_supported(const TfDims& d);
+size_t tf_chain_sync_bytes(const TfDims& d);
+// Forward of all nb blocks: reads F0[block 0][:, 0:DM] (the patch embedding), writes every block's feature buffer, the
+// saved tensors of every layer (tf_save layout) and the channels-last attnall tensor.  `sync`: tf_chain_sync_bytes of
+// device memory owned by the caller (zeroed by the call on `st`).
+int tf_chain_forward(const TfDims& d, const TfChainP& cp, int nb, const float* params, float* F0, float* save,
+                     void* attnall, unsigned* sync, int dtype, hipStream_t st);

@@ -83,6 +83,11 @@ __device__ __forceinline__ f32x4 attn_scores(const float* sKf, int j0, float bq,
 
 __global__ __launch_bounds__(256) void attn_fwd_kernel(int N, const float* __restrict__ qkv, float* __restrict__ ob,
                                                        float* __restrict__ lse) {
+  // Every sum of two products below is written as an explicit fma of one product into the other and contraction is
+  // switched off: left to the compiler, `l * ca + l2 * cb` became fma(l, ca, l2 * cb) in one merge round and two
+  // multiplies + an add in the next (SLP-vectorised products), i.e. the rounding depended on the surrounding code -- and
+  // the persistent kernel of transformer_chain.hip must reproduce this kernel bit for bit.
+#pragma clang fp contract(off)
   HDF_CHAIN_PRIO();
   extern __shared__ float4 skv[];
   const int NP = attn_rows(N);
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(int N, const float* __res
       b23 = __builtin_elementwise_fma(pp, hi2(v[u]), b23);
     }
     const f2 cc = {c, c};
-    l = l * c + ps;
+    l = __builtin_fmaf(l, c, ps);
     a01 = __builtin_elementwise_fma(a01, cc, b01);
     a23 = __builtin_elementwise_fma(a23, cc, b23);
     mx = mn;
@@ -151,16 +156,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(int N, const float* __res
     const float mn = fmaxf(mx, m2);
     const float mr = (mn == -INFINITY) ? 0.f : mn;
     const float ca = __builtin_amdgcn_exp2f(mx - mr), cb = __builtin_amdgcn_exp2f(m2 - mr);
-    l = l * ca + l2 * cb;
-    a01 = a01 * ca + b01 * cb;
-    a23 = a23 * ca + b23 * cb;
+    const f2 ca2 = {ca, ca}, cb2 = {cb, cb};
+    l = __builtin_fmaf(l, ca, l2 * cb);
+    a01 = __builtin_elementwise_fma(a01, ca2, b01 * cb2);
+    a23 = __builtin_elementwise_fma(a23, ca2, b23 * cb2);
     mx = mn;
   }
   if (ok && g == 0) {
     const float inv = 1.f / l;
     *reinterpret_cast<float4*>(ob + (rowbase + qi) * 32 + head * 4) =
         make_float4(a01.x * inv, a01.y * inv, a23.x * inv, a23.y * inv);
-    lse[(rowbase + qi) * 8 + head] = mx * LN2 + __logf(l);  // natural-log units, as the backward expects
+    lse[(rowbase + qi) * 8 + head] = __builtin_fmaf(mx, LN2, __logf(l));  // natural-log units, as the backward expects
   }
 }
 

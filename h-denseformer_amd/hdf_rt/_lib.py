@@ -27,6 +27,7 @@ _PROTOS = {
     "hdf_plan_inference_workspace_bytes": (_i64, [_vp, _i]),
     "hdf_plan_buffer_info": (_i, [_vp, _i, C.c_char_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i),
                                   C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "hdf_plan_region_info": (_i, [_vp, _i, C.c_char_p, C.POINTER(_i64), C.POINTER(_i64)]),
     "hdf_forward": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i, _i, _u64, _vp]),
     "hdf_backward": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "hdf_backward_stages": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),

@@ -61,6 +61,14 @@ class Plan:
         return off.value, pitch.value, c.value, (d.value, h.value, w.value)
 
 
+    def region_info(self, batch, name):
+        """(byte offset, bytes) of a raw fp32 region of the transformer branches inside the workspace (debug / tests)"""
+        off, nb = C.c_int64(), C.c_int64()
+        check(lib().hdf_plan_region_info(self.h, batch, name.encode(), C.byref(off), C.byref(nb)),
+              "hdf_plan_region_info")
+        return off.value, nb.value
+
+
 class Runtime:
     """Per (module, dtype) execution state: plan + workspace.  The flat parameter and gradient buffers
     are owned by the module (shared between dtypes)."""
@@ -122,6 +130,12 @@ class Runtime:
         raw = self.ws[off: off + ((n - 1) * pitch + c) * esz].view(tdt)
         v = torch.as_strided(raw, (n, c), (pitch, 1))
         return v.reshape(self.ws_batch, d, h, w, c).permute(0, 4, 1, 2, 3).float().contiguous()
+
+
+    def read_region(self, name):
+        """a raw fp32 region of the transformer branches (Plan.region_info) as a flat float32 view of the workspace"""
+        off, nb = self.plan.region_info(self.ws_batch, name)
+        return self.ws[off: off + nb].view(torch.float32)
 
 
 class HDFFunction(torch.autograd.Function):

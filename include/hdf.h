@@ -59,6 +59,12 @@ int64_t hdf_plan_inference_workspace_bytes(hdf_plan* p, int batch);
 int hdf_plan_buffer_info(hdf_plan* p, int batch, const char* name, int64_t* byte_offset, int64_t* pitch_elems,
                          int* channels, int* d, int* h, int* w);
 
+/* raw fp32 regions of the transformer branches inside the workspace (debug / parity tests): "tf_F" (feature buffers of
+ * HDenseFormer.py:91-99, [block][row][DM+128]), "tf_save" (per layer h0 | qkv | ob | lse | h1 | h2), "tf_dF", "tf_tape",
+ * "tf_otape" (backward), "tf_sync" (arrival counters and the timeout words of the persistent transformer kernels: word
+ * 32 * (in_channels * batch) of each half is non-zero after a launch whose per-sequence barrier gave up) */
+int hdf_plan_region_info(hdf_plan* p, int batch, const char* name, int64_t* byte_offset, int64_t* bytes);
+
 /* HDenseFormer.forward, models/HDenseFormer.py:229-255.  x: [B,Cin,D,H,W] fp32 NCDHW.  out_i: [B,n_cls,D/2^i,..]
  * NCDHW in the plan's storage dtype.  training!=0 enables the dropout sites (:39,41,61,138) with the
  * counter-hash masks of (seed).  The workspace keeps what backward needs. */

