@@ -182,6 +182,7 @@ struct hdf_plan {
   size_t pool_idx[3];
   size_t tf_F, tf_save, tf_scratch, tf_dF, tf_tape = 0, tf_otape = 0;
   size_t tf_sync = 0;   // arrival counters of the persistent transformer kernels (transformer_chain.hip)
+  size_t tf_wpack = 0;  // fragment-major copies of the dense layers' weight matrices for those kernels
   size_t stat_partials, wgrad_ws, inb_partials, inb_k;
   size_t stat_partials2 = 0, inb_partials2 = 0, inb_k2 = 0;  // the same scratch for the branch stream (see Exec::branch)
   size_t inb_k3 = 0;  // k1 / ka / kb of the first layer's InstanceNorm backward: read by its weight gradient on the SIDE stream,
@@ -482,7 +483,13 @@ void layout(hdf_plan* p, int B) {
   const int64_t rows = (int64_t)p->M * B * p->Ntok;
   p->tf_F = bp.take((size_t)p->nb * rows * p->DMF * sizeof(float));
   p->tf_save = bp.take((size_t)p->nb * 4 * rows * 232 * sizeof(float));
-  p->tf_sync = bp.take(2 * ((size_t)(p->M * B + 1) * 128 + 128));  // forward | backward counters
+  {
+    TfDims dd{};
+    dd.M = p->M;
+    p->tf_wpack = bp.take(tf_chain_wpack_bytes(dd, p->nb));
+  }
+  p->tf_sync = bp.take((size_t)3 << 20);  // forward | backward counters in the first megabyte (one half each), then
+                                           // two megabytes of phase stamps in -DCHAIN_DBG_STAMPS builds
   p->attnall = mkview(p, bp, "attnall", 4, p->M * p->DM, B);
   conv_bufs(p->deep);
   p->attnout = mkview(p, bp, "attnout", 3, 8 * nf, B);
@@ -909,7 +916,7 @@ int transformer_forward(Exec& e, const float* x) {
                              e.st, PE_LP));
   if (tf_use_chain(p, e.B))   // all layers of all blocks in one persistent launch (transformer_chain.hip)
     return tf_chain_forward(d, tf_chain_params(p), p->nb, pm, F0, e.f(p->tf_save), e.at(p->attnall),
-                            reinterpret_cast<unsigned*>(e.ws + p->tf_sync), p->dtype, e.st);
+                            reinterpret_cast<unsigned*>(e.ws + p->tf_sync), e.ws + p->tf_wpack, p->dtype, e.st);
   // token kernel, attention, token kernel, ...: between two attention launches ONE kernel finishes the previous
   // dense layer (and, at a block boundary, runs the block's out_layer) and starts the next one
   TfLayerP prev{}, cur{};
@@ -1319,7 +1326,7 @@ int hdf_plan_region_info(hdf_plan* p, int batch, const char* name, int64_t* byte
   const std::string n = name;
   if (n == "tf_F") *byte_offset = (int64_t)p->tf_F, *bytes = (int64_t)p->nb * rows * p->DMF * 4;
   else if (n == "tf_save") *byte_offset = (int64_t)p->tf_save, *bytes = (int64_t)p->nb * 4 * rows * 232 * 4;
-  else if (n == "tf_sync") *byte_offset = (int64_t)p->tf_sync, *bytes = 2 * ((int64_t)(p->M * batch + 1) * 128 + 128);
+  else if (n == "tf_sync") *byte_offset = (int64_t)p->tf_sync, *bytes = (int64_t)3 << 20;
   else if (n == "tf_dF") *byte_offset = (int64_t)p->tf_dF, *bytes = rows * p->DMF * 4;
   else if (n == "tf_tape") *byte_offset = (int64_t)p->tf_tape, *bytes = (int64_t)p->nb * 4 * rows * TF_TAPE_W * 4;
   else if (n == "tf_otape") *byte_offset = (int64_t)p->tf_otape, *bytes = (int64_t)p->nb * rows * p->DMF * 4;

@@ -159,8 +159,10 @@ struct TfChainP {
 // the launch takes the shape (one workgroup per 16 tokens of a sequence, all resident at once)
 bool tf_chain_supported(const TfDims& d);
 size_t tf_chain_sync_bytes(const TfDims& d);
+size_t tf_chain_wpack_bytes(const TfDims& d, int nb);
 // Forward of all nb blocks: reads F0[block 0][:, 0:DM] (the patch embedding), writes every block's feature buffer, the
 // saved tensors of every layer (tf_save layout) and the channels-last attnall tensor.  `sync`: tf_chain_sync_bytes of
-// device memory owned by the caller (zeroed by the call on `st`).
+// device memory owned by the caller (zeroed by the call on `st`); `wpack`: tf_chain_wpack_bytes of scratch for the
+// fragment-major copies of the layers' weight matrices (written by a small launch in front of the persistent one).
 int tf_chain_forward(const TfDims& d, const TfChainP& cp, int nb, const float* params, float* F0, float* save,
-                     void* attnall, unsigned* sync, int dtype, hipStream_t st);
+                     void* attnall, unsigned* sync, void* wpack, int dtype, hipStream_t st);

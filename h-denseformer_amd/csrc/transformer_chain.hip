@@ -14,7 +14,7 @@
 // workgroups of a sequence publish their 16 rows of q|k|v (write-through stores), add to the sequence's arrival counter
 // and wait until all of them have arrived -- a per-sequence barrier, one per layer; sequences never wait for each other
 // (HDenseFormer.py:93-101 has no cross-sequence term).  Then each of the 8 waves takes one head: its 16 queries against
-// all keys, streamed through LDS in chunks of 64 keys (double-buffered), scores on v_mfma_f32_16x16x4_f32, exponentials
+// all keys, streamed through LDS in chunks of 128 keys (double-buffered), scores on v_mfma_f32_16x16x4_f32, exponentials
 // and P.V on the VALU exactly as attn_fwd_kernel.  The weights of the next token phase are requested before the wait.
 //
 // Hand-off protocol (cdna_hip_programming.md Guideline 16, R1 with a counter; MI355X_MICROARCH.md "Valid forms", first
@@ -31,7 +31,7 @@ namespace {
 using namespace tftok;
 
 constexpr int CT = 512;     // threads per workgroup: 8 waves = the 8 heads of Dense_Attention
-constexpr int KVC = 64;     // keys per staged chunk
+constexpr int KVC = 128;    // keys per staged chunk
 constexpr int KVP = 68;     // floats per row of a chunk image: K (8 heads x 4) | V (8 heads x 4) | pad
 constexpr int LDQ = 100;    // row pitch of the q|k|v tile
 constexpr int SYNC_LINE = 32;  // unsigned words per counter (128-byte lines)
@@ -42,15 +42,71 @@ __device__ __forceinline__ f2 lo2(const float4& v) { return f2{v.x, v.y}; }
 __device__ __forceinline__ f2 hi2(const float4& v) { return f2{v.z, v.w}; }
 __host__ __device__ inline int attn_rows(int N) { return (N + ATRIP - 1) / ATRIP * ATRIP; }
 
-__device__ __forceinline__ TfLayerP chain_layer(const TfChainP& cp, float* base, int b, int l) {
-  float* q = base + cp.blk0 + (int64_t)b * cp.blk_stride;
-  const int32_t* o = cp.loff[l];
-  return TfLayerP{q + o[0], q + o[1], q + o[2], q + o[3], q + o[4], q + o[5], q + o[6],
-                  q + o[7], q + o[8], q + o[9], q + o[10], q + o[11], q + o[12]};
+// ---- fragment-major weight copies.  A token-stage weight fragment (tf_tok.h: wload) is, per lane, a run of float4s of ONE
+// row of the torch Linear weight: the 64 lanes of a load instruction touch 64 different cache lines, and 19 such loads per
+// wave and layer made the REQUEST of a layer's weights cost 2-4 us of vector-cache line lookups per workgroup (measured:
+// the phase scaled with the number of loading waves).  tf_chain_pack_kernel permutes every layer's matrices once per
+// forward into units of 64 lanes x float4 = 1 KB in exactly the order the lanes consume them, so a fragment load reads 8
+// whole lines.  Unit map of a layer's slot (CH_SLOT units):
+constexpr int CH_WO = 0;     // to_out  [32][32]:  tile (0..1) x j (0..1)
+constexpr int CH_W2 = 4;     // net.3   [32][64]:  tile (0..1) x j (0..3)
+constexpr int CH_W1 = 12;    // net.0   [64][32]:  tile (0..3) x j (0..1)
+constexpr int CH_WQ = 20;    // to_qkv  [96][32]:  tile (0..5) x j (0..1)
+constexpr int CH_W0 = 32;    // Linear0 [32][Kq]:  (k half x tile) (0..3) x j (0 .. Kq/32 - 1 <= 10)
+constexpr int CH_SLOT = 76;
+// offsets (floats) of a layer's tensors behind its Linear0 weight [32][Kq] in the flat parameter buffer (state_dict order,
+// entries padded to 16 floats; growth 32, mlp 64: HDenseFormer.py:79-89).  The launcher checks the plan's table against them.
+constexpr int CO_B0 = 0, CO_LN1G = 32, CO_LN1B = 64, CO_WQKV = 96, CO_WOUT = 3168, CO_BOUT = 4192, CO_LN2G = 4224,
+              CO_LN2B = 4256, CO_W1 = 4288, CO_B1 = 6336, CO_W2 = 6400, CO_B2 = 8448;
+
+struct ChainW {              // device-side parameter addressing (a checked digest of TfChainP)
+  int32_t l0[4];             // Linear0 weight of layer l, floats from the block's base
+  int32_t ooff[4];           // out_layer wa, ba, wb, bb
+  int64_t blk0, blk_stride;
+};
+__device__ __forceinline__ float* chain_w0(const ChainW& cw, float* base, int b, int l) {
+  return base + cw.blk0 + (int64_t)b * cw.blk_stride + cw.l0[l];
 }
-__device__ __forceinline__ TfOutP chain_out(const TfChainP& cp, float* base, int b) {
-  float* q = base + cp.blk0 + (int64_t)b * cp.blk_stride;
-  return TfOutP{q + cp.ooff[0], q + cp.ooff[1], q + cp.ooff[2], q + cp.ooff[3]};
+__device__ __forceinline__ TfOutP chain_out(const ChainW& cw, float* base, int b) {
+  float* q = base + cw.blk0 + (int64_t)b * cw.blk_stride;
+  return TfOutP{q + cw.ooff[0], q + cw.ooff[1], q + cw.ooff[2], q + cw.ooff[3]};
+}
+
+// grid (layers, modalities), 256 threads: wave w copies the units u = w (mod 4) of its layer's slot
+__global__ __launch_bounds__(256) void tf_chain_pack_kernel(ChainW cw, const float* __restrict__ params, int64_t mstride,
+                                                            int DM, int nl, float4* __restrict__ wpack) {
+  const int L = blockIdx.x, m = blockIdx.y, b = L >> 2, l = L & 3;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+  const int Kq = DM + 32 * l;
+  const float* w0 = chain_w0(cw, const_cast<float*>(params), b, l) + (int64_t)m * mstride;
+  const float* rest = w0 + 32 * Kq;
+  float4* dst = wpack + ((int64_t)m * nl + L) * (CH_SLOT * 64);
+  for (int u = wave; u < CH_SLOT; u += 4) {
+    const float* W;
+    int ldw, n0, KQ, s0, j;
+    if (u < CH_W2) {
+      W = rest + CO_WOUT, ldw = 32, n0 = 16 * ((u - CH_WO) >> 1), KQ = 8, s0 = 0, j = (u - CH_WO) & 1;
+    } else if (u < CH_W1) {
+      W = rest + CO_W2, ldw = 64, n0 = 16 * ((u - CH_W2) >> 2), KQ = 16, s0 = 0, j = (u - CH_W2) & 3;
+    } else if (u < CH_WQ) {
+      W = rest + CO_W1, ldw = 32, n0 = 16 * ((u - CH_W1) >> 1), KQ = 8, s0 = 0, j = (u - CH_W1) & 1;
+    } else if (u < CH_W0) {
+      W = rest + CO_WQKV, ldw = 32, n0 = 16 * ((u - CH_WQ) >> 1), KQ = 8, s0 = 0, j = (u - CH_WQ) & 1;
+    } else {
+      const int f = (u - CH_W0) / 11;
+      j = (u - CH_W0) - f * 11;
+      if (j >= (Kq >> 5)) continue;
+      W = w0, ldw = Kq, n0 = 16 * (f & 1), KQ = Kq >> 2, s0 = (f >> 1) * (Kq >> 3);
+    }
+    dst[u * 64 + lane] = *reinterpret_cast<const float4*>(W + (int64_t)(n0 + i) * ldw + g * KQ + s0 + 4 * j);
+  }
+}
+// this lane's fragment: units [unit0, unit0 + n4) of the layer's slot (clamped like wload: never branch around a load)
+template <int NF4>
+__device__ __forceinline__ void pload(WFrag<NF4>& f, const float4* __restrict__ slot, int unit0, int n4) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j < NF4; j++) f.v[j] = slot[(unit0 + (j < n4 ? j : 0)) * 64 + lane];
 }
 
 // ---- hand-off pieces
@@ -88,11 +144,25 @@ __device__ __forceinline__ void chain_wait(unsigned* cnt, unsigned target, unsig
   __syncthreads();
 }
 
+// -DCHAIN_DBG_STAMPS: lane 0 of every workgroup leaves the 100 MHz real-time counter at the phase boundaries of every layer
+// in the second megabyte of the sync region (tools/chain_stamps.py); measurement builds only
+#ifdef CHAIN_DBG_STAMPS
+#define CHAIN_STAMP(k)                                                                                   \
+  do {                                                                                                   \
+    if (threadIdx.x == 0)                                                                                \
+      reinterpret_cast<uint64_t*>(a.sync + (1 << 18))[((size_t)blockIdx.x * 32 + L) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define CHAIN_STAMP(k) ((void)0)
+#endif
+
 // ================================================================================================ forward
 struct ChainFwd {
   TfDims d;
-  TfChainP cp;
+  ChainW cw;
   const float* params;
+  const float4* wpack;   // [M][nl][CH_SLOT][64] fragment-major weights (tf_chain_pack_kernel)
+  int dtype;             // storage type of attnall
   float* F0;        // [nb][rows][DMF]
   float* save;      // [nb*4][rows][232] (tf_save layout: h0 | qkv | ob | lse | h1 | h2, segment-major)
   void* attnall;    // channels-last [B][N][M*DM], storage dtype
@@ -101,7 +171,7 @@ struct ChainFwd {
   int64_t rows;
 };
 
-template <typename T>
+template <bool TRAIN>
 __global__ __launch_bounds__(CT) void tf_chain_fwd_kernel(ChainFwd a) {
   HDF_CHAIN_PRIO();
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -114,7 +184,7 @@ __global__ __launch_bounds__(CT) void tf_chain_fwd_kernel(ChainFwd a) {
   float* s_red = s_z + TT * LD64;         // [2][16][16]
   float* s_ob = s_red + 2 * 16 * 16;      // [16][36] attention output of the tile
   float* s_q = s_ob + TT * LD32;          // [16][100] q|k|v of the tile
-  float* s_kv = s_q + TT * LDQ;           // [2][64][68] key / value chunks
+  float* s_kv = s_q + TT * LDQ;           // [2][KVC][68] key / value chunks
   const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6, wave = wave8 & 3, col = lane & 15, g = lane >> 4;
   const bool cw = tid < 256;              // the token stages run on the first four waves (as tok_fwd_kernel)
   // blocks b and b + 8 share an XCD (speed only): the workgroups of a sequence meet in as few L2s as possible
@@ -123,7 +193,7 @@ __global__ __launch_bounds__(CT) void tf_chain_fwd_kernel(ChainFwd a) {
   const int n0 = tile * TT, nvalid = min(TT, N - n0);
   const int t0k = bsm * N + n0;           // modality-local token index of tile row 0 (dropout index, row addresses)
   const int64_t mo = (int64_t)m * d.mstride, rb = (int64_t)m * BN;
-  const DropF dr{d.training, d.seed, d.thresh24, d.keep_scale};
+  const DropF dr{TRAIN ? 1 : 0, d.seed, d.thresh24, d.keep_scale};   // (compile-time: no branch per element)
   auto tok = [&](int row) { return t0k + min(row, nvalid - 1); };
   float* pm = const_cast<float*>(a.params);
   unsigned* cnt = a.sync + seq * SYNC_LINE;
@@ -140,29 +210,40 @@ __global__ __launch_bounds__(CT) void tf_chain_fwd_kernel(ChainFwd a) {
   LnP ln2{}, ln1{};
   float h0r[4] = {0.f, 0.f, 0.f, 0.f};
 
-  // weights of the token phase that finishes layer L - 1 (POST): requested one attention phase ahead; those of the stages
-  // that start layer L (PRE) at the top of the token phase, so that they arrive under the POST stages (all of them live
-  // across the attention phase: 92 registers, and the kernel spilled)
-  auto request_post = [&](int L) __attribute__((always_inline)) {
-    if (!cw || L <= 0) return;
-    const TfLayerP pp = chain_layer(a.cp, pm, (L - 1) >> 2, (L - 1) & 3);
-    if (wave < 2) {
-      wload(f_wo, pp.wout + mo, 32, 16 * wave, 8, 0, 2);
-      wload(f_w2, pp.w2 + mo, 64, 16 * wave, 16, 0, 4);
+  // Weights of the token phase that finishes layer L - 1 (POST): requested one attention phase ahead; those of the stages
+  // that start layer L (PRE) at the top of the token phase, so that they arrive under the POST stages.  Only the four
+  // waves that run the token stages load; the others ZERO their fragment registers (an `if` without that else keeps
+  // the previous contents of all 92 registers live across the whole layer loop on the path that skips the request, and
+  // the kernel spilled).  The last iteration re-requests the last layer for the same reason.
+  auto request_post = [&](int L) __attribute__((always_inline)) {   // L >= 1
+    const int Lp = L - 1;
+    if (cw) {
+      const float4* slot = a.wpack + ((int64_t)m * nl + Lp) * (CH_SLOT * 64);
+      const float* rest = chain_w0(a.cw, pm, Lp >> 2, Lp & 3) + mo + 32 * (DM + 32 * (Lp & 3));
+      pload(f_wo, slot, CH_WO + 2 * (wave & 1), 2);
+      pload(f_w2, slot, CH_W2 + 4 * (wave & 1), 4);
+      pload(f_w1, slot, CH_W1 + 2 * wave, 2);
+      p_bout = rest[CO_BOUT + cw_col], p_b2 = rest[CO_B2 + cw_col], p_b1 = rest[CO_B1 + c4w];
+      ln2 = ln_load(rest + CO_LN2G, rest + CO_LN2B);
+    } else {
+      f_wo = WFrag<2>{}, f_w2 = WFrag<4>{}, f_w1 = WFrag<2>{};
+      p_bout = p_b2 = p_b1 = 0.f, ln2 = LnP{};
     }
-    wload(f_w1, pp.w1 + mo, 32, 16 * wave, 8, 0, 2);
-    p_bout = pp.bout[mo + cw_col], p_b2 = pp.b2[mo + cw_col], p_b1 = pp.b1[mo + c4w];
-    ln2 = ln_load(pp.ln2g + mo, pp.ln2b + mo);
   };
   auto request_pre = [&](int L) __attribute__((always_inline)) {
-    if (!cw || L >= nl) return;
-    const TfLayerP pq = chain_layer(a.cp, pm, L >> 2, L & 3);
-    const int Kq = DM + 32 * (L & 3);
-    wload(f_w0, pq.w0 + mo, Kq, 16 * (wave & 1), Kq >> 2, (wave >> 1) * (Kq >> 3), Kq >> 5);
-    wload(f_q0, pq.wqkv + mo, 32, 16 * wave, 8, 0, 2);
-    if (wave < 2) wload(f_q1, pq.wqkv + mo, 32, 16 * (wave + 4), 8, 0, 2);
-    p_b0 = pq.b0[mo + cw_col];
-    ln1 = ln_load(pq.ln1g + mo, pq.ln1b + mo);
+    const int Lc = min(L, nl - 1);
+    if (cw) {
+      const float4* slot = a.wpack + ((int64_t)m * nl + Lc) * (CH_SLOT * 64);
+      const float* rest = chain_w0(a.cw, pm, Lc >> 2, Lc & 3) + mo + 32 * (DM + 32 * (Lc & 3));
+      pload(f_w0, slot, CH_W0 + 11 * wave, (DM + 32 * (Lc & 3)) >> 5);   // fragment (k half = wave >> 1, tile = wave & 1)
+      pload(f_q0, slot, CH_WQ + 2 * wave, 2);
+      pload(f_q1, slot, CH_WQ + 2 * ((wave & 1) + 4), 2);
+      p_b0 = rest[CO_B0 + cw_col];
+      ln1 = ln_load(rest + CO_LN1G, rest + CO_LN1B);
+    } else {
+      f_w0 = WFrag<11>{}, f_q0 = WFrag<2>{}, f_q1 = WFrag<2>{};
+      p_b0 = 0.f, ln1 = LnP{};
+    }
   };
 
   {  // block 0's input rows (the patch embedding's output)
@@ -183,7 +264,9 @@ __global__ __launch_bounds__(CT) void tf_chain_fwd_kernel(ChainFwd a) {
     int t0 = t0k;
     asm volatile("" : "+s"(t0));
     request_pre(L);
+    CHAIN_STAMP(8);
     __syncthreads();
+    CHAIN_STAMP(0);
     // ------------------------------------------------------------------ POST(bp, lp)
     if (POST) {
       float* sv = a.save + (int64_t)(L - 1) * a.rows * 232;
@@ -207,6 +290,7 @@ __global__ __launch_bounds__(CT) void tf_chain_fwd_kernel(ChainFwd a) {
         }
       }
       __syncthreads();
+      CHAIN_STAMP(9);
 #pragma unroll
       for (int pass = 0; pass < 2; pass++) {  // pass 0: h2 = ff(LN2(h1)) + h1 ; pass 1: feature = ff(LN2(h2))
         if (cw) ln32(s_h, s_x, ln2);
@@ -244,11 +328,13 @@ __global__ __launch_bounds__(CT) void tf_chain_fwd_kernel(ChainFwd a) {
           }
         }
         __syncthreads();
+        if (pass == 0) CHAIN_STAMP(10);
       }
     }
+    CHAIN_STAMP(13);
     // ------------------------------------------------------------------ OUT(bp): DenseForward(DM+128 -> 64 -> DM)
     if (OUT) {
-      const TfOutP po = chain_out(a.cp, pm, bp);
+      const TfOutP po = chain_out(a.cw, pm, bp);
       float* next_F = PRE ? a.F0 + (int64_t)bq * a.rows * DMF : nullptr;
       const uint32_t siteo = hdf_site_id(m, bp, 4, 0);
       if (cw) {
@@ -277,14 +363,20 @@ __global__ __launch_bounds__(CT) void tf_chain_fwd_kernel(ChainFwd a) {
               s_F[row * ldF + c] = v;
               if (row < nvalid) next_F[(rb + t) * DMF + c] = v;
             } else if (row < nvalid) {
-              ST<T>::st(reinterpret_cast<T*>(a.attnall) + ((int64_t)bsm * N + n0 + row) * ((int64_t)d.M * DM) +
-                            (int64_t)m * DM + c, v);
+              const int64_t ai = ((int64_t)bsm * N + n0 + row) * ((int64_t)d.M * DM) + (int64_t)m * DM + c;
+              if (a.dtype == HDF_BF16)
+                ST<bf16_t>::st(reinterpret_cast<bf16_t*>(a.attnall) + ai, v);
+              else if (a.dtype == HDF_F16)
+                ST<f16_t>::st(reinterpret_cast<f16_t*>(a.attnall) + ai, v);
+              else
+                reinterpret_cast<float*>(a.attnall)[ai] = v;
             }
           }
         }
       }
       __syncthreads();
     }
+    CHAIN_STAMP(1);
     if (!PRE) break;
     // ------------------------------------------------------------------ PRE(bq, lq): Linear0 + LN1 + to_qkv
     float* sv = a.save + (int64_t)L * a.rows * 232;
@@ -313,8 +405,10 @@ __global__ __launch_bounds__(CT) void tf_chain_fwd_kernel(ChainFwd a) {
         }
       }
       __syncthreads();
+      CHAIN_STAMP(11);
       if (cw) ln32(s_h, s_x, ln1);
       __syncthreads();
+      CHAIN_STAMP(12);
       if (cw) {
         f32x4 acc1 = zero4();
         wmma(acc1, f_q0, s_x, LD32, 8, 0, 2);
@@ -329,6 +423,7 @@ __global__ __launch_bounds__(CT) void tf_chain_fwd_kernel(ChainFwd a) {
       }
       __syncthreads();
     }
+    CHAIN_STAMP(2);
     // ------------------------------------------------------------------ publish q|k|v, per-sequence barrier
     float* qkvL = sv + a.rows * 32;                               // [rows][96] of this layer
     const __amdgpu_buffer_rsrc_t rq = chain_rsrc(qkvL + (rb + (int64_t)bsm * N) * 96);   // this sequence's rows
@@ -338,85 +433,129 @@ __global__ __launch_bounds__(CT) void tf_chain_fwd_kernel(ChainFwd a) {
         st16_sc1(rq, (uint32_t)(((n0 + row) * 96 + c4) * 4), *reinterpret_cast<const float4*>(s_q + row * LDQ + c4));
     }
     chain_arrive(cnt);
+    CHAIN_STAMP(3);
     request_post(L + 1);   // parameters: never written during the launch, plain loads
     const int head = wave8;
     const float bqv = s_q[col * LDQ + head * 4 + g] * (0.5f * LOG2E);
     chain_wait(cnt, (unsigned)(a.ntile * (L + 1)), tmo, dead);
+    CHAIN_STAMP(4);
     // ------------------------------------------------------------------ attention of layer L: head = wave
     {
 #pragma clang fp contract(off)   // explicit fmas only: attn_fwd_kernel's arithmetic, bit for bit (see there)
       const int NP = attn_rows(N), nchunk = (NP + KVC - 1) / KVC;
-      const int srow = tid >> 3, spart = tid & 7;   // staging: row of the chunk, 16-byte part of its K and V halves
-      float4 pk, pv;
+      // staging: thread -> rows (tid >> 3) and (tid >> 3) + 64 of the chunk, 16-byte part (tid & 7) of their K and V halves
+      const int srow = tid >> 3, spart = tid & 7;
+      float4 pk[2], pv[2];
       auto stage_load = [&](int c) __attribute__((always_inline)) {
-        const int j = min(c * KVC + srow, N - 1);
-        pk = ld16_sc1(rq, (uint32_t)((j * 96 + 32 + 4 * spart) * 4));
-        pv = ld16_sc1(rq, (uint32_t)((j * 96 + 64 + 4 * spart) * 4));
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int j = min(c * KVC + srow + 64 * h, N - 1);
+          pk[h] = ld16_sc1(rq, (uint32_t)((j * 96 + 32 + 4 * spart) * 4));
+          pv[h] = ld16_sc1(rq, (uint32_t)((j * 96 + 64 + 4 * spart) * 4));
+        }
       };
       auto stage_store = [&](int c) __attribute__((always_inline)) {
-        const bool real = c * KVC + srow < N;
-        float* dst = s_kv + (c & 1) * (KVC * KVP) + srow * KVP + 4 * spart;
-        // (component selects: `real ? pk : zero` on the float4s is a select between two ADDRESSES and goes through scratch)
-        *reinterpret_cast<float4*>(dst) = make_float4(real ? pk.x : 0.f, real ? pk.y : 0.f, real ? pk.z : 0.f, real ? pk.w : 0.f);
-        *reinterpret_cast<float4*>(dst + 32) = make_float4(real ? pv.x : 0.f, real ? pv.y : 0.f, real ? pv.z : 0.f, real ? pv.w : 0.f);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const bool real = c * KVC + srow + 64 * h < N;
+          float* dst = s_kv + (c & 1) * (KVC * KVP) + (srow + 64 * h) * KVP + 4 * spart;
+          // (component selects: `real ? pk : zero` on the float4s is a select between two ADDRESSES and goes through scratch)
+          *reinterpret_cast<float4*>(dst) =
+              make_float4(real ? pk[h].x : 0.f, real ? pk[h].y : 0.f, real ? pk[h].z : 0.f, real ? pk[h].w : 0.f);
+          *reinterpret_cast<float4*>(dst + 32) =
+              make_float4(real ? pv[h].x : 0.f, real ? pv[h].y : 0.f, real ? pv[h].z : 0.f, real ? pv[h].w : 0.f);
+        }
       };
       stage_load(0);
       stage_store(0);
       __syncthreads();
+      CHAIN_STAMP(5);
       float mx = -INFINITY, l = 0.f;
       f2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+      // one block of 16 keys against the wave's 16 queries (attn_fwd_kernel's trip, operation for operation)
+      auto trip = [&](const float4 (&v)[4], int j0, const f32x4& sc4, auto masked) __attribute__((always_inline)) {
+        float sc[4];
+        float mn = mx;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          sc[u] = sc4[u];
+          if (decltype(masked)::value) sc[u] = (j0 + 4 * g + u < N) ? sc[u] : -INFINITY;
+          mn = fmaxf(mn, sc[u]);
+        }
+        const float mr = (mn == -INFINITY) ? 0.f : mn;
+        const float cfac = __builtin_amdgcn_exp2f(mx - mr);
+        float ps = 0.f;
+        f2 b01 = {0.f, 0.f}, b23 = {0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const float pr = __builtin_amdgcn_exp2f(sc[u] - mr);
+          const f2 pp = {pr, pr};
+          ps += pr;
+          b01 = __builtin_elementwise_fma(pp, lo2(v[u]), b01);
+          b23 = __builtin_elementwise_fma(pp, hi2(v[u]), b23);
+        }
+        const f2 cc = {cfac, cfac};
+        l = __builtin_fmaf(l, cfac, ps);
+        a01 = __builtin_elementwise_fma(a01, cc, b01);
+        a23 = __builtin_elementwise_fma(a23, cc, b23);
+        mx = mn;
+      };
       for (int c = 0; c < nchunk; c++) {
         if (c + 1 < nchunk) stage_load(c + 1);
         const float* sK = s_kv + (c & 1) * (KVC * KVP);
-        auto scores = [&](int jj) __attribute__((always_inline)) {
+        const float* sKq = sK + col * KVP + head * 4 + g;         // + 16 k rows: the score MFMA's A operand of block k
+        const float* sVq = sK + 4 * g * KVP + 32 + head * 4;      // + (16 k + u) rows: this lane's value rows of block k
+        const int jbase = c * KVC;
+        auto scores = [&](float ka) __attribute__((always_inline)) {
           f32x4 z = {0.f, 0.f, 0.f, 0.f};
-          return __builtin_amdgcn_mfma_f32_16x16x4f32(sK[(jj + col) * KVP + head * 4 + g], bqv, z, 0, 0, 0);
+          return __builtin_amdgcn_mfma_f32_16x16x4f32(ka, bqv, z, 0, 0, 0);
         };
-        auto trip = [&](int jj, int j0, const f32x4& sc4, auto masked) __attribute__((always_inline)) {
-          float4 v[4];
-          float sc[4];
+        if (jbase + KVC <= N) {
+          // whole chunk, no mask: all eight K operands requested at once, the value rows one block ahead of their use (with
+          // one LDS round trip in front of the MFMA and one in front of the first P.V of every block the loop took 600
+          // cycles per block at two waves per SIMD)
+          constexpr int NT = KVC / ATRIP;
+          float ka[NT];
 #pragma unroll
-          for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const float4*>(sK + (jj + 4 * g + u) * KVP + 32 + head * 4);
-          float mn = mx;
+          for (int k = 0; k < NT; k++) ka[k] = sKq[k * ATRIP * KVP];
+          float4 v[2][4];
 #pragma unroll
-          for (int u = 0; u < 4; u++) {
-            sc[u] = sc4[u];
-            if (decltype(masked)::value) sc[u] = (j0 + 4 * g + u < N) ? sc[u] : -INFINITY;
-            mn = fmaxf(mn, sc[u]);
+          for (int u = 0; u < 4; u++) v[0][u] = *reinterpret_cast<const float4*>(sVq + u * KVP);
+          f32x4 cur = scores(ka[0]);
+#pragma unroll
+          for (int k = 0; k < NT; k++) {
+            f32x4 nxt = cur;
+            if (k + 1 < NT) {
+              nxt = scores(ka[k + 1]);
+#pragma unroll
+              for (int u = 0; u < 4; u++)
+                v[(k + 1) & 1][u] = *reinterpret_cast<const float4*>(sVq + ((k + 1) * ATRIP + u) * KVP);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            trip(v[k & 1], jbase + k * ATRIP, cur, std::false_type{});
+            cur = nxt;
           }
-          const float mr = (mn == -INFINITY) ? 0.f : mn;
-          const float cfac = __builtin_amdgcn_exp2f(mx - mr);
-          float ps = 0.f;
-          f2 b01 = {0.f, 0.f}, b23 = {0.f, 0.f};
+        } else {
+          const int ntrip = (NP - jbase) / ATRIP;
+          f32x4 cur = scores(sKq[0]);
+          for (int k = 0; k < ntrip; k++) {
+            const int j0 = jbase + k * ATRIP;
+            const f32x4 nxt = scores(sKq[min(k + 1, ntrip - 1) * ATRIP * KVP]);
+            float4 v[4];
 #pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const float pr = __builtin_amdgcn_exp2f(sc[u] - mr);
-            const f2 pp = {pr, pr};
-            ps += pr;
-            b01 = __builtin_elementwise_fma(pp, lo2(v[u]), b01);
-            b23 = __builtin_elementwise_fma(pp, hi2(v[u]), b23);
+            for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const float4*>(sVq + (k * ATRIP + u) * KVP);
+            __builtin_amdgcn_sched_barrier(0);
+            if (j0 + ATRIP <= N)
+              trip(v, j0, cur, std::false_type{});
+            else
+              trip(v, j0, cur, std::true_type{});
+            cur = nxt;
           }
-          const f2 cc = {cfac, cfac};
-          l = __builtin_fmaf(l, cfac, ps);
-          a01 = __builtin_elementwise_fma(a01, cc, b01);
-          a23 = __builtin_elementwise_fma(a23, cc, b23);
-          mx = mn;
-        };
-        const int jbase = c * KVC, ntrip = min(KVC, NP - jbase) / ATRIP;
-        f32x4 cur = scores(0);
-        for (int k = 0; k < ntrip; k++) {
-          const int jj = k * ATRIP, j0 = jbase + jj;
-          const f32x4 nxt = scores(min(jj + ATRIP, (ntrip - 1) * ATRIP));
-          __builtin_amdgcn_sched_barrier(0);
-          if (j0 + ATRIP <= N)
-            trip(jj, j0, cur, std::false_type{});
-          else
-            trip(jj, j0, cur, std::true_type{});
-          cur = nxt;
         }
         if (c + 1 < nchunk) stage_store(c + 1);
         __syncthreads();
       }
+      CHAIN_STAMP(6);
       // merge the 4 key subsets of a query (lanes q, q + 16, q + 32, q + 48)
 #pragma unroll
       for (int off = 16; off < 64; off <<= 1) {
@@ -444,6 +583,7 @@ __global__ __launch_bounds__(CT) void tf_chain_fwd_kernel(ChainFwd a) {
           lse[R * 8 + head] = __builtin_fmaf(mx, LN2, __logf(l));
         }
       }
+      CHAIN_STAMP(7);
     }
   }
 }
@@ -467,7 +607,21 @@ int chain_allow_lds(Kern kern, size_t bytes) {
 
 }  // namespace
 
+// the plan's parameter table in the form the kernels address it; false when it is not the regular layout they assume
+static bool chain_digest(const TfChainP& cp, int DM, ChainW& w) {
+  static const int rel[13] = {0, CO_B0, CO_LN1G, CO_LN1B, CO_WQKV, CO_WOUT, CO_BOUT, CO_LN2G, CO_LN2B, CO_W1, CO_B1, CO_W2, CO_B2};
+  for (int l = 0; l < 4; l++) {
+    w.l0[l] = cp.loff[l][0];
+    for (int k = 1; k < 13; k++)
+      if (cp.loff[l][k] != cp.loff[l][0] + 32 * (DM + 32 * l) + rel[k]) return false;
+  }
+  for (int k = 0; k < 4; k++) w.ooff[k] = cp.ooff[k];
+  w.blk0 = cp.blk0, w.blk_stride = cp.blk_stride;
+  return true;
+}
+
 size_t tf_chain_sync_bytes(const TfDims& d) { return (size_t)(d.M * d.B + 1) * SYNC_LINE * sizeof(unsigned); }
+size_t tf_chain_wpack_bytes(const TfDims& d, int nb) { return (size_t)d.M * nb * 4 * CH_SLOT * 64 * sizeof(float4); }
 
 bool tf_chain_supported(const TfDims& d) {
   const int ntile = ceil_div(d.N, TT);
@@ -476,23 +630,32 @@ bool tf_chain_supported(const TfDims& d) {
 }
 
 int tf_chain_forward(const TfDims& d, const TfChainP& cp, int nb, const float* params, float* F0, float* save,
-                     void* attnall, unsigned* sync, int dtype, hipStream_t st) {
+                     void* attnall, unsigned* sync, void* wpack, int dtype, hipStream_t st) {
   HDF_CHECK_ARG(tf_chain_supported(d), "transformer chain: shape not supported (M %d B %d N %d DM %d)", d.M, d.B, d.N, d.DM);
   ChainFwd a{};
-  a.d = d, a.cp = cp, a.params = params, a.F0 = F0, a.save = save, a.attnall = attnall, a.sync = sync;
+  HDF_CHECK_ARG(chain_digest(cp, d.DM, a.cw), "transformer chain: irregular parameter layout");
+  a.d = d, a.params = params, a.F0 = F0, a.save = save, a.attnall = attnall, a.sync = sync;
+  a.wpack = reinterpret_cast<const float4*>(wpack), a.dtype = dtype;
   a.nb = nb, a.ntile = ceil_div(d.N, TT), a.nseq = d.M * d.B, a.rows = (int64_t)d.M * d.B * d.N;
   const size_t shm = chain_fwd_lds(d);
   HDF_CHECK_ARG(shm <= LDS_LIMIT_F, "transformer chain: %zu B of LDS", shm);
+  HDF_CHECK_ARG(dtype == HDF_F32 || dtype == HDF_BF16 || dtype == HDF_F16, "unsupported dtype %d", dtype);
   hipError_t e = hipMemsetAsync(sync, 0, tf_chain_sync_bytes(d), st);
   if (e != hipSuccess) {
     hdf_set_error("transformer chain: hipMemsetAsync failed: %s", hipGetErrorString(e));
     return HDF_ERR_HIP;
   }
+  hipLaunchKernelGGL(tf_chain_pack_kernel, dim3(nb * 4, d.M), dim3(256), 0, st, a.cw, params, d.mstride, d.DM, nb * 4,
+                     reinterpret_cast<float4*>(wpack));
+  HDF_LAUNCH_CHECK();
   const dim3 grid(a.nseq * a.ntile);
-  HDF_DISPATCH_T(dtype, {
-    HDF_TRY(chain_allow_lds(tf_chain_fwd_kernel<T>, shm));
-    hipLaunchKernelGGL(tf_chain_fwd_kernel<T>, grid, dim3(CT), shm, st, a);
-  });
+  if (d.training) {
+    HDF_TRY(chain_allow_lds(tf_chain_fwd_kernel<true>, shm));
+    hipLaunchKernelGGL(tf_chain_fwd_kernel<true>, grid, dim3(CT), shm, st, a);
+  } else {
+    HDF_TRY(chain_allow_lds(tf_chain_fwd_kernel<false>, shm));
+    hipLaunchKernelGGL(tf_chain_fwd_kernel<false>, grid, dim3(CT), shm, st, a);
+  }
   HDF_LAUNCH_CHECK();
   return HDF_OK;
 }
