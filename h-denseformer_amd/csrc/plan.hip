@@ -995,6 +995,20 @@ int transformer_backward(Exec& e, const float* x) {
     HDF_TRY(tf_wgrad(w, 1, p->M, e.wgrad_stream()));
     return e.side_done();
   };
+  if (tf_use_chain(p, e.B)) {
+    // one persistent launch for all layers (transformer_chain.hip); then every block's weight-matrix gradients from the
+    // tapes on the side stream, next to the patch embedding's backward on this one
+    HDF_TRY(tf_chain_backward(d, tf_chain_params(p), p->nb, pm, e.grads, F0, e.f(p->tf_save), dF, e.at(p->dAttnall),
+                              e.f(p->tf_tape), e.f(p->tf_otape), scratch,
+                              reinterpret_cast<unsigned*>(e.ws + p->tf_sync) + (1 << 17), p->dtype, e.st));
+    w.b0 = 0;
+    HDF_TRY(tf_wgrad(w, p->nb, p->M, e.wgrad_stream()));
+    HDF_TRY(e.side_done());
+    HDF_TRY(tf_patch_embed_bwd(d, x, p->D, p->H, p->W, dF, e.grads + p->P("attns.0.patch_embeddings.weight"),
+                               e.grads + p->P("attns.0.patch_embeddings.bias"),
+                               e.grads + p->P("attns.0.position_embeddings"), scratch, e.st));
+    return HDF_OK;
+  }
   TfLayerP up{}, gup{}, cur{}, gcur{};
   TfOutP o{}, go{};
   bool have_up = false;

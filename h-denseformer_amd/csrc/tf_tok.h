@@ -95,7 +95,11 @@ __device__ __forceinline__ LnP ln_load(const float* __restrict__ gam, const floa
   const int c = (threadIdx.x & 15) * 2;
   return LnP{gam[c], gam[c + 1], bet[c], bet[c + 1]};
 }
+// (every sum of products in these helpers is an explicit fma under contract(off): the token kernels of
+// transformer_fused.hip and the persistent kernels of transformer_chain.hip must round identically, and left to the
+// compiler `d0 * d0 + d1 * d1` was an fma in one file and two multiplies + an add -- SLP-vectorised -- in the other)
 __device__ __forceinline__ void ln32(const float* sIn, float* sOut, const LnP& p) {
+#pragma clang fp contract(off)
   const int row = threadIdx.x >> 4, c = (threadIdx.x & 15) * 2;
   const float v0 = sIn[row * LD32 + c], v1 = sIn[row * LD32 + c + 1];
   float s = v0 + v1;
@@ -103,16 +107,17 @@ __device__ __forceinline__ void ln32(const float* sIn, float* sOut, const LnP& p
   for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
   const float mean = s * (1.f / 32.f);
   const float d0 = v0 - mean, d1 = v1 - mean;
-  float q = d0 * d0 + d1 * d1;
+  float q = __builtin_fmaf(d1, d1, d0 * d0);
 #pragma unroll
   for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
-  const float rstd = rsqrtf(q * (1.f / 32.f) + 1e-5f);
-  sOut[row * LD32 + c] = d0 * rstd * p.g0 + p.b0;
-  sOut[row * LD32 + c + 1] = d1 * rstd * p.g1 + p.b1;
+  const float rstd = rsqrtf(__builtin_fmaf(q, 1.f / 32.f, 1e-5f));
+  sOut[row * LD32 + c] = __builtin_fmaf(d0 * rstd, p.g0, p.b0);
+  sOut[row * LD32 + c + 1] = __builtin_fmaf(d1 * rstd, p.g1, p.b1);
 }
 
 __device__ __forceinline__ float gelu_grad_f(float x) {
-  return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+#pragma clang fp contract(off)
+  return __builtin_fmaf(x * 0.3989422804014327f, __expf(-0.5f * x * x), 0.5f * (1.f + erff(x * 0.70710678118654752f)));
 }
 
 // Data-gradient GEMMs contract over the OUTPUT index of a Linear: dX[16][I] = dY[16][O] * W[O][I].  The B operand of
@@ -228,6 +233,7 @@ __device__ __forceinline__ void colsum_atomic(float* __restrict__ gb, int width,
 }
 // LayerNorm(32) forward pieces kept for its backward: u = xh*gamma + beta -> sU ; xh -> sXh ; rstd -> return value
 __device__ __forceinline__ float ln32_keep(const float* sIn, float* sU, float* sXh, const LnP& p) {
+#pragma clang fp contract(off)
   const int row = threadIdx.x >> 4, c = (threadIdx.x & 15) * 2;
   const float v0 = sIn[row * LD32 + c], v1 = sIn[row * LD32 + c + 1];
   float s = v0 + v1;
@@ -235,30 +241,31 @@ __device__ __forceinline__ float ln32_keep(const float* sIn, float* sU, float* s
   for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
   const float mean = s * (1.f / 32.f);
   const float d0 = v0 - mean, d1 = v1 - mean;
-  float q = d0 * d0 + d1 * d1;
+  float q = __builtin_fmaf(d1, d1, d0 * d0);
 #pragma unroll
   for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
-  const float rstd = rsqrtf(q * (1.f / 32.f) + 1e-5f);
+  const float rstd = rsqrtf(__builtin_fmaf(q, 1.f / 32.f, 1e-5f));
   sXh[row * LD32 + c] = d0 * rstd, sXh[row * LD32 + c + 1] = d1 * rstd;
-  sU[row * LD32 + c] = d0 * rstd * p.g0 + p.b0;
-  sU[row * LD32 + c + 1] = d1 * rstd * p.g1 + p.b1;
+  sU[row * LD32 + c] = __builtin_fmaf(d0 * rstd, p.g0, p.b0);
+  sU[row * LD32 + c + 1] = __builtin_fmaf(d1 * rstd, p.g1, p.b1);
   return rstd;
 }
 // LayerNorm backward of this thread's two columns: du (gradient w.r.t. the LN output) -> dh; the products du*xh are left
 // in sGx (for the gamma gradient column sums; du itself stays in sDu for beta)
 __device__ __forceinline__ void ln32_bwd(const float* sDu, const float* sXh, float* sGx, float rstd, const LnP& p,
                                          float& dh0, float& dh1) {
+#pragma clang fp contract(off)
   const int row = threadIdx.x >> 4, c = (threadIdx.x & 15) * 2;
   const float u0 = sDu[row * LD32 + c], u1 = sDu[row * LD32 + c + 1];
   const float x0 = sXh[row * LD32 + c], x1 = sXh[row * LD32 + c + 1];
   sGx[row * LD32 + c] = u0 * x0, sGx[row * LD32 + c + 1] = u1 * x1;
   const float a0 = u0 * p.g0, a1 = u1 * p.g1;
-  float s1 = a0 + a1, s2 = a0 * x0 + a1 * x1;
+  float s1 = a0 + a1, s2 = __builtin_fmaf(a1, x1, a0 * x0);
 #pragma unroll
   for (int o = 8; o > 0; o >>= 1) s1 += __shfl_xor(s1, o, 64), s2 += __shfl_xor(s2, o, 64);
   const float m1 = s1 * (1.f / 32.f), m2 = s2 * (1.f / 32.f);
-  dh0 = rstd * (a0 - m1 - x0 * m2);
-  dh1 = rstd * (a1 - m1 - x1 * m2);
+  dh0 = rstd * __builtin_fmaf(-x0, m2, a0 - m1);
+  dh1 = rstd * __builtin_fmaf(-x1, m2, a1 - m1);
 }
 
 // 16-token LDS tile [16][width] -> the tile's rows of tape segment `col0`: a tape is segment-major, segment c of width w

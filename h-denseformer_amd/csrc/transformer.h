@@ -6,6 +6,14 @@
 #pragma once
 #include "hdf_common.h"
 
+// delta of the attention backward: (dO . ob) over the 4 components of a head.  One explicit fma chain under contract(off):
+// as a plain sum of four products its rounding depended on how the surrounding code was vectorised, and the persistent
+// backward kernel (transformer_chain.hip) must reproduce the attention backward kernels bit for bit.
+__device__ __forceinline__ float tf_dot4(const float4& a, const float4& b) {
+#pragma clang fp contract(off)
+  return __builtin_fmaf(a.w, b.w, __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)));
+}
+
 struct TfDims {
   int M;    // modalities (= in_channels)
   int B;    // batch
@@ -166,3 +174,10 @@ size_t tf_chain_wpack_bytes(const TfDims& d, int nb);
 // fragment-major copies of the layers' weight matrices (written by a small launch in front of the persistent one).
 int tf_chain_forward(const TfDims& d, const TfChainP& cp, int nb, const float* params, float* F0, float* save,
                      void* attnall, unsigned* sync, void* wpack, int dtype, hipStream_t st);
+// Backward of all nb blocks (after the UpConv chain's backward left d(attnall)): every bias / LayerNorm-parameter gradient
+// (fp32 atomics into `grads`), the weight-gradient tapes of every layer (tf_wgrad afterwards), and dF[:, 0:DM] = the
+// gradient of block 0's input (tf_patch_embed_bwd afterwards).  `xchg`: 2 * rows * 40 floats of scratch (the dO | delta
+// rows the workgroups of a sequence hand each other); `sync`: tf_chain_sync_bytes, zeroed by the call.
+int tf_chain_backward(const TfDims& d, const TfChainP& cp, int nb, const float* params, float* grads, const float* F0,
+                      const float* save, float* dF, const void* d_attnall, float* tape, float* otape, float* xchg,
+                      unsigned* sync, int dtype, hipStream_t st);

@@ -222,7 +222,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(int N, int seq, const float* __
   const float bg = dO[R * 32 + head * 4 + g];
   attn_stage_kv(N, NP, qkv, rowbase, head, sK, sV);
   __syncthreads();
-  const float delta = go.x * oo.x + go.y * oo.y + go.z * oo.z + go.w * oo.w;
+  const float delta = tf_dot4(go, oo);
   f2 d01 = {0.f, 0.f}, d23 = {0.f, 0.f};
   auto trip = [&](int j0, const f32x4& s4, const f32x4& t4, auto masked) __attribute__((always_inline)) {
     float4 k[AU];
@@ -291,8 +291,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(int N, int seq, const float* _
         const float sc = real ? 0.5f * LOG2E : 0.f;
         sQ[i] = make_float4(q[u].x * sc, q[u].y * sc, q[u].z * sc, q[u].w * sc);
         sG[i] = real ? go[u] : make_float4(0.f, 0.f, 0.f, 0.f);
-        sL[i] = real ? make_float2(lv[u] * LOG2E, go[u].x * oo[u].x + go[u].y * oo[u].y + go[u].z * oo[u].z +
-                                                      go[u].w * oo[u].w)
+        sL[i] = real ? make_float2(lv[u] * LOG2E, tf_dot4(go[u], oo[u]))
                      : make_float2(INFINITY, 0.f);
       }
     }
@@ -409,7 +408,7 @@ __device__ __forceinline__ void attn_bwd_dq_lp_body(int N, int seq, const float*
     }
   }
   __syncthreads();
-  const float delta = go.x * oo.x + go.y * oo.y + go.z * oo.z + go.w * oo.w;
+  const float delta = tf_dot4(go, oo);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const uint16_t* krow = sKt + (size_t)min(c, 4) * NP + 4 * g;
   const int nfull = N / ATRIP * ATRIP;
@@ -488,7 +487,7 @@ __device__ __forceinline__ void attn_bwd_dkv_lp_body(int N, int seq, const float
         sQ[i] = make_float4(q[u].x * sc, q[u].y * sc, q[u].z * sc, q[u].w * sc);
         sG[i] = make_float4(go[u].x * z, go[u].y * z, go[u].z * z, go[u].w * z);
         sLse[i] = real ? -lv[u] * LOG2E : -INFINITY;
-        sDel[i] = -z * (go[u].x * oo[u].x + go[u].y * oo[u].y + go[u].z * oo[u].z + go[u].w * oo[u].w);
+        sDel[i] = -z * tf_dot4(go[u], oo[u]);
         sQt[0 * NP + i] = LpPack<LP>::one(q[u].x * z), sQt[1 * NP + i] = LpPack<LP>::one(q[u].y * z);
         sQt[2 * NP + i] = LpPack<LP>::one(q[u].z * z), sQt[3 * NP + i] = LpPack<LP>::one(q[u].w * z);
         sQt[4 * NP + i] = 0;

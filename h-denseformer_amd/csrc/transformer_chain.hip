@@ -152,8 +152,14 @@ __device__ __forceinline__ void chain_wait(unsigned* cnt, unsigned target, unsig
     if (threadIdx.x == 0)                                                                                \
       reinterpret_cast<uint64_t*>(a.sync + (1 << 18))[((size_t)blockIdx.x * 32 + L) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
+#define CHAIN_STAMPB(k)                                                                                  \
+  do {                                                                                                   \
+    if (threadIdx.x == 0)                                                                                \
+      reinterpret_cast<uint64_t*>(a.sync + (1 << 18) + (1 << 17))[((size_t)blockIdx.x * 32 + (L + 1)) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
 #else
 #define CHAIN_STAMP(k) ((void)0)
+#define CHAIN_STAMPB(k) ((void)0)
 #endif
 
 // ================================================================================================ forward
@@ -588,6 +594,682 @@ __global__ __launch_bounds__(CT) void tf_chain_fwd_kernel(ChainFwd a) {
   }
 }
 
+// ================================================================================================ backward
+// Mirror image of the forward kernel (HDenseFormer.py:78-145 differentiated): per layer L, from the last one down,
+//     token phase:  PREB(L + 1)  Linear0 / LN1 / to_qkv backward of the layer whose attention backward just ran
+//                   OUTB(b)      out_layer backward at a block boundary
+//                   POSTB(L)     ff / ff / to_out backward of layer L -> dO
+//     publish dO | delta (dO . ob per head) of the tile, per-sequence barrier
+//     attention backward of layer L: dQ of the tile's 16 queries against all keys, dK / dV of its 16 keys against all
+//     queries (q, k, v, lse come from the forward LAUNCH: plain loads; only dO | delta are handed off inside this one)
+// and one last PREB(0).  The stages are tok_bwd_kernel's (same operations, same order), the attention halves
+// attn_bwd_kernel's (LP = 0: exact fp32) or attn_bwd_lp_kernel's (LP = 1 / 2: the three accumulations on
+// v_mfma_f32_16x16x16 with bf16 / f16 operands), a wave per head.  What no other workgroup needs stays on the chip: the
+// gradient of the feature buffer (s_dF: only block 0's input gradient is written back, for the patch embedding),
+// d(qkv), the residual-path gradient.  Weight-matrix gradients leave through the tapes (tf_wgrad after this launch).
+struct ChainBwd {
+  TfDims d;
+  ChainW cw;
+  const float* params;
+  float* grads;
+  const float* F0;        // [nb][rows][DMF]
+  const float* save;      // tf_save layout
+  float* dF;              // [rows][DMF]: columns [0, DM) = gradient of block 0's input on return
+  const void* d_attnall;  // storage dtype
+  float* tape;            // [nb*4][TF_TAPE_W segments][rows]
+  float* otape;           // [nb][DMF segments][rows]
+  float* xchg;            // [2][rows][40]: dO | delta hand-off, by layer parity
+  unsigned* sync;         // [nseq + 1][SYNC_LINE]
+  int nb, ntile, nseq, dtype;
+  int64_t rows;
+};
+
+constexpr int QC = 64;      // rows per staged chunk of the attention backward
+constexpr int QP = 84;      // floats per row of the dK/dV chunk image: q (32) | dO (32) | pad; K|V image uses KVP
+constexpr int XW = 40;      // hand-off row: dO (32) | delta (8)
+
+template <int LP>
+struct ChainLp;
+template <>
+struct ChainLp<1> {
+  static __device__ __forceinline__ uint16_t one(float v) { return f2bf(v); }
+  static __device__ __forceinline__ u32x2 four(float a, float b, float c, float d) { return u32x2{pack_bf2(a, b), pack_bf2(c, d)}; }
+  static __device__ __forceinline__ f32x4 mma(const u32x2& a, const u32x2& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+  }
+};
+typedef __attribute__((ext_vector_type(4))) _Float16 chain_f16x4;
+template <>
+struct ChainLp<2> {
+  static __device__ __forceinline__ uint16_t one(float v) { return f2h(v); }
+  static __device__ __forceinline__ u32x2 four(float a, float b, float c, float d) { return u32x2{pack_h2(a, b), pack_h2(c, d)}; }
+  static __device__ __forceinline__ f32x4 mma(const u32x2& a, const u32x2& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(chain_f16x4, a), __builtin_bit_cast(chain_f16x4, b), c, 0, 0, 0);
+  }
+};
+
+__device__ __forceinline__ f32x4 chain_mfma4(float a, float b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+template <bool TRAIN, int LP>
+__global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
+  HDF_CHAIN_PRIO();
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const TfDims& d = a.d;
+  const int DM = d.DM, DMF = d.DMF, ldF = DMF + 4, ldD = DM + 4, N = d.N, BN = d.B * N;
+  float* s_F = sm;                       // [16][ldF]  feature rows of block bo (OUTB)
+  float* s_dF = s_F + TT * ldF;          // [16][ldF]  gradient of the current block's feature rows
+  float* s_do = s_dF + TT * ldF;         // [16][ldD]  masked gradient of the out_layer output
+  float* s_dq = s_do + TT * ldD;         // [16][100]  d(qkv) of the tile (written by the attention backward)
+  float* s_a = s_dq + TT * 100;          // [16][36] x 7 small tiles
+  float* s_b = s_a + TT * LD32;
+  float* s_c = s_b + TT * LD32;
+  float* s_e = s_c + TT * LD32;
+  float* s_dg = s_e + TT * LD32;
+  float* s_gx = s_dg + TT * LD32;
+  float* s_dO = s_gx + TT * LD32;        // dO of the tile (attention backward operand)
+  float* s_f = s_dO + TT * LD32;         // [16][68]
+  float* s_dz = s_f + TT * LD64;         // [16][68]
+  float* s_red = s_dz + TT * LD64;       // [2][16][16]
+  float* s_dl = s_red + 2 * 16 * 16;     // [16][8] delta of the tile
+  float* s_at = s_dl + TT * 8;           // attention chunk images: 2 x (QC x QP floats + 2 x [8][QC] floats + 2 x [8][5][QC] u16)
+  constexpr int AT_IMG = QC * QP, AT_T = 8 * QC, AT_U = 8 * 5 * QC / 2;   // (u16 arrays counted in floats)
+  constexpr int AT_BUF = AT_IMG + 2 * AT_T + 2 * AT_U;
+  const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6, wave = wave8 & 3, col = lane & 15, g = lane >> 4;
+  const bool cw = tid < 256;
+  const int lrow = (tid >> 4) & 15, lc = (tid & 15) * 2;   // the "LayerNorm" thread map of the first 256 threads
+  const int seq = blockIdx.x % a.nseq, tile = blockIdx.x / a.nseq;
+  const int m = seq / d.B, bsm = seq - m * d.B;
+  const int n0 = tile * TT, nvalid = min(TT, N - n0);
+  const int t0k = bsm * N + n0;
+  const int64_t mo = (int64_t)m * d.mstride, rb = (int64_t)m * BN;
+  const int64_t trows = a.rows;
+  const DropF dr{TRAIN ? 1 : 0, d.seed, d.thresh24, d.keep_scale};
+  float* pm = const_cast<float*>(a.params);
+  unsigned* cnt = a.sync + seq * SYNC_LINE;
+  unsigned* tmo = a.sync + a.nseq * SYNC_LINE;
+  bool dead = false;
+  const int nl = a.nb * 4;
+  float r_acc0 = 0.f, r_acc1 = 0.f;      // residual-path gradient of the layer in flight (POSTB -> PREB)
+
+  for (int L = nl - 1; L >= -1; L--) {
+    const bool PREB = L + 1 < nl, POSTB = L >= 0, OUTB = POSTB && (L & 3) == 3;
+    const int Lq = L + 1, bq = Lq >> 2, lq = Lq & 3;   // PREB's layer
+    const int bp = L >> 2, lp = L & 3, bo = bp;        // POSTB's layer, OUTB's block
+    int t0 = t0k;
+    asm volatile("" : "+s"(t0));   // (see the forward kernel: keeps the row addresses of every stage inside the loop)
+    auto tok = [&](int row) { return t0 + min(row, nvalid - 1); };
+    const bool lok = lrow < nvalid;
+    const int64_t lr = (rb + tok(lrow)) * 32 + lc;
+    // ------------------------------------------------------------------ requests of the token phase
+    const int Kq = PREB ? DM + 32 * lq : 0;
+    CFrag<12> c_q{};
+    CFrag<8> c_w0[6]{};
+    WFrag<2> f_w1{};
+    CFrag<8> c_w2{}, c_w1{};
+    CFrag<4> c_wo{};
+    LnP ln1{}, ln2{};
+    float p_b1 = 0.f, r_h[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, r_ob[2] = {0.f, 0.f}, r_h0[2] = {0.f, 0.f};
+    TfLayerP gq{}, gp{};
+    if (PREB) {
+      float* w0 = chain_w0(a.cw, pm, bq, lq) + mo;
+      float* rest = w0 + 32 * Kq;
+      float* gw0 = chain_w0(a.cw, a.grads, bq, lq) + mo;
+      float* grest = gw0 + 32 * Kq;
+      gq.b0 = grest + CO_B0, gq.ln1g = grest + CO_LN1G, gq.ln1b = grest + CO_LN1B;
+      if (cw) {
+        cload(c_q, rest + CO_WQKV, 32, 16 * (wave & 1), 32, 24, 12 * (wave >> 1), 12);
+#pragma unroll
+        for (int j = 0; j < 6; j++) cload(c_w0[j], w0, Kq, 16 * (wave + 4 * j), Kq, 8, 0, 8);
+        ln1 = ln_load(rest + CO_LN1G, rest + CO_LN1B);
+        const float* h0 = a.save + (int64_t)Lq * a.rows * 232;
+        r_h0[0] = h0[lr], r_h0[1] = h0[lr + 1];
+      }
+    }
+    if (POSTB) {
+      float* w0 = chain_w0(a.cw, pm, bp, lp) + mo;
+      float* rest = w0 + 32 * (DM + 32 * lp);
+      float* grest = chain_w0(a.cw, a.grads, bp, lp) + mo + 32 * (DM + 32 * lp);
+      gp.bout = grest + CO_BOUT, gp.ln2g = grest + CO_LN2G, gp.ln2b = grest + CO_LN2B, gp.b1 = grest + CO_B1, gp.b2 = grest + CO_B2;
+      if (cw) {
+        wload(f_w1, rest + CO_W1, 32, 16 * wave, 8, 0, 2);
+        cload(c_w2, rest + CO_W2, 64, 16 * wave, 64, 8, 0, 8);
+        cload(c_w1, rest + CO_W1, 32, 16 * (wave & 1), 32, 16, 8 * (wave >> 1), 8);
+        cload(c_wo, rest + CO_WOUT, 32, 16 * (wave & 1), 32, 8, 4 * (wave >> 1), 4);
+        ln2 = ln_load(rest + CO_LN2G, rest + CO_LN2B);
+        p_b1 = rest[CO_B1 + 16 * wave + col];
+        const float* sv = a.save + (int64_t)L * a.rows * 232;
+        const float* h1s = sv + a.rows * 168;
+        const float* h2s = sv + a.rows * 200;
+        const float* ob = sv + a.rows * 128;
+        r_h[0][0] = h1s[lr], r_h[0][1] = h1s[lr + 1], r_h[1][0] = h2s[lr], r_h[1][1] = h2s[lr + 1];
+        r_ob[0] = ob[lr], r_ob[1] = ob[lr + 1];
+      }
+    }
+    CHAIN_STAMPB(0);
+    if (PREB && cw) s_a[lrow * LD32 + lc] = r_h0[0], s_a[lrow * LD32 + lc + 1] = r_h0[1];
+    __syncthreads();
+    CHAIN_STAMPB(1);
+
+    // ------------------------------------------------------------------ PREB(bq, lq)
+    if (PREB) {
+      float* tape_q = a.tape + (int64_t)Lq * a.rows * TF_TAPE_W;
+      float rs1 = 0.f;
+      if (cw) rs1 = ln32_keep(s_a, s_b, s_c, ln1);   // t = LN1(h0) -> s_b, xh -> s_c
+      __syncthreads();
+      if (cw) {
+        tape_store(tape_q, trows, TF_T_DQ, s_dq, 100, 96, rb + t0, nvalid);
+        tape_store(tape_q, trows, TF_T_T, s_b, LD32, 32, rb + t0, nvalid);
+      }
+      f32x4 accq = zero4();
+      if (cw) {  // dt = dqkv * Wqkv -> s_e
+        cmma(accq, c_q, s_dq, 100, 24, 12 * (wave >> 1), 12);
+        if (wave >= 2) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) s_red[((wave & 1) * 16 + 4 * g + r) * 16 + col] = accq[r];
+        }
+      }
+      __syncthreads();
+      if (cw && wave < 2) {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          s_e[(4 * g + r) * LD32 + 16 * wave + col] = accq[r] + s_red[(wave * 16 + 4 * g + r) * 16 + col];
+      }
+      __syncthreads();
+      if (cw) {  // LN1 backward + the residual-path gradient -> dh0 (s_a)
+        float dh0v, dh1v;
+        ln32_bwd(s_e, s_c, s_gx, rs1, ln1, dh0v, dh1v);
+        s_a[lrow * LD32 + lc] = lok ? dh0v + r_acc0 : 0.f;
+        s_a[lrow * LD32 + lc + 1] = lok ? dh1v + r_acc1 : 0.f;
+      }
+      __syncthreads();
+      if (cw) {
+        colsum_atomic(gq.ln1g, 32, s_gx, LD32, 0);
+        colsum_atomic(gq.ln1b, 32, s_e, LD32, 64);
+        colsum_atomic(gq.b0, 32, s_a, LD32, 128);
+        tape_store(tape_q, trows, TF_T_DH0, s_a, LD32, 32, rb + t0, nvalid);
+        // dF[:, 0:Kq] += dh0 * W0
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+          const int nn = 16 * (wave + 4 * j);
+          if (nn < Kq) {
+            f32x4 acc = zero4();
+            cmma(acc, c_w0[j], s_a, LD32, 8, 0, 8);
+            const int c = nn + col;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              const int row = 4 * g + r;
+              const bool ok = row < nvalid;
+              const float v = ok ? s_dF[row * ldF + min(c, Kq - 1)] + acc[r] : 0.f;
+              if (c < Kq) {
+                if (OUTB) {
+                  s_do[row * ldD + c] = v;          // (lq = 0: Kq = DM) consumed below
+                } else {
+                  if (!POSTB) {                     // the last token phase: block 0's input gradient leaves the chip
+                    if (ok) a.dF[(rb + t0 + row) * DMF + c] = v;
+                  } else {
+                    s_dF[row * ldF + c] = v;
+                    if (c >= Kq - 32) s_dg[row * LD32 + c - (Kq - 32)] = v;
+                  }
+                }
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    CHAIN_STAMPB(2);
+    if (!POSTB) break;
+
+    // ------------------------------------------------------------------ OUTB(bo)
+    if (OUTB) {
+      const TfOutP po = chain_out(a.cw, pm, bo);
+      const TfOutP go = chain_out(a.cw, a.grads, bo);
+      const float* Fo = a.F0 + (int64_t)bo * a.rows * DMF;
+      float* otape = a.otape + (int64_t)bo * a.rows * DMF;
+      const uint32_t siteo = hdf_site_id(m, bo, 4, 0);
+      {
+        const int c4n = DMF >> 2;
+        for (int i = tid; i < TT * c4n; i += CT) {
+          const int row = i / c4n, c4 = (i - row * c4n) * 4;
+          *reinterpret_cast<float4*>(s_F + row * ldF + c4) = *reinterpret_cast<const float4*>(Fo + (rb + tok(row)) * DMF + c4);
+        }
+        for (int i = tid; i < TT * DM; i += CT) {
+          const int row = i / DM, c = i - row * DM, t = t0 + row;
+          float v;
+          if (PREB) {
+            v = s_do[row * ldD + c];
+          } else {
+            const int64_t ai = ((int64_t)bsm * N + n0 + min(row, nvalid - 1)) * ((int64_t)d.M * DM) + (int64_t)m * DM + c;
+            if (a.dtype == HDF_BF16)
+              v = ST<bf16_t>::ld(reinterpret_cast<const bf16_t*>(a.d_attnall) + ai);
+            else if (a.dtype == HDF_F16)
+              v = ST<f16_t>::ld(reinterpret_cast<const f16_t*>(a.d_attnall) + ai);
+            else
+              v = reinterpret_cast<const float*>(a.d_attnall)[ai];
+          }
+          s_do[row * ldD + c] = row < nvalid ? v * dr.mask(siteo + 1, (uint32_t)t * DM + c) : 0.f;
+        }
+      }
+      __syncthreads();
+      float zr[4] = {0.f, 0.f, 0.f, 0.f}, mk[4] = {0.f, 0.f, 0.f, 0.f};
+      if (cw) {
+        {  // z = Wa F + ba (recomputed), f = gelu(z) * mask -> s_f
+          f32x4 acc = zero4();
+          wmma_stream(acc, po.wa + mo, DMF, 16 * wave, s_F, ldF, DMF >> 2);
+          const int c = 16 * wave + col;
+          const float ba = po.ba[mo + c];
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int row = 4 * g + r, t = t0 + row;
+            zr[r] = acc[r] + ba;
+            mk[r] = dr.mask(siteo + 0, (uint32_t)t * 64 + c);
+            s_f[row * LD64 + c] = row < nvalid ? gelu_f(zr[r]) * mk[r] : 0.f;
+          }
+        }
+        {  // df = do * Wb ; dz = df * mask * gelu'(z) -> s_dz
+          f32x4 acc = zero4();
+          cmma_stream(acc, po.wb + mo, 64, 16 * wave, 64, s_do, ldD, DM >> 2);
+          const int c = 16 * wave + col;
+#pragma unroll
+          for (int r = 0; r < 4; r++) s_dz[(4 * g + r) * LD64 + c] = acc[r] * mk[r] * gelu_grad_f(zr[r]);
+        }
+      }
+      __syncthreads();
+      if (cw) {
+        tape_store(otape, trows, 0, s_do, ldD, DM, rb + t0, nvalid);
+        tape_store(otape, trows, DM, s_f, LD64, 64, rb + t0, nvalid);
+        tape_store(otape, trows, DM + 64, s_dz, LD64, 64, rb + t0, nvalid);
+        for (int c0 = 0; c0 < DM; c0 += 128) colsum_atomic(go.bb + mo + c0, min(128, DM - c0), s_do + c0, ldD, 0);
+        colsum_atomic(go.ba + mo, 64, s_dz, LD64, 128);
+        // dF[:, 0:DMF] = dz * Wa  (overwrites: the first writer of block bo's feature gradient)
+        for (int nn = 16 * wave; nn < DMF; nn += 64) {
+          f32x4 acc = zero4();
+          cmma_stream(acc, po.wa + mo, DMF, nn, DMF, s_dz, LD64, 16);
+          const int c = nn + col;
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int row = 4 * g + r;
+            s_dF[row * ldF + c] = acc[r];
+            if (c >= DMF - 32) s_dg[row * LD32 + c - (DMF - 32)] = row < nvalid ? acc[r] : 0.f;
+          }
+        }
+      }
+      __syncthreads();
+    }
+
+    CHAIN_STAMPB(3);
+    // ------------------------------------------------------------------ POSTB(bp, lp)
+    {
+      float* tape_p = a.tape + (int64_t)L * a.rows * TF_TAPE_W;
+      const uint32_t site0 = hdf_site_id(m, bp, lp, 0);
+      const int t = t0 + lrow;
+      const bool ok = lok;
+      float dcur0 = 0.f, dcur1 = 0.f;
+      if (cw) dcur0 = s_dg[lrow * LD32 + lc], dcur1 = s_dg[lrow * LD32 + lc + 1];
+      float dres0 = 0.f, dres1 = 0.f;
+#pragma unroll
+      for (int pass = 1; pass >= 0; pass--) {  // pass 1: the second ff (on h2) ; pass 0: the first ff (on h1)
+        __syncthreads();
+        float rs = 0.f;
+        if (cw) {
+          s_a[lrow * LD32 + lc] = r_h[pass][0];
+          s_a[lrow * LD32 + lc + 1] = r_h[pass][1];
+          rs = ln32_keep(s_a, s_b, s_c, ln2);   // u -> s_b, xh -> s_c
+          s_dg[lrow * LD32 + lc] = ok ? dcur0 * dr.mask(site0 + 2 + 2 * pass, (uint32_t)t * 32 + lc) : 0.f;
+          s_dg[lrow * LD32 + lc + 1] = ok ? dcur1 * dr.mask(site0 + 2 + 2 * pass, (uint32_t)t * 32 + lc + 1) : 0.f;
+        }
+        __syncthreads();
+        if (cw) {
+          f32x4 accz = zero4(), accd = zero4();
+          wmma(accz, f_w1, s_b, LD32, 8, 0, 2);            // z = W1 u  (tile wave)
+          cmma(accd, c_w2, s_dg, LD32, 8, 0, 8);           // df = dg * W2 (tile wave)
+          const int c = 16 * wave + col;
+          const float b1 = p_b1;
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int row = 4 * g + r, tt = t0 + row;
+            const float z = accz[r] + b1, mkv = dr.mask(site0 + 1 + 2 * pass, (uint32_t)tt * 64 + c);
+            s_f[row * LD64 + c] = row < nvalid ? gelu_f(z) * mkv : 0.f;
+            s_dz[row * LD64 + c] = row < nvalid ? accd[r] * mkv * gelu_grad_f(z) : 0.f;
+          }
+        }
+        __syncthreads();
+        f32x4 accu = zero4();
+        if (cw) {
+          const int c0 = pass ? TF_T_P1 : TF_T_P0;
+          tape_store(tape_p, trows, c0, s_dg, LD32, 32, rb + t0, nvalid);
+          tape_store(tape_p, trows, c0 + 32, s_f, LD64, 64, rb + t0, nvalid);
+          tape_store(tape_p, trows, c0 + 96, s_dz, LD64, 64, rb + t0, nvalid);
+          tape_store(tape_p, trows, c0 + 160, s_b, LD32, 32, rb + t0, nvalid);
+          colsum_atomic(gp.b2, 32, s_dg, LD32, 0);
+          colsum_atomic(gp.b1, 64, s_dz, LD64, 64);
+          // du = dz * W1 -> s_e
+          cmma(accu, c_w1, s_dz, LD64, 16, 8 * (wave >> 1), 8);
+          if (wave >= 2) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) s_red[((wave & 1) * 16 + 4 * g + r) * 16 + col] = accu[r];
+          }
+        }
+        __syncthreads();
+        if (cw && wave < 2) {
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            s_e[(4 * g + r) * LD32 + 16 * wave + col] = accu[r] + s_red[(wave * 16 + 4 * g + r) * 16 + col];
+        }
+        __syncthreads();
+        float dh0v = 0.f, dh1v = 0.f;
+        if (cw) {
+          ln32_bwd(s_e, s_c, s_gx, rs, ln2, dh0v, dh1v);
+          dh0v = ok ? dh0v : 0.f, dh1v = ok ? dh1v : 0.f;
+        }
+        __syncthreads();
+        if (cw) {
+          colsum_atomic(gp.ln2g, 32, s_gx, LD32, 0);
+          colsum_atomic(gp.ln2b, 32, s_e, LD32, 64);
+        }
+        if (pass == 1) {
+          dcur0 = dh0v, dcur1 = dh1v;   // h2 feeds only the second ff: its gradient flows into ff#1's output ...
+          dres0 = dh0v, dres1 = dh1v;   // ... and into the residual h1
+        } else {
+          dres0 += dh0v, dres1 += dh1v;
+        }
+      }
+      // to_out: a = (Wout ob + bout) * mask ; h1 = a + h0
+      __syncthreads();
+      if (cw) {
+        s_dg[lrow * LD32 + lc] = ok ? dres0 * dr.mask(site0 + 0, (uint32_t)t * 32 + lc) : 0.f;
+        s_dg[lrow * LD32 + lc + 1] = ok ? dres1 * dr.mask(site0 + 0, (uint32_t)t * 32 + lc + 1) : 0.f;
+        s_b[lrow * LD32 + lc] = r_ob[0];
+        s_b[lrow * LD32 + lc + 1] = r_ob[1];
+        r_acc0 = dres0, r_acc1 = dres1;   // -> PREB of this layer, after its attention backward
+      }
+      __syncthreads();
+      f32x4 acco = zero4();
+      if (cw) {
+        tape_store(tape_p, trows, TF_T_DGO, s_dg, LD32, 32, rb + t0, nvalid);
+        colsum_atomic(gp.bout, 32, s_dg, LD32, 0);
+        cmma(acco, c_wo, s_dg, LD32, 8, 4 * (wave >> 1), 4);
+        if (wave >= 2) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) s_red[((wave & 1) * 16 + 4 * g + r) * 16 + col] = acco[r];
+        }
+      }
+      __syncthreads();
+      if (cw && wave < 2) {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          s_dO[(4 * g + r) * LD32 + 16 * wave + col] = acco[r] + s_red[(wave * 16 + 4 * g + r) * 16 + col];
+      }
+      __syncthreads();
+      // delta = dO . ob per (token, head): attn_bwd's arithmetic (tf_dot4)
+      if (tid < TT * 8) {
+        const int row = tid >> 3, h = tid & 7;
+        s_dl[row * 8 + h] = tf_dot4(*reinterpret_cast<const float4*>(s_dO + row * LD32 + 4 * h),
+                                    *reinterpret_cast<const float4*>(s_b + row * LD32 + 4 * h));
+      }
+      __syncthreads();
+    }
+
+    CHAIN_STAMPB(4);
+    // ------------------------------------------------------------------ publish dO | delta, per-sequence barrier
+    const int par = L & 1;
+    float* xbase = a.xchg + ((int64_t)par * a.rows + rb + (int64_t)bsm * N) * XW;   // this sequence's rows, this parity
+    const __amdgpu_buffer_rsrc_t rx = chain_rsrc(xbase);
+    if (tid < TT * 10) {
+      const int row = tid / 10, c4 = (tid - row * 10) * 4;
+      if (row < nvalid) {
+        const float4 v = c4 < 32 ? *reinterpret_cast<const float4*>(s_dO + row * LD32 + c4)
+                                 : *reinterpret_cast<const float4*>(s_dl + row * 8 + (c4 - 32));
+        st16_sc1(rx, (uint32_t)(((n0 + row) * XW + c4) * 4), v);
+      }
+    }
+    chain_arrive(cnt);
+    // operands of this head (wave) for the tile's own 16 tokens, requested before the wait (forward launch's data)
+    const int head = wave8;
+    const float* sv = a.save + (int64_t)L * a.rows * 232;
+    const float* qkvL = sv + a.rows * 32 + (rb + (int64_t)bsm * N) * 96;   // the sequence's rows
+    const float* lseL = sv + a.rows * 160 + (rb + (int64_t)bsm * N) * 8;
+    const int rown = n0 + min(col, nvalid - 1);   // this lane's token (as a query in the dQ half, as a key in the other)
+    const float own_q = qkvL[(int64_t)rown * 96 + head * 4 + g];
+    const float own_k = qkvL[(int64_t)rown * 96 + 32 + head * 4 + g];
+    const float own_v = qkvL[(int64_t)rown * 96 + 64 + head * 4 + g];
+    const float own_lse = lseL[(int64_t)rown * 8 + head];
+    CHAIN_STAMPB(5);
+    chain_wait(cnt, (unsigned)(a.ntile * (nl - L)), tmo, dead);
+    CHAIN_STAMPB(6);
+
+    // ------------------------------------------------------------------ attention backward of layer L: head = wave
+    {
+      const int NP = attn_rows(N), nchunk = (NP + QC - 1) / QC;
+      const int srow = tid >> 3, spart = tid & 7;   // staging: row of the chunk, 16-byte part
+      const bool rvalid = col < nvalid;
+      // ---- dQ of the tile's queries: K | V chunks (image rows of KVP floats: K (32) | V (32) | pad)
+      {
+        const float4 go = *reinterpret_cast<const float4*>(s_dO + col * LD32 + head * 4);
+        const float delta = s_dl[col * 8 + head];
+        const float ls = own_lse * LOG2E;
+        const float bqv = own_q * (0.5f * LOG2E);
+        const float bg = s_dO[col * LD32 + head * 4 + g];
+        float4 pk, pv;
+        auto stage_load = [&](int c) __attribute__((always_inline)) {
+          const int j = min(c * QC + srow, N - 1);
+          pk = *reinterpret_cast<const float4*>(qkvL + (int64_t)j * 96 + 32 + 4 * spart);
+          pv = *reinterpret_cast<const float4*>(qkvL + (int64_t)j * 96 + 64 + 4 * spart);
+        };
+        auto stage_store = [&](int c) __attribute__((always_inline)) {
+          const float z = c * QC + srow < N ? 1.f : 0.f;
+          float* img = s_at + (c & 1) * AT_BUF;
+          const float4 kk = make_float4(pk.x * z, pk.y * z, pk.z * z, pk.w * z);
+          *reinterpret_cast<float4*>(img + srow * KVP + 4 * spart) = kk;
+          *reinterpret_cast<float4*>(img + srow * KVP + 32 + 4 * spart) = make_float4(pv.x * z, pv.y * z, pv.z * z, pv.w * z);
+          if (LP) {
+            uint16_t* kt = reinterpret_cast<uint16_t*>(img + AT_IMG + 2 * AT_T) + spart * 5 * QC;   // [head][5][QC]
+            constexpr int L1 = LP ? LP : 1;
+            kt[0 * QC + srow] = ChainLp<L1>::one(kk.x), kt[1 * QC + srow] = ChainLp<L1>::one(kk.y);
+            kt[2 * QC + srow] = ChainLp<L1>::one(kk.z), kt[3 * QC + srow] = ChainLp<L1>::one(kk.w);
+            kt[4 * QC + srow] = 0;
+          }
+        };
+        stage_load(0);
+        stage_store(0);
+        __syncthreads();
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};          // LP: dQ[query 4g + r][component col] (col < 4)
+        f2 d01 = {0.f, 0.f}, d23 = {0.f, 0.f};     // exact: this lane's partial dQ of its query
+        const f32x4 nl4 = {-ls, -ls, -ls, -ls}, nd4 = {-delta, -delta, -delta, -delta}, z4 = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < nchunk; c++) {
+          if (c + 1 < nchunk) stage_load(c + 1);
+          const float* img = s_at + (c & 1) * AT_BUF;
+          const uint16_t* kt = reinterpret_cast<const uint16_t*>(img + AT_IMG + 2 * AT_T) + head * 5 * QC + min(col, 4) * QC + 4 * g;
+          const int jbase = c * QC, ntrip = min(QC, NP - jbase) / ATRIP;
+          for (int k = 0; k < ntrip; k++) {
+            const int jj = k * ATRIP, j0 = jbase + jj;
+            const float ka = img[(jj + col) * KVP + head * 4 + g], va = img[(jj + col) * KVP + 32 + head * 4 + g];
+            if (LP) {
+              constexpr int L1 = LP ? LP : 1;
+              const f32x4 cs = chain_mfma4(ka, bqv, nl4), ct = chain_mfma4(va, bg, nd4);
+              const u32x2 kb = *reinterpret_cast<const u32x2*>(kt + jj);
+              float ds[4];
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
+                ds[u] = __builtin_amdgcn_exp2f(cs[u]) * ct[u];
+                if (j0 + ATRIP > N) ds[u] = (j0 + 4 * g + u < N) ? ds[u] : 0.f;
+              }
+              acc = ChainLp<L1>::mma(ChainLp<L1>::four(ds[0], ds[1], ds[2], ds[3]), kb, acc);
+            } else {
+              const f32x4 s4 = chain_mfma4(ka, bqv, z4), t4 = chain_mfma4(va, bg, z4);
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
+                const float4 kr = *reinterpret_cast<const float4*>(img + (jj + 4 * g + u) * KVP + head * 4);
+                float pr = __builtin_amdgcn_exp2f(s4[u] - ls);
+                if (j0 + ATRIP > N) pr = (j0 + 4 * g + u < N) ? pr : 0.f;
+                const float dsv = pr * (t4[u] - delta);
+                const f2 dd = {dsv, dsv};
+                d01 = __builtin_elementwise_fma(dd, lo2(kr), d01);
+                d23 = __builtin_elementwise_fma(dd, hi2(kr), d23);
+              }
+            }
+          }
+          if (c + 1 < nchunk) stage_store(c + 1);
+          __syncthreads();
+        }
+        if (LP) {
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            if (col < 4) s_dq[(4 * g + r) * 100 + head * 4 + col] = (4 * g + r < nvalid) ? 0.5f * acc[r] : 0.f;
+        } else {
+#pragma unroll
+          for (int off = 16; off < 64; off <<= 1) {
+            d01.x += __shfl_xor(d01.x, off, 64), d01.y += __shfl_xor(d01.y, off, 64);
+            d23.x += __shfl_xor(d23.x, off, 64), d23.y += __shfl_xor(d23.y, off, 64);
+          }
+          if (g == 0)
+            *reinterpret_cast<float4*>(s_dq + col * 100 + head * 4) =
+                rvalid ? make_float4(0.5f * d01.x, 0.5f * d01.y, 0.5f * d23.x, 0.5f * d23.y) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+      CHAIN_STAMPB(7);
+      // ---- dK, dV of the tile's keys: q | dO chunks (image rows of QP floats), (lse, delta) per head as [8][QC] arrays
+      {
+        const float bk = own_k, bv = own_v;
+        float4 pq, pg, pl;   // q part, dO part, and for spart < 4: lse (0, 1) / delta (2, 3) halves
+        auto stage_load = [&](int c) __attribute__((always_inline)) {
+          const int j = min(c * QC + srow, N - 1);
+          pq = *reinterpret_cast<const float4*>(qkvL + (int64_t)j * 96 + 4 * spart);
+          pg = ld16_sc1(rx, (uint32_t)((j * XW + 4 * spart) * 4));
+          if (spart < 2)
+            pl = *reinterpret_cast<const float4*>(lseL + (int64_t)j * 8 + 4 * spart);
+          else if (spart < 4)
+            pl = ld16_sc1(rx, (uint32_t)((j * XW + 32 + 4 * (spart - 2)) * 4));
+        };
+        auto stage_store = [&](int c) __attribute__((always_inline)) {
+          const bool real = c * QC + srow < N;
+          const float z = real ? 1.f : 0.f, sc = real ? 0.5f * LOG2E : 0.f;
+          float* img = s_at + (c & 1) * AT_BUF;
+          float* tl = img + AT_IMG;           // [8][QC] lse term
+          float* td = tl + AT_T;              // [8][QC] delta term
+          *reinterpret_cast<float4*>(img + srow * QP + 4 * spart) = make_float4(pq.x * sc, pq.y * sc, pq.z * sc, pq.w * sc);
+          if (LP) {
+            constexpr int L1 = LP ? LP : 1;
+            *reinterpret_cast<float4*>(img + srow * QP + 32 + 4 * spart) = make_float4(pg.x * z, pg.y * z, pg.z * z, pg.w * z);
+            uint16_t* qt = reinterpret_cast<uint16_t*>(td + AT_T) + spart * 5 * QC;
+            uint16_t* gt = qt + 8 * 5 * QC;
+            qt[0 * QC + srow] = ChainLp<L1>::one(pq.x * z), qt[1 * QC + srow] = ChainLp<L1>::one(pq.y * z);
+            qt[2 * QC + srow] = ChainLp<L1>::one(pq.z * z), qt[3 * QC + srow] = ChainLp<L1>::one(pq.w * z);
+            qt[4 * QC + srow] = 0;
+            gt[0 * QC + srow] = ChainLp<L1>::one(pg.x * z), gt[1 * QC + srow] = ChainLp<L1>::one(pg.y * z);
+            gt[2 * QC + srow] = ChainLp<L1>::one(pg.z * z), gt[3 * QC + srow] = ChainLp<L1>::one(pg.w * z);
+            gt[4 * QC + srow] = 0;
+            if (spart < 2) {
+              const int h4 = 4 * spart;
+              tl[(h4 + 0) * QC + srow] = real ? -pl.x * LOG2E : -INFINITY, tl[(h4 + 1) * QC + srow] = real ? -pl.y * LOG2E : -INFINITY;
+              tl[(h4 + 2) * QC + srow] = real ? -pl.z * LOG2E : -INFINITY, tl[(h4 + 3) * QC + srow] = real ? -pl.w * LOG2E : -INFINITY;
+            } else if (spart < 4) {
+              const int h4 = 4 * (spart - 2);
+              td[(h4 + 0) * QC + srow] = -z * pl.x, td[(h4 + 1) * QC + srow] = -z * pl.y;
+              td[(h4 + 2) * QC + srow] = -z * pl.z, td[(h4 + 3) * QC + srow] = -z * pl.w;
+            }
+          } else {
+            *reinterpret_cast<float4*>(img + srow * QP + 32 + 4 * spart) =
+                make_float4(real ? pg.x : 0.f, real ? pg.y : 0.f, real ? pg.z : 0.f, real ? pg.w : 0.f);
+            if (spart < 2) {
+              const int h4 = 4 * spart;
+              tl[(h4 + 0) * QC + srow] = real ? pl.x * LOG2E : INFINITY, tl[(h4 + 1) * QC + srow] = real ? pl.y * LOG2E : INFINITY;
+              tl[(h4 + 2) * QC + srow] = real ? pl.z * LOG2E : INFINITY, tl[(h4 + 3) * QC + srow] = real ? pl.w * LOG2E : INFINITY;
+            } else if (spart < 4) {
+              const int h4 = 4 * (spart - 2);
+              td[(h4 + 0) * QC + srow] = real ? pl.x : 0.f, td[(h4 + 1) * QC + srow] = real ? pl.y : 0.f;
+              td[(h4 + 2) * QC + srow] = real ? pl.z : 0.f, td[(h4 + 3) * QC + srow] = real ? pl.w : 0.f;
+            }
+          }
+        };
+        stage_load(0);
+        stage_store(0);
+        __syncthreads();
+        f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+        f2 dk01 = {0.f, 0.f}, dk23 = {0.f, 0.f}, dv01 = {0.f, 0.f}, dv23 = {0.f, 0.f};
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < nchunk; c++) {
+          if (c + 1 < nchunk) stage_load(c + 1);
+          const float* img = s_at + (c & 1) * AT_BUF;
+          const float* tl = img + AT_IMG + head * QC;
+          const float* td = img + AT_IMG + AT_T + head * QC;
+          const uint16_t* qt = reinterpret_cast<const uint16_t*>(img + AT_IMG + 2 * AT_T) + head * 5 * QC + min(col, 4) * QC + 4 * g;
+          const uint16_t* gt = qt + 8 * 5 * QC;
+          const int ibase = c * QC, ntrip = min(QC, NP - ibase) / ATRIP;
+          for (int k = 0; k < ntrip; k++) {
+            const int ii = k * ATRIP;
+            const float qa = img[(ii + col) * QP + head * 4 + g], ga = img[(ii + col) * QP + 32 + head * 4 + g];
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(tl + ii + 4 * g), d4 = *reinterpret_cast<const f32x4*>(td + ii + 4 * g);
+            if (LP) {
+              constexpr int L1 = LP ? LP : 1;
+              const f32x4 cs = chain_mfma4(qa, bk, l4), ct = chain_mfma4(ga, bv, d4);
+              const u32x2 qb = *reinterpret_cast<const u32x2*>(qt + ii);
+              const u32x2 gb = *reinterpret_cast<const u32x2*>(gt + ii);
+              const float p0 = __builtin_amdgcn_exp2f(cs[0]), p1 = __builtin_amdgcn_exp2f(cs[1]);
+              const float p2 = __builtin_amdgcn_exp2f(cs[2]), p3 = __builtin_amdgcn_exp2f(cs[3]);
+              dv = ChainLp<L1>::mma(ChainLp<L1>::four(p0, p1, p2, p3), gb, dv);
+              dk = ChainLp<L1>::mma(ChainLp<L1>::four(p0 * ct[0], p1 * ct[1], p2 * ct[2], p3 * ct[3]), qb, dk);
+            } else {
+              const f32x4 cs = chain_mfma4(qa, bk, z4), ct = chain_mfma4(ga, bv, z4);
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
+                const float4 qr = *reinterpret_cast<const float4*>(img + (ii + 4 * g + u) * QP + head * 4);
+                const float4 gr = *reinterpret_cast<const float4*>(img + (ii + 4 * g + u) * QP + 32 + head * 4);
+                const float pr = __builtin_amdgcn_exp2f(cs[u] - l4[u]);   // padded queries: exp2(-inf) = 0
+                const f2 pp = {pr, pr};
+                dv01 = __builtin_elementwise_fma(pp, lo2(gr), dv01);
+                dv23 = __builtin_elementwise_fma(pp, hi2(gr), dv23);
+                const float dsv = pr * (ct[u] - d4[u]);
+                const f2 dd = {dsv, dsv};
+                dk01 = __builtin_elementwise_fma(dd, lo2(qr), dk01);
+                dk23 = __builtin_elementwise_fma(dd, hi2(qr), dk23);
+              }
+            }
+          }
+          if (c + 1 < nchunk) stage_store(c + 1);
+          __syncthreads();
+        }
+        if (LP) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            if (col < 4) {
+              const bool ok = 4 * g + r < nvalid;
+              s_dq[(4 * g + r) * 100 + 32 + head * 4 + col] = ok ? 0.5f * dk[r] : 0.f;
+              s_dq[(4 * g + r) * 100 + 64 + head * 4 + col] = ok ? dv[r] : 0.f;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int off = 16; off < 64; off <<= 1) {
+            dk01.x += __shfl_xor(dk01.x, off, 64), dk01.y += __shfl_xor(dk01.y, off, 64);
+            dk23.x += __shfl_xor(dk23.x, off, 64), dk23.y += __shfl_xor(dk23.y, off, 64);
+            dv01.x += __shfl_xor(dv01.x, off, 64), dv01.y += __shfl_xor(dv01.y, off, 64);
+            dv23.x += __shfl_xor(dv23.x, off, 64), dv23.y += __shfl_xor(dv23.y, off, 64);
+          }
+          if (g == 0) {
+            const float un = 1.f / LOG2E;  // the staged queries carry log2(e)
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(s_dq + col * 100 + 32 + head * 4) =
+                rvalid ? make_float4(dk01.x * un, dk01.y * un, dk23.x * un, dk23.y * un) : z;
+            *reinterpret_cast<float4*>(s_dq + col * 100 + 64 + head * 4) =
+                rvalid ? make_float4(dv01.x, dv01.y, dv23.x, dv23.y) : z;
+          }
+        }
+      }
+      CHAIN_STAMPB(8);
+    }
+  }
+}
+
+size_t chain_bwd_lds(const TfDims& d) {
+  const size_t fl = (size_t)2 * TT * (d.DMF + 4) + TT * (d.DM + 4) + TT * 100 + 7 * TT * LD32 + 2 * TT * LD64 +
+                    2 * 16 * 16 + TT * 8 + 2 * (QC * QP + 2 * 8 * QC + 2 * (8 * 5 * QC / 2));
+  return fl * sizeof(float);
+}
+
 size_t chain_fwd_lds(const TfDims& d) {
   return (size_t)(TT * (d.DMF + 4) + 2 * TT * LD32 + TT * LD64 + 2 * 16 * 16 + TT * LD32 + TT * LDQ + 2 * KVC * KVP) *
          sizeof(float);
@@ -656,6 +1338,40 @@ int tf_chain_forward(const TfDims& d, const TfChainP& cp, int nb, const float* p
     HDF_TRY(chain_allow_lds(tf_chain_fwd_kernel<false>, shm));
     hipLaunchKernelGGL(tf_chain_fwd_kernel<false>, grid, dim3(CT), shm, st, a);
   }
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
+int tf_chain_backward(const TfDims& d, const TfChainP& cp, int nb, const float* params, float* grads, const float* F0,
+                      const float* save, float* dF, const void* d_attnall, float* tape, float* otape, float* xchg,
+                      unsigned* sync, int dtype, hipStream_t st) {
+  HDF_CHECK_ARG(tf_chain_supported(d), "transformer chain: shape not supported (M %d B %d N %d DM %d)", d.M, d.B, d.N, d.DM);
+  ChainBwd a{};
+  HDF_CHECK_ARG(chain_digest(cp, d.DM, a.cw), "transformer chain: irregular parameter layout");
+  HDF_CHECK_ARG(dtype == HDF_F32 || dtype == HDF_BF16 || dtype == HDF_F16, "unsupported dtype %d", dtype);
+  a.d = d, a.params = params, a.grads = grads, a.F0 = F0, a.save = save, a.dF = dF, a.d_attnall = d_attnall;
+  a.tape = tape, a.otape = otape, a.xchg = xchg, a.sync = sync, a.dtype = dtype;
+  a.nb = nb, a.ntile = ceil_div(d.N, TT), a.nseq = d.M * d.B, a.rows = (int64_t)d.M * d.B * d.N;
+  const size_t shm = chain_bwd_lds(d);
+  HDF_CHECK_ARG(shm <= LDS_LIMIT_F, "transformer chain backward: %zu B of LDS", shm);
+  hipError_t e = hipMemsetAsync(sync, 0, tf_chain_sync_bytes(d), st);
+  if (e != hipSuccess) {
+    hdf_set_error("transformer chain: hipMemsetAsync failed: %s", hipGetErrorString(e));
+    return HDF_ERR_HIP;
+  }
+  const dim3 grid(a.nseq * a.ntile);
+#define CHAIN_BWD_CASE(TR, LPV)                                                      \
+  if ((d.training != 0) == TR && dtype == LPV) {                                     \
+    HDF_TRY(chain_allow_lds(tf_chain_bwd_kernel<TR, LPV>, shm));                     \
+    hipLaunchKernelGGL((tf_chain_bwd_kernel<TR, LPV>), grid, dim3(CT), shm, st, a);  \
+  }
+  CHAIN_BWD_CASE(true, 0)
+  CHAIN_BWD_CASE(true, 1)
+  CHAIN_BWD_CASE(true, 2)
+  CHAIN_BWD_CASE(false, 0)
+  CHAIN_BWD_CASE(false, 1)
+  CHAIN_BWD_CASE(false, 2)
+#undef CHAIN_BWD_CASE
   HDF_LAUNCH_CHECK();
   return HDF_OK;
 }

@@ -97,3 +97,55 @@ def test_chain_forward_eval_mode_and_repeat_calls():
     for a, b in zip(outs2, got["outs"]):
         assert torch.equal(a, b)
     assert int(rt.read_region("tf_sync").view(torch.int32)[32 * case[0] * case[5]]) == 0
+
+
+def _backward(case, chain):
+    """forward + backward under one arrangement; returns the gradient buffer and the transformer's backward regions"""
+    cin, ncls, nf, image, depth, batch, dtype = case
+    res, (plan, rt, params, x, outs) = _forward(case, chain)
+    if chain:
+        os.environ.pop("HDF_NO_TF_CHAIN", None)
+    else:
+        os.environ["HDF_NO_TF_CHAIN"] = "1"
+    try:
+        g = torch.Generator().manual_seed(5)
+        douts = [(torch.randn(o.shape, generator=g) * 1e-2).to(DEV).to(o.dtype) for o in outs]
+        grads = torch.zeros_like(params)
+        rt.backward(x, params, douts, grads)
+        torch.cuda.synchronize()
+        N = (image[0] // 16) ** 3
+        rows = cin * batch * N
+        DMF = 4 * nf + 128
+        return {"grads": grads.clone(), "tape": rt.read_region("tf_tape").clone(),
+                "otape": rt.read_region("tf_otape").clone(),
+                "dF": rt.read_region("tf_dF").view(rows, DMF)[:, :4 * nf].clone(),
+                "sync": rt.read_region("tf_sync").view(torch.int32).clone(), "table": plan.table}
+    finally:
+        os.environ.pop("HDF_NO_TF_CHAIN", None)
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "in%d_nf%d_%d_td%d_b%d_t%d" % (c[0], c[2], c[3][0], c[4], c[5], c[6]))
+def test_chain_backward_is_bit_identical_to_the_launch_chain(case):
+    """tapes (the operands of every weight-matrix gradient), the input gradient of block 0 and every gradient that is a
+    fixed-order sum: bit for bit; bias / LayerNorm-parameter gradients (fp32 atomics in both arrangements): 1e-4"""
+    ref = _backward(case, chain=False)
+    ref2 = _backward(case, chain=False)   # what the launch chain itself reproduces run to run is what must be bit-identical
+    got = _backward(case, chain=True)
+    nseq = case[0] * case[5]
+    half = 1 << 17
+    assert int(got["sync"][32 * nseq]) == 0 and int(got["sync"][half + 32 * nseq]) == 0, "a per-sequence barrier timed out"
+    for name in ("dF", "tape", "otape"):
+        a, b = got[name], ref[name]
+        nd = a.view(torch.int32) != b.view(torch.int32)
+        assert not bool(nd.any()), "%s differs in %d of %d words, max |d| %.3e" % (
+            name, int(nd.sum()), a.numel(), float((a - b).abs().max()))
+    for name, off, numel, shape in got["table"]:
+        a, b = got["grads"][off:off + numel], ref["grads"][off:off + numel]
+        # fp32 atomics (run-to-run rounding): the transformer's bias / LayerNorm / embedding gradients and the heads'
+        atomic = name.startswith("conv1x1") or (
+            name.startswith("attns.") and (len(shape) == 1 or "position_embeddings" in name or "patch" in name))
+        if atomic or not torch.equal(b.view(torch.int32), ref2["grads"][off:off + numel].view(torch.int32)):
+            scale = float(b.abs().max()) + 1e-12
+            assert float((a - b).abs().max()) <= 1e-4 * scale + 1e-9, name
+        else:
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), name

@@ -17,6 +17,27 @@ cin, ncls, nf, image, depth, batch, dtype = case
 N = (image[0] // 16) ** 3
 nwg = cin * batch * ((N + 15) // 16)
 nl = (depth // 4) * 4
+if which == "bwd":
+    for rep in range(2):
+        got = tc._backward(case, chain=True)
+    sync = got["sync"]
+    st = sync[(1 << 19):(1 << 19) + nwg * 32 * 16 * 2].view(torch.int64).view(nwg, 32, 16).cpu().double() / 100.0
+    # backward stamps are indexed by L + 1 (L = nl - 1 .. -1): row r = token phase that ends with the attention of layer r - 1
+    tot = st[:, 0, 2] - st[:, nl, 0]
+    print("kernel span per workgroup: median %.1f us, max %.1f us" % (tot.median(), tot.max()))
+    PHB = [("requests issued -> barrier", 0, 1), ("PREB", 1, 2), ("OUTB (block boundaries only)", 2, 3), ("POSTB", 3, 4),
+           ("publish", 4, 5), ("poll", 5, 6), ("attention dQ half", 6, 7), ("attention dK/dV half", 7, 8)]
+    R = torch.arange(2, nl - 1)
+    inner = R[((R - 1) % 4) != 3]
+    for name, a, b in PHB:
+        Rs = R[((R - 1) % 4) == 3] if "OUTB" in name else inner
+        dd = st[:, Rs, b] - st[:, Rs, a]
+        print("%-42s median %6.2f  mean %6.2f  max-over-wg (mean over layers) %6.2f" % (name, dd.median(), dd.mean(), dd.max(dim=0).values.mean()))
+    nxt = st[:, R - 1, 0] - st[:, R, 8]
+    print("%-42s median %6.2f" % ("attention end -> next phase's requests", nxt.median()))
+    per = st[:, R - 1, 0] - st[:, R, 0]
+    print("per layer: median %.2f us, mean %.2f us" % (per.median(), per.mean()))
+    sys.exit(0)
 for rep in range(3):
     got, keep = tc._forward(case, chain=True)
 sync = got["sync"]
