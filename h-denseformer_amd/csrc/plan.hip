@@ -182,6 +182,7 @@ struct hdf_plan {
   size_t pool_idx[3];
   size_t tf_F, tf_save, tf_scratch, tf_dF, tf_tape = 0, tf_otape = 0;
   size_t tf_sync = 0;   // arrival counters of the persistent transformer kernels (transformer_chain.hip)
+  size_t tf_frag = 0;   // operand records the forward leaves for the attention backward (16-bit modes)
   size_t tf_wpack = 0;  // fragment-major copies of the dense layers' weight matrices for those kernels
   size_t stat_partials, wgrad_ws, inb_partials, inb_k;
   size_t stat_partials2 = 0, inb_partials2 = 0, inb_k2 = 0;  // the same scratch for the branch stream (see Exec::branch)
@@ -487,6 +488,8 @@ void layout(hdf_plan* p, int B) {
     TfDims dd{};
     dd.M = p->M;
     p->tf_wpack = bp.take(tf_chain_wpack_bytes(dd, p->nb));
+    dd.B = B, dd.N = p->Ntok;
+    p->tf_frag = bp.take(p->dtype == HDF_F32 ? 256 : tf_chain_frag_bytes(dd, p->nb));
   }
   p->tf_sync = bp.take((size_t)3 << 20);  // forward | backward counters in the first megabyte (one half each), then
                                            // two megabytes of phase stamps in -DCHAIN_DBG_STAMPS builds
@@ -916,7 +919,7 @@ int transformer_forward(Exec& e, const float* x) {
                              e.st, PE_LP));
   if (tf_use_chain(p, e.B))   // all layers of all blocks in one persistent launch (transformer_chain.hip)
     return tf_chain_forward(d, tf_chain_params(p), p->nb, pm, F0, e.f(p->tf_save), e.at(p->attnall),
-                            reinterpret_cast<unsigned*>(e.ws + p->tf_sync), e.ws + p->tf_wpack, p->dtype, e.st);
+                            reinterpret_cast<unsigned*>(e.ws + p->tf_sync), e.ws + p->tf_wpack, e.f(p->tf_frag), p->dtype, e.st);
   // token kernel, attention, token kernel, ...: between two attention launches ONE kernel finishes the previous
   // dense layer (and, at a block boundary, runs the block's out_layer) and starts the next one
   TfLayerP prev{}, cur{};
@@ -995,11 +998,11 @@ int transformer_backward(Exec& e, const float* x) {
     HDF_TRY(tf_wgrad(w, 1, p->M, e.wgrad_stream()));
     return e.side_done();
   };
-  if (tf_use_chain(p, e.B)) {
+  if (tf_use_chain(p, e.B) && tf_chain_backward_supported(d, p->dtype)) {
     // one persistent launch for all layers (transformer_chain.hip); then every block's weight-matrix gradients from the
     // tapes on the side stream, next to the patch embedding's backward on this one
     HDF_TRY(tf_chain_backward(d, tf_chain_params(p), p->nb, pm, e.grads, F0, e.f(p->tf_save), dF, e.at(p->dAttnall),
-                              e.f(p->tf_tape), e.f(p->tf_otape), scratch,
+                              e.f(p->tf_tape), e.f(p->tf_otape), scratch, e.f(p->tf_frag),
                               reinterpret_cast<unsigned*>(e.ws + p->tf_sync) + (1 << 17), p->dtype, e.st));
     w.b0 = 0;
     HDF_TRY(tf_wgrad(w, p->nb, p->M, e.wgrad_stream()));

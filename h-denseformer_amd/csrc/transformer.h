@@ -168,16 +168,18 @@ struct TfChainP {
 bool tf_chain_supported(const TfDims& d);
 size_t tf_chain_sync_bytes(const TfDims& d);
 size_t tf_chain_wpack_bytes(const TfDims& d, int nb);
+size_t tf_chain_frag_bytes(const TfDims& d, int nb);   // the forward's operand records for the backward (16-bit modes)
+bool tf_chain_backward_supported(const TfDims& d, int dtype);
 // Forward of all nb blocks: reads F0[block 0][:, 0:DM] (the patch embedding), writes every block's feature buffer, the
 // saved tensors of every layer (tf_save layout) and the channels-last attnall tensor.  `sync`: tf_chain_sync_bytes of
 // device memory owned by the caller (zeroed by the call on `st`); `wpack`: tf_chain_wpack_bytes of scratch for the
 // fragment-major copies of the layers' weight matrices (written by a small launch in front of the persistent one).
 int tf_chain_forward(const TfDims& d, const TfChainP& cp, int nb, const float* params, float* F0, float* save,
-                     void* attnall, unsigned* sync, void* wpack, int dtype, hipStream_t st);
+                     void* attnall, unsigned* sync, void* wpack, float* frag, int dtype, hipStream_t st);
 // Backward of all nb blocks (after the UpConv chain's backward left d(attnall)): every bias / LayerNorm-parameter gradient
 // (fp32 atomics into `grads`), the weight-gradient tapes of every layer (tf_wgrad afterwards), and dF[:, 0:DM] = the
 // gradient of block 0's input (tf_patch_embed_bwd afterwards).  `xchg`: 2 * rows * 40 floats of scratch (the dO | delta
 // rows the workgroups of a sequence hand each other); `sync`: tf_chain_sync_bytes, zeroed by the call.
 int tf_chain_backward(const TfDims& d, const TfChainP& cp, int nb, const float* params, float* grads, const float* F0,
                       const float* save, float* dF, const void* d_attnall, float* tape, float* otape, float* xchg,
-                      unsigned* sync, int dtype, hipStream_t st);
+                      const float* frag, unsigned* sync, int dtype, hipStream_t st);

@@ -35,6 +35,24 @@ constexpr int KVC = 128;    // keys per staged chunk
 constexpr int KVP = 68;     // floats per row of a chunk image: K (8 heads x 4) | V (8 heads x 4) | pad
 constexpr int LDQ = 100;    // row pitch of the q|k|v tile
 constexpr int SYNC_LINE = 32;  // unsigned words per counter (128-byte lines)
+// Operand records of the attention BACKWARD in the 16-bit storage modes.  A workgroup's tile is exactly one block of 16
+// tokens of the score / accumulation MFMAs, so the token's owner can leave every operand any wave of the sequence will
+// ever want from that block in the order the 64 lanes consume it: the backward's key / query loops then run on coalesced
+// loads straight into registers -- no LDS image, no barrier, a prefetch ring -- where the first version staged every
+// chunk of the sequence through LDS in each of the sequence's 32 workgroups (30 us per layer; this form: see DESIGN).
+// Forward record per (layer, sequence, block, head), FR_W floats (plain stores: read by the backward LAUNCH):
+constexpr int FR_KA = 0;      // [64] k of key (lane & 15), component (lane >> 4), zero for padded rows: score MFMA A operand
+constexpr int FR_VA = 64;     // [64] v likewise                                                   (T = dO . v)
+constexpr int FR_QA = 128;    // [64] q x 0.5 log2(e)                                              (dK/dV half)
+constexpr int FR_KB = 192;    // [5][4] x 8 B: 16-bit k of keys 4g .. 4g+3, component c (row 4: zeros): B operand of dS . K
+constexpr int FR_QB = 232;    // [5][4] x 8 B: 16-bit q likewise                                    (dS^T . Q)
+constexpr int FR_LS = 272;    // [16] -lse log2(e) (-inf for padded rows)
+constexpr int FR_W = 288;
+// hand-off record of the backward per (layer parity, sequence, block, head), XG_W floats (sc1 stores and loads):
+constexpr int XG_GA = 0;      // [64] dO of query (lane & 15), component (lane >> 4)
+constexpr int XG_GB = 64;     // [5][4] x 8 B: 16-bit dO
+constexpr int XG_DL = 104;    // [16] -delta
+constexpr int XG_W = 128;
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 constexpr int ATRIP = 16;
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -173,6 +191,7 @@ struct ChainFwd {
   float* save;      // [nb*4][rows][232] (tf_save layout: h0 | qkv | ob | lse | h1 | h2, segment-major)
   void* attnall;    // channels-last [B][N][M*DM], storage dtype
   unsigned* sync;   // [nseq + 1][SYNC_LINE]: arrival counters, then the timeout word
+  float* frag;      // [nl][nseq][ntile][8][FR_W] operand records for the backward (16-bit storage modes), or null
   int nb, ntile, nseq;
   int64_t rows;
 };
@@ -438,6 +457,34 @@ __global__ __launch_bounds__(CT) void tf_chain_fwd_kernel(ChainFwd a) {
       if (row < nvalid)
         st16_sc1(rq, (uint32_t)(((n0 + row) * 96 + c4) * 4), *reinterpret_cast<const float4*>(s_q + row * LDQ + c4));
     }
+    if (a.frag) {   // the backward's operand records of this block: every wave its head (see FR_*)
+      float* rec = a.frag + ((((int64_t)L * a.nseq + seq) * a.ntile + tile) * 8 + wave8) * FR_W;
+      const bool vrow = col < nvalid;
+      const float* qr = s_q + col * LDQ + wave8 * 4 + g;
+      rec[FR_KA + lane] = vrow ? qr[32] : 0.f;
+      rec[FR_VA + lane] = vrow ? qr[64] : 0.f;
+      rec[FR_QA + lane] = vrow ? qr[0] * (0.5f * LOG2E) : 0.f;
+      if (lane < 20) {
+        const int c = lane >> 2, gg = lane & 3;
+        float kq[4] = {0.f, 0.f, 0.f, 0.f}, qq[4] = {0.f, 0.f, 0.f, 0.f};
+        if (c < 4) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const float* r = s_q + (4 * gg + e) * LDQ + wave8 * 4 + c;
+            const bool v = 4 * gg + e < nvalid;
+            kq[e] = v ? r[32] : 0.f, qq[e] = v ? r[0] : 0.f;
+          }
+        }
+        u32x2* ru = reinterpret_cast<u32x2*>(rec);
+        if (a.dtype == HDF_F16) {
+          ru[FR_KB / 2 + lane] = u32x2{pack_h2(kq[0], kq[1]), pack_h2(kq[2], kq[3])};
+          ru[FR_QB / 2 + lane] = u32x2{pack_h2(qq[0], qq[1]), pack_h2(qq[2], qq[3])};
+        } else {
+          ru[FR_KB / 2 + lane] = u32x2{pack_bf2(kq[0], kq[1]), pack_bf2(kq[2], kq[3])};
+          ru[FR_QB / 2 + lane] = u32x2{pack_bf2(qq[0], qq[1]), pack_bf2(qq[2], qq[3])};
+        }
+      }
+    }
     chain_arrive(cnt);
     CHAIN_STAMP(3);
     request_post(L + 1);   // parameters: never written during the launch, plain loads
@@ -581,13 +628,17 @@ __global__ __launch_bounds__(CT) void tf_chain_fwd_kernel(ChainFwd a) {
         const float inv = 1.f / l;
         const float4 o = make_float4(a01.x * inv, a01.y * inv, a23.x * inv, a23.y * inv);
         *reinterpret_cast<float4*>(s_ob + col * LD32 + head * 4) = o;
+        const float lsv = __builtin_fmaf(mx, LN2, __logf(l));
         if (col < nvalid) {
           float* ob = sv + a.rows * 128;
           float* lse = sv + a.rows * 160;
           const int64_t R = rb + t0 + col;
           *reinterpret_cast<float4*>(ob + R * 32 + head * 4) = o;
-          lse[R * 8 + head] = __builtin_fmaf(mx, LN2, __logf(l));
+          lse[R * 8 + head] = lsv;
         }
+        if (a.frag)
+          a.frag[((((int64_t)L * a.nseq + seq) * a.ntile + tile) * 8 + head) * FR_W + FR_LS + col] =
+              col < nvalid ? -lsv * LOG2E : -INFINITY;
       }
       CHAIN_STAMP(7);
     }
@@ -618,7 +669,9 @@ struct ChainBwd {
   const void* d_attnall;  // storage dtype
   float* tape;            // [nb*4][TF_TAPE_W segments][rows]
   float* otape;           // [nb][DMF segments][rows]
-  float* xchg;            // [2][rows][40]: dO | delta hand-off, by layer parity
+  float* xchg;            // hand-off scratch, by layer parity: [2][rows][40] dO | delta rows (exact mode) or
+                          // [2][nseq][ntile][8][XG_W] operand records (16-bit modes)
+  const float* frag;      // the forward's operand records (16-bit modes)
   unsigned* sync;         // [nseq + 1][SYNC_LINE]
   int nb, ntile, nseq, dtype;
   int64_t rows;
@@ -1018,7 +1071,29 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
     const int par = L & 1;
     float* xbase = a.xchg + ((int64_t)par * a.rows + rb + (int64_t)bsm * N) * XW;   // this sequence's rows, this parity
     const __amdgpu_buffer_rsrc_t rx = chain_rsrc(xbase);
-    if (tid < TT * 10) {
+    float* xgseq = a.xchg + ((int64_t)par * a.nseq + seq) * a.ntile * 8 * XG_W;    // LP: this sequence's records
+    if (LP) {
+      constexpr int L1 = LP ? LP : 1;
+      float* rec = xgseq + ((int64_t)tile * 8 + wave8) * XG_W;   // every wave its head
+      const bool vrow = col < nvalid;
+      __hip_atomic_store(rec + XG_GA + lane, vrow ? s_dO[col * LD32 + wave8 * 4 + g] : 0.f, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+      if (lane < 20) {
+        const int c = lane >> 2, gg = lane & 3;
+        float gv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (c < 4) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) gv[e] = 4 * gg + e < nvalid ? s_dO[(4 * gg + e) * LD32 + wave8 * 4 + c] : 0.f;
+        }
+        const u32x2 pk = ChainLp<L1>::four(gv[0], gv[1], gv[2], gv[3]);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(rec + XG_GB) + lane,
+                           (unsigned long long)pk[0] | ((unsigned long long)pk[1] << 32), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (lane < 16)
+        __hip_atomic_store(rec + XG_DL + lane, lane < nvalid ? -s_dl[lane * 8 + wave8] : 0.f, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    } else if (tid < TT * 10) {
       const int row = tid / 10, c4 = (tid - row * 10) * 4;
       if (row < nvalid) {
         const float4 v = c4 < 32 ? *reinterpret_cast<const float4*>(s_dO + row * LD32 + c4)
@@ -1042,7 +1117,111 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
     CHAIN_STAMPB(6);
 
     // ------------------------------------------------------------------ attention backward of layer L: head = wave
-    {
+    if constexpr (LP != 0) {
+      // 16-bit storage modes: attn_bwd_lp_kernel's arithmetic on operand records (FR_* / XG_*), prefetch ring of PD blocks
+      constexpr int PD = 4;
+      const int NP = attn_rows(N), nblk = a.ntile;
+      const float* fr = a.frag + ((int64_t)L * a.nseq + seq) * a.ntile * 8 * FR_W + (int64_t)head * FR_W;   // + blk * 8 * FR_W
+      const float* xg = xgseq + (int64_t)head * XG_W;                                                        // + blk * 8 * XG_W
+      const int cb = min(col, 4) * 4 + g;      // this lane's entry of a 16-bit B operand table (row 4: zeros)
+      float* s_ls = s_at;                      // [8][NP] -lse log2(e) of every query of the sequence
+      float* s_dlq = s_at + 8 * NP;            // [8][NP] -delta
+      // the queries' (-lse) terms come from the forward launch: staged before the wait's data is needed
+      for (int i = tid; i < nblk * 8 * 16; i += CT) {
+        const int b = i >> 7, h = (i >> 4) & 7, r = i & 15;
+        s_ls[h * NP + b * 16 + r] = a.frag[(((int64_t)L * a.nseq + seq) * a.ntile + b) * 8 * FR_W + h * FR_W + FR_LS + r];
+      }
+      for (int i = tid; i < nblk * 8 * 16; i += CT) {
+        const int b = i >> 7, h = (i >> 4) & 7, r = i & 15;
+        s_dlq[h * NP + b * 16 + r] =
+            __hip_atomic_load(xgseq + ((int64_t)b * 8 + h) * XG_W + XG_DL + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // ---- dQ of the tile's queries
+      {
+        const float delta = s_dl[col * 8 + head];
+        const float ls = own_lse * LOG2E;
+        const float bqv = own_q * (0.5f * LOG2E);
+        const float bg = s_dO[col * LD32 + head * 4 + g];
+        const f32x4 nl4 = {-ls, -ls, -ls, -ls}, nd4 = {-delta, -delta, -delta, -delta};
+        float ka[PD], va[PD];
+        u32x2 kb[PD];
+        auto ld = [&](int b, int i) __attribute__((always_inline)) {
+          const float* r = fr + (int64_t)min(b, nblk - 1) * 8 * FR_W;
+          ka[i] = r[FR_KA + lane], va[i] = r[FR_VA + lane];
+          kb[i] = reinterpret_cast<const u32x2*>(r + FR_KB)[cb];
+        };
+#pragma unroll
+        for (int i = 0; i < PD; i++) ld(i, i);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int b0 = 0; b0 < nblk; b0 += PD) {
+#pragma unroll
+          for (int i = 0; i < PD; i++) {
+            const int b = b0 + i, j0 = b * ATRIP;
+            if (b < nblk) {
+              const f32x4 cs = chain_mfma4(ka[i], bqv, nl4), ct = chain_mfma4(va[i], bg, nd4);
+              float ds[4];
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
+                ds[u] = __builtin_amdgcn_exp2f(cs[u]) * ct[u];
+                if (j0 + ATRIP > N) ds[u] = (j0 + 4 * g + u < N) ? ds[u] : 0.f;
+              }
+              acc = ChainLp<LP>::mma(ChainLp<LP>::four(ds[0], ds[1], ds[2], ds[3]), kb[i], acc);
+              ld(b + PD, i);
+            }
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          if (col < 4) s_dq[(4 * g + r) * 100 + head * 4 + col] = (4 * g + r < nvalid) ? 0.5f * acc[r] : 0.f;
+      }
+      CHAIN_STAMPB(7);
+      __syncthreads();   // s_ls / s_dlq complete
+      // ---- dK, dV of the tile's keys
+      {
+        const float bk = own_k, bv = own_v;
+        const float* tl = s_ls + head * NP + 4 * g;
+        const float* td = s_dlq + head * NP + 4 * g;
+        float qa[PD], ga[PD];
+        u32x2 qb[PD], gb[PD];
+        auto ld = [&](int b, int i) __attribute__((always_inline)) {
+          const int bc = min(b, nblk - 1);
+          const float* r = fr + (int64_t)bc * 8 * FR_W;
+          const float* x = xg + (int64_t)bc * 8 * XG_W;
+          qa[i] = r[FR_QA + lane];
+          qb[i] = reinterpret_cast<const u32x2*>(r + FR_QB)[cb];
+          ga[i] = __hip_atomic_load(x + XG_GA + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long w = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(x + XG_GB) + cb,
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          gb[i] = u32x2{(uint32_t)w, (uint32_t)(w >> 32)};
+        };
+#pragma unroll
+        for (int i = 0; i < PD; i++) ld(i, i);
+        f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+        for (int b0 = 0; b0 < nblk; b0 += PD) {
+#pragma unroll
+          for (int i = 0; i < PD; i++) {
+            const int b = b0 + i;
+            if (b < nblk) {
+              const f32x4 l4 = *reinterpret_cast<const f32x4*>(tl + b * ATRIP), d4 = *reinterpret_cast<const f32x4*>(td + b * ATRIP);
+              const f32x4 cs = chain_mfma4(qa[i], bk, l4), ct = chain_mfma4(ga[i], bv, d4);
+              const float p0 = __builtin_amdgcn_exp2f(cs[0]), p1 = __builtin_amdgcn_exp2f(cs[1]);
+              const float p2 = __builtin_amdgcn_exp2f(cs[2]), p3 = __builtin_amdgcn_exp2f(cs[3]);
+              dv = ChainLp<LP>::mma(ChainLp<LP>::four(p0, p1, p2, p3), gb[i], dv);
+              dk = ChainLp<LP>::mma(ChainLp<LP>::four(p0 * ct[0], p1 * ct[1], p2 * ct[2], p3 * ct[3]), qb[i], dk);
+              ld(b + PD, i);
+            }
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          if (col < 4) {
+            const bool ok = 4 * g + r < nvalid;
+            s_dq[(4 * g + r) * 100 + 32 + head * 4 + col] = ok ? 0.5f * dk[r] : 0.f;
+            s_dq[(4 * g + r) * 100 + 64 + head * 4 + col] = ok ? dv[r] : 0.f;
+          }
+        }
+      }
+    } else {
       const int NP = attn_rows(N), nchunk = (NP + QC - 1) / QC;
       const int srow = tid >> 3, spart = tid & 7;   // staging: row of the chunk, 16-byte part
       const bool rvalid = col < nvalid;
@@ -1264,10 +1443,10 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
   }
 }
 
-size_t chain_bwd_lds(const TfDims& d) {
-  const size_t fl = (size_t)2 * TT * (d.DMF + 4) + TT * (d.DM + 4) + TT * 100 + 7 * TT * LD32 + 2 * TT * LD64 +
-                    2 * 16 * 16 + TT * 8 + 2 * (QC * QP + 2 * 8 * QC + 2 * (8 * 5 * QC / 2));
-  return fl * sizeof(float);
+size_t chain_bwd_lds(const TfDims& d, int dtype) {
+  const size_t tiles = (size_t)2 * TT * (d.DMF + 4) + TT * (d.DM + 4) + TT * 100 + 7 * TT * LD32 + 2 * TT * LD64 + 2 * 16 * 16 + TT * 8;
+  const size_t att = dtype == HDF_F32 ? (size_t)2 * (QC * QP + 2 * 8 * QC + 2 * (8 * 5 * QC / 2)) : (size_t)2 * 8 * attn_rows(d.N);
+  return (tiles + att) * sizeof(float);
 }
 
 size_t chain_fwd_lds(const TfDims& d) {
@@ -1303,6 +1482,14 @@ static bool chain_digest(const TfChainP& cp, int DM, ChainW& w) {
 }
 
 size_t tf_chain_sync_bytes(const TfDims& d) { return (size_t)(d.M * d.B + 1) * SYNC_LINE * sizeof(unsigned); }
+bool tf_chain_supported(const TfDims& d);
+size_t tf_chain_frag_bytes(const TfDims& d, int nb) {
+  return (size_t)nb * 4 * d.M * d.B * ceil_div(d.N, TT) * 8 * FR_W * sizeof(float);
+}
+bool tf_chain_backward_supported(const TfDims& d, int dtype) {
+  return tf_chain_supported(d) && chain_bwd_lds(d, dtype) <= LDS_LIMIT_F &&
+         (size_t)2 * d.M * d.B * ceil_div(d.N, TT) * 8 * XG_W <= (size_t)d.M * d.B * d.N * 160;   // the hand-off records fit tf_scratch
+}
 size_t tf_chain_wpack_bytes(const TfDims& d, int nb) { return (size_t)d.M * nb * 4 * CH_SLOT * 64 * sizeof(float4); }
 
 bool tf_chain_supported(const TfDims& d) {
@@ -1312,12 +1499,13 @@ bool tf_chain_supported(const TfDims& d) {
 }
 
 int tf_chain_forward(const TfDims& d, const TfChainP& cp, int nb, const float* params, float* F0, float* save,
-                     void* attnall, unsigned* sync, void* wpack, int dtype, hipStream_t st) {
+                     void* attnall, unsigned* sync, void* wpack, float* frag, int dtype, hipStream_t st) {
   HDF_CHECK_ARG(tf_chain_supported(d), "transformer chain: shape not supported (M %d B %d N %d DM %d)", d.M, d.B, d.N, d.DM);
   ChainFwd a{};
   HDF_CHECK_ARG(chain_digest(cp, d.DM, a.cw), "transformer chain: irregular parameter layout");
   a.d = d, a.params = params, a.F0 = F0, a.save = save, a.attnall = attnall, a.sync = sync;
   a.wpack = reinterpret_cast<const float4*>(wpack), a.dtype = dtype;
+  a.frag = dtype == HDF_F32 ? nullptr : frag;
   a.nb = nb, a.ntile = ceil_div(d.N, TT), a.nseq = d.M * d.B, a.rows = (int64_t)d.M * d.B * d.N;
   const size_t shm = chain_fwd_lds(d);
   HDF_CHECK_ARG(shm <= LDS_LIMIT_F, "transformer chain: %zu B of LDS", shm);
@@ -1344,15 +1532,16 @@ int tf_chain_forward(const TfDims& d, const TfChainP& cp, int nb, const float* p
 
 int tf_chain_backward(const TfDims& d, const TfChainP& cp, int nb, const float* params, float* grads, const float* F0,
                       const float* save, float* dF, const void* d_attnall, float* tape, float* otape, float* xchg,
-                      unsigned* sync, int dtype, hipStream_t st) {
-  HDF_CHECK_ARG(tf_chain_supported(d), "transformer chain: shape not supported (M %d B %d N %d DM %d)", d.M, d.B, d.N, d.DM);
+                      const float* frag, unsigned* sync, int dtype, hipStream_t st) {
+  HDF_CHECK_ARG(tf_chain_backward_supported(d, dtype), "transformer chain: shape not supported (M %d B %d N %d DM %d)", d.M, d.B, d.N, d.DM);
   ChainBwd a{};
   HDF_CHECK_ARG(chain_digest(cp, d.DM, a.cw), "transformer chain: irregular parameter layout");
   HDF_CHECK_ARG(dtype == HDF_F32 || dtype == HDF_BF16 || dtype == HDF_F16, "unsupported dtype %d", dtype);
   a.d = d, a.params = params, a.grads = grads, a.F0 = F0, a.save = save, a.dF = dF, a.d_attnall = d_attnall;
-  a.tape = tape, a.otape = otape, a.xchg = xchg, a.sync = sync, a.dtype = dtype;
+  a.tape = tape, a.otape = otape, a.xchg = xchg, a.sync = sync, a.dtype = dtype, a.frag = frag;
+  HDF_CHECK_ARG(dtype == HDF_F32 || frag, "transformer chain backward: no operand records");
   a.nb = nb, a.ntile = ceil_div(d.N, TT), a.nseq = d.M * d.B, a.rows = (int64_t)d.M * d.B * d.N;
-  const size_t shm = chain_bwd_lds(d);
+  const size_t shm = chain_bwd_lds(d, dtype);
   HDF_CHECK_ARG(shm <= LDS_LIMIT_F, "transformer chain backward: %zu B of LDS", shm);
   hipError_t e = hipMemsetAsync(sync, 0, tf_chain_sync_bytes(d), st);
   if (e != hipSuccess) {

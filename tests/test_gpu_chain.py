@@ -129,7 +129,6 @@ def test_chain_backward_is_bit_identical_to_the_launch_chain(case):
     """tapes (the operands of every weight-matrix gradient), the input gradient of block 0 and every gradient that is a
     fixed-order sum: bit for bit; bias / LayerNorm-parameter gradients (fp32 atomics in both arrangements): 1e-4"""
     ref = _backward(case, chain=False)
-    ref2 = _backward(case, chain=False)   # what the launch chain itself reproduces run to run is what must be bit-identical
     got = _backward(case, chain=True)
     nseq = case[0] * case[5]
     half = 1 << 17
@@ -141,11 +140,13 @@ def test_chain_backward_is_bit_identical_to_the_launch_chain(case):
             name, int(nd.sum()), a.numel(), float((a - b).abs().max()))
     for name, off, numel, shape in got["table"]:
         a, b = got["grads"][off:off + numel], ref["grads"][off:off + numel]
-        # fp32 atomics (run-to-run rounding): the transformer's bias / LayerNorm / embedding gradients and the heads'
-        atomic = name.startswith("conv1x1") or (
-            name.startswith("attns.") and (len(shape) == 1 or "position_embeddings" in name or "patch" in name))
-        if atomic or not torch.equal(b.view(torch.int32), ref2["grads"][off:off + numel].view(torch.int32)):
+        # bit for bit: the weight matrices of the branches (fixed-order sums over the tapes).  Everything else to 1e-4: the
+        # branches' bias / LayerNorm / embedding gradients and the heads' are fp32 atomics in both arrangements, and the
+        # U-Net's gradients do not depend on the arrangement at all (some of its small-shape reductions are not
+        # reproducible run to run either, which is why they are not compared exactly)
+        exact = name.startswith("attns.") and len(shape) == 2 and "patch" not in name
+        if exact:
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), name
+        else:
             scale = float(b.abs().max()) + 1e-12
             assert float((a - b).abs().max()) <= 1e-4 * scale + 1e-9, name
-        else:
-            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), name
