@@ -46,13 +46,14 @@ constexpr int FR_VA = 64;     // [64] v likewise                                
 constexpr int FR_QA = 128;    // [64] q x 0.5 log2(e)                                              (dK/dV half)
 constexpr int FR_KB = 192;    // [5][4] x 8 B: 16-bit k of keys 4g .. 4g+3, component c (row 4: zeros): B operand of dS . K
 constexpr int FR_QB = 232;    // [5][4] x 8 B: 16-bit q likewise                                    (dS^T . Q)
-constexpr int FR_LS = 272;    // [16] -lse log2(e) (-inf for padded rows)
-constexpr int FR_W = 288;
+constexpr int FR_W = 288;      // (16 spare floats: whole 128-byte lines)
+// -lse log2(e) of the queries (-inf for padded rows) follows the records as [layer][sequence][head][ntile * 16]: a wave
+// stages its head's row with two 16-byte loads per lane
 // hand-off record of the backward per (layer parity, sequence, block, head), XG_W floats (sc1 stores and loads):
 constexpr int XG_GA = 0;      // [64] dO of query (lane & 15), component (lane >> 4)
 constexpr int XG_GB = 64;     // [5][4] x 8 B: 16-bit dO
-constexpr int XG_DL = 104;    // [16] -delta
 constexpr int XG_W = 128;
+// -delta of the queries follows the hand-off records as [parity][sequence][head][ntile * 16]
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 constexpr int ATRIP = 16;
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -636,8 +637,8 @@ __global__ __launch_bounds__(CT) void tf_chain_fwd_kernel(ChainFwd a) {
           *reinterpret_cast<float4*>(ob + R * 32 + head * 4) = o;
           lse[R * 8 + head] = lsv;
         }
-        if (a.frag)
-          a.frag[((((int64_t)L * a.nseq + seq) * a.ntile + tile) * 8 + head) * FR_W + FR_LS + col] =
+        if (a.frag)   // -lse log2(e) of every query, head-major: [layer][sequence][head][ntile * 16] behind the records
+          a.frag[(int64_t)nl * a.nseq * a.ntile * 8 * FR_W + (((int64_t)L * a.nseq + seq) * 8 + head) * (a.ntile * TT) + n0 + col] =
               col < nvalid ? -lsv * LOG2E : -INFINITY;
       }
       CHAIN_STAMP(7);
@@ -1091,8 +1092,9 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
                            __HIP_MEMORY_SCOPE_AGENT);
       }
       if (lane < 16)
-        __hip_atomic_store(rec + XG_DL + lane, lane < nvalid ? -s_dl[lane * 8 + wave8] : 0.f, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.xchg + (int64_t)2 * a.nseq * a.ntile * 8 * XG_W +
+                               (((int64_t)par * a.nseq + seq) * 8 + wave8) * (a.ntile * TT) + n0 + lane,
+                           lane < nvalid ? -s_dl[lane * 8 + wave8] : 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else if (tid < TT * 10) {
       const int row = tid / 10, c4 = (tid - row * 10) * 4;
       if (row < nvalid) {
@@ -1103,7 +1105,7 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
     }
     chain_arrive(cnt);
     // operands of this head (wave) for the tile's own 16 tokens, requested before the wait (forward launch's data)
-    const int head = wave8;
+    const int head = __builtin_amdgcn_readfirstlane(wave8);   // (uniform: per-wave pointers then live in SGPRs)
     const float* sv = a.save + (int64_t)L * a.rows * 232;
     const float* qkvL = sv + a.rows * 32 + (rb + (int64_t)bsm * N) * 96;   // the sequence's rows
     const float* lseL = sv + a.rows * 160 + (rb + (int64_t)bsm * N) * 8;
@@ -1124,17 +1126,20 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
       const float* fr = a.frag + ((int64_t)L * a.nseq + seq) * a.ntile * 8 * FR_W + (int64_t)head * FR_W;   // + blk * 8 * FR_W
       const float* xg = xgseq + (int64_t)head * XG_W;                                                        // + blk * 8 * XG_W
       const int cb = min(col, 4) * 4 + g;      // this lane's entry of a 16-bit B operand table (row 4: zeros)
-      float* s_ls = s_at;                      // [8][NP] -lse log2(e) of every query of the sequence
-      float* s_dlq = s_at + 8 * NP;            // [8][NP] -delta
-      // the queries' (-lse) terms come from the forward launch: staged before the wait's data is needed
-      for (int i = tid; i < nblk * 8 * 16; i += CT) {
-        const int b = i >> 7, h = (i >> 4) & 7, r = i & 15;
-        s_ls[h * NP + b * 16 + r] = a.frag[(((int64_t)L * a.nseq + seq) * a.ntile + b) * 8 * FR_W + h * FR_W + FR_LS + r];
-      }
-      for (int i = tid; i < nblk * 8 * 16; i += CT) {
-        const int b = i >> 7, h = (i >> 4) & 7, r = i & 15;
-        s_dlq[h * NP + b * 16 + r] =
-            __hip_atomic_load(xgseq + ((int64_t)b * 8 + h) * XG_W + XG_DL + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (-lse log2(e), -delta) of every query of the sequence for THIS wave's head: two [NP] rows of LDS, filled by the
+      // wave itself from the head-major arrays (requested here, written behind the dQ loop: no workgroup barrier)
+      float* s_ls = s_at + head * 2 * NP;
+      float* s_dlq = s_ls + NP;
+      const float* lsrow = a.frag + (int64_t)nl * a.nseq * a.ntile * 8 * FR_W + (((int64_t)L * a.nseq + seq) * 8 + head) * NP;
+      const __amdgpu_buffer_rsrc_t rdl = chain_rsrc(a.xchg + (int64_t)2 * a.nseq * a.ntile * 8 * XG_W +
+                                                    (((int64_t)par * a.nseq + seq) * 8 + head) * NP);
+      constexpr int NLS = 4;   // 16-byte pieces per lane: covers NP <= 1024
+      float4 r_ls[NLS], r_dl[NLS];
+#pragma unroll
+      for (int k = 0; k < NLS; k++) {
+        const int i4 = min((k * 64 + lane) * 4, NP - 4);
+        r_ls[k] = *reinterpret_cast<const float4*>(lsrow + i4);
+        r_dl[k] = ld16_sc1(rdl, (uint32_t)(i4 * 4));
       }
       // ---- dQ of the tile's queries
       {
@@ -1153,34 +1158,53 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
 #pragma unroll
         for (int i = 0; i < PD; i++) ld(i, i);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int b0 = 0; b0 < nblk; b0 += PD) {
+        auto step = [&](int i, int j0, auto masked) __attribute__((always_inline)) {
+          const f32x4 cs = chain_mfma4(ka[i], bqv, nl4), ct = chain_mfma4(va[i], bg, nd4);
+          float ds[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            ds[u] = __builtin_amdgcn_exp2f(cs[u]) * ct[u];
+            if (decltype(masked)::value) ds[u] = (j0 + 4 * g + u < N) ? ds[u] : 0.f;
+          }
+          acc = ChainLp<LP>::mma(ChainLp<LP>::four(ds[0], ds[1], ds[2], ds[3]), kb[i], acc);
+        };
+        const int nfullb = N / ATRIP;   // whole blocks
+        int bb = 0;
+        for (; bb + PD <= nfullb; bb += PD) {   // no mask, no bounds test: the ring's loads are clamped, never branched around
 #pragma unroll
           for (int i = 0; i < PD; i++) {
-            const int b = b0 + i, j0 = b * ATRIP;
-            if (b < nblk) {
-              const f32x4 cs = chain_mfma4(ka[i], bqv, nl4), ct = chain_mfma4(va[i], bg, nd4);
-              float ds[4];
-#pragma unroll
-              for (int u = 0; u < 4; u++) {
-                ds[u] = __builtin_amdgcn_exp2f(cs[u]) * ct[u];
-                if (j0 + ATRIP > N) ds[u] = (j0 + 4 * g + u < N) ? ds[u] : 0.f;
-              }
-              acc = ChainLp<LP>::mma(ChainLp<LP>::four(ds[0], ds[1], ds[2], ds[3]), kb[i], acc);
-              ld(b + PD, i);
-            }
+            step(i, 0, std::false_type{});
+            ld(bb + i + PD, i);
           }
+        }
+        for (int i = 0; bb < nblk; bb++, i++) {   // up to PD - 1 whole blocks and the partial one (i < PD: static after unrolling)
+#pragma unroll
+          for (int k = 0; k < PD; k++)
+            if (k == i) {
+              if ((bb + 1) * ATRIP <= N)
+                step(k, 0, std::false_type{});
+              else
+                step(k, bb * ATRIP, std::true_type{});
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; r++)
           if (col < 4) s_dq[(4 * g + r) * 100 + head * 4 + col] = (4 * g + r < nvalid) ? 0.5f * acc[r] : 0.f;
       }
+#pragma unroll
+      for (int k = 0; k < NLS; k++) {
+        const int i4 = (k * 64 + lane) * 4;
+        if (i4 < NP) {
+          *reinterpret_cast<float4*>(s_ls + i4) = r_ls[k];
+          *reinterpret_cast<float4*>(s_dlq + i4) = r_dl[k];
+        }
+      }
       CHAIN_STAMPB(7);
-      __syncthreads();   // s_ls / s_dlq complete
       // ---- dK, dV of the tile's keys
       {
         const float bk = own_k, bv = own_v;
-        const float* tl = s_ls + head * NP + 4 * g;
-        const float* td = s_dlq + head * NP + 4 * g;
+        const float* tl = s_ls + 4 * g;
+        const float* td = s_dlq + 4 * g;
         float qa[PD], ga[PD];
         u32x2 qb[PD], gb[PD];
         auto ld = [&](int b, int i) __attribute__((always_inline)) {
@@ -1197,20 +1221,26 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
 #pragma unroll
         for (int i = 0; i < PD; i++) ld(i, i);
         f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
-        for (int b0 = 0; b0 < nblk; b0 += PD) {
+        auto step = [&](int i, int b) __attribute__((always_inline)) {
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(tl + b * ATRIP), d4 = *reinterpret_cast<const f32x4*>(td + b * ATRIP);
+          const f32x4 cs = chain_mfma4(qa[i], bk, l4), ct = chain_mfma4(ga[i], bv, d4);
+          const float p0 = __builtin_amdgcn_exp2f(cs[0]), p1 = __builtin_amdgcn_exp2f(cs[1]);
+          const float p2 = __builtin_amdgcn_exp2f(cs[2]), p3 = __builtin_amdgcn_exp2f(cs[3]);
+          dv = ChainLp<LP>::mma(ChainLp<LP>::four(p0, p1, p2, p3), gb[i], dv);
+          dk = ChainLp<LP>::mma(ChainLp<LP>::four(p0 * ct[0], p1 * ct[1], p2 * ct[2], p3 * ct[3]), qb[i], dk);
+        };
+        int bb = 0;
+        for (; bb + PD <= nblk; bb += PD) {
 #pragma unroll
           for (int i = 0; i < PD; i++) {
-            const int b = b0 + i;
-            if (b < nblk) {
-              const f32x4 l4 = *reinterpret_cast<const f32x4*>(tl + b * ATRIP), d4 = *reinterpret_cast<const f32x4*>(td + b * ATRIP);
-              const f32x4 cs = chain_mfma4(qa[i], bk, l4), ct = chain_mfma4(ga[i], bv, d4);
-              const float p0 = __builtin_amdgcn_exp2f(cs[0]), p1 = __builtin_amdgcn_exp2f(cs[1]);
-              const float p2 = __builtin_amdgcn_exp2f(cs[2]), p3 = __builtin_amdgcn_exp2f(cs[3]);
-              dv = ChainLp<LP>::mma(ChainLp<LP>::four(p0, p1, p2, p3), gb[i], dv);
-              dk = ChainLp<LP>::mma(ChainLp<LP>::four(p0 * ct[0], p1 * ct[1], p2 * ct[2], p3 * ct[3]), qb[i], dk);
-              ld(b + PD, i);
-            }
+            step(i, bb + i);
+            ld(bb + i + PD, i);
           }
+        }
+        for (int i = 0; bb < nblk; bb++, i++) {   // (padded queries: -inf in the lse term, zeros elsewhere)
+#pragma unroll
+          for (int k = 0; k < PD; k++)
+            if (k == i) step(k, bb);
         }
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -1438,8 +1468,8 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
           }
         }
       }
-      CHAIN_STAMPB(8);
     }
+    CHAIN_STAMPB(8);
   }
 }
 
@@ -1484,11 +1514,14 @@ static bool chain_digest(const TfChainP& cp, int DM, ChainW& w) {
 size_t tf_chain_sync_bytes(const TfDims& d) { return (size_t)(d.M * d.B + 1) * SYNC_LINE * sizeof(unsigned); }
 bool tf_chain_supported(const TfDims& d);
 size_t tf_chain_frag_bytes(const TfDims& d, int nb) {
-  return (size_t)nb * 4 * d.M * d.B * ceil_div(d.N, TT) * 8 * FR_W * sizeof(float);
+  const size_t nt = ceil_div(d.N, TT);
+  return (size_t)nb * 4 * d.M * d.B * (nt * 8 * FR_W + 8 * nt * TT) * sizeof(float);   // records + the -lse rows
 }
 bool tf_chain_backward_supported(const TfDims& d, int dtype) {
+  // (16-bit modes: the hand-off records must fit tf_scratch = rows x 160 floats; whole tiles always do)
   return tf_chain_supported(d) && chain_bwd_lds(d, dtype) <= LDS_LIMIT_F &&
-         (size_t)2 * d.M * d.B * ceil_div(d.N, TT) * 8 * XG_W <= (size_t)d.M * d.B * d.N * 160;   // the hand-off records fit tf_scratch
+         (dtype == HDF_F32 || ((size_t)2 * d.M * d.B * ceil_div(d.N, TT) * (8 * XG_W + 8 * TT) <= (size_t)d.M * d.B * d.N * 160 &&
+                               attn_rows(d.N) <= 1024));
 }
 size_t tf_chain_wpack_bytes(const TfDims& d, int nb) { return (size_t)d.M * nb * 4 * CH_SLOT * 64 * sizeof(float4); }
 
