@@ -487,7 +487,7 @@ void layout(hdf_plan* p, int B) {
   {
     TfDims dd{};
     dd.M = p->M;
-    p->tf_wpack = bp.take(tf_chain_wpack_bytes(dd, p->nb));
+    p->tf_wpack = bp.take(tf_chain_wpack_bytes(dd, p->nb));   // (forward region: the backward reads what the forward packed)
     dd.B = B, dd.N = p->Ntok;
     p->tf_frag = bp.take(p->dtype == HDF_F32 ? 256 : tf_chain_frag_bytes(dd, p->nb));
   }
@@ -1002,7 +1002,7 @@ int transformer_backward(Exec& e, const float* x) {
     // one persistent launch for all layers (transformer_chain.hip); then every block's weight-matrix gradients from the
     // tapes on the side stream, next to the patch embedding's backward on this one
     HDF_TRY(tf_chain_backward(d, tf_chain_params(p), p->nb, pm, e.grads, F0, e.f(p->tf_save), dF, e.at(p->dAttnall),
-                              e.f(p->tf_tape), e.f(p->tf_otape), scratch, e.f(p->tf_frag),
+                              e.f(p->tf_tape), e.f(p->tf_otape), scratch, e.f(p->tf_frag), e.ws + p->tf_wpack,
                               reinterpret_cast<unsigned*>(e.ws + p->tf_sync) + (1 << 17), p->dtype, e.st));
     w.b0 = 0;
     HDF_TRY(tf_wgrad(w, p->nb, p->M, e.wgrad_stream()));

@@ -182,4 +182,4 @@ int tf_chain_forward(const TfDims& d, const TfChainP& cp, int nb, const float* p
 // rows the workgroups of a sequence hand each other); `sync`: tf_chain_sync_bytes, zeroed by the call.
 int tf_chain_backward(const TfDims& d, const TfChainP& cp, int nb, const float* params, float* grads, const float* F0,
                       const float* save, float* dF, const void* d_attnall, float* tape, float* otape, float* xchg,
-                      const float* frag, unsigned* sync, int dtype, hipStream_t st);
+                      const float* frag, const void* wpack, unsigned* sync, int dtype, hipStream_t st);

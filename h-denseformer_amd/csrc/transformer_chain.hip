@@ -72,7 +72,19 @@ constexpr int CH_W2 = 4;     // net.3   [32][64]:  tile (0..1) x j (0..3)
 constexpr int CH_W1 = 12;    // net.0   [64][32]:  tile (0..3) x j (0..1)
 constexpr int CH_WQ = 20;    // to_qkv  [96][32]:  tile (0..5) x j (0..1)
 constexpr int CH_W0 = 32;    // Linear0 [32][Kq]:  (k half x tile) (0..3) x j (0 .. Kq/32 - 1 <= 10)
-constexpr int CH_SLOT = 76;
+// backward (tok_bwd_kernel's column fragments: cload), same slot:
+constexpr int CB_Q = 76;     // dt = dqkv Wqkv:   (o half x tile) (0..3) x j (0..2)      (12 scalars per lane)
+constexpr int CB_W0 = 88;    // dF += dh0 W0:     tile (0 .. Kq/16 - 1 <= 23) x j (0..1)
+constexpr int CB_W2 = 136;   // df = dg W2:       tile (0..3) x j (0..1)
+constexpr int CB_W1 = 144;   // du = dz W1:       (o half x tile) (0..3) x j (0..1)
+constexpr int CB_WO = 152;   // dO = dgo Wout:    (o half x tile) (0..3)
+constexpr int CH_SLOT = 156;
+// a block's out_layer, behind all layer slots: [M][nb][CO_SLOT] units
+constexpr int OA_F = 0;      // wa rows   (wmma_stream: z = Wa F):        tile (0..3) x j (0 .. DMF/16 - 1 <= 23)
+constexpr int OB_F = 96;     // wb rows   (wmma_stream: out = Wb f):      tile (0 .. DM/16 - 1 <= 15) x j (0..3)
+constexpr int OB_B = 160;    // wb columns (cmma_stream: df = do Wb):     tile (0..3) x j (0 .. DM/16 - 1 <= 15)
+constexpr int OA_B = 224;    // wa columns (cmma_stream: dF = dz Wa):     tile (0 .. DMF/16 - 1 <= 23) x j (0..3)
+constexpr int CO_SLOT = 320;
 // offsets (floats) of a layer's tensors behind its Linear0 weight [32][Kq] in the flat parameter buffer (state_dict order,
 // entries padded to 16 floats; growth 32, mlp 64: HDenseFormer.py:79-89).  The launcher checks the plan's table against them.
 constexpr int CO_B0 = 0, CO_LN1G = 32, CO_LN1B = 64, CO_WQKV = 96, CO_WOUT = 3168, CO_BOUT = 4192, CO_LN2G = 4224,
@@ -91,41 +103,155 @@ __device__ __forceinline__ TfOutP chain_out(const ChainW& cw, float* base, int b
   return TfOutP{q + cw.ooff[0], q + cw.ooff[1], q + cw.ooff[2], q + cw.ooff[3]};
 }
 
-// grid (layers, modalities), 256 threads: wave w copies the units u = w (mod 4) of its layer's slot
+// grid (layers + blocks, modalities), 256 threads: wave w copies the units u = w (mod 4) of its slot.
+// Row fragment (wload): lane (i, g) <- W[n0 + i][g KQ + s0 + 4 j .. + 3]; column fragment (cload): element e of the lane's
+// float4 <- W[g OQ + s0 + 4 j + e][n0 + i].
 __global__ __launch_bounds__(256) void tf_chain_pack_kernel(ChainW cw, const float* __restrict__ params, int64_t mstride,
                                                             int DM, int nl, float4* __restrict__ wpack) {
-  const int L = blockIdx.x, m = blockIdx.y, b = L >> 2, l = L & 3;
+  const int m = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
-  const int Kq = DM + 32 * l;
-  const float* w0 = chain_w0(cw, const_cast<float*>(params), b, l) + (int64_t)m * mstride;
-  const float* rest = w0 + 32 * Kq;
-  float4* dst = wpack + ((int64_t)m * nl + L) * (CH_SLOT * 64);
-  for (int u = wave; u < CH_SLOT; u += 4) {
-    const float* W;
-    int ldw, n0, KQ, s0, j;
-    if (u < CH_W2) {
-      W = rest + CO_WOUT, ldw = 32, n0 = 16 * ((u - CH_WO) >> 1), KQ = 8, s0 = 0, j = (u - CH_WO) & 1;
-    } else if (u < CH_W1) {
-      W = rest + CO_W2, ldw = 64, n0 = 16 * ((u - CH_W2) >> 2), KQ = 16, s0 = 0, j = (u - CH_W2) & 3;
-    } else if (u < CH_WQ) {
-      W = rest + CO_W1, ldw = 32, n0 = 16 * ((u - CH_W1) >> 1), KQ = 8, s0 = 0, j = (u - CH_W1) & 1;
-    } else if (u < CH_W0) {
-      W = rest + CO_WQKV, ldw = 32, n0 = 16 * ((u - CH_WQ) >> 1), KQ = 8, s0 = 0, j = (u - CH_WQ) & 1;
-    } else {
-      const int f = (u - CH_W0) / 11;
-      j = (u - CH_W0) - f * 11;
-      if (j >= (Kq >> 5)) continue;
-      W = w0, ldw = Kq, n0 = 16 * (f & 1), KQ = Kq >> 2, s0 = (f >> 1) * (Kq >> 3);
+  const int DMF = DM + 128, M = gridDim.y, nb = nl >> 2;
+  auto rowf = [&](const float* W, int ldw, int n0, int KQ, int s0, int j) {
+    return *reinterpret_cast<const float4*>(W + (int64_t)(n0 + i) * ldw + g * KQ + s0 + 4 * j);
+  };
+  auto colf = [&](const float* W, int ldw, int n0, int OQ, int s0, int j) {
+    const float* q = W + (int64_t)(g * OQ + s0 + 4 * j) * ldw + n0 + i;
+    return make_float4(q[0], q[ldw], q[2 * ldw], q[3 * ldw]);
+  };
+  if ((int)blockIdx.x < nl) {
+    const int L = blockIdx.x, b = L >> 2, l = L & 3, Kq = DM + 32 * l;
+    const float* w0 = chain_w0(cw, const_cast<float*>(params), b, l) + (int64_t)m * mstride;
+    const float* rest = w0 + 32 * Kq;
+    float4* dst = wpack + ((int64_t)m * nl + L) * (CH_SLOT * 64);
+    for (int u = wave; u < CH_SLOT; u += 4) {
+      float4 v;
+      if (u < CH_W2) {
+        v = rowf(rest + CO_WOUT, 32, 16 * ((u - CH_WO) >> 1), 8, 0, (u - CH_WO) & 1);
+      } else if (u < CH_W1) {
+        v = rowf(rest + CO_W2, 64, 16 * ((u - CH_W2) >> 2), 16, 0, (u - CH_W2) & 3);
+      } else if (u < CH_WQ) {
+        v = rowf(rest + CO_W1, 32, 16 * ((u - CH_W1) >> 1), 8, 0, (u - CH_W1) & 1);
+      } else if (u < CH_W0) {
+        v = rowf(rest + CO_WQKV, 32, 16 * ((u - CH_WQ) >> 1), 8, 0, (u - CH_WQ) & 1);
+      } else if (u < CB_Q) {
+        const int f = (u - CH_W0) / 11, j = (u - CH_W0) - f * 11;
+        if (j >= (Kq >> 5)) continue;
+        v = rowf(w0, Kq, 16 * (f & 1), Kq >> 2, (f >> 1) * (Kq >> 3), j);
+      } else if (u < CB_W0) {
+        const int f = (u - CB_Q) / 3, j = (u - CB_Q) - f * 3;
+        v = colf(rest + CO_WQKV, 32, 16 * (f & 1), 24, 12 * (f >> 1), j);
+      } else if (u < CB_W2) {
+        const int t = (u - CB_W0) >> 1, j = (u - CB_W0) & 1;
+        if (16 * t >= Kq) continue;
+        v = colf(w0, Kq, 16 * t, 8, 0, j);
+      } else if (u < CB_W1) {
+        v = colf(rest + CO_W2, 64, 16 * ((u - CB_W2) >> 1), 8, 0, (u - CB_W2) & 1);
+      } else if (u < CB_WO) {
+        const int f = (u - CB_W1) >> 1;
+        v = colf(rest + CO_W1, 32, 16 * (f & 1), 16, 8 * (f >> 1), (u - CB_W1) & 1);
+      } else {
+        const int f = u - CB_WO;
+        v = colf(rest + CO_WOUT, 32, 16 * (f & 1), 8, 4 * (f >> 1), 0);
+      }
+      dst[u * 64 + lane] = v;
     }
-    dst[u * 64 + lane] = *reinterpret_cast<const float4*>(W + (int64_t)(n0 + i) * ldw + g * KQ + s0 + 4 * j);
+  } else {
+    const int b = blockIdx.x - nl;
+    const TfOutP po = chain_out(cw, const_cast<float*>(params), b);
+    const float* wa = po.wa + (int64_t)m * mstride;
+    const float* wb = po.wb + (int64_t)m * mstride;
+    float4* dst = wpack + (int64_t)M * nl * (CH_SLOT * 64) + ((int64_t)m * nb + b) * (CO_SLOT * 64);
+    const int nja = DMF >> 4, ntb = DM >> 4;
+    for (int u = wave; u < CO_SLOT; u += 4) {
+      float4 v;
+      if (u < OB_F) {
+        const int t = u / 24, j = u - t * 24;
+        if (j >= nja) continue;
+        v = rowf(wa, DMF, 16 * t, DMF >> 2, 0, j);
+      } else if (u < OB_B) {
+        const int t = (u - OB_F) >> 2;
+        if (t >= ntb) continue;
+        v = rowf(wb, 64, 16 * t, 16, 0, (u - OB_F) & 3);
+      } else if (u < OA_B) {
+        const int t = (u - OB_B) >> 4, j = (u - OB_B) & 15;
+        if (j >= ntb) continue;
+        v = colf(wb, 64, 16 * t, DM >> 2, 0, j);
+      } else {
+        const int t = (u - OA_B) >> 2;
+        if (t >= nja) continue;
+        v = colf(wa, DMF, 16 * t, 16, 0, (u - OA_B) & 3);
+      }
+      dst[u * 64 + lane] = v;
+    }
   }
 }
-// this lane's fragment: units [unit0, unit0 + n4) of the layer's slot (clamped like wload: never branch around a load)
+// this lane's fragment: units [unit0, unit0 + n4) of the slot (clamped like wload: never branch around a load)
 template <int NF4>
 __device__ __forceinline__ void pload(WFrag<NF4>& f, const float4* __restrict__ slot, int unit0, int n4) {
   const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int j = 0; j < NF4; j++) f.v[j] = slot[(unit0 + (j < n4 ? j : 0)) * 64 + lane];
+}
+// column fragment of NS scalars = NS / 4 units
+template <int NS>
+__device__ __forceinline__ void cpload(CFrag<NS>& f, const float4* __restrict__ slot, int unit0) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j < NS / 4; j++) {
+    const float4 v = slot[(unit0 + j) * 64 + lane];
+    f.v[4 * j] = v.x, f.v[4 * j + 1] = v.y, f.v[4 * j + 2] = v.z, f.v[4 * j + 3] = v.w;
+  }
+}
+// wmma_stream / cmma_stream (tf_tok.h) on packed units: the same MFMA order, the weights of the next chunk in flight
+__device__ __forceinline__ void wmma_stream_p(f32x4& acc, const float4* __restrict__ slot, int unit0, int n4, const float* sA,
+                                              int lda, int KQ) {
+  const int lane = threadIdx.x & 63;
+  const float4* pw = slot + unit0 * 64 + lane;
+  const float4* pa = reinterpret_cast<const float4*>(sA + (lane & 15) * lda + (lane >> 4) * KQ);
+  float4 w[4], wn[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) w[j] = pw[min(j, n4 - 1) * 64];
+  for (int c = 0; c < n4; c += 4) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) wn[j] = pw[min(c + 4 + j, n4 - 1) * 64];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (c + j < n4) {
+        const float4 av = pa[c + j];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, w[j].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, w[j].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, w[j].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, w[j].w, acc, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) w[j] = wn[j];
+  }
+}
+// OQ scalars per lane = OQ / 4 units
+__device__ __forceinline__ void cmma_stream_p(f32x4& acc, const float4* __restrict__ slot, int unit0, const float* sA, int lda,
+                                              int OQ) {
+  const int lane = threadIdx.x & 63;
+  const float4* pw = slot + unit0 * 64 + lane;
+  const float4* pa = reinterpret_cast<const float4*>(sA + (lane & 15) * lda + (lane >> 4) * OQ);
+  const int n4 = OQ >> 2;
+  for (int c = 0; c < n4; c += 2) {
+    const float4 w0 = pw[c * 64], w1 = pw[min(c + 1, n4 - 1) * 64];
+    {
+      const float4 av = pa[c];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, w0.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, w0.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, w0.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, w0.w, acc, 0, 0, 0);
+    }
+    if (c + 1 < n4) {
+      const float4 av = pa[c + 1];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, w1.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, w1.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, w1.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, w1.w, acc, 0, 0, 0);
+    }
+  }
 }
 
 // ---- hand-off pieces
@@ -361,11 +487,12 @@ __global__ __launch_bounds__(CT) void tf_chain_fwd_kernel(ChainFwd a) {
     // ------------------------------------------------------------------ OUT(bp): DenseForward(DM+128 -> 64 -> DM)
     if (OUT) {
       const TfOutP po = chain_out(a.cw, pm, bp);
+      const float4* oslot = a.wpack + (int64_t)d.M * nl * (CH_SLOT * 64) + ((int64_t)m * a.nb + bp) * (CO_SLOT * 64);
       float* next_F = PRE ? a.F0 + (int64_t)bq * a.rows * DMF : nullptr;
       const uint32_t siteo = hdf_site_id(m, bp, 4, 0);
       if (cw) {
         f32x4 acc = zero4();
-        wmma_stream(acc, po.wa + mo, DMF, 16 * wave, s_F, ldF, DMF >> 2);
+        wmma_stream_p(acc, oslot, OA_F + 24 * wave, DMF >> 4, s_F, ldF, DMF >> 2);
         const int c = 16 * wave + col;
         const float ba = po.ba[mo + c];
 #pragma unroll
@@ -378,7 +505,7 @@ __global__ __launch_bounds__(CT) void tf_chain_fwd_kernel(ChainFwd a) {
       if (cw) {
         for (int nn = 16 * wave; nn < DM; nn += 64) {
           f32x4 acc = zero4();
-          wmma_stream(acc, po.wb + mo, 64, nn, s_z, LD64, 16);
+          wmma_stream_p(acc, oslot, OB_F + 4 * (nn >> 4), 4, s_z, LD64, 16);
           const int c = nn + col;
           const float bb = po.bb[mo + c];
 #pragma unroll
@@ -668,6 +795,7 @@ struct ChainBwd {
   const float* save;      // tf_save layout
   float* dF;              // [rows][DMF]: columns [0, DM) = gradient of block 0's input on return
   const void* d_attnall;  // storage dtype
+  const float4* wpack;    // fragment-major weights (written by the forward's pack launch: same parameters)
   float* tape;            // [nb*4][TF_TAPE_W segments][rows]
   float* otape;           // [nb][DMF segments][rows]
   float* xchg;            // hand-off scratch, by layer parity: [2][rows][40] dO | delta rows (exact mode) or
@@ -730,9 +858,9 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
   float* s_at = s_dl + TT * 8;           // attention chunk images: 2 x (QC x QP floats + 2 x [8][QC] floats + 2 x [8][5][QC] u16)
   constexpr int AT_IMG = QC * QP, AT_T = 8 * QC, AT_U = 8 * 5 * QC / 2;   // (u16 arrays counted in floats)
   constexpr int AT_BUF = AT_IMG + 2 * AT_T + 2 * AT_U;
-  const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6, wave = wave8 & 3, col = lane & 15, g = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6, wave = wave8 & 3, col0 = lane & 15, g0 = lane >> 4;
   const bool cw = tid < 256;
-  const int lrow = (tid >> 4) & 15, lc = (tid & 15) * 2;   // the "LayerNorm" thread map of the first 256 threads
+  const int lrow0 = (tid >> 4) & 15, lc0 = (tid & 15) * 2;   // the "LayerNorm" thread map of the first 256 threads
   const int seq = blockIdx.x % a.nseq, tile = blockIdx.x / a.nseq;
   const int m = seq / d.B, bsm = seq - m * d.B;
   const int n0 = tile * TT, nvalid = min(TT, N - n0);
@@ -746,6 +874,10 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
   bool dead = false;
   const int nl = a.nb * 4;
   float r_acc0 = 0.f, r_acc1 = 0.f;      // residual-path gradient of the layer in flight (POSTB -> PREB)
+  // Side outputs of a stage -- tape segments, column sums for the bias / LayerNorm-parameter gradients -- are written by the
+  // four waves that sit out the token stages, in the same barrier interval in which waves 0-3 run the next GEMM on the same
+  // tiles (tok_bwd_kernel: the computing waves did both, one after the other).
+  const int htid = tid - 256;
 
   for (int L = nl - 1; L >= -1; L--) {
     const bool PREB = L + 1 < nl, POSTB = L >= 0, OUTB = POSTB && (L & 3) == 3;
@@ -753,7 +885,28 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
     const int bp = L >> 2, lp = L & 3, bo = bp;        // POSTB's layer, OUTB's block
     int t0 = t0k;
     asm volatile("" : "+s"(t0));   // (see the forward kernel: keeps the row addresses of every stage inside the loop)
+    // the lane coordinates too: loop-invariant, hipcc hoists the 24 (row, column) addresses of the Linear0 data gradient
+    // (and more) out of the layer loop, spills them at kernel entry and re-loads two per row from scratch in every layer
+    int col = col0, g = g0, lrow = lrow0, lc = lc0;
+    asm volatile("" : "+v"(col), "+v"(g), "+v"(lrow), "+v"(lc));
     auto tok = [&](int row) { return t0 + min(row, nvalid - 1); };
+    auto tape_h = [&](float* tape, int col0, const float* sT, int lds_ld, int width) __attribute__((always_inline)) {
+      const int w4 = width >> 2;
+      float* seg = tape + trows * col0 + (rb + t0) * width;
+      for (int i = htid; i < TT * w4; i += 256) {
+        const int row = i / w4, c4 = (i - row * w4) * 4;
+        if (row < nvalid) *reinterpret_cast<float4*>(seg + i * 4) = *reinterpret_cast<const float4*>(sT + row * lds_ld + c4);
+      }
+    };
+    auto colsum_h = [&](float* gb, int width, const float* sv, int ld, int tbase) __attribute__((always_inline)) {
+      const int c = htid - tbase;
+      if (c >= 0 && c < width) {
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < TT; r++) acc += sv[r * ld + c];
+        atomicAdd(gb + c, acc);
+      }
+    };
     const bool lok = lrow < nvalid;
     const int64_t lr = (rb + tok(lrow)) * 32 + lc;
     // ------------------------------------------------------------------ requests of the token phase
@@ -773,9 +926,10 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
       float* grest = gw0 + 32 * Kq;
       gq.b0 = grest + CO_B0, gq.ln1g = grest + CO_LN1G, gq.ln1b = grest + CO_LN1B;
       if (cw) {
-        cload(c_q, rest + CO_WQKV, 32, 16 * (wave & 1), 32, 24, 12 * (wave >> 1), 12);
+        const float4* slot = a.wpack + ((int64_t)m * nl + Lq) * (CH_SLOT * 64);
+        cpload(c_q, slot, CB_Q + 3 * wave);
 #pragma unroll
-        for (int j = 0; j < 6; j++) cload(c_w0[j], w0, Kq, 16 * (wave + 4 * j), Kq, 8, 0, 8);
+        for (int j = 0; j < 6; j++) cpload(c_w0[j], slot, CB_W0 + 2 * min(wave + 4 * j, (Kq >> 4) - 1));
         ln1 = ln_load(rest + CO_LN1G, rest + CO_LN1B);
         const float* h0 = a.save + (int64_t)Lq * a.rows * 232;
         r_h0[0] = h0[lr], r_h0[1] = h0[lr + 1];
@@ -787,10 +941,11 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
       float* grest = chain_w0(a.cw, a.grads, bp, lp) + mo + 32 * (DM + 32 * lp);
       gp.bout = grest + CO_BOUT, gp.ln2g = grest + CO_LN2G, gp.ln2b = grest + CO_LN2B, gp.b1 = grest + CO_B1, gp.b2 = grest + CO_B2;
       if (cw) {
-        wload(f_w1, rest + CO_W1, 32, 16 * wave, 8, 0, 2);
-        cload(c_w2, rest + CO_W2, 64, 16 * wave, 64, 8, 0, 8);
-        cload(c_w1, rest + CO_W1, 32, 16 * (wave & 1), 32, 16, 8 * (wave >> 1), 8);
-        cload(c_wo, rest + CO_WOUT, 32, 16 * (wave & 1), 32, 8, 4 * (wave >> 1), 4);
+        const float4* slot = a.wpack + ((int64_t)m * nl + L) * (CH_SLOT * 64);
+        pload(f_w1, slot, CH_W1 + 2 * wave, 2);
+        cpload(c_w2, slot, CB_W2 + 2 * wave);
+        cpload(c_w1, slot, CB_W1 + 2 * wave);
+        cpload(c_wo, slot, CB_WO + wave);
         ln2 = ln_load(rest + CO_LN2G, rest + CO_LN2B);
         p_b1 = rest[CO_B1 + 16 * wave + col];
         const float* sv = a.save + (int64_t)L * a.rows * 232;
@@ -812,9 +967,9 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
       float rs1 = 0.f;
       if (cw) rs1 = ln32_keep(s_a, s_b, s_c, ln1);   // t = LN1(h0) -> s_b, xh -> s_c
       __syncthreads();
-      if (cw) {
-        tape_store(tape_q, trows, TF_T_DQ, s_dq, 100, 96, rb + t0, nvalid);
-        tape_store(tape_q, trows, TF_T_T, s_b, LD32, 32, rb + t0, nvalid);
+      if (!cw) {
+        tape_h(tape_q, TF_T_DQ, s_dq, 100, 96);
+        tape_h(tape_q, TF_T_T, s_b, LD32, 32);
       }
       f32x4 accq = zero4();
       if (cw) {  // dt = dqkv * Wqkv -> s_e
@@ -838,11 +993,12 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
         s_a[lrow * LD32 + lc + 1] = lok ? dh1v + r_acc1 : 0.f;
       }
       __syncthreads();
-      if (cw) {
-        colsum_atomic(gq.ln1g, 32, s_gx, LD32, 0);
-        colsum_atomic(gq.ln1b, 32, s_e, LD32, 64);
-        colsum_atomic(gq.b0, 32, s_a, LD32, 128);
-        tape_store(tape_q, trows, TF_T_DH0, s_a, LD32, 32, rb + t0, nvalid);
+      if (!cw) {
+        colsum_h(gq.ln1g, 32, s_gx, LD32, 0);
+        colsum_h(gq.ln1b, 32, s_e, LD32, 64);
+        colsum_h(gq.b0, 32, s_a, LD32, 128);
+        tape_h(tape_q, TF_T_DH0, s_a, LD32, 32);
+      } else {
         // dF[:, 0:Kq] += dh0 * W0
 #pragma unroll
         for (int j = 0; j < 6; j++) {
@@ -881,6 +1037,7 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
     if (OUTB) {
       const TfOutP po = chain_out(a.cw, pm, bo);
       const TfOutP go = chain_out(a.cw, a.grads, bo);
+      const float4* oslot = a.wpack + (int64_t)d.M * nl * (CH_SLOT * 64) + ((int64_t)m * a.nb + bo) * (CO_SLOT * 64);
       const float* Fo = a.F0 + (int64_t)bo * a.rows * DMF;
       float* otape = a.otape + (int64_t)bo * a.rows * DMF;
       const uint32_t siteo = hdf_site_id(m, bo, 4, 0);
@@ -912,7 +1069,7 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
       if (cw) {
         {  // z = Wa F + ba (recomputed), f = gelu(z) * mask -> s_f
           f32x4 acc = zero4();
-          wmma_stream(acc, po.wa + mo, DMF, 16 * wave, s_F, ldF, DMF >> 2);
+          wmma_stream_p(acc, oslot, OA_F + 24 * wave, DMF >> 4, s_F, ldF, DMF >> 2);
           const int c = 16 * wave + col;
           const float ba = po.ba[mo + c];
 #pragma unroll
@@ -925,23 +1082,24 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
         }
         {  // df = do * Wb ; dz = df * mask * gelu'(z) -> s_dz
           f32x4 acc = zero4();
-          cmma_stream(acc, po.wb + mo, 64, 16 * wave, 64, s_do, ldD, DM >> 2);
+          cmma_stream_p(acc, oslot, OB_B + 16 * wave, s_do, ldD, DM >> 2);
           const int c = 16 * wave + col;
 #pragma unroll
           for (int r = 0; r < 4; r++) s_dz[(4 * g + r) * LD64 + c] = acc[r] * mk[r] * gelu_grad_f(zr[r]);
         }
       }
       __syncthreads();
-      if (cw) {
-        tape_store(otape, trows, 0, s_do, ldD, DM, rb + t0, nvalid);
-        tape_store(otape, trows, DM, s_f, LD64, 64, rb + t0, nvalid);
-        tape_store(otape, trows, DM + 64, s_dz, LD64, 64, rb + t0, nvalid);
-        for (int c0 = 0; c0 < DM; c0 += 128) colsum_atomic(go.bb + mo + c0, min(128, DM - c0), s_do + c0, ldD, 0);
-        colsum_atomic(go.ba + mo, 64, s_dz, LD64, 128);
+      if (!cw) {
+        tape_h(otape, 0, s_do, ldD, DM);
+        tape_h(otape, DM, s_f, LD64, 64);
+        tape_h(otape, DM + 64, s_dz, LD64, 64);
+        for (int c0 = 0; c0 < DM; c0 += 128) colsum_h(go.bb + mo + c0, min(128, DM - c0), s_do + c0, ldD, 0);
+        colsum_h(go.ba + mo, 64, s_dz, LD64, 128);
+      } else {
         // dF[:, 0:DMF] = dz * Wa  (overwrites: the first writer of block bo's feature gradient)
         for (int nn = 16 * wave; nn < DMF; nn += 64) {
           f32x4 acc = zero4();
-          cmma_stream(acc, po.wa + mo, DMF, nn, DMF, s_dz, LD64, 16);
+          cmma_stream_p(acc, oslot, OA_B + 4 * (nn >> 4), s_dz, LD64, 16);
           const int c = nn + col;
 #pragma unroll
           for (int r = 0; r < 4; r++) {
@@ -992,14 +1150,15 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
         }
         __syncthreads();
         f32x4 accu = zero4();
-        if (cw) {
+        if (!cw) {
           const int c0 = pass ? TF_T_P1 : TF_T_P0;
-          tape_store(tape_p, trows, c0, s_dg, LD32, 32, rb + t0, nvalid);
-          tape_store(tape_p, trows, c0 + 32, s_f, LD64, 64, rb + t0, nvalid);
-          tape_store(tape_p, trows, c0 + 96, s_dz, LD64, 64, rb + t0, nvalid);
-          tape_store(tape_p, trows, c0 + 160, s_b, LD32, 32, rb + t0, nvalid);
-          colsum_atomic(gp.b2, 32, s_dg, LD32, 0);
-          colsum_atomic(gp.b1, 64, s_dz, LD64, 64);
+          tape_h(tape_p, c0, s_dg, LD32, 32);
+          tape_h(tape_p, c0 + 32, s_f, LD64, 64);
+          tape_h(tape_p, c0 + 96, s_dz, LD64, 64);
+          tape_h(tape_p, c0 + 160, s_b, LD32, 32);
+          colsum_h(gp.b2, 32, s_dg, LD32, 0);
+          colsum_h(gp.b1, 64, s_dz, LD64, 64);
+        } else {
           // du = dz * W1 -> s_e
           cmma(accu, c_w1, s_dz, LD64, 16, 8 * (wave >> 1), 8);
           if (wave >= 2) {
@@ -1020,9 +1179,9 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
           dh0v = ok ? dh0v : 0.f, dh1v = ok ? dh1v : 0.f;
         }
         __syncthreads();
-        if (cw) {
-          colsum_atomic(gp.ln2g, 32, s_gx, LD32, 0);
-          colsum_atomic(gp.ln2b, 32, s_e, LD32, 64);
+        if (!cw) {
+          colsum_h(gp.ln2g, 32, s_gx, LD32, 0);
+          colsum_h(gp.ln2b, 32, s_e, LD32, 64);
         }
         if (pass == 1) {
           dcur0 = dh0v, dcur1 = dh1v;   // h2 feeds only the second ff: its gradient flows into ff#1's output ...
@@ -1042,9 +1201,10 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
       }
       __syncthreads();
       f32x4 acco = zero4();
-      if (cw) {
-        tape_store(tape_p, trows, TF_T_DGO, s_dg, LD32, 32, rb + t0, nvalid);
-        colsum_atomic(gp.bout, 32, s_dg, LD32, 0);
+      if (!cw) {
+        tape_h(tape_p, TF_T_DGO, s_dg, LD32, 32);
+        colsum_h(gp.bout, 32, s_dg, LD32, 0);
+      } else {
         cmma(acco, c_wo, s_dg, LD32, 8, 4 * (wave >> 1), 4);
         if (wave >= 2) {
 #pragma unroll
@@ -1114,33 +1274,46 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
     const float own_k = qkvL[(int64_t)rown * 96 + 32 + head * 4 + g];
     const float own_v = qkvL[(int64_t)rown * 96 + 64 + head * 4 + g];
     const float own_lse = lseL[(int64_t)rown * 8 + head];
+    // 16-bit modes: everything of the attention backward that comes from the forward launch is requested before the wait:
+    // the dQ loop's first PD blocks of key operands and this head's -lse row
+    constexpr int PD = 8, NLS = 4;   // prefetch ring depth (blocks); 16-byte pieces per lane of an [NP <= 1024] row
+    const int NPq = attn_rows(N);
+    const float* fr = nullptr;
+    const int cb = min(col, 4) * 4 + g;      // this lane's entry of a 16-bit B operand table (row 4: zeros)
+    float ka[PD], va[PD];
+    u32x2 kb[PD];
+    float4 r_ls[NLS];
+    auto ldk = [&](int b, int i) __attribute__((always_inline)) {
+      const float* r = fr + (int64_t)min(b, a.ntile - 1) * 8 * FR_W;
+      ka[i] = r[FR_KA + lane], va[i] = r[FR_VA + lane];
+      kb[i] = reinterpret_cast<const u32x2*>(r + FR_KB)[cb];
+    };
+    if constexpr (LP != 0) {
+      fr = a.frag + ((int64_t)L * a.nseq + seq) * a.ntile * 8 * FR_W + (int64_t)head * FR_W;   // + blk * 8 * FR_W
+      const float* lsrow = a.frag + (int64_t)nl * a.nseq * a.ntile * 8 * FR_W + (((int64_t)L * a.nseq + seq) * 8 + head) * NPq;
+#pragma unroll
+      for (int i = 0; i < PD; i++) ldk(i, i);
+#pragma unroll
+      for (int k = 0; k < NLS; k++) r_ls[k] = *reinterpret_cast<const float4*>(lsrow + min((k * 64 + lane) * 4, NPq - 4));
+    }
     CHAIN_STAMPB(5);
     chain_wait(cnt, (unsigned)(a.ntile * (nl - L)), tmo, dead);
     CHAIN_STAMPB(6);
 
     // ------------------------------------------------------------------ attention backward of layer L: head = wave
     if constexpr (LP != 0) {
-      // 16-bit storage modes: attn_bwd_lp_kernel's arithmetic on operand records (FR_* / XG_*), prefetch ring of PD blocks
-      constexpr int PD = 4;
-      const int NP = attn_rows(N), nblk = a.ntile;
-      const float* fr = a.frag + ((int64_t)L * a.nseq + seq) * a.ntile * 8 * FR_W + (int64_t)head * FR_W;   // + blk * 8 * FR_W
+      // 16-bit storage modes: attn_bwd_lp_kernel's arithmetic on operand records (FR_* / XG_*), prefetch rings of PD blocks
+      const int NP = NPq, nblk = a.ntile;
       const float* xg = xgseq + (int64_t)head * XG_W;                                                        // + blk * 8 * XG_W
-      const int cb = min(col, 4) * 4 + g;      // this lane's entry of a 16-bit B operand table (row 4: zeros)
       // (-lse log2(e), -delta) of every query of the sequence for THIS wave's head: two [NP] rows of LDS, filled by the
-      // wave itself from the head-major arrays (requested here, written behind the dQ loop: no workgroup barrier)
+      // wave itself from the head-major arrays (written behind the dQ loop: no workgroup barrier)
       float* s_ls = s_at + head * 2 * NP;
       float* s_dlq = s_ls + NP;
-      const float* lsrow = a.frag + (int64_t)nl * a.nseq * a.ntile * 8 * FR_W + (((int64_t)L * a.nseq + seq) * 8 + head) * NP;
       const __amdgpu_buffer_rsrc_t rdl = chain_rsrc(a.xchg + (int64_t)2 * a.nseq * a.ntile * 8 * XG_W +
                                                     (((int64_t)par * a.nseq + seq) * 8 + head) * NP);
-      constexpr int NLS = 4;   // 16-byte pieces per lane: covers NP <= 1024
-      float4 r_ls[NLS], r_dl[NLS];
+      float4 r_dl[NLS];
 #pragma unroll
-      for (int k = 0; k < NLS; k++) {
-        const int i4 = min((k * 64 + lane) * 4, NP - 4);
-        r_ls[k] = *reinterpret_cast<const float4*>(lsrow + i4);
-        r_dl[k] = ld16_sc1(rdl, (uint32_t)(i4 * 4));
-      }
+      for (int k = 0; k < NLS; k++) r_dl[k] = ld16_sc1(rdl, (uint32_t)(min((k * 64 + lane) * 4, NP - 4) * 4));
       // ---- dQ of the tile's queries
       {
         const float delta = s_dl[col * 8 + head];
@@ -1148,15 +1321,6 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
         const float bqv = own_q * (0.5f * LOG2E);
         const float bg = s_dO[col * LD32 + head * 4 + g];
         const f32x4 nl4 = {-ls, -ls, -ls, -ls}, nd4 = {-delta, -delta, -delta, -delta};
-        float ka[PD], va[PD];
-        u32x2 kb[PD];
-        auto ld = [&](int b, int i) __attribute__((always_inline)) {
-          const float* r = fr + (int64_t)min(b, nblk - 1) * 8 * FR_W;
-          ka[i] = r[FR_KA + lane], va[i] = r[FR_VA + lane];
-          kb[i] = reinterpret_cast<const u32x2*>(r + FR_KB)[cb];
-        };
-#pragma unroll
-        for (int i = 0; i < PD; i++) ld(i, i);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         auto step = [&](int i, int j0, auto masked) __attribute__((always_inline)) {
           const f32x4 cs = chain_mfma4(ka[i], bqv, nl4), ct = chain_mfma4(va[i], bg, nd4);
@@ -1174,7 +1338,7 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
 #pragma unroll
           for (int i = 0; i < PD; i++) {
             step(i, 0, std::false_type{});
-            ld(bb + i + PD, i);
+            ldk(bb + i + PD, i);
           }
         }
         for (int i = 0; bb < nblk; bb++, i++) {   // up to PD - 1 whole blocks and the partial one (i < PD: static after unrolling)
@@ -1523,7 +1687,9 @@ bool tf_chain_backward_supported(const TfDims& d, int dtype) {
          (dtype == HDF_F32 || ((size_t)2 * d.M * d.B * ceil_div(d.N, TT) * (8 * XG_W + 8 * TT) <= (size_t)d.M * d.B * d.N * 160 &&
                                attn_rows(d.N) <= 1024));
 }
-size_t tf_chain_wpack_bytes(const TfDims& d, int nb) { return (size_t)d.M * nb * 4 * CH_SLOT * 64 * sizeof(float4); }
+size_t tf_chain_wpack_bytes(const TfDims& d, int nb) {
+  return ((size_t)d.M * nb * 4 * CH_SLOT + (size_t)d.M * nb * CO_SLOT) * 64 * sizeof(float4);
+}
 
 bool tf_chain_supported(const TfDims& d) {
   const int ntile = ceil_div(d.N, TT);
@@ -1548,7 +1714,7 @@ int tf_chain_forward(const TfDims& d, const TfChainP& cp, int nb, const float* p
     hdf_set_error("transformer chain: hipMemsetAsync failed: %s", hipGetErrorString(e));
     return HDF_ERR_HIP;
   }
-  hipLaunchKernelGGL(tf_chain_pack_kernel, dim3(nb * 4, d.M), dim3(256), 0, st, a.cw, params, d.mstride, d.DM, nb * 4,
+  hipLaunchKernelGGL(tf_chain_pack_kernel, dim3(nb * 4 + nb, d.M), dim3(256), 0, st, a.cw, params, d.mstride, d.DM, nb * 4,
                      reinterpret_cast<float4*>(wpack));
   HDF_LAUNCH_CHECK();
   const dim3 grid(a.nseq * a.ntile);
@@ -1565,13 +1731,14 @@ int tf_chain_forward(const TfDims& d, const TfChainP& cp, int nb, const float* p
 
 int tf_chain_backward(const TfDims& d, const TfChainP& cp, int nb, const float* params, float* grads, const float* F0,
                       const float* save, float* dF, const void* d_attnall, float* tape, float* otape, float* xchg,
-                      const float* frag, unsigned* sync, int dtype, hipStream_t st) {
+                      const float* frag, const void* wpack, unsigned* sync, int dtype, hipStream_t st) {
   HDF_CHECK_ARG(tf_chain_backward_supported(d, dtype), "transformer chain: shape not supported (M %d B %d N %d DM %d)", d.M, d.B, d.N, d.DM);
   ChainBwd a{};
   HDF_CHECK_ARG(chain_digest(cp, d.DM, a.cw), "transformer chain: irregular parameter layout");
   HDF_CHECK_ARG(dtype == HDF_F32 || dtype == HDF_BF16 || dtype == HDF_F16, "unsupported dtype %d", dtype);
   a.d = d, a.params = params, a.grads = grads, a.F0 = F0, a.save = save, a.dF = dF, a.d_attnall = d_attnall;
   a.tape = tape, a.otape = otape, a.xchg = xchg, a.sync = sync, a.dtype = dtype, a.frag = frag;
+  a.wpack = reinterpret_cast<const float4*>(wpack);
   HDF_CHECK_ARG(dtype == HDF_F32 || frag, "transformer chain backward: no operand records");
   a.nb = nb, a.ntile = ceil_div(d.N, TT), a.nseq = d.M * d.B, a.rows = (int64_t)d.M * d.B * d.N;
   const size_t shm = chain_bwd_lds(d, dtype);
