@@ -113,6 +113,74 @@ def conv_source_digest():
     return h.hexdigest()
 
 
+# The stride-1 convolution launches of one training step that run conv_ws2_kernel (csrc/conv_igemm.hip): forward and data
+# gradient of every 3x3x3 layer at 128^3 / 64^3 with <= 64 input channels, minus the first layer (conv_first_kernel) and
+# block_1_1_right's forward (conv_wr_kernel).  (cin, cout, size): reference layers models/HDenseFormer.py:196-221,190-194.
+WS2_FAMILY = [
+    (32, 32, 128), (32, 32, 128),                                        # block_1_2_left, block_1_2_right forward
+    (32, 64, 64), (64, 64, 64), (64, 64, 64), (64, 32, 64),              # block_2_1_left, block_2_2_left/right, up3 forward
+    (32, 32, 128), (32, 32, 128), (32, 64, 128),                         # data gradients at 128^3 (1_2_left, 1_2_right, 1_1_right)
+    (64, 32, 64), (64, 64, 64), (64, 64, 64), (64, 128, 64), (32, 64, 64),   # data gradients at 64^3
+]
+
+
+def roofline_conv_family(dev, passes=6):
+    """Live HIP-event timing of the kernel family with the largest share of the step (profiles/*_step_kernel_table.txt):
+    conv_ws2_kernel, 14 launches per step.  One pass = those 14 GEMM shapes back to back through hdf_op_conv3d (the plan's
+    own routing); achieved = their algorithmic FLOPs (2*27*Cin*Cout*voxels*batch) / the time of a pass."""
+    from hdf_rt._lib import BF16, check, lib, ptr
+    n = 2
+    st = torch.cuda.current_stream().cuda_stream
+    bufs = {}
+    for cin, cout, s in set(WS2_FAMILY):
+        x = torch.randn(n, s, s, s, cin, device=dev).to(torch.bfloat16)
+        w = (torch.randn(27 * ((cout + 31) // 32 * 32) * cin, device=dev) * 0.02).to(torch.bfloat16)
+        out = torch.empty(n, s, s, s, cout, device=dev, dtype=torch.bfloat16)
+        tiles = lib().hdf_op_conv3d_stat_tiles(BF16, cin, s, s, s)
+        part = torch.empty(n * tiles * ((cout + 31) // 32 * 32) * 2, device=dev)
+        bufs[(cin, cout, s)] = (x, w, out, part)
+
+    def one_pass():
+        for cin, cout, s in WS2_FAMILY:
+            x, w, out, part = bufs[(cin, cout, s)]
+            check(lib().hdf_op_conv3d(BF16, 0, ptr(x), cin, cin, n, s, s, s, ptr(w), None, None, None, 0, ptr(out), cout,
+                                      cout, ptr(part), 0, st), "conv")
+    for _ in range(3):
+        one_pass()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(passes):
+        one_pass()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / passes
+    flops = sum(2.0 * 27 * cin * cout * (s ** 3) * n for cin, cout, s in WS2_FAMILY)
+    byt = sum(2.0 * n * s ** 3 * (cin + cout) for cin, cout, s in WS2_FAMILY)
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": None,
+            "kernel": "conv_ws2_kernel family: the 14 stride-1 3x3x3 conv launches (forward + data gradient, 128^3 / 64^3, "
+                      "batch 2) of one training step -- the family with the largest share of the step's kernel time",
+            "launches_per_pass": len(WS2_FAMILY), "pass_ms": ms, "avg_launch_ms": ms / len(WS2_FAMILY),
+            "flops_per_pass": flops, "algorithmic_bytes_per_pass": byt}
+
+
+def step_roofline_from_profile():
+    """roofline.step: algorithmic FLOPs of all matrix-core conv kernels of a step / their summed one-stream time / peak, from
+    the newest committed profile set (tools/profile_summarise.py writes profiles/*_step_roofline.json); not measurable
+    live (it needs a one-stream kernel trace)."""
+    best = None
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+        if name.endswith("_step_roofline.json"):
+            best = name
+            break
+    if best is None:
+        return None
+    rec = json.load(open(os.path.join(ROOT, "profiles", best)))
+    rec["source"] = "profiles/" + best
+    return rec
+
+
 def roofline_dominant_kernel(dev):
     """Live HIP-event timing of the dominant kernel class of the step: the bf16 implicit-GEMM conv on its largest layer,
     block_1_1_right: 64->32 channels at 128^3, batch 2 (round 4: conv_wr_kernel, csrc/conv_wr.hip -- the launch goes
@@ -185,7 +253,11 @@ def main():
         torch.cuda.set_device(0)
         from hdf_rt import _lib
         _lib.lib()
-        print(json.dumps({"roofline": roofline_dominant_kernel(torch.device("cuda", 0))}), flush=True)
+        dev0 = torch.device("cuda", 0)
+        r = roofline_conv_family(dev0)
+        r["wr"] = roofline_dominant_kernel(dev0)
+        r["step"] = step_roofline_from_profile()
+        print(json.dumps({"roofline": r}), flush=True)
         return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -308,14 +380,22 @@ def main():
             "host_issue_ms_per_step": t_enqueued / a.steps * 1e3,
         }
         if world == 1 and not a.no_roofline:
-            rec["roofline"] = roofline_dominant_kernel(dev)
+            wr = roofline_dominant_kernel(dev)
+            rec["roofline"] = roofline_conv_family(dev)
+            rec["roofline"]["step"] = step_roofline_from_profile()
+            rec["roofline"]["wr"] = wr      # the single conv_wr_kernel launch of a step (rounds 1-4 reported this one)
+            # HBM bytes of the family's 14 launches from the committed PMC passes of the same build (else null)
+            stp = rec["roofline"]["step"]
+            if stp and stp.get("conv_source_digest") == conv_source_digest():
+                rec["roofline"]["traffic"] = stp.get("families", {}).get("conv_ws2_kernel", {}).get("hbm_bytes") or None
+                rec["roofline"]["traffic_source"] = stp["source"]
             if in_step_ms:
                 # the same launch as it runs inside the timed steps (HIP events recorded by the library around it, one
                 # pair per step): `frac` above stays the back-to-back figure of the earlier rounds, this is what the
                 # kernel does in the workload (the chip is not at its power cap between two launches of a step)
                 ms_in = sum(in_step_ms) / len(in_step_ms)
-                fl = rec["roofline"]["flops_per_launch"]
-                rec["roofline"]["in_step"] = {
+                fl = wr["flops_per_launch"]
+                wr["in_step"] = {
                     "avg_launch_ms": ms_in, "median_ms": in_step_ms[len(in_step_ms) // 2], "min_ms": in_step_ms[0],
                     "max_ms": in_step_ms[-1], "launches": len(in_step_ms),
                     "achieved": fl / (ms_in * 1e-3) / 1e12, "frac": fl / (ms_in * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS}

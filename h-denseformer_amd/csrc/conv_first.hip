@@ -40,6 +40,9 @@ template <typename T, int NB>
 __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void conv_first_kernel(ConvFirstArgs a) {
   __shared__ __attribute__((aligned(16))) char s_col[CF_VOX * CF_PITCH];
   __shared__ u32x2 s_box[(CF_TD + 2) * (CF_TH + 2) * (CF_TW + 2)];
+  // channels >= Cin of the 4-channel (8-byte) voxel load are masked when the box is committed: the op-level entry promises
+  // that only the first Cin channels are read, and a NaN there would reach every output as 0 * NaN
+  const uint32_t cmask0 = a.Cin >= 2 ? 0xffffffffu : 0x0000ffffu, cmask1 = a.Cin >= 4 ? 0xffffffffu : (a.Cin == 3 ? 0x0000ffffu : 0u);
   __shared__ float s_red[4 * 32 * NB * 2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const int n = blockIdx.y;
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void conv_first_kernel(ConvFi
 #pragma unroll
     for (int j = 0; j < NSL; j++) {
       const bool ok = (pf_ok >> j) & 1u;
-      if (tid + 256 * j < BOX) s_box[tid + 256 * j] = u32x2{ok ? pf[j][0] : 0u, ok ? pf[j][1] : 0u};
+      if (tid + 256 * j < BOX) s_box[tid + 256 * j] = u32x2{ok ? pf[j][0] & cmask0 : 0u, ok ? pf[j][1] & cmask1 : 0u};
     }
   };
   // the tile's 256 x 27 (voxel, tap) items, tap fastest, dealt to the threads in order: a wave then writes 64 CONSECUTIVE
@@ -311,6 +314,9 @@ __global__ __launch_bounds__(256) void wgrad_first_kernel(WgradFirstArgs a) {
   __shared__ __attribute__((aligned(16))) char s_col[WF_VOX * WF_PITCH];
   __shared__ __attribute__((aligned(16))) char s_dy[2][WF_VOX * 64 * MB];
   __shared__ u32x2 s_box[WF_BOX];
+  // channels >= Cin of the 4-channel (8-byte) voxel load are masked when the box is committed: the op-level entry promises
+  // that only the first Cin channels are read, and a NaN there would reach every output as 0 * NaN
+  const uint32_t cmask0 = a.Cin >= 2 ? 0xffffffffu : 0x0000ffffu, cmask1 = a.Cin >= 4 ? 0xffffffffu : (a.Cin == 3 ? 0x0000ffffu : 0u);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = blockIdx.y;
   const int ntz = (a.D + WF_TD - 1) / WF_TD, nty = (a.H + CF_TH - 1) / CF_TH, ntx = (a.W + CF_TW - 1) / CF_TW;
@@ -377,7 +383,7 @@ __global__ __launch_bounds__(256) void wgrad_first_kernel(WgradFirstArgs a) {
 #pragma unroll
     for (int j = 0; j < NBX; j++) {
       const bool ok = (pf_ok >> j) & 1u;
-      if (tid + 256 * j < WF_BOX) s_box[tid + 256 * j] = u32x2{ok ? pfb[j][0] : 0u, ok ? pfb[j][1] : 0u};
+      if (tid + 256 * j < WF_BOX) s_box[tid + 256 * j] = u32x2{ok ? pfb[j][0] & cmask0 : 0u, ok ? pfb[j][1] & cmask1 : 0u};
     }
 #pragma unroll
     for (int j = 0; j < NDY; j++) {
@@ -526,6 +532,8 @@ int hdf_launch_conv_first(int dtype, const void* in, int64_t in_pitch, int Cin, 
   HDF_CHECK_ARG(hdf_conv_first_can(dtype, Cin, Cout, D, H, W, in_pitch), "conv_first: dtype %d Cin %d Cout %d %dx%dx%d",
                 dtype, Cin, Cout, D, H, W);
   HDF_CHECK_ARG((reinterpret_cast<uintptr_t>(in) & 7) == 0, "conv_first: input must be 8-byte aligned");
+  HDF_CHECK_ARG((reinterpret_cast<uintptr_t>(out) & 7) == 0 && out_pitch % 4 == 0,
+                "conv_first: output must be 8-byte aligned with a pitch that is a multiple of 4 channels");
   ConvFirstArgs a{};
   a.in = in, a.in_pitch = in_pitch, a.Cin = Cin, a.N = N, a.D = D, a.H = H, a.W = W;
   a.w32 = w32, a.bias = bias, a.out = out, a.out_pitch = out_pitch, a.Cout = Cout, a.CoutP = (Cout + 31) / 32 * 32;

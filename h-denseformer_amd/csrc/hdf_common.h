@@ -237,7 +237,9 @@ __device__ __forceinline__ float wave_max(float v) {
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
-static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }// The transformer branches are ~100 short, latency-bound launches on the critical path that run NEXT TO the heavy
+static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
+
+// The transformer branches are ~100 short, latency-bound launches on the critical path that run NEXT TO the heavy
 // persistent convolutions of the other streams (plan.hip: forward and backward3d fork).  Their waves co-reside with the
 // conv waves on a SIMD; raising the wave priority lets their few instructions issue ahead of the conv's stream of
 // MFMA / LDS work (the stream priority only orders workgroup DISPATCH).  HDF_NO_CHAIN_PRIO: A/B builds.

@@ -756,7 +756,8 @@ struct Xf {
 };
 Xf xf_of(const Exec& e, const Conv3& c) { return Xf{e.f(c.st.scale), e.f(c.st.shift), 1}; }
 
-int conv_forward(Exec& e, Conv3& c, const View& in, Xf xf) {
+// probe: record the plan's probe events immediately around the convolution launch (hdf_plan_set_probe)
+int conv_forward(Exec& e, Conv3& c, const View& in, Xf xf, bool probe = false) {
   hdf_plan* p = e.p;
   const int* d = e.dm(c.lvl);
   const int CoutP = round_up(c.Cout, 32);
@@ -788,7 +789,18 @@ int conv_forward(Exec& e, Conv3& c, const View& in, Xf xf) {
                                   e.at(c.y), c.y.pitch, c.Cout, e.statp(), e.st));
   } else
 #endif
-  HDF_TRY(hdf_launch_conv(p->dtype, 0, a, e.st));
+  {
+    const bool pr = probe && p->probe_start && p->probe_stop;
+    if (pr && hipEventRecord(p->probe_start, e.st) != hipSuccess) {
+      hdf_set_error("probe: hipEventRecord failed");
+      return HDF_ERR_HIP;
+    }
+    HDF_TRY(hdf_launch_conv(p->dtype, 0, a, e.st));
+    if (pr && hipEventRecord(p->probe_stop, e.st) != hipSuccess) {
+      hdf_set_error("probe: hipEventRecord failed");
+      return HDF_ERR_HIP;
+    }
+  }
   int tiles = hdf_conv_stat_tiles(0, d[0], d[1], d[2], c.CinP * p->esz);
   HDF_TRY(hdf_launch_in_finalize(e.statp(), e.B, tiles, c.Cout, CoutP, p->vox(c.lvl), e.P(c.gamma),
                                  e.P(c.beta), 1e-5f, e.f(c.st.mean), e.f(c.st.rstd), e.f(c.st.scale),
@@ -1502,16 +1514,7 @@ static int forward3d(hdf_plan* p, const float* x, const float* params, void* wor
   for (int k = 2; k >= 0; k--) {
     View up_out = subview(p, p->cat[k], 0, ch[k]);
     HDF_TRY(convt_forward(e, p->upc[k], *dec_in, dec_xf, up_out));
-    const bool probe = k == 0 && p->probe_start && p->probe_stop;   // block_1_1_right: bench.py's roofline kernel
-    if (probe && hipEventRecord(p->probe_start, e.st) != hipSuccess) {
-      hdf_set_error("probe: hipEventRecord failed");
-      return HDF_ERR_HIP;
-    }
-    HDF_TRY(conv_forward(e, p->dec[k][0], p->cat[k], none));
-    if (probe && hipEventRecord(p->probe_stop, e.st) != hipSuccess) {
-      hdf_set_error("probe: hipEventRecord failed");
-      return HDF_ERR_HIP;
-    }
+    HDF_TRY(conv_forward(e, p->dec[k][0], p->cat[k], none, k == 0));   // k == 0: block_1_1_right, the probed launch
     HDF_TRY(conv_forward(e, p->dec[k][1], p->dec[k][0].y, xf_of(e, p->dec[k][0])));
     dec_in = &p->dec[k][1].y;
     dec_xf = xf_of(e, p->dec[k][1]);

@@ -89,8 +89,8 @@ int hdf_backward_stages(hdf_plan* p, const float* x, const float* params, void* 
 
 /* hdf_backward (ONE call, with its internal side / branch streams) that also tells the caller when each of the three
  * gradient buckets of hdf_backward_stages is final: bucket_events[k] (k = 0: encoder / decoder / heads, 1: UpConv chain,
- * 2: transformer branches) receives an event owned by the plan -- valid until the next hdf_backward_events call on it or
- * hdf_plan_destroy --, already recorded, on whichever internal stream finishes that bucket, when the call returns.  A
+ * 2: transformer branches) receives an event owned by the plan -- the three handles are stable for the plan's lifetime and
+ * RE-RECORDED by every hdf_backward_events call, so a waiter must enqueue its wait before the next call --, already recorded, on whichever internal stream finishes that bucket, when the call returns.  A
  * communication stream that waits for event k (hdf_stream_wait_event, or hipStreamWaitEvent on the handle) may all-reduce
  * bucket k while the rest of the backward is still running: no host round trip between the stages, the branch-stream
  * fork of the one-call backward stays.  Order of finality in the default arrangement: bucket 1 (chain), 0, 2.

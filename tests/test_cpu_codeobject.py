@@ -1,0 +1,100 @@
+"""Gate on what hipcc made of the kernels: the shipped library's gfx950 code objects are read
+without a GPU (tools/codeobj.py: NT_AMDGPU_METADATA notes + llvm-objdump) and checked against what DESIGN.md relies on --
+no scratch in the matrix-core families and the token / attention kernels, the register ceilings that let kernels of the
+three streams share a SIMD, and, for the one kernel that does spill (conv_wr_kernel, csrc/conv_wr.hip: 512 registers,
+hand-counted vmcnt), that no scratch access sits inside a 216-MFMA tile phase and that spills do not grow.  A compiler
+bump that moves any of this fails here instead of silently costing time on the GPU."""
+import os
+import re
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import codeobj  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not os.path.exists(codeobj.LIB), reason="libhdf_hip.so not built")
+
+
+@pytest.fixture(scope="module")
+def ks():
+    return codeobj.kernels()
+
+
+NO_SCRATCH = ("conv_ws2_kernel", "conv_wgrad2_kernel", "conv_igemm_kernel", "conv_wgrad_s2_kernel", "conv_gather_s2_kernel",
+              "convt_ws_kernel", "convt_fused_kernel", "conv_first_kernel", "wgrad_first_kernel", "tok_fwd_kernel",
+              "tok_bwd_kernel", "attn_fwd_kernel", "attn_bwd_kernel", "attn_bwd_lp_kernel", "tf_wgrad_kernel",
+              "patch_embed_fwd2_kernel", "patch_embed_wgrad_kernel", "tf_chain_fwd_kernel", "tf_chain_pack_kernel",
+              "in_bwd_apply4_kernel", "in_bwd_reduce4_kernel", "head_fwd_kernel", "enc_tail_up_kernel", "loss_fwd_kernel",
+              "loss_bwd_kernel", "adam_kernel")
+
+
+def test_the_library_holds_the_expected_kernel_families(ks):
+    assert len(ks) >= 240
+    for fam in NO_SCRATCH + ("conv_wr_kernel", "tf_chain_bwd_kernel"):
+        assert any(n.startswith(fam) for n in ks), fam
+
+
+@pytest.mark.parametrize("family", NO_SCRATCH)
+def test_no_scratch_and_no_register_spills(ks, family):
+    bad = {n: (k.get("private_segment_fixed_size", 0), k.get("vgpr_spill_count", 0)) for n, k in ks.items()
+           if n.startswith(family) and (k.get("private_segment_fixed_size", 0) or k.get("vgpr_spill_count", 0))}
+    assert not bad, bad
+
+
+def test_register_ceilings_that_let_the_streams_share_a_simd(ks):
+    """DESIGN 6d 'Sharing the SIMDs': beside a persistent conv / weight-gradient workgroup another stream's wave runs only
+    in what is left of the 512 registers per lane"""
+    for n, k in ks.items():
+        if n.startswith("conv_wgrad2_kernel"):
+            assert k["regs"] <= 384, (n, k["regs"])            # leaves 128: a token / attention / chain wave fits
+        if n.startswith("conv_ws2_kernel") and ", 32, 64, " in n and ", 1, " in n:
+            assert k["regs"] <= 384, (n, k["regs"])            # the two-pass 64-byte-row form (round 3: not 512)
+        if n.startswith(("attn_fwd_kernel", "attn_bwd_kernel", "attn_bwd_lp_kernel")):
+            assert k["regs"] <= 128, (n, k["regs"])
+        if n.startswith(("in_bwd_apply4", "in_bwd_reduce4", "in_finalize", "in_bwd_finalize", "head_bwd_kernel<bf16_t, 4", "head_bwd_kernel<f16_t, 4")):   # (n_cls <= 4: the benchmarked class count)
+            assert k["regs"] <= 128, (n, k["regs"])
+        if n.startswith("tok_bwd_kernel"):
+            assert k["regs"] <= 216, (n, k["regs"])
+        if n.startswith(("tf_chain_fwd_kernel", "tf_chain_bwd_kernel")):
+            assert k["regs"] <= 256 and k["max_flat_workgroup_size"] == 512, (n, k["regs"])   # two waves per SIMD
+    # static LDS of the persistent conv kernels: one workgroup per CU, below the 160 KiB of a CU
+    for n, k in ks.items():
+        if n.startswith(("conv_ws2_kernel", "conv_wr_kernel", "conv_wgrad2_kernel")):
+            assert k["group_segment_fixed_size"] <= 160 * 1024, (n, k["group_segment_fixed_size"])
+
+
+def test_the_persistent_backward_kernel_spills_only_its_staged_lse_rows(ks):
+    """tf_chain_bwd_kernel keeps four 16-byte pieces of -lse per lane across the dQ loop (64 B) at most in scratch; anything
+    beyond that would be reloads inside the token stages (each one a vmcnt(0) wait)"""
+    for n, k in ks.items():
+        if n.startswith("tf_chain_bwd_kernel"):
+            assert k.get("private_segment_fixed_size", 0) <= 96, (n, k.get("private_segment_fixed_size"))
+
+
+@pytest.mark.parametrize("T", ["bf16_t", "f16_t"])
+def test_conv_wr_routed_instantiation_keeps_scratch_out_of_the_tile_phase(ks, T):
+    """the instantiation the plan routes (hdf_conv_wr_takes: 128-byte rows, K split, no transform).  Its 216-MFMA tile
+    phases must stay free of scratch traffic (a scratch reload is an s_waitcnt vmcnt(0): it drains the LDS-DMA prefetch
+    queue), its spills must not grow, and the hand-counted vmcnt structure must be the one the source was written for."""
+    k = ks["conv_wr_kernel<%s, 128, 1, 2, 4, false>" % T]
+    assert k["vgpr_spill_count"] <= 196 and k["private_segment_fixed_size"] <= 404, k
+    ins = codeobj.disassemble(k["mangled"])
+    assert len(ins) > 10000
+    runs, cur = [], 0
+    for l in ins:
+        op = l.split()[0]
+        if op.startswith("scratch_"):
+            runs.append(cur)
+            cur = 0
+        elif op.startswith("v_mfma"):
+            cur += 1
+    runs.append(cur)
+    assert sum(runs) % 216 == 0 and sum(runs) >= 4 * 216, sum(runs)
+    assert all(r % 216 == 0 for r in runs), [r for r in runs if r % 216]      # no scratch access splits a phase
+    # LDS-DMA staging: 19 rounds per tile copy, counted waits in front of the barrier that hands the buffer over
+    ndma = sum(1 for l in ins if l.startswith("global_load_lds_dwordx4"))
+    assert ndma > 0 and ndma % 19 == 0, ndma
+    counted = [int(m.group(1)) for l in ins for m in [re.search(r"s_waitcnt.*vmcnt\((\d+)\)", l)] if m]
+    assert any(c >= 15 for c in counted), "no counted vmcnt left: the DMA queue is drained at every wait"

@@ -120,6 +120,34 @@ if f1 and f3:
                      (f"{lds_per:8.2f} " if lds_per is not None else f"{'-':>8s} ") + (f"{conf:5.2f}" if conf is not None else f"{'-':>5s}") + "\n")
         fh.write(f"\nsum of kernel durations: {t1:.1f} us on one stream, {t3:.1f} us summed over the three streams\n")
     print("wrote", f"{pre}_step_kernel_table.txt")
+    # 1c. roofline.step of bench.py: algorithmic FLOPs of every matrix-core convolution kernel of a step / their summed
+    #     one-stream time / the bf16 MFMA peak, and the same per kernel family (with the family's HBM bytes)
+    MFMA_FAMILIES = ("conv_ws2_kernel", "conv_wgrad2_kernel", "conv_igemm_kernel", "conv_wr_kernel", "conv_wgrad_s2_kernel",
+                     "conv_wgrad_kernel", "convt_fused_kernel", "convt_ws_kernel", "conv_gather_s2_kernel", "conv_first_kernel",
+                     "wgrad_first_kernel")
+    fam = defaultdict(lambda: {"us_1s": 0.0, "launches": 0, "hbm_bytes": 0.0})
+    for k, (d, n) in clean.items():
+        for f_ in MFMA_FAMILIES:
+            if k.startswith(f_):
+                fe = pm["FETCH_SIZE"].get(k, {}).get("FETCH_SIZE")
+                wr_ = pm["WRITE_SIZE"].get(k, {}).get("WRITE_SIZE")
+                fam[f_]["us_1s"] += d
+                fam[f_]["launches"] += n
+                if fe and wr_ and fe[0]:
+                    fam[f_]["hbm_bytes"] += (2 * fe[1] + wr_[1]) * 1024 * (n / fe[0])
+                break
+    # SURVEY.md App. B, per sample forward: 14 BasicConv3d 892 G + 4 UpConv 54.4 G + 3 ConvTranspose3d 50.7 G; x3 for
+    # forward + data gradient + weight gradient, minus the first layer's data gradient (14.5 G: it has none), x batch 2
+    gflop = ((892.0 + 54.4 + 50.7) * 3 - 14.5) * 2
+    us = sum(v["us_1s"] for v in fam.values())
+    dom = max(fam.items(), key=lambda kv: kv[1]["us_1s"])[0] if fam else None
+    rec = {"what": "all matrix-core convolution kernels of one training step (4x128^3, batch 2, bf16), one-stream kernel trace",
+           "algorithmic_gflop": gflop, "mfma_kernels_us_one_stream": us, "achieved": gflop / us * 1e-3 if us else None,
+           "peak": 2500.0, "unit": "TFLOP/s", "frac": gflop / us * 1e-3 / 2500.0 if us else None,
+           "dominant_family": dom, "families": {k: v for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["us_1s"])},
+           "conv_source_digest": conv_source_digest()}
+    json.dump(rec, open(os.path.join(dst, f"{pre}_step_roofline.json"), "w"), indent=1)
+    print("roofline.step", rec["frac"], "dominant", dom)
 
 f = one("bench/**/*_kernel_trace.csv")
 if f:

@@ -10,7 +10,7 @@ for v in $VARS; do
 done
 wait
 for v in $VARS; do
-  objs="build/conv_igemm.o build/unet_ops.o build/transformer.o build/transformer_fused.o build/loss.o build/plan.o"
+  objs="build/conv_igemm.o build/conv_first.o build/unet_ops.o build/transformer.o build/transformer_fused.o build/transformer_chain.o build/loss.o build/plan.o"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o lib/libhdf_hip_wr_$v.so $objs build/wr_$v/conv_wr.o
 done
 ls -la lib/
