@@ -644,6 +644,7 @@ struct Exec {
   bool async = false;                           // weight gradients on the side stream
   bool on_branch = false;                       // this Exec issues onto the plan's branch stream (own scratch)
   hipEvent_t last_side = nullptr;               // last event recorded on the side stream in this call
+  hipEvent_t tf_packed = nullptr;               // branch Exec: the persistent transformer kernel's weight copies are ready (forward3d)
   std::map<size_t, hipEvent_t> readers;         // workspace offset of a buffer -> side-stream event after its last reader
   hipEvent_t next_event() {
     if (p->events.size() < 256) {
@@ -929,9 +930,14 @@ int transformer_forward(Exec& e, const float* x) {
   HDF_TRY(tf_patch_embed_fwd(d, x, p->D, p->H, p->W, pm + p->P("attns.0.patch_embeddings.weight"),
                              pm + p->P("attns.0.patch_embeddings.bias"), pm + p->P("attns.0.position_embeddings"), F0,
                              e.st, PE_LP));
-  if (tf_use_chain(p, e.B))   // all layers of all blocks in one persistent launch (transformer_chain.hip)
+  if (tf_use_chain(p, e.B)) {  // all layers of all blocks in one persistent launch (transformer_chain.hip)
+    if (e.tf_packed && hipStreamWaitEvent(e.st, e.tf_packed, 0) != hipSuccess) {
+      hdf_set_error("branch stream: wait failed");
+      return HDF_ERR_HIP;
+    }
     return tf_chain_forward(d, tf_chain_params(p), p->nb, pm, F0, e.f(p->tf_save), e.at(p->attnall),
                             reinterpret_cast<unsigned*>(e.ws + p->tf_sync), e.ws + p->tf_wpack, e.f(p->tf_frag), p->dtype, e.st);
+  }
   // token kernel, attention, token kernel, ...: between two attention launches ONE kernel finishes the previous
   // dense layer (and, at a block boundary, runs the block's out_layer) and starts the next one
   TfLayerP prev{}, cur{};
@@ -1016,12 +1022,13 @@ int transformer_backward(Exec& e, const float* x) {
     HDF_TRY(tf_chain_backward(d, tf_chain_params(p), p->nb, pm, e.grads, F0, e.f(p->tf_save), dF, e.at(p->dAttnall),
                               e.f(p->tf_tape), e.f(p->tf_otape), scratch, e.f(p->tf_frag), e.ws + p->tf_wpack,
                               reinterpret_cast<unsigned*>(e.ws + p->tf_sync) + (1 << 17), p->dtype, e.st));
-    w.b0 = 0;
-    HDF_TRY(tf_wgrad(w, p->nb, p->M, e.wgrad_stream()));
-    HDF_TRY(e.side_done());
+    // (on this stream, not on the side stream: that one still holds the level-0 weight gradients, and tf_wgrad -- HBM-bound,
+    // 110 us -- would run behind them as the last kernel of the step)
     HDF_TRY(tf_patch_embed_bwd(d, x, p->D, p->H, p->W, dF, e.grads + p->P("attns.0.patch_embeddings.weight"),
                                e.grads + p->P("attns.0.patch_embeddings.bias"),
                                e.grads + p->P("attns.0.position_embeddings"), scratch, e.st));
+    w.b0 = 0;
+    HDF_TRY(tf_wgrad(w, p->nb, p->M, e.st));
     return HDF_OK;
   }
   TfLayerP up{}, gup{}, cur{}, gcur{};
@@ -1433,6 +1440,10 @@ static int forward3d(hdf_plan* p, const float* x, const float* params, void* wor
   // the fork sits in front of the weight pack: the token kernels read the fp32 parameters themselves, only the branch's
   // convs (deep_conv, up1..3) wait for the packed panels
   HDF_TRY(hdf_launch_pack_batch(p->dtype, params, e.ws, p->pack_jobs.data(), (int)p->pack_jobs.size(), e.st));
+  // ... and the persistent transformer kernel's fragment-major weight copies: on this stream too, i.e. next to the patch
+  // embedding of the branch stream instead of in front of the chain kernel on its critical path
+  if (tf_use_chain(p, batch))
+    HDF_TRY(tf_chain_pack(tf_dims(p, batch), tf_chain_params(p), p->nb, params, e.ws + p->tf_wpack, e.st));
   hipEvent_t packed = nullptr;
   if (bst) {
     packed = e.next_event();
@@ -1451,6 +1462,7 @@ static int forward3d(hdf_plan* p, const float* x, const float* params, void* wor
   HDF_TRY(hdf_launch_nchw_to_ndhwc(p->dtype, x, e.at(p->xin), batch, p->M, 16, p->vox(0), e.st));
   HDF_TRY(conv_forward(e, p->enc[0][0], p->xin, none));
   HDF_TRY(conv_forward(e, p->enc[0][1], p->enc[0][0].y, xf_of(e, p->enc[0][0])));
+  eb.tf_packed = packed;
   HDF_TRY(transformer_forward(eb, x));
   if (packed && hipStreamWaitEvent(bst, packed, 0) != hipSuccess) {
     hdf_set_error("branch stream: wait failed");

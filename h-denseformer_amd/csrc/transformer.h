@@ -170,10 +170,13 @@ size_t tf_chain_sync_bytes(const TfDims& d);
 size_t tf_chain_wpack_bytes(const TfDims& d, int nb);
 size_t tf_chain_frag_bytes(const TfDims& d, int nb);   // the forward's operand records for the backward (16-bit modes)
 bool tf_chain_backward_supported(const TfDims& d, int dtype);
+// fragment-major copies of every layer's and block's weight matrices for both directions (any stream: it only reads the
+// parameters; tf_chain_forward / tf_chain_backward must be ordered behind it)
+int tf_chain_pack(const TfDims& d, const TfChainP& cp, int nb, const float* params, void* wpack, hipStream_t st);
 // Forward of all nb blocks: reads F0[block 0][:, 0:DM] (the patch embedding), writes every block's feature buffer, the
 // saved tensors of every layer (tf_save layout) and the channels-last attnall tensor.  `sync`: tf_chain_sync_bytes of
 // device memory owned by the caller (zeroed by the call on `st`); `wpack`: tf_chain_wpack_bytes of scratch for the
-// fragment-major copies of the layers' weight matrices (written by a small launch in front of the persistent one).
+// fragment-major copies of the layers' weight matrices (tf_chain_pack).
 int tf_chain_forward(const TfDims& d, const TfChainP& cp, int nb, const float* params, float* F0, float* save,
                      void* attnall, unsigned* sync, void* wpack, float* frag, int dtype, hipStream_t st);
 // Backward of all nb blocks (after the UpConv chain's backward left d(attnall)): every bias / LayerNorm-parameter gradient

@@ -103,7 +103,7 @@ __device__ __forceinline__ TfOutP chain_out(const ChainW& cw, float* base, int b
   return TfOutP{q + cw.ooff[0], q + cw.ooff[1], q + cw.ooff[2], q + cw.ooff[3]};
 }
 
-// grid (layers + blocks, modalities), 256 threads: wave w copies the units u = w (mod 4) of its slot.
+// grid (layers + blocks, modalities, z), 256 threads: wave w of slice z copies the units u = 4 z + w (mod 4 gridDim.z) of its slot.
 // Row fragment (wload): lane (i, g) <- W[n0 + i][g KQ + s0 + 4 j .. + 3]; column fragment (cload): element e of the lane's
 // float4 <- W[g OQ + s0 + 4 j + e][n0 + i].
 __global__ __launch_bounds__(256) void tf_chain_pack_kernel(ChainW cw, const float* __restrict__ params, int64_t mstride,
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void tf_chain_pack_kernel(ChainW cw, const flo
     const float* w0 = chain_w0(cw, const_cast<float*>(params), b, l) + (int64_t)m * mstride;
     const float* rest = w0 + 32 * Kq;
     float4* dst = wpack + ((int64_t)m * nl + L) * (CH_SLOT * 64);
-    for (int u = wave; u < CH_SLOT; u += 4) {
+    for (int u = blockIdx.z * 4 + wave; u < CH_SLOT; u += 4 * gridDim.z) {
       float4 v;
       if (u < CH_W2) {
         v = rowf(rest + CO_WOUT, 32, 16 * ((u - CH_WO) >> 1), 8, 0, (u - CH_WO) & 1);
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void tf_chain_pack_kernel(ChainW cw, const flo
     const float* wb = po.wb + (int64_t)m * mstride;
     float4* dst = wpack + (int64_t)M * nl * (CH_SLOT * 64) + ((int64_t)m * nb + b) * (CO_SLOT * 64);
     const int nja = DMF >> 4, ntb = DM >> 4;
-    for (int u = wave; u < CO_SLOT; u += 4) {
+    for (int u = blockIdx.z * 4 + wave; u < CO_SLOT; u += 4 * gridDim.z) {
       float4 v;
       if (u < OB_F) {
         const int t = u / 24, j = u - t * 24;
@@ -266,8 +266,8 @@ __device__ __forceinline__ float4 ld16_sc1(__amdgpu_buffer_rsrc_t r, uint32_t by
   return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16));
 }
 // arrival: called by the whole workgroup after its payload stores
-__device__ __forceinline__ void chain_arrive(unsigned* cnt) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY storing wave drains its write-through stores
+__device__ __forceinline__ void chain_arrive(unsigned* cnt, bool storing = true) {
+  if (storing) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY storing wave drains its write-through stores
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -1233,28 +1233,38 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
     float* xbase = a.xchg + ((int64_t)par * a.rows + rb + (int64_t)bsm * N) * XW;   // this sequence's rows, this parity
     const __amdgpu_buffer_rsrc_t rx = chain_rsrc(xbase);
     float* xgseq = a.xchg + ((int64_t)par * a.nseq + seq) * a.ntile * 8 * XG_W;    // LP: this sequence's records
+    // The payload is stored by waves 0-3 only (two heads each in the 16-bit modes): waves 4-7 still have the tape stores and
+    // the column-sum atomics of this token phase in flight -- an atomic stays counted in vmcnt for thousands of cycles when
+    // every workgroup of a modality adds to the same 32 words -- and the drain in front of the arrival waits for a storing
+    // wave's WHOLE queue.  (Guideline 16 R1: every STORING wave drains; the others only join the barrier.)
     if (LP) {
       constexpr int L1 = LP ? LP : 1;
-      float* rec = xgseq + ((int64_t)tile * 8 + wave8) * XG_W;   // every wave its head
-      const bool vrow = col < nvalid;
-      __hip_atomic_store(rec + XG_GA + lane, vrow ? s_dO[col * LD32 + wave8 * 4 + g] : 0.f, __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
-      if (lane < 20) {
-        const int c = lane >> 2, gg = lane & 3;
-        float gv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (c < 4) {
+      if (cw) {
 #pragma unroll
-          for (int e = 0; e < 4; e++) gv[e] = 4 * gg + e < nvalid ? s_dO[(4 * gg + e) * LD32 + wave8 * 4 + c] : 0.f;
+        for (int hh = 0; hh < 2; hh++) {
+          const int hd = 2 * wave + hh;
+          float* rec = xgseq + ((int64_t)tile * 8 + hd) * XG_W;
+          const bool vrow = col < nvalid;
+          __hip_atomic_store(rec + XG_GA + lane, vrow ? s_dO[col * LD32 + hd * 4 + g] : 0.f, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+          if (lane < 20) {
+            const int c = lane >> 2, gg = lane & 3;
+            float gv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (c < 4) {
+#pragma unroll
+              for (int e = 0; e < 4; e++) gv[e] = 4 * gg + e < nvalid ? s_dO[(4 * gg + e) * LD32 + hd * 4 + c] : 0.f;
+            }
+            const u32x2 pk = ChainLp<L1>::four(gv[0], gv[1], gv[2], gv[3]);
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(rec + XG_GB) + lane,
+                               (unsigned long long)pk[0] | ((unsigned long long)pk[1] << 32), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+          }
+          if (lane < 16)
+            __hip_atomic_store(a.xchg + (int64_t)2 * a.nseq * a.ntile * 8 * XG_W +
+                                   (((int64_t)par * a.nseq + seq) * 8 + hd) * (a.ntile * TT) + n0 + lane,
+                               lane < nvalid ? -s_dl[lane * 8 + hd] : 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        const u32x2 pk = ChainLp<L1>::four(gv[0], gv[1], gv[2], gv[3]);
-        __hip_atomic_store(reinterpret_cast<unsigned long long*>(rec + XG_GB) + lane,
-                           (unsigned long long)pk[0] | ((unsigned long long)pk[1] << 32), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
       }
-      if (lane < 16)
-        __hip_atomic_store(a.xchg + (int64_t)2 * a.nseq * a.ntile * 8 * XG_W +
-                               (((int64_t)par * a.nseq + seq) * 8 + wave8) * (a.ntile * TT) + n0 + lane,
-                           lane < nvalid ? -s_dl[lane * 8 + wave8] : 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else if (tid < TT * 10) {
       const int row = tid / 10, c4 = (tid - row * 10) * 4;
       if (row < nvalid) {
@@ -1263,7 +1273,7 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
         st16_sc1(rx, (uint32_t)(((n0 + row) * XW + c4) * 4), v);
       }
     }
-    chain_arrive(cnt);
+    chain_arrive(cnt, cw);
     // operands of this head (wave) for the tile's own 16 tokens, requested before the wait (forward launch's data)
     const int head = __builtin_amdgcn_readfirstlane(wave8);   // (uniform: per-wave pointers then live in SGPRs)
     const float* sv = a.save + (int64_t)L * a.rows * 232;
@@ -1697,6 +1707,15 @@ bool tf_chain_supported(const TfDims& d) {
          (int64_t)d.N * 96 * 4 < ((int64_t)1 << 31);
 }
 
+int tf_chain_pack(const TfDims& d, const TfChainP& cp, int nb, const float* params, void* wpack, hipStream_t st) {
+  ChainW w{};
+  HDF_CHECK_ARG(chain_digest(cp, d.DM, w), "transformer chain: irregular parameter layout");
+  hipLaunchKernelGGL(tf_chain_pack_kernel, dim3(nb * 4 + nb, d.M, 8), dim3(256), 0, st, w, params, d.mstride, d.DM, nb * 4,
+                     reinterpret_cast<float4*>(wpack));
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
 int tf_chain_forward(const TfDims& d, const TfChainP& cp, int nb, const float* params, float* F0, float* save,
                      void* attnall, unsigned* sync, void* wpack, float* frag, int dtype, hipStream_t st) {
   HDF_CHECK_ARG(tf_chain_supported(d), "transformer chain: shape not supported (M %d B %d N %d DM %d)", d.M, d.B, d.N, d.DM);
@@ -1714,9 +1733,6 @@ int tf_chain_forward(const TfDims& d, const TfChainP& cp, int nb, const float* p
     hdf_set_error("transformer chain: hipMemsetAsync failed: %s", hipGetErrorString(e));
     return HDF_ERR_HIP;
   }
-  hipLaunchKernelGGL(tf_chain_pack_kernel, dim3(nb * 4 + nb, d.M), dim3(256), 0, st, a.cw, params, d.mstride, d.DM, nb * 4,
-                     reinterpret_cast<float4*>(wpack));
-  HDF_LAUNCH_CHECK();
   const dim3 grid(a.nseq * a.ntile);
   if (d.training) {
     HDF_TRY(chain_allow_lds(tf_chain_fwd_kernel<true>, shm));

@@ -4,7 +4,7 @@
 # usage: bash tools/chain_trace.sh
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/chain_trace
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for v in chain launches; do
   if [ $v = launches ]; then export HDF_NO_TF_CHAIN=1; else unset HDF_NO_TF_CHAIN; fi
@@ -16,8 +16,8 @@ done
 unset HDF_NO_TF_CHAIN
 cd $REPO
 for v in chain launches; do
-  f=$(find $OUT/${v}_1s -name "*kernel_stats.csv" | head -1)
+  f=$(ls -t $(find $OUT/${v}_1s -name "*kernel_stats.csv") | head -1)
   echo "== $v one stream"; grep -i "tf_chain\|tok_\|attn_\|tf_wgrad\|patch" $f | awk -F, '{print $1, $2, $3, $4}' | head -20
-  t=$(find $OUT/${v}_3s -name "*kernel_trace.csv" | head -1)
+  t=$(ls -t $(find $OUT/${v}_3s -name "*kernel_trace.csv") | head -1)
   echo "== $v three streams"; python3 tools/branch_timeline.py $t | tail -12
 done
