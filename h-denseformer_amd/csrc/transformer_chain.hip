@@ -279,8 +279,13 @@ __device__ __forceinline__ void chain_wait(unsigned* cnt, unsigned target, unsig
     while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(2);
       if (__builtin_amdgcn_s_memrealtime() - t_start > 150000000ull) {   // 1.5 s at 100 MHz
+        // a sibling never arrived (the grid was not resident together for 1.5 s: the device is shared with something that
+        // holds its compute units): leave the word for the tests' diagnostics and ABORT the launch -- the results would be
+        // wrong, and nothing on the product path reads the word; a trapped kernel surfaces as a HIP error at the caller's
+        // next synchronisation
         __hip_atomic_store(tmo, 1u + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         dead = true;
+        __builtin_trap();
         break;
       }
     }
@@ -1238,32 +1243,38 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
     // every workgroup of a modality adds to the same 32 words -- and the drain in front of the arrival waits for a storing
     // wave's WHOLE queue.  (Guideline 16 R1: every STORING wave drains; the others only join the barrier.)
     if (LP) {
+      // the 8 records of the tile (XG_GA | XG_GB) and its 8 x 16 -delta values are assembled in LDS by all waves (s_f is free
+      // here) and leave as ONE 16-byte write-through store per lane of waves 0-3 (4-byte sc1 stores are one fabric write
+      // each: ~6x the time per byte of 16-byte ones)
       constexpr int L1 = LP ? LP : 1;
-      if (cw) {
+      float* s_rec = s_f;                       // [8][XG_W]: GA (64) | GB (40 words) | -delta (16) | pad
+      {
+        const int hd = wave8;
+        float* rec = s_rec + hd * XG_W;
+        const bool vrow = col < nvalid;
+        rec[XG_GA + lane] = vrow ? s_dO[col * LD32 + hd * 4 + g] : 0.f;
+        if (lane < 20) {
+          const int c = lane >> 2, gg = lane & 3;
+          float gv[4] = {0.f, 0.f, 0.f, 0.f};
+          if (c < 4) {
 #pragma unroll
-        for (int hh = 0; hh < 2; hh++) {
-          const int hd = 2 * wave + hh;
-          float* rec = xgseq + ((int64_t)tile * 8 + hd) * XG_W;
-          const bool vrow = col < nvalid;
-          __hip_atomic_store(rec + XG_GA + lane, vrow ? s_dO[col * LD32 + hd * 4 + g] : 0.f, __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
-          if (lane < 20) {
-            const int c = lane >> 2, gg = lane & 3;
-            float gv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (c < 4) {
-#pragma unroll
-              for (int e = 0; e < 4; e++) gv[e] = 4 * gg + e < nvalid ? s_dO[(4 * gg + e) * LD32 + hd * 4 + c] : 0.f;
-            }
-            const u32x2 pk = ChainLp<L1>::four(gv[0], gv[1], gv[2], gv[3]);
-            __hip_atomic_store(reinterpret_cast<unsigned long long*>(rec + XG_GB) + lane,
-                               (unsigned long long)pk[0] | ((unsigned long long)pk[1] << 32), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+            for (int e = 0; e < 4; e++) gv[e] = 4 * gg + e < nvalid ? s_dO[(4 * gg + e) * LD32 + hd * 4 + c] : 0.f;
           }
-          if (lane < 16)
-            __hip_atomic_store(a.xchg + (int64_t)2 * a.nseq * a.ntile * 8 * XG_W +
-                                   (((int64_t)par * a.nseq + seq) * 8 + hd) * (a.ntile * TT) + n0 + lane,
-                               lane < nvalid ? -s_dl[lane * 8 + hd] : 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          reinterpret_cast<u32x2*>(rec + XG_GB)[lane] = ChainLp<L1>::four(gv[0], gv[1], gv[2], gv[3]);
         }
+        if (lane < 16) rec[XG_GB + 40 + lane] = lane < nvalid ? -s_dl[lane * 8 + hd] : 0.f;
+      }
+      __syncthreads();
+      if (tid < 8 * 26) {          // GA | GB of head tid / 26: 104 floats = 26 pieces
+        const int hd = tid / 26, pc = tid - hd * 26;
+        const __amdgpu_buffer_rsrc_t rr = chain_rsrc(xgseq + (int64_t)tile * 8 * XG_W);
+        st16_sc1(rr, (uint32_t)((hd * XG_W + 4 * pc) * 4), *reinterpret_cast<const float4*>(s_rec + hd * XG_W + 4 * pc));
+      } else if (tid < 8 * 26 + 32) {   // -delta rows of the 8 heads: 4 pieces each, head-major [parity][sequence][head][NP]
+        const int i = tid - 8 * 26, hd = i >> 2, pc = i & 3;
+        const __amdgpu_buffer_rsrc_t rr = chain_rsrc(a.xchg + (int64_t)2 * a.nseq * a.ntile * 8 * XG_W +
+                                                     ((int64_t)par * a.nseq + seq) * 8 * (a.ntile * TT));
+        st16_sc1(rr, (uint32_t)((hd * (a.ntile * TT) + n0 + 4 * pc) * 4),
+                 *reinterpret_cast<const float4*>(s_rec + hd * XG_W + XG_GB + 40 + 4 * pc));
       }
     } else if (tid < TT * 10) {
       const int row = tid / 10, c4 = (tid - row * 10) * 4;
@@ -1273,7 +1284,8 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
         st16_sc1(rx, (uint32_t)(((n0 + row) * XW + c4) * 4), v);
       }
     }
-    chain_arrive(cnt, cw);
+    // (the forward launch's operands of the attention backward are requested BEFORE the drain: their round trip passes under
+    // the write-through stores')
     // operands of this head (wave) for the tile's own 16 tokens, requested before the wait (forward launch's data)
     const int head = __builtin_amdgcn_readfirstlane(wave8);   // (uniform: per-wave pointers then live in SGPRs)
     const float* sv = a.save + (int64_t)L * a.rows * 232;
@@ -1306,6 +1318,7 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
 #pragma unroll
       for (int k = 0; k < NLS; k++) r_ls[k] = *reinterpret_cast<const float4*>(lsrow + min((k * 64 + lane) * 4, NPq - 4));
     }
+    chain_arrive(cnt, cw);
     CHAIN_STAMPB(5);
     chain_wait(cnt, (unsigned)(a.ntile * (nl - L)), tmo, dead);
     CHAIN_STAMPB(6);
