@@ -142,8 +142,8 @@ if f1 and f3:
     us = sum(v["us_1s"] for v in fam.values())
     dom = max(fam.items(), key=lambda kv: kv[1]["us_1s"])[0] if fam else None
     rec = {"what": "all matrix-core convolution kernels of one training step (4x128^3, batch 2, bf16), one-stream kernel trace",
-           "algorithmic_gflop": gflop, "mfma_kernels_us_one_stream": us, "achieved": gflop / us * 1e-3 if us else None,
-           "peak": 2500.0, "unit": "TFLOP/s", "frac": gflop / us * 1e-3 / 2500.0 if us else None,
+           "algorithmic_gflop": gflop, "mfma_kernels_us_one_stream": us, "achieved": gflop / us * 1e3 if us else None,
+           "peak": 2500.0, "unit": "TFLOP/s", "frac": gflop / us * 1e3 / 2500.0 if us else None,
            "dominant_family": dom, "families": {k: v for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["us_1s"])},
            "conv_source_digest": conv_source_digest()}
     json.dump(rec, open(os.path.join(dst, f"{pre}_step_roofline.json"), "w"), indent=1)
