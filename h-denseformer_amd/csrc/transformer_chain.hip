@@ -1320,7 +1320,8 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
     }
     chain_arrive(cnt, cw);
     CHAIN_STAMPB(5);
-    chain_wait(cnt, (unsigned)(a.ntile * (nl - L)), tmo, dead);
+    // (no wait here: the dQ half needs only this tile's own dO and the forward launch's k / v -- the hand-off's latency
+    // passes under it; the wait sits in front of the dK / dV half, the first reader of the siblings' records)
     CHAIN_STAMPB(6);
 
     // ------------------------------------------------------------------ attention backward of layer L: head = wave
@@ -1334,9 +1335,6 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
       float* s_dlq = s_ls + NP;
       const __amdgpu_buffer_rsrc_t rdl = chain_rsrc(a.xchg + (int64_t)2 * a.nseq * a.ntile * 8 * XG_W +
                                                     (((int64_t)par * a.nseq + seq) * 8 + head) * NP);
-      float4 r_dl[NLS];
-#pragma unroll
-      for (int k = 0; k < NLS; k++) r_dl[k] = ld16_sc1(rdl, (uint32_t)(min((k * 64 + lane) * 4, NP - 4) * 4));
       // ---- dQ of the tile's queries
       {
         const float delta = s_dl[col * 8 + head];
@@ -1378,12 +1376,18 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
         for (int r = 0; r < 4; r++)
           if (col < 4) s_dq[(4 * g + r) * 100 + head * 4 + col] = (4 * g + r < nvalid) ? 0.5f * acc[r] : 0.f;
       }
+      chain_wait(cnt, (unsigned)(a.ntile * (nl - L)), tmo, dead);
+      {
+        float4 r_dl[NLS];
 #pragma unroll
-      for (int k = 0; k < NLS; k++) {
-        const int i4 = (k * 64 + lane) * 4;
-        if (i4 < NP) {
-          *reinterpret_cast<float4*>(s_ls + i4) = r_ls[k];
-          *reinterpret_cast<float4*>(s_dlq + i4) = r_dl[k];
+        for (int k = 0; k < NLS; k++) r_dl[k] = ld16_sc1(rdl, (uint32_t)(min((k * 64 + lane) * 4, NP - 4) * 4));
+#pragma unroll
+        for (int k = 0; k < NLS; k++) {
+          const int i4 = (k * 64 + lane) * 4;
+          if (i4 < NP) {
+            *reinterpret_cast<float4*>(s_ls + i4) = r_ls[k];
+            *reinterpret_cast<float4*>(s_dlq + i4) = r_dl[k];
+          }
         }
       }
       CHAIN_STAMPB(7);
@@ -1526,6 +1530,7 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
                 rvalid ? make_float4(0.5f * d01.x, 0.5f * d01.y, 0.5f * d23.x, 0.5f * d23.y) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
+      chain_wait(cnt, (unsigned)(a.ntile * (nl - L)), tmo, dead);
       CHAIN_STAMPB(7);
       // ---- dK, dV of the tile's keys: q | dO chunks (image rows of QP floats), (lse, delta) per head as [8][QC] arrays
       {
