@@ -1139,6 +1139,7 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
           s_dg[lrow * LD32 + lc + 1] = ok ? dcur1 * dr.mask(site0 + 2 + 2 * pass, (uint32_t)t * 32 + lc + 1) : 0.f;
         }
         __syncthreads();
+        if (pass == 1) CHAIN_STAMPB(9);
         if (cw) {
           f32x4 accz = zero4(), accd = zero4();
           wmma(accz, f_w1, s_b, LD32, 8, 0, 2);            // z = W1 u  (tile wave)
@@ -1154,6 +1155,7 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
           }
         }
         __syncthreads();
+        if (pass == 1) CHAIN_STAMPB(10);
         f32x4 accu = zero4();
         if (!cw) {
           const int c0 = pass ? TF_T_P1 : TF_T_P0;
@@ -1172,18 +1174,21 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
           }
         }
         __syncthreads();
+        if (pass == 1) CHAIN_STAMPB(11);
         if (cw && wave < 2) {
 #pragma unroll
           for (int r = 0; r < 4; r++)
             s_e[(4 * g + r) * LD32 + 16 * wave + col] = accu[r] + s_red[(wave * 16 + 4 * g + r) * 16 + col];
         }
         __syncthreads();
+        if (pass == 1) CHAIN_STAMPB(12);
         float dh0v = 0.f, dh1v = 0.f;
         if (cw) {
           ln32_bwd(s_e, s_c, s_gx, rs, ln2, dh0v, dh1v);
           dh0v = ok ? dh0v : 0.f, dh1v = ok ? dh1v : 0.f;
         }
         __syncthreads();
+        if (pass == 1) CHAIN_STAMPB(13);
         if (!cw) {
           colsum_h(gp.ln2g, 32, s_gx, LD32, 0);
           colsum_h(gp.ln2b, 32, s_e, LD32, 64);
@@ -1205,6 +1210,7 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
         r_acc0 = dres0, r_acc1 = dres1;   // -> PREB of this layer, after its attention backward
       }
       __syncthreads();
+      CHAIN_STAMPB(14);
       f32x4 acco = zero4();
       if (!cw) {
         tape_h(tape_p, TF_T_DGO, s_dg, LD32, 32);
@@ -1223,6 +1229,7 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
           s_dO[(4 * g + r) * LD32 + 16 * wave + col] = acco[r] + s_red[(wave * 16 + 4 * g + r) * 16 + col];
       }
       __syncthreads();
+      CHAIN_STAMPB(15);
       // delta = dO . ob per (token, head): attn_bwd's arithmetic (tf_dot4)
       if (tid < TT * 8) {
         const int row = tid >> 3, h = tid & 7;

@@ -26,6 +26,9 @@ if which == "bwd":
     tot = st[:, 0, 2] - st[:, nl, 0]
     print("kernel span per workgroup: median %.1f us, max %.1f us" % (tot.median(), tot.max()))
     PHB = [("requests issued -> barrier", 0, 1), ("PREB", 1, 2), ("OUTB (block boundaries only)", 2, 3), ("POSTB", 3, 4),
+           ("  POSTB pass 1: LN keep + mask", 3, 9), ("  pass 1: two GEMMs + GELU epilogue", 9, 10), ("  pass 1: du GEMM (+ side outputs)", 10, 11),
+           ("  pass 1: reduce", 11, 12), ("  pass 1: LN backward", 12, 13), ("  pass 0 (whole)", 13, 14),
+           ("  to_out: dg, wgrad operands, dO GEMM", 14, 15), ("  to_out: reduce, delta", 15, 4),
            ("publish", 4, 5), ("poll", 5, 6), ("attention dQ half", 6, 7), ("attention dK/dV half", 7, 8)]
     R = torch.arange(2, nl - 1)
     inner = R[((R - 1) % 4) != 3]
