@@ -395,9 +395,7 @@ __global__ __launch_bounds__(256) void wgrad_first_kernel(WgradFirstArgs a) {
         ST<T>::unpack(pfy[j], f);
 #pragma unroll
         for (int e = 0; e < 8; e++) {
-          const float gg = (f[e] * xsc[e] + xsh[e] > 0.f) ? g[e] : 0.f;
-          const float xh = (f[e] - xmu[e]) * xrs[e];
-          g[e] = xk1[e] * (gg - xka[e] - xh * xkb[e]);
+          g[e] = in_bwd_elem(g[e], f[e], xsc[e], xsh[e], xmu[e], xrs[e], xk1[e], xka[e], xkb[e]);
         }
         v = ST<T>::pack(g);
       }

@@ -60,7 +60,19 @@ struct WgradArgs {
   float* partials;  // [G][27][SCp][LCp]
   int SCp, LCp;
   int tiles_per_group, num_tiles;
+  // Fused InstanceNorm(+ReLU) backward (optional; 16-bit stride-1 launches that hdf_wgrad_apply_takes accepts): `sm` is then
+  // the gradient w.r.t. the layer's ACTIVATION relu(IN(y)), and the kernel applies the second pass of that norm's backward
+  // (in_bwd_elem, hdf_common.h: the arithmetic and storage rounding of hdf_launch_in_bwd_apply) to the rows it stages --
+  // every voxel of the small operand is staged exactly once per (small, large) channel-block pair -- and the workgroups of
+  // large-channel block 0 store the result to ap_out: the dy the data-gradient conv reads afterwards.  The stand-alone
+  // pass (read da, read y, write dy: three tensors through HBM at its roof) and the weight gradient's own read of dy go.
+  const void* ap_y = nullptr;  // raw conv output of the layer, [N][vox][ap_y_pitch]
+  int64_t ap_y_pitch = 0;
+  void* ap_out = nullptr;  // dy, [N][vox][ap_out_pitch]
+  int64_t ap_out_pitch = 0;
+  const float* ap_tab[7] = {};  // scale, shift, mean, rstd, k1, ka, kb: [N][SC] each
 };
+bool hdf_wgrad_apply_takes(int dtype, int stride, const WgradArgs& a);
 
 // conv_wr.hip: weights-in-registers form of the mode-0 launches with 64- / 128-byte rows at >= 48^3 (16-bit storage)
 // csrc/conv_first.hip: the encoder's first layer (1..4 real input channels, 16-bit storage) with tap-packed K.  Reads the

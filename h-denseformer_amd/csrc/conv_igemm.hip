@@ -1483,7 +1483,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 // under the MFMAs (T0, buffer PAR) is read with a one-k-step look-ahead while, in the gaps of the same stream,
 // tile T1 goes registers -> (InstanceNorm/ReLU) -> the other buffer and tile T2's loads refill the registers.
 // One barrier per tile; slot offsets are per-thread constants; tile coordinates advance incrementally.
-template <typename T, bool XFL>
+// AP (WgradArgs::ap_*): the small operand arrives as d(activation); its InstanceNorm(+ReLU) backward is applied on the way
+// into LDS (in_bwd_elem) from a second staged stream (the layer's raw output y), and the rows leave for ap_out as well.
+template <typename T, bool XFL, bool AP = false>
 __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
   static_assert(sizeof(T) == 2, "16-bit storage only");
   constexpr int TD = 4, TH = 8, TW = 8, MT = TD * TH * TW, BD = TD + 2, BH = TH + 2, BW = TW + 2, BOXL = BD * BH * BW;
@@ -1495,8 +1497,9 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
   constexpr int KS = MT / 16, NT = 7;  // k-steps per tile, taps per wave (7,7,7,6 + one dummy)
   constexpr int PD = 6, NPF = PD + 1;  // a slot's global load is issued PD k-steps before its commit; register ring
   static_assert(NSLOT + 2 <= KS && NSLOT >= PD, "slot schedule: commits at k-steps 0..NSLOT-1, loads PD steps ahead");
-  __shared__ __attribute__((aligned(256))) char lds[2 * BUF + 256];
+  __shared__ __attribute__((aligned(256))) char lds[2 * BUF + 256 + (AP ? 7 * 32 * 4 : 0)];
   float* const s_xf = reinterpret_cast<float*>(lds + 2 * BUF);  // [32 scale][32 shift] of the large operand
+  float* const s_ap = reinterpret_cast<float*>(lds + 2 * BUF + 256);  // AP: [7][32] constants of the small operand's block
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int scb = blockIdx.y, lcb = blockIdx.z;
@@ -1543,6 +1546,22 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
   };
   const bool sc_ok = scb * 32 + part * EPC < a.SC, lc_ok = lcb * 32 + part * EPC < a.LC;
   const bool chan_all = (a.SC % 32 == 0) && (a.LC % 32 == 0);
+  // AP: y is read and dy written through buffer descriptors with 32-bit byte offsets (launcher: both tensors < 2 GiB); an
+  // offset with bit 31 set is out of range -- such a load returns 0 and such a store is dropped, so neither is ever
+  // branched around.  Slot s of a tile: tile offset (uniform) + v0 offset + s planes.
+  constexpr uint32_t AP_OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t ap_ry =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(AP ? a.ap_y : nullptr), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ap_ro = __builtin_amdgcn_make_buffer_rsrc(AP ? a.ap_out : nullptr, 0, 0x7fffffff, 0x00020000);
+  const uint32_t ap_yv0 = AP ? (uint32_t)(((s_by * a.Ws + s_bx) * (int)a.ap_y_pitch + scb * 32 + part * EPC) * 2) : 0u;
+  const uint32_t ap_yplane = AP ? (uint32_t)(a.Hs * a.Ws * (int)a.ap_y_pitch * 2) : 0u;
+  const uint32_t ap_ov0 = AP ? (uint32_t)(((s_by * a.Ws + s_bx) * (int)a.ap_out_pitch + scb * 32 + part * EPC) * 2) : 0u;
+  const uint32_t ap_oplane = AP ? (uint32_t)(a.Hs * a.Ws * (int)a.ap_out_pitch * 2) : 0u;
+  auto ap_tile_vox = [&](const WsTile& c) { return (uint32_t)(((c.n * a.Ds + c.z0) * a.Hs + c.y0) * a.Ws + c.x0); };
+  auto ap_ty_of = [&](const WsTile& c, bool valid) { return valid ? ap_tile_vox(c) * (uint32_t)a.ap_y_pitch * 2u : AP_OOB; };
+  auto ap_to_of = [&](const WsTile& c, bool valid) {  // only the workgroups of large-channel block 0 store
+    return (valid && lcb == 0) ? ap_tile_vox(c) * (uint32_t)a.ap_out_pitch * 2u : AP_OOB;
+  };
   const T* const s_safe = reinterpret_cast<const T*>(a.sm);
   const T* const l_safe = reinterpret_cast<const T*>(a.lg);
   const T* const s_src = s_safe + scb * 32 + part * EPC;
@@ -1639,15 +1658,21 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
   };
 
   u32x4 pf[NPF];  // slot s lives in pf[s % NPF] from its load to its commit PD k-steps later
+  u32x4 py[AP ? NS_ : 1];  // AP: the y chunk of small slot s, requested together with its d(activation) chunk
   // unconditional loads from a clamped address (never branch around a load)
-  auto load_one = [&](auto fast_tag, int s, const WsTile& c, bool valid, const T* sorg, const T* lorg) {
+  // ty (AP): byte offset of the tile's first voxel in y, or AP_OOB for a tile past the end of the list
+  auto load_one = [&](auto fast_tag, int s, const WsTile& c, bool valid, const T* sorg, const T* lorg, uint32_t ty) {
     const T* org = (s < NS_) ? sorg : lorg;
     if constexpr (decltype(fast_tag)::value) {
       pf[s % NPF] = *reinterpret_cast<const u32x4*>(org + goff(s));
+      if constexpr (AP)
+        if (s < NS_) py[s] = __builtin_amdgcn_raw_buffer_load_b128(ap_ry, ty + ap_yv0 + s * ap_yplane, 0, 0);
     } else {
       const bool ok = valid & slot_ok(s, c);
       const T* p = ok ? org + goff(s) : ((s < NS_) ? s_safe : l_safe);
       pf[s % NPF] = *reinterpret_cast<const u32x4*>(p);
+      if constexpr (AP)
+        if (s < NS_) py[s] = __builtin_amdgcn_raw_buffer_load_b128(ap_ry, ok ? ty + ap_yv0 + s * ap_yplane : AP_OOB, 0, 0);
     }
   };
   float sc[EPC], sh[EPC];
@@ -1663,7 +1688,23 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
       }
     }
   };
-  auto commit_one = [&](auto fast_tag, int s, const WsTile& c, char* dst) {
+  // AP: the seven constants of this thread's 8 channels, re-read from s_ap at the top of every tile (56 registers that live
+  // for the four small-slot commits only)
+  float apk[AP ? 7 : 1][EPC];
+  auto read_ap = [&]() {
+    if constexpr (AP) {
+#pragma unroll
+      for (int k = 0; k < 7; k++)
+#pragma unroll
+        for (int e = 0; e < EPC; e += 4) {
+          const f32x4 u = *reinterpret_cast<const f32x4*>(s_ap + k * 32 + part * EPC + e);
+#pragma unroll
+          for (int i = 0; i < 4; i++) apk[k][e + i] = u[i];
+        }
+    }
+  };
+  // to (AP): byte offset of the tile's first voxel in ap_out, or AP_OOB (tile past the end / not this workgroup's to store)
+  auto commit_one = [&](auto fast_tag, int s, const WsTile& c, char* dst, uint32_t to) {
     u32x4 v = pf[s % NPF];
     if constexpr (XFL) {
       if (s >= NS_) {
@@ -1674,23 +1715,45 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
         v = ST<T>::pack(f);
       }
     }
+    if constexpr (AP) {
+      if (s < NS_) {
+        float g[EPC], f[EPC];
+        ST<T>::unpack(v, g);
+        ST<T>::unpack(py[s < NS_ ? s : 0], f);
+#pragma unroll
+        for (int e = 0; e < EPC; e++)
+          g[e] = in_bwd_elem(g[e], f[e], apk[0][e], apk[1][e], apk[2][e], apk[3][e], apk[4][e], apk[5][e], apk[6][e]);
+        v = ST<T>::pack(g);
+      }
+    }
+    bool ok = true;
     if constexpr (!decltype(fast_tag)::value) {
-      const bool ok = slot_ok(s, c);
+      ok = slot_ok(s, c);
 #pragma unroll
       for (int k = 0; k < 4; k++) v[k] = ok ? v[k] : 0u;
     }
     *reinterpret_cast<u32x4*>(dst + woff(s)) = v;
+    if constexpr (AP)
+      if (s < NS_) __builtin_amdgcn_raw_buffer_store_b128(v, ap_ro, ok ? to + ap_ov0 + s * ap_oplane : AP_OOB, 0, 0);
   };
   int tbl_n = -1;
-  auto refresh_xf = [&](int n) {  // uniform; nobody reads the old table any more (its values live in sc/sh)
-    if (tid < 32) {
-      const int c = min(lcb * 32 + tid, a.LC - 1);
-      s_xf[tid] = a.lg_scale[(int64_t)n * a.LC + c];
-      s_xf[32 + tid] = a.lg_shift[(int64_t)n * a.LC + c];
+  auto refresh_xf = [&](int n) {  // uniform; nobody reads the old tables any more (sc/sh hold theirs; apk is per tile)
+    if constexpr (XFL) {
+      if (tid < 32) {
+        const int c = min(lcb * 32 + tid, a.LC - 1);
+        s_xf[tid] = a.lg_scale[(int64_t)n * a.LC + c];
+        s_xf[32 + tid] = a.lg_shift[(int64_t)n * a.LC + c];
+      }
+    }
+    if constexpr (AP) {
+      if (tid >= 32) {
+        const int i = tid - 32, k = i >> 5, c = min(scb * 32 + (i & 31), a.SC - 1);
+        s_ap[i] = a.ap_tab[k][(int64_t)n * a.SC + c];
+      }
     }
     tbl_n = n;
     __syncthreads();
-    read_xf();
+    if constexpr (XFL) read_xf();
   };
 
   f32x16 acc[NT];
@@ -1707,6 +1770,7 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
     WsTile T0, T1, T2;
     bool v1 = false, v2 = false;
     const T *so1 = s_safe, *lo1 = l_safe, *so2 = s_safe, *lo2 = l_safe;
+    uint32_t ty1 = AP_OOB, ty2 = AP_OOB, to1 = AP_OOB, to2 = AP_OOB;  // AP: tile offsets in y / ap_out (see load_one, commit_one)
     int left = 0, par = 0;
     // start a pass at its k-th tile: T0 -> buffer 0 (not overlapped, NPF slots at a time), first PD slots of T1 ->
     // registers
@@ -1734,18 +1798,21 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
       lo2 = v2 ? l_org_of(T2) : l_safe;
       const T* so0 = s_org_of(T0);
       const T* lo0 = l_org_of(T0);
+      ty1 = ap_ty_of(T1, v1), ty2 = ap_ty_of(T2, v2);
+      to1 = ap_to_of(T1, v1), to2 = ap_to_of(T2, v2);
       __syncthreads();  // the previous pass is done with both buffers
       par = 0;
-      if constexpr (XFL) refresh_xf(T0.n);
+      if constexpr (XFL || AP) refresh_xf(T0.n);
+      read_ap();
 #pragma unroll
       for (int s0 = 0; s0 < NSLOT; s0 += NPF) {
 #pragma unroll
-        for (int s = s0; s < s0 + NPF && s < NSLOT; s++) load_one(std::false_type{}, s, T0, true, so0, lo0);
+        for (int s = s0; s < s0 + NPF && s < NSLOT; s++) load_one(std::false_type{}, s, T0, true, so0, lo0, ap_ty_of(T0, true));
 #pragma unroll
-        for (int s = s0; s < s0 + NPF && s < NSLOT; s++) commit_one(std::false_type{}, s, T0, lds);
+        for (int s = s0; s < s0 + NPF && s < NSLOT; s++) commit_one(std::false_type{}, s, T0, lds, ap_to_of(T0, true));
       }
 #pragma unroll
-      for (int s = 0; s < PD; s++) load_one(std::false_type{}, s, T1, v1, so1, lo1);
+      for (int s = 0; s < PD; s++) load_one(std::false_type{}, s, T1, v1, so1, lo1, ty1);
       WS_BARRIER();
     };
 
@@ -1765,9 +1832,10 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
       int lBw[NT];
 #pragma unroll
       for (int j = 0; j < NT; j++) lBw[j] = lB[j] + par * BUF;
-      if constexpr (XFL) {
+      if constexpr (XFL || AP) {
         if (v1 && T1.n != tbl_n) refresh_xf(T1.n);
       }
+      read_ap();
       WS2_STAMP(0)
       // B fragments: ONE register set, re-read for k-step ks+1 right behind the MFMA that consumed them (the arch
       // VGPR file is 256 deep: a second set pushed the staging ring into AGPR/scratch spills); A: two sets
@@ -1789,11 +1857,11 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
         if (ks + 1 < KS) read_a(ks + 1);
         // staging: commit slot ks of T1; load the slot that commits PD k-steps from now (T1's, or T2's when that
         // falls into the next tile phase)
-        if (ks < NSLOT) commit_one(fast_tag, ks, T1, a_wr);
+        if (ks < NSLOT) commit_one(fast_tag, ks, T1, a_wr, to1);
         if (ks + PD < NSLOT)
-          load_one(fast_tag, ks + PD, T1, v1, so1, lo1);
+          load_one(fast_tag, ks + PD, T1, v1, so1, lo1, ty1);
         else if (ks + PD >= KS)
-          load_one(fast_tag, ks + PD - KS, T2, v2, so2, lo2);
+          load_one(fast_tag, ks + PD - KS, T2, v2, so2, lo2, ty2);
         const u32x4 af = {A0[ks & 1][0], A0[ks & 1][1], A1[ks & 1][0], A1[ks & 1][1]};
 #pragma unroll
         for (int j = 0; j < NT; j++) {
@@ -1824,6 +1892,7 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
       v1 = v2;
       so1 = so2;
       lo1 = lo2;
+      ty1 = ty2, to1 = to2;
       if constexpr (BORDER)
         bor_next(T2);
       else
@@ -1831,6 +1900,7 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
       v2 = left >= 2;
       so2 = v2 ? s_org_of(T2) : s_safe;
       lo2 = v2 ? l_org_of(T2) : l_safe;
+      ty2 = ap_ty_of(T2, v2), to2 = ap_to_of(T2, v2);
     };
     if (int_cnt > 0) {  // interior pass: the unchecked copy, one run (its own back edge: nothing drained per tile)
       begin_pass(std::false_type{}, int_begin, int_cnt);
@@ -2897,7 +2967,12 @@ int launch_wgrad_t(WgradArgs a, float* dw, int sc_store, int lc_store, int accum
   }
   if constexpr (sizeof(T) == 2 && S == 1) {
     if (use_new) {
-      if (a.lg_scale)
+      if (a.ap_y) {
+        if (a.lg_scale)
+          hipLaunchKernelGGL((conv_wgrad2_kernel<T, true, true>), grid, dim3(256), 0, st, a);
+        else
+          hipLaunchKernelGGL((conv_wgrad2_kernel<T, false, true>), grid, dim3(256), 0, st, a);
+      } else if (a.lg_scale)
         hipLaunchKernelGGL((conv_wgrad2_kernel<T, true>), grid, dim3(256), 0, st, a);
       else
         hipLaunchKernelGGL((conv_wgrad2_kernel<T, false>), grid, dim3(256), 0, st, a);
@@ -2973,11 +3048,26 @@ size_t hdf_wgrad_workspace_bytes(int stride, int N, int Ds, int Hs, int Ws, int 
   return (size_t)bytes;
 }
 
+// the launches conv_wgrad2_kernel<., ., true> serves: 16-bit storage, stride 1, untransformed small operand, 16-byte rows
+// on both extra tensors, and 32-bit byte offsets into them with bit 31 free for the out-of-range marker
+bool hdf_wgrad_apply_takes(int dtype, int stride, const WgradArgs& a) {
+  if (hdf_esz(dtype) != 2 || stride != 1 || a.sm_scale || !a.ap_y || !a.ap_out) return false;
+  for (int k = 0; k < 7; k++)
+    if (!a.ap_tab[k]) return false;
+  const int64_t vox = (int64_t)a.N * a.Ds * a.Hs * a.Ws;
+  if (vox * a.ap_y_pitch * 2 >= (1ll << 31) || vox * a.ap_out_pitch * 2 >= (1ll << 31)) return false;
+  if (a.ap_y_pitch % 8 || a.ap_out_pitch % 8 || a.SC % 16) return false;
+  if ((reinterpret_cast<uintptr_t>(a.ap_y) | reinterpret_cast<uintptr_t>(a.ap_out)) & 15) return false;
+  return a.Ds == a.Dl && a.Hs == a.Hl && a.Ws == a.Wl;
+}
+
 int hdf_launch_wgrad(int dtype, int stride, WgradArgs a, float* dw, int sc_store, int lc_store, int accumulate,
                      void* workspace, size_t workspace_bytes, hipStream_t st) {
   HDF_CHECK_ARG(a.SC % 16 == 0 && a.LC % 16 == 0, "wgrad: channel counts must be multiples of 16 (SC=%d LC=%d)", a.SC,
                 a.LC);
   HDF_CHECK_ARG(stride == 1 || stride == 2, "wgrad: stride %d", stride);
+  HDF_CHECK_ARG(!a.ap_y || hdf_wgrad_apply_takes(dtype, stride, a),
+                "wgrad: the fused InstanceNorm backward does not take this launch (ask hdf_wgrad_apply_takes first)");
   HDF_DISPATCH_T(dtype, {
     if (stride == 1)
       return launch_wgrad_t<T, 4, 8, 8, 1>(a, dw, sc_store, lc_store, accumulate, workspace, workspace_bytes, st);

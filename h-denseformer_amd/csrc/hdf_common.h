@@ -239,6 +239,18 @@ static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b;
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 
+// Second pass of the InstanceNorm(+ReLU) backward for one element: g = d(activation), f = the raw conv output y; scale /
+// shift / mean / rstd are the forward's constants of the (sample, channel), k1 / ka / kb come from in_bwd_finalize.  The
+// arithmetic is pinned (explicit fma: left to -ffp-contract hipcc fuses differently per context) because the pass exists
+// in four places that must round identically -- the stand-alone kernels (unet_ops.hip), the first layer's weight gradient
+// (conv_first.hip) and the 16-bit weight gradient's staging (conv_wgrad2_kernel<.,.,true>); tests compare them bit for bit.
+__device__ __forceinline__ float in_bwd_elem(float g, float f, float scale, float shift, float mean, float rstd, float k1,
+                                             float ka, float kb) {
+  const float gg = (__builtin_fmaf(f, scale, shift) > 0.f) ? g : 0.f;
+  const float xh = (f - mean) * rstd;
+  return k1 * __builtin_fmaf(-xh, kb, gg - ka);
+}
+
 // The transformer branches are ~100 short, latency-bound launches on the critical path that run NEXT TO the heavy
 // persistent convolutions of the other streams (plan.hip: forward and backward3d fork).  Their waves co-reside with the
 // conv waves on a SIMD; raising the wave priority lets their few instructions issue ahead of the conv's stream of

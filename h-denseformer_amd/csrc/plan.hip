@@ -1116,10 +1116,15 @@ int in_backward(Exec& e, const Conv3& c, const View& da, const View& dy, int pre
 // bs_next / bs_rows (optional): the conv whose InstanceNorm(+ReLU) backward consumes *din next.  Where the data-gradient
 // launch can (hdf_conv_bwd_stats_ok) its epilogue writes the first pass of that backward into e.inbp() and *bs_rows is
 // set to the rows per sample (pass it to in_backward as pre_blocks); else *bs_rows = 0.
-int conv_backward(Exec& e, Conv3& c, const View& dy, const View& in, Xf xf, const View* din, int accumulate,
-                  const View* din2 = nullptr, float* din_colsum = nullptr, int colsum_C = 0,
-                  const Conv3* bs_next = nullptr, int* bs_rows = nullptr) {
-  hdf_plan* p = e.p;
+// ap (optional): dy has NOT been written yet.  ap->da is the gradient w.r.t. c's activation and in_backward(.., apply =
+// false) has left k1 | ka | kb at ap->k: the weight-gradient launch applies the second pass of the InstanceNorm backward to
+// the rows it stages and writes dy as it goes (WgradArgs::ap_*); this stream waits for it before the data gradient.
+struct InApply {
+  const View* da;
+  const float* k;
+};
+// the weight-gradient launch of conv layer c (without the fused pass)
+static WgradArgs wgrad_args(Exec& e, const Conv3& c, const View& dy, const View& in, Xf xf) {
   const int* d = e.dm(c.lvl);
   WgradArgs w{};
   w.sm = e.at(dy);
@@ -1135,9 +1140,30 @@ int conv_backward(Exec& e, Conv3& c, const View& dy, const View& in, Xf xf, cons
   w.lg_scale = xf.scale;
   w.lg_shift = xf.shift;
   w.lg_relu = xf.relu;
+  return w;
+}
+static void wgrad_args_apply(WgradArgs& w, Exec& e, const Conv3& c, const View& dy, const InApply& ap) {
+  w.sm = e.at(*ap.da);
+  w.sm_pitch = ap.da->pitch;
+  w.ap_y = e.at(c.y);
+  w.ap_y_pitch = c.y.pitch;
+  w.ap_out = e.at(dy);
+  w.ap_out_pitch = dy.pitch;
+  w.ap_tab[0] = e.f(c.st.scale), w.ap_tab[1] = e.f(c.st.shift), w.ap_tab[2] = e.f(c.st.mean), w.ap_tab[3] = e.f(c.st.rstd);
+  w.ap_tab[4] = ap.k, w.ap_tab[5] = ap.k + (size_t)e.B * c.Cout, w.ap_tab[6] = ap.k + (size_t)2 * e.B * c.Cout;
+}
+
+int conv_backward(Exec& e, Conv3& c, const View& dy, const View& in, Xf xf, const View* din, int accumulate,
+                  const View* din2 = nullptr, float* din_colsum = nullptr, int colsum_C = 0,
+                  const Conv3* bs_next = nullptr, int* bs_rows = nullptr, const InApply* ap = nullptr) {
+  hdf_plan* p = e.p;
+  const int* d = e.dm(c.lvl);
+  WgradArgs w = wgrad_args(e, c, dy, in, xf);
+  if (ap) wgrad_args_apply(w, e, c, dy, *ap);
 #if !defined(HDF_NO_CONV_FIRST) && !defined(HDF_NO_WGRAD_FIRST)  // (A/B builds)
   // the encoder's first layer: K = (tap, channel) from the other side, csrc/conv_first.hip
-  if (c.Cin <= 4 && !xf.scale && hdf_wgrad_first_takes(p->dtype, c.Cin, c.Cout, d[0], d[1], d[2], in.pitch, dy.pitch)) {
+  if (!ap && c.Cin <= 4 && !xf.scale &&
+      hdf_wgrad_first_takes(p->dtype, c.Cin, c.Cout, d[0], d[1], d[2], in.pitch, dy.pitch)) {
     HDF_TRY(hdf_launch_wgrad_first(p->dtype, e.at(dy), dy.pitch, c.Cout, e.at(in), in.pitch, c.Cin, e.B, d[0], d[1], d[2],
                                    e.G(c.w), 0, e.ws + p->wgrad_ws, p->wgrad_ws_bytes, e.wgrad_stream()));
   } else
@@ -1145,6 +1171,9 @@ int conv_backward(Exec& e, Conv3& c, const View& dy, const View& in, Xf xf, cons
   HDF_TRY(hdf_launch_wgrad(p->dtype, 1, w, e.G(c.w), c.Cout, c.Cin, 0, e.ws + p->wgrad_ws, p->wgrad_ws_bytes,
                            e.wgrad_stream()));
   HDF_TRY(e.wgrad_done(dy));
+  // (the side stream runs its launches in order, so the earlier readers of dy's previous contents are done before this
+  // launch writes it; the data gradient below is the first reader of the new contents)
+  if (ap) e.wait_readers(dy);
   // Conv3 layers with a bias are the UpConvs (HDenseFormer.py:162-175): conv(bias) -> InstanceNorm3d(affine=False).
   // The norm subtracts the per-(sample, channel) mean, so dL/dbias = sum_voxels dy is identically zero (the reference
   // accumulates ~3e-8 of rounding noise there); the gradient buffer was zeroed at the start of backward,
@@ -1194,6 +1223,49 @@ int conv_backward(Exec& e, Conv3& c, const View& dy, const View& in, Xf xf, cons
     }
   }
   return HDF_OK;
+}
+
+// InstanceNorm(+ReLU) backward of conv layer c followed by the conv's own backward (in_backward + conv_backward).  Where the
+// weight-gradient launch can take the norm's second pass along (16-bit stride-1 layers: conv_wgrad2_kernel<., ., true>) that
+// pass need not run on its own: one launch, the read of d(activation) + y and the write + re-read of dy by a pass that does
+// nothing else (in_bwd_apply4 at 128^3 x 32 channels: 86 us alone, 165 us inside the step, three times per step).
+// Measured (round 5, same box, interleaved, bench geometry):
+//   one stream, sum of kernel times: -0.27 ms with every level fused (apply -0.60 ms, weight gradients +0.33 ms: the pass
+//     costs ~400 VALU instructions per tile and wave in a kernel with ONE wave per SIMD);
+//   the step as shipped (three streams): fused at 128^3 only 10.88 ms, not fused 10.90 ms, fused at >= 64^3 11.06 ms
+//     (6 rounds each).  The stand-alone pass is HBM-bound and ran UNDER the matrix kernels of the other streams; fused, its
+//     work sits in the matrix kernels' instruction stream, and the data gradient waits for the weight gradient (i.e. for
+//     whatever the side stream still holds).
+// So the default fuses the 128^3 layers only (0.8 GB of the step's HBM traffic and three launches less at the same step
+// time); HDF_FUSED_APPLY_MIN_VOX (environment, voxels per sample) moves the threshold, HDF_NO_FUSED_APPLY switches the
+// fused form off.  The UpConv chain on the branch stream (the critical path) always keeps the stand-alone pass.
+static int64_t fused_apply_min_vox() {
+  static const int64_t v = [] {
+    const char* s = getenv("HDF_FUSED_APPLY_MIN_VOX");
+    return s ? (int64_t)atoll(s) : (int64_t)128 * 128 * 128;
+  }();
+  return v;
+}
+int norm_conv_backward(Exec& e, Conv3& c, const View& da, const View& dy, int pre_blocks, const View& in, Xf xf,
+                       const View* din, int accumulate, const View* din2 = nullptr, float* din_colsum = nullptr,
+                       int colsum_C = 0, const Conv3* bs_next = nullptr, int* bs_rows = nullptr) {
+  static const bool off = getenv("HDF_NO_FUSED_APPLY") != nullptr;  // A/B knob (tests/test_gpu_knobs.py)
+  hdf_plan* p = e.p;
+  const int* d = e.dm(c.lvl);
+  InApply ap{&da, e.inbk()};
+  bool fuse = !off && !e.on_branch && p->vox(c.lvl) >= fused_apply_min_vox();
+  if (fuse) {
+#if !defined(HDF_NO_CONV_FIRST) && !defined(HDF_NO_WGRAD_FIRST)
+    if (c.Cin <= 4 && !xf.scale && hdf_wgrad_first_takes(p->dtype, c.Cin, c.Cout, d[0], d[1], d[2], in.pitch, dy.pitch))
+      fuse = false;  // the first layer's own kernel
+#endif
+    WgradArgs w = wgrad_args(e, c, dy, in, xf);
+    wgrad_args_apply(w, e, c, dy, ap);
+    fuse = fuse && hdf_wgrad_apply_takes(p->dtype, 1, w);
+  }
+  HDF_TRY(in_backward(e, c, da, dy, pre_blocks, !fuse));
+  return conv_backward(e, c, dy, in, xf, din, accumulate, din2, din_colsum, colsum_C, bs_next, bs_rows,
+                       fuse ? &ap : nullptr);
 }
 
 // ConvTranspose3d backward: dOut (hi-res) -> dIn (lo-res, grad w.r.t. the activation fed to the convT)
@@ -1713,16 +1785,16 @@ static int backward3d(hdf_plan* p, const float* x, const float* params, void* wo
     // gA[k] holds d/d(activation of c2): head gradient (+ convT input gradient from the level above, k>0)
     int pre = 0;
     HDF_TRY(head_backward(e, p->head[k], douts[k], c2.y, xf_of(e, c2), p->gA[k], k > 0 ? 1 : 0, &c2, &pre));
-    HDF_TRY(in_backward(e, c2, p->gA[k], p->gY[k], pre));
     int bsr = 0;  // the data-gradient conv may leave the first pass of c1's InstanceNorm backward behind (level 0)
-    HDF_TRY(conv_backward(e, c2, p->gY[k], c1.y, xf_of(e, c1), &p->gA[k], 0, nullptr, nullptr, 0, &c1, &bsr));
-    HDF_TRY(in_backward(e, c1, p->gA[k], p->gY2[k], bsr));
+    HDF_TRY(norm_conv_backward(e, c2, p->gA[k], p->gY[k], pre, c1.y, xf_of(e, c1), &p->gA[k], 0, nullptr, nullptr, 0, &c1,
+                               &bsr));
     // the upconv half of d(cat) is the gradient of upconv_{k+1}'s output: its bias gradient rides on this conv
     float* up_db = e.G(p->upc[k].b);
     if (p->dcat_split[k])
-      HDF_TRY(conv_backward(e, c1, p->gY2[k], p->cat[k], none, &p->dUp[k], 0, &p->dSkip[k], up_db, ch[k]));
+      HDF_TRY(norm_conv_backward(e, c1, p->gA[k], p->gY2[k], bsr, p->cat[k], none, &p->dUp[k], 0, &p->dSkip[k], up_db,
+                                 ch[k]));
     else
-      HDF_TRY(conv_backward(e, c1, p->gY2[k], p->cat[k], none, &p->dCat[k], 0, nullptr, up_db, ch[k]));
+      HDF_TRY(norm_conv_backward(e, c1, p->gA[k], p->gY2[k], bsr, p->cat[k], none, &p->dCat[k], 0, nullptr, up_db, ch[k]));
     // upconv_{k+1}: input is dec[k+1][1] activation (k<2) or the bottleneck x4 (k==2)
     const View& dup = p->dUp[k];
     if (k < 2)
@@ -1779,9 +1851,9 @@ static int backward3d(hdf_plan* p, const float* x, const float* params, void* wo
         }
       }
     }
-    HDF_TRY(in_backward(e, c2, dskip, p->gY[k], pre));
     int bsr = 0;
-    HDF_TRY(conv_backward(e, c2, p->gY[k], c1.y, xf_of(e, c1), &p->gA[k], 0, nullptr, nullptr, 0, &c1, &bsr));
+    HDF_TRY(norm_conv_backward(e, c2, dskip, p->gY[k], pre, c1.y, xf_of(e, c1), &p->gA[k], 0, nullptr, nullptr, 0, &c1,
+                               &bsr));
     bool first_fused = false;
 #if !defined(HDF_NO_CONV_FIRST) && !defined(HDF_NO_WGRAD_FIRST) && !defined(HDF_NO_WGRAD_FIRST_IN)
     // The first layer has no input gradient: the second pass of its InstanceNorm backward would write dy (268 MB at the
@@ -1801,11 +1873,10 @@ static int backward3d(hdf_plan* p, const float* x, const float* params, void* wo
     }
 #endif
     if (!first_fused) {
-      HDF_TRY(in_backward(e, c1, p->gA[k], p->gY2[k], bsr));
       if (k > 0)
-        HDF_TRY(conv_backward(e, c1, p->gY2[k], p->pooled[k - 1], none, &p->dP[k - 1], 0));
+        HDF_TRY(norm_conv_backward(e, c1, p->gA[k], p->gY2[k], bsr, p->pooled[k - 1], none, &p->dP[k - 1], 0));
       else
-        HDF_TRY(conv_backward(e, c1, p->gY2[k], p->xin, none, nullptr, 0));
+        HDF_TRY(norm_conv_backward(e, c1, p->gA[k], p->gY2[k], bsr, p->xin, none, nullptr, 0));
     }
     // (host order: the ten level-0 launches of the caller's stream first, then the ~100 of the transformer backward)
     if (k == 0 && forked) {

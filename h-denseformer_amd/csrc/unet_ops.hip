@@ -1033,9 +1033,7 @@ __global__ __launch_bounds__(256, 8) void in_bwd_apply4_kernel(const T* __restri
         float d[4];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-          const float gg = (f[u][e] * sc[e] + sh[e] > 0.f) ? g[u][e] : 0.f;
-          const float xh = (f[u][e] - mu[e]) * rs[e];
-          d[e] = c1[e] * (gg - ca[e] - xh * cb[e]);
+          d[e] = in_bwd_elem(g[u][e], f[u][e], sc[e], sh[e], mu[e], rs[e], c1[e], ca[e], cb[e]);
         }
         ST<T>::st4(dyp + v * dy_pitch, d[0], d[1], d[2], d[3]);
       }
@@ -1137,9 +1135,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__
       if (v0 + (int64_t)u * vlanes < ve) {
 #pragma unroll
         for (int e = 0; e < EPC; e++) {
-          float gg = (f[u][e] * sc[e] + sh[e] > 0.f) ? g[u][e] : 0.f;
-          float xh = (f[u][e] - mu[e]) * rs[e];
-          g[u][e] = c1[e] * (gg - ca[e] - xh * cb[e]);
+          g[u][e] = in_bwd_elem(g[u][e], f[u][e], sc[e], sh[e], mu[e], rs[e], c1[e], ca[e], cb[e]);
         }
         store_chunk<T>(dy + rowv[u] * dy_pitch + c0, g[u]);
       }

@@ -1,8 +1,11 @@
-"""Every environment knob the library still reads selects another ARRANGEMENT of the same kernels (streams), never
-other arithmetic: a step under each knob must reproduce the default step -- convolution weight gradients bit for bit
-(fixed-order sums), everything else (float atomics in the bias / LayerNorm / head gradients) to 1e-4.  The knobs are read
-once per process, so each configuration runs tools/knob_check.py in its own process.  (Round 2 carried 22 knobs that
-switched to older kernels nothing tested; round 3 deleted those kernels and their knobs.)"""
+"""Every environment knob the library still reads selects another ARRANGEMENT of the same kernels (streams, fused or stand-
+alone passes), never other arithmetic: a step under each knob must reproduce the default step -- convolution weight
+gradients bit for bit (fixed-order sums), everything else (float atomics in the bias / LayerNorm / head gradients) to 1e-4.
+HDF_FUSED_APPLY_MIN_VOX=1 fuses the second InstanceNorm-backward pass into EVERY 16-bit stride-1 weight gradient of the
+encoder / decoder (default: the 128^3 layers only, which this 64^3 geometry does not have): that run against the default
+one is the bit-for-bit test of conv_wgrad2_kernel<., ., true> and of the dy it writes for the data-gradient convs.
+The knobs are read once per process, so each configuration runs tools/knob_check.py in its own process.  (Round 2 carried
+22 knobs that switched to older kernels nothing tested; round 3 deleted those kernels and their knobs.)"""
 import json
 import os
 import re
@@ -14,7 +17,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KNOBS = ["HDF_NO_BRANCH_OVERLAP", "HDF_NO_ASYNC_WGRAD", "HDF_NO_TF_CHAIN"]
+KNOBS = ["HDF_NO_BRANCH_OVERLAP", "HDF_NO_ASYNC_WGRAD", "HDF_NO_TF_CHAIN", "HDF_NO_FUSED_APPLY", "HDF_FUSED_APPLY_MIN_VOX"]
 
 
 def _run(env_extra):
