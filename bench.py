@@ -36,8 +36,10 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-CPU_THREADS = 16          # torch/oneDNN on all 256 host threads of the GPU box is pathologically slow (measured:
-#                           811 s/step vs 12.6 s/step on 8 threads elsewhere), so the baseline pins 16 threads
+# torch/oneDNN on all 256 host threads of the GPU box is pathologically slow (811 s/step, round 1), so the baseline pins a
+# thread count: the best of the sweep 8 / 16 / 32 / 64 on that host (tools/cpu_thread_sweep.sh, profiles/r05_cpu_thread_sweep.txt).
+# HDF_BENCH_CPU_THREADS overrides it (the sweep's knob; bench.py is not part of the library).
+CPU_THREADS = int(os.environ.get("HDF_BENCH_CPU_THREADS", "16"))
 CPU_BUDGET_S = 240
 
 

@@ -887,10 +887,10 @@ int launch_wr(const ConvArgs& a, hipStream_t st) {
   const int tiles = a.N * ceil_div(a.Do, TD) * ceil_div(a.Ho, 8) * ceil_div(a.Wo, 8);
   const int cout_tiles = a.CoutP / (32 * NB);
   const int gx = std::min(tiles, std::max(1, hdf_cu_budget() / cout_tiles));
-  if (a.in_scale)
-    hipLaunchKernelGGL((conv_wr_kernel<T, RB, NB, KSPLIT, TD, true>), dim3(gx, cout_tiles), dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL((conv_wr_kernel<T, RB, NB, KSPLIT, TD, false>), dim3(gx, cout_tiles), dim3(256), 0, st, a);
+  // (round 5: the only instantiation per storage type.  The 64-byte-row forms <64, 2, 2, 4> / <64, 1, 1, 8> and the
+  // forms with the producer's InstanceNorm + ReLU applied on load were built, parity-tested and measured level with or
+  // behind conv_ws2 in rounds 4-5 and are no longer compiled; the template keeps their parameters.)
+  hipLaunchKernelGGL((conv_wr_kernel<T, RB, NB, KSPLIT, TD, false>), dim3(gx, cout_tiles), dim3(256), 0, st, a);
   HDF_LAUNCH_CHECK();
   return HDF_OK;
 }
@@ -900,20 +900,16 @@ int launch_wr(const ConvArgs& a, hipStream_t st) {
 // Does the weights-in-registers kernel take this mode-0 launch?  (16-bit storage, 64- or 128-byte rows, a volume the old
 // weights-stationary kernel would take, a sample below 2 GiB so that 32-bit byte offsets address it.)
 // Measured against conv_ws2_kernel on one box (tools/conv_ab.sh, round 4): 64 -> 32 @128^3 without an input transform
-// 482 vs 502 us; with a transform, at 64^3 and for the 64-byte-row instantiations it is level or behind (DESIGN.md
-// section 6e), so only that class is routed here.  hdf_op_conv3d_wr runs any eligible shape through it (tests, tools).
+// 482 vs 502 us; with a transform, at 64^3 and for 64-byte rows it was level or behind, so only
+// that class exists.  hdf_op_conv3d_wr runs any eligible shape (>= 48^3) through it (tests, tools).
 bool hdf_conv_wr_takes(int dtype, const ConvArgs& a) {
-  if (!hdf_conv_wr_can(dtype, a) || (int64_t)a.Do * a.Ho * a.Wo < 96 * 96 * 96) return false;
-#ifdef HDF_WR_ROUTE_B  // A/B builds: the 32 -> 32 layers too (with and without a transform)
-  if (a.Cin * 2 == 64 && a.CoutP == 32) return true;
-#endif
-  return a.Cin * 2 == 128 && !a.in_scale;
+  return hdf_conv_wr_can(dtype, a) && (int64_t)a.Do * a.Ho * a.Wo >= 96 * 96 * 96;
 }
 
 bool hdf_conv_wr_can(int dtype, const ConvArgs& a) {
   if (dtype == HDF_F32 || a.wfrag) return false;
   const int rb = a.Cin * 2;
-  if (rb != 64 && rb != 128) return false;
+  if (rb != 128 || a.in_scale) return false;
   if ((int64_t)a.Do * a.Ho * a.Wo < 48 * 48 * 48) return false;
   if ((int64_t)a.Di * a.Hi * a.Wi * a.in_pitch * 2 >= ((int64_t)1 << 31)) return false;
   if ((int64_t)a.Hi * a.Wi * a.in_pitch * 2 >= (1 << 24)) return false;  // 24-bit multiplies by the z stride
@@ -925,15 +921,11 @@ int hdf_launch_conv_wr(int dtype, const ConvArgs& a, hipStream_t st) {
   const int rb = a.Cin * 2;
   if (dtype == HDF_BF16) {
     using T = bf16_t;
-    if (rb == 128) return launch_wr<T, 128, 1, 2, 4>(a, st);
-    if (a.CoutP % 64 == 0) return launch_wr<T, 64, 2, 2, 4>(a, st);
-    return launch_wr<T, 64, 1, 1, 8>(a, st);
+    if (rb == 128 && !a.in_scale) return launch_wr<T, 128, 1, 2, 4>(a, st);
   } else if (dtype == HDF_F16) {
     using T = f16_t;
-    if (rb == 128) return launch_wr<T, 128, 1, 2, 4>(a, st);
-    if (a.CoutP % 64 == 0) return launch_wr<T, 64, 2, 2, 4>(a, st);
-    return launch_wr<T, 64, 1, 1, 8>(a, st);
+    if (rb == 128 && !a.in_scale) return launch_wr<T, 128, 1, 2, 4>(a, st);
   }
-  hdf_set_error("conv_wr: dtype %d", dtype);
+  hdf_set_error("conv_wr: dtype %d, %d-byte rows%s: not built", dtype, rb, a.in_scale ? " with an input transform" : "");
   return HDF_ERR_UNSUPPORTED;
 }

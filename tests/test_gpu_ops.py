@@ -57,17 +57,15 @@ def _conv3d_wr(dtype, x_cl, cin, w_packed, cout, bias=None, scale=None, shift=No
 
 
 @pytest.mark.parametrize("dtype", [BF16, F16])
-@pytest.mark.parametrize("xf", [False, True])
-@pytest.mark.parametrize("cin,cout,size,n", [(32, 32, (56, 52, 50), 2),      # 8x8x8 tiles, ragged in y and x, two samples
-                                            (32, 32, (64, 64, 64), 1),      # whole tiles only
-                                            (64, 32, (64, 56, 48), 2),      # K split over the waves + LDS exchange
+@pytest.mark.parametrize("xf", [False])
+@pytest.mark.parametrize("cin,cout,size,n", [(64, 32, (64, 56, 48), 2),      # K split over the waves + LDS exchange
+                                            (64, 32, (56, 52, 50), 2),      # ragged in y and x, two samples
                                             (64, 64, (48, 52, 56), 1),      # two output blocks through blockIdx.y
-                                            (64, 48, (50, 49, 51), 1),      # channel count below the padded block
-                                            (32, 64, (50, 49, 51), 2),      # two output blocks per wave (NB = 2)
-                                            (32, 96, (48, 48, 48), 1)])
+                                            (64, 48, (50, 49, 51), 1)])     # channel count below the padded block
 def test_conv3d_weights_in_registers(dtype, xf, cin, cout, size, n):
-    """conv_wr_kernel (csrc/conv_wr.hip) through hdf_op_conv3d_wr: 16-bit storage, 64- / 128-byte rows at >= 48^3 -- every
-    instantiation, with and without the producer's InstanceNorm + ReLU on load (the in-place LDS transform), ragged extents
+    """conv_wr_kernel (csrc/conv_wr.hip) through hdf_op_conv3d_wr: 16-bit storage, 128-byte rows at >= 48^3, no input
+    transform -- the one instantiation per storage type that is built (round 5 dropped the five the plan never routed:
+    64-byte rows and the in-place LDS transform; the `xf` branch below is kept for the day one returns) --, ragged extents
     (the checked border phase), several samples (the tile list, the deferred epilogue and the statistics rows cross
     samples), bias, InstanceNorm partial sums.  Reference: torch fp32 conv3d on the storage-rounded operands."""
     x, w, b = _mk((n, cin) + size, 21), _mk((cout, cin, 3, 3, 3), 22) * (cin * 27) ** -0.5, _mk((cout,), 23)
@@ -90,7 +88,7 @@ def test_conv3d_weights_in_registers(dtype, xf, cin, cout, size, n):
     assert rel_err(s[..., 1], (ref * ref).sum((2, 3, 4))) < 5e-3 + TOL[dtype]
 
 
-@pytest.mark.parametrize("cin,cout,size,n", [(64, 32, (48, 48, 56), 2), (32, 32, (56, 48, 48), 1)])
+@pytest.mark.parametrize("cin,cout,size,n", [(64, 32, (48, 48, 56), 2), (64, 64, (56, 48, 48), 1)])
 def test_conv3d_weights_in_registers_accumulate_and_pitch(cin, cout, size, n):
     """out += conv(x) into a channel slice of a wider buffer, input a slice too: the launch is not `plain`, every tile runs
     the checked phase with the immediate epilogue."""
