@@ -38,6 +38,12 @@ struct ConvArgs {
   const void* bs_y;
   int64_t bs_y_pitch;
   const float *bs_scale, *bs_shift, *bs_mean, *bs_rstd;   // [N][Cout]
+  // raised wave priority (HDF_LIGHT_PRIO, hdf_common.h): the launch belongs to a latency-bound chain that runs next to
+  // another stream's persistent kernels (the UpConv chain on the plan's branch stream)
+  int prio = 0;
+  // workgroups of a persistent launch (conv_ws2_kernel), 0 = hdf_cu_budget(): a launch that should leave compute units to
+  // another stream's chain asks for fewer
+  int cu_budget = 0;
 };
 // split-K scratch a plan keeps per stream
 constexpr size_t HDF_KSPLIT_BYTES = (size_t)16 << 20;

@@ -92,6 +92,7 @@ __device__ __forceinline__ void stage_box(char* lds, const T* __restrict__ src, 
 // forward-style kernel (modes 0,1,2)
 template <typename T, int TD, int TH, int TW, int WM, int WN, int MB, int S, bool CONVT>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+  if (a.prio) HDF_LIGHT_PRIO();
   static_assert(WM * WN == 4, "4 waves");
   static_assert(WM * MB * 32 == TD * TH * TW, "tile/wave decomposition");
   constexpr int BD = CONVT ? TD + 1 : S * (TD - 1) + 3;
@@ -389,6 +390,7 @@ __device__ __attribute__((aligned(16))) uint32_t g_zero_line[4] = {0u, 0u, 0u, 0
 // round 3: DESIGN.md section 6d.)
 template <typename T, int CH, int RB, bool XF, int NB, bool BS = false>
 __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
+  if (a.prio) HDF_LIGHT_PRIO();
   constexpr int TD = 4, TH = 8, TW = 8, BD = TD + 2, BH = TH + 2, BW = TW + 2, BOX = BD * BH * BW;
   constexpr int ESZ = sizeof(T), EPC = ST<T>::EPC;
   constexpr int CIN = RB / ESZ;
@@ -2740,6 +2742,7 @@ __global__ void pack_batch_kernel(PackBatch b, const float* __restrict__ params,
 // (sum, sum of squares) of the tile reduced over the 16 voxel lanes in a fixed order.
 template <typename T, int TD, int TH, int TW>
 __global__ __launch_bounds__(256) void conv_ksplit_reduce_kernel(ConvArgs a) {
+  if (a.prio) HDF_LIGHT_PRIO();
   __shared__ float red[16][64][2];
   const int ntz = (a.Do + TD - 1) / TD, nty = (a.Ho + TH - 1) / TH, ntx = (a.Wo + TW - 1) / TW;
   int t = blockIdx.x;
@@ -2853,7 +2856,8 @@ template <typename T, int CH, int RB, int NB>
 int launch_ws2(const ConvArgs& a, hipStream_t st) {
   const int tiles = a.N * ceil_div(a.Do, 4) * ceil_div(a.Ho, 8) * ceil_div(a.Wo, 8);
   const int cout_tiles = a.CoutP / (32 * NB);
-  const int gx = std::min(tiles, std::max(1, hdf_cu_budget() / cout_tiles));  // one workgroup per CU; the kernel splits the tiles
+  const int budget = a.cu_budget > 0 ? std::min(a.cu_budget, hdf_cu_budget()) : hdf_cu_budget();
+  const int gx = std::min(tiles, std::max(1, budget / cout_tiles));  // one workgroup per CU; the kernel splits the tiles
   if constexpr (sizeof(T) == 2 && NB == 1 && RB == 64) {   // the level-0 32 -> 32 data gradient (hdf_conv_bwd_stats_ok)
     if (a.bs_y && !a.in_scale) {
       hipLaunchKernelGGL((conv_ws2_kernel<T, CH, RB, false, NB, true>), dim3(gx, cout_tiles), dim3(256), 0, st, a);

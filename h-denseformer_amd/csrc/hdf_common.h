@@ -260,5 +260,17 @@ __device__ __forceinline__ float in_bwd_elem(float g, float f, float scale, floa
 #else
 #define HDF_CHAIN_PRIO() __builtin_amdgcn_s_setprio(3)
 #endif
+// (round 5) The same for every LIGHT kernel -- normalisation statistics, pooling / up-sampling, heads: memory-bound passes of
+// a few hundred instructions per thread -- and, through ConvArgs::prio, for the small convolutions of the UpConv chain.
+// They are dispatched next to a persistent convolution of another stream (its workgroup leaves 130-180 registers per lane
+// free), but at equal priority the issue arbiter serves the OLDEST wave first, and a conv wave at one wave per SIMD always
+// has something to issue: up1's trilinear up-sampling (7 us alone) took 268 us beside the encoder's second 128^3 conv and
+// held the whole UpConv chain -- which the caller's stream then waited 220 us for (tools/timeline.py).  HDF_NO_LIGHT_PRIO:
+// A/B builds.
+#ifdef HDF_NO_LIGHT_PRIO
+#define HDF_LIGHT_PRIO() ((void)0)
+#else
+#define HDF_LIGHT_PRIO() __builtin_amdgcn_s_setprio(3)
+#endif
 
 

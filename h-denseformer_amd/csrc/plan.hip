@@ -641,6 +641,7 @@ struct Exec {
   float* grads;
   int B;
   hipStream_t st;
+  int conv_budget = 0;                          // ConvArgs::cu_budget of the convolutions issued through this Exec (0: all)
   bool async = false;                           // weight gradients on the side stream
   bool on_branch = false;                       // this Exec issues onto the plan's branch stream (own scratch)
   hipEvent_t last_side = nullptr;               // last event recorded on the side stream in this call
@@ -763,6 +764,8 @@ int conv_forward(Exec& e, Conv3& c, const View& in, Xf xf, bool probe = false) {
   const int* d = e.dm(c.lvl);
   const int CoutP = round_up(c.Cout, 32);
   ConvArgs a{};  // weights: packed by hdf_forward's pack batch
+  a.prio = e.on_branch;  // the UpConv chain's convolutions run next to the encoder's persistent ones (ConvArgs::prio)
+  a.cu_budget = e.conv_budget;
   a.in = e.at(in);
   a.in_pitch = in.pitch;
   a.Cin = c.CinP;
@@ -1182,6 +1185,7 @@ int conv_backward(Exec& e, Conv3& c, const View& dy, const View& in, Xf xf, cons
     // dgrad = the same conv with taps reversed and channel roles swapped: Wd[t][ci][co] = W[co][ci][26-t]
     const int OP = round_up(c.Cin, 32);
     ConvArgs a{};
+    a.prio = e.on_branch;
     a.in = e.at(dy);
     a.in_pitch = dy.pitch;
     a.Cin = c.Cout;
@@ -1533,7 +1537,19 @@ static int forward3d(hdf_plan* p, const float* x, const float* params, void* wor
 #endif
   HDF_TRY(hdf_launch_nchw_to_ndhwc(p->dtype, x, e.at(p->xin), batch, p->M, 16, p->vox(0), e.st));
   HDF_TRY(conv_forward(e, p->enc[0][0], p->xin, none));
+  // (round 5) The second level-0 conv takes three quarters of the compute units: it runs while the branch stream works
+  // through deep_conv / up1..3 (the persistent transformer kernel in front of them holds every unit, so the order on
+  // the device is conv_first, transformer, then this conv NEXT TO the UpConv chain), and the chain's low-resolution
+  // convs cannot share a unit with a persistent 128^3 workgroup (LDS, registers): at 256 workgroups they queued behind it
+  // (deep_conv: 291 us instead of 72) and the caller's stream then waited 220 us for at3.  192 of 256: conv 277 -> 363 us,
+  // at3 ready 85 us earlier (tools/timeline.py, profiles/r05_forward_timeline.txt).  The grid is the same in every
+  // stream arrangement: the InstanceNorm partial sums are grouped per workgroup, and tests/test_gpu_knobs.py compares
+  // arrangements bit for bit.  HDF_NO_L0_BUDGET: A/B builds.
+#ifndef HDF_NO_L0_BUDGET
+  e.conv_budget = (hdf_cu_budget() * 3 / 4) & ~7;
+#endif
   HDF_TRY(conv_forward(e, p->enc[0][1], p->enc[0][0].y, xf_of(e, p->enc[0][0])));
+  e.conv_budget = 0;
   eb.tf_packed = packed;
   HDF_TRY(transformer_forward(eb, x));
   if (packed && hipStreamWaitEvent(bst, packed, 0) != hipSuccess) {

@@ -25,6 +25,7 @@ __device__ __forceinline__ void store_chunk(T* p, const float* f) {
 template <typename T>
 __global__ void nchw_to_ndhwc_kernel(const float* __restrict__ x, T* __restrict__ out, int N, int C, int CP,
                                      int64_t vox) {
+  HDF_LIGHT_PRIO();
   int64_t total = (int64_t)N * vox;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t n = i / vox, v = i - n * vox;
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(256, 4) void in_finalize_kernel(const float* __rest
                                                            const float* __restrict__ beta, float eps,
                                                            float* __restrict__ mean, float* __restrict__ rstd,
                                                            float* __restrict__ scale, float* __restrict__ shift) {
+  HDF_LIGHT_PRIO();
   __shared__ double red[FIN_LANES][FIN_CG][2];
   const int n = blockIdx.y, cg = blockIdx.x;
   const int cl = threadIdx.x & (FIN_CG - 1), c = cg * FIN_CG + cl, tl = threadIdx.x / FIN_CG;
@@ -97,6 +99,7 @@ template <typename T>
 __global__ void norm_relu_add_kernel(const T* __restrict__ y, int64_t y_pitch, const float* __restrict__ scale,
                                      const float* __restrict__ shift, const T* __restrict__ skip, int64_t skip_pitch,
                                      T* __restrict__ out, int64_t out_pitch, int N, int C, int64_t vox) {
+  HDF_LIGHT_PRIO();
   constexpr int EPC = ST<T>::EPC;
   const int cols = C / EPC;
   int64_t total = (int64_t)N * vox * cols;
@@ -230,6 +233,7 @@ __global__ __launch_bounds__(256, 2) void enc_tail_kernel(const T* __restrict__ 
                                                           int64_t ds_pitch, T* __restrict__ pooled,
                                                           int64_t pooled_pitch, uint8_t* __restrict__ idx, int N, int C,
                                                           int Do, int Ho, int Wo) {
+  HDF_LIGHT_PRIO();
   constexpr int EPC = ST<T>::EPC;
   const int cols = C / EPC;
   const int Hi = 2 * Ho, Wi = 2 * Wo;
@@ -325,6 +329,7 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const T* __restrict__
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift, T* __restrict__ out,
                                                            int64_t out_pitch, int N, int C, int Di, int Hi, int Wi) {
+  HDF_LIGHT_PRIO();
   constexpr int EPC = ST<T>::EPC;
   const int cols = C / EPC;
   const int Ho = 2 * Hi, Wo = 2 * Wi;
@@ -415,6 +420,7 @@ __global__ __launch_bounds__(256, 2) void enc_tail_up_kernel(const T* __restrict
                                                              int64_t ds_pitch, T* __restrict__ pooled,
                                                              int64_t pooled_pitch, uint8_t* __restrict__ idx, int N, int C,
                                                              int Do, int Ho, int Wo) {
+  HDF_LIGHT_PRIO();
   constexpr int EPC = 4;  // four channels per thread (8-byte accesses in the 16-bit modes): two workgroups per SIMD set
   // grid (x tiles, oh, n * Do + od): the plane and row coordinates are uniform per workgroup, so every base address is
   // scalar arithmetic and a thread adds 32-bit offsets inside one row (the first version, a flat index with 64-bit
@@ -542,6 +548,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__ dout, int64_t dout_pitch,
                                                            T* __restrict__ din, int64_t din_pitch, int N, int C, int Di,
                                                            int Hi, int Wi, int gx) {
+  HDF_LIGHT_PRIO();
   constexpr int EPC = ST<T>::EPC;
   const int cols = C / EPC;
   const int Ho = 2 * Hi, Wo = 2 * Wi;
@@ -603,6 +610,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ in,
                                                        const float* __restrict__ w, const float* __restrict__ b,
                                                        T* __restrict__ logits, int N, int C, int ncls, int64_t vox,
                                                        int per, int vec4) {
+  HDF_LIGHT_PRIO();
   constexpr int EPC = ST<T>::EPC;
   extern __shared__ float outs[];  // [MC][per], then [256][MC] partials when cols is not a power of two
   float* part = outs + MC * per;
@@ -717,6 +725,7 @@ __global__ __launch_bounds__(256, (MC == 4 && sizeof(T) == 2) ? 4 : 1) void head
                                                        const float* __restrict__ in_mean,
                                                        const float* __restrict__ in_rstd,
                                                        float* __restrict__ inb_partials, int vec4) {
+  HDF_LIGHT_PRIO();
   constexpr int EPC = 4;
   // inb_partials (optional): this kernel produces the complete gradient dx of the activation relu(IN(in)), so it
   // also writes the first pass of that InstanceNorm's backward -- per workgroup and channel (sum g, sum g*xhat) with
@@ -872,6 +881,7 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const T* __restrict_
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, float* __restrict__ partials,
                                                             int blocks, int C, int64_t vox) {
+  HDF_LIGHT_PRIO();
   constexpr int EPC = ST<T>::EPC;
   extern __shared__ float red[];  // [vlanes][C][2]
   const int n = blockIdx.y;
@@ -940,6 +950,7 @@ __global__ __launch_bounds__(256, 6) void in_bwd_reduce4_kernel(const T* __restr
                                                                 const float* __restrict__ rstd,
                                                                 float* __restrict__ partials, int blocks, int C,
                                                                 int64_t vox) {
+  HDF_LIGHT_PRIO();
   extern __shared__ float red[];  // [vlanes][C][2]
   const int n = blockIdx.y;
   const int cols = C >> 2, vlanes = 256 / cols;
@@ -1001,6 +1012,7 @@ __global__ __launch_bounds__(256, 8) void in_bwd_apply4_kernel(const T* __restri
                                                                const float* __restrict__ ka,
                                                                const float* __restrict__ kb, T* __restrict__ dy,
                                                                int64_t dy_pitch, int C, int64_t vox) {
+  HDF_LIGHT_PRIO();
   constexpr int U = 4;
   const int n = blockIdx.y;
   const int cols = C >> 2, vlanes = 256 / cols;
@@ -1048,6 +1060,7 @@ __global__ __launch_bounds__(256, 4) void in_bwd_finalize_kernel(const float* __
                                                                const float* __restrict__ rstd, float* __restrict__ k1,
                                                                float* __restrict__ ka, float* __restrict__ kb,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  HDF_LIGHT_PRIO();
   constexpr int BL = 32;
   __shared__ double red[BL][FIN_CG][2];
   const int n = blockIdx.y, cl = threadIdx.x & (FIN_CG - 1), c = blockIdx.x * FIN_CG + cl, bl = threadIdx.x / FIN_CG;
@@ -1099,6 +1112,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ k1, const float* __restrict__ ka,
                                                            const float* __restrict__ kb, T* __restrict__ dy,
                                                            int64_t dy_pitch, int C, int64_t vox) {
+  HDF_LIGHT_PRIO();
   constexpr int EPC = ST<T>::EPC;
   constexpr int U = 4;  // chunks per thread per iteration: 8 independent 16-byte loads in flight
   const int n = blockIdx.y;
@@ -1222,6 +1236,7 @@ int hdf_launch_nchw_to_ndhwc(int dtype, const float* x, void* out, int N, int C,
 // InstanceNorm partial table), c < C.  grid ceil(C/8), 256 threads = 32 row lanes x 8 channels, fixed order.
 __global__ __launch_bounds__(256, 6) void stat_rows_sum_kernel(const float* __restrict__ partials, int rows, int C, int CP,
                                                              float* __restrict__ out) {
+  HDF_LIGHT_PRIO();
   __shared__ double red[32][FIN_CG];
   const int cl = threadIdx.x & (FIN_CG - 1), c = blockIdx.x * FIN_CG + cl, rl = threadIdx.x / FIN_CG;
   double s = 0.0;
@@ -1324,6 +1339,7 @@ __global__ __launch_bounds__(256, 4) void maxpool_bwd_inb_kernel(const T* __rest
                                                                  const float* __restrict__ rstd,
                                                                  float* __restrict__ partials, int C, int Do, int Ho,
                                                                  int Wo) {
+  HDF_LIGHT_PRIO();
   extern __shared__ float red[];  // [vlanes][C][2]
   const int n = blockIdx.y, blocks = gridDim.x;
   const int cols = C >> 2, vlanes = 256 / cols;
