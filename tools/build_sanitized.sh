@@ -9,6 +9,7 @@ python build.py > /dev/null
 mkdir -p build/san
 SAN="-fsanitize=address,undefined -fno-gpu-sanitize -shared-libsan -fno-sanitize-recover=undefined -fno-omit-frame-pointer -g"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -std=c++17 -fPIC $SAN -c csrc/plan.hip -o build/san/plan.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $SAN -o lib/libhdf_hip_san.so build/conv_igemm.o build/conv_wr.o build/conv_first.o \
-  build/unet_ops.o build/transformer.o build/transformer_fused.o build/loss.o build/san/plan.o
+# every product object except plan.o (the list follows build.py's SOURCES: a source added there is linked here too)
+objs=$(python -c "import build; print(' '.join('build/' + s[:-4] + '.o' for s in build.SOURCES if s != 'plan.hip'))")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $SAN -o lib/libhdf_hip_san.so $objs build/san/plan.o
 echo built lib/libhdf_hip_san.so
