@@ -2718,6 +2718,7 @@ struct PackBatch {
 // consecutive threads are consecutive `in` indices, i.e. coalesced
 template <typename T>
 __global__ void pack_batch_kernel(PackBatch b, const float* __restrict__ params, char* __restrict__ ws) {
+  HDF_LIGHT_PRIO();   // (runs beside the first level-0 conv since round 5: plan.hip forward3d)
   const PackJob& jb = b.j[blockIdx.y];
   const float* src = params + jb.src_off;
   T* dst = reinterpret_cast<T*>(ws + jb.dst_off);

@@ -1513,30 +1513,51 @@ static int forward3d(hdf_plan* p, const float* x, const float* params, void* wor
       if (armed) (void)e.join_branch(eb);
     }
   } rejoin{e, eb, bst != nullptr};
-  // the fork sits in front of the weight pack: the token kernels read the fp32 parameters themselves, only the branch's
-  // convs (deep_conv, up1..3) wait for the packed panels
-  HDF_TRY(hdf_launch_pack_batch(p->dtype, params, e.ws, p->pack_jobs.data(), (int)p->pack_jobs.size(), e.st));
-  // ... and the persistent transformer kernel's fragment-major weight copies: on this stream too, i.e. next to the patch
-  // embedding of the branch stream instead of in front of the chain kernel on its critical path
-  if (tf_use_chain(p, batch))
-    HDF_TRY(tf_chain_pack(tf_dims(p, batch), tf_chain_params(p), p->nb, params, e.ws + p->tf_wpack, e.st));
-  hipEvent_t packed = nullptr;
-  if (bst) {
-    packed = e.next_event();
-    if (!packed || hipEventRecord(packed, e.st) != hipSuccess) {
-      hdf_set_error("branch stream: event failed");
-      return HDF_ERR_HIP;
-    }
-  }
-  // the caller's stream first (4 launches), then the ~65 launches of the branch: the host issues launches one after the
-  // other, and whatever is issued second starts that much later when the host is not far ahead of the GPU
 #ifdef HDF_NO_FUSED_AT3  // A/B builds
   const bool fused_at3 = false;
 #else
   const bool fused_at3 = true;
 #endif
-  HDF_TRY(hdf_launch_nchw_to_ndhwc(p->dtype, x, e.at(p->xin), batch, p->M, 16, p->vox(0), e.st));
-  HDF_TRY(conv_forward(e, p->enc[0][0], p->xin, none));
+  // (round 5) Order of the first launches.  The first level-0 conv reads the fp32 weights itself (csrc/conv_first.hip) and
+  // needs only the converted input, so where that kernel takes the layer the caller's stream starts with conversion +
+  // conv, and the weight packs -- every conv's 16-bit panels and the persistent transformer kernel's fragment-major copies,
+  // ~80 us of light kernels -- go to the BRANCH stream in front of the patch embedding: the conv runs beside them instead
+  // of behind them, and the transformer kernel (which holds every unit and therefore effectively starts when that conv
+  // ends) starts ~120 us earlier.  `packed` orders the second conv (and the branch's own convs, by stream order) behind the
+  // packs.  Without a branch stream, or where the generic conv takes the first layer, the packs stay in front.
+#if defined(HDF_NO_CONV_FIRST) || defined(HDF_NO_PACK_ON_BRANCH)
+  const bool first_direct = false;
+#else
+  const bool first_direct = bst && p->enc[0][0].Cin <= 4 &&
+                            hdf_conv_first_takes(p->dtype, p->enc[0][0].Cin, p->enc[0][0].Cout, p->dims[0][0], p->dims[0][1],
+                                                 p->dims[0][2], p->xin.pitch);
+#endif
+  hipStream_t pst = first_direct ? bst : e.st;
+  if (first_direct) {
+    HDF_TRY(hdf_launch_nchw_to_ndhwc(p->dtype, x, e.at(p->xin), batch, p->M, 16, p->vox(0), e.st));
+    HDF_TRY(conv_forward(e, p->enc[0][0], p->xin, none));
+  }
+  HDF_TRY(hdf_launch_pack_batch(p->dtype, params, e.ws, p->pack_jobs.data(), (int)p->pack_jobs.size(), pst));
+  if (tf_use_chain(p, batch))
+    HDF_TRY(tf_chain_pack(tf_dims(p, batch), tf_chain_params(p), p->nb, params, e.ws + p->tf_wpack, pst));
+  hipEvent_t packed = nullptr;
+  if (bst) {
+    packed = e.next_event();
+    if (!packed || hipEventRecord(packed, pst) != hipSuccess) {
+      hdf_set_error("branch stream: event failed");
+      return HDF_ERR_HIP;
+    }
+    if (first_direct && hipStreamWaitEvent(e.st, packed, 0) != hipSuccess) {
+      hdf_set_error("branch stream: wait failed");
+      return HDF_ERR_HIP;
+    }
+  }
+  // the caller's stream first (4 launches), then the ~65 launches of the branch: the host issues launches one after the
+  // other, and whatever is issued second starts that much later when the host is not far ahead of the GPU
+  if (!first_direct) {
+    HDF_TRY(hdf_launch_nchw_to_ndhwc(p->dtype, x, e.at(p->xin), batch, p->M, 16, p->vox(0), e.st));
+    HDF_TRY(conv_forward(e, p->enc[0][0], p->xin, none));
+  }
   // (round 5) The second level-0 conv takes three quarters of the compute units: it runs while the branch stream works
   // through deep_conv / up1..3 (the persistent transformer kernel in front of them holds every unit, so the order on
   // the device is conv_first, transformer, then this conv NEXT TO the UpConv chain), and the chain's low-resolution
@@ -1545,13 +1566,25 @@ static int forward3d(hdf_plan* p, const float* x, const float* params, void* wor
   // at3 ready 85 us earlier (tools/timeline.py, profiles/r05_forward_timeline.txt).  The grid is the same in every
   // stream arrangement: the InstanceNorm partial sums are grouped per workgroup, and tests/test_gpu_knobs.py compares
   // arrangements bit for bit.  HDF_NO_L0_BUDGET: A/B builds.
+  // With the persistent transformer kernel the device order conv_first -> transformer -> this conv is made explicit: the
+  // kernel needs every unit, and this conv's 192 workgroups in front of it would leave it spinning on the other 64 for the
+  // conv's whole duration.  (The launch chain of small kernels co-runs with the conv instead: no wait.)
+  const bool chain_first = first_direct && tf_use_chain(p, batch);
+  eb.tf_packed = first_direct ? nullptr : packed;   // (packs on the branch stream itself: stream order)
+  if (chain_first) {
+    HDF_TRY(transformer_forward(eb, x));
+    hipEvent_t tf_done = e.next_event();
+    if (!tf_done || hipEventRecord(tf_done, bst) != hipSuccess || hipStreamWaitEvent(e.st, tf_done, 0) != hipSuccess) {
+      hdf_set_error("branch stream: event failed");
+      return HDF_ERR_HIP;
+    }
+  }
 #ifndef HDF_NO_L0_BUDGET
   e.conv_budget = (hdf_cu_budget() * 3 / 4) & ~7;
 #endif
   HDF_TRY(conv_forward(e, p->enc[0][1], p->enc[0][0].y, xf_of(e, p->enc[0][0])));
   e.conv_budget = 0;
-  eb.tf_packed = packed;
-  HDF_TRY(transformer_forward(eb, x));
+  if (!chain_first) HDF_TRY(transformer_forward(eb, x));
   if (packed && hipStreamWaitEvent(bst, packed, 0) != hipSuccess) {
     hdf_set_error("branch stream: wait failed");
     return HDF_ERR_HIP;

@@ -108,6 +108,7 @@ __device__ __forceinline__ TfOutP chain_out(const ChainW& cw, float* base, int b
 // float4 <- W[g OQ + s0 + 4 j + e][n0 + i].
 __global__ __launch_bounds__(256) void tf_chain_pack_kernel(ChainW cw, const float* __restrict__ params, int64_t mstride,
                                                             int DM, int nl, float4* __restrict__ wpack) {
+  HDF_LIGHT_PRIO();   // (runs beside the first level-0 conv since round 5: plan.hip forward3d)
   const int m = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
   const int DMF = DM + 128, M = gridDim.y, nb = nl >> 2;
