@@ -378,7 +378,8 @@ def main():
                        "collective": (torch.distributed.get_backend() if dist_on else None)},
             "step_tflops": FWD_BWD_GFLOP_PER_SAMPLE * sps / 1e3,
             "hip_event_ms_per_step": {"median": median_ms, "min": per_step[0], "max": per_step[-1],
-                                      "slowest_step": raw_steps.index(per_step[-1])},
+                                      "slowest_step": raw_steps.index(per_step[-1]),
+                                      "all": [round(v, 3) for v in raw_steps]},
             "host_issue_ms_per_step": t_enqueued / a.steps * 1e3,
         }
         if world == 1 and not a.no_roofline:
