@@ -34,6 +34,13 @@ def test_the_library_holds_the_expected_kernel_families(ks):
     assert len(ks) >= 240
     for fam in NO_SCRATCH + ("conv_wr_kernel", "tf_chain_bwd_kernel"):
         assert any(n.startswith(fam) for n in ks), fam
+    # round 5: the weight gradients that carry the second InstanceNorm-backward pass (16-bit storage, with and without the
+    # large operand's transform), and only the routed conv_wr instantiation per storage type
+    for T in ("bf16_t", "f16_t"):
+        for xfl in ("true", "false"):
+            assert "conv_wgrad2_kernel<%s, %s, true>" % (T, xfl) in ks
+    assert sorted(n for n in ks if n.startswith("conv_wr_kernel")) == [
+        "conv_wr_kernel<bf16_t, 128, 1, 2, 4, false>", "conv_wr_kernel<f16_t, 128, 1, 2, 4, false>"]
 
 
 @pytest.mark.parametrize("family", NO_SCRATCH)
