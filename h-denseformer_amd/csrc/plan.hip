@@ -1236,12 +1236,14 @@ int conv_backward(Exec& e, Conv3& c, const View& dy, const View& in, Xf xf, cons
 // Measured (round 5, same box, interleaved, bench geometry):
 //   one stream, sum of kernel times: -0.27 ms with every level fused (apply -0.60 ms, weight gradients +0.33 ms: the pass
 //     costs ~400 VALU instructions per tile and wave in a kernel with ONE wave per SIMD);
-//   the step as shipped (three streams): fused at 128^3 only 10.88 ms, not fused 10.90 ms, fused at >= 64^3 11.06 ms
-//     (6 rounds each).  The stand-alone pass is HBM-bound and ran UNDER the matrix kernels of the other streams; fused, its
-//     work sits in the matrix kernels' instruction stream, and the data gradient waits for the weight gradient (i.e. for
-//     whatever the side stream still holds).
-// So the default fuses the 128^3 layers only (0.8 GB of the step's HBM traffic and three launches less at the same step
-// time); HDF_FUSED_APPLY_MIN_VOX (environment, voxels per sample) moves the threshold, HDF_NO_FUSED_APPLY switches the
+//   the step (three streams), when this was built: fused at 128^3 only 10.88 ms, not fused 10.90 ms, fused at >= 64^3
+//     11.06 ms (6 rounds each); under the round's final schedule (light kernels prioritised, forward reordered): 10.42 vs
+//     10.55 vs 10.60 ms, and 10.83 ms at >= 32^3 (7-8 rounds each, medians).  The stand-alone pass is HBM-bound and runs
+//     UNDER the matrix kernels of the other streams; fused, its work sits in the matrix kernels' instruction stream, and the
+//     data gradient waits for the weight gradient (i.e. for whatever the side stream still holds) -- at 128^3 x 32 channels
+//     the saved traffic wins, at the smaller levels (more channels: every voxel's pass is redone per large-channel block) it
+//     does not.
+// So the default fuses the 128^3 layers only (0.8 GB of the step's HBM traffic and three launches less, -0.13 ms); HDF_FUSED_APPLY_MIN_VOX (environment, voxels per sample) moves the threshold, HDF_NO_FUSED_APPLY switches the
 // fused form off.  The UpConv chain on the branch stream (the critical path) always keeps the stand-alone pass.
 static int64_t fused_apply_min_vox() {
   static const int64_t v = [] {
