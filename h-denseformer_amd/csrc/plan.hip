@@ -2232,6 +2232,40 @@ int hdf_op_in_bwd(int dtype, const void* da, int64_t da_pitch, const void* y, in
   return hdf_launch_in_bwd_apply(dtype, da, da_pitch, y, y_pitch, scale, shift, mean, rstd, k1, ka, kb, dy, dy_pitch, N,
                                  C, voxels, st);
 }
+int hdf_op_in_bwd_wgrad(int dtype, const void* da, int64_t da_pitch, const void* y, int64_t y_pitch, const float* scale,
+                        const float* shift, const float* mean, const float* rstd, const float* gamma, void* dy,
+                        int64_t dy_pitch, float* dgamma, float* dbeta, const void* x, int64_t x_pitch, int Cin,
+                        const float* x_scale, const float* x_shift, int x_relu, int N, int Cout, int D, int H, int W,
+                        float* dw, float* workspace, void* wgrad_workspace, int64_t wgrad_workspace_bytes,
+                        hdf_stream stream) {
+  HDF_CHECK_ARG(da && y && scale && shift && mean && rstd && dy && x && dw && workspace && wgrad_workspace,
+                "in_bwd_wgrad: null argument");
+  const int64_t voxels = (int64_t)D * H * W;
+  const int blocks = hdf_in_bwd_blocks(voxels, Cout);
+  float* partials = workspace;
+  float* k1 = workspace + (int64_t)N * blocks * Cout * 2;
+  float* ka = k1 + (int64_t)N * Cout;
+  float* kb = ka + (int64_t)N * Cout;
+  hipStream_t st = (hipStream_t)stream;
+  WgradArgs w{};
+  w.sm = da, w.sm_pitch = da_pitch, w.SC = Cout;
+  w.lg = x, w.lg_pitch = x_pitch, w.LC = Cin;
+  w.N = N;
+  w.Ds = w.Dl = D, w.Hs = w.Hl = H, w.Ws = w.Wl = W;
+  w.lg_scale = x_scale, w.lg_shift = x_shift, w.lg_relu = x_relu;
+  w.ap_y = y, w.ap_y_pitch = y_pitch, w.ap_out = dy, w.ap_out_pitch = dy_pitch;
+  w.ap_tab[0] = scale, w.ap_tab[1] = shift, w.ap_tab[2] = mean, w.ap_tab[3] = rstd;
+  w.ap_tab[4] = k1, w.ap_tab[5] = ka, w.ap_tab[6] = kb;
+  if (!hdf_wgrad_apply_takes(dtype, 1, w)) {
+    hdf_set_error("in_bwd_wgrad: the fused kernel does not take this launch (dtype %d, %d -> %d channels, %dx%dx%d)", dtype,
+                  Cin, Cout, D, H, W);
+    return HDF_ERR_UNSUPPORTED;
+  }
+  HDF_TRY(hdf_launch_in_bwd_reduce(dtype, da, da_pitch, y, y_pitch, scale, shift, mean, rstd, partials, blocks, N, Cout,
+                                   voxels, st));
+  HDF_TRY(hdf_launch_in_bwd_finalize(partials, blocks, N, Cout, voxels, gamma, rstd, k1, ka, kb, dgamma, dbeta, st));
+  return hdf_launch_wgrad(dtype, 1, w, dw, Cout, Cin, 0, wgrad_workspace, (size_t)wgrad_workspace_bytes, st);
+}
 int hdf_op_norm_relu_add(int dtype, const void* y, int64_t y_pitch, const float* scale, const float* shift,
                          const void* skip, int64_t skip_pitch, void* out, int64_t out_pitch, int N, int C,
                          int64_t voxels, hdf_stream stream) {

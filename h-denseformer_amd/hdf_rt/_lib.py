@@ -72,6 +72,8 @@ _PROTOS = {
     "hdf_op_in_bwd": (_i, [_i, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _i, _i64, _vp,
                            _vp]),
     "hdf_op_wgrad_workspace_bytes": (_i64, [_i, _i, _i, _i, _i, _i, _i]),
+    "hdf_op_in_bwd_wgrad": (_i, [_i, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i,
+                                 _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i64, _vp]),
     "hdf_op_conv3d_wgrad": (_i, [_i, _i, _vp, _i64, _i, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i,
                                  _vp, _i, _i, _i, _vp, _i64, _vp]),
     "hdf_op_in_finalize": (_i, [_vp, _i, _i, _i, _i, _i64, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),

@@ -262,6 +262,19 @@ int hdf_op_in_bwd(int dtype, const void* da, int64_t da_pitch, const void* y, in
                   const float* shift, const float* mean, const float* rstd, const float* gamma, void* dy,
                   int64_t dy_pitch, float* dgamma, float* dbeta, int N, int C, int64_t voxels, float* workspace,
                   hdf_stream stream);
+/* The same backward with its second pass INSIDE the layer's weight gradient (round 5; 16-bit storage, Conv3d k3 s1 p1;
+ * reference: models/HDenseFormer.py:148-159 backward): the reduce + finalize passes of hdf_op_in_bwd, then ONE launch that
+ * applies the second pass to the rows of d(activation) it stages, writes dy (bit-identical to hdf_op_in_bwd's) and
+ * contracts it with the layer's input x -- optionally x -> relu(x * x_scale + x_shift), [N][Cin] -- into
+ * dw [Cout][Cin][27] (bit-identical to hdf_op_conv3d_wgrad on that dy).  What hdf_backward does for the 128^3 layers.
+ * HDF_ERR_UNSUPPORTED where the fused kernel does not take the launch (fp32 storage, tensors of 2 GiB and more).
+ * workspace: hdf_op_in_bwd_workspace_floats(N, Cout, D*H*W) floats; wgrad_workspace: hdf_op_wgrad_workspace_bytes(1, ...). */
+int hdf_op_in_bwd_wgrad(int dtype, const void* da, int64_t da_pitch, const void* y, int64_t y_pitch, const float* scale,
+                        const float* shift, const float* mean, const float* rstd, const float* gamma, void* dy,
+                        int64_t dy_pitch, float* dgamma, float* dbeta, const void* x, int64_t x_pitch, int Cin,
+                        const float* x_scale, const float* x_shift, int x_relu, int N, int Cout, int D, int H, int W,
+                        float* dw, float* workspace, void* wgrad_workspace, int64_t wgrad_workspace_bytes,
+                        hdf_stream stream);
 int hdf_op_norm_relu_add(int dtype, const void* y, int64_t y_pitch, const float* scale, const float* shift,
                          const void* skip, int64_t skip_pitch, void* out, int64_t out_pitch, int N, int C,
                          int64_t voxels, hdf_stream stream);

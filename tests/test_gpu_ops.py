@@ -647,6 +647,70 @@ def test_instance_norm_relu_backward(dtype, n, c, size):
     assert rel_err(dg.cpu(), gamma.grad) < 2e-3 and rel_err(db.cpu(), beta.grad) < 2e-3
 
 
+@pytest.mark.parametrize("dtype", [BF16, F16])
+@pytest.mark.parametrize("xf", [False, True])
+@pytest.mark.parametrize("n,cin,cout,size", [(2, 32, 32, (16, 16, 24)),     # whole tiles, interior + border passes
+                                            (1, 64, 32, (20, 18, 26)),     # ragged extents, two large-channel blocks
+                                            (2, 32, 48, (12, 17, 9)),      # partial small-channel block (n_filters 48)
+                                            (3, 48, 64, (8, 8, 16))])      # odd batch, two small-channel blocks
+def test_instance_norm_backward_inside_the_weight_gradient(dtype, xf, n, cin, cout, size):
+    """hdf_op_in_bwd_wgrad (conv_wgrad2_kernel<., ., true>: the second InstanceNorm-backward pass applied while the weight
+    gradient stages d(activation), dy written as its by-product) against the unfused pair hdf_op_in_bwd + hdf_op_conv3d_wgrad
+    on the same operands: dy and dw BIT FOR BIT; and dw against torch autograd of
+    conv3d(relu(IN(.))) -> relu(IN(y)) loosely (the unfused ops carry the tight comparison).  Reference:
+    models/HDenseFormer.py:148-159 backward."""
+    vox = size[0] * size[1] * size[2]
+    y = rnd(_mk((n, cout) + size, 51), dtype)
+    da = rnd(_mk((n, cout) + size, 52), dtype)
+    x = rnd(_mk((n, cin) + size, 53), dtype)
+    gamma, beta = _mk((cout,), 54) * 0.3 + 1.0, _mk((cout,), 55) * 0.2
+    mean = y.mean((2, 3, 4))
+    rstd = (y.var((2, 3, 4), unbiased=False) + 1e-5).rsqrt()
+    scale = (gamma[None] * rstd).contiguous()
+    shift = (beta[None] - mean * scale).contiguous()
+    xs, xh = (_mk((n, cin), 56) * 0.5 + 1.0, _mk((n, cin), 57) * 0.3) if xf else (None, None)
+    dev = [t.to(DEV).contiguous() for t in (scale, shift, mean, rstd, gamma)]
+    da_cl, y_cl, x_cl = to_cl(da, dtype), to_cl(y, dtype), to_cl(x, dtype)
+    xs_d, xh_d = (xs.to(DEV), xh.to(DEV)) if xf else (None, None)
+    ws = torch.empty(lib().hdf_op_in_bwd_workspace_floats(n, cout, vox), device=DEV)
+    wsb = lib().hdf_op_wgrad_workspace_bytes(1, n, *size, cout, cin)
+    wws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+
+    def run(fused):
+        dy = torch.full((n,) + size + (cout,), 7.0, dtype=y_cl.dtype, device=DEV)
+        dg, db = torch.zeros(cout, device=DEV), torch.zeros(cout, device=DEV)
+        dw = torch.zeros((cout, cin, 27), dtype=torch.float32, device=DEV)
+        if fused:
+            check(lib().hdf_op_in_bwd_wgrad(dtype, ptr(da_cl), cout, ptr(y_cl), cout, ptr(dev[0]), ptr(dev[1]), ptr(dev[2]),
+                                            ptr(dev[3]), ptr(dev[4]), ptr(dy), cout, ptr(dg), ptr(db), ptr(x_cl), cin, cin,
+                                            ptr(xs_d), ptr(xh_d), 1 if xf else 0, n, cout, *size, ptr(dw), ptr(ws),
+                                            ptr(wws), wsb, st()), "in_bwd_wgrad")
+        else:
+            check(lib().hdf_op_in_bwd(dtype, ptr(da_cl), cout, ptr(y_cl), cout, ptr(dev[0]), ptr(dev[1]), ptr(dev[2]),
+                                      ptr(dev[3]), ptr(dev[4]), ptr(dy), cout, ptr(dg), ptr(db), n, cout, vox, ptr(ws),
+                                      st()), "in_bwd")
+            check(lib().hdf_op_conv3d_wgrad(dtype, 1, ptr(dy), cout, cout, ptr(x_cl), cin, cin, n, *size, None, None, 0,
+                                            ptr(xs_d), ptr(xh_d), 1 if xf else 0, ptr(dw), cout, cin, 0, ptr(wws), wsb,
+                                            st()), "wgrad")
+        torch.cuda.synchronize()
+        return dy, dg, db, dw
+
+    dy0, dg0, db0, dw0 = run(False)
+    dy1, dg1, db1, dw1 = run(True)
+    assert torch.equal(dy0.view(torch.int16), dy1.view(torch.int16))
+    assert torch.equal(dw0, dw1)
+    # (dgamma / dbeta are summed over the samples with float atomics: the same reduce + finalize launches in both runs)
+    assert rel_err(dg1.cpu(), dg0.cpu()) < 1e-6 and rel_err(db1.cpu(), db0.cpu()) < 1e-6
+    # and against autograd (storage-rounded operands, fp32 arithmetic)
+    yt = y.clone().requires_grad_(True)
+    act = torch.relu(F.instance_norm(yt, weight=gamma, bias=beta, eps=1e-5))
+    act.backward(da)
+    xin = torch.relu(x * xs[:, :, None, None, None] + xh[:, :, None, None, None]) if xf else x
+    w = torch.zeros(cout, cin, 3, 3, 3, requires_grad=True)
+    F.conv3d(rnd(xin, dtype), w, None, padding=1).backward(rnd(yt.grad, dtype))
+    assert rel_err(dw1.cpu().view(cout, cin, 3, 3, 3), w.grad) < 3 * TOL[dtype]
+
+
 @pytest.mark.parametrize("dtype,c", [(F32, 16), (BF16, 32), (F16, 32)])
 @pytest.mark.parametrize("n,size", [(2, (32, 32, 32)), (1, (33, 38, 41))])
 def test_upsample_bwd_large_pitched_vs_autograd(dtype, c, n, size):
