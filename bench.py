@@ -117,36 +117,67 @@ def conv_source_digest():
 
 # The stride-1 convolution launches of one training step that run conv_ws2_kernel (csrc/conv_igemm.hip): forward and data
 # gradient of every 3x3x3 layer at 128^3 / 64^3 with <= 64 input channels, minus the first layer (conv_first_kernel) and
-# block_1_1_right's forward (conv_wr_kernel).  (cin, cout, size): reference layers models/HDenseFormer.py:196-221,190-194.
+# block_1_1_right's forward (conv_wr_kernel).  (cin, cout, size, form): reference layers models/HDenseFormer.py:196-221,
+# 190-194.  `form` selects the INSTANTIATION the step runs (round 6, VERDICT r05 #2: the round-5 replay ran every shape
+# through the plain form and reported 0.39 where the step's own launches ran at 0.35):
+#   "xf"    input transform on the way into LDS (the producer's InstanceNorm + ReLU): conv_ws2_kernel<.., XF=true, ..>
+#   "bs"    data gradient with the next InstanceNorm backward's first pass in its epilogue: <.., BS=true> (hdf_op_conv3d_bwd_stats)
+#   "split" data gradient of a decoder concat: two dense output halves (hdf_op_conv3d_split)
+#   "acc"   data gradient that adds into the skip gradient (the UpConv chain)
+#   ""      the plain form
 WS2_FAMILY = [
-    (32, 32, 128), (32, 32, 128),                                        # block_1_2_left, block_1_2_right forward
-    (32, 64, 64), (64, 64, 64), (64, 64, 64), (64, 32, 64),              # block_2_1_left, block_2_2_left/right, up3 forward
-    (32, 32, 128), (32, 32, 128), (32, 64, 128),                         # data gradients at 128^3 (1_2_left, 1_2_right, 1_1_right)
-    (64, 32, 64), (64, 64, 64), (64, 64, 64), (64, 128, 64), (32, 64, 64),   # data gradients at 64^3
+    (32, 32, 128, "xf"), (32, 32, 128, "xf"),                            # block_1_2_left, block_1_2_right forward
+    (32, 64, 64, ""), (64, 64, 64, "xf"), (64, 64, 64, "xf"), (64, 32, 64, ""),   # block_2_1_left, block_2_2_left/right, up3 forward
+    (32, 32, 128, "bs"), (32, 32, 128, "bs"), (32, 64, 128, "split"),    # data gradients at 128^3 (1_2_right, 1_2_left, 1_1_right)
+    (64, 32, 64, ""), (64, 64, 64, ""), (64, 64, 64, ""), (64, 128, 64, "split"), (32, 64, 64, "acc"),   # data gradients at 64^3
 ]
+ROOFLINE_SCHEMA = 3   # 1: one conv launch (rounds 1-4); 2: the family through the plain form (round 5); 3: the family through
+                      # the step's own instantiations (this file)
 
 
 def roofline_conv_family(dev, passes=6):
     """Live HIP-event timing of the kernel family with the largest share of the step (profiles/*_step_kernel_table.txt):
-    conv_ws2_kernel, 14 launches per step.  One pass = those 14 GEMM shapes back to back through hdf_op_conv3d (the plan's
-    own routing); achieved = their algorithmic FLOPs (2*27*Cin*Cout*voxels*batch) / the time of a pass."""
+    conv_ws2_kernel, 14 launches per step.  One pass = those 14 launches back to back, each through the operator entry
+    that reaches the instantiation the step runs for it (WS2_FAMILY); achieved = their algorithmic FLOPs
+    (2*27*Cin*Cout*voxels*batch) / the time of a pass."""
     from hdf_rt._lib import BF16, check, lib, ptr
     n = 2
     st = torch.cuda.current_stream().cuda_stream
     bufs = {}
-    for cin, cout, s in set(WS2_FAMILY):
+    for cin, cout, s, form in set(WS2_FAMILY):
         x = torch.randn(n, s, s, s, cin, device=dev).to(torch.bfloat16)
         w = (torch.randn(27 * ((cout + 31) // 32 * 32) * cin, device=dev) * 0.02).to(torch.bfloat16)
-        out = torch.empty(n, s, s, s, cout, device=dev, dtype=torch.bfloat16)
+        out = torch.zeros(n, s, s, s, cout, device=dev, dtype=torch.bfloat16)
         tiles = lib().hdf_op_conv3d_stat_tiles(BF16, cin, s, s, s)
-        part = torch.empty(n * tiles * ((cout + 31) // 32 * 32) * 2, device=dev)
-        bufs[(cin, cout, s)] = (x, w, out, part)
+        part = torch.empty(max(n * tiles, 1024) * ((cout + 31) // 32 * 32) * 2, device=dev)
+        extra = None
+        if form == "xf":
+            extra = (torch.rand(n * cin, device=dev) + 0.5, torch.randn(n * cin, device=dev) * 0.1)
+        elif form == "bs":
+            extra = (torch.randn(n, s, s, s, cout, device=dev).to(torch.bfloat16), torch.rand(n * cout, device=dev) + 0.5,
+                     torch.randn(n * cout, device=dev) * 0.1, torch.randn(n * cout, device=dev) * 0.1,
+                     torch.rand(n * cout, device=dev) + 0.5)
+        bufs[(cin, cout, s, form)] = (x, w, out, part, extra)
 
     def one_pass():
-        for cin, cout, s in WS2_FAMILY:
-            x, w, out, part = bufs[(cin, cout, s)]
-            check(lib().hdf_op_conv3d(BF16, 0, ptr(x), cin, cin, n, s, s, s, ptr(w), None, None, None, 0, ptr(out), cout,
-                                      cout, ptr(part), 0, st), "conv")
+        for key in WS2_FAMILY:
+            cin, cout, s, form = key
+            x, w, out, part, extra = bufs[key]
+            if form == "xf":
+                check(lib().hdf_op_conv3d(BF16, 0, ptr(x), cin, cin, n, s, s, s, ptr(w), None, ptr(extra[0]), ptr(extra[1]), 1,
+                                          ptr(out), cout, cout, ptr(part), 0, st), "conv xf")
+            elif form == "bs":
+                y, sc, sh, mu, rs = extra
+                check(lib().hdf_op_conv3d_bwd_stats(BF16, ptr(x), cin, cin, n, s, s, s, ptr(w), ptr(out), cout, cout, ptr(y),
+                                                    cout, ptr(sc), ptr(sh), ptr(mu), ptr(rs), ptr(part), st), "conv bs")
+            elif form == "split":
+                half = cout // 2
+                o2 = out.view(-1)[out.numel() // 2:]
+                check(lib().hdf_op_conv3d_split(BF16, ptr(x), cin, cin, n, s, s, s, ptr(w), ptr(out), ptr(o2), half, cout,
+                                                half, ptr(part), None, 0, st), "conv split")
+            else:
+                check(lib().hdf_op_conv3d(BF16, 0, ptr(x), cin, cin, n, s, s, s, ptr(w), None, None, None, 0, ptr(out), cout,
+                                          cout, ptr(part), 1 if form == "acc" else 0, st), "conv")
     for _ in range(3):
         one_pass()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -156,11 +187,15 @@ def roofline_conv_family(dev, passes=6):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / passes
-    flops = sum(2.0 * 27 * cin * cout * (s ** 3) * n for cin, cout, s in WS2_FAMILY)
-    byt = sum(2.0 * n * s ** 3 * (cin + cout) for cin, cout, s in WS2_FAMILY)
+    flops = sum(2.0 * 27 * cin * cout * (s ** 3) * n for cin, cout, s, _f in WS2_FAMILY)
+    byt = sum(2.0 * n * s ** 3 * (cin + cout) for cin, cout, s, _f in WS2_FAMILY)
     achieved = flops / (ms * 1e-3) / 1e12
     return {"bound": "mfma", "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": None,
+            "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": None, "schema": ROOFLINE_SCHEMA,
+            "frac_definition": "algorithmic FLOPs of the 14 conv_ws2_kernel launches of a step / the HIP-event time of one "
+                               "back-to-back pass over them, each launch in the instantiation the step runs (input "
+                               "transform, statistics epilogue, split / accumulating outputs) / 2.5 PF; rounds 1-4 reported "
+                               "the single conv_wr launch (now roofline.wr), round 5 the plain-form replay",
             "kernel": "conv_ws2_kernel family: the 14 stride-1 3x3x3 conv launches (forward + data gradient, 128^3 / 64^3, "
                       "batch 2) of one training step -- the family with the largest share of the step's kernel time",
             "launches_per_pass": len(WS2_FAMILY), "pass_ms": ms, "avg_launch_ms": ms / len(WS2_FAMILY),
@@ -170,17 +205,22 @@ def roofline_conv_family(dev, passes=6):
 def step_roofline_from_profile():
     """roofline.step: algorithmic FLOPs of all matrix-core conv kernels of a step / their summed one-stream time / peak, from
     the newest committed profile set (tools/profile_summarise.py writes profiles/*_step_roofline.json); not measurable
-    live (it needs a one-stream kernel trace)."""
+    live (it needs a one-stream kernel trace).  Emitted only when that profile was taken on THIS build's conv kernels
+    (conv_source_digest); otherwise null plus the reason (a stale fraction next to live numbers)."""
     best = None
     for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
         if name.endswith("_step_roofline.json"):
             best = name
             break
     if best is None:
-        return None
+        return None, "no profiles/*_step_roofline.json"
     rec = json.load(open(os.path.join(ROOT, "profiles", best)))
+    if rec.get("conv_source_digest") != conv_source_digest():
+        return None, ("profiles/%s was taken on other conv kernel sources (digest %s, this build %s): not reported"
+                      % (best, str(rec.get("conv_source_digest"))[:12], conv_source_digest()[:12]))
     rec["source"] = "profiles/" + best
-    return rec
+    rec["from_committed_profile"] = True
+    return rec, None
 
 
 def roofline_dominant_kernel(dev):
@@ -258,7 +298,9 @@ def main():
         dev0 = torch.device("cuda", 0)
         r = roofline_conv_family(dev0)
         r["wr"] = roofline_dominant_kernel(dev0)
-        r["step"] = step_roofline_from_profile()
+        r["step"], why = step_roofline_from_profile()
+        if why:
+            r["step_unavailable"] = why
         print(json.dumps({"roofline": r}), flush=True)
         return
 
@@ -385,13 +427,21 @@ def main():
         if world == 1 and not a.no_roofline:
             wr = roofline_dominant_kernel(dev)
             rec["roofline"] = roofline_conv_family(dev)
-            rec["roofline"]["step"] = step_roofline_from_profile()
+            rec["roofline"]["step"], why = step_roofline_from_profile()
+            if why:
+                rec["roofline"]["step_unavailable"] = why
+                log("roofline.step:", why)
             rec["roofline"]["wr"] = wr      # the single conv_wr_kernel launch of a step (rounds 1-4 reported this one)
-            # HBM bytes of the family's 14 launches from the committed PMC passes of the same build (else null)
+            # HBM bytes of the family's 14 launches from the committed PMC passes of the same build (else null), and the
+            # family's fraction INSIDE the step (one-stream kernel trace of the same build) next to the live replay
             stp = rec["roofline"]["step"]
-            if stp and stp.get("conv_source_digest") == conv_source_digest():
-                rec["roofline"]["traffic"] = stp.get("families", {}).get("conv_ws2_kernel", {}).get("hbm_bytes") or None
+            if stp:
+                fam = stp.get("families", {}).get("conv_ws2_kernel", {})
+                rec["roofline"]["traffic"] = fam.get("hbm_bytes") or None
                 rec["roofline"]["traffic_source"] = stp["source"]
+                if fam.get("us_1s"):
+                    rec["roofline"]["frac_in_step_profile"] = (rec["roofline"]["flops_per_pass"] / (fam["us_1s"] * 1e-6) / 1e12
+                                                               / BF16_MFMA_PEAK_TFLOPS)
             if in_step_ms:
                 # the same launch as it runs inside the timed steps (HIP events recorded by the library around it, one
                 # pair per step): `frac` above stays the back-to-back figure of the earlier rounds, this is what the

@@ -9,6 +9,7 @@
 #define HDF_ERR_ARG 1
 #define HDF_ERR_HIP 2
 #define HDF_ERR_UNSUPPORTED 3
+#define HDF_ERR_CHAIN_TIMEOUT 4   // a persistent transformer launch of an earlier call gave up (see include/hdf.h)
 
 enum { HDF_F32 = 0, HDF_BF16 = 1, HDF_F16 = 2 };
 static inline int hdf_esz(int dtype) { return dtype == HDF_F32 ? 4 : 2; }  // bytes per stored activation element

@@ -19,7 +19,23 @@ static thread_local char g_err[1024] = "";
 // process-wide (relaxed atomic): forward runs on the caller's thread and backward on autograd's worker thread, and both
 // must size their grids -- and take their split-K decisions -- from the same value
 static std::atomic<int> g_cu_budget{256};
-int hdf_cu_budget() { return g_cu_budget.load(std::memory_order_relaxed); }
+// The budget is capped by what the CURRENT DEVICE has (round 6): on a partitioned MI355X (DPX / QPX / CPX: 128 /
+// 64 / 32 compute units) or any smaller gfx950 part a literal 256 let the persistent transformer kernels -- whose
+// per-sequence barriers need every workgroup resident at once -- launch a grid that could never be resident together.
+// hdf_set_cu_budget stays a DOWNWARD override.  No device (CPU-only layout queries): the literal.
+static int device_cus() {
+  static std::atomic<int> cache[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+  int v = cache[dev].load(std::memory_order_relaxed);
+  if (v > 0) return v;
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
+  if (n >= 8) n &= ~7;   // grids of the persistent conv kernels are split over the 8 XCDs
+  cache[dev].store(n, std::memory_order_relaxed);
+  return n;
+}
+int hdf_cu_budget() { return std::min(g_cu_budget.load(std::memory_order_relaxed), device_cus()); }
 
 void hdf_set_error(const char* fmt, ...) {
   va_list ap;
@@ -204,7 +220,19 @@ struct hdf_plan {
   hipEvent_t bucket_ev[3] = {nullptr, nullptr, nullptr};
   // hdf_plan_set_probe: caller-owned events recorded around the dominant conv launch of the forward (measurement only)
   hipEvent_t probe_start = nullptr, probe_stop = nullptr;
+  // Persistent transformer kernels (transformer_chain.hip).  chain_flag: one host-mapped word a launch writes (system
+  // scope) when one of its per-sequence barriers gives up; read by the next forward / backward call of the plan without
+  // synchronising (chain_flag_check).  chain_off: sticky -- after a give-up the plan runs the launch chain.
+  // tf_fwd_chain: which arrangement the LAST forward ran; its backward follows it (the operand records and the
+  // fragment-major weight copies of the persistent backward exist only behind a persistent forward).
+  unsigned* chain_flag = nullptr;      // host address
+  unsigned* chain_flag_dev = nullptr;  // device address of the same word
+  bool chain_off = false;
+  bool tf_fwd_chain = false;
+  unsigned chain_last_giveup = 0;      // 1 + workgroup id of the last give-up seen (hdf_plan_chain_state)
+  unsigned chain_ticks = 150000000u;   // deadline of one barrier wait, 100 MHz ticks (hdf_plan_set_chain_timeout_us)
   ~hdf_plan() {
+    if (chain_flag) (void)hipHostFree(chain_flag);
     for (hipEvent_t ev : bucket_ev)
       if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : events) (void)hipEventDestroy(ev);
@@ -592,9 +620,11 @@ void layout(hdf_plan* p, int B) {
   p->inb_k2 = bp.take((size_t)3 * B * 8 * nf * sizeof(float));
   p->inb_k3 = bp.take((size_t)3 * B * 8 * nf * sizeof(float));
   for (int k = 0; k < 4; k++) {
-    p->gA[k] = mkview(p, bp, "", k, ch[k], B);
-    p->gY[k] = mkview(p, bp, "", k, ch[k], B);
-    p->gY2[k] = mkview(p, bp, "", k, ch[k], B);  // the level's second conv keeps its own dy (read by a side-stream wgrad)
+    // (named for tools/cos_probe.py: after a backward g.y2_<k> holds the raw-output gradient of the encoder's second conv of
+    // level k, g.y_<k> that of its first conv -- the last writers of the two buffers)
+    p->gA[k] = mkview(p, bp, "g.a_" + std::to_string(k), k, ch[k], B);
+    p->gY[k] = mkview(p, bp, "g.y_" + std::to_string(k), k, ch[k], B);
+    p->gY2[k] = mkview(p, bp, "g.y2_" + std::to_string(k), k, ch[k], B);  // the level's second conv keeps its own dy (read by a side-stream wgrad)
     if (k < 3) {
       // gradient of cat_k = [upconv | ds]: two dense buffers when the halves are whole 32-channel blocks (every
       // consumer of a half -- InstanceNorm backward, max-pool backward, up-sampling backward, the transposed conv's
@@ -914,9 +944,54 @@ TfChainP tf_chain_params(const hdf_plan* p) {
 // The persistent kernels take the plan's transformer when every 16-token tile of every sequence gets a compute unit of
 // its own (resident together: their per-sequence barriers need that).  HDF_NO_TF_CHAIN=1: the launch chain
 // (tok_fwd / attention / tok_bwd ...) instead -- the third arrangement knob of tests/test_gpu_knobs.py.
+// Decided ONCE per forward (forward3d stores the answer in p->tf_fwd_chain); the backward follows the forward it belongs
+// to instead of reading the environment again (a knob flipped between the two calls made the persistent
+// backward consume records the launch-chain forward never wrote).
 bool tf_use_chain(const hdf_plan* p, int B) {
-  const bool off = getenv("HDF_NO_TF_CHAIN") != nullptr;   // read per call: tests switch it inside one process
-  return !off && tf_chain_supported(tf_dims(p, B));
+  const bool off = getenv("HDF_NO_TF_CHAIN") != nullptr;   // read per FORWARD call: tests switch it inside one process
+  return !off && !p->chain_off && tf_chain_supported(tf_dims(p, B));
+}
+// the plan's host-mapped give-up word, created on first use
+int chain_flag_ensure(hdf_plan* p) {
+  if (p->chain_flag) return HDF_OK;
+  void* h = nullptr;
+  if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) {
+    hdf_set_error("transformer chain: could not allocate the host-mapped status word");
+    return HDF_ERR_HIP;
+  }
+  void* dv = nullptr;
+  if (hipHostGetDevicePointer(&dv, h, 0) != hipSuccess) {
+    (void)hipHostFree(h);
+    hdf_set_error("transformer chain: no device address for the host-mapped status word");
+    return HDF_ERR_HIP;
+  }
+  memset(h, 0, 64);
+  p->chain_flag = reinterpret_cast<unsigned*>(h);
+  p->chain_flag_dev = reinterpret_cast<unsigned*>(dv);
+  return HDF_OK;
+}
+// Called at the top of every forward / backward: a persistent launch of an EARLIER call gave up at a barrier (the device
+// was shared: its grid was not resident together within the deadline).  That call's outputs are NaN-poisoned garbage; this
+// call reports it once -- HDF_ERR_CHAIN_TIMEOUT, nothing launched -- and the plan runs the launch chain from now on.
+// (Asynchronous by nature: the host is ahead of the device, so the report can be one or more calls late; a caller that
+// synchronises can ask at once with hdf_plan_chain_state.)
+int chain_flag_check(hdf_plan* p) {
+  if (!p->chain_flag) return HDF_OK;
+  const unsigned v = __atomic_load_n(p->chain_flag, __ATOMIC_ACQUIRE);
+  if (v == 0) return HDF_OK;
+  __atomic_store_n(p->chain_flag, 0u, __ATOMIC_RELEASE);
+  p->chain_last_giveup = v;
+  p->chain_off = true;
+  hdf_set_error("persistent transformer kernel: workgroup %u gave up at a per-sequence barrier (the compute units were not "
+                "all available to the launch); the outputs of that call are NaN; this plan uses the launch chain from now on",
+                v - 1);
+  return HDF_ERR_CHAIN_TIMEOUT;
+}
+TfChainCtl chain_ctl(const hdf_plan* p) {
+  TfChainCtl c;
+  c.host_flag = p->chain_flag_dev;
+  c.ticks = p->chain_ticks;
+  return c;
 }
 
 int transformer_forward(Exec& e, const float* x) {
@@ -933,13 +1008,14 @@ int transformer_forward(Exec& e, const float* x) {
   HDF_TRY(tf_patch_embed_fwd(d, x, p->D, p->H, p->W, pm + p->P("attns.0.patch_embeddings.weight"),
                              pm + p->P("attns.0.patch_embeddings.bias"), pm + p->P("attns.0.position_embeddings"), F0,
                              e.st, PE_LP));
-  if (tf_use_chain(p, e.B)) {  // all layers of all blocks in one persistent launch (transformer_chain.hip)
+  if (p->tf_fwd_chain) {  // all layers of all blocks in one persistent launch (transformer_chain.hip)
     if (e.tf_packed && hipStreamWaitEvent(e.st, e.tf_packed, 0) != hipSuccess) {
       hdf_set_error("branch stream: wait failed");
       return HDF_ERR_HIP;
     }
     return tf_chain_forward(d, tf_chain_params(p), p->nb, pm, F0, e.f(p->tf_save), e.at(p->attnall),
-                            reinterpret_cast<unsigned*>(e.ws + p->tf_sync), e.ws + p->tf_wpack, e.f(p->tf_frag), p->dtype, e.st);
+                            reinterpret_cast<unsigned*>(e.ws + p->tf_sync), e.ws + p->tf_wpack, e.f(p->tf_frag), p->dtype, e.st,
+                            chain_ctl(p));
   }
   // token kernel, attention, token kernel, ...: between two attention launches ONE kernel finishes the previous
   // dense layer (and, at a block boundary, runs the block's out_layer) and starts the next one
@@ -1019,12 +1095,12 @@ int transformer_backward(Exec& e, const float* x) {
     HDF_TRY(tf_wgrad(w, 1, p->M, e.wgrad_stream()));
     return e.side_done();
   };
-  if (tf_use_chain(p, e.B) && tf_chain_backward_supported(d, p->dtype)) {
+  if (p->tf_fwd_chain && tf_chain_backward_supported(d, p->dtype)) {
     // one persistent launch for all layers (transformer_chain.hip); then every block's weight-matrix gradients from the
     // tapes on the side stream, next to the patch embedding's backward on this one
     HDF_TRY(tf_chain_backward(d, tf_chain_params(p), p->nb, pm, e.grads, F0, e.f(p->tf_save), dF, e.at(p->dAttnall),
                               e.f(p->tf_tape), e.f(p->tf_otape), scratch, e.f(p->tf_frag), e.ws + p->tf_wpack,
-                              reinterpret_cast<unsigned*>(e.ws + p->tf_sync) + (1 << 17), p->dtype, e.st));
+                              reinterpret_cast<unsigned*>(e.ws + p->tf_sync) + (1 << 17), p->dtype, e.st, chain_ctl(p)));
     // (on this stream, not on the side stream: that one still holds the level-0 weight gradients, and tf_wgrad -- HBM-bound,
     // 110 us -- would run behind them as the last kernel of the step)
     HDF_TRY(tf_patch_embed_bwd(d, x, p->D, p->H, p->W, dF, e.grads + p->P("attns.0.patch_embeddings.weight"),
@@ -1491,8 +1567,11 @@ static int forward3d(hdf_plan* p, const float* x, const float* params, void* wor
   layout(p, batch);
   HDF_CHECK_ARG((size_t)workspace_bytes >= p->ws_fwd_bytes, "forward: workspace %lld < %zu bytes",
                 (long long)workspace_bytes, p->ws_fwd_bytes);
+  HDF_TRY(chain_flag_check(p));
   p->training = training ? 1 : 0;
   p->seed = (uint32_t)(seed & 0xffffffffu);
+  p->tf_fwd_chain = tf_use_chain(p, batch);
+  if (p->tf_fwd_chain) HDF_TRY(chain_flag_ensure(p));
   Exec e{p, (char*)workspace, params, nullptr, batch, (hipStream_t)stream};
   const int nf = p->nf;
   const int ch[4] = {nf, 2 * nf, 4 * nf, 8 * nf};
@@ -1540,7 +1619,7 @@ static int forward3d(hdf_plan* p, const float* x, const float* params, void* wor
     HDF_TRY(conv_forward(e, p->enc[0][0], p->xin, none));
   }
   HDF_TRY(hdf_launch_pack_batch(p->dtype, params, e.ws, p->pack_jobs.data(), (int)p->pack_jobs.size(), pst));
-  if (tf_use_chain(p, batch))
+  if (p->tf_fwd_chain)
     HDF_TRY(tf_chain_pack(tf_dims(p, batch), tf_chain_params(p), p->nb, params, e.ws + p->tf_wpack, pst));
   hipEvent_t packed = nullptr;
   if (bst) {
@@ -1571,7 +1650,7 @@ static int forward3d(hdf_plan* p, const float* x, const float* params, void* wor
   // With the persistent transformer kernel the device order conv_first -> transformer -> this conv is made explicit: the
   // kernel needs every unit, and this conv's 192 workgroups in front of it would leave it spinning on the other 64 for the
   // conv's whole duration.  (The launch chain of small kernels co-runs with the conv instead: no wait.)
-  const bool chain_first = first_direct && tf_use_chain(p, batch);
+  const bool chain_first = first_direct && p->tf_fwd_chain;
   eb.tf_packed = first_direct ? nullptr : packed;   // (packs on the branch stream itself: stream order)
   if (chain_first) {
     HDF_TRY(transformer_forward(eb, x));
@@ -1692,6 +1771,45 @@ int hdf_backward_events(hdf_plan* p, const float* x, const float* params, void* 
                       p->bucket_ev);
 }
 
+int hdf_plan_set_chain_timeout_us(hdf_plan* p, int64_t usec) {
+  HDF_CHECK_ARG(p && usec >= 100 && usec <= 30000000, "plan_set_chain_timeout_us: 100 us .. 30 s");
+  p->chain_ticks = (unsigned)(usec * 100);   // s_memrealtime: 100 MHz
+  return HDF_OK;
+}
+
+int hdf_plan_chain_state(hdf_plan* p, int batch, int* persistent, int* gave_up_workgroup) {
+  HDF_CHECK_ARG(p && batch >= 1, "plan_chain_state: null plan / batch < 1");
+  // (reads the host-mapped word like the next forward would, without consuming it: that call still reports the error)
+  const unsigned pending = p->chain_flag ? __atomic_load_n(p->chain_flag, __ATOMIC_ACQUIRE) : 0u;
+  if (gave_up_workgroup) *gave_up_workgroup = pending ? (int)pending - 1 : (p->chain_last_giveup ? (int)p->chain_last_giveup - 1 : -1);
+  if (persistent) *persistent = (!pending && tf_use_chain(p, batch)) ? 1 : 0;
+  return HDF_OK;
+}
+
+// Stand-in for a collective's kernel (tests / tools): `workgroups` workgroups of 256 threads that each hold `lds_bytes` of
+// LDS (160 KiB = a compute unit of its own) and spin on the 100 MHz real-time counter for `usec`.
+__global__ __launch_bounds__(256) void occupy_kernel(unsigned ticks) {
+  extern __shared__ char occ_lds[];
+  if (threadIdx.x == 0) occ_lds[0] = 1;
+  const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < (uint64_t)ticks) __builtin_amdgcn_s_sleep(8);
+}
+int hdf_op_occupy(int workgroups, int lds_bytes, int usec, hdf_stream stream) {
+  HDF_CHECK_ARG(workgroups >= 1 && workgroups <= 4096 && lds_bytes >= 0 && lds_bytes <= 160 * 1024 && usec >= 1 &&
+                    usec <= 10000000,
+                "op_occupy: workgroups 1..4096, lds 0..160 KiB, 1 us..10 s");
+  if (lds_bytes > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          160 * 1024) != hipSuccess) {
+    hdf_set_error("op_occupy: hipFuncSetAttribute failed");
+    return HDF_ERR_HIP;
+  }
+  hipLaunchKernelGGL(occupy_kernel, dim3(workgroups), dim3(256), (size_t)lds_bytes, (hipStream_t)stream,
+                     (unsigned)usec * 100u);
+  HDF_LAUNCH_CHECK();
+  return HDF_OK;
+}
+
 int hdf_plan_set_probe(hdf_plan* p, void* ev_start, void* ev_stop) {
   HDF_CHECK_ARG(p && ((ev_start == nullptr) == (ev_stop == nullptr)), "plan_set_probe: both events or none");
   p->probe_start = (hipEvent_t)ev_start, p->probe_stop = (hipEvent_t)ev_stop;
@@ -1777,6 +1895,7 @@ static int backward3d(hdf_plan* p, const float* x, const float* params, void* wo
                       const void* dout0, const void* dout1, const void* dout2, const void* dout3, float* grads,
                       int batch, int stages, hdf_stream stream, hipEvent_t* bev) {
   HDF_CHECK_ARG(p->batch == batch, "backward: batch %d differs from the forward's %d", batch, p->batch);
+  HDF_TRY(chain_flag_check(p));
   auto record = [&](int k, hipStream_t s) -> int {
     if (bev && hipEventRecord(bev[k], s) != hipSuccess) {
       hdf_set_error("backward: could not record the event of gradient bucket %d", k + 1);

@@ -164,8 +164,17 @@ struct TfChainP {
   int32_t ooff[4];
   int64_t blk0, blk_stride;
 };
-// the launch takes the shape (one workgroup per 16 tokens of a sequence, all resident at once)
+// the launch takes the shape (one workgroup per 16 tokens of a sequence, all resident at once: tiles <= hdf_cu_budget(),
+// which is capped by the device's compute-unit count)
 bool tf_chain_supported(const TfDims& d);
+// What a persistent launch does when a per-sequence barrier is not completed in time (the grid was not resident together:
+// the device is shared).  `host_flag`: device address of a host-mapped word (the plan's; null for operator-level calls)
+// that receives 1 + the id of the workgroup that gave up; `ticks`: deadline of one wait in 100 MHz real-time ticks.
+// The launch then ends by itself (no trap) with NaN in the rows of the workgroups that gave up: see chain_wait.
+struct TfChainCtl {
+  unsigned* host_flag = nullptr;
+  unsigned ticks = 150000000u;   // 1.5 s
+};
 size_t tf_chain_sync_bytes(const TfDims& d);
 size_t tf_chain_wpack_bytes(const TfDims& d, int nb);
 size_t tf_chain_frag_bytes(const TfDims& d, int nb);   // the forward's operand records for the backward (16-bit modes)
@@ -178,11 +187,13 @@ int tf_chain_pack(const TfDims& d, const TfChainP& cp, int nb, const float* para
 // device memory owned by the caller (zeroed by the call on `st`); `wpack`: tf_chain_wpack_bytes of scratch for the
 // fragment-major copies of the layers' weight matrices (tf_chain_pack).
 int tf_chain_forward(const TfDims& d, const TfChainP& cp, int nb, const float* params, float* F0, float* save,
-                     void* attnall, unsigned* sync, void* wpack, float* frag, int dtype, hipStream_t st);
+                     void* attnall, unsigned* sync, void* wpack, float* frag, int dtype, hipStream_t st,
+                     const TfChainCtl& ctl = TfChainCtl{});
 // Backward of all nb blocks (after the UpConv chain's backward left d(attnall)): every bias / LayerNorm-parameter gradient
 // (fp32 atomics into `grads`), the weight-gradient tapes of every layer (tf_wgrad afterwards), and dF[:, 0:DM] = the
 // gradient of block 0's input (tf_patch_embed_bwd afterwards).  `xchg`: 2 * rows * 40 floats of scratch (the dO | delta
 // rows the workgroups of a sequence hand each other); `sync`: tf_chain_sync_bytes, zeroed by the call.
 int tf_chain_backward(const TfDims& d, const TfChainP& cp, int nb, const float* params, float* grads, const float* F0,
                       const float* save, float* dF, const void* d_attnall, float* tape, float* otape, float* xchg,
-                      const float* frag, const void* wpack, unsigned* sync, int dtype, hipStream_t st);
+                      const float* frag, const void* wpack, unsigned* sync, int dtype, hipStream_t st,
+                      const TfChainCtl& ctl = TfChainCtl{});

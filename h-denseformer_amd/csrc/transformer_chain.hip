@@ -24,6 +24,8 @@
 // sc1 buffer load to registers.  Counters are monotonic within a launch (target = tiles x (phase + 1)) and zeroed by a
 // hipMemsetAsync in front of every launch.  All workgroups of the grid must be resident (grid <= compute units, checked
 // by the launcher); every spin is bounded by the 100 MHz real-time counter and leaves a timeout word behind.
+#include <mutex>
+
 #include "tf_tok.h"
 
 namespace {
@@ -273,26 +275,44 @@ __device__ __forceinline__ void chain_arrive(unsigned* cnt, bool storing = true)
   if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // wait until the counter reaches `target`; one lane polls, the workgroup's barrier releases the others.  `dead` is the
-// workgroup's sticky give-up flag (lane 0's copy decides; after a timeout no further wait is attempted)
-__device__ __forceinline__ void chain_wait(unsigned* cnt, unsigned target, unsigned* tmo, bool& dead) {
+// workgroup's sticky give-up flag (lane 0's copy decides; after a timeout no further wait is attempted).
+// Giving up (round 6; rounds 5 trapped here, which killed the caller's HIP context): a sibling that has not arrived within
+// `c.ticks` of the 100 MHz real-time counter means the grid is not resident together -- the device is shared with something
+// that holds compute units.  The workgroup then leaves 1 + its id in the sync region's timeout word AND in the plan's
+// host-mapped flag word (system scope: the host reads it without synchronising, plan.hip chain_flag_check), stops waiting
+// for the rest of the launch and runs to the end on whatever it reads; every other workgroup sees the word in its own poll
+// loop and does the same, so the launch ends within about one timeout.  Its results are garbage BY DEFINITION: dead
+// workgroups overwrite their output rows with NaN at the end of the kernel (chain_poison_*), so the step's loss /
+// gradients are NaN rather than plausible, and the plan's next call returns HDF_ERR_CHAIN_TIMEOUT once and routes this
+// plan to the launch chain from then on.
+using ChainCtl = TfChainCtl;   // (transformer.h: host-mapped flag word + give-up deadline)
+__device__ __forceinline__ void chain_wait(unsigned* cnt, unsigned target, unsigned* tmo, const ChainCtl& c, bool& dead) {
   if (threadIdx.x == 0 && !dead) {
     const uint64_t t_start = __builtin_amdgcn_s_memrealtime();
+    unsigned spins = 0;
     while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(2);
-      if (__builtin_amdgcn_s_memrealtime() - t_start > 150000000ull) {   // 1.5 s at 100 MHz
-        // a sibling never arrived (the grid was not resident together for 1.5 s: the device is shared with something that
-        // holds its compute units): leave the word for the tests' diagnostics and ABORT the launch -- the results would be
-        // wrong, and nothing on the product path reads the word; a trapped kernel surfaces as a HIP error at the caller's
-        // next synchronisation
+      if ((++spins & 31u) == 0u && __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        dead = true;   // a sibling (of any sequence) gave up: the launch is lost, do not sit out a deadline of our own
+        break;
+      }
+      if (__builtin_amdgcn_s_memrealtime() - t_start > (uint64_t)c.ticks) {
         __hip_atomic_store(tmo, 1u + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c.host_flag) __hip_atomic_store(c.host_flag, 1u + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         dead = true;
-        __builtin_trap();
         break;
       }
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // (no instruction: keeps the loads below the poll)
   __syncthreads();
+}
+// lane 0's give-up flag -> the whole workgroup (uniform result); `word`: any LDS word nobody reads across this call
+__device__ __forceinline__ bool chain_any_dead(bool dead, unsigned* word) {
+  __syncthreads();
+  if (threadIdx.x == 0) *word = dead ? 1u : 0u;
+  __syncthreads();
+  return *word != 0u;
 }
 
 // -DCHAIN_DBG_STAMPS: lane 0 of every workgroup leaves the 100 MHz real-time counter at the phase boundaries of every layer
@@ -324,6 +344,7 @@ struct ChainFwd {
   float* save;      // [nb*4][rows][232] (tf_save layout: h0 | qkv | ob | lse | h1 | h2, segment-major)
   void* attnall;    // channels-last [B][N][M*DM], storage dtype
   unsigned* sync;   // [nseq + 1][SYNC_LINE]: arrival counters, then the timeout word
+  TfChainCtl ctl;
   float* frag;      // [nl][nseq][ntile][8][FR_W] operand records for the backward (16-bit storage modes), or null
   int nb, ntile, nseq;
   int64_t rows;
@@ -624,7 +645,7 @@ __global__ __launch_bounds__(CT) void tf_chain_fwd_kernel(ChainFwd a) {
     request_post(L + 1);   // parameters: never written during the launch, plain loads
     const int head = wave8;
     const float bqv = s_q[col * LDQ + head * 4 + g] * (0.5f * LOG2E);
-    chain_wait(cnt, (unsigned)(a.ntile * (L + 1)), tmo, dead);
+    chain_wait(cnt, (unsigned)(a.ntile * (L + 1)), tmo, a.ctl, dead);
     CHAIN_STAMP(4);
     // ------------------------------------------------------------------ attention of layer L: head = wave
     {
@@ -777,6 +798,21 @@ __global__ __launch_bounds__(CT) void tf_chain_fwd_kernel(ChainFwd a) {
       CHAIN_STAMP(7);
     }
   }
+  // a workgroup that gave up at a barrier overwrites its rows of the branch output with NaN (chain_wait): the decoder's
+  // InstanceNorm statistics, and with them the loss, are then NaN instead of plausible
+  if (chain_any_dead(dead, reinterpret_cast<unsigned*>(s_red))) {
+    const float qnan = __builtin_nanf("");
+    for (int i = tid; i < nvalid * DM; i += CT) {
+      const int row = i / DM, c = i - row * DM;
+      const int64_t ai = ((int64_t)bsm * N + n0 + row) * ((int64_t)d.M * DM) + (int64_t)m * DM + c;
+      if (a.dtype == HDF_BF16)
+        ST<bf16_t>::st(reinterpret_cast<bf16_t*>(a.attnall) + ai, qnan);
+      else if (a.dtype == HDF_F16)
+        ST<f16_t>::st(reinterpret_cast<f16_t*>(a.attnall) + ai, qnan);
+      else
+        reinterpret_cast<float*>(a.attnall)[ai] = qnan;
+    }
+  }
 }
 
 // ================================================================================================ backward
@@ -808,6 +844,7 @@ struct ChainBwd {
                           // [2][nseq][ntile][8][XG_W] operand records (16-bit modes)
   const float* frag;      // the forward's operand records (16-bit modes)
   unsigned* sync;         // [nseq + 1][SYNC_LINE]
+  TfChainCtl ctl;
   int nb, ntile, nseq, dtype;
   int64_t rows;
 };
@@ -1384,7 +1421,7 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
         for (int r = 0; r < 4; r++)
           if (col < 4) s_dq[(4 * g + r) * 100 + head * 4 + col] = (4 * g + r < nvalid) ? 0.5f * acc[r] : 0.f;
       }
-      chain_wait(cnt, (unsigned)(a.ntile * (nl - L)), tmo, dead);
+      chain_wait(cnt, (unsigned)(a.ntile * (nl - L)), tmo, a.ctl, dead);
       {
         float4 r_dl[NLS];
 #pragma unroll
@@ -1538,7 +1575,7 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
                 rvalid ? make_float4(0.5f * d01.x, 0.5f * d01.y, 0.5f * d23.x, 0.5f * d23.y) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
-      chain_wait(cnt, (unsigned)(a.ntile * (nl - L)), tmo, dead);
+      chain_wait(cnt, (unsigned)(a.ntile * (nl - L)), tmo, a.ctl, dead);
       CHAIN_STAMPB(7);
       // ---- dK, dV of the tile's keys: q | dO chunks (image rows of QP floats), (lse, delta) per head as [8][QC] arrays
       {
@@ -1671,6 +1708,15 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
     }
     CHAIN_STAMPB(8);
   }
+  // a workgroup that gave up at a barrier (chain_wait) overwrites its rows of block 0's input gradient with NaN: the patch
+  // embedding's gradients, and the optimizer step, are then NaN instead of plausible
+  if (chain_any_dead(dead, reinterpret_cast<unsigned*>(s_red))) {
+    const float qnan = __builtin_nanf("");
+    for (int i = tid; i < nvalid * DM; i += CT) {
+      const int row = i / DM, c = i - row * DM;
+      a.dF[(rb + t0k + row) * DMF + c] = qnan;
+    }
+  }
 }
 
 size_t chain_bwd_lds(const TfDims& d, int dtype) {
@@ -1742,60 +1788,113 @@ int tf_chain_pack(const TfDims& d, const TfChainP& cp, int nb, const float* para
   return HDF_OK;
 }
 
+// At most ONE persistent transformer launch in flight per device and process: two of them resident together
+// -- two plans or models on different streams -- can each hold a part of the compute units and wait for siblings that are
+// never dispatched.  Every launch therefore waits for the event of the previous persistent launch of the process on the
+// same device and records its own, under a mutex (launches of one stream are ordered anyway: the wait is then free).
+// Another PROCESS on the same device is outside this chain: that case ends in the give-up path of chain_wait.
+namespace {
+struct ChainSerial {
+  std::mutex mu;
+  hipEvent_t last[16] = {};
+  bool armed[16] = {};
+};
+ChainSerial g_chain_serial;
+// call with the launch parameters ready: orders `st` behind the previous persistent launch; `done` must be called right
+// after the launch (both under the caller-held lock)
+int chain_serial_enter(hipStream_t st, int& dev) {
+  dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+  if (g_chain_serial.armed[dev] && hipStreamWaitEvent(st, g_chain_serial.last[dev], 0) != hipSuccess) {
+    hdf_set_error("transformer chain: could not order the launch behind the previous persistent launch");
+    return HDF_ERR_HIP;
+  }
+  return HDF_OK;
+}
+int chain_serial_done(hipStream_t st, int dev) {
+  if (!g_chain_serial.last[dev] &&
+      hipEventCreateWithFlags(&g_chain_serial.last[dev], hipEventDisableTiming) != hipSuccess) {
+    g_chain_serial.last[dev] = nullptr;
+    hdf_set_error("transformer chain: could not create the serialisation event");
+    return HDF_ERR_HIP;
+  }
+  if (hipEventRecord(g_chain_serial.last[dev], st) != hipSuccess) {
+    hdf_set_error("transformer chain: could not record the serialisation event");
+    return HDF_ERR_HIP;
+  }
+  g_chain_serial.armed[dev] = true;
+  return HDF_OK;
+}
+}  // namespace
+
 int tf_chain_forward(const TfDims& d, const TfChainP& cp, int nb, const float* params, float* F0, float* save,
-                     void* attnall, unsigned* sync, void* wpack, float* frag, int dtype, hipStream_t st) {
+                     void* attnall, unsigned* sync, void* wpack, float* frag, int dtype, hipStream_t st,
+                     const TfChainCtl& ctl) {
   HDF_CHECK_ARG(tf_chain_supported(d), "transformer chain: shape not supported (M %d B %d N %d DM %d)", d.M, d.B, d.N, d.DM);
   ChainFwd a{};
   HDF_CHECK_ARG(chain_digest(cp, d.DM, a.cw), "transformer chain: irregular parameter layout");
   a.d = d, a.params = params, a.F0 = F0, a.save = save, a.attnall = attnall, a.sync = sync;
-  a.wpack = reinterpret_cast<const float4*>(wpack), a.dtype = dtype;
+  a.wpack = reinterpret_cast<const float4*>(wpack), a.dtype = dtype, a.ctl = ctl;
   a.frag = dtype == HDF_F32 ? nullptr : frag;
   a.nb = nb, a.ntile = ceil_div(d.N, TT), a.nseq = d.M * d.B, a.rows = (int64_t)d.M * d.B * d.N;
   const size_t shm = chain_fwd_lds(d);
   HDF_CHECK_ARG(shm <= LDS_LIMIT_F, "transformer chain: %zu B of LDS", shm);
   HDF_CHECK_ARG(dtype == HDF_F32 || dtype == HDF_BF16 || dtype == HDF_F16, "unsupported dtype %d", dtype);
+  HDF_TRY(chain_allow_lds(tf_chain_fwd_kernel<true>, shm));
+  HDF_TRY(chain_allow_lds(tf_chain_fwd_kernel<false>, shm));
+  std::lock_guard<std::mutex> lock(g_chain_serial.mu);
+  int dev = 0;
+  HDF_TRY(chain_serial_enter(st, dev));
   hipError_t e = hipMemsetAsync(sync, 0, tf_chain_sync_bytes(d), st);
   if (e != hipSuccess) {
     hdf_set_error("transformer chain: hipMemsetAsync failed: %s", hipGetErrorString(e));
     return HDF_ERR_HIP;
   }
   const dim3 grid(a.nseq * a.ntile);
-  if (d.training) {
-    HDF_TRY(chain_allow_lds(tf_chain_fwd_kernel<true>, shm));
+  if (d.training)
     hipLaunchKernelGGL(tf_chain_fwd_kernel<true>, grid, dim3(CT), shm, st, a);
-  } else {
-    HDF_TRY(chain_allow_lds(tf_chain_fwd_kernel<false>, shm));
+  else
     hipLaunchKernelGGL(tf_chain_fwd_kernel<false>, grid, dim3(CT), shm, st, a);
-  }
   HDF_LAUNCH_CHECK();
-  return HDF_OK;
+  return chain_serial_done(st, dev);
 }
 
 int tf_chain_backward(const TfDims& d, const TfChainP& cp, int nb, const float* params, float* grads, const float* F0,
                       const float* save, float* dF, const void* d_attnall, float* tape, float* otape, float* xchg,
-                      const float* frag, const void* wpack, unsigned* sync, int dtype, hipStream_t st) {
+                      const float* frag, const void* wpack, unsigned* sync, int dtype, hipStream_t st,
+                      const TfChainCtl& ctl) {
   HDF_CHECK_ARG(tf_chain_backward_supported(d, dtype), "transformer chain: shape not supported (M %d B %d N %d DM %d)", d.M, d.B, d.N, d.DM);
   ChainBwd a{};
   HDF_CHECK_ARG(chain_digest(cp, d.DM, a.cw), "transformer chain: irregular parameter layout");
   HDF_CHECK_ARG(dtype == HDF_F32 || dtype == HDF_BF16 || dtype == HDF_F16, "unsupported dtype %d", dtype);
   a.d = d, a.params = params, a.grads = grads, a.F0 = F0, a.save = save, a.dF = dF, a.d_attnall = d_attnall;
   a.tape = tape, a.otape = otape, a.xchg = xchg, a.sync = sync, a.dtype = dtype, a.frag = frag;
-  a.wpack = reinterpret_cast<const float4*>(wpack);
+  a.wpack = reinterpret_cast<const float4*>(wpack), a.ctl = ctl;
   HDF_CHECK_ARG(dtype == HDF_F32 || frag, "transformer chain backward: no operand records");
   a.nb = nb, a.ntile = ceil_div(d.N, TT), a.nseq = d.M * d.B, a.rows = (int64_t)d.M * d.B * d.N;
   const size_t shm = chain_bwd_lds(d, dtype);
   HDF_CHECK_ARG(shm <= LDS_LIMIT_F, "transformer chain backward: %zu B of LDS", shm);
+#define CHAIN_BWD_LDS(TR, LPV) \
+  if ((d.training != 0) == TR && dtype == LPV) HDF_TRY(chain_allow_lds(tf_chain_bwd_kernel<TR, LPV>, shm));
+  CHAIN_BWD_LDS(true, 0)
+  CHAIN_BWD_LDS(true, 1)
+  CHAIN_BWD_LDS(true, 2)
+  CHAIN_BWD_LDS(false, 0)
+  CHAIN_BWD_LDS(false, 1)
+  CHAIN_BWD_LDS(false, 2)
+#undef CHAIN_BWD_LDS
+  std::lock_guard<std::mutex> lock(g_chain_serial.mu);
+  int dev = 0;
+  HDF_TRY(chain_serial_enter(st, dev));
   hipError_t e = hipMemsetAsync(sync, 0, tf_chain_sync_bytes(d), st);
   if (e != hipSuccess) {
     hdf_set_error("transformer chain: hipMemsetAsync failed: %s", hipGetErrorString(e));
     return HDF_ERR_HIP;
   }
   const dim3 grid(a.nseq * a.ntile);
-#define CHAIN_BWD_CASE(TR, LPV)                                                      \
-  if ((d.training != 0) == TR && dtype == LPV) {                                     \
-    HDF_TRY(chain_allow_lds(tf_chain_bwd_kernel<TR, LPV>, shm));                     \
-    hipLaunchKernelGGL((tf_chain_bwd_kernel<TR, LPV>), grid, dim3(CT), shm, st, a);  \
-  }
+#define CHAIN_BWD_CASE(TR, LPV)                \
+  if ((d.training != 0) == TR && dtype == LPV) \
+    hipLaunchKernelGGL((tf_chain_bwd_kernel<TR, LPV>), grid, dim3(CT), shm, st, a);
   CHAIN_BWD_CASE(true, 0)
   CHAIN_BWD_CASE(true, 1)
   CHAIN_BWD_CASE(true, 2)
@@ -1804,5 +1903,5 @@ int tf_chain_backward(const TfDims& d, const TfChainP& cp, int nb, const float* 
   CHAIN_BWD_CASE(false, 2)
 #undef CHAIN_BWD_CASE
   HDF_LAUNCH_CHECK();
-  return HDF_OK;
+  return chain_serial_done(st, dev);
 }

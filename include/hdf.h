@@ -32,7 +32,10 @@ const char* hdf_last_error(void);
  * are one workgroup per CU.  256 = the whole MI355X (default); a multiple of 8 below that for launches on a stream the
  * CALLER created with hipExtStreamCreateWithCUMask, so that every workgroup of a launch is resident at once.  Process-wide
  * (forward and autograd's backward thread see the same value: it also enters the split-K decision of the low-resolution
- * convs, i.e. their summation order); a diagnostic knob -- the plan never changes it and owns no masked streams. */
+ * convs, i.e. their summation order); a diagnostic knob -- the plan never changes it and owns no masked streams.
+ * Round 6: a DOWNWARD override only -- the effective budget is min(this, the current device's compute-unit count
+ * (hipDeviceAttributeMultiprocessorCount)), so partitioned or smaller gfx950 devices size their grids, and decide whether
+ * the persistent transformer kernels can be resident together, from what they have. */
 int hdf_set_cu_budget(int cus);
 
 /* ---- model plan: models/HDenseFormer.py:177-227 (HDenseFormer.__init__) ------------------------------- */
@@ -98,6 +101,27 @@ int hdf_backward_stages(hdf_plan* p, const float* x, const float* params, void* 
 int hdf_backward_events(hdf_plan* p, const float* x, const float* params, void* workspace, int64_t workspace_bytes,
                         const void* dout0, const void* dout1, const void* dout2, const void* dout3, float* grads,
                         int batch, hdf_stream stream, void** bucket_events /* [3] hipEvent_t out */);
+/* ---- the persistent transformer kernels and a shared device (round 6) ----------------------------------------------
+ * The plan runs all dense layers of the multi-path transformer (models/HDenseFormer.py:78-145) as ONE persistent launch per
+ * direction when every 16-token tile gets a compute unit of its own (tiles <= the device's compute units; else, and under
+ * HDF_NO_TF_CHAIN=1, as a chain of ~100 small launches).  Those launches wait on each other inside the kernel, so all their
+ * workgroups must be resident together.  The library guarantees that within the PROCESS (one such launch in flight per
+ * device at a time: each waits for the previous one's event).  If something else holds compute units long enough that a
+ * per-sequence barrier is not completed within the deadline (default 1.5 s), the launch does NOT trap any more: it ends by
+ * itself, overwrites the rows of the workgroups that gave up with NaN (loss / gradients of that step become NaN, never
+ * plausible garbage), and writes a host-mapped status word.  The plan's NEXT hdf_forward / hdf_backward* call then launches
+ * nothing and returns HDF_ERR_CHAIN_TIMEOUT (4) once, and the plan uses the launch chain from then on: redo the step.
+ * hdf_plan_set_chain_timeout_us: the deadline of one barrier wait (100 us .. 30 s).
+ * hdf_plan_chain_state: *persistent = 1 when the next forward of `batch` samples would take the persistent kernels;
+ * *gave_up_workgroup = id of the workgroup whose give-up is pending or was last reported, -1 if none.  Meaningful right
+ * after the caller synchronised the device; never synchronises itself. */
+#define HDF_ERR_CHAIN_TIMEOUT 4
+int hdf_plan_set_chain_timeout_us(hdf_plan* p, int64_t usec);
+int hdf_plan_chain_state(hdf_plan* p, int batch, int* persistent, int* gave_up_workgroup);
+/* Tests and tools: a stand-in for a collective's kernel -- `workgroups` workgroups of 256 threads, each holding `lds_bytes`
+ * of LDS (160 KiB: a compute unit of its own), spinning for `usec` on the device's real-time counter. */
+int hdf_op_occupy(int workgroups, int lds_bytes, int usec, hdf_stream stream);
+
 /* Measurement hook: every following hdf_forward on this plan records ev_start immediately before and ev_stop immediately
  * after the launch of the forward's dominant convolution (block_1_1_right, 64 -> 32 channels at full resolution: the
  * kernel bench.py's `roofline` object reports) on the caller's stream.  Two caller-owned HIP events created with timing

@@ -150,3 +150,96 @@ def test_chain_backward_is_bit_identical_to_the_launch_chain(case):
         else:
             scale = float(b.abs().max()) + 1e-12
             assert float((a - b).abs().max()) <= 1e-4 * scale + 1e-9, name
+
+
+def test_a_persistent_launch_that_cannot_be_resident_gives_up_cleanly_and_the_plan_falls_back():
+    """a per-sequence barrier that is not completed in time no longer traps (a trap kills the caller's HIP
+    context).  A stand-in kernel holds all but 8 compute units for 60 ms while a forward with a 3 ms deadline launches its 32
+    persistent workgroups: 8 become resident, wait for siblings that cannot be dispatched, give up -- the launch ends by
+    itself, the device stays usable, the outputs of that call are NaN (never plausible garbage), the plan's NEXT call
+    reports HDF_ERR_CHAIN_TIMEOUT once without launching anything, and from then on the plan runs the launch chain, whose
+    results equal the persistent kernels' bit for bit."""
+    import ctypes as C
+    from hdf_rt._lib import HdfError, check, lib
+    case = CASES[2]
+    cin, ncls, nf, image, depth, batch, dtype = case
+    good, (plan, rt, params, x, _) = _forward(case, chain=True)
+    pers, who = C.c_int(-1), C.c_int(-2)
+    check(lib().hdf_plan_chain_state(plan.h, batch, C.byref(pers), C.byref(who)), "chain_state")
+    assert (pers.value, who.value) == (1, -1)
+    check(lib().hdf_plan_set_chain_timeout_us(plan.h, 3000), "set_chain_timeout")
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    side = torch.cuda.Stream()
+    check(lib().hdf_op_occupy(cus - 8, 160 * 1024, 60000, side.cuda_stream), "occupy")
+    outs = rt.forward(x, params, 1, 1234, need_backward=True)
+    torch.cuda.synchronize()                      # returns: no trap, no HIP error
+    sync = rt.read_region("tf_sync").view(torch.int32)
+    assert int(sync[32 * cin * batch]) != 0, "the forward was expected to give up (were the compute units really held?)"
+    check(lib().hdf_plan_chain_state(plan.h, batch, C.byref(pers), C.byref(who)), "chain_state")
+    assert pers.value == 0 and 0 <= who.value < 32, (pers.value, who.value)
+    assert bool(torch.isnan(outs[0].float()).any()), "a launch that gave up must poison its outputs"
+    with pytest.raises(HdfError, match="gave up"):
+        rt.forward(x, params, 1, 1234, need_backward=True)
+    outs3 = rt.forward(x, params, 1, 1234, need_backward=True)    # the launch chain from now on
+    torch.cuda.synchronize()
+    check(lib().hdf_plan_chain_state(plan.h, batch, C.byref(pers), C.byref(who)), "chain_state")
+    assert pers.value == 0
+    for a, b in zip(outs3, good["outs"]):
+        assert torch.equal(a, b)
+    assert torch.equal(rt.read_region("tf_save").view(torch.int32), good["save"].view(torch.int32))
+    # ... and a backward behind that forward follows it (launch chain), finite gradients
+    g = torch.Generator().manual_seed(5)
+    douts = [(torch.randn(o.shape, generator=g) * 1e-2).to(DEV).to(o.dtype) for o in outs3]
+    grads = torch.zeros_like(params)
+    rt.backward(x, params, douts, grads)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(grads).all())
+
+
+def test_the_backward_follows_the_arrangement_its_forward_ran():
+    """HDF_NO_TF_CHAIN is read once per FORWARD; flipping it between the forward and its backward must not
+    make the persistent backward consume operand records the launch-chain forward never wrote."""
+    case = CASES[2]
+    ref = _backward(case, chain=False)
+    res, (plan, rt, params, x, outs) = _forward(case, chain=False)     # launch-chain forward ...
+    os.environ.pop("HDF_NO_TF_CHAIN", None)                             # ... and the knob is gone before the backward
+    g = torch.Generator().manual_seed(5)
+    douts = [(torch.randn(o.shape, generator=g) * 1e-2).to(DEV).to(o.dtype) for o in outs]
+    grads = torch.zeros_like(params)
+    rt.backward(x, params, douts, grads)
+    torch.cuda.synchronize()
+    assert torch.equal(rt.read_region("tf_tape").view(torch.int32), ref["tape"].view(torch.int32))
+    for name, off, numel, shape in plan.table:
+        if name.startswith("attns.") and len(shape) == 2 and "patch" not in name:
+            assert torch.equal(grads[off:off + numel].view(torch.int32), ref["grads"][off:off + numel].view(torch.int32)), name
+
+
+def test_two_plans_on_two_streams_take_turns_with_their_persistent_launches():
+    """two persistent launches resident together could each hold a part of the compute units and wait for
+    siblings that are never dispatched.  The library orders every persistent launch of the process behind the previous one
+    (an event chain per device), so two plans at the 256-workgroup geometry driven from two streams both finish, without a
+    give-up, with the results of a solo run."""
+    import ctypes as C
+    from hdf_rt._lib import check, lib
+    case = (4, 4, 32, (128, 128, 128), 8, 2, BF16)
+    cin, ncls, nf, image, depth, batch, dtype = case
+    solo, (plan_a, rt_a, params, x, _) = _forward(case, chain=True, training=0)
+    plan_b = Plan(cin, ncls, nf, image, depth, dtype)
+    rt_b = Runtime(plan_b, DEV)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    res = []
+    for _ in range(3):
+        with torch.cuda.stream(sa):
+            oa = rt_a.forward(x, params, 0, 1234, need_backward=False)
+        with torch.cuda.stream(sb):
+            ob = rt_b.forward(x, params, 0, 1234, need_backward=False)
+        res.append((oa, ob))
+    torch.cuda.synchronize()
+    pers, who = C.c_int(), C.c_int()
+    for pl in (plan_a, plan_b):
+        check(lib().hdf_plan_chain_state(pl.h, batch, C.byref(pers), C.byref(who)), "chain_state")
+        assert (pers.value, who.value) == (1, -1)
+    for oa, ob in res:
+        for a, b, c in zip(oa, ob, solo["outs"]):
+            assert torch.equal(a, c) and torch.equal(b, c)

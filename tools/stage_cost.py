@@ -2,6 +2,11 @@
    a) backward as one call (stages=7), no hook                     -- what `python bench.py` times
    b) backward in three stages (1, 2, 4) with a hook that does nothing -- the cost of the three side-stream joins
    c) three stages + GradSync over RCCL with world_size 1          -- + the bucket all-reduces on the comm stream
+   d) one call + bucket events + a STAND-IN collective per bucket that holds 16 / 32 compute units for 300 us
+      (hdf_op_occupy: 160 KiB of LDS per workgroup, i.e. a compute unit of its own -- what an 8-GPU ring all-reduce of a
+      19-26 MB bucket costs over xGMI, on the comm stream, behind the bucket's event)  -- round 6, VERDICT r05 #3: the
+      persistent transformer backward needs all 256 compute units resident and is launched while the stand-ins of buckets
+      2 and 1 may still hold theirs; the leg reports what that waiting costs and that no barrier gives up
 Run under `python -m torch.distributed.run --nproc-per-node 1 --master-addr 127.0.0.1 ... tools/stage_cost.py`
 (or plainly: it then sets up a one-rank rendezvous on 127.0.0.1 itself).  Prints one JSON line."""
 import json
@@ -41,6 +46,19 @@ def main():
     x = torch.rand(2, 4, size, size, size, generator=g).to(dev)
     lab = torch.randint(0, 4, (2, size, size, size), generator=g)
     t = torch.nn.functional.one_hot(lab, 4).permute(0, 4, 1, 2, 3).float().contiguous().to(dev)
+    import ctypes as C
+    from hdf_rt._lib import check, lib
+
+    class OccupySync(GradSync):
+        """GradSync whose collective is a kernel that holds `wgs` compute units for `usec` (no data moved)"""
+
+        def __init__(self, model, wgs, usec):
+            super().__init__(model)
+            self.wgs, self.usec = wgs, usec
+
+        def _reduce(self, chunk):
+            check(lib().hdf_op_occupy(self.wgs, 160 * 1024, self.usec, torch.cuda.current_stream().cuda_stream), "occupy")
+
     sync = GradSync(net)                      # one-call backward + bucket events (default protocol)
     sync_staged = GradSync(net, staged=True)  # round-3 protocol: three staged backward calls
 
@@ -50,7 +68,7 @@ def main():
         opt.zero_grad()
         loss = crit(net(x), t)
         loss.backward()
-        if net.grad_hook is sync or net.grad_hook is sync_staged:
+        if isinstance(net.grad_hook, GradSync):
             net.grad_hook.wait()
         return loss
 
@@ -81,6 +99,12 @@ def main():
 
     rec = {"world": dist.get_world_size(), "backend": dist.get_backend(), "size": size, "grad_rel_err": err,
            "ms_one_call": timed(None), "ms_three_stages_noop_hook": timed(lambda stage: None), "ms_three_stages_rccl": timed(sync_staged), "ms_one_call_events_rccl": timed(sync)}
+    for wgs in (16, 32):
+        rec["ms_one_call_events_standin_%dcu_300us" % wgs] = timed(OccupySync(net, wgs, 300))
+    pers, who = C.c_int(), C.c_int()
+    check(lib().hdf_plan_chain_state(net._last_rt.plan.h, 2, C.byref(pers), C.byref(who)), "chain_state")
+    rec["persistent_kernels_still_on"] = pers.value
+    rec["gave_up_workgroup"] = who.value
     print(json.dumps(rec), flush=True)
     dist.destroy_process_group()
 
