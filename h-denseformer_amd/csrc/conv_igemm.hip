@@ -388,10 +388,18 @@ __device__ __attribute__((aligned(16))) uint32_t g_zero_line[4] = {0u, 0u, 0u, 0
 // (An LDS-DMA staging variant of the transform-free 32-byte-chunk layers -- global_load_lds_dwordx4 instead of the pf
 // registers and ds_write commits -- was built at the end of round 2, measured neutral (536 vs 539 us) and removed in
 // round 3: DESIGN.md section 6d.)
-template <typename T, int CH, int RB, bool XF, int NB, bool BS = false>
+// TDP (round 6): tile depth, 4 or 8.  TDP = 8 -- an 8x8x8 tile, taken by the 64-byte-row single-block layers (32 -> 32
+// channels at the top level: the four launches of a step that are co-bound by HBM and MFMA, VERDICT r05 #1a) -- stages a
+// 10x10x10 box for 512 outputs instead of 6x10x10 for 256: 1.95 instead of 2.34 box voxels per output through L2 ->
+// registers -> LDS, the z halo fetched 1.25x instead of 1.5x, 8 A + 3 B fragment reads per 12 MFMAs instead of 4 + 3 per
+// 6, one epilogue / barrier / tile step per 108 MFMAs instead of per 54.  A wave then owns four M-blocks (z half zh, row
+// mb): MFMA row -> (dz + 4 zh, x) with the same ws_row_to_zx map, so the fragment addresses of z half 1 are those of half
+// 0 plus a compile-time offset.  Needs the padded tile-buffer layout (two 1000-row buffers + the panel: 150 KiB).
+template <typename T, int CH, int RB, bool XF, int NB, bool BS = false, int TDP = 4>
 __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
   if (a.prio) HDF_LIGHT_PRIO();
-  constexpr int TD = 4, TH = 8, TW = 8, BD = TD + 2, BH = TH + 2, BW = TW + 2, BOX = BD * BH * BW;
+  constexpr int TD = TDP, ZH = TDP / 4, TH = 8, TW = 8, BD = TD + 2, BH = TH + 2, BW = TW + 2, BOX = BD * BH * BW;
+  static_assert(TDP == 4 || TDP == 8, "tile depth");
   constexpr int ESZ = sizeof(T), EPC = ST<T>::EPC;
   constexpr int CIN = RB / ESZ;
   constexpr int NCH = RB / CH, NFS = CH / 32, NG = 9 * NFS;
@@ -410,6 +418,7 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
   static_assert(NCH == 1 || NCH % 2 == 0, "buffer parity at tile start must be compile-time");
   static_assert(2 * CIN * 4 <= 512, "scale/shift table");
   static_assert(OFF_W + 27 * NC * RB <= 160 * 1024, "LDS budget");
+  static_assert(ZH == 1 || !SWZ, "the 8-deep tile needs the padded layout");
   __shared__ __attribute__((aligned(256))) char lds[OFF_W + 27 * NC * RB];
 #ifdef WS_DBG_STAMPS
   const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();
@@ -516,11 +525,11 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
           }
     }
   }
-  auto a_addr = [&](int jz, int yp, int jx, int fs) {
+  auto a_addr = [&](int jz, int yp, int jx, int fs, int zh = 0) {
     if constexpr (SWZ)
       return aaddr[jz][yp][jx] ^ (fs * 32);
     else
-      return abase + ((jz * BH + yp) * BW + jx) * AP + fs * 32;
+      return abase + (((jz + 4 * zh) * BH + yp) * BW + jx) * AP + fs * 32;
   };
   int bvar[NCH];  // this lane's 16-byte slot inside a weight row, per channel chunk
 #pragma unroll
@@ -550,7 +559,7 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
   };
 
   // linear index of a tile in raster order (the InstanceNorm partial row it owns)
-  auto tile_lin = [&](const WsTile& c) { return ((c.n * ntz + (c.z0 >> 2)) * nty + (c.y0 >> 3)) * ntx + (c.x0 >> 3); };
+  auto tile_lin = [&](const WsTile& c) { return ((c.n * ntz + c.z0 / TD) * nty + (c.y0 >> 3)) * ntx + (c.x0 >> 3); };
   // k-th interior tile / k-th border tile, in raster order
   auto int_init = [&](WsTile& c, int k) {
     int t = k;
@@ -563,7 +572,7 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
     c.tile = tile_lin(c);
   };
   auto int_next = [&](WsTile& c) {  // + WPX tiles in raster order of the interior grid
-    int xi = (c.x0 >> 3) - 1 + sdx, yi = (c.y0 >> 3) - 1 + sdy, zi = (c.z0 >> 2) - 1 + sdz;
+    int xi = (c.x0 >> 3) - 1 + sdx, yi = (c.y0 >> 3) - 1 + sdy, zi = c.z0 / TD - 1 + sdz;
     c.n += sdn;
     if (xi >= ipx) xi -= ipx, yi++;
     if (yi >= ipy) yi -= ipy, zi++;
@@ -750,6 +759,7 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
     eplane[q4] = dz * a.Ho * a.Wo * (int)a.out_pitch;
   }
   auto eoff = [&](int i) { return eplane[i >> 2] + ((i & 3) + 4 * ((i >> 2) & 1)) * (int)a.out_pitch; };
+  const int ezh = 4 * a.Ho * a.Wo * (int)a.out_pitch;   // z half 1 of an 8-deep tile: four planes further
   // InstanceNorm partial rows are per WORKGROUP, not per tile: sample n owns WS_STAT_ROWS rows, row
   // pass * 256 + blockIdx.x (+ k gridDim.x for the slots no workgroup has) holds this workgroup's sums over its
   // tiles of n in that pass.  Every lane keeps running sums of ITS channel over the voxels it has produced (lr1 / lr2:
@@ -844,7 +854,7 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
   // stores too and retires in order; with a conditional store path in the loop hipcc assumes that no store is younger than
   // the loads the next tile's first commit waits for, emits vmcnt(4) and thereby waits for the write acknowledgements of
   // this tile's 32 NB stores at every tile top (the "tile top" share of the round-3 stamps).
-  auto epilogue = [&](f32x16 (&acc)[2 * NB], const WsTile& ET, auto plain_tag) __attribute__((always_inline)) {
+  auto epilogue = [&](f32x16 (&acc)[2 * NB * ZH], const WsTile& ET, auto plain_tag) __attribute__((always_inline)) {
     constexpr bool PLAIN = decltype(plain_tag)::value;
     const int z0 = ET.z0, y0 = ET.y0, x0 = ET.x0;
     const bool full = PLAIN || (z0 + TD <= a.Do && y0 + TH <= a.Ho && x0 + TW <= a.Wo);
@@ -857,8 +867,10 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
         if constexpr (BS) {
           // the y values of the tile's 32 voxels are requested first, the outputs stored under their latency; the sums
           // use the STORED (storage-rounded) gradient, as in_bwd_reduce would read it back
+#pragma unroll
+          for (int zh = 0; zh < ZH; zh++) {
           const T* const ybase = reinterpret_cast<const T*>(a.bs_y) +
-                                 ((((int64_t)ET.n * a.Do + z0) * a.Ho + y0 + 2 * wave) * a.Wo + x0) * a.bs_y_pitch + ch;
+                                 ((((int64_t)ET.n * a.Do + z0 + 4 * zh) * a.Ho + y0 + 2 * wave) * a.Wo + x0) * a.bs_y_pitch + ch;
           float yv[2][16];
 #pragma unroll
           for (int mb = 0; mb < 2; mb++)
@@ -868,10 +880,10 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
                                                 a.bs_y_pitch);
 #pragma unroll
           for (int mb = 0; mb < 2; mb++) {
-            T* const orow = obase + (int64_t)mb * a.Wo * a.out_pitch;
+            T* const orow = obase + (int64_t)mb * a.Wo * a.out_pitch + zh * ezh;
 #pragma unroll
             for (int i = 0; i < 16; i++) {
-              const float v = acc[nb * 2 + mb][i] + bias[nb];
+              const float v = acc[(nb * ZH + zh) * 2 + mb][i] + bias[nb];
               ST<T>::st(orow + eoff(i), v);
               T tmp;
               ST<T>::st(&tmp, v);
@@ -880,13 +892,16 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
               s2 += g * ((yv[mb][i] - bmu) * brs);
             }
           }
+          }
         } else {
 #pragma unroll
+        for (int zh = 0; zh < ZH; zh++)
+#pragma unroll
         for (int mb = 0; mb < 2; mb++) {
-          T* const orow = obase + (int64_t)mb * a.Wo * a.out_pitch;
+          T* const orow = obase + (int64_t)mb * a.Wo * a.out_pitch + zh * ezh;
 #pragma unroll
           for (int i = 0; i < 16; i++) {
-            const float v = acc[nb * 2 + mb][i] + bias[nb];
+            const float v = acc[(nb * ZH + zh) * 2 + mb][i] + bias[nb];
             ST<T>::st(orow + eoff(i), v);
             s1 += v;
             s2 += v * v;
@@ -899,14 +914,16 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
         // 2-byte value at a time behind a branch (up3's data gradient at 64^3: 252 us against 76 us for the same conv
         // without accumulation, on the critical path of the backward)
 #pragma unroll
+        for (int zh = 0; zh < ZH; zh++)
+#pragma unroll
         for (int mb = 0; mb < 2; mb++) {
-          T* const orow = obase + (int64_t)mb * a.Wo * a.out_pitch;
+          T* const orow = obase + (int64_t)mb * a.Wo * a.out_pitch + zh * ezh;
           float old[16];
 #pragma unroll
           for (int i = 0; i < 16; i++) old[i] = ST<T>::ld(orow + eoff(i));
 #pragma unroll
           for (int i = 0; i < 16; i++) {
-            const float v = acc[nb * 2 + mb][i] + bias[nb];
+            const float v = acc[(nb * ZH + zh) * 2 + mb][i] + bias[nb];
             ST<T>::st(orow + eoff(i), v + old[i]);
             s1 += v;
             s2 += v * v;
@@ -914,13 +931,15 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
         }
       } else {
 #pragma unroll
+        for (int zh = 0; zh < ZH; zh++)
+#pragma unroll
         for (int mb = 0; mb < 2; mb++) {
           const int gy = y0 + 2 * wave + mb;
-          T* const orow = obase + (int64_t)mb * a.Wo * a.out_pitch;
+          T* const orow = obase + (int64_t)mb * a.Wo * a.out_pitch + zh * ezh;
 #pragma unroll
           for (int i = 0; i < 16; i++) {
-            const int gz = z0 + edz[i >> 2], gx = x0 + (i & 3) + 4 * ((i >> 2) & 1);
-            const float v = acc[nb * 2 + mb][i] + bias[nb];
+            const int gz = z0 + edz[i >> 2] + 4 * zh, gx = x0 + (i & 3) + 4 * ((i >> 2) & 1);
+            const float v = acc[(nb * ZH + zh) * 2 + mb][i] + bias[nb];
             const bool ok = gz < a.Do && gy < a.Ho && gx < a.Wo;
             if (ok && ch_ok[nb]) {
               float o = v;
@@ -945,7 +964,7 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
   // (Rounds 1-2 deferred the epilogue of single-pass tiles into the MFMA gaps of the next tile, with two accumulator
   // register sets; once the 64-byte-row layers became two-pass that served only the 16->32 first layer, where it was
   // worth 3 % of the launch and nothing in the step, at 30 more registers: removed in round 3.)
-  f32x16 acc[2 * NB];  // [nb * 2 + mb]
+  f32x16 acc[2 * NB * ZH];  // [(nb * ZH + zh) * 2 + mb]
   auto tile_phase = [&](auto par_tag, auto fast_tag, auto plain_tag) __attribute__((always_inline)) {
     constexpr int PAR0 = decltype(par_tag)::value;
 #pragma unroll
@@ -972,16 +991,19 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
         read_xf(c_chunk);
       }
       WS2_STAMP(0)
-      u32x4 af[2][4], bf[2][3 * NB];
+      u32x4 af[2][4 * ZH], bf[2][3 * NB];
       // RB == 32: the 27 weight fragments of the single pass are the same LDS words for every tile, and hipcc hoists
       // their reads out of the tile loop into 108 AGPRs (384 registers in all: nothing of another stream fits beside
       // the workgroup -- the branch stream's first token kernels waited 150 us for the first encoder conv).  The
       // laundered pointer keeps the reads in the loop, as in the wider variants.
       const char* w_rd = w_lds;
       if constexpr (RB == 32) asm volatile("" : "+v"(w_rd));
-      auto read_group = [&](int g, u32x4 (&A)[4], u32x4 (&B)[3 * NB]) {
+      auto read_group = [&](int g, u32x4 (&A)[4 * ZH], u32x4 (&B)[3 * NB]) {
         const int t = g / NFS, fs = g % NFS, jz = t / 3, jx = t % 3;
-        auto rdA = [&](int yp) { A[yp] = *reinterpret_cast<const u32x4*>(a_rd + a_addr(jz, yp, jx, fs)); };
+        auto rdA = [&](int yp) {
+#pragma unroll
+          for (int zh = 0; zh < ZH; zh++) A[zh * 4 + yp] = *reinterpret_cast<const u32x4*>(a_rd + a_addr(jz, yp, jx, fs, zh));
+        };
         auto rdB = [&](int jy) {
 #pragma unroll
           for (int nb = 0; nb < NB; nb++)
@@ -1015,21 +1037,23 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
 #endif
           }
         }
-        u32x4(&A)[4] = af[g & 1];
+        u32x4(&A)[4 * ZH] = af[g & 1];
         u32x4(&B)[3 * NB] = bf[g & 1];
         if (c == 0 && g == 0) {  // first MFMAs of the tile take a zero C operand: no accumulator clearing
 #pragma unroll
-          for (int q2 = 0; q2 < 2 * NB; q2++)
+          for (int q2 = 0; q2 < 2 * NB * ZH; q2++)
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[q2][i] = 0.f;
         }
 #pragma unroll
         for (int jy = 0; jy < 3; jy++)
 #pragma unroll
-          for (int nb = 0; nb < NB; nb++) {
-            Mma<T>::run(A[jy], B[jy * NB + nb], acc[nb * 2 + 0]);      // mb 0: box row y' = jy
-            Mma<T>::run(A[jy + 1], B[jy * NB + nb], acc[nb * 2 + 1]);  // mb 1: box row y' = jy + 1
-          }
+          for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+            for (int zh = 0; zh < ZH; zh++) {
+              Mma<T>::run(A[zh * 4 + jy], B[jy * NB + nb], acc[(nb * ZH + zh) * 2 + 0]);      // mb 0: box row y' = jy
+              Mma<T>::run(A[zh * 4 + jy + 1], B[jy * NB + nb], acc[(nb * ZH + zh) * 2 + 1]);  // mb 1: box row y' = jy + 1
+            }
         __builtin_amdgcn_sched_barrier(0);
       }
       WS2_STAMP(1)
@@ -2855,9 +2879,27 @@ inline bool convt_fused_rows(int rb) { return rb == 32 || rb == 64 || rb == 128 
 
 template <typename T, int CH, int RB, int NB>
 int launch_ws2(const ConvArgs& a, hipStream_t st) {
-  const int tiles = a.N * ceil_div(a.Do, 4) * ceil_div(a.Ho, 8) * ceil_div(a.Wo, 8);
-  const int cout_tiles = a.CoutP / (32 * NB);
   const int budget = a.cu_budget > 0 ? std::min(a.cu_budget, hdf_cu_budget()) : hdf_cu_budget();
+  const int cout_tiles = a.CoutP / (32 * NB);
+#ifndef HDF_NO_WS2_TD8   // (A/B builds: the 4-deep tile everywhere)
+  // 64-byte rows, one output block, 16-bit storage, WITH an input transform (32 -> 32 channels at the top level, forward:
+  // block_1_2_left / block_1_2_right): the 8x8x8 tile (TDP = 8, see the kernel) when the depth is a whole number of tiles.
+  // Measured (tools/td8_ab.sh, same box, 32 -> 32 @128^3 batch 2): with the transform 303 vs 328 us; without 297 vs 300;
+  // data gradient with the statistics epilogue 351 vs 356 -- but the 8-deep form needs all 512 registers (384 spill 203),
+  // and a 512-register workgroup shares its compute unit with nothing: with all four launches of a step on it the step
+  // was 0.1 ms SLOWER (2 of 3 pairs).  So only the two forward launches take it: they run with the other streams idle or
+  // on their own quarter of the chip (forward3d), and they are where the gain is.
+  if constexpr (sizeof(T) == 2 && NB == 1 && RB == 64) {
+    if (a.in_scale && !a.bs_y && a.Do % 8 == 0 && a.Do >= 24 && a.Ho >= 24 && a.Wo >= 24) {
+      const int tiles8 = a.N * (a.Do / 8) * ceil_div(a.Ho, 8) * ceil_div(a.Wo, 8);
+      const int gx8 = std::min(tiles8, std::max(1, budget / cout_tiles));
+      hipLaunchKernelGGL((conv_ws2_kernel<T, CH, RB, true, NB, false, 8>), dim3(gx8, cout_tiles), dim3(256), 0, st, a);
+      HDF_LAUNCH_CHECK();
+      return HDF_OK;
+    }
+  }
+#endif
+  const int tiles = a.N * ceil_div(a.Do, 4) * ceil_div(a.Ho, 8) * ceil_div(a.Wo, 8);
   const int gx = std::min(tiles, std::max(1, budget / cout_tiles));  // one workgroup per CU; the kernel splits the tiles
   if constexpr (sizeof(T) == 2 && NB == 1 && RB == 64) {   // the level-0 32 -> 32 data gradient (hdf_conv_bwd_stats_ok)
     if (a.bs_y && !a.in_scale) {

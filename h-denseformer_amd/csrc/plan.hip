@@ -228,6 +228,7 @@ struct hdf_plan {
   unsigned* chain_flag = nullptr;      // host address
   unsigned* chain_flag_dev = nullptr;  // device address of the same word
   bool chain_off = false;
+  bool chain_forced = false;           // hdf_plan_force_persistent (tests): skip the residency check
   bool tf_fwd_chain = false;
   unsigned chain_last_giveup = 0;      // 1 + workgroup id of the last give-up seen (hdf_plan_chain_state)
   unsigned chain_ticks = 150000000u;   // deadline of one barrier wait, 100 MHz ticks (hdf_plan_set_chain_timeout_us)
@@ -620,8 +621,8 @@ void layout(hdf_plan* p, int B) {
   p->inb_k2 = bp.take((size_t)3 * B * 8 * nf * sizeof(float));
   p->inb_k3 = bp.take((size_t)3 * B * 8 * nf * sizeof(float));
   for (int k = 0; k < 4; k++) {
-    // (named for tools/cos_probe.py: after a backward g.y2_<k> holds the raw-output gradient of the encoder's second conv of
-    // level k, g.y_<k> that of its first conv -- the last writers of the two buffers)
+    // (named for tools/cos_probe.py: after a backward g.y_<k> holds the raw-output gradient of the encoder's SECOND conv of
+    // level k and g.a_<k> the gradient of its input activation -- the last writers of the two buffers)
     p->gA[k] = mkview(p, bp, "g.a_" + std::to_string(k), k, ch[k], B);
     p->gY[k] = mkview(p, bp, "g.y_" + std::to_string(k), k, ch[k], B);
     p->gY2[k] = mkview(p, bp, "g.y2_" + std::to_string(k), k, ch[k], B);  // the level's second conv keeps its own dy (read by a side-stream wgrad)
@@ -949,7 +950,9 @@ TfChainP tf_chain_params(const hdf_plan* p) {
 // backward consume records the launch-chain forward never wrote).
 bool tf_use_chain(const hdf_plan* p, int B) {
   const bool off = getenv("HDF_NO_TF_CHAIN") != nullptr;   // read per FORWARD call: tests switch it inside one process
-  return !off && !p->chain_off && tf_chain_supported(tf_dims(p, B));
+  if (off || p->chain_off) return false;
+  TfDims d = tf_dims(p, B);
+  return p->chain_forced ? tf_chain_shape_ok(d) : tf_chain_supported(d);
 }
 // the plan's host-mapped give-up word, created on first use
 int chain_flag_ensure(hdf_plan* p) {
@@ -1406,6 +1409,39 @@ int head_backward(Exec& e, const Head1& h, const void* dlogits, const View& in, 
 
 }  // namespace
 
+// A persistent transformer launch that gave up (transformer_chain.hip: chain_wait) leaves 1 + a workgroup id in its timeout
+// word.  NaN written into the branch output does NOT survive the network -- relu(InstanceNorm(.)) is fmaxf(x * scale +
+// shift, 0), and fmaxf returns the operand that is not NaN -- so the step would end with finite, plausible-looking logits
+// and gradients.  These two launches (one workgroup each, the LAST launch of a forward / of a backward on the caller's
+// stream, only when the persistent kernels ran) make the failure visible in the data itself: the first rows of every output
+// / the head of the flat gradient buffer become NaN, so the loss, and the optimizer step, are NaN.
+template <typename T>
+__global__ void chain_poison_outputs_kernel(const unsigned* __restrict__ tmo, T* o0, T* o1, T* o2, T* o3, int n0, int n1,
+                                            int n2, int n3) {
+  if (__hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+  T* o[4] = {o0, o1, o2, o3};
+  const int n[4] = {n0, n1, n2, n3};
+  for (int k = 0; k < 4; k++)
+    for (int i = threadIdx.x; i < n[k]; i += blockDim.x) ST<T>::st(o[k] + i, __builtin_nanf(""));
+}
+__global__ void chain_poison_grads_kernel(const unsigned* __restrict__ tmo, float* grads, int n) {
+  if (__hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) grads[i] = __builtin_nanf("");
+}
+
+// Stand-in for a collective's kernel (tests / tools): `workgroups` workgroups of 256 threads that each hold `lds_bytes` of
+// LDS (160 KiB = a compute unit of its own) and `vgprs` vector registers per lane (0: a handful; 128: what a RCCL
+// all-reduce kernel holds -- next to it a 304-register conv wave still fits a SIMD, a 512-register conv_wr wave or the
+// two 252-register waves of a persistent transformer workgroup do not), spinning on the 100 MHz real-time counter for `usec`.
+template <bool FAT>
+__global__ __launch_bounds__(256) void occupy_kernel(unsigned ticks) {
+  extern __shared__ char occ_lds[];
+  if (threadIdx.x == 0) occ_lds[0] = 1;
+  if (FAT) asm volatile("v_mov_b32 v127, 0" ::: "v127");   // forces an allocation of 128 VGPRs
+  const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < (uint64_t)ticks) __builtin_amdgcn_s_sleep(8);
+}
+
 // ================================================================================================ C ABI
 extern "C" {
 
@@ -1734,6 +1770,21 @@ static int forward3d(hdf_plan* p, const float* x, const float* params, void* wor
     dec_xf = xf_of(e, p->dec[k][1]);
     HDF_TRY(head_forward(e, p->head[k], *dec_in, dec_xf, outs[k]));
   }
+  if (p->tf_fwd_chain) {  // (see chain_poison_outputs_kernel: a launch that gave up must not leave plausible outputs)
+    const unsigned* tmo = reinterpret_cast<const unsigned*>(e.ws + p->tf_sync) + p->M * batch * 32;
+    int n[4];
+    for (int i = 0; i < 4; i++) n[i] = (int)std::min<int64_t>(p->vox(i) * p->ncls * batch, 4096);
+    if (p->dtype == HDF_F32)
+      hipLaunchKernelGGL(chain_poison_outputs_kernel<float>, dim3(1), dim3(256), 0, e.st, tmo, (float*)outs[0], (float*)outs[1],
+                         (float*)outs[2], (float*)outs[3], n[0], n[1], n[2], n[3]);
+    else if (p->dtype == HDF_BF16)
+      hipLaunchKernelGGL(chain_poison_outputs_kernel<bf16_t>, dim3(1), dim3(256), 0, e.st, tmo, (bf16_t*)outs[0],
+                         (bf16_t*)outs[1], (bf16_t*)outs[2], (bf16_t*)outs[3], n[0], n[1], n[2], n[3]);
+    else
+      hipLaunchKernelGGL(chain_poison_outputs_kernel<f16_t>, dim3(1), dim3(256), 0, e.st, tmo, (f16_t*)outs[0], (f16_t*)outs[1],
+                         (f16_t*)outs[2], (f16_t*)outs[3], n[0], n[1], n[2], n[3]);
+    HDF_LAUNCH_CHECK();
+  }
   return HDF_OK;
 }
 
@@ -1777,6 +1828,12 @@ int hdf_plan_set_chain_timeout_us(hdf_plan* p, int64_t usec) {
   return HDF_OK;
 }
 
+int hdf_plan_force_persistent(hdf_plan* p, int on) {
+  HDF_CHECK_ARG(p != nullptr, "plan_force_persistent: null plan");
+  p->chain_forced = on != 0;
+  return HDF_OK;
+}
+
 int hdf_plan_chain_state(hdf_plan* p, int batch, int* persistent, int* gave_up_workgroup) {
   HDF_CHECK_ARG(p && batch >= 1, "plan_chain_state: null plan / batch < 1");
   // (reads the host-mapped word like the next forward would, without consuming it: that call still reports the error)
@@ -1786,26 +1843,19 @@ int hdf_plan_chain_state(hdf_plan* p, int batch, int* persistent, int* gave_up_w
   return HDF_OK;
 }
 
-// Stand-in for a collective's kernel (tests / tools): `workgroups` workgroups of 256 threads that each hold `lds_bytes` of
-// LDS (160 KiB = a compute unit of its own) and spin on the 100 MHz real-time counter for `usec`.
-__global__ __launch_bounds__(256) void occupy_kernel(unsigned ticks) {
-  extern __shared__ char occ_lds[];
-  if (threadIdx.x == 0) occ_lds[0] = 1;
-  const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-  while (__builtin_amdgcn_s_memrealtime() - t0 < (uint64_t)ticks) __builtin_amdgcn_s_sleep(8);
-}
-int hdf_op_occupy(int workgroups, int lds_bytes, int usec, hdf_stream stream) {
+int hdf_op_occupy(int workgroups, int lds_bytes, int vgprs, int usec, hdf_stream stream) {
   HDF_CHECK_ARG(workgroups >= 1 && workgroups <= 4096 && lds_bytes >= 0 && lds_bytes <= 160 * 1024 && usec >= 1 &&
-                    usec <= 10000000,
-                "op_occupy: workgroups 1..4096, lds 0..160 KiB, 1 us..10 s");
-  if (lds_bytes > 64 * 1024 &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          160 * 1024) != hipSuccess) {
+                    usec <= 10000000 && (vgprs == 0 || vgprs == 128),
+                "op_occupy: workgroups 1..4096, lds 0..160 KiB, vgprs 0 or 128, 1 us..10 s");
+  const void* fn = vgprs ? reinterpret_cast<const void*>(occupy_kernel<true>) : reinterpret_cast<const void*>(occupy_kernel<false>);
+  if (lds_bytes > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
     hdf_set_error("op_occupy: hipFuncSetAttribute failed");
     return HDF_ERR_HIP;
   }
-  hipLaunchKernelGGL(occupy_kernel, dim3(workgroups), dim3(256), (size_t)lds_bytes, (hipStream_t)stream,
-                     (unsigned)usec * 100u);
+  if (vgprs)
+    hipLaunchKernelGGL(occupy_kernel<true>, dim3(workgroups), dim3(256), (size_t)lds_bytes, (hipStream_t)stream, (unsigned)usec * 100u);
+  else
+    hipLaunchKernelGGL(occupy_kernel<false>, dim3(workgroups), dim3(256), (size_t)lds_bytes, (hipStream_t)stream, (unsigned)usec * 100u);
   HDF_LAUNCH_CHECK();
   return HDF_OK;
 }
@@ -2079,6 +2129,12 @@ static int backward3d(hdf_plan* p, const float* x, const float* params, void* wo
     }
   }
   e.join();
+  if ((stages & 4) && p->tf_fwd_chain) {  // (chain_poison_grads_kernel: the persistent backward's timeout word, second half)
+    const unsigned* tmo = reinterpret_cast<const unsigned*>(e.ws + p->tf_sync) + (1 << 17) + p->M * batch * 32;
+    hipLaunchKernelGGL(chain_poison_grads_kernel, dim3(1), dim3(256), 0, e.st, tmo, grads,
+                       (int)std::min<int64_t>(p->total_floats, 4096));
+    HDF_LAUNCH_CHECK();
+  }
   return HDF_OK;
 }
 

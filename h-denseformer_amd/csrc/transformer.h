@@ -167,6 +167,7 @@ struct TfChainP {
 // the launch takes the shape (one workgroup per 16 tokens of a sequence, all resident at once: tiles <= hdf_cu_budget(),
 // which is capped by the device's compute-unit count)
 bool tf_chain_supported(const TfDims& d);
+bool tf_chain_shape_ok(const TfDims& d);   // the shape alone (hdf_plan_force_persistent: tests of the give-up path)
 // What a persistent launch does when a per-sequence barrier is not completed in time (the grid was not resident together:
 // the device is shared).  `host_flag`: device address of a host-mapped word (the plan's; null for operator-level calls)
 // that receives 1 + the id of the workgroup that gave up; `ticks`: deadline of one wait in 100 MHz real-time ticks.

@@ -282,9 +282,11 @@ __device__ __forceinline__ void chain_arrive(unsigned* cnt, bool storing = true)
 // host-mapped flag word (system scope: the host reads it without synchronising, plan.hip chain_flag_check), stops waiting
 // for the rest of the launch and runs to the end on whatever it reads; every other workgroup sees the word in its own poll
 // loop and does the same, so the launch ends within about one timeout.  Its results are garbage BY DEFINITION: dead
-// workgroups overwrite their output rows with NaN at the end of the kernel (chain_poison_*), so the step's loss /
-// gradients are NaN rather than plausible, and the plan's next call returns HDF_ERR_CHAIN_TIMEOUT once and routes this
-// plan to the launch chain from then on.
+// workgroups overwrite their rows of the branch output with NaN at the end of the kernel (which rows were lost: NaN does
+// not survive relu(InstanceNorm(.)) = fmaxf(.., 0) downstream), the plan's last launch of the call turns the head of every
+// output / of the gradient buffer into NaN when the timeout word is set (plan.hip: chain_poison_*_kernel), so the step's
+// loss and optimizer step are NaN rather than plausible, and the plan's next call returns HDF_ERR_CHAIN_TIMEOUT once and
+// routes this plan to the launch chain from then on.
 using ChainCtl = TfChainCtl;   // (transformer.h: host-mapped flag word + give-up deadline)
 __device__ __forceinline__ void chain_wait(unsigned* cnt, unsigned target, unsigned* tmo, const ChainCtl& c, bool& dead) {
   if (threadIdx.x == 0 && !dead) {
@@ -798,8 +800,8 @@ __global__ __launch_bounds__(CT) void tf_chain_fwd_kernel(ChainFwd a) {
       CHAIN_STAMP(7);
     }
   }
-  // a workgroup that gave up at a barrier overwrites its rows of the branch output with NaN (chain_wait): the decoder's
-  // InstanceNorm statistics, and with them the loss, are then NaN instead of plausible
+  // a workgroup that gave up at a barrier overwrites its rows of the branch output with NaN (chain_wait; a marker of WHICH
+  // rows were lost -- what makes the step's loss NaN is plan.hip's chain_poison_outputs_kernel)
   if (chain_any_dead(dead, reinterpret_cast<unsigned*>(s_red))) {
     const float qnan = __builtin_nanf("");
     for (int i = tid; i < nvalid * DM; i += CT) {
@@ -1709,7 +1711,7 @@ __global__ __launch_bounds__(CT) void tf_chain_bwd_kernel(ChainBwd a) {
     CHAIN_STAMPB(8);
   }
   // a workgroup that gave up at a barrier (chain_wait) overwrites its rows of block 0's input gradient with NaN: the patch
-  // embedding's gradients, and the optimizer step, are then NaN instead of plausible
+  // embedding's gradients are then NaN (and plan.hip's chain_poison_grads_kernel marks the head of the gradient buffer)
   if (chain_any_dead(dead, reinterpret_cast<unsigned*>(s_red))) {
     const float qnan = __builtin_nanf("");
     for (int i = tid; i < nvalid * DM; i += CT) {
@@ -1773,10 +1775,14 @@ size_t tf_chain_wpack_bytes(const TfDims& d, int nb) {
   return ((size_t)d.M * nb * 4 * CH_SLOT + (size_t)d.M * nb * CO_SLOT) * 64 * sizeof(float4);
 }
 
+// what the kernels can address, whatever the grid
+bool tf_chain_shape_ok(const TfDims& d) {
+  return d.DM % 32 == 0 && d.DM >= 32 && d.DM <= 256 && d.N >= 1 && (int64_t)d.N * 96 * 4 < ((int64_t)1 << 31);
+}
+// ... and every workgroup of the grid resident at once: one compute unit each (512 threads at ~250 registers fill a unit's
+// register files), so tiles <= the units the launch may assume -- hdf_cu_budget(), capped by the device's own count
 bool tf_chain_supported(const TfDims& d) {
-  const int ntile = ceil_div(d.N, TT);
-  return d.DM % 32 == 0 && d.DM >= 32 && d.DM <= 256 && d.N >= 1 && d.M * d.B * ntile <= hdf_cu_budget() &&
-         (int64_t)d.N * 96 * 4 < ((int64_t)1 << 31);
+  return tf_chain_shape_ok(d) && d.M * d.B * ceil_div(d.N, TT) <= hdf_cu_budget();
 }
 
 int tf_chain_pack(const TfDims& d, const TfChainP& cp, int nb, const float* params, void* wpack, hipStream_t st) {
@@ -1830,7 +1836,7 @@ int chain_serial_done(hipStream_t st, int dev) {
 int tf_chain_forward(const TfDims& d, const TfChainP& cp, int nb, const float* params, float* F0, float* save,
                      void* attnall, unsigned* sync, void* wpack, float* frag, int dtype, hipStream_t st,
                      const TfChainCtl& ctl) {
-  HDF_CHECK_ARG(tf_chain_supported(d), "transformer chain: shape not supported (M %d B %d N %d DM %d)", d.M, d.B, d.N, d.DM);
+  HDF_CHECK_ARG(tf_chain_shape_ok(d), "transformer chain: shape not supported (M %d B %d N %d DM %d)", d.M, d.B, d.N, d.DM);
   ChainFwd a{};
   HDF_CHECK_ARG(chain_digest(cp, d.DM, a.cw), "transformer chain: irregular parameter layout");
   a.d = d, a.params = params, a.F0 = F0, a.save = save, a.attnall = attnall, a.sync = sync;

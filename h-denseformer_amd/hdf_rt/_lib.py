@@ -36,7 +36,8 @@ _PROTOS = {
     "hdf_plan_set_probe": (_i, [_vp, _vp, _vp]),
     "hdf_plan_set_chain_timeout_us": (_i, [_vp, _i64]),
     "hdf_plan_chain_state": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(_i)]),
-    "hdf_op_occupy": (_i, [_i, _i, _i, _vp]),
+    "hdf_plan_force_persistent": (_i, [_vp, _i]),
+    "hdf_op_occupy": (_i, [_i, _i, _i, _i, _vp]),
     "hdf_loss_workspace_bytes": (_i64, [_i]),
     "hdf_loss_forward": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "hdf_loss_backward": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,

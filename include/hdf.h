@@ -118,9 +118,13 @@ int hdf_backward_events(hdf_plan* p, const float* x, const float* params, void* 
 #define HDF_ERR_CHAIN_TIMEOUT 4
 int hdf_plan_set_chain_timeout_us(hdf_plan* p, int64_t usec);
 int hdf_plan_chain_state(hdf_plan* p, int batch, int* persistent, int* gave_up_workgroup);
+/* Tests only: take the persistent kernels even when their grid cannot be resident together (more 16-token tiles than
+ * compute units).  Such a forward gives up by construction: this is how tests/test_gpu_chain.py exercises the path above. */
+int hdf_plan_force_persistent(hdf_plan* p, int on);
 /* Tests and tools: a stand-in for a collective's kernel -- `workgroups` workgroups of 256 threads, each holding `lds_bytes`
- * of LDS (160 KiB: a compute unit of its own), spinning for `usec` on the device's real-time counter. */
-int hdf_op_occupy(int workgroups, int lds_bytes, int usec, hdf_stream stream);
+ * of LDS (160 KiB: a compute unit of its own) and `vgprs` (0 or 128) vector registers per lane, spinning for `usec` on the
+ * device's real-time counter. */
+int hdf_op_occupy(int workgroups, int lds_bytes, int vgprs, int usec, hdf_stream stream);
 
 /* Measurement hook: every following hdf_forward on this plan records ev_start immediately before and ev_stop immediately
  * after the launch of the forward's dominant convolution (block_1_1_right, 64 -> 32 channels at full resolution: the

@@ -154,40 +154,46 @@ def test_chain_backward_is_bit_identical_to_the_launch_chain(case):
 
 def test_a_persistent_launch_that_cannot_be_resident_gives_up_cleanly_and_the_plan_falls_back():
     """a per-sequence barrier that is not completed in time no longer traps (a trap kills the caller's HIP
-    context).  A stand-in kernel holds all but 8 compute units for 60 ms while a forward with a 3 ms deadline launches its 32
-    persistent workgroups: 8 become resident, wait for siblings that cannot be dispatched, give up -- the launch ends by
-    itself, the device stays usable, the outputs of that call are NaN (never plausible garbage), the plan's NEXT call
-    reports HDF_ERR_CHAIN_TIMEOUT once without launching anything, and from then on the plan runs the launch chain, whose
-    results equal the persistent kernels' bit for bit."""
+    context).  The grid of this geometry -- 8 modalities x 2 samples x 32 tiles = 512 workgroups -- cannot be resident on
+    256 compute units; hdf_plan_force_persistent (tests only) makes the plan launch it anyway with a 3 ms deadline.  The
+    resident half waits for siblings that cannot be dispatched and gives up: the launch ends by itself, the device stays
+    usable, the outputs of that call are NaN (never plausible garbage), the plan's NEXT call reports
+    HDF_ERR_CHAIN_TIMEOUT once without launching anything, and from then on the plan runs the launch chain -- the same
+    results as a plan that never tried."""
     import ctypes as C
     from hdf_rt._lib import HdfError, check, lib
-    case = CASES[2]
+    case = (8, 2, 16, (128, 128, 128), 4, 2, BF16)
     cin, ncls, nf, image, depth, batch, dtype = case
-    good, (plan, rt, params, x, _) = _forward(case, chain=True)
+    assert cin * batch * 32 > torch.cuda.get_device_properties(0).multi_processor_count
+    good, _ = _forward(case, chain=True)        # (not forced: 512 tiles > 256 units, i.e. the launch chain)
+    plan = Plan(cin, ncls, nf, image, depth, dtype)
+    rt = Runtime(plan, DEV)
+    params = _params(plan, 1)
+    x = torch.rand((batch, cin) + image, generator=torch.Generator().manual_seed(2)).to(DEV)
     pers, who = C.c_int(-1), C.c_int(-2)
     check(lib().hdf_plan_chain_state(plan.h, batch, C.byref(pers), C.byref(who)), "chain_state")
-    assert (pers.value, who.value) == (1, -1)
+    assert (pers.value, who.value) == (0, -1)
+    check(lib().hdf_plan_force_persistent(plan.h, 1), "force_persistent")
     check(lib().hdf_plan_set_chain_timeout_us(plan.h, 3000), "set_chain_timeout")
-    cus = torch.cuda.get_device_properties(0).multi_processor_count
-    side = torch.cuda.Stream()
-    check(lib().hdf_op_occupy(cus - 8, 160 * 1024, 60000, side.cuda_stream), "occupy")
+    check(lib().hdf_plan_chain_state(plan.h, batch, C.byref(pers), C.byref(who)), "chain_state")
+    assert pers.value == 1
     outs = rt.forward(x, params, 1, 1234, need_backward=True)
     torch.cuda.synchronize()                      # returns: no trap, no HIP error
     sync = rt.read_region("tf_sync").view(torch.int32)
-    assert int(sync[32 * cin * batch]) != 0, "the forward was expected to give up (were the compute units really held?)"
+    assert int(sync[32 * cin * batch]) != 0, "a 512-workgroup persistent grid was expected to give up on 256 units"
     check(lib().hdf_plan_chain_state(plan.h, batch, C.byref(pers), C.byref(who)), "chain_state")
-    assert pers.value == 0 and 0 <= who.value < 32, (pers.value, who.value)
+    assert pers.value == 0 and 0 <= who.value < 512, (pers.value, who.value)
     assert bool(torch.isnan(outs[0].float()).any()), "a launch that gave up must poison its outputs"
     with pytest.raises(HdfError, match="gave up"):
         rt.forward(x, params, 1, 1234, need_backward=True)
-    outs3 = rt.forward(x, params, 1, 1234, need_backward=True)    # the launch chain from now on
+    outs3 = rt.forward(x, params, 1, 1234, need_backward=True)    # the launch chain from now on, forced or not
     torch.cuda.synchronize()
     check(lib().hdf_plan_chain_state(plan.h, batch, C.byref(pers), C.byref(who)), "chain_state")
     assert pers.value == 0
     for a, b in zip(outs3, good["outs"]):
         assert torch.equal(a, b)
     assert torch.equal(rt.read_region("tf_save").view(torch.int32), good["save"].view(torch.int32))
-    # ... and a backward behind that forward follows it (launch chain), finite gradients
+    # ... and a backward behind that forward follows it (launch chain): finite gradients
     g = torch.Generator().manual_seed(5)
     douts = [(torch.randn(o.shape, generator=g) * 1e-2).to(DEV).to(o.dtype) for o in outs3]
     grads = torch.zeros_like(params)

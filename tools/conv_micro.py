@@ -20,6 +20,7 @@ ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--xf", type=int, default=0)
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--wr", type=int, default=0, help="1: force conv_wr_kernel (hdf_op_conv3d_wr)")
+ap.add_argument("--bs", type=int, default=0, help="1: the data-gradient form with the statistics epilogue (hdf_op_conv3d_bwd_stats)")
 ap.add_argument("--cold", type=int, default=0, help="1: evict L2 / memory-side cache before every timed launch")
 a = ap.parse_args()
 dt = BF16 if a.dtype == "bf16" else F32
@@ -38,7 +39,17 @@ if a.op == "conv":
     sc = torch.rand(n, cin, device=dev) + 0.5 if a.xf else None
     sh = torch.randn(n, cin, device=dev) * 0.1 if a.xf else None
 
+    if a.bs:
+        ybs = torch.randn(n, s, s, s, cout, device=dev).to(tdt)
+        bsv = [torch.rand(n * cout, device=dev) + 0.5, torch.randn(n * cout, device=dev) * 0.1,
+               torch.randn(n * cout, device=dev) * 0.1, torch.rand(n * cout, device=dev) + 0.5]
+        part = torch.empty(max(n * tiles, n * 512) * coutp * 2, device=dev)
+
     def launch():
+        if a.bs:
+            check(lib().hdf_op_conv3d_bwd_stats(dt, ptr(x), cin, cin, n, s, s, s, ptr(w), ptr(out), cout, cout, ptr(ybs), cout,
+                                                ptr(bsv[0]), ptr(bsv[1]), ptr(bsv[2]), ptr(bsv[3]), ptr(part), st), "conv_bs")
+            return
         if a.wr:
             check(lib().hdf_op_conv3d_wr(dt, ptr(x), cin, cin, n, s, s, s, ptr(w), None, ptr(sc), ptr(sh), 1, ptr(out),
                                          cout, cout, ptr(part), 0, st), "conv_wr")
@@ -115,4 +126,4 @@ if os.environ.get("WS_STAMPS") and a.op == "wgrad":
     t = ws.view(torch.float32)[: 256 * per].view(256, per)[:, :8].double().cpu()
     names = ["top", "kloop-fast", "barrier", "-", "-", "kloop-slow", "-", "-"]
     print("  per-WG cycles (mean over groups):", {n: int(v) for n, v in zip(names, t.mean(0).tolist())}, "total", int(t.sum(1).mean().item()))
-print(f"{a.op} {cin}->{cout} @{s}^3 n={n} {a.dtype} xf={a.xf}: {ms*1e3:.1f} us  {flops/ms/1e9:.1f} TFLOP/s")
+print(f"{a.op} {cin}->{cout} @{s}^3 n={n} {a.dtype} xf={a.xf} bs={a.bs}: {ms*1e3:.1f} us  {flops/ms/1e9:.1f} TFLOP/s")

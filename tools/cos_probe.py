@@ -2,7 +2,7 @@
 (reference models/HDenseFormer.py:196-199) -- sit at cosine 0.950 against the fp32 run when every other tensor of the bf16
 step is >= 0.98?  (VERDICT r05 #7.)  The tool separates the kernel's arithmetic from its operands.  A g4-geometry step
 (n_filters 32, 64^3, batch 2, train mode) is run with fp32 storage and with bf16 storage; for that layer it takes
-     dy  = the gradient w.r.t. the conv's raw output (workspace buffer g.y2_0 after the backward) and
+     dy  = the gradient w.r.t. the conv's raw output (workspace buffer g.y_0 after the backward) and
      x   = relu(InstanceNorm(raw output of block_1_1_left)) = the conv's input (buffer y.block_1_1_left + its statistics)
 from both runs and forms the weight gradient  dW[o][i][tap] = sum_v dy[v][o] x[v + tap - 1][i]  with torch in float64 from
 every combination of the two runs' operands.  Prints the cosines; one JSON line at the end."""
@@ -46,7 +46,7 @@ def run(cfg, batch, dtype, seed=11):
     torch.cuda.synchronize()
     rt = net._last_rt
     grads = {k: p.grad.detach().double().clone() for k, p in net.named_parameters()}
-    dy = rt.read_buffer("g.y2_0").double()                       # [B, C, D, H, W]
+    dy = rt.read_buffer("g.y_0").double()                       # [B, C, D, H, W]
     yprev = rt.read_buffer("y." + PREV).double()
     params = dict(net.named_parameters())
     gamma, beta = params[PREV + ".norm.weight"].detach().double(), params[PREV + ".norm.bias"].detach().double()
@@ -55,7 +55,29 @@ def run(cfg, batch, dtype, seed=11):
     xin = torch.relu((yprev - mu) / torch.sqrt(var + 1e-5) * gamma.view(1, -1, 1, 1, 1) + beta.view(1, -1, 1, 1, 1))
     if dtype != "fp32":   # what the kernels see: the transformed input rounded to the storage type on its way into LDS
         xin = xin.to(torch.bfloat16).double()
-    return grads, dy, xin
+    # the InstanceNorm(+ReLU) backward of LAYER itself, in float64, from what the run stored: da = d(ds_0) (buffer g.ds0, the
+    # gradient of relu(IN(y))), y = the conv's raw output
+    da = rt.read_buffer("g.ds0").double()
+    y = rt.read_buffer("y." + LAYER).double()
+    g2, b2 = params[LAYER + ".norm.weight"].detach().double(), params[LAYER + ".norm.bias"].detach().double()
+    mu2 = y.mean(dim=(2, 3, 4), keepdim=True)
+    rstd2 = 1.0 / torch.sqrt(y.var(dim=(2, 3, 4), unbiased=False, keepdim=True) + 1e-5)
+    xh = (y - mu2) * rstd2
+    gg = da * ((xh * g2.view(1, -1, 1, 1, 1) + b2.view(1, -1, 1, 1, 1)) > 0)
+    m1 = gg.mean(dim=(2, 3, 4), keepdim=True)
+    m2 = (gg * xh).mean(dim=(2, 3, 4), keepdim=True)
+    k1 = g2.view(1, -1, 1, 1, 1) * rstd2
+    dy_f64 = k1 * (gg - m1 - xh * m2)
+    # d(ds_0) = [gradient routed back through MaxPool3d(2)] + [the decoder's skip-path gradient].  The first part is
+    # g.pool1 scattered to the arg-max voxel of every 2x2x2 window of ds_0 (this run's OWN stored ds_0 decides the voxel)
+    ds0 = rt.read_buffer("ds0").double()
+    dpool = rt.read_buffer("g.pool1").double()
+    _, idx = F.max_pool3d(ds0.float(), 2, return_indices=True)
+    pool_part = F.max_unpool3d(dpool.float(), idx, 2).double()
+    extra = {"da": da, "dy_f64": dy_f64, "cancel": float(dy_f64.norm() / (k1 * gg).norm()),
+             "pool_part": pool_part, "skip_part": da - pool_part, "idx": idx, "dpool": dpool,
+             "mean_share": float((k1 * m1.expand_as(gg)).norm() / (k1 * gg).norm())}
+    return grads, dy, xin, extra
 
 
 def wgrad(dy, x):
@@ -73,12 +95,33 @@ def wgrad(dy, x):
 
 def main():
     cfg, batch = (4, 4, 32, (64, 64, 64), 8), 2
-    g32, dy32, x32 = run(cfg, batch, "fp32")
-    g16, dy16, x16 = run(cfg, batch, "bf16")
+    g32, dy32, x32, e32 = run(cfg, batch, "fp32")
+    g16, dy16, x16, e16 = run(cfg, batch, "bf16")
     name = LAYER + ".conv.weight"
     rec = {"layer": name, "cos_step_bf16_vs_fp32": cos(g16[name], g32[name]),
            "cos_dy": cos(dy16, dy32), "cos_x": cos(x16, x32),
            "rel_l2_dy": float((dy16 - dy32).norm() / dy32.norm()), "rel_l2_x": float((x16 - x32).norm() / x32.norm())}
+    # where dy's error comes from: the stored d(activation) of the two runs, the InstanceNorm backward redone in float64
+    # from each run's stored tensors, and how much of |k1 g| survives the subtraction of the two means
+    rec["cos_da"] = cos(e16["da"], e32["da"])
+    rec["rel_l2_da"] = float((e16["da"] - e32["da"]).norm() / e32["da"].norm())
+    rec["cos_f64_in_bwd_of_bf16_tensors_vs_bf16_dy"] = cos(e16["dy_f64"], dy16)
+    rec["cos_f64_in_bwd_of_bf16_tensors_vs_fp32_dy"] = cos(e16["dy_f64"], dy32)
+    rec["cos_f64_in_bwd_of_fp32_tensors_vs_fp32_dy"] = cos(e32["dy_f64"], dy32)
+    rec["norm_dy_over_norm_k1_g"] = e32["cancel"]
+    rec["norm_mean_term_over_norm_k1_g"] = e32["mean_share"]
+    # ... and which of the two parts of d(ds_0) differs: arg-max decisions of the pooling windows that changed between the
+    # runs (values that are distinct in fp32 and equal, or swapped, after rounding ds_0 to bf16) move a window's whole
+    # gradient to another voxel
+    live = e32["dpool"].abs() > 0
+    rec["pool_windows_with_another_argmax"] = float(((e16["idx"] != e32["idx"]) & live).sum() / live.sum())
+    rec["cos_pool_part"] = cos(e16["pool_part"], e32["pool_part"])
+    rec["cos_skip_part"] = cos(e16["skip_part"], e32["skip_part"])
+    rec["cos_pooled_gradient_g_pool1"] = cos(e16["dpool"], e32["dpool"])
+    rec["pool_part_energy_share"] = float(e32["pool_part"].norm() ** 2 / e32["da"].norm() ** 2)
+    # the fp32 run's pooled gradient routed by the BF16 run's arg-max decisions: isolates the decisions from the values
+    mixed = F.max_unpool3d(e32["dpool"].float(), e16["idx"], 2).double()
+    rec["cos_fp32_pooled_gradient_routed_by_bf16_argmax"] = cos(mixed, e32["pool_part"])
     combos = {"dy32_x32": (dy32, x32), "dy16_x16": (dy16, x16), "dy16_x32": (dy16, x32), "dy32_x16": (dy32, x16)}
     dw = {k: wgrad(a, b) for k, (a, b) in combos.items()}
     rec["cos_f64_from_fp32_operands_vs_fp32_step"] = cos(dw["dy32_x32"], g32[name])     # sanity: the probe reads the right buffers

@@ -52,12 +52,13 @@ def main():
     class OccupySync(GradSync):
         """GradSync whose collective is a kernel that holds `wgs` compute units for `usec` (no data moved)"""
 
-        def __init__(self, model, wgs, usec):
+        def __init__(self, model, wgs, usec, lds, vgprs):
             super().__init__(model)
-            self.wgs, self.usec = wgs, usec
+            self.wgs, self.usec, self.lds, self.vgprs = wgs, usec, lds, vgprs
 
         def _reduce(self, chunk):
-            check(lib().hdf_op_occupy(self.wgs, 160 * 1024, self.usec, torch.cuda.current_stream().cuda_stream), "occupy")
+            check(lib().hdf_op_occupy(self.wgs, self.lds, self.vgprs, self.usec, torch.cuda.current_stream().cuda_stream),
+                  "occupy")
 
     sync = GradSync(net)                      # one-call backward + bucket events (default protocol)
     sync_staged = GradSync(net, staged=True)  # round-3 protocol: three staged backward calls
@@ -97,10 +98,31 @@ def main():
     g_sync = net.flat_grads().clone()
     err = float((g_sync - g_plain).abs().max() / (g_plain.abs().max() + 1e-30))
 
-    rec = {"world": dist.get_world_size(), "backend": dist.get_backend(), "size": size, "grad_rel_err": err,
-           "ms_one_call": timed(None), "ms_three_stages_noop_hook": timed(lambda stage: None), "ms_three_stages_rccl": timed(sync_staged), "ms_one_call_events_rccl": timed(sync)}
-    for wgs in (16, 32):
-        rec["ms_one_call_events_standin_%dcu_300us" % wgs] = timed(OccupySync(net, wgs, 300))
+    rec = {"world": dist.get_world_size(), "backend": dist.get_backend(), "size": size, "grad_rel_err": err}
+    # Legs, measured in ROUNDS (every leg once per round, in this order, so that drift of the box shows up as a difference
+    # between rounds rather than between legs).  Stand-in collectives: "rccl_like" = 128 VGPRs + 16 KiB of LDS per workgroup;
+    # "whole_cu" = 160 KiB of LDS (shares a unit with nothing).  "budget224": the persistent kernels' grids sized for 224 of
+    # the 256 units (32 left to the collective: hdf_set_cu_budget; the transformer branches then run as the launch chain).
+    legs = [("ms_one_call", 256, lambda: None),
+            ("ms_three_stages_noop_hook", 256, lambda: (lambda stage: None)),
+            ("ms_three_stages_rccl", 256, lambda: sync_staged),
+            ("ms_one_call_events_rccl", 256, lambda: sync)]
+    for tag, lds, vg in (("rccl_like", 16 * 1024, 128), ("whole_cu", 160 * 1024, 0)):
+        for wgs in (16, 32):
+            legs.append(("ms_one_call_events_standin_%s_%dwg_300us" % (tag, wgs), 256,
+                         lambda wgs=wgs, lds=lds, vg=vg: OccupySync(net, wgs, 300, lds, vg)))
+    legs.append(("ms_one_call_budget224", 224, lambda: None))
+    for tag, lds, vg in (("rccl_like", 16 * 1024, 128), ("whole_cu", 160 * 1024, 0)):
+        legs.append(("ms_one_call_events_budget224_standin_%s_32wg_300us" % tag, 224,
+                     lambda lds=lds, vg=vg: OccupySync(net, 32, 300, lds, vg)))
+    rounds = int(os.environ.get("HDF_STAGE_COST_ROUNDS", "2"))
+    for name, _b, _m in legs:
+        rec[name] = []
+    for _ in range(rounds):
+        for name, budget, make in legs:
+            check(lib().hdf_set_cu_budget(budget), "budget")
+            rec[name].append(round(timed(make()), 4))
+    check(lib().hdf_set_cu_budget(256), "budget")
     pers, who = C.c_int(), C.c_int()
     check(lib().hdf_plan_chain_state(net._last_rt.plan.h, 2, C.byref(pers), C.byref(who)), "chain_state")
     rec["persistent_kernels_still_on"] = pers.value
