@@ -230,6 +230,7 @@ struct hdf_plan {
   bool chain_off = false;
   bool chain_forced = false;           // hdf_plan_force_persistent (tests): skip the residency check
   bool tf_fwd_chain = false;
+  bool tf_bwd_chain = false;           // the last backward ran the persistent kernel (its timeout word is valid)
   unsigned chain_last_giveup = 0;      // 1 + workgroup id of the last give-up seen (hdf_plan_chain_state)
   unsigned chain_ticks = 150000000u;   // deadline of one barrier wait, 100 MHz ticks (hdf_plan_set_chain_timeout_us)
   ~hdf_plan() {
@@ -1098,7 +1099,8 @@ int transformer_backward(Exec& e, const float* x) {
     HDF_TRY(tf_wgrad(w, 1, p->M, e.wgrad_stream()));
     return e.side_done();
   };
-  if (p->tf_fwd_chain && tf_chain_backward_supported(d, p->dtype)) {
+  p->tf_bwd_chain = p->tf_fwd_chain && tf_chain_backward_supported(d, p->dtype);
+  if (p->tf_bwd_chain) {
     // one persistent launch for all layers (transformer_chain.hip); then every block's weight-matrix gradients from the
     // tapes on the side stream, next to the patch embedding's backward on this one
     HDF_TRY(tf_chain_backward(d, tf_chain_params(p), p->nb, pm, e.grads, F0, e.f(p->tf_save), dF, e.at(p->dAttnall),
@@ -2129,7 +2131,7 @@ static int backward3d(hdf_plan* p, const float* x, const float* params, void* wo
     }
   }
   e.join();
-  if ((stages & 4) && p->tf_fwd_chain) {  // (chain_poison_grads_kernel: the persistent backward's timeout word, second half)
+  if ((stages & 4) && p->tf_bwd_chain) {  // (chain_poison_grads_kernel: the persistent backward's timeout word, second half)
     const unsigned* tmo = reinterpret_cast<const unsigned*>(e.ws + p->tf_sync) + (1 << 17) + p->M * batch * 32;
     hipLaunchKernelGGL(chain_poison_grads_kernel, dim3(1), dim3(256), 0, e.st, tmo, grads,
                        (int)std::min<int64_t>(p->total_floats, 4096));

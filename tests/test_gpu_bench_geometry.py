@@ -196,6 +196,29 @@ def _cosines(net, ref_grads, min_energy=1e-3):
     return out
 
 
+def _gate_cosines(cos, low="bf16"):
+    """The 16-bit gate on per-tensor gradient cosines (list sorted ascending).  Every tensor >= 0.95 -- except ONE with a
+    two-sided band of its own: block_1_2_left.conv.weight, the encoder's second convolution at full resolution, sits at
+    0.950 +- 0.002 in every bf16 run (0.9496 at 64^3, 0.9517 at 128^3, 0.9493 at 144^3) and at 0.9927 in float16.
+    tools/cos_probe.py (profiles/r06_cos_probe.txt) took it apart: the weight-gradient kernel is exact on its own operands
+    (cosine 0.99999997 against a float64 contraction of the tensors the bf16 run stored), its input activation agrees with
+    the fp32 run to 0.99999, and all of the loss is in the incoming gradient d(ds_0) (cosine 0.942), which is already at
+    0.946 when it arrives from level 1 through the pooling layer: it is the end of the longest backward path of the
+    network (bottleneck -> three encoder levels), and on that path the cosine falls level by level (3_1: 0.979, 2_1:
+    0.970, 1_2: 0.950) by DECISIONS that flip -- ReLU gates and max-pool arg-maxima recomputed from activations stored
+    with an 8-bit mantissa -- not by accumulated rounding: 1 - cos shrinks 6.9x from bf16 to float16, the 8x of the
+    rounding step, where rounding noise alone would shrink 64x.  The reference's autocast stores the same tensors in 16
+    bits.  A band on both sides pins the value (VERDICT r05 #7: a floor that follows the measurement is not a gate)."""
+    special = "block_1_2_left.conv.weight"
+    for name, c in cos:
+        if name == special and low == "bf16":
+            assert 0.944 <= c <= 0.957, (name, c)
+        elif name == special:
+            assert c >= 0.985, (name, c)           # float16 storage: 0.9927
+        else:
+            assert c >= 0.95, (name, c, cos[:4])
+
+
 def _norm_ratios(net, ref_grads, scale=1.0, min_energy=1e-2):
     """worst |g| / |g_ref| over the tensors that carry >= min_energy of the reference's squared gradient norm"""
     tot = sum(float(v.double().norm()) ** 2 for v in ref_grads.values())
@@ -248,10 +271,7 @@ def test_mid_train_step_vs_reference_golden(dtype):
         cos = _cosines(net, {k: v.grad for k, v in tr.sd.items()})
         for k, c in cos[:6]:
             print(f"  bf16 cosine {k:60s} {c:.4f}")
-        # (the worst tensor, block_1_2_left.conv.weight, sits at 0.950 +- 0.001: the value moves in the fourth digit with
-        # ulp-level changes of the fp32 token arithmetic -- 0.9503 in round 4, 0.9497 once round 5 pinned the LayerNorm /
-        # GELU helpers' fused multiply-adds, identically in the launch chain and in the persistent kernels)
-        assert cos[0][1] >= 0.945, cos[:4]
+        _gate_cosines(cos)
 
 
 # ------------------------------------------------------------------------------------------------- BENCH shape
@@ -291,7 +311,7 @@ def test_full_size_train_step_fp32_and_bench_bf16_vs_reference_golden():
     cos = _cosines(net, ref_grads)
     for k, c in cos[:8]:
         print(f"  bf16 cosine {k:60s} {c:.4f}")
-    assert cos[0][1] >= 0.945, cos[:4]   # (block_1_2_left.conv.weight sits at 0.950 +- 0.001: see test_mid_train_step_vs_reference_golden)
+    _gate_cosines(cos)
     mine = torch.cat([p.grad.flatten() for p in net.parameters()]).double()
     theirs = torch.cat([ref_grads[k].flatten() for k, _ in net.named_parameters()]).double()
     whole = float((mine @ theirs) / (mine.norm() * theirs.norm()))
@@ -361,7 +381,7 @@ def test_baseline_config_shapes_forward_vs_oracle_and_low_precision_step(name, c
     cos = _cosines(net, ref_grads)
     for k, c in cos[:5]:
         print(f"  {low} cosine {k:60s} {c:.4f}")
-    assert cos[0][1] >= 0.945, cos[:4]   # (block_1_2_left.conv.weight sits at 0.950 +- 0.001: see test_mid_train_step_vs_reference_golden)
+    _gate_cosines(cos, low)
     assert all(bool(torch.isfinite(p.grad).all()) for p in net.parameters())
     scale = 65536.0 if low == "fp16" else 1.0
     worst = _norm_ratios(net, ref_grads, scale)
