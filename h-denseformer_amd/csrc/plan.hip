@@ -217,7 +217,7 @@ struct hdf_plan {
   std::vector<hipEvent_t> events;
   size_t ev_next = 0;
   // "gradient bucket k is final" (hdf_backward_events): recorded on whichever stream of the call finishes the bucket
-  hipEvent_t bucket_ev[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t bucket_ev[HDF_NUM_GRAD_BUCKETS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   // hdf_plan_set_probe: caller-owned events recorded around the dominant conv launch of the forward (measurement only)
   hipEvent_t probe_start = nullptr, probe_stop = nullptr;
   // Persistent transformer kernels (transformer_chain.hip).  chain_flag: one host-mapped word a launch writes (system
@@ -1812,7 +1812,7 @@ int hdf_backward_events(hdf_plan* p, const float* x, const float* params, void* 
                         const void* dout0, const void* dout1, const void* dout2, const void* dout3, float* grads,
                         int batch, hdf_stream stream, void** bucket_events) {
   HDF_CHECK_ARG(p && bucket_events, "backward_events: null argument");
-  for (int k = 0; k < 3; k++) {
+  for (int k = 0; k < HDF_NUM_GRAD_BUCKETS; k++) {
     if (!p->bucket_ev[k] && hipEventCreateWithFlags(&p->bucket_ev[k], hipEventDisableTiming) != hipSuccess) {
       p->bucket_ev[k] = nullptr;
       hdf_set_error("backward_events: could not create an event");
@@ -1862,6 +1862,18 @@ int hdf_op_occupy(int workgroups, int lds_bytes, int vgprs, int usec, hdf_stream
   return HDF_OK;
 }
 
+int hdf_plan_grad_bucket(const hdf_plan* p, int k, int64_t* lo, int64_t* hi) {
+  HDF_CHECK_ARG(p && lo && hi && k >= 0 && k < HDF_NUM_GRAD_BUCKETS, "plan_grad_bucket: bucket 0..%d", HDF_NUM_GRAD_BUCKETS - 1);
+  HDF_CHECK_ARG(!p->is2d, "plan_grad_bucket: the 2-D plan's gradients are final together (one bucket: the whole buffer)");
+  // state_dict order: attns.* | deep_conv, up1..3 | block_1_*_left | block_2_*_left .. block_4_*_left | upconv_3 .. heads
+  const int64_t chain = p->P("deep_conv.double_conv.0.weight"), enc0 = p->P("block_1_1_left.conv.weight"),
+                enc1 = p->P("block_2_1_left.conv.weight"), dec = p->P("upconv_3.weight"), end = p->total_floats;
+  HDF_CHECK_ARG(0 < chain && chain < enc0 && enc0 < enc1 && enc1 < dec && dec < end, "plan_grad_bucket: unexpected parameter order");
+  const int64_t b[HDF_NUM_GRAD_BUCKETS][2] = {{dec, end}, {chain, enc0}, {0, chain}, {enc1, dec}, {enc0, enc1}};
+  *lo = b[k][0], *hi = b[k][1];
+  return HDF_OK;
+}
+
 int hdf_plan_set_probe(hdf_plan* p, void* ev_start, void* ev_stop) {
   HDF_CHECK_ARG(p && ((ev_start == nullptr) == (ev_stop == nullptr)), "plan_set_probe: both events or none");
   p->probe_start = (hipEvent_t)ev_start, p->probe_stop = (hipEvent_t)ev_stop;
@@ -1900,8 +1912,8 @@ static int backward_any(hdf_plan* p, const float* x, const float* params, void* 
   HDF_TRY(backward3d(p, (const float*)(ws + p->e_x3d), (const float*)(ws + p->e_params3d), workspace, workspace_bytes,
                      d3[0], d3[1], d3[2], d3[3], g3, batch, stages, stream));
   HDF_TRY(launch_extract2d(p, stages, g3, grads, st));
-  if (bev) {  // the 2-D gradients exist only after the extraction: all three buckets are final here
-    for (int k = 0; k < 3; k++)
+  if (bev) {  // the 2-D gradients exist only after the extraction: every bucket is final here
+    for (int k = 0; k < HDF_NUM_GRAD_BUCKETS; k++)
       if (hipEventRecord(bev[k], st) != hipSuccess) {
         hdf_set_error("backward: could not record a bucket event");
         return HDF_ERR_HIP;
@@ -1939,10 +1951,16 @@ static int upconv_chain_backward(Exec& e, int batch) {
   return HDF_OK;
 }
 
-// bev (optional, stages == 7): three events, recorded where the parameter gradients of bucket 1 (encoder / decoder /
-// heads), 2 (UpConv chain) and 3 (transformer branches) are final -- on the caller's stream, the side stream or the
-// branch stream, whichever finishes them -- so that a communication stream can start a bucket's all-reduce while the
-// rest of this one call is still running (no staged calls, the branch-stream fork stays).
+// bev (optional, stages == 7): HDF_NUM_GRAD_BUCKETS events, recorded where the parameter gradients of a bucket
+// (hdf_plan_grad_bucket: 0 decoder + heads, 1 UpConv chain, 2 transformer branches, 3 encoder levels 1-3, 4 encoder
+// level 0) are final -- on the caller's stream, the side stream or the branch stream, whichever finishes them -- so that a
+// communication stream can start a bucket's all-reduce while the rest of this one call is still running (no staged calls,
+// the branch-stream fork stays).  Round 6: five buckets instead of three.  With one "encoder / decoder / heads" bucket 26
+// of the 62 MB became final with the LAST kernel of the backward (the first encoder layer's weight gradient) and their
+// all-reduce was fully exposed (profiles/r06_timeline_standin_32cu_300us.txt: two of three stand-in collectives ran
+// behind the backward); now the decoder + heads (final a third of the way into the backward) and the encoder's levels
+// 1-3 (final before the UpConv chain's backward starts) are reduced under the rest, and what is final at the very end is
+// the first level's two layers: 0.1 MB.
 static int backward3d(hdf_plan* p, const float* x, const float* params, void* workspace, int64_t workspace_bytes,
                       const void* dout0, const void* dout1, const void* dout2, const void* dout3, float* grads,
                       int batch, int stages, hdf_stream stream, hipEvent_t* bev) {
@@ -1950,10 +1968,26 @@ static int backward3d(hdf_plan* p, const float* x, const float* params, void* wo
   HDF_TRY(chain_flag_check(p));
   auto record = [&](int k, hipStream_t s) -> int {
     if (bev && hipEventRecord(bev[k], s) != hipSuccess) {
-      hdf_set_error("backward: could not record the event of gradient bucket %d", k + 1);
+      hdf_set_error("backward: could not record the event of gradient bucket %d", k);
       return HDF_ERR_HIP;
     }
     return HDF_OK;
+  };
+  enum { BK_DEC = 0, BK_CHAIN = 1, BK_TF = 2, BK_ENC = 3, BK_ENC0 = 4 };
+  // "everything enqueued so far on the caller's stream AND on the side stream": the side stream (where the bucket's conv
+  // weight gradients run) waits for the caller's position (InstanceNorm / head / bias gradients) and carries the event.
+  // Every side-stream launch already waits for the caller's position of its own launch point, so this orders nothing new.
+  auto record_joined = [&](int k, Exec& ex) -> int {
+    if (!bev) return HDF_OK;
+    if (ex.async && p->side) {
+      hipEvent_t f = ex.next_event();
+      if (!f || hipEventRecord(f, ex.st) != hipSuccess || hipStreamWaitEvent(p->side, f, 0) != hipSuccess) {
+        hdf_set_error("backward: could not order the side stream for the event of gradient bucket %d", k);
+        return HDF_ERR_HIP;
+      }
+      return record(k, p->side);
+    }
+    return record(k, ex.st);
   };
   HDF_CHECK_ARG((size_t)workspace_bytes >= p->ws_bytes,
                 "backward: workspace of %lld bytes holds a forward only (hdf_plan_workspace_bytes = %zu)",
@@ -2025,6 +2059,7 @@ static int backward3d(hdf_plan* p, const float* x, const float* params, void* wo
       HDF_TRY(convt_backward(e, p->upc[k], dup, p->x4, none, p->dX4));
   }
   HDF_TRY(head_backward(e, p->head[3], douts[3], p->x4, none, p->dX4, 1));
+  HDF_TRY(record_joined(BK_DEC, e));   // upconv_1..3, block_*_right, the four heads: nothing below touches their gradients
 
   // ---- encoder, bottom (level 3) up to level 0.  dskip: gradient of ds_k (= of the transformer feature at_k too)
   for (int k = 3; k >= 0; k--) {
@@ -2069,7 +2104,7 @@ static int backward3d(hdf_plan* p, const float* x, const float* params, void* wo
             hdf_set_error("side stream: event failed");
             return HDF_ERR_HIP;
           }
-          HDF_TRY(record(1, p->side));
+          HDF_TRY(record(BK_CHAIN, p->side));
         }
       }
     }
@@ -2100,18 +2135,19 @@ static int backward3d(hdf_plan* p, const float* x, const float* params, void* wo
       else
         HDF_TRY(norm_conv_backward(e, c1, p->gA[k], p->gY2[k], bsr, p->xin, none, nullptr, 0));
     }
+    if (k == 1) HDF_TRY(record_joined(BK_ENC, e));   // block_2_* .. block_4_*_left: the encoder below the top level is done
     // (host order: the ten level-0 launches of the caller's stream first, then the ~100 of the transformer backward)
     if (k == 0 && forked) {
       HDF_TRY(transformer_backward(eb, x));
       if (bev) {
         eb.join();  // (the branch's own side-stream launches, if any)
-        HDF_TRY(record(2, eb.st));
+        HDF_TRY(record(BK_TF, eb.st));
       }
     }
   }
 
   if (!(stages & 6) || bev) e.join();  // staged call (gradient buckets) / bucket event: final here
-  HDF_TRY(record(0, e.st));
+  HDF_TRY(record(BK_ENC0, e.st));
   }  // stage 1: every gradient of the encoder / decoder / head parameters is final here
   if (forked) {
     HDF_TRY(e.join_branch(eb));
@@ -2120,13 +2156,13 @@ static int backward3d(hdf_plan* p, const float* x, const float* params, void* wo
     if (stages & 2) {
       HDF_TRY(upconv_chain_backward(e, batch));
       if (!(stages & 4) || bev) e.join();  // staged call: final when it returns; else the transformer branches run under them
-      HDF_TRY(record(1, e.st));
+      HDF_TRY(record(BK_CHAIN, e.st));
     }  // stage 2: deep_conv / up1..3 gradients are final
     if (stages & 4) {
       HDF_TRY(transformer_backward(e, x));
       if (bev) {
         e.join();
-        HDF_TRY(record(2, e.st));
+        HDF_TRY(record(BK_TF, e.st));
       }
     }
   }

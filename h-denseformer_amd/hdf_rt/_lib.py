@@ -32,6 +32,7 @@ _PROTOS = {
     "hdf_backward": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "hdf_backward_stages": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "hdf_backward_events": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _vp, C.POINTER(_vp)]),
+    "hdf_plan_grad_bucket": (_i, [_vp, _i, C.POINTER(_i64), C.POINTER(_i64)]),
     "hdf_stream_wait_event": (_i, [_vp, _vp]),
     "hdf_plan_set_probe": (_i, [_vp, _vp, _vp]),
     "hdf_plan_set_chain_timeout_us": (_i, [_vp, _i64]),

@@ -108,16 +108,28 @@ class Runtime:
                                         ptr(douts[0]), ptr(douts[1]), ptr(douts[2]), ptr(douts[3]), ptr(flat_grads),
                                         b, stages, stream_ptr()), "hdf_backward")
 
+    NUM_GRAD_BUCKETS = 5        # HDF_NUM_GRAD_BUCKETS (include/hdf.h)
+
+    def grad_buckets(self):
+        """[(lo, hi)] float ranges of the gradient buckets of hdf_backward_events (hdf_plan_grad_bucket): 0 decoder +
+        heads, 1 UpConv chain, 2 transformer branches, 3 encoder levels 1-3, 4 encoder level 0."""
+        out = []
+        for k in range(self.NUM_GRAD_BUCKETS):
+            lo, hi = C.c_int64(), C.c_int64()
+            check(lib().hdf_plan_grad_bucket(self.plan.h, k, C.byref(lo), C.byref(hi)), "hdf_plan_grad_bucket")
+            out.append((lo.value, hi.value))
+        return out
+
     def backward_events(self, x, flat_params, douts, flat_grads):
-        """The one-call backward; returns three opaque event handles: gradient bucket k (the stage-(k+1) bucket of
-        hdf_rt.parallel.bucket_bounds) is final once handle k has fired (include/hdf.h: hdf_backward_events)."""
+        """The one-call backward; returns NUM_GRAD_BUCKETS opaque event handles: gradient bucket k (grad_buckets()[k]) is
+        final once handle k has fired (include/hdf.h: hdf_backward_events)."""
         import ctypes
         b = x.shape[0]
-        evs = (ctypes.c_void_p * 3)()
+        evs = (ctypes.c_void_p * self.NUM_GRAD_BUCKETS)()
         check(lib().hdf_backward_events(self.plan.h, ptr(x), ptr(flat_params), ptr(self.ws), self.ws.numel(),
                                         ptr(douts[0]), ptr(douts[1]), ptr(douts[2]), ptr(douts[3]), ptr(flat_grads),
                                         b, stream_ptr(), evs), "hdf_backward_events")
-        return [evs[0], evs[1], evs[2]]
+        return [evs[k] for k in range(self.NUM_GRAD_BUCKETS)]
 
     def read_buffer(self, name):
         """Debug / parity helper: copy a named channels-last activation out of the workspace as NCDHW fp32

@@ -362,7 +362,12 @@ class HDenseFormer(nn.Module):
             # ONE backward call (the branch-stream fork stays, no host round trip between the stages); the library
             # hands back one event per gradient bucket, recorded where that bucket becomes final, and the hook makes
             # its communication stream wait for them
-            self.grad_hook.on_bucket_events(rt.backward_events(x, self._flat, douts, gflat))
+            if getattr(rt.plan, "is2d", False) or len(rt.plan.cfg[3]) == 2:
+                # 2-D plans: every bucket is final when the 2-D gradients are extracted -- one range, the last event
+                evs = rt.backward_events(x, self._flat, douts, gflat)
+                self.grad_hook.on_bucket_events([evs[-1]] * len(evs), [(0, gflat.numel())] + [(0, 0)] * (len(evs) - 1))
+            else:
+                self.grad_hook.on_bucket_events(rt.backward_events(x, self._flat, douts, gflat), rt.grad_buckets())
         else:
             # each stage's parameter gradients are final when it returns: their all-reduce overlaps the next stage
             rt.backward(x, self._flat, douts, gflat, stages=1)      # decoder / encoder / heads

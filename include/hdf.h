@@ -90,17 +90,27 @@ int hdf_backward_stages(hdf_plan* p, const float* x, const float* params, void* 
                         const void* dout0, const void* dout1, const void* dout2, const void* dout3, float* grads,
                         int batch, int stages, hdf_stream stream);
 
-/* hdf_backward (ONE call, with its internal side / branch streams) that also tells the caller when each of the three
- * gradient buckets of hdf_backward_stages is final: bucket_events[k] (k = 0: encoder / decoder / heads, 1: UpConv chain,
- * 2: transformer branches) receives an event owned by the plan -- the three handles are stable for the plan's lifetime and
- * RE-RECORDED by every hdf_backward_events call, so a waiter must enqueue its wait before the next call --, already recorded, on whichever internal stream finishes that bucket, when the call returns.  A
- * communication stream that waits for event k (hdf_stream_wait_event, or hipStreamWaitEvent on the handle) may all-reduce
- * bucket k while the rest of the backward is still running: no host round trip between the stages, the branch-stream
- * fork of the one-call backward stays.  Order of finality in the default arrangement: bucket 1 (chain), 0, 2.
- * Replaces nn.DataParallel's reduce (trainer.py:228-229). */
+/* hdf_backward (ONE call, with its internal side / branch streams) that also tells the caller when each gradient BUCKET is
+ * final.  The flat gradient buffer is cut into HDF_NUM_GRAD_BUCKETS contiguous ranges (hdf_plan_grad_bucket, floats):
+ *   0  decoder + heads      (upconv_3 .. conv1x1_d3)        final a third of the way into the backward
+ *   1  UpConv chain         (deep_conv, up1..3)             final when the chain's backward is through
+ *   2  transformer branches (attns.*)                       final at the end of the branch stream
+ *   3  encoder levels 1-3   (block_2_1_left .. block_4_2_left)   final before the UpConv chain's backward starts
+ *   4  encoder level 0      (block_1_1_left, block_1_2_left: 0.1 MB)   final with the last kernel of the call
+ * (round 6: five buckets; rounds 4-5 had three, and their "encoder / decoder / heads" bucket -- 26 of 62 MB at n_filters 32
+ * -- was final only at the very end, i.e. its all-reduce was exposed.)  bucket_events[k] receives an event owned by the plan
+ * -- the handles are stable for the plan's lifetime and RE-RECORDED by every hdf_backward_events call, so a waiter must
+ * enqueue its wait before the next call --, already recorded, on whichever internal stream finishes that bucket, when the
+ * call returns.  A communication stream that waits for event k (hdf_stream_wait_event, or hipStreamWaitEvent on the
+ * handle) may all-reduce bucket k while the rest of the backward is still running: no host round trip between the stages,
+ * the branch-stream fork of the one-call backward stays.  Order of finality in the default arrangement: 0, 3, 1, 2, 4.
+ * 2-D plans: all five events are recorded at the end (their gradients are extracted from the embedding in one pass), and
+ * hdf_plan_grad_bucket is refused.  Replaces nn.DataParallel's reduce (trainer.py:228-229). */
+#define HDF_NUM_GRAD_BUCKETS 5
+int hdf_plan_grad_bucket(const hdf_plan* p, int k, int64_t* lo, int64_t* hi);
 int hdf_backward_events(hdf_plan* p, const float* x, const float* params, void* workspace, int64_t workspace_bytes,
                         const void* dout0, const void* dout1, const void* dout2, const void* dout3, float* grads,
-                        int batch, hdf_stream stream, void** bucket_events /* [3] hipEvent_t out */);
+                        int batch, hdf_stream stream, void** bucket_events /* [HDF_NUM_GRAD_BUCKETS] hipEvent_t out */);
 /* ---- the persistent transformer kernels and a shared device (round 6) ----------------------------------------------
  * The plan runs all dense layers of the multi-path transformer (models/HDenseFormer.py:78-145) as ONE persistent launch per
  * direction when every 16-token tile gets a compute unit of its own (tiles <= the device's compute units; else, and under
@@ -108,8 +118,9 @@ int hdf_backward_events(hdf_plan* p, const float* x, const float* params, void* 
  * workgroups must be resident together.  The library guarantees that within the PROCESS (one such launch in flight per
  * device at a time: each waits for the previous one's event).  If something else holds compute units long enough that a
  * per-sequence barrier is not completed within the deadline (default 1.5 s), the launch does NOT trap any more: it ends by
- * itself, overwrites the rows of the workgroups that gave up with NaN (loss / gradients of that step become NaN, never
- * plausible garbage), and writes a host-mapped status word.  The plan's NEXT hdf_forward / hdf_backward* call then launches
+ * itself and writes a host-mapped status word; the call's last launch then turns the head of every output (forward) / of
+ * the gradient buffer (backward) into NaN, so the loss and the optimizer step of that iteration are NaN, never plausible
+ * garbage.  The plan's NEXT hdf_forward / hdf_backward* call then launches
  * nothing and returns HDF_ERR_CHAIN_TIMEOUT (4) once, and the plan uses the launch chain from then on: redo the step.
  * hdf_plan_set_chain_timeout_us: the deadline of one barrier wait (100 us .. 30 s).
  * hdf_plan_chain_state: *persistent = 1 when the next forward of `batch` samples would take the persistent kernels;

@@ -681,10 +681,10 @@ def test_fp16_storage_flat_adam_with_gradscaler():
 def test_gradsync_bucket_events_keep_the_one_call_backward():
     """under GradSync the backward stays ONE call (hdf_backward_events: branch-stream fork, no host round
     trip between the stages); the library hands back one event per gradient bucket and the communication stream waits
-    for them.  Stand-in collective as in the staged test below.  Asserted with HIP events: the three reduces run in the
-    order the buckets become final (UpConv chain, encoder/decoder/heads, transformer), the first one STARTS before the
-    backward has finished on the caller's stream (it overlaps), wait() orders the optimizer behind all of them, and the
-    gradient equals the one-shot backward's."""
+    for them.  Stand-in collective as in the staged test below.  Asserted with HIP events: the five reduces (round 6:
+    decoder + heads, encoder levels 1-3, UpConv chain, transformer, encoder level 0 -- hdf_plan_grad_bucket) run in the
+    order the buckets become final, the first three START before the backward has finished on the caller's stream (they
+    overlap), wait() orders the optimizer behind all of them, and the gradient equals the one-shot backward's."""
     import torch.distributed as dist
     from hdf_rt import parallel
     from loss.combine_loss import CEPlusDice, DeepSuperloss
@@ -737,14 +737,23 @@ def test_gradsync_bucket_events_keep_the_one_call_backward():
             parallel.flat_allreduce_mean = orig
             net.grad_hook = None
         ms = lambda a, b: a.elapsed_time(b)      # noqa: E731
-        assert len(marks) == 3
-        want = [sync.buckets[k][1] - sync.buckets[k][0] for k in sync.EVENT_ORDER]
-        assert [abs(a - b) < 32 for a, b in zip(sizes, want)] == [True] * 3, (sizes, want)
+        assert len(marks) == 5
+        ranges = net._last_rt.grad_buckets()
+        # the five ranges tile the flat gradient buffer exactly (state_dict order: transformer | chain | encoder level 0 |
+        # encoder levels 1-3 | decoder + heads)
+        order = sorted(ranges)
+        assert order[0][0] == 0 and all(order[i][1] == order[i + 1][0] for i in range(4))
+        assert abs(order[-1][1] - net.flat_grads().numel()) < 32
+        assert [r for r in order] == [ranges[2], ranges[1], ranges[4], ranges[3], ranges[0]]
+        want = [ranges[k][1] - ranges[k][0] for k in sync.EVENT_ORDER]
+        assert [abs(a - b) < 32 for a, b in zip(sizes, want)] == [True] * 5, (sizes, want)
         print("  backward end %.3f ms; reduce spans:" % ms(t_begin, t_bwd_end),
               [(round(ms(t_begin, a), 3), round(ms(t_begin, b), 3)) for a, b in marks])
-        assert ms(marks[0][0], t_bwd_end) > 0.0          # the chain bucket's reduce starts while the backward still runs
-        assert ms(marks[1][0], t_bwd_end) > 0.0          # ... and so does the encoder / decoder bucket's
+        # the first three buckets (decoder + heads, encoder levels 1-3, UpConv chain) start their reduce while the backward
+        # still runs: only the transformer branches' and the 0.1 MB of encoder level 0 are final at its end
         for k in range(3):
+            assert ms(marks[k][0], t_bwd_end) > 0.0, k
+        for k in range(5):
             assert ms(marks[k][1], t_after_wait) >= 0.0
         assert _rl2(net.flat_grads(), g_ref) < 1e-5
     finally:

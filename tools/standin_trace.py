@@ -26,7 +26,8 @@ from models.HDenseFormer import HDenseFormer
 
 class OccupySync(GradSync):
     def _reduce(self, chunk):
-        check(lib().hdf_op_occupy(wgs, lds, vg, usec, torch.cuda.current_stream().cuda_stream), "occupy")
+        us = max(10, int(usec * chunk.numel() * 4 / 26.0e6))     # `usec` per 26 MB (the largest bucket of rounds 4-5)
+        check(lib().hdf_op_occupy(wgs, lds, vg, us, torch.cuda.current_stream().cuda_stream), "occupy")
 
 
 dev = torch.device("cuda", 0)
