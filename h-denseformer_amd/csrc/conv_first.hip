@@ -520,7 +520,7 @@ bool hdf_conv_first_can(int dtype, int Cin, int Cout, int D, int H, int W, int64
 
 // the plan's routing rule: where the generic launcher would use conv_ws2_kernel (same InstanceNorm partials geometry)
 bool hdf_conv_first_takes(int dtype, int Cin, int Cout, int D, int H, int W, int64_t in_pitch) {
-  return hdf_conv_first_can(dtype, Cin, Cout, D, H, W, in_pitch) && (int64_t)D * H * W >= 48 * 48 * 48 &&
+  return hdf_conv_first_can(dtype, Cin, Cout, D, H, W, in_pitch) && D > 1 && (int64_t)D * H * W >= 48 * 48 * 48 &&
          hdf_conv_stat_tiles(0, D, H, W, 32) == WS_STAT_ROWS;
 }
 
@@ -557,7 +557,7 @@ int hdf_launch_conv_first(int dtype, const void* in, int64_t in_pitch, int Cin, 
 
 bool hdf_wgrad_first_takes(int dtype, int Cin, int Cout, int D, int H, int W, int64_t x_pitch, int64_t dy_pitch) {
   return hdf_conv_first_can(dtype, Cin, Cout, D, H, W, x_pitch) && Cout % 8 == 0 && dy_pitch % 8 == 0 &&
-         (int64_t)D * H * W * dy_pitch < ((int64_t)1 << 31) && (int64_t)D * H * W >= 48 * 48 * 48;
+         (int64_t)D * H * W * dy_pitch < ((int64_t)1 << 31) && D > 1 && (int64_t)D * H * W >= 48 * 48 * 48;
 }
 
 int hdf_launch_wgrad_first(int dtype, const void* dy, int64_t dy_pitch, int Cout, const void* x, int64_t x_pitch, int Cin,

@@ -90,12 +90,18 @@ __device__ __forceinline__ void stage_box(char* lds, const T* __restrict__ src, 
 
 // ------------------------------------------------------------------------------------------------
 // forward-style kernel (modes 0,1,2)
-template <typename T, int TD, int TH, int TW, int WM, int WN, int MB, int S, bool CONVT>
+// FLAT (round 6): the 2-D operators of models/HDenseFormer_2D.py (Conv2d k3, ConvTranspose2d k3 s2 p1 op1 and its data
+// gradient) on tensors of depth 1 -- TD = 1 tiles, only the 9 taps of the centre depth plane of the [27][CoutP][Cin] panel
+// (a Conv2d kernel sits on depth tap 1 of the Conv3d panel: plan.hip "2-D embedding"), a one-plane box, and a depth axis
+// that is never strided (stride-2 gather and transposed conv stride y and x only: 4 output-parity classes, not 8).  For the
+// stride-1 conv this is exactly the 3-D operator on a depth-1 volume (the other 18 taps meet zero padding only).
+template <typename T, int TD, int TH, int TW, int WM, int WN, int MB, int S, bool CONVT, bool FLAT = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   if (a.prio) HDF_LIGHT_PRIO();
   static_assert(WM * WN == 4, "4 waves");
   static_assert(WM * MB * 32 == TD * TH * TW, "tile/wave decomposition");
-  constexpr int BD = CONVT ? TD + 1 : S * (TD - 1) + 3;
+  static_assert(!FLAT || TD == 1, "flat tiles are one voxel deep");
+  constexpr int BD = FLAT ? 1 : (CONVT ? TD + 1 : S * (TD - 1) + 3);
   constexpr int BH = CONVT ? TH + 1 : S * (TH - 1) + 3;
   constexpr int BW = CONVT ? TW + 1 : S * (TW - 1) + 3;
   constexpr int SS = CONVT ? 1 : S;
@@ -120,17 +126,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   const int z0 = tz * TD, y0 = ty * TH, x0 = tx * TW;
   const int n_base = blockIdx.y * (WN * 32) + wn * 32;
   const int cls = CONVT ? blockIdx.z : 0;
-  const int pz = (cls >> 2) & 1, py = (cls >> 1) & 1, px = cls & 1;
-  const int ntapz = CONVT ? (pz ? 2 : 1) : 3, ntapy = CONVT ? (py ? 2 : 1) : 3, ntapx = CONVT ? (px ? 2 : 1) : 3;
+  const int pz = FLAT ? 0 : (cls >> 2) & 1, py = (cls >> 1) & 1, px = cls & 1;
+  const int ntapz = FLAT ? 1 : (CONVT ? (pz ? 2 : 1) : 3), ntapy = CONVT ? (py ? 2 : 1) : 3, ntapx = CONVT ? (px ? 2 : 1) : 3;
 
-  const int oz = CONVT ? z0 : S * z0 - 1, oy = CONVT ? y0 : S * y0 - 1, ox = CONVT ? x0 : S * x0 - 1;
+  const int oz = (CONVT || FLAT) ? z0 : S * z0 - 1, oy = CONVT ? y0 : S * y0 - 1, ox = CONVT ? x0 : S * x0 - 1;
 
   int rowbase[MB];
 #pragma unroll
   for (int mb = 0; mb < MB; mb++) {
     int lin = (wm * MB + mb) * 32 + r;
     int lz = lin / (TH * TW), ly = (lin / TW) % TH, lx = lin % TW;
-    rowbase[mb] = ((SS * lz) * BH + SS * ly) * BW + SS * lx;
+    rowbase[mb] = (((FLAT ? 0 : SS * lz)) * BH + SS * ly) * BW + SS * lx;
   }
   f32x16 acc[MB];
 #pragma unroll
@@ -158,7 +164,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     // plain loop below waited for one L2 round trip per step, which at the low resolutions (one or two workgroups
     // per CU, nothing to switch to) left the matrix pipe idle 70-90 % of the time.
     if ((a.Cin * ESZ) % 64 == 0) {
-      constexpr int NS = 54;                       // fragment steps per chunk
+      constexpr int NS = FLAT ? 18 : 54;           // fragment steps per chunk (taps x 2)
+      constexpr int TAP0 = FLAT ? 9 : 0;           // first tap of the panel this kernel uses (flat: the centre depth plane)
 #ifndef V1_RING_BIG
 #define V1_RING_BIG 6
 #endif
@@ -178,12 +185,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       // the same size in both layouts.  With row-major panels a fragment load touched 32 cache lines for 1 KB and
       // the vector cache's line rate, not latency, bounded the low-resolution layers.
       auto b_load = [&](int chunk, int s_) -> u32x4 {
-        const int tap = s_ >> 1, fs = s_ & 1;
+        const int tap = TAP0 + (s_ >> 1), fs = s_ & 1;
         const char* p = wfr + tap * wtap_stride + (int64_t)chunk * cstride + fs * fstride;
         return *reinterpret_cast<const u32x4*>(n_active ? p : reinterpret_cast<const char*>(a.w));
       };
       auto a_off = [&](int s_) {
-        const int tap = s_ >> 1, fs = s_ & 1;
+        const int tap = s_ >> 1, fs = s_ & 1;   // (flat: tap = 3 ky + kx in the one staged plane)
         return ((tap / 9 * BH + (tap / 3) % 3) * BW + tap % 3) * PITCH + h * 16 + fs * 32;
       };
 #pragma unroll
@@ -235,7 +242,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     if (n_active) {
       const int nfs = row_bytes >> 5;  // fragment steps (32 B each) in this chunk
       for (int jz = 0; jz < ntapz; jz++) {
-        const int offz = CONVT ? (pz ? 1 - jz : 0) : jz, wz = CONVT ? (pz ? 2 * jz : 1) : jz;
+        const int offz = FLAT ? 0 : (CONVT ? (pz ? 1 - jz : 0) : jz), wz = FLAT ? 1 : (CONVT ? (pz ? 2 * jz : 1) : jz);
         for (int jy = 0; jy < ntapy; jy++) {
           const int offy = CONVT ? (py ? 1 - jy : 0) : jy, wy = CONVT ? (py ? 2 * jy : 1) : jy;
 #pragma unroll
@@ -301,7 +308,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         int lz = lin / (TH * TW), ly = (lin / TW) % TH, lx = lin % TW;
         int gz = z0 + lz, gy = y0 + ly, gx = x0 + lx;
         const bool ok = ch_ok && gz < Td && gy < Th && gx < Tw;
-        int qz = CONVT ? 2 * gz + pz : gz, qy = CONVT ? 2 * gy + py : gy, qx = CONVT ? 2 * gx + px : gx;
+        int qz = (CONVT && !FLAT) ? 2 * gz + pz : gz, qy = CONVT ? 2 * gy + py : gy, qx = CONVT ? 2 * gx + px : gx;
         const T* p = outp + ((((int64_t)n * a.Do + qz) * a.Ho + qy) * a.Wo + qx) * a.out_pitch + ch;
         old[i] = ST<T>::ld(ok ? p : outp);
       }
@@ -316,7 +323,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       int lz = lin / (TH * TW), ly = (lin / TW) % TH, lx = lin % TW;
       int gz = z0 + lz, gy = y0 + ly, gx = x0 + lx;
       if (ch_ok && gz < Td && gy < Th && gx < Tw) {
-        int qz = CONVT ? 2 * gz + pz : gz, qy = CONVT ? 2 * gy + py : gy, qx = CONVT ? 2 * gx + px : gx;
+        int qz = (CONVT && !FLAT) ? 2 * gz + pz : gz, qy = CONVT ? 2 * gy + py : gy, qx = CONVT ? 2 * gx + px : gx;
         T* p = outp + ((((int64_t)n * a.Do + qz) * a.Ho + qy) * a.Wo + qx) * a.out_pitch + ch;
         float v = acc[mb][i] + bias + old[i];
         ST<T>::st(p, v);
@@ -1280,16 +1287,21 @@ struct WG<float> {
   static constexpr int KV = 2;
 };
 
-template <typename T, int TD, int TH, int TW, int S>
+// FLAT (round 6): the 2-D weight gradients of models/HDenseFormer_2D.py (Conv2d, ConvTranspose2d) on depth-1 tensors: the 9
+// taps of the centre depth plane (three per wave, the fourth wave only stages), a one-plane box of the large operand, a
+// depth axis that is never strided; the other 18 taps of the [27] slab are written as zeros.
+template <typename T, int TD, int TH, int TW, int S, bool FLAT = false>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+  static_assert(!FLAT || TD == 1, "flat tiles are one voxel deep");
   constexpr int MT = TD * TH * TW;
-  constexpr int BD = S * (TD - 1) + 3, BH = S * (TH - 1) + 3, BW = S * (TW - 1) + 3;
+  constexpr int BD = FLAT ? 1 : S * (TD - 1) + 3, BH = S * (TH - 1) + 3, BW = S * (TW - 1) + 3;
+  constexpr int NTAP = FLAT ? 9 : 27, TAP0 = FLAT ? 9 : 0, ZO = FLAT ? 0 : 1;   // taps, first tap of the slab, z halo
   constexpr int ROWB = 32 * sizeof(T);  // 32 channels per LDS row
   // LDS row pitch.  bf16 transposed reads touch 4 voxel rows x 16 dwords per half-wave: with stride 2 those rows are
   // 2 box rows apart, and a 96-byte pitch (24 dwords: 0, 48, 32, 16 mod 64) tiles the 64 banks exactly; 80 bytes
   // overlapped the 1st and 4th row (2-way conflicts).  (Stride 1 bf16 runs conv_wgrad2_kernel with 64-byte rows.)
   constexpr int LP = (sizeof(T) == 2 && S == 2) ? ROWB + 32 : ROWB + 16;
-  constexpr int TAPS_PER_WAVE = 7;
+  constexpr int TAPS_PER_WAVE = FLAT ? 3 : 7;
   __shared__ __attribute__((aligned(16))) char lds[(MT + BD * BH * BW) * LP];
   char* s_lds = lds;
   char* l_lds = lds + MT * LP;
@@ -1308,11 +1320,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
   for (int j = 0; j < TAPS_PER_WAVE; j++) {
     int tap = wave * TAPS_PER_WAVE + j;
-    if (tap >= 27) tap = 0;  // dummy slot of the last wave (never stored)
+    if (tap >= NTAP) tap = 0;  // dummy slot of the last wave (never stored)
     int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
     tapoff[j] = ((kz * BH + ky) * BW + kx) * LP;
   }
-  const int ntaps_here = min(TAPS_PER_WAVE, 27 - wave * TAPS_PER_WAVE);  // 7,7,7,6
+  const int ntaps_here = max(0, min(TAPS_PER_WAVE, NTAP - wave * TAPS_PER_WAVE));  // 7,7,7,6 (flat: 3,3,3,0)
 
   const int t_begin = blockIdx.x * a.tiles_per_group;
   const int t_end = min(a.num_tiles, t_begin + a.tiles_per_group);
@@ -1356,7 +1368,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
       for (int j = 0; j < NL_; j++) {
         int vox = min((int)threadIdx.x + 256 * j, BOXL * CPV - 1) / CPV;
         int bz = vox / (BH * BW), rem = vox - bz * (BH * BW), by = rem / BW, bx = rem - by * BW;
-        int iz = S * z0 - 1 + bz, iy = S * y0 - 1 + by, ix = S * x0 - 1 + bx;
+        int iz = (FLAT ? z0 : S * z0 - ZO) + bz, iy = S * y0 - 1 + by, ix = S * x0 - 1 + bx;
         bool ok = lc_ok && (unsigned)iz < (unsigned)a.Dl && (unsigned)iy < (unsigned)a.Hl && (unsigned)ix < (unsigned)a.Wl;
         const T* p = ok ? lsrc + ((((int64_t)n * a.Dl + iz) * a.Hl + iy) * a.Wl + ix) * a.lg_pitch : lsrc - part * EPC - lcb * 32;
         pl[j] = *reinterpret_cast<const u32x4*>(p);
@@ -1436,7 +1448,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
           int lin = ks * 16 + 8 * hh + 4 * tt + q;
           int lz = lin / (TH * TW), ly = (lin / TW) % TH, lx = lin % TW;
           sA[tt] = lin * LP + colb;
-          lB[tt] = (((S * lz) * BH + S * ly) * BW + S * lx) * LP + colb;
+          lB[tt] = ((((FLAT ? 0 : S * lz)) * BH + S * ly) * BW + S * lx) * LP + colb;
         }
         // all 16 transposed reads of this k-step are requested before its 7 MFMAs (wave 3's 7th tap is a dummy
         // pointing at tap 0: uniform instruction stream, its accumulator is never stored)
@@ -1466,7 +1478,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
       stage_box<T, TD, TH, TW, ROWB, LP>(s_lds, reinterpret_cast<const T*>(a.sm), a.sm_pitch, a.SC, n, a.Ds, a.Hs, a.Ws,
                                          z0, y0, x0, scb * 32, ROWB, a.sm_scale, a.sm_shift, a.sm_relu);
       stage_box<T, BD, BH, BW, ROWB, LP>(l_lds, reinterpret_cast<const T*>(a.lg), a.lg_pitch, a.LC, n, a.Dl, a.Hl, a.Wl,
-                                         S * z0 - 1, S * y0 - 1, S * x0 - 1, lcb * 32, ROWB, a.lg_scale, a.lg_shift,
+                                         FLAT ? z0 : S * z0 - 1, S * y0 - 1, S * x0 - 1, lcb * 32, ROWB, a.lg_scale, a.lg_shift,
                                          a.lg_relu);
       __syncthreads();
       const int r = lane & 31, hh = lane >> 5;
@@ -1474,7 +1486,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         int lin = ks * 2 + hh;
         int lz = lin / (TH * TW), ly = (lin / TW) % TH, lx = lin % TW;
         float av = *reinterpret_cast<const float*>(s_lds + lin * LP + r * 4);
-        const char* lb = l_lds + (((S * lz) * BH + S * ly) * BW + S * lx) * LP + r * 4;
+        const char* lb = l_lds + ((((FLAT ? 0 : S * lz)) * BH + S * ly) * BW + S * lx) * LP + r * 4;
 #pragma unroll
         for (int j = 0; j < TAPS_PER_WAVE; j++) {
           if (j < ntaps_here) {
@@ -1491,13 +1503,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
   for (int j = 0; j < TAPS_PER_WAVE; j++) {
     if (j < ntaps_here) {
-      int tap = wave * TAPS_PER_WAVE + j;
+      int tap = TAP0 + wave * TAPS_PER_WAVE + j;
       float* base = a.partials + (((int64_t)blockIdx.x * 27 + tap) * a.SCp + scb * 32) * a.LCp + lcb * 32 + col;
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         int row = (i & 3) + 8 * (i >> 2) + 4 * hh2;
         base[(int64_t)row * a.LCp] = acc[j][i];
       }
+    }
+  }
+  if constexpr (FLAT) {   // the 18 taps off the centre depth plane: zero blocks (the slab reduction sums all 27)
+    for (int t = wave; t < 18; t += 4) {
+      const int tap = t < 9 ? t : t + 9;
+      float* base = a.partials + (((int64_t)blockIdx.x * 27 + tap) * a.SCp + scb * 32) * a.LCp + lcb * 32 + col;
+#pragma unroll
+      for (int i = 0; i < 16; i++) base[(int64_t)((i & 3) + 8 * (i >> 2) + 4 * hh2) * a.LCp] = 0.f;
     }
   }
 }
@@ -2828,7 +2848,7 @@ __global__ __launch_bounds__(256) void conv_ksplit_reduce_kernel(ConvArgs a) {
   }
 }
 
-template <typename T, int TD, int TH, int TW, int WM, int WN, int MB, int S, bool CONVT>
+template <typename T, int TD, int TH, int TW, int WM, int WN, int MB, int S, bool CONVT, bool FLAT = false>
 int launch_cfg(const ConvArgs& a0, hipStream_t st) {
   ConvArgs a = a0;
   const int Td = CONVT ? a.Di : a.Do, Th = CONVT ? a.Hi : a.Ho, Tw = CONVT ? a.Wi : a.Wo;
@@ -2848,8 +2868,8 @@ int launch_cfg(const ConvArgs& a0, hipStream_t st) {
       }
     }
   }
-  dim3 grid(tiles, nblk, CONVT ? 8 : a.ksplit);
-  hipLaunchKernelGGL((conv_igemm_kernel<T, TD, TH, TW, WM, WN, MB, S, CONVT>), grid, dim3(256), 0, st, a);
+  dim3 grid(tiles, nblk, CONVT ? (FLAT ? 4 : 8) : a.ksplit);   // transposed conv: one grid slice per output-parity class
+  hipLaunchKernelGGL((conv_igemm_kernel<T, TD, TH, TW, WM, WN, MB, S, CONVT, FLAT>), grid, dim3(256), 0, st, a);
   HDF_LAUNCH_CHECK();
   if constexpr (!CONVT && S == 1) {
     if (a.ksplit > 1) {
@@ -2870,7 +2890,7 @@ inline bool tiny_tile(int Do, int Ho, int Wo) {
 }
 // weights-stationary kernel: mode 0, whole Cin row <= 128 B, enough tiles to amortise the weight panel
 inline int ws_cfg(int mode, int Do, int Ho, int Wo, int row_bytes) {
-  if (mode != 0 || row_bytes > 128 || (int64_t)Do * Ho * Wo < 48 * 48 * 48) return 0;
+  if (mode != 0 || row_bytes > 128 || (int64_t)Do * Ho * Wo < 48 * 48 * 48 || Do == 1) return 0;   // (depth 1: the flat kernels)
   return (row_bytes == 32 || row_bytes == 64 || row_bytes == 128) ? 1 : 0;
 }
 
@@ -2917,8 +2937,28 @@ int launch_ws2(const ConvArgs& a, hipStream_t st) {
   return HDF_OK;
 }
 
+// Tile of a flat (depth-1, 2-D) stride-1 conv: 1x16x16 (256 voxels), 1x8x16 below 64x64, 1x8x8 below 32x32
+inline int flat_tile(int Ho, int Wo) { return (int64_t)Ho * Wo <= 32 * 32 ? 0 : ((int64_t)Ho * Wo <= 64 * 64 ? 1 : 2); }
+
 template <typename T>
 int launch_conv_t(int mode, const ConvArgs& a, hipStream_t st) {
+  if (a.Di == 1) {
+    // ---- the 2-D operators (models/HDenseFormer_2D.py:125-170): depth-1 tensors, centre-plane taps, y / x strides only
+    HDF_CHECK_ARG(a.Do == 1 && !a.bs_y, "conv: a depth-1 input selects the 2-D operator (output depth 1, no statistics epilogue of the 3-D data gradient)");
+    if (mode == 0) {
+      const int ft = flat_tile(a.Ho, a.Wo);
+      if (ft == 0) return launch_cfg<T, 1, 8, 8, 2, 2, 1, 1, false, true>(a, st);        // 64 vox x 64 ch
+      if (ft == 1) return launch_cfg<T, 1, 8, 16, 2, 2, 2, 1, false, true>(a, st);       // 128 vox x 64 ch
+      if (a.CoutP <= 32) return launch_cfg<T, 1, 16, 16, 4, 1, 2, 1, false, true>(a, st);  // 256 vox x 32 ch
+      return launch_cfg<T, 1, 16, 16, 2, 2, 4, 1, false, true>(a, st);                   // 256 vox x 64 ch
+    } else if (mode == 1) {
+      if (a.CoutP <= 64) return launch_cfg<T, 1, 8, 8, 2, 2, 1, 2, false, true>(a, st);   // 64 vox x 64 ch, stride 2 in y, x
+      return launch_cfg<T, 1, 8, 8, 1, 4, 2, 2, false, true>(a, st);                      // 64 vox x 128 ch
+    } else {
+      if (a.CoutP <= 32) return launch_cfg<T, 1, 16, 16, 4, 1, 2, 1, true, true>(a, st);
+      return launch_cfg<T, 1, 8, 16, 2, 2, 2, 1, true, true>(a, st);
+    }
+  }
   if (mode == 0) {
     const int rb = a.Cin * (int)sizeof(T);
     const int ws = ws_cfg(mode, a.Do, a.Ho, a.Wo, rb);
@@ -2980,20 +3020,20 @@ int launch_conv_t(int mode, const ConvArgs& a, hipStream_t st) {
   }
 }
 
-template <typename T, int TD, int TH, int TW, int S>
+template <typename T, int TD, int TH, int TW, int S, bool FLAT = false>
 int launch_wgrad_t(WgradArgs a, float* dw, int sc_store, int lc_store, int accumulate, void* ws, size_t ws_bytes,
                    hipStream_t st) {
   a.SCp = round_up(a.SC, 32);
   a.LCp = round_up(a.LC, 32);
   a.num_tiles = a.N * ceil_div(a.Ds, TD) * ceil_div(a.Hs, TH) * ceil_div(a.Ws, TW);
   // 16-bit stride 2 without a transform of the large operand: conv_wgrad_s2_kernel, SB small-channel blocks per workgroup
-  const bool use_s2 = sizeof(T) == 2 && S == 2 && !a.lg_scale && a.Ds % 4 == 0 && a.Hs % 4 == 0 &&
+  const bool use_s2 = !FLAT && sizeof(T) == 2 && S == 2 && !a.lg_scale && a.Ds % 4 == 0 && a.Hs % 4 == 0 &&
                       a.Ws % 4 == 0 && a.Dl == 2 * a.Ds && a.Hl == 2 * a.Hs && a.Wl == 2 * a.Ws;
   const int sb = (use_s2 && a.SCp >= 64) ? 2 : 1;
   const int sblocks = ceil_div(a.SCp / 32, sb);
   const int pairs = sblocks * (a.LCp / 32);
   const int64_t per = (int64_t)27 * a.SCp * a.LCp * sizeof(float);
-  const bool use_new = sizeof(T) == 2 && S == 1 && !a.sm_scale;
+  const bool use_new = !FLAT && sizeof(T) == 2 && S == 1 && !a.sm_scale;
   const int wg_target = hdf_cu_budget();  // one workgroup per CU
   int G = ceil_div(wg_target, pairs);
   G = (int)std::min<int64_t>(G, std::max<int64_t>(1, (int64_t)ws_bytes / per));
@@ -3026,7 +3066,7 @@ int launch_wgrad_t(WgradArgs a, float* dw, int sc_store, int lc_store, int accum
     }
   }
   if (!use_new && !use_s2) {
-    hipLaunchKernelGGL((conv_wgrad_kernel<T, TD, TH, TW, S>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, TD, TH, TW, S, FLAT>), grid, dim3(256), 0, st, a);
   }
   HDF_LAUNCH_CHECK();
   int64_t n = (int64_t)27 * a.SCp * a.LCp;
@@ -3045,6 +3085,7 @@ int launch_wgrad_t(WgradArgs a, float* dw, int sc_store, int lc_store, int accum
 int hdf_conv_weight_layout(int dtype, int mode, int Cin, int Do, int Ho, int Wo) {
   const int rb = Cin * hdf_esz(dtype);
   if (rb % 64 != 0) return 0;                       // the pipelined path needs whole 64-byte chunks
+  if (Do == 1) return 1;                            // depth 1 (the 2-D operators): always conv_igemm_kernel
   if (mode == 0) return ws_cfg(mode, Do, Ho, Wo, rb) ? 0 : 1;  // conv_ws2_kernel stages row-major panels
   if (mode == 1) return 1;                                 // stride-2 gather conv: pipelined path
   return convt_fused_rows(rb) ? 0 : 1;  // transposed conv: convt_fused_kernel reads row-major panels, other widths run per class
@@ -3062,6 +3103,10 @@ bool hdf_conv_bwd_stats_ok(int dtype, const ConvArgs& a) {
 
 int hdf_conv_stat_tiles(int mode, int Do, int Ho, int Wo, int row_bytes) {
   if (mode != 0) return 0;
+  if (Do == 1) {   // the flat tiles of launch_conv_t
+    const int ft = flat_tile(Ho, Wo);
+    return ft == 0 ? ceil_div(Ho, 8) * ceil_div(Wo, 8) : (ft == 1 ? ceil_div(Ho, 8) * ceil_div(Wo, 16) : ceil_div(Ho, 16) * ceil_div(Wo, 16));
+  }
   if (ws_cfg(mode, Do, Ho, Wo, row_bytes)) return WS_STAT_ROWS;  // per-workgroup rows (conv_ws2_kernel)
   if (tiny_tile(Do, Ho, Wo)) return ceil_div(Do, 2) * ceil_div(Ho, 4) * ceil_div(Wo, 8);
   if (small_tile(Do, Ho, Wo)) return ceil_div(Do, 4) * ceil_div(Ho, 4) * ceil_div(Wo, 8);
@@ -3090,6 +3135,7 @@ size_t hdf_wgrad_workspace_bytes(int stride, int N, int Ds, int Hs, int Ws, int 
   int pairs = (SCp / 32) * (LCp / 32);
   int tiles = stride == 1 ? N * ceil_div(Ds, 4) * ceil_div(Hs, 8) * ceil_div(Ws, 8)
                           : N * ceil_div(Ds, 4) * ceil_div(Hs, 4) * ceil_div(Ws, 4);
+  if (Ds == 1) tiles = stride == 1 ? N * ceil_div(Hs, 16) * ceil_div(Ws, 16) : N * ceil_div(Hs, 8) * ceil_div(Ws, 8);   // flat tiles
   int G = std::min(ceil_div(1024, pairs), tiles);
   int64_t bytes = std::min<int64_t>((int64_t)G * per, std::max<int64_t>(per, (int64_t)96 << 20));
   return (size_t)bytes;
@@ -3098,7 +3144,7 @@ size_t hdf_wgrad_workspace_bytes(int stride, int N, int Ds, int Hs, int Ws, int 
 // the launches conv_wgrad2_kernel<., ., true> serves: 16-bit storage, stride 1, untransformed small operand, 16-byte rows
 // on both extra tensors, and 32-bit byte offsets into them with bit 31 free for the out-of-range marker
 bool hdf_wgrad_apply_takes(int dtype, int stride, const WgradArgs& a) {
-  if (hdf_esz(dtype) != 2 || stride != 1 || a.sm_scale || !a.ap_y || !a.ap_out) return false;
+  if (hdf_esz(dtype) != 2 || stride != 1 || a.sm_scale || !a.ap_y || !a.ap_out || a.Ds == 1) return false;
   for (int k = 0; k < 7; k++)
     if (!a.ap_tab[k]) return false;
   const int64_t vox = (int64_t)a.N * a.Ds * a.Hs * a.Ws;
@@ -3116,6 +3162,12 @@ int hdf_launch_wgrad(int dtype, int stride, WgradArgs a, float* dw, int sc_store
   HDF_CHECK_ARG(!a.ap_y || hdf_wgrad_apply_takes(dtype, stride, a),
                 "wgrad: the fused InstanceNorm backward does not take this launch (ask hdf_wgrad_apply_takes first)");
   HDF_DISPATCH_T(dtype, {
+    if (a.Ds == 1) {   // depth-1 operands: the 2-D weight gradients (Conv2d / ConvTranspose2d, models/HDenseFormer_2D.py)
+      HDF_CHECK_ARG(a.Dl == 1 && !a.ap_y, "wgrad: depth-1 small operand selects the 2-D operator (large operand of depth 1, no fused InstanceNorm backward)");
+      if (stride == 1)
+        return launch_wgrad_t<T, 1, 16, 16, 1, true>(a, dw, sc_store, lc_store, accumulate, workspace, workspace_bytes, st);
+      return launch_wgrad_t<T, 1, 8, 8, 2, true>(a, dw, sc_store, lc_store, accumulate, workspace, workspace_bytes, st);
+    }
     if (stride == 1)
       return launch_wgrad_t<T, 4, 8, 8, 1>(a, dw, sc_store, lc_store, accumulate, workspace, workspace_bytes, st);
     return launch_wgrad_t<T, 4, 4, 4, 2>(a, dw, sc_store, lc_store, accumulate, workspace, workspace_bytes, st);

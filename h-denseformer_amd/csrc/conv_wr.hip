@@ -907,7 +907,7 @@ bool hdf_conv_wr_takes(int dtype, const ConvArgs& a) {
 }
 
 bool hdf_conv_wr_can(int dtype, const ConvArgs& a) {
-  if (dtype == HDF_F32 || a.wfrag) return false;
+  if (dtype == HDF_F32 || a.wfrag || a.Di == 1) return false;   // (depth 1: the 2-D operators of conv_igemm.hip)
   const int rb = a.Cin * 2;
   if (rb != 128 || a.in_scale) return false;
   if ((int64_t)a.Do * a.Ho * a.Wo < 48 * 48 * 48) return false;

@@ -2303,6 +2303,7 @@ int hdf_op_conv3d(int dtype, int mode, const void* in, int64_t in_pitch, int Cin
     a.Do = Di / 2, a.Ho = Hi / 2, a.Wo = Wi / 2;
   else
     a.Do = 2 * Di, a.Ho = 2 * Hi, a.Wo = 2 * Wi;
+  if (Di == 1) a.Do = 1;   // depth 1 selects the 2-D operator: the depth axis is never strided (include/hdf.h)
   a.w = w_packed;
   a.bias = bias;
   a.in_scale = in_scale;
@@ -2413,7 +2414,7 @@ int hdf_op_conv3d_wgrad(int dtype, int stride, const void* sm, int64_t sm_pitch,
   w.lg = lg, w.lg_pitch = lg_pitch, w.LC = LC;
   w.N = N;
   w.Ds = Ds, w.Hs = Hs, w.Ws = Ws;
-  w.Dl = stride * Ds, w.Hl = stride * Hs, w.Wl = stride * Ws;
+  w.Dl = Ds == 1 ? 1 : stride * Ds, w.Hl = stride * Hs, w.Wl = stride * Ws;   // (depth 1: the 2-D operator)
   w.sm_scale = sm_scale, w.sm_shift = sm_shift, w.sm_relu = sm_relu;
   w.lg_scale = lg_scale, w.lg_shift = lg_shift, w.lg_relu = lg_relu;
   return hdf_launch_wgrad(dtype, stride, w, dw, sc_store, lc_store, accumulate, workspace, (size_t)workspace_bytes,

@@ -51,6 +51,8 @@ def conv3d(dtype, mode, x_cl, cin, w_packed, cout, bias=None, scale=None, shift=
         od, oh, ow = d // 2, h // 2, w // 2
     else:
         od, oh, ow = 2 * d, 2 * h, 2 * w
+    if d == 1:
+        od = 1          # depth 1 selects the 2-D operator: the depth axis is never strided
     if out is None:
         out = torch.zeros((n, od, oh, ow, cout), dtype=x_cl.dtype, device=DEV)
         out_pitch = cout
