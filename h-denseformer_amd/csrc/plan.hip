@@ -244,6 +244,13 @@ struct hdf_plan {
   bool dcat_split[3] = {false, false, false};
   // ---- 2-D model (models/HDenseFormer_2D.py) run as its exact depth-replicated 3-D embedding (see embed2d below)
   bool is2d = false;
+  // Round 6: the 2-D model runs NATIVELY on depth-1 tensors (flat): every level has depth 1, the convolutions / transposed
+  // convolutions / weight gradients are the FLAT instantiations of conv_igemm.hip (centre-plane taps of the embedded 27-tap
+  // panels), pooling and up-sampling their 2-D forms (unet_ops.hip), and only the patch embedding still sees a depth-16
+  // copy of the input (its 16 x 16 kernel sits on depth slice 0 of the 16^3 one).  flat = false keeps the depth-16
+  // replicated embedding of rounds 3-5 (hdf_plan_create_2d_embedded: the oracle of tests/test_gpu_model_2d.py).
+  bool flat = false;
+  const float* xtok = nullptr;   // flat: the depth-16 copy of the input the patch embedding reads (set around the 3-D calls)
   std::vector<ParamInfo> params2d;  // the 2-D reference state_dict: conv kernels [..,3,3], patch kernels [..,16,16]
   int64_t total_floats2d = 0;
   std::vector<Embed2dJob> ejobs;
@@ -531,6 +538,8 @@ void layout(hdf_plan* p, int B) {
   p->at[1] = mkview(p, bp, "at2", 1, 2 * nf, B);
 #ifdef HDF_NO_FUSED_AT3  // (A/B builds; the product evaluates at3 inside the level-0 encoder tail: forward3d)
   p->at[0] = mkview(p, bp, "at3", 0, nf, B);
+#else
+  if (p->flat) p->at[0] = mkview(p, bp, "at3", 0, nf, B);   // (the 2-D encoder tail reads a materialised at3)
 #endif
   for (int k = 0; k < 4; k++) {
     conv_bufs(p->enc[k][0]);
@@ -549,7 +558,7 @@ void layout(hdf_plan* p, int B) {
   }
   p->x4 = mkview(p, bp, "bottleneck", 3, 8 * nf, B);
   if (p->is2d) {  // depth-replicated input, embedded parameters / their gradients, 3-D logits and logit gradients
-    p->e_x3d = bp.take((size_t)B * p->M * p->vox(0) * sizeof(float));
+    p->e_x3d = bp.take((size_t)B * p->M * p->D * p->H * p->W * sizeof(float));   // depth-16 copy of the input
     p->e_params3d = bp.take((size_t)p->total_floats * sizeof(float));
     p->e_grads3d = bp.take((size_t)p->total_floats * sizeof(float));
     for (int i = 0; i < 4; i++) {
@@ -854,7 +863,7 @@ int convt_forward(Exec& e, ConvT3& t, const View& in, Xf xf, const View& out) {
   a.Cin = t.Cin;
   a.N = e.B;
   a.Di = d[0], a.Hi = d[1], a.Wi = d[2];
-  a.Do = 2 * d[0], a.Ho = 2 * d[1], a.Wo = 2 * d[2];
+  a.Do = (p->flat ? 1 : 2) * d[0], a.Ho = 2 * d[1], a.Wo = 2 * d[2];
   a.w = e.ws + t.wf;
   a.wfrag = t.wf_frag;
   a.bias = e.P(t.b);
@@ -1009,6 +1018,7 @@ int transformer_forward(Exec& e, const float* x) {
 #else
   const int PE_LP = p->dtype;
 #endif
+  if (p->xtok) x = p->xtok;
   HDF_TRY(tf_patch_embed_fwd(d, x, p->D, p->H, p->W, pm + p->P("attns.0.patch_embeddings.weight"),
                              pm + p->P("attns.0.patch_embeddings.bias"), pm + p->P("attns.0.position_embeddings"), F0,
                              e.st, PE_LP));
@@ -1055,6 +1065,7 @@ int transformer_forward(Exec& e, const float* x) {
 
 int transformer_backward(Exec& e, const float* x) {
   hdf_plan* p = e.p;
+  if (p->xtok) x = p->xtok;
   TfDims d = tf_dims(p, e.B);
   float* pm = const_cast<float*>(e.params);
   const int64_t rows = (int64_t)p->M * e.B * p->Ntok;
@@ -1369,7 +1380,7 @@ int convt_backward(Exec& e, ConvT3& t, const View& dout, const View& in, Xf xf, 
   w.LC = t.Cout;
   w.N = e.B;
   w.Ds = d[0], w.Hs = d[1], w.Ws = d[2];
-  w.Dl = 2 * d[0], w.Hl = 2 * d[1], w.Wl = 2 * d[2];
+  w.Dl = (p->flat ? 1 : 2) * d[0], w.Hl = 2 * d[1], w.Wl = 2 * d[2];
   w.sm_scale = xf.scale;
   w.sm_shift = xf.shift;
   w.sm_relu = xf.relu;
@@ -1383,7 +1394,7 @@ int convt_backward(Exec& e, ConvT3& t, const View& dout, const View& in, Xf xf, 
   a.in_pitch = dout.pitch;
   a.Cin = t.Cout;
   a.N = e.B;
-  a.Di = 2 * d[0], a.Hi = 2 * d[1], a.Wi = 2 * d[2];
+  a.Di = (p->flat ? 1 : 2) * d[0], a.Hi = 2 * d[1], a.Wi = 2 * d[2];
   a.Do = d[0], a.Ho = d[1], a.Wo = d[2];
   a.w = e.ws + t.wd;
   a.wfrag = t.wd_frag;
@@ -1456,7 +1467,7 @@ int hdf_set_cu_budget(int cus) {
 const char* hdf_last_error(void) { return g_err; }
 
 static int create_plan(int in_channels, int n_cls, int n_filters, int D, int H, int W, int transformer_depth, int dtype,
-                       bool is2d, hdf_plan** out) {
+                       bool is2d, hdf_plan** out, bool flat = false) {
   HDF_CHECK_ARG(out != nullptr, "plan_create: null out");
   HDF_CHECK_ARG(in_channels >= 1 && in_channels <= 8, "plan_create: in_channels=%d unsupported (1..8)", in_channels);
   HDF_CHECK_ARG(n_cls >= 2 && n_cls <= 8, "plan_create: n_cls=%d unsupported (2..8)", n_cls);
@@ -1476,6 +1487,9 @@ static int create_plan(int in_channels, int n_cls, int n_filters, int D, int H, 
   p->dtype = dtype;
   p->esz = hdf_esz(dtype);
   for (int l = 0; l < 5; l++) p->dims[l][0] = D >> l, p->dims[l][1] = H >> l, p->dims[l][2] = W >> l;
+  p->flat = is2d && flat;
+  if (p->flat)   // (p->D stays 16: the depth of the patch embedding's input copy)
+    for (int l = 0; l < 5; l++) p->dims[l][0] = 1;
   p->DM = 4 * n_filters;
   p->DMF = p->DM + 128;
   p->Ntok = (D / 16) * (H / 16) * (W / 16);
@@ -1497,9 +1511,13 @@ int hdf_plan_create(int in_channels, int n_cls, int n_filters, int D, int H, int
                     hdf_plan** out) {
   return create_plan(in_channels, n_cls, n_filters, D, H, W, transformer_depth, dtype, false, out);
 }
+int hdf_plan_create_2d_embedded(int in_channels, int n_cls, int n_filters, int H, int W, int transformer_depth, int dtype,
+                               hdf_plan** out) {
+  return create_plan(in_channels, n_cls, n_filters, 16, H, W, transformer_depth, dtype, true, out, false);
+}
 int hdf_plan_create_2d(int in_channels, int n_cls, int n_filters, int H, int W, int transformer_depth, int dtype,
                        hdf_plan** out) {
-  return create_plan(in_channels, n_cls, n_filters, 16, H, W, transformer_depth, dtype, true, out);
+  return create_plan(in_channels, n_cls, n_filters, 16, H, W, transformer_depth, dtype, true, out, true);
 }
 
 void hdf_plan_destroy(hdf_plan* p) { delete p; }
@@ -1589,6 +1607,14 @@ int hdf_forward(hdf_plan* p, const float* x, const float* params, void* workspac
   const int64_t hw = (int64_t)p->H * p->W;
   hipLaunchKernelGGL(replicate_depth_kernel, dim3(2048), dim3(256), 0, st, x, x3, (int64_t)batch * p->M, p->D, hw);
   HDF_LAUNCH_CHECK();
+  if (p->flat) {
+    // native 2-D path: depth-1 tensors throughout; the logits [B, n_cls, 1, H, W] ARE the 2-D outputs, the depth-16 copy of
+    // the input feeds the patch embedding only
+    p->xtok = x3;
+    const int rc = forward3d(p, x, p3, workspace, workspace_bytes, out0, out1, out2, out3, batch, training, seed, stream);
+    p->xtok = nullptr;
+    return rc;
+  }
   void* o3[4];
   for (int i = 0; i < 4; i++) o3[i] = ws + p->e_out3d[i];
   HDF_TRY(forward3d(p, x3, p3, workspace, workspace_bytes, o3[0], o3[1], o3[2], o3[3], batch, training, seed, stream));
@@ -1635,8 +1661,9 @@ static int forward3d(hdf_plan* p, const float* x, const float* params, void* wor
 #ifdef HDF_NO_FUSED_AT3  // A/B builds
   const bool fused_at3 = false;
 #else
-  const bool fused_at3 = true;
+  const bool fused_at3 = !p->flat;   // (the 2-D model: materialised at3 + the 2-D encoder tail)
 #endif
+  const int flat = p->flat ? 1 : 0;
   // (round 5) Order of the first launches.  The first level-0 conv reads the fp32 weights itself (csrc/conv_first.hip) and
   // needs only the converted input, so where that kernel takes the layer the caller's stream starts with conversion +
   // conv, and the weight packs -- every conv's 16-bit panels and the persistent transformer kernel's fragment-major copies,
@@ -1711,7 +1738,7 @@ static int forward3d(hdf_plan* p, const float* x, const float* params, void* wor
   HDF_TRY(conv_forward(eb, p->deep, p->attnall, none));
   HDF_TRY(hdf_launch_upsample_fwd(p->dtype, eb.at(p->deep.y), p->deep.y.pitch, eb.f(p->deep.st.scale),
                                   eb.f(p->deep.st.shift), eb.at(p->attnout), p->attnout.pitch, batch, 8 * nf,
-                                  p->dims[4][0], p->dims[4][1], p->dims[4][2], eb.st));
+                                  p->dims[4][0], p->dims[4][1], p->dims[4][2], eb.st, flat));
   {
     const View* src = &p->attnout;
     for (int k = 0; k < 3; k++) {  // up1 -> at1 (lvl 2), up2 -> at2 (lvl 1), up3 -> at3 (lvl 0)
@@ -1722,7 +1749,7 @@ static int forward3d(hdf_plan* p, const float* x, const float* params, void* wor
       if (k == 2 && fused_at3) break;
       HDF_TRY(hdf_launch_upsample_fwd(p->dtype, eb.at(c.y), c.y.pitch, eb.f(c.st.scale), eb.f(c.st.shift), eb.at(dst),
                                       dst.pitch, batch, c.Cout, p->dims[c.lvl][0], p->dims[c.lvl][1],
-                                      p->dims[c.lvl][2], eb.st));
+                                      p->dims[c.lvl][2], eb.st, flat));
       src = &dst;
     }
   }
@@ -1751,7 +1778,7 @@ static int forward3d(hdf_plan* p, const float* x, const float* params, void* wor
       HDF_TRY(hdf_launch_enc_tail(p->dtype, e.at(c.y), c.y.pitch, e.f(c.st.scale), e.f(c.st.shift), e.at(p->at[k]),
                                   p->at[k].pitch, e.at(ds), ds.pitch, e.at(p->pooled[k]), p->pooled[k].pitch,
                                   (uint8_t*)(e.ws + p->pool_idx[k]), batch, ch[k], p->dims[k + 1][0], p->dims[k + 1][1],
-                                  p->dims[k + 1][2], e.st));
+                                  p->dims[k + 1][2], e.st, flat));
       cur = &p->pooled[k];
     } else {
       HDF_TRY(hdf_launch_norm_relu_add(p->dtype, e.at(c.y), c.y.pitch, e.f(c.st.scale), e.f(c.st.shift),
@@ -1903,12 +1930,25 @@ static int backward_any(hdf_plan* p, const float* x, const float* params, void* 
   void* d3[4];
   const void* d2[4] = {dout0, dout1, dout2, dout3};
   for (int i = 0; i < 4; i++) {
+    if (p->flat) {   // the 2-D logit gradients are the depth-1 tensors the native path reads
+      d3[i] = const_cast<void*>(d2[i]);
+      continue;
+    }
     d3[i] = ws + p->e_dout3d[i];
     if (stages & 1)  // the loss sees depth slice 0 only
       HDF_TRY(launch_depth_slice(p->dtype, d3[i], const_cast<void*>(d2[i]), (int64_t)batch * p->ncls, p->dims[i][0],
                                  (int64_t)p->dims[i][1] * p->dims[i][2], 0, st));
   }
   float* g3 = (float*)(ws + p->e_grads3d);
+  if (p->flat) {
+    // (x: the 2-D input itself is not read by the backward of the U-Net -- the first layer's weight gradient reads the
+    // channels-last copy the forward left in the workspace -- ; the patch embedding's backward reads the depth-16 copy)
+    p->xtok = (const float*)(ws + p->e_x3d);
+    const int rc = backward3d(p, x, (const float*)(ws + p->e_params3d), workspace, workspace_bytes, d3[0], d3[1], d3[2],
+                              d3[3], g3, batch, stages, stream);
+    p->xtok = nullptr;
+    HDF_TRY(rc);
+  } else
   HDF_TRY(backward3d(p, (const float*)(ws + p->e_x3d), (const float*)(ws + p->e_params3d), workspace, workspace_bytes,
                      d3[0], d3[1], d3[2], d3[3], g3, batch, stages, stream));
   HDF_TRY(launch_extract2d(p, stages, g3, grads, st));
@@ -1933,7 +1973,7 @@ static int upconv_chain_backward(Exec& e, int batch) {
     View& da = p->dUa[4 - c.lvl];
     View& dy = p->dUy[4 - c.lvl];
     HDF_TRY(hdf_launch_upsample_bwd(p->dtype, e.at(dat), dat.pitch, e.at(da), da.pitch, batch, c.Cout, d[0], d[1], d[2],
-                                    e.st));
+                                    e.st, p->flat ? 1 : 0));
     HDF_TRY(in_backward(e, c, da, dy));
     // input of up[k]: attnout (k==0) or at_{lvl} ; its gradient buffer already holds the skip-path gradient
     const View& cin = (k == 0) ? p->attnout : p->at[c.lvl];
@@ -1944,7 +1984,7 @@ static int upconv_chain_backward(Exec& e, int batch) {
     Conv3& c = p->deep;
     const int* d = p->dims[4];
     HDF_TRY(hdf_launch_upsample_bwd(p->dtype, e.at(p->dX4), p->dX4.pitch, e.at(p->dUa[0]), p->dUa[0].pitch, batch,
-                                    c.Cout, d[0], d[1], d[2], e.st));
+                                    c.Cout, d[0], d[1], d[2], e.st, p->flat ? 1 : 0));
     HDF_TRY(in_backward(e, c, p->dUa[0], p->dUy[0]));
     HDF_TRY(conv_backward(e, c, p->dUy[0], p->attnall, none, &p->dAttnall, 0));
   }
@@ -2073,7 +2113,7 @@ static int backward3d(hdf_plan* p, const float* x, const float* params, void* wo
       HDF_TRY(hdf_launch_maxpool_bwd_in(p->dtype, e.at(p->dP[k]), p->dP[k].pitch, (const uint8_t*)(e.ws + p->pool_idx[k]),
                                         e.at(dskip), dskip.pitch, e.at(c2.y), c2.y.pitch, e.f(c2.st.scale),
                                         e.f(c2.st.shift), e.f(c2.st.mean), e.f(c2.st.rstd), e.inbp(), batch, ch[k],
-                                        p->dims[k + 1][0], p->dims[k + 1][1], p->dims[k + 1][2], e.st));
+                                        p->dims[k + 1][0], p->dims[k + 1][1], p->dims[k + 1][2], e.st, p->flat ? 1 : 0));
     }
     if (k == 0 && fork_ok) {
       // d(ds_0) = d(at3) is final.  What is left: (1) the UpConv chain backward, (2) the transformer branches' backward,

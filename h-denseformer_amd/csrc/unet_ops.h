@@ -21,7 +21,8 @@ int hdf_launch_norm_relu_add(int dtype, const void* y, int64_t y_pitch, const fl
 // (dims Do,Ho,Wo); else `skip` is a materialised full-resolution tensor.
 int hdf_launch_enc_tail(int dtype, const void* y, int64_t y_pitch, const float* scale, const float* shift,
                         const void* skip, int64_t skip_pitch, void* ds, int64_t ds_pitch, void* pooled,
-                        int64_t pooled_pitch, uint8_t* idx, int N, int C, int Do, int Ho, int Wo, hipStream_t st);
+                        int64_t pooled_pitch, uint8_t* idx, int N, int C, int Do, int Ho, int Wo, hipStream_t st,
+                        int flat = 0 /* 1: the 2-D form on depth-1 tensors (MaxPool2d(2)), round 6 */);
 // the same with skip = trilinear x2 of relu(low * lscale + lshift), low at (Do, Ho, Wo): the skip tensor is never materialised
 int hdf_launch_enc_tail_up(int dtype, const void* y, int64_t y_pitch, const float* scale, const float* shift,
                            const void* low, int64_t low_pitch, const float* lscale, const float* lshift, void* ds,
@@ -35,10 +36,11 @@ int hdf_launch_maxpool_bwd(int dtype, const void* dout, int64_t dout_pitch, cons
 
 // trilinear x2, align_corners=False, of relu(y*scale+shift)
 int hdf_launch_upsample_fwd(int dtype, const void* y, int64_t y_pitch, const float* scale, const float* shift,
-                            void* out, int64_t out_pitch, int N, int C, int Di, int Hi, int Wi, hipStream_t st);
+                            void* out, int64_t out_pitch, int N, int C, int Di, int Hi, int Wi, hipStream_t st,
+                            int flat = 0 /* 1: bilinear x2 of a depth-1 tensor */);
 // transposed stencil: din[lo-res] = sum of weighted dout[hi-res]
 int hdf_launch_upsample_bwd(int dtype, const void* dout, int64_t dout_pitch, void* din, int64_t din_pitch, int N,
-                            int C, int Di, int Hi, int Wi, hipStream_t st);
+                            int C, int Di, int Hi, int Wi, hipStream_t st, int flat = 0);
 
 // 1x1x1 head: logits[N][ncls][vox] (NCDHW) = W[ncls][C] . act(in) + b ;  act = relu(in*scale+shift) if scale
 int hdf_launch_head_fwd(int dtype, const void* in, int64_t in_pitch, const float* scale, const float* shift,
@@ -52,7 +54,7 @@ int hdf_maxpool_bwd_in_blocks(int64_t pooled_vox, int C);
 int hdf_launch_maxpool_bwd_in(int dtype, const void* dout, int64_t dout_pitch, const uint8_t* idx, void* din,
                               int64_t din_pitch, const void* y, int64_t y_pitch, const float* scale, const float* shift,
                               const float* mean, const float* rstd, float* partials, int N, int C, int Do, int Ho, int Wo,
-                              hipStream_t st);
+                              hipStream_t st, int flat = 0 /* 1: MaxPool2d(2) windows of a depth-1 tensor */);
 int hdf_launch_head_bwd(int dtype, const void* dlogits, const void* in, int64_t in_pitch, const float* scale,
                         const float* shift, const float* w, void* dx, int64_t dx_pitch, int accumulate_dx, float* dw,
                         float* db, int N, int C, int ncls, int64_t vox, hipStream_t st, const float* in_mean = nullptr,

@@ -225,7 +225,9 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dout, int64_t dout_pitc
 // once and never re-read for pooling.  (Round 1 also evaluated the trilinear x2 of up3's output inside this kernel so
 // that at3 was never materialised; with the 27-loads-per-8-outputs upsample kernel reading the materialised tensor is
 // 0.09 ms per step faster, and that variant -- VALU-bound with register spills -- was removed in round 3.)
-template <typename T>
+// FLAT (round 6): the 2-D form (models/HDenseFormer_2D.py:232-240: MaxPool2d(2)) on depth-1 tensors -- a thread owns a
+// 1x2x2 block, the depth axis is not pooled; window index k = 2 dy + dx as in the 3-D form with dz = 0.
+template <typename T, bool FLAT = false>
 __global__ __launch_bounds__(256, 2) void enc_tail_kernel(const T* __restrict__ y, int64_t y_pitch,
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift, const T* __restrict__ skip,
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void enc_tail_kernel(const T* __restrict__ 
     }
     // one output z plane (dz) of the 2x2x2 block: ds = relu(y*s+t) + skip, stored, and folded into the running
     // maximum in scan order d,h,w (strict > keeps the FIRST maximum: torch's tie rule)
-    const int64_t row0 = (((int64_t)nz * 2) * Hi + 2 * oh) * Wi + 2 * ow;  // first voxel of the 2x2x2 block
+    const int64_t row0 = (((int64_t)nz * (FLAT ? 1 : 2)) * Hi + 2 * oh) * Wi + 2 * ow;  // first voxel of the 2x2x2 block
     const T* const ybase = y + row0 * y_pitch + c0;
     T* const dbase = ds + row0 * ds_pitch + c0;
     auto finish_plane = [&](int dz, const float (&sk)[4][EPC]) __attribute__((always_inline)) {
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void enc_tail_kernel(const T* __restrict__ 
       }
     };
 #pragma unroll
-    for (int dz = 0; dz < 2; dz++) {
+    for (int dz = 0; dz < (FLAT ? 1 : 2); dz++) {
       float sk[4][EPC];
 #pragma unroll
       for (int q = 0; q < 4; q++)
@@ -324,7 +326,9 @@ __device__ __forceinline__ void up_taps(int o, int n, int& ia, float& wa, int& i
 // first version gave every OUTPUT chunk its own 8 loads + 8 transforms (64 per block) and was VALU-bound: 204 us for the
 // 268 MB of at3 (1.5 TB/s).  Edge voxels: the clamped neighbour index makes the .25 / .75 pair collapse onto the same
 // voxel, which is torch's align_corners=False edge rule.
-template <typename T>
+// FLAT (round 6): bilinear x2 of a depth-1 tensor (models/HDenseFormer_2D.py:166-170: F.interpolate(scale_factor=2,
+// mode='bilinear', align_corners=False)): the y / x arithmetic of the 3-D form, the depth axis untouched.
+template <typename T, bool FLAT = false>
 __global__ __launch_bounds__(256) void upsample_fwd_kernel(const T* __restrict__ y, int64_t y_pitch,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift, T* __restrict__ out,
@@ -379,7 +383,7 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const T* __restrict__
         }
       }
     };
-    T* const obase = out + ((((int64_t)nz * 2) * Ho + 2 * ih) * Wo + 2 * iw) * out_pitch + c0;
+    T* const obase = out + ((((int64_t)nz * (FLAT ? 1 : 2)) * Ho + 2 * ih) * Wo + 2 * iw) * out_pitch + c0;
     auto store_plane = [&](int dz, const float (&A)[4][EPC], float wa, const float (&B)[4][EPC], float wb)
         __attribute__((always_inline)) {
 #pragma unroll
@@ -391,11 +395,16 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const T* __restrict__
       }
     };
     float P0[4][EPC], P1[4][EPC];
-    plane_yx(0, P0);
-    plane_yx(1, P1);
-    store_plane(0, P0, 0.25f, P1, 0.75f);
-    plane_yx(2, P0);
-    store_plane(1, P1, 0.75f, P0, 0.25f);
+    if constexpr (FLAT) {
+      plane_yx(1, P1);                       // zs[1] = id: the tensor's one plane
+      store_plane(0, P1, 1.f, P1, 0.f);
+    } else {
+      plane_yx(0, P0);
+      plane_yx(1, P1);
+      store_plane(0, P0, 0.25f, P1, 0.75f);
+      plane_yx(2, P0);
+      store_plane(1, P1, 0.75f, P0, 0.25f);
+    }
   }
 }
 
@@ -544,7 +553,7 @@ __device__ __forceinline__ int xcd_slab_id(int L, int W) { return (W & 7) ? L : 
 // version decoded its coordinates with 64-bit divisions), and the XCD slab order above keeps the 16 output rows a
 // workgroup reads in the L2 that read them for the previous row (the raster order fetched 1.1 GB per step for 0.35 GB of
 // operands: three XCDs per output row).
-template <typename T>
+template <typename T, bool FLAT = false>   // FLAT: the adjoint of the bilinear x2 of a depth-1 tensor (4 x 4 taps)
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__ dout, int64_t dout_pitch,
                                                            T* __restrict__ din, int64_t din_pitch, int N, int C, int Di,
                                                            int Hi, int Wi, int gx) {
@@ -561,7 +570,12 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__
   const int iw = t / cols, c0 = (t - iw * cols) * EPC;
   int oz[4], oy[4], ox[4];
   float wz[4], wy[4], wx[4];
-  up_bwd_taps(id, Di, oz, wz);
+  if constexpr (FLAT) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) oz[q] = 0, wz[q] = q == 0 ? 1.f : 0.f;
+  } else {
+    up_bwd_taps(id, Di, oz, wz);
+  }
   up_bwd_taps(ih, Hi, oy, wy);
   up_bwd_taps(iw, Wi, ox, wx);
   float acc[EPC];
@@ -570,7 +584,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__
   // all 64 taps unconditionally (indices are clamped into range, out-of-range taps carry weight 0): no branch around
   // any load, so the loads of a thread are all in flight together.  Addresses: one 64-bit sample base, 32-bit element
   // offsets z + y (uniform) + x (the launcher checks that a sample fits 2^31 elements)
-  const T* const sbase = dout + (int64_t)n * (2 * Di) * Ho * Wo * dout_pitch + c0;
+  const T* const sbase = dout + (int64_t)n * ((FLAT ? 1 : 2) * Di) * Ho * Wo * dout_pitch + c0;
   const int pit = (int)dout_pitch;
   int zo[4], yo[4], xo[4];
 #pragma unroll
@@ -580,7 +594,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__
     xo[q] = ox[q] * pit;
   }
 #pragma unroll
-  for (int a = 0; a < 4; a++) {
+  for (int a = 0; a < (FLAT ? 1 : 4); a++) {
 #pragma unroll
     for (int b = 0; b < 4; b++) {
       const float wzy = wz[a] * wy[b];
@@ -1285,15 +1299,20 @@ int hdf_launch_norm_relu_add(int dtype, const void* y, int64_t y_pitch, const fl
 
 int hdf_launch_enc_tail(int dtype, const void* y, int64_t y_pitch, const float* scale, const float* shift,
                         const void* skip, int64_t skip_pitch, void* ds, int64_t ds_pitch, void* pooled,
-                        int64_t pooled_pitch, uint8_t* idx, int N, int C, int Do, int Ho, int Wo, hipStream_t st) {
+                        int64_t pooled_pitch, uint8_t* idx, int N, int C, int Do, int Ho, int Wo, hipStream_t st, int flat) {
   HDF_CHECK_ARG(C % 16 == 0, "enc_tail: C=%d", C);
+  HDF_CHECK_ARG(!flat || Do == 1, "enc_tail: the 2-D form takes depth-1 tensors");
   // (a form with the two x neighbours of a pooled voxel on neighbouring lanes -- whole contiguous rows per instruction, the
   // partial maxima merged through one lane exchange -- was built and measured: 163 vs 155 us at 128^3; this form already
   // streams at 5.5 TB/s alone, the 206 us it shows inside a step come from what runs around it)
   DISPATCH_T(dtype, {
     unsigned g = grid_for((int64_t)N * Do * Ho * Wo * (C / ST<T>::EPC));
-    hipLaunchKernelGGL((enc_tail_kernel<T>), dim3(g), dim3(256), 0, st, (const T*)y, y_pitch, scale, shift,
-                       (const T*)skip, skip_pitch, (T*)ds, ds_pitch, (T*)pooled, pooled_pitch, idx, N, C, Do, Ho, Wo);
+    if (flat)
+      hipLaunchKernelGGL((enc_tail_kernel<T, true>), dim3(g), dim3(256), 0, st, (const T*)y, y_pitch, scale, shift,
+                         (const T*)skip, skip_pitch, (T*)ds, ds_pitch, (T*)pooled, pooled_pitch, idx, N, C, Do, Ho, Wo);
+    else
+      hipLaunchKernelGGL((enc_tail_kernel<T>), dim3(g), dim3(256), 0, st, (const T*)y, y_pitch, scale, shift,
+                         (const T*)skip, skip_pitch, (T*)ds, ds_pitch, (T*)pooled, pooled_pitch, idx, N, C, Do, Ho, Wo);
   });
   HDF_LAUNCH_CHECK();
   return HDF_OK;
@@ -1329,7 +1348,8 @@ int hdf_launch_maxpool_fwd(int dtype, const void* in, int64_t in_pitch, void* ou
 // layer's InstanceNorm(+ReLU) backward -- per workgroup and channel (sum g, sum g * xhat) with g = the STORED din where
 // relu(IN(y)) is positive, rows of in_bwd_reduce_kernel's layout with gridDim.x rows per sample -- and saves that pass its
 // read of din (one of its two tensors; y is read here instead).  grid (blocks, N); thread = (pooled-voxel lane, 4 channels).
-template <typename T>
+// FLAT (round 6): MaxPool2d(2) windows (1x2x2) of a depth-1 tensor, window index k = 2 dy + dx.
+template <typename T, bool FLAT = false>
 __global__ __launch_bounds__(256, 4) void maxpool_bwd_inb_kernel(const T* __restrict__ dout, int64_t dout_pitch,
                                                                  const uint8_t* __restrict__ idx, T* __restrict__ din,
                                                                  int64_t din_pitch, const T* __restrict__ y,
@@ -1362,11 +1382,12 @@ __global__ __launch_bounds__(256, 4) void maxpool_bwd_inb_kernel(const T* __rest
       float g[4];
       ST<T>::ld4(dout + prow * dout_pitch + c0, g);
       const uint32_t pk = *reinterpret_cast<const uint32_t*>(idx + prow * C + c0);
-      const int64_t row0 = (((int64_t)n * 2 * Do + 2 * od) * Hi + 2 * oh) * Wi + 2 * ow;
+      constexpr int NZ = FLAT ? 1 : 2;
+      const int64_t row0 = (((int64_t)n * NZ * Do + NZ * od) * Hi + 2 * oh) * Wi + 2 * ow;
       // both z planes of the 2x2x2 block: 16 loads in flight per thread (one plane at a time, 8 loads: 203 vs 177 us at 128^3)
-      float f[2][4][4], yv[2][4][4];
+      float f[NZ][4][4], yv[NZ][4][4];
 #pragma unroll
-      for (int half = 0; half < 2; half++)
+      for (int half = 0; half < NZ; half++)
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           const int64_t irow = row0 + ((int64_t)half * Hi + (q >> 1)) * Wi + (q & 1);
@@ -1374,7 +1395,7 @@ __global__ __launch_bounds__(256, 4) void maxpool_bwd_inb_kernel(const T* __rest
           ST<T>::ld4(y + irow * y_pitch + c0, yv[half][q]);
         }
 #pragma unroll
-      for (int half = 0; half < 2; half++) {
+      for (int half = 0; half < NZ; half++) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           const int k = half * 4 + q;
@@ -1414,14 +1435,20 @@ int hdf_maxpool_bwd_in_blocks(int64_t pooled_vox, int C) {
 int hdf_launch_maxpool_bwd_in(int dtype, const void* dout, int64_t dout_pitch, const uint8_t* idx, void* din,
                               int64_t din_pitch, const void* y, int64_t y_pitch, const float* scale, const float* shift,
                               const float* mean, const float* rstd, float* partials, int N, int C, int Do, int Ho, int Wo,
-                              hipStream_t st) {
+                              hipStream_t st, int flat) {
   HDF_CHECK_ARG(C % 16 == 0 && C <= 1024, "maxpool_bwd_in: C=%d", C);
   HDF_CHECK_ARG((int64_t)Do * Ho * Wo < ((int64_t)1 << 28), "maxpool_bwd_in: %dx%dx%d pooled voxels per sample", Do, Ho, Wo);
   const int blocks = hdf_maxpool_bwd_in_blocks((int64_t)Do * Ho * Wo, C);
   const int vlanes = 256 / (C / 4);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool_bwd_inb_kernel<T>, dim3(blocks, N), dim3(256),
-                                       (size_t)vlanes * C * 2 * sizeof(float), st, (const T*)dout, dout_pitch, idx, (T*)din,
-                                       din_pitch, (const T*)y, y_pitch, scale, shift, mean, rstd, partials, C, Do, Ho, Wo));
+  if (flat) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool_bwd_inb_kernel<T, true>), dim3(blocks, N), dim3(256),
+                                         (size_t)vlanes * C * 2 * sizeof(float), st, (const T*)dout, dout_pitch, idx, (T*)din,
+                                         din_pitch, (const T*)y, y_pitch, scale, shift, mean, rstd, partials, C, Do, Ho, Wo));
+  } else {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool_bwd_inb_kernel<T>, dim3(blocks, N), dim3(256),
+                                         (size_t)vlanes * C * 2 * sizeof(float), st, (const T*)dout, dout_pitch, idx, (T*)din,
+                                         din_pitch, (const T*)y, y_pitch, scale, shift, mean, rstd, partials, C, Do, Ho, Wo));
+  }
   HDF_LAUNCH_CHECK();
   return HDF_OK;
 }
@@ -1437,18 +1464,26 @@ int hdf_launch_maxpool_bwd(int dtype, const void* dout, int64_t dout_pitch, cons
 }
 
 int hdf_launch_upsample_fwd(int dtype, const void* y, int64_t y_pitch, const float* scale, const float* shift,
-                            void* out, int64_t out_pitch, int N, int C, int Di, int Hi, int Wi, hipStream_t st) {
+                            void* out, int64_t out_pitch, int N, int C, int Di, int Hi, int Wi, hipStream_t st, int flat) {
   HDF_CHECK_ARG(C % 16 == 0, "upsample: C=%d", C);
   HDF_CHECK_ARG(scale && shift, "upsample_fwd: the producer's InstanceNorm scale / shift are required");
-  DISPATCH_T(dtype, hipLaunchKernelGGL(upsample_fwd_kernel<T>,
-                                       dim3(grid_for((int64_t)N * Di * Hi * Wi * (C / ST<T>::EPC))), dim3(256), 0, st,
-                                       (const T*)y, y_pitch, scale, shift, (T*)out, out_pitch, N, C, Di, Hi, Wi));
+  HDF_CHECK_ARG(!flat || Di == 1, "upsample_fwd: the 2-D form takes depth-1 tensors");
+  if (flat) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((upsample_fwd_kernel<T, true>),
+                                         dim3(grid_for((int64_t)N * Di * Hi * Wi * (C / ST<T>::EPC))), dim3(256), 0, st,
+                                         (const T*)y, y_pitch, scale, shift, (T*)out, out_pitch, N, C, Di, Hi, Wi));
+  } else {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(upsample_fwd_kernel<T>,
+                                         dim3(grid_for((int64_t)N * Di * Hi * Wi * (C / ST<T>::EPC))), dim3(256), 0, st,
+                                         (const T*)y, y_pitch, scale, shift, (T*)out, out_pitch, N, C, Di, Hi, Wi));
+  }
   HDF_LAUNCH_CHECK();
   return HDF_OK;
 }
 
 int hdf_launch_upsample_bwd(int dtype, const void* dout, int64_t dout_pitch, void* din, int64_t din_pitch, int N,
-                            int C, int Di, int Hi, int Wi, hipStream_t st) {
+                            int C, int Di, int Hi, int Wi, hipStream_t st, int flat) {
+  HDF_CHECK_ARG(!flat || Di == 1, "upsample_bwd: the 2-D form takes depth-1 tensors");
   HDF_CHECK_ARG((int64_t)8 * Di * Hi * Wi * dout_pitch < ((int64_t)1 << 31),
                 "upsample_bwd: a sample of %dx%dx%d voxels x pitch %lld exceeds 32-bit element offsets", 2 * Di, 2 * Hi,
                 2 * Wi, (long long)dout_pitch);
@@ -1456,8 +1491,12 @@ int hdf_launch_upsample_bwd(int dtype, const void* dout, int64_t dout_pitch, voi
     const int gx = ceil_div(Wi * (C / ST<T>::EPC), 256);
     const int64_t wgs = (int64_t)gx * Hi * N * Di;
     HDF_CHECK_ARG(wgs < ((int64_t)1 << 31), "upsample_bwd: %lld workgroups", (long long)wgs);
-    hipLaunchKernelGGL(upsample_bwd_kernel<T>, dim3((unsigned)wgs), dim3(256), 0, st, (const T*)dout, dout_pitch, (T*)din,
-                       din_pitch, N, C, Di, Hi, Wi, gx);
+    if (flat)
+      hipLaunchKernelGGL((upsample_bwd_kernel<T, true>), dim3((unsigned)wgs), dim3(256), 0, st, (const T*)dout, dout_pitch,
+                         (T*)din, din_pitch, N, C, Di, Hi, Wi, gx);
+    else
+      hipLaunchKernelGGL(upsample_bwd_kernel<T>, dim3((unsigned)wgs), dim3(256), 0, st, (const T*)dout, dout_pitch, (T*)din,
+                         din_pitch, N, C, Di, Hi, Wi, gx);
   });
   HDF_LAUNCH_CHECK();
   return HDF_OK;

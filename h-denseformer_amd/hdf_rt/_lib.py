@@ -18,6 +18,7 @@ _PROTOS = {
     "hdf_set_cu_budget": (_i, [_i]),
     "hdf_plan_create": (_i, [_i] * 8 + [C.POINTER(_vp)]),
     "hdf_plan_create_2d": (_i, [_i] * 7 + [C.POINTER(_vp)]),
+    "hdf_plan_create_2d_embedded": (_i, [_i] * 7 + [C.POINTER(_vp)]),
     "hdf_plan_destroy": (None, [_vp]),
     "hdf_plan_num_params": (_i64, [_vp]),
     "hdf_plan_param_floats": (_i64, [_vp]),

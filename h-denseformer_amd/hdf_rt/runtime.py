@@ -15,15 +15,17 @@ _TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
 class Plan:
     """Owns an hdf_plan* (parameter table, workspace layout)."""
 
-    def __init__(self, in_channels, n_cls, n_filters, image_size, transformer_depth, dtype):
+    def __init__(self, in_channels, n_cls, n_filters, image_size, transformer_depth, dtype, embedded_2d=False):
+        """embedded_2d (2-D plans only): the depth-16 replicated 3-D embedding of rounds 3-5 instead of the native depth-1
+        path -- the oracle of tests/test_gpu_model_2d.py"""
         self.cfg = (int(in_channels), int(n_cls), int(n_filters), tuple(int(v) for v in image_size),
                     int(transformer_depth))
         self.dtype = dtype
         h = C.c_void_p()
         if len(self.cfg[3]) == 2:      # HDenseFormer_2D: the plan's parameter table is the 2-D state_dict
             hh, w = self.cfg[3]
-            check(lib().hdf_plan_create_2d(self.cfg[0], self.cfg[1], self.cfg[2], hh, w, self.cfg[4], dtype,
-                                           C.byref(h)), "hdf_plan_create_2d")
+            create = lib().hdf_plan_create_2d_embedded if embedded_2d else lib().hdf_plan_create_2d
+            check(create(self.cfg[0], self.cfg[1], self.cfg[2], hh, w, self.cfg[4], dtype, C.byref(h)), "hdf_plan_create_2d")
         else:
             d, hh, w = self.cfg[3]
             check(lib().hdf_plan_create(self.cfg[0], self.cfg[1], self.cfg[2], d, hh, w, self.cfg[4], dtype,

@@ -161,7 +161,7 @@ class HDenseFormer(nn.Module):
     def _plan(self, dtype):
         if dtype not in self._plans:
             self._plans[dtype] = Plan(self.in_channels, self.n_cls, self.n_filters, self.image_size,
-                                      self.transformer_depth, dtype)
+                                      self.transformer_depth, dtype, embedded_2d=getattr(self, "_embedded_2d", False))
         return self._plans[dtype]
 
     def _walk_params(self):

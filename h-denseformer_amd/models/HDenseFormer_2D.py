@@ -2,10 +2,11 @@
 factories and state_dict (Conv2d / ConvTranspose2d / InstanceNorm2d parameter shapes), 4-output forward on
 [B, C, H, W] inputs, all arithmetic in libhdf_hip.so.
 
-The library runs the 2-D model as its exact depth-replicated 3-D embedding (hdf_plan_create_2d, csrc/plan.hip
-"2-D embedding"): every 2-D kernel is placed on the depth taps of a 3-D kernel such that all activations consist of
-identical depth slices, the 2-D logits are depth slice 0, and the 2-D parameter gradients are the embedded sums of the
-3-D ones.  Same kernels, same parity, at the cost of the redundant slices."""
+Round 6: the library runs the 2-D model natively on depth-1 tensors (hdf_plan_create_2d: 2-D convolutions, transposed
+convolutions and weight gradients on the 9 centre-plane taps, MaxPool2d, bilinear x2; csrc/plan.hip "2-D embedding" for
+how the 2-D parameters sit in the 27-tap panels).  `net._embedded_2d = True` before the first forward selects the exact
+depth-16 replicated 3-D embedding of rounds 3-5 instead (16x ... 2x the arithmetic): the oracle of
+tests/test_gpu_model_2d.py."""
 from .HDenseFormer import HDenseFormer
 
 __all__ = ["HDenseFormer_2D", "HDenseFormer_2D_32", "HDenseFormer_2D_16"]

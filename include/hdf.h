@@ -44,9 +44,18 @@ int hdf_plan_create(int in_channels, int n_cls, int n_filters, int D, int H, int
 /* models/HDenseFormer_2D.py:172-229 (HDenseFormer_2D.__init__): the 2-D model.  The plan's parameter table is then the
  * 2-D reference state_dict (Conv2d / ConvTranspose2d kernels [..,3,3], patch kernels [..,16,16]); hdf_forward takes
  * x [B,C,H,W] and returns out_i [B,n_cls,H/2^i,W/2^i]; hdf_backward* take 2-D logit gradients and write 2-D parameter
- * gradients.  Internally the model runs as its exact depth-replicated 3-D embedding (csrc/plan.hip "2-D embedding"). */
+ * gradients.  Round 6: the model runs NATIVELY on depth-1 tensors -- 2-D convolutions / transposed convolutions / weight
+ * gradients (the 9 centre-plane taps of the embedded 27-tap panels), MaxPool2d, bilinear x2 -- and only the patch embedding
+ * reads a depth-16 copy of the input.  hdf_plan_create_2d_embedded keeps the exact depth-16 replicated 3-D embedding of
+ * rounds 3-5 (16x ... 2x the arithmetic): the oracle of tests/test_gpu_model_2d.py. */
 int hdf_plan_create_2d(int in_channels, int n_cls, int n_filters, int H, int W, int transformer_depth, int dtype,
                        hdf_plan** out);
+int hdf_plan_create_2d_embedded(int in_channels, int n_cls, int n_filters, int H, int W, int transformer_depth, int dtype,
+                                hdf_plan** out);
+/* Operator level (hdf_op_conv3d, hdf_op_conv3d_wgrad, below): a tensor depth of 1 selects the 2-D operator -- Conv2d(k3,p1),
+ * the stride-2 gather in y and x, ConvTranspose2d(k3,s2,p1,op1) and their weight gradients; the depth axis is never
+ * strided (output depth 1), the packed panel keeps its 27-tap layout with the 2-D kernel on depth tap 1, and a weight
+ * gradient comes back as [.., 27] with zeros off the centre plane (tests/test_gpu_ops_2d.py). */
 void hdf_plan_destroy(hdf_plan* p);
 /* parameter table = the reference state_dict, in registration order; the flat fp32
  * parameter / gradient buffers place tensor i at offset_i (64-byte aligned) */

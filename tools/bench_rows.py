@@ -135,7 +135,7 @@ x2 = torch.rand(2, 4, 256, 256, generator=g).to(DEV)
 net2.eval()
 with torch.no_grad():
     ms = gpu_ms(lambda: net2(x2), reps=5, warm=2)
-emit(row="8f-4 HDenseFormer_2D_32 eval forward", config="batch 2 of 4x256^2, n_cls 2, td 24, bf16 (depth-16 embedding into the 3-D plan)",
+emit(row="8f-4 HDenseFormer_2D_32 eval forward", config="batch 2 of 4x256^2, n_cls 2, td 24, bf16 (native depth-1 path, round 6)",
      gpu_ms=ms, samples_per_s=2 / ms * 1e3)
 net2.train()
 crit = DeepSuperloss(criterion=CEPlusDice(weight=None, ignore_index=0))
@@ -164,7 +164,7 @@ try:
     net3.eval()
     with torch.no_grad():
         ms = gpu_ms(lambda: net3(x3), reps=3, warm=1)
-    emit(row="8f-4 HDenseFormer_2D_32 eval forward, PI-CAI shape", config="batch 24 of 2x384^2, n_cls 2, td 16, bf16 (depth-16 embedding)",
+    emit(row="8f-4 HDenseFormer_2D_32 eval forward, PI-CAI shape", config="batch 24 of 2x384^2, n_cls 2, td 16, bf16 (native depth-1 path, round 6)",
          gpu_ms=ms, samples_per_s=24 / ms * 1e3)
     net3.train()
     opt3 = FlatAdam(net3, lr=1e-3, weight_decay=1e-4)
