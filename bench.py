@@ -24,6 +24,13 @@ for p in (ROOT, os.path.join(ROOT, "h-denseformer_amd")):
 
 # the host driver only supports dmabuf IPC: RCCL / cross-process device memory need this before HIP initialises
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# Data-parallel runs (launched through torch.distributed.run): two hardware queues per process.  The step uses four HIP
+# streams (caller's, weight gradients, transformer branch, communication); with the runtime's default of four hardware queues
+# the communication stream's queue assignment decides whether a collective that holds 16-32 compute units costs the step
+# +0.2 or +1.9 ms (bimodal from run to run), with two it is +0.2 (16 workgroups) / +0.9 ms (32), stable, and the step
+# without a collective is unchanged (tools/stage_cost.py, profiles/r06_stage_cost_hw_queues_*.json).
+if "RANK" in os.environ and "MASTER_ADDR" in os.environ:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
 
 import torch  # noqa: E402
 
