@@ -134,3 +134,60 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, os.path.join(dp, f)
+
+
+@pytest.mark.parametrize("cfg", [(4, 4, 32, (128, 128, 128), 24), (2, 3, 16, (32, 32, 32), 8), (4, 4, 48, (160, 160, 160), 24)])
+def test_gradient_buckets_tile_the_flat_buffer_in_state_dict_order(lib, cfg):
+    """hdf_plan_grad_bucket (round 6: five buckets of hdf_backward_events): contiguous ranges that tile the flat gradient
+    buffer exactly, in state_dict order transformer | UpConv chain | encoder level 0 | encoder levels 1-3 | decoder +
+    heads, every tensor whole inside one bucket (host-side only: no GPU needed)."""
+    from hdf_rt import _lib
+    from hdf_rt.runtime import Plan
+    plan = Plan(*cfg, _lib.F32)
+    rng = []
+    for k in range(5):
+        lo, hi = C.c_int64(), C.c_int64()
+        assert lib.hdf_plan_grad_bucket(plan.h, k, C.byref(lo), C.byref(hi)) == 0
+        rng.append((lo.value, hi.value))
+    order = [rng[2], rng[1], rng[4], rng[3], rng[0]]
+    assert order[0][0] == 0 and order[-1][1] == plan.param_floats
+    assert all(order[i][1] == order[i + 1][0] for i in range(4))
+    want = {2: "attns.", 1: ("deep_conv.", "up1.", "up2.", "up3."), 4: ("block_1_1_left.", "block_1_2_left."),
+            3: ("block_2_", "block_3_", "block_4_"), 0: ("upconv_", "block_", "conv1x1")}
+    for name, off, numel, _shape in plan.table:
+        k = next(i for i, (lo, hi) in enumerate(rng) if lo <= off < hi)
+        assert off + numel <= rng[k][1], name
+        assert name.startswith(want[k]), (name, k)
+        if k == 3:
+            assert "_left." in name
+        if k == 0 and name.startswith("block_"):
+            assert "_right." in name
+    lo, hi = C.c_int64(), C.c_int64()
+    assert lib.hdf_plan_grad_bucket(plan.h, 5, C.byref(lo), C.byref(hi)) != 0
+    # 2-D plans report one bucket (their gradients are extracted in one pass): the ranges are refused
+    plan2 = Plan(2, 2, 16, (64, 64), 8, _lib.F32)
+    assert lib.hdf_plan_grad_bucket(plan2.h, 0, C.byref(lo), C.byref(hi)) != 0
+
+
+def test_persistent_kernel_controls_on_the_host(lib):
+    """the round-6 controls of the persistent transformer kernels are host-side state of the plan: deadline bounds, the
+    residency rule (tiles <= compute units: BASELINE configs[1] is exactly 256, configs[4] at batch 2 is 504), the forcing
+    hook of the tests, no pending give-up on a fresh plan"""
+    from hdf_rt import _lib
+    from hdf_rt.runtime import Plan
+    plan = Plan(4, 4, 32, (128, 128, 128), 24, _lib.BF16)
+    pers, who = C.c_int(-1), C.c_int(-2)
+    assert lib.hdf_plan_chain_state(plan.h, 2, C.byref(pers), C.byref(who)) == 0
+    assert (pers.value, who.value) == (1, -1)
+    assert lib.hdf_plan_chain_state(plan.h, 3, C.byref(pers), C.byref(who)) == 0 and pers.value == 0      # 384 tiles
+    assert lib.hdf_plan_set_chain_timeout_us(plan.h, 50) != 0 and lib.hdf_plan_set_chain_timeout_us(plan.h, 5000) == 0
+    big = Plan(4, 4, 48, (160, 160, 160), 24, _lib.F16)
+    assert lib.hdf_plan_chain_state(big.h, 1, C.byref(pers), C.byref(who)) == 0 and pers.value == 1       # 252 tiles
+    assert lib.hdf_plan_chain_state(big.h, 2, C.byref(pers), C.byref(who)) == 0 and pers.value == 0       # 504 tiles
+    assert lib.hdf_plan_force_persistent(big.h, 1) == 0
+    assert lib.hdf_plan_chain_state(big.h, 2, C.byref(pers), C.byref(who)) == 0 and pers.value == 1
+    assert lib.hdf_set_cu_budget(128) == 0
+    try:
+        assert lib.hdf_plan_chain_state(plan.h, 2, C.byref(pers), C.byref(who)) == 0 and pers.value == 0   # 256 tiles > 128
+    finally:
+        assert lib.hdf_set_cu_budget(256) == 0
