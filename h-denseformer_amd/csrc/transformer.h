@@ -124,8 +124,13 @@ struct TfWgradArgs {
   const float* save;               // [nb*4][rows][232]
   int64_t rows;                    // M * B * N
   int BN, DMF, b0;
+  int kchunks = 1, ntiles = 0;     // set by tf_wgrad: token chunks per tile (> 1: partial products added with fp32 atomics)
 };
-// all weight-matrix gradients of blocks [b0, b0 + nblocks) in one launch (overwrites them)
+// all weight-matrix gradients of blocks [b0, b0 + nblocks) in one launch.  Up to 4096 tokens per modality a workgroup
+// contracts ALL tokens of its 32 x 32 tile and overwrites the gradient (fixed order, bitwise reproducible); beyond that
+// (round 6: the 2-D model at batch 24 has 13,824) the token range is cut into chunks of ~2048 over more workgroups, which
+// ADD into the zeroed gradient buffer with float atomics -- one workgroup per tile walked 13.5x the tokens of the 3-D
+// benchmark with the same four waves (806 us per launch at 0.3 TB/s).
 int tf_wgrad(const TfWgradArgs& a, int nblocks, int M, hipStream_t st);
 
 struct TfTokenBwd {

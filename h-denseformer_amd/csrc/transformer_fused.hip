@@ -662,7 +662,8 @@ __global__ __launch_bounds__(256) void tf_wgrad_kernel(TfWgradArgs a) {
   // grid.x = 16 tile slots per matrix: slot x always landed on XCD x mod 8, XCD 0 received 7.7x the average work and
   // the launch took 360 us with the matrix pipes 11 % busy.)
   const int b = blockIdx.y, m = blockIdx.z;
-  int en = 0, tile = blockIdx.x;
+  const int chunk = (int)blockIdx.x / a.ntiles;      // token chunk (tf_wgrad: one chunk up to 4096 tokens per modality)
+  int en = 0, tile = (int)blockIdx.x - chunk * a.ntiles;
   for (; en < TF_WG_ENTRIES - 1; en++) {
     const int nt = (a.e[en].O >> 5) * (a.e[en].I >> 5);
     if (tile < nt) break;
@@ -687,7 +688,8 @@ __global__ __launch_bounds__(256) void tf_wgrad_kernel(TfWgradArgs a) {
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; i++) acc[i] = 0.f;
-  const int per = (a.BN + 3) / 4, t_lo = wave * per, t_hi = min(a.BN, t_lo + per);
+  const int cper = (a.BN + a.kchunks - 1) / a.kchunks, c_lo = chunk * cper, c_hi = min(a.BN, c_lo + cper);
+  const int per = (c_hi - c_lo + 3) / 4, t_lo = c_lo + wave * per, t_hi = min(c_hi, t_lo + per);
 #pragma unroll
   for (int pair = 0; pair < 2; pair++) {
     if (pair == 1 && e.y1 < 0) break;
@@ -727,7 +729,11 @@ __global__ __launch_bounds__(256) void tf_wgrad_kernel(TfWgradArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-      gW[(int64_t)(o0 + row) * e.I + i0 + r] = ((acc[i] + red[0][row][r]) + red[1][row][r]) + red[2][row][r];
+      const float v = ((acc[i] + red[0][row][r]) + red[1][row][r]) + red[2][row][r];
+      if (a.kchunks > 1)
+        atomicAdd(&gW[(int64_t)(o0 + row) * e.I + i0 + r], v);   // (the backward zeroes the gradient buffer first)
+      else
+        gW[(int64_t)(o0 + row) * e.I + i0 + r] = v;
     }
   }
 }
@@ -752,11 +758,14 @@ int launch_tok_bwd(const TokBwd& a, hipStream_t st) {
 
 }  // namespace
 
-int tf_wgrad(const TfWgradArgs& a, int nblocks, int M, hipStream_t st) {
+int tf_wgrad(const TfWgradArgs& a0, int nblocks, int M, hipStream_t st) {
+  TfWgradArgs a = a0;
   int tiles = 0;
   for (int k = 0; k < TF_WG_ENTRIES; k++) tiles += (a.e[k].O >> 5) * (a.e[k].I >> 5);
   HDF_CHECK_ARG(tiles > 0 && a.e[TF_WG_ENTRIES - 1].O > 0, "tf_wgrad: empty entry table");
-  hipLaunchKernelGGL(tf_wgrad_kernel, dim3(tiles, nblocks, M), dim3(256), 0, st, a);
+  a.ntiles = tiles;
+  a.kchunks = a.BN <= 4096 ? 1 : std::min(16, (a.BN + 2047) / 2048);
+  hipLaunchKernelGGL(tf_wgrad_kernel, dim3(tiles * a.kchunks, nblocks, M), dim3(256), 0, st, a);
   HDF_LAUNCH_CHECK();
   return HDF_OK;
 }

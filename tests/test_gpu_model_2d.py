@@ -157,3 +157,36 @@ def test_2d_native_path_against_the_replicated_embedding(dtype):
             worst = max(worst, (k, 1 - c), key=lambda kv: kv[1])
             assert c > 0.97, (k, c)
     print("  worst gradient tensor native vs embedded:", worst)
+
+
+def test_2d_large_batch_transformer_weight_gradients_vs_oracle():
+    """24 images of 2x256^2 give 6,144 tokens per modality: tf_wgrad then cuts the token range into chunks over more
+    workgroups that add into the zeroed gradient buffer with float atomics (csrc/transformer.h tf_wgrad; one workgroup per
+    32 x 32 tile walked 13.5x the tokens of the 3-D benchmark with four waves).  fp32 train step against the oracle:
+    every weight matrix of the branches to 2e-2 rel-L2 (the reference's own fp32 noise floor), the loss to 1e-4."""
+    from loss.combine_loss import CEPlusDice, DeepSuperloss
+    cfg, batch, seed = (2, 2, 16, (256, 256), 4), 24, 23
+    net, sd = _build(cfg, "fp32")
+    x, onehot = _data(cfg, batch, "large_batch_2d")
+    crit = DeepSuperloss(criterion=CEPlusDice(weight=None, ignore_index=0))
+    net.train()
+    net.set_dropout_seed(seed)
+    loss = crit(net(x.to(DEV)), onehot.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    tr = orc.OracleTrainer(sd)
+    ref_loss, _ = tr.loss_and_grads(x, onehot, seed)
+    assert abs(loss.item() - float(ref_loss)) < 1e-4 * max(1.0, abs(float(ref_loss)))
+    worst = ("", 0.0)
+    n = 0
+    for name, p in net.named_parameters():
+        if not (name.startswith("attns.") and p.dim() == 2):
+            continue
+        rg = tr.sd[name].grad
+        if float(rg.norm()) < 1e-7:
+            continue
+        e = _rl2(p.grad, rg)
+        worst = max(worst, (name, e), key=lambda kv: kv[1])
+        n += 1
+    print(f"  {n} branch weight matrices, worst {worst[0]} rel-l2 {worst[1]:.3e}")
+    assert n >= 40 and worst[1] < 2e-2, worst
