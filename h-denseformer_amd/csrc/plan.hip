@@ -246,11 +246,10 @@ struct hdf_plan {
   bool is2d = false;
   // Round 6: the 2-D model runs NATIVELY on depth-1 tensors (flat): every level has depth 1, the convolutions / transposed
   // convolutions / weight gradients are the FLAT instantiations of conv_igemm.hip (centre-plane taps of the embedded 27-tap
-  // panels), pooling and up-sampling their 2-D forms (unet_ops.hip), and only the patch embedding still sees a depth-16
-  // copy of the input (its 16 x 16 kernel sits on depth slice 0 of the 16^3 one).  flat = false keeps the depth-16
+  // panels), pooling and up-sampling their 2-D forms (unet_ops.hip), the patch embedding contracts depth slice 0 of the
+  // embedded 16^3 kernels with the input's 16 x 16 patches (K = 256).  flat = false keeps the depth-16
   // replicated embedding of rounds 3-5 (hdf_plan_create_2d_embedded: the oracle of tests/test_gpu_model_2d.py).
   bool flat = false;
-  const float* xtok = nullptr;   // flat: the depth-16 copy of the input the patch embedding reads (set around the 3-D calls)
   std::vector<ParamInfo> params2d;  // the 2-D reference state_dict: conv kernels [..,3,3], patch kernels [..,16,16]
   int64_t total_floats2d = 0;
   std::vector<Embed2dJob> ejobs;
@@ -1018,10 +1017,10 @@ int transformer_forward(Exec& e, const float* x) {
 #else
   const int PE_LP = p->dtype;
 #endif
-  if (p->xtok) x = p->xtok;
-  HDF_TRY(tf_patch_embed_fwd(d, x, p->D, p->H, p->W, pm + p->P("attns.0.patch_embeddings.weight"),
+  // (flat: the 2-D input itself, depth 1, against depth slice 0 of the embedded 16^3 patch kernel)
+  HDF_TRY(tf_patch_embed_fwd(d, x, p->flat ? 1 : p->D, p->H, p->W, pm + p->P("attns.0.patch_embeddings.weight"),
                              pm + p->P("attns.0.patch_embeddings.bias"), pm + p->P("attns.0.position_embeddings"), F0,
-                             e.st, PE_LP));
+                             e.st, PE_LP, p->flat ? 1 : 16));
   if (p->tf_fwd_chain) {  // all layers of all blocks in one persistent launch (transformer_chain.hip)
     if (e.tf_packed && hipStreamWaitEvent(e.st, e.tf_packed, 0) != hipSuccess) {
       hdf_set_error("branch stream: wait failed");
@@ -1065,7 +1064,6 @@ int transformer_forward(Exec& e, const float* x) {
 
 int transformer_backward(Exec& e, const float* x) {
   hdf_plan* p = e.p;
-  if (p->xtok) x = p->xtok;
   TfDims d = tf_dims(p, e.B);
   float* pm = const_cast<float*>(e.params);
   const int64_t rows = (int64_t)p->M * e.B * p->Ntok;
@@ -1119,9 +1117,9 @@ int transformer_backward(Exec& e, const float* x) {
                               reinterpret_cast<unsigned*>(e.ws + p->tf_sync) + (1 << 17), p->dtype, e.st, chain_ctl(p)));
     // (on this stream, not on the side stream: that one still holds the level-0 weight gradients, and tf_wgrad -- HBM-bound,
     // 110 us -- would run behind them as the last kernel of the step)
-    HDF_TRY(tf_patch_embed_bwd(d, x, p->D, p->H, p->W, dF, e.grads + p->P("attns.0.patch_embeddings.weight"),
+    HDF_TRY(tf_patch_embed_bwd(d, x, p->flat ? 1 : p->D, p->H, p->W, dF, e.grads + p->P("attns.0.patch_embeddings.weight"),
                                e.grads + p->P("attns.0.patch_embeddings.bias"),
-                               e.grads + p->P("attns.0.position_embeddings"), scratch, e.st));
+                               e.grads + p->P("attns.0.position_embeddings"), scratch, e.st, p->flat ? 1 : 16));
     w.b0 = 0;
     HDF_TRY(tf_wgrad(w, p->nb, p->M, e.st));
     return HDF_OK;
@@ -1171,9 +1169,9 @@ int transformer_backward(Exec& e, const float* x) {
   t.tape_pre = e.f(p->tf_tape);
   HDF_TRY(tf_token_bwd(d, t, p->dtype, e.st));
   HDF_TRY(wgrad_block(0));
-  HDF_TRY(tf_patch_embed_bwd(d, x, p->D, p->H, p->W, dF, e.grads + p->P("attns.0.patch_embeddings.weight"),
+  HDF_TRY(tf_patch_embed_bwd(d, x, p->flat ? 1 : p->D, p->H, p->W, dF, e.grads + p->P("attns.0.patch_embeddings.weight"),
                              e.grads + p->P("attns.0.patch_embeddings.bias"),
-                             e.grads + p->P("attns.0.position_embeddings"), scratch, e.st));
+                             e.grads + p->P("attns.0.position_embeddings"), scratch, e.st, p->flat ? 1 : 16));
   return HDF_OK;
 }
 
@@ -1604,17 +1602,13 @@ int hdf_forward(hdf_plan* p, const float* x, const float* params, void* workspac
   float* p3 = (float*)(ws + p->e_params3d);
   float* x3 = (float*)(ws + p->e_x3d);
   HDF_TRY(launch_embed2d(p, params, p3, st));
+  if (p->flat)
+    // native 2-D path: depth-1 tensors throughout; the logits [B, n_cls, 1, H, W] ARE the 2-D outputs, and the patch
+    // embedding contracts the input's 16 x 16 patches with depth slice 0 of the embedded kernels (kd = 1)
+    return forward3d(p, x, p3, workspace, workspace_bytes, out0, out1, out2, out3, batch, training, seed, stream);
   const int64_t hw = (int64_t)p->H * p->W;
   hipLaunchKernelGGL(replicate_depth_kernel, dim3(2048), dim3(256), 0, st, x, x3, (int64_t)batch * p->M, p->D, hw);
   HDF_LAUNCH_CHECK();
-  if (p->flat) {
-    // native 2-D path: depth-1 tensors throughout; the logits [B, n_cls, 1, H, W] ARE the 2-D outputs, the depth-16 copy of
-    // the input feeds the patch embedding only
-    p->xtok = x3;
-    const int rc = forward3d(p, x, p3, workspace, workspace_bytes, out0, out1, out2, out3, batch, training, seed, stream);
-    p->xtok = nullptr;
-    return rc;
-  }
   void* o3[4];
   for (int i = 0; i < 4; i++) o3[i] = ws + p->e_out3d[i];
   HDF_TRY(forward3d(p, x3, p3, workspace, workspace_bytes, o3[0], o3[1], o3[2], o3[3], batch, training, seed, stream));
@@ -1940,15 +1934,10 @@ static int backward_any(hdf_plan* p, const float* x, const float* params, void* 
                                  (int64_t)p->dims[i][1] * p->dims[i][2], 0, st));
   }
   float* g3 = (float*)(ws + p->e_grads3d);
-  if (p->flat) {
-    // (x: the 2-D input itself is not read by the backward of the U-Net -- the first layer's weight gradient reads the
-    // channels-last copy the forward left in the workspace -- ; the patch embedding's backward reads the depth-16 copy)
-    p->xtok = (const float*)(ws + p->e_x3d);
-    const int rc = backward3d(p, x, (const float*)(ws + p->e_params3d), workspace, workspace_bytes, d3[0], d3[1], d3[2],
-                              d3[3], g3, batch, stages, stream);
-    p->xtok = nullptr;
-    HDF_TRY(rc);
-  } else
+  if (p->flat)   // (x: the patch embedding's weight gradient reads the 2-D input itself)
+    HDF_TRY(backward3d(p, x, (const float*)(ws + p->e_params3d), workspace, workspace_bytes, d3[0], d3[1], d3[2], d3[3], g3,
+                       batch, stages, stream));
+  else
   HDF_TRY(backward3d(p, (const float*)(ws + p->e_x3d), (const float*)(ws + p->e_params3d), workspace, workspace_bytes,
                      d3[0], d3[1], d3[2], d3[3], g3, batch, stages, stream));
   HDF_TRY(launch_extract2d(p, stages, g3, grads, st));

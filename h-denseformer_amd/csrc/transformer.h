@@ -46,9 +46,10 @@ struct TfLayerSave {
 };
 
 int tf_patch_embed_fwd(const TfDims& d, const float* x /*[B][M][D][H][W]*/, int D, int H, int W, const float* wpe,
-                       const float* bpe, const float* pos, float* F /*[rows][DMF]*/, hipStream_t st, int lp = 0);
+                       const float* bpe, const float* pos, float* F /*[rows][DMF]*/, hipStream_t st, int lp = 0,
+                       int kd = 16 /* depth slices of the 16^3 kernel contracted: 1 = the 2-D model's 16 x 16 patches on a depth-1 input */);
 int tf_patch_embed_bwd(const TfDims& d, const float* x, int D, int H, int W, const float* dF /*[rows][DMF]*/,
-                       float* dwpe, float* dbpe, float* dpos, float* scratch /*[rows][DM]*/, hipStream_t st);
+                       float* dwpe, float* dbpe, float* dpos, float* scratch /*[rows][DM]*/, hipStream_t st, int kd = 16);
 
 // Dense_Attention core (HDenseFormer.py:67-74): qkv [nseq*N][96] (q | k | v, 8 heads x 4) -> ob [nseq*N][32] (heads
 // merged, before to_out), lse [nseq*N][8] (natural-log row log-sum-exp of the 0.5-scaled scores)

@@ -560,11 +560,15 @@ __global__ __launch_bounds__(256) void attn_bwd_lp_kernel(int N, int nseq, const
 // four consecutive fp32 values of a 16-byte load are exactly the four k of one 16x16x16 step (k = 4 g + e), for A and B
 // alike: one matrix instruction per load pair instead of four, 32 per 64-deep chunk instead of 128 (this launch is the
 // first of the forward's critical chain, and with fp32 steps it is bound by the matrix pipe: 2,048 steps of 32 cycles).
+// kd (round 6): depth slices of the 16^3 kernel that are contracted -- 16, or 1 for the 2-D model's 16 x 16 patches on a
+// depth-1 input (models/HDenseFormer_2D.py:112: the 2-D kernel sits on depth slice 0 of the embedded 16^3 one, i.e. the first
+// 256 of a weight row's 4096 entries): K = 256, one 64-deep chunk per wave.
 template <int LP>
 __global__ __launch_bounds__(256) void patch_embed_fwd2_kernel(TfDims d, const float* __restrict__ x, int D, int H,
                                                                int W, const float* __restrict__ wpe,
                                                                const float* __restrict__ bpe,
-                                                               const float* __restrict__ pos, float* __restrict__ F) {
+                                                               const float* __restrict__ pos, float* __restrict__ F,
+                                                               int kd) {
   __shared__ float red[4][32][65];
   const int m = blockIdx.z, BN = d.B * d.N, DM = d.DM;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i16 = lane & 15, g = lane >> 4;
@@ -579,7 +583,7 @@ __global__ __launch_bounds__(256) void patch_embed_fwd2_kernel(TfDims d, const f
     const int gz = n / (gh * gw), gy = (n / gw) % gh, gx = n % gw;
     xt[mt] = x + ((((int64_t)b * d.M + m) * D + gz * 16) * H + gy * 16) * W + gx * 16;
   }
-  constexpr int NCH = 4096 / 64 / 4;  // chunks per wave
+  const int NCH = kd;  // chunks per wave: kd * 256 / 64 / 4
   f32x4 ra[2][2][4], rb[2][4][4];
   auto load_chunk = [&](int i, int slot) __attribute__((always_inline)) {
     const int c = i * 4 + wave;
@@ -636,10 +640,10 @@ __global__ __launch_bounds__(256) void patch_embed_fwd2_kernel(TfDims d, const f
   };
   load_chunk(0, 0);
   for (int i = 0; i < NCH; i += 2) {
-    load_chunk(i + 1, 1);  // NCH is even
+    if (i + 1 < NCH) load_chunk(i + 1, 1);
     mma_chunk(0);
     if (i + 2 < NCH) load_chunk(i + 2, 0);
-    mma_chunk(1);
+    if (i + 1 < NCH) mma_chunk(1);
   }
   // C/D layout: row = 4 (lane >> 4) + i, column = lane & 15
 #pragma unroll
@@ -685,16 +689,20 @@ __global__ void patch_embed_bwd_prep_kernel(TfDims d, const float* __restrict__ 
   }
 }
 
-// dW[c][k] = sum_t dtok[t][c] * patch[t][k].  grid (4096/128, ceil(DM/32), M); wave w owns k columns w*32..+32
+// dW[c][k] = sum_t dtok[t][c] * patch[t][k].  grid (kblocks * tchunks, ceil(DM/32), M); wave w owns k columns w*32..+32.
+// kblocks = 4096/128 (3-D) or 256/128 (round 6: the 2-D model's depth-1 patches, slice 0 of the embedded kernel); tchunks
+// > 1 (the 2-D model: two K blocks would leave 16 workgroups walking 13,824 tokens each): a workgroup contracts its chunk of
+// the tokens and ADDS with float atomics.
 __global__ __launch_bounds__(256) void patch_embed_wgrad_kernel(TfDims d, const float* __restrict__ x, int D, int H,
                                                                 int W, const float* __restrict__ dtok,
-                                                                float* __restrict__ dwpe) {
+                                                                float* __restrict__ dwpe, int kblocks, int tchunks) {
   constexpr int TT = 32, LDD = 33, LDP = 129;
   __shared__ float sD[TT * LDD], sP[TT * LDP];
   extern __shared__ int sTok[];  // [BN]: element offset of every token's brick in x (the per-load divisions by the
                                  // token grid cost more VALU time than the MFMAs: 25 runtime divisions per tile)
   const int m = blockIdx.z, BN = d.B * d.N, DM = d.DM;
-  const int cb = blockIdx.y * 32, kb = blockIdx.x * 128;
+  const int tchunk = (int)blockIdx.x / kblocks;
+  const int cb = blockIdx.y * 32, kb = ((int)blockIdx.x - tchunk * kblocks) * 128;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int gh = H / 16, gw = W / 16;
   f32x16 acc;
@@ -728,8 +736,12 @@ __global__ __launch_bounds__(256) void patch_embed_wgrad_kernel(TfDims d, const 
       if (t0 + tl >= BN) rp[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  load_tile_regs(0);
-  for (int t0 = 0; t0 < BN; t0 += TT) {
+  // this workgroup's token range (whole tiles of TT)
+  const int tper = ((BN + tchunks - 1) / tchunks + TT - 1) / TT * TT;
+  const int tb = tchunk * tper, te = min(BN, tb + tper);
+  if (tb >= te) return;
+  load_tile_regs(tb);
+  for (int t0 = tb; t0 < te; t0 += TT) {
     __syncthreads();  // the previous tile's MFMAs are done with the LDS tiles
     {
       int i = threadIdx.x * 4, tl = i >> 5, c = i & 31;
@@ -743,7 +755,7 @@ __global__ __launch_bounds__(256) void patch_embed_wgrad_kernel(TfDims d, const 
       dst[0] = rp[u].x, dst[1] = rp[u].y, dst[2] = rp[u].z, dst[3] = rp[u].w;
     }
     __syncthreads();
-    if (t0 + TT < BN) load_tile_regs(t0 + TT);
+    if (t0 + TT < te) load_tile_regs(t0 + TT);
     for (int t2 = 0; t2 < TT / 2; t2++) {
       float av = sD[(2 * t2 + h) * LDD + r];
       float bv = sP[(2 * t2 + h) * LDP + wave * 32 + r];
@@ -753,7 +765,13 @@ __global__ __launch_bounds__(256) void patch_embed_wgrad_kernel(TfDims d, const 
 #pragma unroll
   for (int i = 0; i < 16; i++) {
     int c = cb + (i & 3) + 8 * (i >> 2) + 4 * h;
-    if (c < DM) dwpe[(int64_t)m * d.mstride + (int64_t)c * 4096 + kb + wave * 32 + r] += acc[i];
+    if (c < DM) {
+      float* q = dwpe + (int64_t)m * d.mstride + (int64_t)c * 4096 + kb + wave * 32 + r;
+      if (tchunks > 1)
+        atomicAdd(q, acc[i]);
+      else
+        *q += acc[i];
+    }
   }
 }
 
@@ -773,28 +791,33 @@ int allow_lds(Kern kern, size_t bytes) {
 }  // namespace
 
 int tf_patch_embed_fwd(const TfDims& d, const float* x, int D, int H, int W, const float* wpe, const float* bpe,
-                       const float* pos, float* F, hipStream_t st, int lp) {
+                       const float* pos, float* F, hipStream_t st, int lp, int kd) {
+  HDF_CHECK_ARG(kd == 16 || (kd == 1 && D == 1), "patch_embed: kernel depth %d on an input of depth %d", kd, D);
   // token dim = 4 * n_filters with n_filters % 16 == 0 (plan): a multiple of 64
   HDF_CHECK_ARG(d.DM <= 256 && d.DM % 64 == 0, "patch_embed: token dim %d unsupported (a multiple of 64, <= 256)", d.DM);
   const dim3 grid(ceil_div(d.B * d.N, 32), d.DM / 64, d.M);
   if (lp == HDF_BF16)
-    hipLaunchKernelGGL(patch_embed_fwd2_kernel<1>, grid, dim3(256), 0, st, d, x, D, H, W, wpe, bpe, pos, F);
+    hipLaunchKernelGGL(patch_embed_fwd2_kernel<1>, grid, dim3(256), 0, st, d, x, D, H, W, wpe, bpe, pos, F, kd);
   else if (lp == HDF_F16)
-    hipLaunchKernelGGL(patch_embed_fwd2_kernel<2>, grid, dim3(256), 0, st, d, x, D, H, W, wpe, bpe, pos, F);
+    hipLaunchKernelGGL(patch_embed_fwd2_kernel<2>, grid, dim3(256), 0, st, d, x, D, H, W, wpe, bpe, pos, F, kd);
   else
-    hipLaunchKernelGGL(patch_embed_fwd2_kernel<0>, grid, dim3(256), 0, st, d, x, D, H, W, wpe, bpe, pos, F);
+    hipLaunchKernelGGL(patch_embed_fwd2_kernel<0>, grid, dim3(256), 0, st, d, x, D, H, W, wpe, bpe, pos, F, kd);
   HDF_LAUNCH_CHECK();
   return HDF_OK;
 }
 
 int tf_patch_embed_bwd(const TfDims& d, const float* x, int D, int H, int W, const float* dF, float* dwpe, float* dbpe,
-                       float* dpos, float* scratch, hipStream_t st) {
+                       float* dpos, float* scratch, hipStream_t st, int kd) {
+  HDF_CHECK_ARG(kd == 16 || (kd == 1 && D == 1), "patch_embed: kernel depth %d on an input of depth %d", kd, D);
   hipLaunchKernelGGL(patch_embed_bwd_prep_kernel, dim3(ceil_div(d.N * d.DM, 256), d.M), dim3(256), 0, st, d, dF,
                      scratch, dbpe, dpos);
   HDF_LAUNCH_CHECK();
   HDF_CHECK_ARG((int64_t)d.B * d.M * D * H * W < ((int64_t)1 << 31), "patch_embed: volume exceeds 32-bit element offsets");
-  hipLaunchKernelGGL(patch_embed_wgrad_kernel, dim3(4096 / 128, ceil_div(d.DM, 32), d.M), dim3(256),
-                     (size_t)d.B * d.N * sizeof(int), st, d, x, D, H, W, scratch, dwpe);
+  const int kblocks = kd * 256 / 128;
+  // enough workgroups for the chip: the 3-D form has 32 K blocks x DM/32 x M; the depth-1 form cuts the tokens instead
+  const int tchunks = kd == 16 ? 1 : std::max(1, std::min(ceil_div(d.B * d.N, 256), 512 / std::max(1, kblocks * ceil_div(d.DM, 32) * d.M)));
+  hipLaunchKernelGGL(patch_embed_wgrad_kernel, dim3(kblocks * tchunks, ceil_div(d.DM, 32), d.M), dim3(256),
+                     (size_t)d.B * d.N * sizeof(int), st, d, x, D, H, W, scratch, dwpe, kblocks, tchunks);
   HDF_LAUNCH_CHECK();
   return HDF_OK;
 }

@@ -45,8 +45,8 @@ int hdf_plan_create(int in_channels, int n_cls, int n_filters, int D, int H, int
  * 2-D reference state_dict (Conv2d / ConvTranspose2d kernels [..,3,3], patch kernels [..,16,16]); hdf_forward takes
  * x [B,C,H,W] and returns out_i [B,n_cls,H/2^i,W/2^i]; hdf_backward* take 2-D logit gradients and write 2-D parameter
  * gradients.  Round 6: the model runs NATIVELY on depth-1 tensors -- 2-D convolutions / transposed convolutions / weight
- * gradients (the 9 centre-plane taps of the embedded 27-tap panels), MaxPool2d, bilinear x2 -- and only the patch embedding
- * reads a depth-16 copy of the input.  hdf_plan_create_2d_embedded keeps the exact depth-16 replicated 3-D embedding of
+ * gradients (the 9 centre-plane taps of the embedded 27-tap panels), MaxPool2d, bilinear x2, 16 x 16 patches against depth
+ * slice 0 of the embedded patch kernels.  hdf_plan_create_2d_embedded keeps the exact depth-16 replicated 3-D embedding of
  * rounds 3-5 (16x ... 2x the arithmetic): the oracle of tests/test_gpu_model_2d.py. */
 int hdf_plan_create_2d(int in_channels, int n_cls, int n_filters, int H, int W, int transformer_depth, int dtype,
                        hdf_plan** out);
