@@ -112,15 +112,17 @@ def test_2d_train_step_vs_reference_golden(dtype):
         assert cos > 0.98
 
 
+@pytest.mark.parametrize("cfg,batch", [((2, 3, 16, (96, 128), 8), 3), ((1, 2, 48, (64, 96), 4), 2)],
+                         ids=["nf16_96x128", "nf48_64x96"])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_2d_native_path_against_the_replicated_embedding(dtype):
+def test_2d_native_path_against_the_replicated_embedding(dtype, cfg, batch):
     """The native depth-1 path and the depth-16 replicated 3-D embedding are the same function of the 2-D parameters: one
     train step (dropout on) through each, every output and every parameter gradient compared.  fp32: both are exact-fp32
     MFMA chains with different summation orders (1e-4 on the logits; per gradient tensor that carries energy 1e-2 rel-L2, the
     reference's own fp32 noise floor of 1.5e-3 ... 6.4e-3 -- ReLU / arg-max decisions flip under 1e-6 perturbations, DESIGN 4);
     bf16: storage rounding differs along the way (2e-2 / cosine 0.98)."""
     from loss.combine_loss import CEPlusDice, DeepSuperloss
-    cfg, batch, seed = (2, 3, 16, (96, 128), 8), 3, 17
+    seed = 17      # (n_filters 48: 96-byte channel rows, the convs' non-pipelined chunk loop; one modality)
     x, onehot = _data(cfg, batch, "native_vs_embedded")
     crit = DeepSuperloss(criterion=CEPlusDice(weight=None, ignore_index=0))
     res = []
@@ -190,3 +192,49 @@ def test_2d_large_batch_transformer_weight_gradients_vs_oracle():
         n += 1
     print(f"  {n} branch weight matrices, worst {worst[0]} rel-l2 {worst[1]:.3e}")
     assert n >= 40 and worst[1] < 2e-2, worst
+
+
+def test_2d_model_under_gradsync_reduces_its_one_bucket():
+    """The 2-D plan's gradients are extracted from the 27-tap panels in one pass at the end of the backward: all five bucket
+    events fire there and GradSync reduces ONE range, the whole 2-D gradient buffer (models/HDenseFormer.py _run_backward).
+    gloo world 1, a stand-in collective that scales by 1: the synced gradient equals the plain backward's."""
+    import torch.distributed as dist
+    from hdf_rt import parallel
+    from loss.combine_loss import CEPlusDice, DeepSuperloss
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29586")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        cfg, batch = (2, 3, 16, (64, 64), 4), 2
+        net, _ = _build(cfg, "bf16")
+        net.train()
+        x, onehot = _data(cfg, batch, "sync2d")
+        crit = DeepSuperloss(criterion=CEPlusDice(weight=None, ignore_index=0))
+        net.set_dropout_seed(5)
+        crit(net(x.to(DEV)), onehot.to(DEV)).backward()
+        torch.cuda.synchronize()
+        g_ref = net.flat_grads().clone()
+        sizes = []
+
+        def fake_allreduce(flat, world, group=None):
+            sizes.append(flat.numel())
+            flat.mul_(1.0)
+        orig = parallel.flat_allreduce_mean
+        parallel.flat_allreduce_mean = fake_allreduce
+        try:
+            sync = parallel.GradSync(net)
+            net.grad_hook = sync
+            for p in net.parameters():
+                p.grad = None
+            net.set_dropout_seed(5)
+            crit(net(x.to(DEV)), onehot.to(DEV)).backward()
+            sync.wait()
+            torch.cuda.synchronize()
+        finally:
+            parallel.flat_allreduce_mean = orig
+            net.grad_hook = None
+        assert sizes == [net.flat_grads().numel()], sizes
+        assert _rl2(net.flat_grads(), g_ref) < 1e-5
+    finally:
+        dist.destroy_process_group()
