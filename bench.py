@@ -321,6 +321,10 @@ def main():
     one_dev = os.environ.get("HDF_BENCH_ONE_DEVICE") == "1"
     if one_dev:
         local = 0
+        # two processes on one device cannot both hold every compute unit: the persistent transformer kernels of the two
+        # ranks can each be left with half a grid resident and give up at a barrier (include/hdf.h: HDF_ERR_CHAIN_TIMEOUT;
+        # the in-process serialisation does not reach across processes) -- this diagnostic mode runs the launch chain
+        os.environ["HDF_NO_TF_CHAIN"] = "1"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # Launched through torch.distributed.run (RANK / MASTER_ADDR in the environment) the process group, GradSync and
