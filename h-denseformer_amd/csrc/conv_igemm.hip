@@ -131,11 +131,41 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 
   const int oz = (CONVT || FLAT) ? z0 : S * z0 - 1, oy = CONVT ? y0 : S * y0 - 1, ox = CONVT ? x0 : S * x0 - 1;
 
+  // MFMA row -> tile voxel.  Tile order (32 consecutive voxels per M-block) put the 16 lanes of a ds_read_b128 service
+  // group (conv_tile.h: ds128_group) on box rows that repeat mod 16 -- with the 80-byte pitch that is the same 16-byte
+  // bank slot up to three times (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.66 in every round's kernel table: the A
+  // fragment reads of this kernel took 3x their LDS cycles).  Where the tile shape allows it the M-block is a slab whose
+  // groups see 16 distinct rows mod 16:
+  //  ZXMAP (8-wide tiles 4 deep, stride 1): M-block = one y, rows -> (z, x) as in conv_ws2_kernel (a group = z {0,2} or
+  //        {1,3}: 2 BH BW = 8 mod 16 for BH BW = 100 and 60)
+  //  YXMAP (flat 16-wide tiles): M-block = two y rows, one whole x row of 16 per group
+  // Which voxel an accumulator row stands for changes nothing in a voxel's own arithmetic; only the order in which the
+  // InstanceNorm partial sums of a workgroup add their voxels moves.
+#ifdef HDF_IGEMM_LINEAR_MAP   // (A/B builds: tile order everywhere)
+  constexpr bool ZXMAP = false, YXMAP = false;
+#else
+  constexpr bool ZXMAP = !CONVT && !FLAT && S == 1 && TD == 4 && TW == 8 && WM * MB == TH && (2 * BH * BW) % 16 == 8;
+  constexpr bool YXMAP = FLAT && SS == 1 && TW == 16 && 2 * WM * MB == TH;
+#endif
+  auto mrow_voxel = [](int mblk, int row, int& lz, int& ly, int& lx) {
+    if constexpr (ZXMAP) {
+      ws_row_to_zx(row, lz, lx);
+      ly = mblk;
+    } else if constexpr (YXMAP) {
+      int g2;
+      ds128_group(row, g2, lx);
+      lz = 0;
+      ly = 2 * mblk + g2;
+    } else {
+      const int lin = mblk * 32 + row;
+      lz = lin / (TH * TW), ly = (lin / TW) % TH, lx = lin % TW;
+    }
+  };
   int rowbase[MB];
 #pragma unroll
   for (int mb = 0; mb < MB; mb++) {
-    int lin = (wm * MB + mb) * 32 + r;
-    int lz = lin / (TH * TW), ly = (lin / TW) % TH, lx = lin % TW;
+    int lz, ly, lx;
+    mrow_voxel(wm * MB + mb, r, lz, ly, lx);
     rowbase[mb] = (((FLAT ? 0 : SS * lz)) * BH + SS * ly) * BW + SS * lx;
   }
   f32x16 acc[MB];
@@ -278,8 +308,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
           for (int i = 0; i < 16; i++) {
             const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-            const int lin = (wm * MB + mb) * 32 + row;
-            const int lz = lin / (TH * TW), ly = (lin / TW) % TH, lx = lin % TW;
+            int lz, ly, lx;
+            mrow_voxel(wm * MB + mb, row, lz, ly, lx);
             const int gz = z0 + lz, gy = y0 + ly, gx = x0 + lx;
             if (gz < Td && gy < Th && gx < Tw)
               a.kpart[((int64_t)blockIdx.z * mtot + (((int64_t)n * a.Do + gz) * a.Ho + gy) * a.Wo + gx) * a.CoutP + ch] =
@@ -304,8 +334,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-        int lin = (wm * MB + mb) * 32 + row;
-        int lz = lin / (TH * TW), ly = (lin / TW) % TH, lx = lin % TW;
+        int lz, ly, lx;
+        mrow_voxel(wm * MB + mb, row, lz, ly, lx);
         int gz = z0 + lz, gy = y0 + ly, gx = x0 + lx;
         const bool ok = ch_ok && gz < Td && gy < Th && gx < Tw;
         int qz = (CONVT && !FLAT) ? 2 * gz + pz : gz, qy = CONVT ? 2 * gy + py : gy, qx = CONVT ? 2 * gx + px : gx;
@@ -319,8 +349,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-      int lin = (wm * MB + mb) * 32 + row;
-      int lz = lin / (TH * TW), ly = (lin / TW) % TH, lx = lin % TW;
+      int lz, ly, lx;
+      mrow_voxel(wm * MB + mb, row, lz, ly, lx);
       int gz = z0 + lz, gy = y0 + ly, gx = x0 + lx;
       if (ch_ok && gz < Td && gy < Th && gx < Tw) {
         int qz = (CONVT && !FLAT) ? 2 * gz + pz : gz, qy = CONVT ? 2 * gy + py : gy, qx = CONVT ? 2 * gx + px : gx;

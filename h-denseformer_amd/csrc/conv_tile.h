@@ -34,9 +34,14 @@ struct Mma<float> {
 // 28-31} (and the same +32) as groups; group 1 gets z in {0,2}, group 2 z in {1,3}: box row = 100*z + 10*y + x
 // (BH = BW = 10) is then distinct mod 16 inside each group.
 constexpr int WS_STAT_ROWS = 512;  // conv_ws2_kernel: InstanceNorm partial rows per sample (2 passes x 256 workgroup slots)
+// (g2, rank): which of the two ds_read_b128 service groups MFMA row r (0..31) belongs to, and its position 0..15 there
+__device__ __forceinline__ void ds128_group(int r, int& g2, int& rank) {
+  g2 = ((r >= 4 && r < 12) || (r >= 16 && r < 20) || r >= 28) ? 1 : 0;
+  rank = g2 ? (r < 12 ? r - 4 : (r < 20 ? r - 8 : r - 16)) : (r < 4 ? r : (r < 16 ? r - 8 : r - 12));
+}
 __device__ __forceinline__ void ws_row_to_zx(int r, int& dz, int& x) {
-  const int g2 = ((r >= 4 && r < 12) || (r >= 16 && r < 20) || r >= 28) ? 1 : 0;
-  const int rank = g2 ? (r < 12 ? r - 4 : (r < 20 ? r - 8 : r - 16)) : (r < 4 ? r : (r < 16 ? r - 8 : r - 12));
+  int g2, rank;
+  ds128_group(r, g2, rank);
   dz = 2 * (rank >> 3) + g2;
   x = rank & 7;
 }
