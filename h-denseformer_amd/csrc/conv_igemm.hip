@@ -96,7 +96,14 @@ __device__ __forceinline__ void stage_box(char* lds, const T* __restrict__ src, 
 // that is never strided (stride-2 gather and transposed conv stride y and x only: 4 output-parity classes, not 8).  For the
 // stride-1 conv this is exactly the 3-D operator on a depth-1 volume (the other 18 taps meet zero padding only).
 template <typename T, int TD, int TH, int TW, int WM, int WN, int MB, int S, bool CONVT, bool FLAT = false>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+// (256, 2): two workgroups per compute unit.  Left to itself hipcc let the big-tile instantiations grow past 256 registers
+// (276 for the 256-voxel x 64-channel tile: one workgroup per unit, nobody to run while a workgroup stages its next channel
+// chunk); with the bound it fits them into 178-201 without scratch.  Same-box pairs (round 6, call c37): bench step -0.09 ms
+// (4 of 4), the 2-D PI-CAI step 16.8 -> 15.95 ms.
+#ifndef HDF_IGEMM_WG_PER_CU   // (A/B builds)
+#define HDF_IGEMM_WG_PER_CU 2
+#endif
+__global__ __launch_bounds__(256, HDF_IGEMM_WG_PER_CU) void conv_igemm_kernel(ConvArgs a) {
   if (a.prio) HDF_LIGHT_PRIO();
   static_assert(WM * WN == 4, "4 waves");
   static_assert(WM * MB * 32 == TD * TH * TW, "tile/wave decomposition");
@@ -168,12 +175,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     mrow_voxel(wm * MB + mb, r, lz, ly, lx);
     rowbase[mb] = (((FLAT ? 0 : SS * lz)) * BH + SS * ly) * BW + SS * lx;
   }
-  f32x16 acc[MB];
-#pragma unroll
-  for (int mb = 0; mb < MB; mb++)
-#pragma unroll
-    for (int i = 0; i < 16; i++) acc[mb][i] = 0.f;
-
   const bool n_active = n_base < a.CoutP;  // wave-uniform
   const char* wrow = reinterpret_cast<const char*>(a.w) + ((int64_t)(n_base + r) * a.Cin) * ESZ + h * 16;
   const int64_t wtap_stride = (int64_t)a.CoutP * a.Cin * ESZ;
@@ -186,6 +187,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   const int cstride = a.wfrag ? 2048 : 64, fstride = a.wfrag ? 1024 : 32;  // per 64-byte chunk / per 32-byte step
 
   bool done = false;
+  f32x16 acc[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[mb][i] = 0.f;
   if constexpr (!CONVT) {
     // Conv (stride 1 or the stride-2 gather) with whole 64-byte channel chunks: the 27 taps x 2 fragment steps of a chunk are unrolled and
     // software-pipelined.  The weight fragments come straight from L2 (~500+ cycles): a register ring keeps RING
