@@ -100,8 +100,11 @@ template <typename T, int TD, int TH, int TW, int WM, int WN, int MB, int S, boo
 // (276 for the 256-voxel x 64-channel tile: one workgroup per unit, nobody to run while a workgroup stages its next channel
 // chunk); with the bound it fits them into 178-201 without scratch.  Same-box pairs (round 6, call c37): bench step -0.09 ms
 // (4 of 4), the 2-D PI-CAI step 16.8 -> 15.95 ms.
+// The flat (2-D) stride-1 instantiations take three (<= 168 registers, no scratch; their step -0.1 ms of 15.9; the stride-2
+// gather would spill); for the 3-D ones three cost the
+// bench step +0.07 ms (call c38).
 #ifndef HDF_IGEMM_WG_PER_CU   // (A/B builds)
-#define HDF_IGEMM_WG_PER_CU 2
+#define HDF_IGEMM_WG_PER_CU ((FLAT && S == 1) ? 3 : 2)
 #endif
 __global__ __launch_bounds__(256, HDF_IGEMM_WG_PER_CU) void conv_igemm_kernel(ConvArgs a) {
   if (a.prio) HDF_LIGHT_PRIO();
