@@ -109,6 +109,11 @@ def test_the_persistent_backward_kernel_spills_only_its_staged_lse_rows(ks):
     for n, k in ks.items():
         if n.startswith("tf_chain_bwd_kernel"):
             assert k.get("private_segment_fixed_size", 0) <= 96, (n, k.get("private_segment_fixed_size"))
+            # spilled scalar registers (v_writelane / v_readlane pairs in the layer loop: ~2 us of 39 per layer at 301):
+            # the count is pinned so that it cannot grow unnoticed; bringing it under 64 is open
+            assert k.get("sgpr_spill_count", 0) <= 310, (n, k.get("sgpr_spill_count"))
+        if n.startswith("tf_chain_fwd_kernel"):
+            assert k.get("sgpr_spill_count", 0) <= 96, (n, k.get("sgpr_spill_count"))
 
 
 @pytest.mark.parametrize("T", ["bf16_t", "f16_t"])
