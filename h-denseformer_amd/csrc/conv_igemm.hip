@@ -33,7 +33,7 @@ __device__ __forceinline__ void stage_box(char* lds, const T* __restrict__ src, 
                                           const float* __restrict__ scale, const float* __restrict__ shift, int relu) {
   constexpr int EPC = ST<T>::EPC;
   const int cpv = row_bytes >> 4;  // 16-B chunks per voxel row (power of two)
-  const int cpv_shift = (cpv == 16) ? 4 : (cpv == 8) ? 3 : (cpv == 4) ? 2 : (cpv == 2) ? 1 : 0;
+  const int cpv_shift = (cpv == 32) ? 5 : (cpv == 16) ? 4 : (cpv == 8) ? 3 : (cpv == 4) ? 2 : (cpv == 2) ? 1 : 0;
   const int total = (BD * BH * BW) << cpv_shift;
   const int part = threadIdx.x & (cpv - 1);  // constant per thread (256 % cpv == 0)
   const int cbase = c0 + part * EPC;
@@ -1199,12 +1199,36 @@ __global__ __launch_bounds__(256) void conv_ws2_kernel(ConvArgs a) {
 // a class is straight-line code.  Written as run-time loops, hipcc carried the accumulators in VGPRs and bracketed
 // EVERY pair of MFMAs with 64 v_accvgpr moves (SQ_INSTS_VALU 88 M against 57 M MFMA-busy cycles per launch: the kernel
 // was VALU-bound at 280 TF); an `asm("" : "+a"(acc))` pin does not survive the dynamic-trip-count loop nest.
+// (round 6) The weight fragments come straight from L2, one per pair of MFMAs, and hipcc kept ONE of them in flight
+// (`s_waitcnt vmcnt(1)` in front of every pair: a 64-cycle pair waited out a 500+ cycle load -- 0.086 of the MFMA roof for
+// upconv_2).  The 27 x NFS fragment steps of a workgroup are one compile-time sequence (class, tap, step): a register ring
+// keeps CT_RING of them in flight across tap and class boundaries, as conv_igemm_kernel does for its chunks.
+constexpr int CT_RING = 8;
+// tap (in the [27] panel) of the k-th (class, tap) pair in the order the classes walk them, and the first pair of a class
+constexpr int ct_class_base(int cls) {
+  int n = 0;
+  for (int c = 0; c < cls; c++) n += (((c >> 2) & 1) ? 2 : 1) * (((c >> 1) & 1) ? 2 : 1) * ((c & 1) ? 2 : 1);
+  return n;
+}
+constexpr int ct_pair_tap(int k) {
+  int idx = 0;
+  for (int cls = 0; cls < 8; cls++) {
+    const int pz = (cls >> 2) & 1, py = (cls >> 1) & 1, px = cls & 1;
+    for (int jz = 0; jz < (pz ? 2 : 1); jz++)
+      for (int jy = 0; jy < (py ? 2 : 1); jy++)
+        for (int jx = 0; jx < (px ? 2 : 1); jx++) {
+          if (idx == k) return (((pz ? 2 * jz : 1) * 3 + (py ? 2 * jy : 1)) * 3 + (px ? 2 * jx : 1));
+          idx++;
+        }
+  }
+  return 0;
+}
 template <typename T, int TD, int TH, int TW, int MB, int NFS>
 __global__ __launch_bounds__(256) void convt_fused_kernel(ConvArgs a) {
   static_assert(4 * MB * 32 == TD * TH * TW, "tile/wave decomposition");
   constexpr int BD = TD + 1, BH = TH + 1, BW = TW + 1, BOX = BD * BH * BW;
   constexpr int ESZ = sizeof(T), EPC = ST<T>::EPC;
-  constexpr int ROWB = NFS > 4 ? 256 : 128;  // row payload the box is laid out for (full Cin: up to 128 / 256 B)
+  constexpr int ROWB = NFS > 8 ? 512 : (NFS > 4 ? 256 : 128);  // row payload the box is laid out for (full Cin: up to 128 / 256 / 512 B)
   constexpr int LP = ROWB + 16;              // box row pitch
   static_assert(BOX * LP <= 160 * 1024, "LDS budget");
   __shared__ __attribute__((aligned(16))) char lds[BOX * LP];
@@ -1252,10 +1276,19 @@ __global__ __launch_bounds__(256) void convt_fused_kernel(ConvArgs a) {
       voff[mb][i] = (gz < a.Di && gy < a.Hi && gx < a.Wi) ? ((2 * gz * a.Ho + 2 * gy) * a.Wo + 2 * gx) * (int)a.out_pitch : -1;
     }
 
+  constexpr int NSTEP = 27 * NFS;
+  auto b_load = [&](int g) -> u32x4 {   // g: compile-time after unrolling
+    return *reinterpret_cast<const u32x4*>(wrow + ct_pair_tap(g / NFS) * wtap_stride + (g % NFS) * 32);
+  };
+  u32x4 bq[CT_RING];
+#pragma unroll
+  for (int g = 0; g < CT_RING; g++) bq[g] = b_load(g);
+
   auto do_class = [&](auto cls_tag) __attribute__((always_inline)) {
     constexpr int cls = decltype(cls_tag)::value;
     constexpr int pz = (cls >> 2) & 1, py = (cls >> 1) & 1, px = cls & 1;
     constexpr int ntapz = pz ? 2 : 1, ntapy = py ? 2 : 1, ntapx = px ? 2 : 1;
+    constexpr int g0 = ct_class_base(cls) * NFS;   // first fragment step of this class
     f32x16 acc[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; mb++)
@@ -1273,16 +1306,19 @@ __global__ __launch_bounds__(256) void convt_fused_kernel(ConvArgs a) {
         for (int jx = 0; jx < ntapx; jx++) {
           const int offx = px ? 1 - jx : 0, wx = px ? 2 * jx : 1;
           const int tapoff = ((offz * BH + offy) * BW + offx) * LP;
-          const char* wp = wrow + ((wz * 3 + wy) * 3 + wx) * wtap_stride;
+          (void)wz, (void)wy, (void)wx;   // (the tap's panel index is ct_pair_tap of its position in the sequence)
 #pragma unroll
           for (int fs = 0; fs < NFS; fs++) {
-            u32x4 bfrag = *reinterpret_cast<const u32x4*>(wp + fs * 32);
+            const int g = g0 + ((jz * ntapy + jy) * ntapx + jx) * NFS + fs;
+            const u32x4 bfrag = bq[g % CT_RING];
             u32x4 afrag[MB];
 #pragma unroll
             for (int mb = 0; mb < MB; mb++)
               afrag[mb] = *reinterpret_cast<const u32x4*>(lds + rowbase[mb] + tapoff + fs * 32);
 #pragma unroll
             for (int mb = 0; mb < MB; mb++) Mma<T>::run(afrag[mb], bfrag, acc[mb]);
+            if (g + CT_RING < NSTEP) bq[g % CT_RING] = b_load(g + CT_RING);
+            __builtin_amdgcn_sched_barrier(0);   // (without it hipcc sinks the refill down to its use again)
           }
         }
       }
@@ -2934,7 +2970,7 @@ inline int ws_cfg(int mode, int Do, int Ho, int Wo, int row_bytes) {
 }
 
 // transposed conv: row widths convt_fused_kernel is instantiated for
-inline bool convt_fused_rows(int rb) { return rb == 32 || rb == 64 || rb == 128 || rb == 256; }
+inline bool convt_fused_rows(int rb) { return rb == 32 || rb == 64 || rb == 128 || rb == 256 || rb == 512; }
 
 template <typename T, int CH, int RB, int NB>
 int launch_ws2(const ConvArgs& a, hipStream_t st) {
@@ -3043,7 +3079,10 @@ int launch_conv_t(int mode, const ConvArgs& a, hipStream_t st) {
     if (convt_fused_rows(a.Cin * (int)sizeof(T)) && !a.accumulate) {
       dim3 grid(a.N * ceil_div(a.Di, 4) * ceil_div(a.Hi, 8) * ceil_div(a.Wi, 8), a.CoutP / 32);
       const int nfs = a.Cin * (int)sizeof(T) / 32;
-      if (nfs == 8)
+      if (nfs == 16) {   // 512-byte rows (16-bit upconv_1: 256 -> 128 channels at the bottom of the decoder): 2-deep tiles, a 128 KB box
+        dim3 grid2(a.N * ceil_div(a.Di, 2) * ceil_div(a.Hi, 8) * ceil_div(a.Wi, 8), a.CoutP / 32);
+        hipLaunchKernelGGL((convt_fused_kernel<T, 2, 8, 8, 1, 16>), grid2, dim3(256), 0, st, a);
+      } else if (nfs == 8)
         hipLaunchKernelGGL((convt_fused_kernel<T, 4, 8, 8, 2, 8>), grid, dim3(256), 0, st, a);
       else if (nfs == 4)
         hipLaunchKernelGGL((convt_fused_kernel<T, 4, 8, 8, 2, 4>), grid, dim3(256), 0, st, a);
