@@ -1223,10 +1223,14 @@ constexpr int ct_pair_tap(int k) {
   }
   return 0;
 }
-template <typename T, int TD, int TH, int TW, int MB, int NFS>
+// FLAT (round 6): ConvTranspose2d(k3, s2, p1, op1) of the 2-D model on depth-1 tensors -- the four (y, x) parity classes, the
+// 9 taps of the panel's centre depth plane, a one-plane box; until then the 2-D decoder ran one launch slice per class
+// through conv_igemm_kernel's unpipelined fallback loop.
+template <typename T, int TD, int TH, int TW, int MB, int NFS, bool FLAT = false>
 __global__ __launch_bounds__(256) void convt_fused_kernel(ConvArgs a) {
   static_assert(4 * MB * 32 == TD * TH * TW, "tile/wave decomposition");
-  constexpr int BD = TD + 1, BH = TH + 1, BW = TW + 1, BOX = BD * BH * BW;
+  static_assert(!FLAT || TD == 1, "flat tiles are one voxel deep");
+  constexpr int BD = FLAT ? 1 : TD + 1, BH = TH + 1, BW = TW + 1, BOX = BD * BH * BW;
   constexpr int ESZ = sizeof(T), EPC = ST<T>::EPC;
   constexpr int ROWB = NFS > 8 ? 512 : (NFS > 4 ? 256 : 128);  // row payload the box is laid out for (full Cin: up to 128 / 256 / 512 B)
   constexpr int LP = ROWB + 16;              // box row pitch
@@ -1273,10 +1277,10 @@ __global__ __launch_bounds__(256) void convt_fused_kernel(ConvArgs a) {
     for (int i = 0; i < 16; i++) {
       const int lin = (wave * MB + mb) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
       const int gz = z0 + lin / (TH * TW), gy = y0 + (lin / TW) % TH, gx = x0 + lin % TW;
-      voff[mb][i] = (gz < a.Di && gy < a.Hi && gx < a.Wi) ? ((2 * gz * a.Ho + 2 * gy) * a.Wo + 2 * gx) * (int)a.out_pitch : -1;
+      voff[mb][i] = (gz < a.Di && gy < a.Hi && gx < a.Wi) ? (((FLAT ? gz : 2 * gz) * a.Ho + 2 * gy) * a.Wo + 2 * gx) * (int)a.out_pitch : -1;
     }
 
-  constexpr int NSTEP = 27 * NFS;
+  constexpr int NSTEP = (FLAT ? 9 : 27) * NFS;   // (flat: classes 0..3, the first 9 pairs of the sequence, all on depth tap 1)
   auto b_load = [&](int g) -> u32x4 {   // g: compile-time after unrolling
     return *reinterpret_cast<const u32x4*>(wrow + ct_pair_tap(g / NFS) * wtap_stride + (g % NFS) * 32);
   };
@@ -1337,10 +1341,12 @@ __global__ __launch_bounds__(256) void convt_fused_kernel(ConvArgs a) {
   do_class(std::integral_constant<int, 1>{});
   do_class(std::integral_constant<int, 2>{});
   do_class(std::integral_constant<int, 3>{});
-  do_class(std::integral_constant<int, 4>{});
-  do_class(std::integral_constant<int, 5>{});
-  do_class(std::integral_constant<int, 6>{});
-  do_class(std::integral_constant<int, 7>{});
+  if constexpr (!FLAT) {
+    do_class(std::integral_constant<int, 4>{});
+    do_class(std::integral_constant<int, 5>{});
+    do_class(std::integral_constant<int, 6>{});
+    do_class(std::integral_constant<int, 7>{});
+  }
 }
 
 // weight gradient:  D[tap][sc][lc] = sum_{n,i} S[n,i][sc] * L[n, STRIDE*i-1+tap][lc]
@@ -3030,6 +3036,26 @@ int launch_conv_t(int mode, const ConvArgs& a, hipStream_t st) {
       if (a.CoutP <= 64) return launch_cfg<T, 1, 8, 8, 2, 2, 1, 2, false, true>(a, st);   // 64 vox x 64 ch, stride 2 in y, x
       return launch_cfg<T, 1, 8, 8, 1, 4, 2, 2, false, true>(a, st);                      // 64 vox x 128 ch
     } else {
+#ifndef HDF_NO_CONVT_FUSED_FLAT   // (A/B builds)
+      // all four parity classes in one workgroup, the box staged once, the weight fragments through a register ring
+      const int rbt = a.Cin * (int)sizeof(T);
+      if (convt_fused_rows(rbt) && !a.accumulate && !a.wfrag) {
+        dim3 grid(a.N * ceil_div(a.Hi, 16) * ceil_div(a.Wi, 16), a.CoutP / 32);
+        const int nfs = rbt / 32;
+        if (nfs == 16)
+          hipLaunchKernelGGL((convt_fused_kernel<T, 1, 16, 16, 2, 16, true>), grid, dim3(256), 0, st, a);
+        else if (nfs == 8)
+          hipLaunchKernelGGL((convt_fused_kernel<T, 1, 16, 16, 2, 8, true>), grid, dim3(256), 0, st, a);
+        else if (nfs == 4)
+          hipLaunchKernelGGL((convt_fused_kernel<T, 1, 16, 16, 2, 4, true>), grid, dim3(256), 0, st, a);
+        else if (nfs == 2)
+          hipLaunchKernelGGL((convt_fused_kernel<T, 1, 16, 16, 2, 2, true>), grid, dim3(256), 0, st, a);
+        else
+          hipLaunchKernelGGL((convt_fused_kernel<T, 1, 16, 16, 2, 1, true>), grid, dim3(256), 0, st, a);
+        HDF_LAUNCH_CHECK();
+        return HDF_OK;
+      }
+#endif
       if (a.CoutP <= 32) return launch_cfg<T, 1, 16, 16, 4, 1, 2, 1, true, true>(a, st);
       return launch_cfg<T, 1, 8, 16, 2, 2, 2, 1, true, true>(a, st);
     }
@@ -3163,7 +3189,8 @@ int launch_wgrad_t(WgradArgs a, float* dw, int sc_store, int lc_store, int accum
 int hdf_conv_weight_layout(int dtype, int mode, int Cin, int Do, int Ho, int Wo) {
   const int rb = Cin * hdf_esz(dtype);
   if (rb % 64 != 0) return 0;                       // the pipelined path needs whole 64-byte chunks
-  if (Do == 1) return 1;                            // depth 1 (the 2-D operators): always conv_igemm_kernel
+  if (Do == 1)                                      // depth 1 (the 2-D operators): conv_igemm_kernel, but the transposed conv
+    return (mode == 2 && convt_fused_rows(rb)) ? 0 : 1;   // runs convt_fused_kernel<FLAT> (row-major panels)
   if (mode == 0) return ws_cfg(mode, Do, Ho, Wo, rb) ? 0 : 1;  // conv_ws2_kernel stages row-major panels
   if (mode == 1) return 1;                                 // stride-2 gather conv: pipelined path
   return convt_fused_rows(rb) ? 0 : 1;  // transposed conv: convt_fused_kernel reads row-major panels, other widths run per class
